@@ -1,0 +1,284 @@
+"""ctypes binding of libcontrack_hip.so (include/contrack_hip.h).  No torch, no other HIP binding.
+
+The library is the product's only compute path: if it is missing or no GPU is visible the calls raise
+-- there is no CPU fallback (the CPU restatement lives in oracle/ and is test infrastructure).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcontrack_hip.so")
+_lib = None
+
+CMP_OPS = {">=": 0, "ge": 0, "<=": 1, "le": 1, ">": 2, "gt": 2, "<": 3, "lt": 3}
+GORL_ERRMSG = ' Please select from [>, >=, <, >=] for gorl'      # contrack.py:658
+
+TIMER_NAMES = ["k_threshold", "k_scan", "k_label2d", "k_overlap", "k_extent", "k_run_values", "k_relabel",
+               "k_count", "host_resolve", "tables_d2h", "result_h2d", "total"]
+
+EXPORTS = [
+    "ctk_version", "ctk_last_error", "ctk_device_count", "ctk_create", "ctk_destroy", "ctk_track_f32",
+    "ctk_track_f32_dev", "ctk_shard_label2d", "ctk_shard_halo_size", "ctk_shard_halo_export",
+    "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_resolve", "ctk_result_free",
+    "ctk_result_info", "ctk_result_arrays", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
+    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_set_timing", "ctk_get_timings",
+    "ctk_dev_malloc", "ctk_dev_free", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
+    "ctk_synth_fill",
+]
+
+
+class ContrackHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ContrackHipError(
+            "libcontrack_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C contrack_amd/csrc`; the HIP path has no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    p, i64, i32, dbl, sz = C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_size_t
+    pp = C.POINTER(C.c_void_p)
+    L.ctk_last_error.restype = C.c_char_p
+    L.ctk_create.argtypes = [pp, i32]
+    L.ctk_destroy.argtypes = [p]
+    L.ctk_destroy.restype = None
+    track_args = [p, p, i64, i32, i32, p, i32, p, dbl, i32, i32, p, C.POINTER(i64)]
+    L.ctk_track_f32.argtypes = track_args
+    L.ctk_track_f32_dev.argtypes = track_args
+    L.ctk_shard_label2d.argtypes = [p, p, i64, i32, i32, p, i32, p, i32]
+    L.ctk_shard_halo_size.argtypes = [p, C.POINTER(sz)]
+    L.ctk_shard_halo_export.argtypes = [p, pp, C.POINTER(sz)]
+    L.ctk_shard_halo_import.argtypes = [p, p, sz]
+    L.ctk_shard_overlap.argtypes = [p]
+    L.ctk_shard_tables.argtypes = [p, pp, C.POINTER(sz)]
+    L.ctk_resolve.argtypes = [pp, C.POINTER(sz), i32, dbl, i32, pp]
+    L.ctk_result_free.argtypes = [p]
+    L.ctk_result_free.restype = None
+    L.ctk_result_info.argtypes = [p] + [C.POINTER(i64)] * 5
+    L.ctk_result_arrays.argtypes = [p, pp, C.POINTER(i64), pp, C.POINTER(i64), pp, pp]
+    L.ctk_weights_to_limbs.argtypes = [p, i32, p, p, C.POINTER(C.c_int32)]
+    L.ctk_shard_extents.argtypes = [p, p, i32, i64, pp, C.POINTER(i64)]
+    L.ctk_shard_write.argtypes = [p, i32, p, C.POINTER(i64), C.POINTER(i32)]
+    L.ctk_shard_count_tracked.argtypes = [p, C.POINTER(i64)]
+    L.ctk_debug_mask.argtypes = [p, p]
+    L.ctk_debug_label2d.argtypes = [p, i32, p]
+    L.ctk_set_timing.argtypes = [p, i32]
+    L.ctk_get_timings.argtypes = [p, p]
+    L.ctk_dev_malloc.argtypes = [p, pp, sz]
+    L.ctk_dev_free.argtypes = [p, p]
+    L.ctk_memcpy_h2d.argtypes = [p, p, p, sz]
+    L.ctk_memcpy_d2h.argtypes = [p, p, p, sz]
+    L.ctk_sync.argtypes = [p]
+    L.ctk_stream.argtypes = [p]
+    L.ctk_stream.restype = p
+    L.ctk_synth_fill.argtypes = [p, p, i64, i32, i32, C.c_uint64]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().ctk_last_error().decode("utf-8", "replace")
+        if rc == -3:
+            raise MemoryError(msg)
+        if rc in (-1, -4):
+            raise ValueError(msg)
+        raise ContrackHipError("libcontrack_hip rc=%d: %s" % (rc, msg))
+
+
+def device_count():
+    return int(lib().ctk_device_count())
+
+
+def weights_to_limbs(wrow):
+    wrow = np.ascontiguousarray(wrow, dtype=np.float32)
+    lo = np.empty(wrow.shape[0], dtype=np.int32)
+    hi = np.empty(wrow.shape[0], dtype=np.int32)
+    sh = C.c_int32(0)
+    check(lib().ctk_weights_to_limbs(wrow.ctypes.data, wrow.shape[0], lo.ctypes.data, hi.ctypes.data, C.byref(sh)))
+    return lo, hi, int(sh.value)
+
+
+class Result:
+    """Owner of a ctk_result (output of the host-side resolver)."""
+
+    def __init__(self, ptr):
+        self._p = ptr
+
+    def __del__(self):
+        self.free()
+
+    def free(self):
+        if getattr(self, "_p", None):
+            lib().ctk_result_free(self._p)
+            self._p = None
+
+    @property
+    def ptr(self):
+        return self._p
+
+    def info(self):
+        v = [C.c_int64(0) for _ in range(5)]
+        check(lib().ctk_result_info(self._p, *[C.byref(x) for x in v]))
+        return dict(zip(("n_labels", "n_ops", "n_complex", "n_ambiguous", "n_components"), (int(x.value) for x in v)))
+
+    def arrays(self):
+        cl, ops, sco, sto = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nc, nops = C.c_int64(0), C.c_int64(0)
+        check(lib().ctk_result_arrays(self._p, C.byref(cl), C.byref(nc), C.byref(ops), C.byref(nops), C.byref(sco), C.byref(sto)))
+        n = int(nc.value)
+        comp_label = np.ctypeslib.as_array(C.cast(cl, C.POINTER(C.c_int32)), shape=(max(n, 1),))[:n].copy()
+        k = int(nops.value)
+        opsa = np.ctypeslib.as_array(C.cast(ops, C.POINTER(C.c_int32)), shape=(max(k, 1) * 8,))[:k * 8].copy().reshape(k, 8)
+        return comp_label, opsa
+
+
+def resolve(blobs, overlap, twosided):
+    """blobs: list of bytes-like / (address, nbytes) table blobs in time order."""
+    L = lib()
+    n = len(blobs)
+    ptrs = (C.c_void_p * n)()
+    sizes = (C.c_size_t * n)()
+    keep = []
+    for i, b in enumerate(blobs):
+        if isinstance(b, tuple):
+            ptrs[i], sizes[i] = b
+        else:
+            arr = np.frombuffer(b, dtype=np.uint8)
+            keep.append(arr)
+            ptrs[i], sizes[i] = arr.ctypes.data, arr.size
+    out = C.c_void_p()
+    check(L.ctk_resolve(ptrs, sizes, n, float(overlap), int(bool(twosided)), C.byref(out)))
+    return Result(out)
+
+
+class Tracker:
+    """One GPU + stream + reusable device workspace (ctk_handle)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(lib().ctk_create(C.byref(self._h), int(device)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ctk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- one call, host numpy in / out ------------------------------------------------------
+    def track(self, anom, thr, cmp_op, wrow, overlap, persistence, twosided=True):
+        anom = np.ascontiguousarray(anom, dtype=np.float32)
+        T, ny, nx = anom.shape
+        thr = np.ascontiguousarray(thr, dtype=np.float64)
+        wrow = np.ascontiguousarray(wrow, dtype=np.float32)
+        if thr.shape != (T,) or wrow.shape != (ny,):
+            raise ValueError("thr must have shape (T,) and wrow (ny,)")
+        flag = np.empty((T, ny, nx), dtype=np.int32)
+        n = C.c_int64(0)
+        check(lib().ctk_track_f32(self._h, anom.ctypes.data, T, ny, nx, thr.ctypes.data, int(cmp_op), wrow.ctypes.data,
+                                  float(overlap), int(persistence), int(bool(twosided)), flag.ctypes.data, C.byref(n)))
+        return flag, int(n.value)
+
+    # ---- device-resident --------------------------------------------------------------------------
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        check(lib().ctk_dev_malloc(self._h, C.byref(p), int(nbytes)))
+        return p
+
+    def free(self, p):
+        check(lib().ctk_dev_free(self._h, p))
+
+    def h2d(self, dst, arr):
+        arr = np.ascontiguousarray(arr)
+        check(lib().ctk_memcpy_h2d(self._h, dst, arr.ctypes.data, arr.nbytes))
+
+    def d2h(self, arr, src):
+        assert arr.flags.c_contiguous
+        check(lib().ctk_memcpy_d2h(self._h, arr.ctypes.data, src, arr.nbytes))
+
+    def sync(self):
+        check(lib().ctk_sync(self._h))
+
+    def synth_fill(self, dst, T, ny, nx, seed=0):
+        check(lib().ctk_synth_fill(self._h, dst, T, ny, nx, int(seed)))
+
+    def track_dev(self, anom_dev, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev):
+        thr = np.ascontiguousarray(thr, dtype=np.float64)
+        wrow = np.ascontiguousarray(wrow, dtype=np.float32)
+        n = C.c_int64(0)
+        check(lib().ctk_track_f32_dev(self._h, anom_dev, T, ny, nx, thr.ctypes.data, int(cmp_op), wrow.ctypes.data,
+                                      float(overlap), int(persistence), int(bool(twosided)), flag_dev, C.byref(n)))
+        return int(n.value)
+
+    def set_timing(self, on=True):
+        check(lib().ctk_set_timing(self._h, int(bool(on))))
+
+    def timings(self):
+        ms = np.zeros(len(TIMER_NAMES), dtype=np.float64)
+        check(lib().ctk_get_timings(self._h, ms.ctypes.data))
+        return dict(zip(TIMER_NAMES, ms.tolist()))
+
+    # ---- staged (time-sharded) -------------------------------------------------------------------
+    def shard_label2d(self, anom_dev, T, ny, nx, thr, cmp_op, wrow, has_prev):
+        thr = np.ascontiguousarray(thr, dtype=np.float64)
+        wrow = np.ascontiguousarray(wrow, dtype=np.float32)
+        check(lib().ctk_shard_label2d(self._h, anom_dev, T, ny, nx, thr.ctypes.data, int(cmp_op), wrow.ctypes.data, int(bool(has_prev))))
+
+    def halo_size(self):
+        s = C.c_size_t(0)
+        check(lib().ctk_shard_halo_size(self._h, C.byref(s)))
+        return int(s.value)
+
+    def halo_export(self):
+        p, s = C.c_void_p(), C.c_size_t(0)
+        check(lib().ctk_shard_halo_export(self._h, C.byref(p), C.byref(s)))
+        return p, int(s.value)
+
+    def halo_import(self, blob_dev, nbytes):
+        check(lib().ctk_shard_halo_import(self._h, blob_dev, int(nbytes)))
+
+    def shard_overlap(self):
+        check(lib().ctk_shard_overlap(self._h))
+
+    def shard_tables(self):
+        p, s = C.c_void_p(), C.c_size_t(0)
+        check(lib().ctk_shard_tables(self._h, C.byref(p), C.byref(s)))
+        return C.string_at(p, s.value)
+
+    def shard_extents(self, result, shard, t_begin):
+        p, n = C.c_void_p(), C.c_int64(0)
+        check(lib().ctk_shard_extents(self._h, result.ptr, int(shard), int(t_begin), C.byref(p), C.byref(n)))
+        return p, int(n.value)
+
+    def shard_write(self, persistence, flag_dev):
+        n, z = C.c_int64(0), C.c_int(0)
+        check(lib().ctk_shard_write(self._h, int(persistence), flag_dev, C.byref(n), C.byref(z)))
+        return int(n.value), bool(z.value)
+
+    def debug_mask(self, T, ny, nx):
+        m = np.empty((T, ny, nx), dtype=np.uint8)
+        check(lib().ctk_debug_mask(self._h, m.ctypes.data))
+        return m
+
+    def debug_label2d(self, T, ny, nx, before_seam):
+        lab = np.empty((T, ny, nx), dtype=np.int32)
+        check(lib().ctk_debug_label2d(self._h, int(bool(before_seam)), lab.ctypes.data))
+        return lab

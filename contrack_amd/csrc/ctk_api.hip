@@ -1,0 +1,777 @@
+// ctk_api.hip -- host side of libcontrack_hip.so: handle, workspace, stage orchestration, C ABI
+// (include/contrack_hip.h).  The kernels are in ctk_kernels.hip (same translation unit), the GPU-free
+// sequential resolver in ctk_resolve.cpp.
+#include "ctk_kernels.hip"
+#include "../../include/contrack_hip.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+
+int ctk_set_error(int code, const char *fmt, ...);            // ctk_resolve.cpp
+extern "C" int ctk_weights_to_limbs(const float *wrow, int ny, int32_t *wlo, int32_t *whi, int32_t *wshift);
+
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return ctk_set_error(e_ == hipErrorOutOfMemory ? CTK_E_NOMEM : CTK_E_NODEVICE, "%s failed: %s (%s:%d)", \
+                                 #expr, hipGetErrorString(e_), __FILE__, __LINE__);                           \
+    } while (0)
+#define CTKCHK(expr)               \
+    do {                           \
+        int r_ = (expr);           \
+        if (r_ != CTK_OK) return r_; \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+enum State { ST_IDLE = 0, ST_LABELLED, ST_OVERLAPPED, ST_TABLES, ST_EXTENTS };
+
+}  // namespace
+
+struct ctk_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    State state = ST_IDLE;
+    // geometry of the current shard
+    int64_t T = 0;
+    int ny = 0, nx = 0, W = 0, has_prev = 0, cmp_op = 0;
+    int32_t wshift = 0;
+    uint32_t total_runs = 0, max_runs_step = 0, total_comps = 0;
+    uint32_t pair_cap = 0, seam_cap = 0;
+    bool need_glb = false;
+    // device buffers
+    DevBuf mask, rowcnt, rowstart, tcount, run_base, ncomp, cprefix, thr32, wlo, whi, counters;
+    DevBuf run_comp, run_val, cs_mrep, cs_box, cs_area, d_mrep, d_box, d_area, comp_label;
+    DevBuf g_x0, g_x1, g_y, g_parent, g_root, g_idmap, g_rs;
+    DevBuf pairs, seams, ext, ops, oi_hi, oi_idx, halo_in, halo_out, dbg;
+    // host (pinned) buffers
+    void *h_blob = nullptr;
+    size_t h_blob_cap = 0, h_blob_bytes = 0;
+    void *h_small = nullptr;         // pinned scratch: counters, run_base download
+    size_t h_small_cap = 0;
+    // results kept between extents and write
+    int64_t n_labels = 0, t_begin = 0;
+    int32_t nops = 0;
+    // timing
+    int timing = 0;
+    hipEvent_t ev[CTK_K_COUNT + 1][2];
+    bool ev_used[CTK_K_COUNT + 1];
+    double ms[CTK_NTIMERS];
+    bool ev_ready = false;
+};
+
+namespace {
+
+int ensure(ctk_handle *h, DevBuf &b, size_t need)
+{
+    if (need == 0) need = 8;
+    if (b.cap >= need) return CTK_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t cap = need + need / 8 + 256;                   // a little head room: sizes vary between calls
+    hipError_t e = hipMalloc(&b.p, cap);
+    if (e != hipSuccess) {
+        e = hipMalloc(&b.p, need);
+        cap = need;
+        if (e != hipSuccess) {
+            b.p = nullptr;
+            return ctk_set_error(CTK_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(e));
+        }
+    }
+    b.cap = cap;
+    (void)h;
+    return CTK_OK;
+}
+
+int ensure_host(void **p, size_t *cap, size_t need)
+{
+    if (*cap >= need && *p) return CTK_OK;
+    if (*p) { (void)hipHostFree(*p); *p = nullptr; *cap = 0; }
+    size_t c = need + need / 4 + 4096;
+    hipError_t e = hipHostMalloc(p, c, hipHostMallocDefault);
+    if (e != hipSuccess) { *p = nullptr; return ctk_set_error(CTK_E_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", c, hipGetErrorString(e)); }
+    *cap = c;
+    return CTK_OK;
+}
+
+template <typename T>
+T *P(const DevBuf &b) { return (T *)b.p; }
+
+struct Timer {
+    ctk_handle *h;
+    int k;
+    Timer(ctk_handle *h_, int k_) : h(h_), k(k_)
+    {
+        if (h->timing && h->ev_ready) { (void)hipEventRecord(h->ev[k][0], h->stream); }
+    }
+    ~Timer()
+    {
+        if (h->timing && h->ev_ready) { (void)hipEventRecord(h->ev[k][1], h->stream); h->ev_used[k] = true; }
+    }
+};
+
+// float32 threshold such that the float32 compare `x <op> thr32` equals `(double)x <op> thr`
+float adjust_threshold(double thr, int op)
+{
+    if (thr != thr) return __builtin_nanf("");
+    float f = (float)thr;
+    if (op == 0 || op == 3) {                // x >= thr  <=>  x >= ceil32(thr);  x < thr <=> x < ceil32(thr)
+        if ((double)f < thr) f = std::nextafterf(f, INFINITY);
+    } else {                                 // x <= thr  <=>  x <= floor32(thr); x > thr <=> x > floor32(thr)
+        if ((double)f > thr) f = std::nextafterf(f, -INFINITY);
+    }
+    return f;
+}
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int grid_for_rows(int64_t nrows)
+{
+    int64_t g = (nrows + 3) / 4;             // 4 waves per 256-thread workgroup, one row per wave
+    if (g > 256 * 16) g = 256 * 16;          // >> 256 CUs, grid-stride over the rest
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int ctk_version(void) { return 100; }
+
+extern "C" int ctk_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { ctk_set_error(CTK_E_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); return 0; }
+    return n;
+}
+
+extern "C" int ctk_create(ctk_handle **out, int device)
+{
+    if (!out) return ctk_set_error(CTK_E_INVALID, "ctk_create: null handle pointer");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return ctk_set_error(CTK_E_NODEVICE, "ctk_create: no HIP device available (%s) -- the HIP path has no CPU fallback",
+                             e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= n) return ctk_set_error(CTK_E_INVALID, "ctk_create: device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    ctk_handle *h = new (std::nothrow) ctk_handle();
+    if (!h) return ctk_set_error(CTK_E_NOMEM, "ctk_create: out of memory");
+    h->device = device;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return ctk_set_error(CTK_E_NODEVICE, "hipStreamCreate failed"); }
+    memset(h->ms, 0, sizeof(h->ms));
+    memset(h->ev_used, 0, sizeof(h->ev_used));
+    *out = h;
+    return CTK_OK;
+}
+
+extern "C" void ctk_destroy(ctk_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    DevBuf *bufs[] = {&h->mask, &h->rowcnt, &h->rowstart, &h->tcount, &h->run_base, &h->ncomp, &h->cprefix, &h->thr32, &h->wlo, &h->whi,
+                      &h->counters, &h->run_comp, &h->run_val, &h->cs_mrep, &h->cs_box, &h->cs_area, &h->d_mrep, &h->d_box, &h->d_area,
+                      &h->comp_label, &h->g_x0, &h->g_x1, &h->g_y, &h->g_parent, &h->g_root, &h->g_idmap, &h->g_rs, &h->pairs, &h->seams,
+                      &h->ext, &h->ops, &h->oi_hi, &h->oi_idx, &h->halo_in, &h->halo_out, &h->dbg};
+    for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
+    if (h->h_blob) (void)hipHostFree(h->h_blob);
+    if (h->h_small) (void)hipHostFree(h->h_small);
+    if (h->ev_ready) for (int k = 0; k <= CTK_K_COUNT; k++) { (void)hipEventDestroy(h->ev[k][0]); (void)hipEventDestroy(h->ev[k][1]); }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int ctk_set_timing(ctk_handle *h, int enable)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (enable && !h->ev_ready) {
+        for (int k = 0; k <= CTK_K_COUNT; k++) { HIPCHK(hipEventCreate(&h->ev[k][0])); HIPCHK(hipEventCreate(&h->ev[k][1])); }
+        h->ev_ready = true;
+    }
+    h->timing = enable;
+    return CTK_OK;
+}
+
+static int collect_event_times(ctk_handle *h)
+{
+    if (!h->timing || !h->ev_ready) return CTK_OK;
+    for (int k = 0; k <= CTK_K_COUNT; k++) {
+        if (!h->ev_used[k]) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev[k][0], h->ev[k][1]) == hipSuccess) h->ms[k] += ms;
+        h->ev_used[k] = false;
+    }
+    return CTK_OK;
+}
+
+extern "C" int ctk_get_timings(ctk_handle *h, double *ms)
+{
+    if (!h || !ms) return ctk_set_error(CTK_E_INVALID, "null argument");
+    memcpy(ms, h->ms, sizeof(h->ms));
+    return CTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 1
+// ------------------------------------------------------------------------------------------------
+extern "C" int ctk_shard_label2d(ctk_handle *h, const float *anom_dev, int64_t T, int ny, int nx, const double *thr,
+                                 int cmp_op, const float *wrow, int has_prev)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    if (T < 0 || ny < 1 || nx < 1 || (T > 0 && (!anom_dev || !thr)) || !wrow)
+        return ctk_set_error(CTK_E_INVALID, "ctk_shard_label2d: bad shape (T=%lld ny=%d nx=%d) or null pointer", (long long)T, ny, nx);
+    if (cmp_op < 0 || cmp_op > 3) return ctk_set_error(CTK_E_INVALID, "ctk_shard_label2d: cmp_op %d not in 0..3", cmp_op);
+    if (nx > 65535 || ny > 65535) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: grid %dx%d exceeds 65535 per axis", ny, nx);
+    if (T > 0x7ffffff0ll) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: T too large");
+    HIPCHK(hipSetDevice(h->device));
+    memset(h->ms, 0, sizeof(h->ms));
+    h->state = ST_IDLE;
+    h->T = T; h->ny = ny; h->nx = nx; h->W = (nx + 63) / 64; h->has_prev = has_prev ? 1 : 0; h->cmp_op = cmp_op;
+    const int W = h->W;
+    const int64_t nrows = T * ny;
+    hipStream_t s = h->stream;
+
+    // host-side preparation: thresholds for the float32 compare, exact integer limbs of the row weights
+    std::vector<float> thr32((size_t)std::max<int64_t>(T, 1));
+    for (int64_t t = 0; t < T; t++) thr32[(size_t)t] = adjust_threshold(thr[t], cmp_op);
+    std::vector<int32_t> wlo((size_t)ny), whi((size_t)ny);
+    CTKCHK(ctk_weights_to_limbs(wrow, ny, wlo.data(), whi.data(), &h->wshift));
+
+    CTKCHK(ensure(h, h->mask, (size_t)nrows * W * 8));
+    CTKCHK(ensure(h, h->rowcnt, (size_t)nrows * 2));
+    CTKCHK(ensure(h, h->rowstart, (size_t)nrows * 4));
+    CTKCHK(ensure(h, h->tcount, (size_t)T * 4));
+    CTKCHK(ensure(h, h->run_base, (size_t)(T + 1) * 4));
+    CTKCHK(ensure(h, h->ncomp, (size_t)T * 4));
+    CTKCHK(ensure(h, h->cprefix, (size_t)(T + 1) * 4));
+    CTKCHK(ensure(h, h->thr32, (size_t)T * 4));
+    CTKCHK(ensure(h, h->wlo, (size_t)ny * 4));
+    CTKCHK(ensure(h, h->whi, (size_t)ny * 4));
+    CTKCHK(ensure(h, h->counters, CTK_CNT_N * 4));
+    CTKCHK(ensure_host(&h->h_small, &h->h_small_cap, (size_t)(T + 1) * 4 + 256));
+
+    HIPCHK(hipMemsetAsync(h->counters.p, 0, CTK_CNT_N * 4, s));
+    if (T > 0) {
+        HIPCHK(hipMemsetAsync(h->tcount.p, 0, (size_t)T * 4, s));
+        HIPCHK(hipMemcpyAsync(h->thr32.p, thr32.data(), (size_t)T * 4, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(hipMemcpyAsync(h->wlo.p, wlo.data(), (size_t)ny * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->whi.p, whi.data(), (size_t)ny * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));        // the staging vectors above are stack/heap temporaries
+
+    if (T > 0) {
+        Timer tm(h, CTK_K_THRESHOLD);
+        const int g = grid_for_rows(nrows);
+#define LAUNCH_THR(OP) k_threshold<OP><<<g, 256, 0, s>>>(anom_dev, P<float>(h->thr32), nrows, ny, nx, W, P<uint64_t>(h->mask), P<uint16_t>(h->rowcnt), P<uint32_t>(h->tcount))
+        switch (cmp_op) {
+        case 0: LAUNCH_THR(0); break;
+        case 1: LAUNCH_THR(1); break;
+        case 2: LAUNCH_THR(2); break;
+        default: LAUNCH_THR(3); break;
+        }
+#undef LAUNCH_THR
+        HIPCHK(hipGetLastError());
+    }
+    {
+        Timer tm(h, CTK_K_SCAN);
+        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+        HIPCHK(hipGetLastError());
+    }
+    // runs per timestep decide the workspace size and whether the global-memory variant is needed
+    uint32_t *hb = (uint32_t *)h->h_small;
+    HIPCHK(hipMemcpyAsync(hb, h->run_base.p, (size_t)(T + 1) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hb + T + 1, P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (hb[T + 1] & CTK_OVF_RUNS) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: more than 2^32-1 runs in one shard");
+    h->total_runs = hb[T];
+    h->max_runs_step = 0;
+    for (int64_t t = 0; t < T; t++) h->max_runs_step = std::max(h->max_runs_step, hb[t + 1] - hb[t]);
+    h->need_glb = (h->max_runs_step > CTK_LDS_RUNS) || (ny > CTK_LDS_NY);
+    const size_t R = h->total_runs;
+    CTKCHK(ensure(h, h->run_comp, R * 4));
+    CTKCHK(ensure(h, h->run_val, R * 4));
+    CTKCHK(ensure(h, h->cs_mrep, R * 4));
+    CTKCHK(ensure(h, h->cs_box, R * 16));
+    CTKCHK(ensure(h, h->cs_area, R * 16));
+    CTKCHK(ensure(h, h->d_mrep, R * 4));
+    CTKCHK(ensure(h, h->d_box, R * 8));
+    CTKCHK(ensure(h, h->d_area, R * 16));
+    h->seam_cap = (uint32_t)std::min<int64_t>(nrows, 0x7fffffff);
+    CTKCHK(ensure(h, h->seams, (size_t)h->seam_cap * sizeof(CtkSeam)));
+    if (h->need_glb) {
+        CTKCHK(ensure(h, h->g_x0, R * 2)); CTKCHK(ensure(h, h->g_x1, R * 2)); CTKCHK(ensure(h, h->g_y, R * 2));
+        CTKCHK(ensure(h, h->g_parent, R * 4)); CTKCHK(ensure(h, h->g_root, R * 4)); CTKCHK(ensure(h, h->g_idmap, R * 4));
+        CTKCHK(ensure(h, h->g_rs, (size_t)T * (ny + 1) * 4));
+    }
+    if (T > 0) {
+        Label2dArgs a;
+        a.mask = P<uint64_t>(h->mask); a.rowcnt = P<uint16_t>(h->rowcnt); a.rowstart = P<uint32_t>(h->rowstart);
+        a.run_base = P<uint32_t>(h->run_base); a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp);
+        a.cs_mrep = P<uint32_t>(h->cs_mrep); a.cs_box = P<uint32_t>(h->cs_box); a.cs_area = P<int64_t>(h->cs_area);
+        a.seams = P<CtkSeam>(h->seams); a.counters = P<uint32_t>(h->counters); a.seam_cap = h->seam_cap;
+        a.wlo = P<int32_t>(h->wlo); a.whi = P<int32_t>(h->whi);
+        a.ny = ny; a.nx = nx; a.W = W; a.lds_cap = CTK_LDS_RUNS;
+        a.g_x0 = P<uint16_t>(h->g_x0); a.g_x1 = P<uint16_t>(h->g_x1); a.g_y = P<uint16_t>(h->g_y);
+        a.g_parent = P<uint32_t>(h->g_parent); a.g_root = P<uint32_t>(h->g_root); a.g_idmap = P<uint32_t>(h->g_idmap);
+        Timer tm(h, CTK_K_LABEL2D);
+        k_label2d_lds<<<(int)T, 256, 0, s>>>(a);
+        HIPCHK(hipGetLastError());
+        if (h->need_glb) {
+            k_label2d_glb<<<(int)T, 256, 0, s>>>(a, P<uint32_t>(h->g_rs));
+            HIPCHK(hipGetLastError());
+        }
+    }
+    {
+        Timer tm(h, CTK_K_SCAN);
+        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->ncomp), T, P<uint32_t>(h->cprefix), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+        HIPCHK(hipGetLastError());
+        if (T > 0) {
+            k_compact_comps<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), P<uint32_t>(h->cprefix), P<uint32_t>(h->cs_mrep),
+                                                   P<uint32_t>(h->cs_box), P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box),
+                                                   P<int64_t>(h->d_area));
+            HIPCHK(hipGetLastError());
+        }
+    }
+    h->state = ST_LABELLED;
+    return CTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// halo (last labelled timestep of this shard, for the next rank)
+//   layout: [uint64 mask[ny*W]] [uint32 rowstart[ny] (padded to 8 B)] [uint32 run_comp[max]]
+// ------------------------------------------------------------------------------------------------
+static size_t halo_off_rowstart(const ctk_handle *h) { return (size_t)h->ny * h->W * 8; }
+static size_t halo_off_runcomp(const ctk_handle *h) { return halo_off_rowstart(h) + ctk_align8((size_t)h->ny * 4); }
+static size_t halo_max_bytes(const ctk_handle *h) { return halo_off_runcomp(h) + (size_t)h->ny * ((size_t)h->nx / 2 + 1) * 4; }
+
+extern "C" int ctk_shard_halo_size(ctk_handle *h, size_t *max_bytes)
+{
+    if (!h || !max_bytes) return ctk_set_error(CTK_E_INVALID, "null argument");
+    if (h->state < ST_LABELLED) return ctk_set_error(CTK_E_STATE, "ctk_shard_halo_size before ctk_shard_label2d");
+    *max_bytes = halo_max_bytes(h);
+    return CTK_OK;
+}
+
+extern "C" int ctk_shard_halo_export(ctk_handle *h, void **blob_dev, size_t *nbytes)
+{
+    if (!h || !blob_dev || !nbytes) return ctk_set_error(CTK_E_INVALID, "null argument");
+    if (h->state < ST_LABELLED) return ctk_set_error(CTK_E_STATE, "ctk_shard_halo_export before ctk_shard_label2d");
+    HIPCHK(hipSetDevice(h->device));
+    CTKCHK(ensure(h, h->halo_out, halo_max_bytes(h)));
+    char *dst = (char *)h->halo_out.p;
+    hipStream_t s = h->stream;
+    if (h->T > 0) {
+        const int64_t t = h->T - 1;
+        const uint32_t *hb = (const uint32_t *)h->h_small;                    // run_base, downloaded in stage 1
+        const uint32_t n = hb[t + 1] - hb[t];
+        HIPCHK(hipMemcpyAsync(dst, P<uint64_t>(h->mask) + t * h->ny * h->W, (size_t)h->ny * h->W * 8, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(dst + halo_off_rowstart(h), P<uint32_t>(h->rowstart) + t * h->ny, (size_t)h->ny * 4, hipMemcpyDeviceToDevice, s));
+        if (n) HIPCHK(hipMemcpyAsync(dst + halo_off_runcomp(h), P<uint32_t>(h->run_comp) + hb[t], (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        *nbytes = halo_off_runcomp(h) + (size_t)n * 4;
+    } else {
+        HIPCHK(hipMemsetAsync(dst, 0, halo_off_runcomp(h), s));
+        *nbytes = halo_off_runcomp(h);
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    *blob_dev = dst;
+    return CTK_OK;
+}
+
+extern "C" int ctk_shard_halo_import(ctk_handle *h, const void *blob_dev, size_t nbytes)
+{
+    if (!h || !blob_dev) return ctk_set_error(CTK_E_INVALID, "null argument");
+    if (h->state != ST_LABELLED) return ctk_set_error(CTK_E_STATE, "ctk_shard_halo_import needs a labelled shard");
+    if (nbytes < halo_off_runcomp(h) || nbytes > halo_max_bytes(h)) return ctk_set_error(CTK_E_INVALID, "halo blob has %zu bytes, expected %zu..%zu", nbytes, halo_off_runcomp(h), halo_max_bytes(h));
+    HIPCHK(hipSetDevice(h->device));
+    CTKCHK(ensure(h, h->halo_in, halo_max_bytes(h)));
+    HIPCHK(hipMemcpyAsync(h->halo_in.p, blob_dev, nbytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 2
+// ------------------------------------------------------------------------------------------------
+static int launch_overlap(ctk_handle *h)
+{
+    OverlapArgs a;
+    a.mask = P<uint64_t>(h->mask); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
+    a.run_comp = P<uint32_t>(h->run_comp);
+    const char *hl = (const char *)h->halo_in.p;
+    a.halo_mask = (const uint64_t *)hl;
+    a.halo_rowstart = hl ? (const uint32_t *)(hl + halo_off_rowstart(h)) : nullptr;
+    a.halo_run_comp = hl ? (const uint32_t *)(hl + halo_off_runcomp(h)) : nullptr;
+    a.has_prev = (h->has_prev && hl) ? 1 : 0;
+    a.pairs = P<CtkPair>(h->pairs); a.pair_cap = h->pair_cap; a.counters = P<uint32_t>(h->counters);
+    a.wlo = P<int32_t>(h->wlo); a.whi = P<int32_t>(h->whi);
+    a.ny = h->ny; a.nx = h->nx; a.W = h->W;
+    Timer tm(h, CTK_K_OVERLAP);
+    k_overlap<<<(int)h->T, 256, 0, h->stream>>>(a);
+    HIPCHK(hipGetLastError());
+    return CTK_OK;
+}
+
+extern "C" int ctk_shard_overlap(ctk_handle *h)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    if (h->state != ST_LABELLED) return ctk_set_error(CTK_E_STATE, "ctk_shard_overlap needs ctk_shard_label2d first");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->has_prev && !h->halo_in.p) return ctk_set_error(CTK_E_STATE, "ctk_shard_overlap: has_prev set but no halo imported");
+    size_t want = (size_t)h->total_runs / 2 + (size_t)h->T * 8 + 4096;
+    if (want > 0x7fffffffull) want = 0x7fffffffull;
+    if (h->pair_cap < want || !h->pairs.p) {
+        CTKCHK(ensure(h, h->pairs, want * sizeof(CtkPair)));
+        h->pair_cap = (uint32_t)std::min<size_t>(h->pairs.cap / sizeof(CtkPair), 0x7fffffffull);
+    }
+    if (h->T > 0) CTKCHK(launch_overlap(h));
+    h->state = ST_OVERLAPPED;
+    return CTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tables: download into the blob layout of ctk_tables.h
+// ------------------------------------------------------------------------------------------------
+extern "C" int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes)
+{
+    if (!h || !blob || !nbytes) return ctk_set_error(CTK_E_INVALID, "null argument");
+    if (h->state != ST_OVERLAPPED) return ctk_set_error(CTK_E_STATE, "ctk_shard_tables needs ctk_shard_overlap first");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const double t0 = now_ms();
+    uint32_t *hc = (uint32_t *)h->h_small + (h->T + 2);                       // after the run_base copy
+    uint32_t cnt[CTK_CNT_N], ctot = 0;
+    for (int attempt = 0;; attempt++) {
+        HIPCHK(hipMemcpyAsync(hc, h->counters.p, CTK_CNT_N * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hc + CTK_CNT_N, P<uint32_t>(h->cprefix) + h->T, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        memcpy(cnt, hc, sizeof(cnt));
+        ctot = hc[CTK_CNT_N];
+        if (cnt[CTK_CNT_OVERFLOW] & CTK_OVF_SEAMS) return ctk_set_error(CTK_E_INTERNAL, "seam table overflow");
+        if (!(cnt[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS)) break;
+        if (attempt >= 6) return ctk_set_error(CTK_E_RANGE, "pair table keeps overflowing");
+        // grow the pair table to what was asked for and redo the histogram
+        size_t want = std::max<size_t>((size_t)cnt[CTK_CNT_PAIRS] + 1024, (size_t)h->pair_cap * 2);
+        if (want > 0xfffffff0ull) return ctk_set_error(CTK_E_RANGE, "pair table beyond 2^32 records");
+        CTKCHK(ensure(h, h->pairs, want * sizeof(CtkPair)));
+        h->pair_cap = (uint32_t)std::min<size_t>(h->pairs.cap / sizeof(CtkPair), 0xfffffff0ull);
+        uint32_t zero[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(P<uint32_t>(h->counters) + CTK_CNT_PAIRS, zero, 4, hipMemcpyHostToDevice, s));
+        uint32_t ovf = cnt[CTK_CNT_OVERFLOW] & ~CTK_OVF_PAIRS;
+        HIPCHK(hipMemcpyAsync(P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, &ovf, 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        CTKCHK(launch_overlap(h));
+    }
+    h->total_comps = ctot;
+    const int64_t T = h->T, NC = ctot, NP = cnt[CTK_CNT_PAIRS], NS = cnt[CTK_CNT_SEAMS];
+    const size_t bytes = ctk_blob_bytes(T, NC, NP, NS);
+    CTKCHK(ensure_host(&h->h_blob, &h->h_blob_cap, bytes));
+    char *p = (char *)h->h_blob;
+    CtkBlobHeader *hd = (CtkBlobHeader *)p;
+    hd->magic = CTK_BLOB_MAGIC; hd->T = T; hd->ny = h->ny; hd->nx = h->nx; hd->wshift = h->wshift; hd->has_prev = (h->has_prev && h->halo_in.p) ? 1 : 0;
+    hd->ncomps = NC; hd->npairs = NP; hd->nseams = NS;
+    p += sizeof(CtkBlobHeader);
+    if (T) HIPCHK(hipMemcpyAsync(p, h->ncomp.p, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+    p += ctk_align8((size_t)T * 4);
+    if (NC) HIPCHK(hipMemcpyAsync(p, h->d_mrep.p, (size_t)NC * 4, hipMemcpyDeviceToHost, s));
+    p += ctk_align8((size_t)NC * 4);
+    if (NC) HIPCHK(hipMemcpyAsync(p, h->d_box.p, (size_t)NC * 8, hipMemcpyDeviceToHost, s));
+    p += ctk_align8((size_t)NC * 8);
+    if (NC) HIPCHK(hipMemcpyAsync(p, h->d_area.p, (size_t)NC * 16, hipMemcpyDeviceToHost, s));
+    p += (size_t)NC * 16;
+    if (NP) HIPCHK(hipMemcpyAsync(p, h->pairs.p, (size_t)NP * sizeof(CtkPair), hipMemcpyDeviceToHost, s));
+    p += (size_t)NP * sizeof(CtkPair);
+    if (NS) HIPCHK(hipMemcpyAsync(p, h->seams.p, (size_t)NS * sizeof(CtkSeam), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h->h_blob_bytes = bytes;
+    *blob = h->h_blob;
+    *nbytes = bytes;
+    h->ms[CTK_T_D2H] += now_ms() - t0;
+    h->state = ST_TABLES;
+    return CTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 3
+// ------------------------------------------------------------------------------------------------
+static FoldArgs fold_args(const ctk_handle *h)
+{
+    FoldArgs f;
+    f.ops = P<CtkOp>(h->ops); f.oi_hi = P<int32_t>(h->oi_hi); f.oi_idx = P<int32_t>(h->oi_idx); f.nops = h->nops;
+    return f;
+}
+
+extern "C" int ctk_shard_extents(ctk_handle *h, const ctk_result *r, int shard, int64_t t_begin, int32_t **ext_dev, int64_t *n_labels)
+{
+    if (!h || !r) return ctk_set_error(CTK_E_INVALID, "null argument");
+    if (h->state != ST_TABLES) return ctk_set_error(CTK_E_STATE, "ctk_shard_extents needs ctk_shard_tables first");
+    if (shard < 0 || shard >= r->nshards) return ctk_set_error(CTK_E_INVALID, "shard %d out of range", shard);
+    const int64_t c0 = r->shard_comp_off[shard], c1 = r->shard_comp_off[shard + 1];
+    if (c1 - c0 != (int64_t)h->total_comps || r->shard_t_off[shard + 1] - r->shard_t_off[shard] != h->T)
+        return ctk_set_error(CTK_E_INVALID, "result does not belong to this shard (%lld components vs %u)", (long long)(c1 - c0), h->total_comps);
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const double t0 = now_ms();
+    h->n_labels = r->n_labels; h->t_begin = t_begin; h->nops = (int32_t)r->nops;
+    CTKCHK(ensure(h, h->comp_label, (size_t)(c1 - c0) * 4));
+    if (c1 > c0) HIPCHK(hipMemcpyAsync(h->comp_label.p, r->comp_label + c0, (size_t)(c1 - c0) * 4, hipMemcpyHostToDevice, s));
+    std::vector<int32_t> oi_hi, oi_idx;
+    if (r->nops) {
+        std::vector<int32_t> order((size_t)r->nops);
+        for (int32_t i = 0; i < (int32_t)r->nops; i++) order[(size_t)i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return r->ops[a].hi < r->ops[b].hi; });
+        oi_hi.resize((size_t)r->nops); oi_idx.resize((size_t)r->nops);
+        for (size_t i = 0; i < order.size(); i++) { oi_hi[i] = r->ops[order[i]].hi; oi_idx[i] = order[i]; }
+        CTKCHK(ensure(h, h->ops, (size_t)r->nops * sizeof(CtkOp)));
+        CTKCHK(ensure(h, h->oi_hi, (size_t)r->nops * 4));
+        CTKCHK(ensure(h, h->oi_idx, (size_t)r->nops * 4));
+        HIPCHK(hipMemcpyAsync(h->ops.p, r->ops, (size_t)r->nops * sizeof(CtkOp), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->oi_hi.p, oi_hi.data(), (size_t)r->nops * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->oi_idx.p, oi_idx.data(), (size_t)r->nops * 4, hipMemcpyHostToDevice, s));
+    }
+    CTKCHK(ensure(h, h->ext, (size_t)(r->n_labels + 1) * 8));
+    HIPCHK(hipStreamSynchronize(s));                                         // staging vectors go out of scope
+    h->ms[CTK_T_H2D] += now_ms() - t0;
+    {
+        Timer tm(h, CTK_K_EXTENT);
+        const int64_t n1 = r->n_labels + 1;
+        k_fill_ext<<<(int)((n1 + 255) / 256), 256, 0, s>>>(P<int32_t>(h->ext), r->n_labels);
+        HIPCHK(hipGetLastError());
+        if (h->T > 0) {
+            ExtentArgs a;
+            a.mask = P<uint64_t>(h->mask); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
+            a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp); a.cprefix = P<uint32_t>(h->cprefix);
+            a.comp_label = P<int32_t>(h->comp_label); a.ext = P<int32_t>(h->ext); a.n_labels = r->n_labels; a.t_begin = t_begin;
+            a.fold = fold_args(h); a.ny = h->ny; a.nx = h->nx; a.W = h->W;
+            k_extent<<<(int)h->T, 256, 0, s>>>(a);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    if (ext_dev) *ext_dev = P<int32_t>(h->ext);
+    if (n_labels) *n_labels = r->n_labels;
+    h->state = ST_EXTENTS;
+    return CTK_OK;
+}
+
+static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, bool with_fold)
+{
+    RelabelArgs a;
+    a.mask = P<uint64_t>(h->mask); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
+    a.run_val = P<int32_t>(h->run_val); a.ext = P<int32_t>(h->ext); a.n_labels = h->n_labels; a.persistence = persistence;
+    a.t_begin = h->t_begin;
+    if (with_fold) a.fold = fold_args(h); else { a.fold.ops = nullptr; a.fold.oi_hi = nullptr; a.fold.oi_idx = nullptr; a.fold.nops = 0; }
+    a.flag = flag_dev; a.counters = P<uint32_t>(h->counters);
+    a.nrows = h->T * h->ny; a.ny = h->ny; a.nx = h->nx; a.W = h->W;
+    k_relabel<<<grid_for_rows(a.nrows), 256, 0, h->stream>>>(a);
+    HIPCHK(hipGetLastError());
+    return CTK_OK;
+}
+
+extern "C" int ctk_shard_write(ctk_handle *h, int persistence, int32_t *flag_dev, int64_t *n_alive_local, int *wrote_background)
+{
+    if (!h || (h->T > 0 && !flag_dev)) return ctk_set_error(CTK_E_INVALID, "null argument");
+    if (h->state != ST_EXTENTS) return ctk_set_error(CTK_E_STATE, "ctk_shard_write needs ctk_shard_extents first");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    uint32_t zero2[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(P<uint32_t>(h->counters) + CTK_CNT_WROTE_ZERO, zero2, 8, hipMemcpyHostToDevice, s));
+    if (h->T > 0) {
+        {
+            Timer tm(h, CTK_K_RUNLABEL);
+            k_run_values<<<(int)h->T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), P<uint32_t>(h->cprefix), P<int32_t>(h->comp_label),
+                                                   P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->d_mrep), 0, 0, P<int32_t>(h->run_val));
+            HIPCHK(hipGetLastError());
+        }
+        {
+            Timer tm(h, CTK_K_RELABEL);
+            CTKCHK(launch_relabel(h, persistence, flag_dev, true));
+        }
+    }
+    {
+        Timer tm(h, CTK_K_COUNT);
+        k_count_alive<<<(int)((h->n_labels + 255) / 256 + 1), 256, 0, s>>>(P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->counters));
+        HIPCHK(hipGetLastError());
+    }
+    uint32_t *hc = (uint32_t *)h->h_small + (h->T + 2);
+    HIPCHK(hipMemcpyAsync(hc, h->counters.p, CTK_CNT_N * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (n_alive_local) *n_alive_local = hc[CTK_CNT_ALIVE];
+    if (wrote_background) *wrote_background = hc[CTK_CNT_WROTE_ZERO] ? 1 : 0;
+    collect_event_times(h);
+    h->state = ST_TABLES;           // extents may be recomputed (e.g. another persistence) from the same tables
+    return CTK_OK;
+}
+
+extern "C" int ctk_shard_count_tracked(ctk_handle *h, int64_t *n_alive)
+{
+    if (!h || !n_alive) return ctk_set_error(CTK_E_INVALID, "null argument");
+    const uint32_t *hc = (const uint32_t *)h->h_small + (h->T + 2);
+    *n_alive = hc[CTK_CNT_ALIVE];
+    return CTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// whole path, one GPU
+// ------------------------------------------------------------------------------------------------
+extern "C" int ctk_track_f32_dev(ctk_handle *h, const float *anom_dev, int64_t T, int ny, int nx, const double *thr, int cmp_op,
+                                 const float *wrow, double overlap, int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    const double t0 = now_ms();
+    CTKCHK(ctk_shard_label2d(h, anom_dev, T, ny, nx, thr, cmp_op, wrow, 0));
+    CTKCHK(ctk_shard_overlap(h));
+    const void *blob = nullptr;
+    size_t nbytes = 0;
+    CTKCHK(ctk_shard_tables(h, &blob, &nbytes));
+    const double t1 = now_ms();
+    ctk_result *res = nullptr;
+    CTKCHK(ctk_resolve(&blob, &nbytes, 1, overlap, twosided, &res));
+    h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t1;
+    int rc = ctk_shard_extents(h, res, 0, 0, nullptr, nullptr);
+    ctk_result_free(res);
+    CTKCHK(rc);
+    int64_t alive = 0;
+    int wrote0 = 0;
+    CTKCHK(ctk_shard_write(h, persistence, flag_dev, &alive, &wrote0));
+    if (n_tracked) *n_tracked = alive + (wrote0 ? 1 : 0) - 1;       // len(np.unique(flag)) - 1, contrack.py:793
+    h->ms[CTK_T_TOTAL] += now_ms() - t0;
+    return CTK_OK;
+}
+
+extern "C" int ctk_track_f32(ctk_handle *h, const float *anom, int64_t T, int ny, int nx, const double *thr, int cmp_op, const float *wrow,
+                             double overlap, int persistence, int twosided, int32_t *flag, int64_t *n_tracked)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    if (T < 0 || ny < 1 || nx < 1 || (T > 0 && (!anom || !flag))) return ctk_set_error(CTK_E_INVALID, "ctk_track_f32: bad shape or null pointer");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = (size_t)T * ny * nx;
+    float *a_dev = nullptr;
+    int32_t *f_dev = nullptr;
+    if (n) {
+        hipError_t e = hipMalloc((void **)&a_dev, n * 4);
+        if (e != hipSuccess) return ctk_set_error(CTK_E_NOMEM, "hipMalloc(%zu) for the input slab failed: %s", n * 4, hipGetErrorString(e));
+        e = hipMalloc((void **)&f_dev, n * 4);
+        if (e != hipSuccess) { (void)hipFree(a_dev); return ctk_set_error(CTK_E_NOMEM, "hipMalloc(%zu) for the flag slab failed: %s", n * 4, hipGetErrorString(e)); }
+        e = hipMemcpy(a_dev, anom, n * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(a_dev); (void)hipFree(f_dev); return ctk_set_error(CTK_E_NODEVICE, "H2D copy failed: %s", hipGetErrorString(e)); }
+    }
+    int rc = ctk_track_f32_dev(h, a_dev, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, f_dev, n_tracked);
+    if (rc == CTK_OK && n) {
+        hipError_t e = hipMemcpy(flag, f_dev, n * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = ctk_set_error(CTK_E_NODEVICE, "D2H copy failed: %s", hipGetErrorString(e));
+    }
+    if (a_dev) (void)hipFree(a_dev);
+    if (f_dev) (void)hipFree(f_dev);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// debug / staged parity
+// ------------------------------------------------------------------------------------------------
+extern "C" int ctk_debug_mask(ctk_handle *h, uint8_t *mask)
+{
+    if (!h || !mask) return ctk_set_error(CTK_E_INVALID, "null argument");
+    if (h->state < ST_LABELLED) return ctk_set_error(CTK_E_STATE, "no labelled shard");
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t n = h->T * h->ny * (int64_t)h->nx;
+    if (n == 0) return CTK_OK;
+    CTKCHK(ensure(h, h->dbg, (size_t)n));
+    k_expand_mask<<<(int)((n + 255) / 256), 256, 0, h->stream>>>(P<uint64_t>(h->mask), h->T * h->ny, h->nx, h->W, P<uint8_t>(h->dbg));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(mask, h->dbg.p, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CTK_OK;
+}
+
+extern "C" int ctk_debug_label2d(ctk_handle *h, int before_seam, int32_t *lab)
+{
+    if (!h || !lab) return ctk_set_error(CTK_E_INVALID, "null argument");
+    if (h->state < ST_LABELLED) return ctk_set_error(CTK_E_STATE, "no labelled shard");
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t n = h->T * h->ny * (int64_t)h->nx;
+    if (n == 0) return CTK_OK;
+    CTKCHK(ensure(h, h->dbg, (size_t)n * 4));
+    k_run_values<<<(int)h->T, 256, 0, h->stream>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), P<uint32_t>(h->cprefix), nullptr, nullptr, 0, 0,
+                                                   P<uint32_t>(h->d_mrep), 0, before_seam ? 1 : 2, P<int32_t>(h->run_val));
+    HIPCHK(hipGetLastError());
+    const int64_t tb = h->t_begin;
+    h->t_begin = 0;
+    int rc = launch_relabel(h, 0, P<int32_t>(h->dbg), false);
+    h->t_begin = tb;
+    CTKCHK(rc);
+    HIPCHK(hipMemcpyAsync(lab, h->dbg.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-memory helpers for a ctypes host
+// ------------------------------------------------------------------------------------------------
+extern "C" int ctk_dev_malloc(ctk_handle *h, void **p, size_t nbytes)
+{
+    if (!h || !p) return ctk_set_error(CTK_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipError_t e = hipMalloc(p, nbytes ? nbytes : 8);
+    if (e != hipSuccess) { *p = nullptr; return ctk_set_error(CTK_E_NOMEM, "hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(e)); }
+    return CTK_OK;
+}
+extern "C" int ctk_dev_free(ctk_handle *h, void *p)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (p) HIPCHK(hipFree(p));
+    return CTK_OK;
+}
+extern "C" int ctk_memcpy_h2d(ctk_handle *h, void *dst_dev, const void *src, size_t nbytes)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpy(dst_dev, src, nbytes, hipMemcpyHostToDevice));
+    return CTK_OK;
+}
+extern "C" int ctk_memcpy_d2h(ctk_handle *h, void *dst, const void *src_dev, size_t nbytes)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpy(dst, src_dev, nbytes, hipMemcpyDeviceToHost));
+    return CTK_OK;
+}
+extern "C" int ctk_sync(ctk_handle *h)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipDeviceSynchronize());
+    return CTK_OK;
+}
+extern "C" void *ctk_stream(ctk_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+extern "C" int ctk_synth_fill(ctk_handle *h, float *anom_dev, int64_t T, int ny, int nx, uint64_t seed)
+{
+    if (!h || !anom_dev) return ctk_set_error(CTK_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t n = T * (int64_t)ny * nx;
+    if (n > 0) {
+        const int64_t blocks = (n + 255) / 256;
+        if (blocks > 0x7fffffff) return ctk_set_error(CTK_E_RANGE, "slab too large for ctk_synth_fill");
+        k_synth<<<(int)blocks, 256, 0, h->stream>>>(anom_dev, T, ny, nx, seed);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CTK_OK;
+}

@@ -1,0 +1,16 @@
+// ctk_device.h -- constants shared by the kernels and the host API (internal)
+#pragma once
+#include <stdint.h>
+
+// device counters (uint32 each)
+#define CTK_CNT_PAIRS      0
+#define CTK_CNT_SEAMS      1
+#define CTK_CNT_OVERFLOW   2
+#define CTK_CNT_WROTE_ZERO 3
+#define CTK_CNT_ALIVE      4
+#define CTK_CNT_N          8
+
+// overflow bits
+#define CTK_OVF_PAIRS 1u
+#define CTK_OVF_SEAMS 2u
+#define CTK_OVF_RUNS  4u

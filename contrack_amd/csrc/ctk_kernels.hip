@@ -1,0 +1,867 @@
+// ctk_kernels.hip -- gfx950 (MI355X, wave64) kernels of the run_contrack hot path.
+//
+// Data layout in HBM (one shard = T consecutive timesteps of a (ny, nx) grid, W = ceil(nx/64)):
+//   anom      float32 [T][ny][nx]        input slab, read ONCE (k_threshold)
+//   mask      uint64  [T][ny][W]         1 bit per pixel (bit x&63 of word x>>6), 1/32 of the slab
+//   rowcnt    uint16  [T][ny]            foreground runs per row
+//   rowstart  uint32  [T][ny]            first run of the row, relative to the timestep
+//   run_base  uint32  [T+1]              first run of the timestep (exclusive scan of runs/timestep)
+//   run_comp  uint32  [runs]             id of the no-wrap 2-D component of each run (raster order ids)
+//   comp_*            [components]       per component: merged-representative, bbox, exact area limbs
+//   pairs / seams                        co-occurrence records / seam rows (ctk_tables.h)
+//   run_val   int32   [runs]             final flag value of each run (after resolve + persistence)
+//   flag      int32   [T][ny][nx]        output, written ONCE (k_relabel)
+// A run is a maximal horizontal segment of foreground pixels; all labelling works on runs (about 1 % of
+// the pixel count on Z500 anomaly fields), the only per-pixel passes are the first and the last kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ctk_tables.h"
+#include "ctk_device.h"
+
+#define WAVE 64
+#define FULL64 0xffffffffffffffffull
+
+// ------------------------------------------------------------------------------------------------
+// small wave / block helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint32_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d)
+{
+    uint32_t lo = __shfl_up((uint32_t)v, d), hi = __shfl_up((uint32_t)(v >> 32), d);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_down_u64(uint64_t v, int d)
+{
+    uint32_t lo = __shfl_down((uint32_t)v, d), hi = __shfl_down((uint32_t)(v >> 32), d);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src)
+{
+    uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Block-wide exclusive scan of one uint32 per thread.  `sm` holds (blockDim.x/64 + 1) words.
+// Returns the exclusive prefix; *total receives the block sum.  Contains two __syncthreads().
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *sm, uint32_t *total)
+{
+    int lane = lane_id(), wv = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+    uint32_t inc = wave_incl_scan_u32(v);
+    __syncthreads();                       // protect sm against the previous use
+    if (lane == WAVE - 1) sm[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (int i = 0; i < nw; i++) {
+        uint32_t s = sm[i];
+        if (i < wv) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+// lock-free union-find with "smaller index wins" hooking (root = smallest index of the set)
+__device__ __forceinline__ uint32_t uf_find(uint32_t *p, uint32_t i)
+{
+    for (;;) {
+        uint32_t q = __hip_atomic_load(&p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (q == i) return i;
+        i = q;
+    }
+}
+__device__ __forceinline__ void uf_unite(uint32_t *p, uint32_t a, uint32_t b)
+{
+    for (;;) {
+        a = uf_find(p, a);
+        b = uf_find(p, b);
+        if (a == b) return;
+        if (a < b) { uint32_t s = a; a = b; b = s; }          // a > b: hook a below b
+        uint32_t old = atomicMin(&p[a], b);
+        if (old == a) return;                                  // a was still a root
+        a = old;                                               // somebody re-hooked a: unite that with b
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0  threshold -> bit mask + runs per row            (contrack/contrack.py:646-674, NaN -> 0)
+// One wave per row, lane l tests pixel 64k+l, __ballot packs 64 pixels into one mask word.
+// thr32[t] is the float32 threshold the host derived so that the float32 compare equals the
+// reference's compare (see ctk_api: adjust_threshold).
+// ------------------------------------------------------------------------------------------------
+template <int OP>
+__device__ __forceinline__ bool cmp_op(float v, float th)
+{
+    if (OP == 0) return v >= th;
+    if (OP == 1) return v <= th;
+    if (OP == 2) return v > th;
+    return v < th;
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_threshold(const float *__restrict__ anom, const float *__restrict__ thr32,
+                                                   int64_t nrows, int ny, int nx, int W,
+                                                   uint64_t *__restrict__ mask, uint16_t *__restrict__ rowcnt,
+                                                   uint32_t *__restrict__ tcount)
+{
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t row = wave; row < nrows; row += nwaves) {
+        const int64_t t = row / ny;
+        const float th = thr32[t];
+        const float *src = anom + row * (int64_t)nx;
+        uint64_t carry = 0;          // last pixel of the previous word
+        uint32_t nruns = 0;
+        for (int w0 = 0; w0 < W; w0 += WAVE) {
+            const int wn = min(WAVE, W - w0);
+            uint64_t mine = 0;
+            int k = 0;
+            for (; k + 8 <= wn; k += 8) {                     // 8 independent loads in flight per lane
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    int x = (w0 + k + j) * 64 + lane;
+                    v[j] = (x < nx) ? src[x] : __builtin_nanf("");
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    uint64_t b = __ballot(cmp_op<OP>(v[j], th));
+                    if (lane == k + j) mine = b;
+                }
+            }
+            for (; k < wn; k++) {
+                int x = (w0 + k) * 64 + lane;
+                float v = (x < nx) ? src[x] : __builtin_nanf("");
+                uint64_t b = __ballot(cmp_op<OP>(v, th));
+                if (lane == k) mine = b;
+            }
+            uint64_t prev = shfl_up_u64(mine, 1);
+            uint64_t cin = (lane == 0) ? carry : (prev >> 63);
+            uint64_t starts = mine & ~((mine << 1) | cin);
+            if (lane < wn) mask[row * W + w0 + lane] = mine;
+            nruns += wave_sum_u32(lane < wn ? (uint32_t)__popcll(starts) : 0u);
+            carry = shfl_u64(mine, wn - 1) >> 63;
+        }
+        if (lane == 0) {
+            rowcnt[row] = (uint16_t)nruns;
+            if (nruns) atomicAdd(&tcount[t], nruns);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1  exclusive scan of a uint32 vector by ONE workgroup (n is the number of timesteps: small)
+// out[0..n] (n+1 entries, out[n] = total).  Totals beyond 2^32-1 set *ovf.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v)
+{
+    int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint64_t o = shfl_up_u64(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ in, int64_t n,
+                                                   uint32_t *__restrict__ out, uint32_t *ovf)
+{
+    __shared__ uint64_t wsum[16];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t b = min(n, (int64_t)tid * per), e = min(n, b + per);
+    uint64_t s = 0;
+    for (int64_t i = b; i < e; i++) s += in[i];
+    uint64_t inc = wave_incl_scan_u64(s);
+    if (lane == WAVE - 1) wsum[wv] = inc;
+    __syncthreads();
+    uint64_t base = 0;
+    for (int i = 0; i < wv; i++) base += wsum[i];
+    uint64_t run = base + inc - s;
+    for (int64_t i = b; i < e; i++) { out[i] = (uint32_t)run; run += in[i]; }
+    if (tid == 1023) {
+        out[n] = (uint32_t)run;
+        if (run > 0xffffffffull) atomicOr(ovf, CTK_OVF_RUNS);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2  2-D connected-component labelling of one timestep on RUNS, 8-connectivity, plus the
+//     longitude seam merge.           (contrack/contrack.py:684-698; scipy.ndimage.label numbering)
+//
+// One workgroup per timestep.  Run arrays + union-find parents live in LDS (k_label2d_lds) or, for
+// timesteps with more runs than the LDS variant carries, in a global scratch area (k_label2d_glb).
+//   phase 1  rowstart = exclusive scan of runs per row
+//   phase 2  run extraction from the mask words (wave per row, lane per word, ctz over start/end bits)
+//   phase 3  union every run with the runs of the previous row it touches (8-connectivity: x0-1..x1+1)
+//   phase 4  flatten -> root of every run; root = smallest run index = the run holding the component's
+//            first raster pixel, so ranking the roots reproduces scipy's label order
+//   phase 5  seam: rows whose first run starts at x=0 and last run ends at x=nx-1 unite those two runs
+//            (same-row pairs only, contrack.py:693-698); second flatten -> merged component
+//   phase 6  component ids, per-component bbox and exact area limbs, seam-row records
+// ------------------------------------------------------------------------------------------------
+struct Label2dArgs {
+    const uint64_t *mask;
+    const uint16_t *rowcnt;
+    uint32_t *rowstart;
+    const uint32_t *run_base;      // [T+1]
+    uint32_t *run_comp;
+    uint32_t *ncomp;               // [T]
+    // per-component tables in run-indexed scratch slots (slot = run_base[t] + c)
+    uint32_t *cs_mrep;
+    uint32_t *cs_box;              // 4 x uint32 per slot: y0, y1, x0, x1
+    int64_t *cs_area;              // 2 per slot
+    CtkSeam *seams;
+    uint32_t *counters;            // CTK_CNT_*
+    uint32_t seam_cap;
+    const int32_t *wlo, *whi;      // [ny] weight limbs
+    int ny, nx, W;
+    uint32_t lds_cap;              // runs the LDS variant carries
+    // global scratch for the fallback variant (indexed by run_base[t] + r)
+    uint16_t *g_x0, *g_x1, *g_y;
+    uint32_t *g_parent, *g_root, *g_idmap;
+};
+
+template <int THREADS>
+__device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, const uint32_t nruns,
+                                             uint16_t *x0, uint16_t *x1, uint16_t *yrow, uint32_t *parent,
+                                             uint32_t *root, uint32_t *idmap, uint32_t *rs /* rowstart, ny+1 */,
+                                             uint32_t *sm_scan)
+{
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, nwv = THREADS >> 6;
+    const int ny = a.ny, nx = a.nx, W = a.W;
+    const uint64_t *mrow = a.mask + (int64_t)t * ny * W;
+    const uint16_t *rc = a.rowcnt + (int64_t)t * ny;
+    const uint32_t rbase = a.run_base[t];
+
+    // ---- phase 1: rowstart -------------------------------------------------------------------
+    {
+        uint32_t carry = 0;
+        for (int y0 = 0; y0 < ny; y0 += THREADS) {
+            int y = y0 + tid;
+            uint32_t v = (y < ny) ? rc[y] : 0u, tot;
+            uint32_t ex = block_excl_scan(v, sm_scan, &tot);
+            if (y < ny) { rs[y] = carry + ex; a.rowstart[(int64_t)t * ny + y] = carry + ex; }
+            carry += tot;
+        }
+        if (tid == 0) rs[ny] = carry;
+    }
+    __syncthreads();
+
+    // ---- phase 2: run extraction ---------------------------------------------------------------
+    for (int y = wv; y < ny; y += nwv) {
+        if (rc[y] == 0) continue;
+        const uint64_t *mw = mrow + (int64_t)y * W;
+        uint32_t sbase = rs[y], ebase = rs[y];
+        uint64_t carry = 0;
+        for (int w0 = 0; w0 < W; w0 += WAVE) {
+            const int wn = min(WAVE, W - w0);
+            uint64_t m = (lane < wn) ? mw[w0 + lane] : 0ull;
+            uint64_t prev = shfl_up_u64(m, 1), next = shfl_down_u64(m, 1);
+            uint64_t cin = (lane == 0) ? carry : (prev >> 63);
+            uint64_t nin;
+            if (lane == wn - 1) nin = (w0 + wn < W) ? (mw[w0 + wn] & 1ull) : 0ull; else nin = next & 1ull;
+            uint64_t starts = m & ~((m << 1) | cin);
+            uint64_t ends = m & ~((m >> 1) | (nin << 63));
+            uint32_t cs = (uint32_t)__popcll(starts), ce = (uint32_t)__popcll(ends);
+            uint32_t is = wave_incl_scan_u32(cs), ie = wave_incl_scan_u32(ce);
+            uint32_t si = sbase + is - cs, ei = ebase + ie - ce;
+            const int xb = (w0 + lane) * 64;
+            while (starts) {
+                int b = __builtin_ctzll(starts);
+                starts &= starts - 1;
+                x0[si] = (uint16_t)(xb + b);
+                yrow[si] = (uint16_t)y;
+                parent[si] = si;
+                si++;
+            }
+            while (ends) {
+                int b = __builtin_ctzll(ends);
+                ends &= ends - 1;
+                x1[ei] = (uint16_t)(xb + b);
+                ei++;
+            }
+            sbase += __shfl(is, WAVE - 1);
+            ebase += __shfl(ie, WAVE - 1);
+            carry = shfl_u64(m, wn - 1) >> 63;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: unions with the previous row ------------------------------------------------
+    for (uint32_t r = tid; r < nruns; r += THREADS) {
+        const int y = yrow[r];
+        if (y == 0) continue;
+        uint32_t lo = rs[y - 1], hi = rs[y];
+        if (lo == hi) continue;
+        const int xa = (int)x0[r] - 1, xb = (int)x1[r] + 1;
+        // first run s in [lo,hi) with x1[s] >= xa
+        uint32_t l = lo, h = hi;
+        while (l < h) {
+            uint32_t m = (l + h) >> 1;
+            if ((int)x1[m] < xa) l = m + 1; else h = m;
+        }
+        for (uint32_t s = l; s < hi && (int)x0[s] <= xb; s++) uf_unite(parent, r, s);
+    }
+    __syncthreads();
+
+    // ---- phase 4: flatten (no-wrap components) --------------------------------------------------
+    for (uint32_t r = tid; r < nruns; r += THREADS) root[r] = uf_find(parent, r);
+    __syncthreads();
+    for (uint32_t r = tid; r < nruns; r += THREADS) parent[r] = root[r];
+    __syncthreads();
+
+    // ---- phase 5: seam unions on top, second flatten (kept in `parent`) ----------------------------
+    for (int y = tid; y < ny; y += THREADS) {
+        uint32_t f = rs[y], l = rs[y + 1];
+        if (f == l) continue;
+        l--;
+        if (x0[f] == 0 && x1[l] == (uint16_t)(nx - 1) && f != l) uf_unite(parent, f, l);
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < nruns; r += THREADS) {
+        uint32_t m = uf_find(parent, r);
+        idmap[r] = m;                      // temporarily: merged root of r
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < nruns; r += THREADS) parent[r] = idmap[r];
+    __syncthreads();
+
+    // ---- phase 6: ids, tables ------------------------------------------------------------------------
+    uint32_t ncomp = 0;
+    {
+        uint32_t carry = 0;
+        for (uint32_t r0 = 0; r0 < nruns; r0 += THREADS) {
+            uint32_t r = r0 + tid;
+            uint32_t v = (r < nruns && root[r] == r) ? 1u : 0u, tot;
+            uint32_t ex = block_excl_scan(v, sm_scan, &tot);
+            if (r < nruns) idmap[r] = carry + ex;          // meaningful at roots only
+            carry += tot;
+        }
+        ncomp = carry;
+    }
+    __syncthreads();
+    if (tid == 0) a.ncomp[t] = ncomp;
+    uint32_t *cmrep = a.cs_mrep + rbase;
+    uint32_t *cbox = a.cs_box + (int64_t)rbase * 4;
+    int64_t *carea = a.cs_area + (int64_t)rbase * 2;
+    for (uint32_t c = tid; c < ncomp; c += THREADS) {
+        cbox[c * 4 + 0] = 0xffffu; cbox[c * 4 + 1] = 0u; cbox[c * 4 + 2] = 0xffffu; cbox[c * 4 + 3] = 0u;
+        carea[c * 2] = 0; carea[c * 2 + 1] = 0;
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < nruns; r += THREADS) {
+        const uint32_t rt = root[r];
+        const uint32_t c = idmap[rt];
+        a.run_comp[rbase + r] = c;
+        const int y = yrow[r];
+        const int64_t len = (int64_t)x1[r] - (int64_t)x0[r] + 1;
+        atomicAdd((unsigned long long *)&carea[c * 2], (unsigned long long)(len * (int64_t)a.wlo[y]));
+        atomicAdd((unsigned long long *)&carea[c * 2 + 1], (unsigned long long)(len * (int64_t)a.whi[y]));
+        atomicMin(&cbox[c * 4 + 0], (uint32_t)y);
+        atomicMax(&cbox[c * 4 + 1], (uint32_t)y);
+        atomicMin(&cbox[c * 4 + 2], (uint32_t)x0[r]);
+        atomicMax(&cbox[c * 4 + 3], (uint32_t)x1[r]);
+        if (rt == r) cmrep[c] = idmap[parent[r]];          // merged root is itself a no-wrap root (smallest run)
+    }
+    // seam rows: both seam pixels set (also when they are one run / one component: chain events can still
+    // split them)
+    {
+        for (int y0 = 0; y0 < ny; y0 += THREADS) {
+            int y = y0 + tid;
+            uint32_t f = 0, l = 0, v = 0;
+            if (y < ny) {
+                f = rs[y]; l = rs[y + 1];
+                if (f != l) { l--; v = (x0[f] == 0 && x1[l] == (uint16_t)(nx - 1)) ? 1u : 0u; }
+            }
+            uint32_t tot;
+            uint32_t ex = block_excl_scan(v, sm_scan, &tot);
+            __shared__ uint32_t seam_base;
+            if (tid == 0 && tot) seam_base = atomicAdd(&a.counters[CTK_CNT_SEAMS], tot);
+            __syncthreads();
+            if (v) {
+                uint32_t i = seam_base + ex;
+                if (i < a.seam_cap) {
+                    CtkSeam q;
+                    q.t = (uint32_t)t; q.y = (uint32_t)y; q.cl = idmap[root[f]]; q.cr = idmap[root[l]];
+                    a.seams[i] = q;
+                } else atomicOr(&a.counters[CTK_CNT_OVERFLOW], CTK_OVF_SEAMS);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+#define CTK_LDS_RUNS 2048
+#define CTK_LDS_NY 2048
+
+__global__ __launch_bounds__(256) void k_label2d_lds(Label2dArgs a)
+{
+    const int t = (int)blockIdx.x;
+    const uint32_t nruns = a.run_base[t + 1] - a.run_base[t];
+    if (nruns > CTK_LDS_RUNS || a.ny > CTK_LDS_NY) return;        // k_label2d_glb takes it
+    if (nruns == 0) {
+        if (threadIdx.x == 0) a.ncomp[t] = 0;
+        for (int y = (int)threadIdx.x; y < a.ny; y += 256) a.rowstart[(int64_t)t * a.ny + y] = 0;
+        return;
+    }
+    __shared__ uint16_t x0[CTK_LDS_RUNS], x1[CTK_LDS_RUNS], yrow[CTK_LDS_RUNS];
+    __shared__ uint32_t parent[CTK_LDS_RUNS], root[CTK_LDS_RUNS], idmap[CTK_LDS_RUNS];
+    __shared__ uint32_t rs[CTK_LDS_NY + 1];
+    __shared__ uint32_t sm_scan[8];
+    label2d_body<256>(a, t, nruns, x0, x1, yrow, parent, root, idmap, rs, sm_scan);
+}
+
+__global__ __launch_bounds__(256) void k_label2d_glb(Label2dArgs a, uint32_t *g_rs /* [T][ny+1] scratch */)
+{
+    const int t = (int)blockIdx.x;
+    const uint32_t rb = a.run_base[t];
+    const uint32_t nruns = a.run_base[t + 1] - rb;
+    if (!(nruns > CTK_LDS_RUNS || a.ny > CTK_LDS_NY)) return;
+    __shared__ uint32_t sm_scan[8];
+    label2d_body<256>(a, t, nruns, a.g_x0 + rb, a.g_x1 + rb, a.g_y + rb, a.g_parent + rb, a.g_root + rb,
+                      a.g_idmap + rb, g_rs + (int64_t)t * (a.ny + 1), sm_scan);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3  compaction of the per-component scratch slots into dense (t, c) order
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compact_comps(const uint32_t *__restrict__ run_base, const uint32_t *__restrict__ ncomp,
+                                                       const uint32_t *__restrict__ cprefix, const uint32_t *__restrict__ cs_mrep,
+                                                       const uint32_t *__restrict__ cs_box, const int64_t *__restrict__ cs_area,
+                                                       uint32_t *__restrict__ d_mrep, uint16_t *__restrict__ d_box,
+                                                       int64_t *__restrict__ d_area)
+{
+    const int t = (int)blockIdx.x;
+    const uint32_t n = ncomp[t], rb = run_base[t], cb = cprefix[t];
+    for (uint32_t c = threadIdx.x; c < n; c += blockDim.x) {
+        d_mrep[cb + c] = cs_mrep[rb + c];
+        for (int k = 0; k < 4; k++) d_box[(int64_t)(cb + c) * 4 + k] = (uint16_t)cs_box[(int64_t)(rb + c) * 4 + k];
+        d_area[(int64_t)(cb + c) * 2] = cs_area[(int64_t)(rb + c) * 2];
+        d_area[(int64_t)(cb + c) * 2 + 1] = cs_area[(int64_t)(rb + c) * 2 + 1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4  label co-occurrence histogram between timestep t and t-1     (contrack/contrack.py:718-719 areas,
+//     and the temporal links of the 3-D structure at contrack.py:748-750)
+// One workgroup per timestep; wave per row, lane per mask word; o = m[t] & m[t-1]; every maximal piece
+// of o inside a word belongs to exactly one (run@t, run@t-1) pair, whose ranks follow from popcounts
+// of the start bits.  (component@t, component@t-1) -> exact area limbs are accumulated in an
+// LDS-resident hash table with LDS atomics; entries that do not find a slot are emitted directly
+// (records are additive, duplicates are fine).
+// ------------------------------------------------------------------------------------------------
+#define CTK_HASH_SLOTS 1024
+#define CTK_HASH_PROBES 12
+
+struct OverlapArgs {
+    const uint64_t *mask;
+    const uint32_t *rowstart;
+    const uint32_t *run_base;
+    const uint32_t *run_comp;
+    // halo = last timestep of the previous shard (used for t == 0 when has_prev)
+    const uint64_t *halo_mask;
+    const uint32_t *halo_rowstart;
+    const uint32_t *halo_run_comp;
+    int has_prev;
+    CtkPair *pairs;
+    uint32_t pair_cap;
+    uint32_t *counters;
+    const int32_t *wlo, *whi;
+    int ny, nx, W;
+};
+
+__device__ __forceinline__ void emit_pair(const OverlapArgs &a, uint32_t t, uint32_t c, uint32_t d, int64_t lo, int64_t hi)
+{
+    uint32_t i = atomicAdd(&a.counters[CTK_CNT_PAIRS], 1u);
+    if (i < a.pair_cap) {
+        CtkPair p;
+        p.t = t; p.c = c; p.d = d; p.pad = 0; p.lo = lo; p.hi = hi;
+        a.pairs[i] = p;
+    } else atomicOr(&a.counters[CTK_CNT_OVERFLOW], CTK_OVF_PAIRS);
+}
+
+__global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
+{
+    const int t = (int)blockIdx.x;
+    if (t == 0 && !a.has_prev) return;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, nwv = 256 >> 6;
+    const int ny = a.ny, W = a.W;
+    __shared__ unsigned long long hkey[CTK_HASH_SLOTS];
+    __shared__ long long hlo[CTK_HASH_SLOTS], hhi[CTK_HASH_SLOTS];
+    __shared__ uint32_t sm_scan[8];
+    __shared__ uint32_t out_base;
+    for (int i = tid; i < CTK_HASH_SLOTS; i += 256) { hkey[i] = FULL64; hlo[i] = 0; hhi[i] = 0; }
+    __syncthreads();
+
+    const uint64_t *mc = a.mask + (int64_t)t * ny * W;
+    const uint32_t *rsc = a.rowstart + (int64_t)t * ny;
+    const uint32_t *rcc = a.run_comp + a.run_base[t];
+    const uint64_t *mp;
+    const uint32_t *rsp, *rcp;
+    if (t == 0) { mp = a.halo_mask; rsp = a.halo_rowstart; rcp = a.halo_run_comp; }
+    else { mp = a.mask + (int64_t)(t - 1) * ny * W; rsp = a.rowstart + (int64_t)(t - 1) * ny; rcp = a.run_comp + a.run_base[t - 1]; }
+
+    for (int y = wv; y < ny; y += nwv) {
+        const uint64_t *rowc = mc + (int64_t)y * W, *rowp = mp + (int64_t)y * W;
+        uint32_t basec = rsc[y], basep = rsp[y];
+        uint64_t carryc = 0, carryp = 0;
+        const int64_t wl = a.wlo[y], wh = a.whi[y];
+        for (int w0 = 0; w0 < W; w0 += WAVE) {
+            const int wn = min(WAVE, W - w0);
+            uint64_t c = (lane < wn) ? rowc[w0 + lane] : 0ull;
+            uint64_t p = (lane < wn) ? rowp[w0 + lane] : 0ull;
+            uint64_t pc = shfl_up_u64(c, 1), pp = shfl_up_u64(p, 1);
+            uint64_t sc = c & ~((c << 1) | ((lane == 0) ? carryc : (pc >> 63)));
+            uint64_t sp = p & ~((p << 1) | ((lane == 0) ? carryp : (pp >> 63)));
+            uint32_t nc = (uint32_t)__popcll(sc), np = (uint32_t)__popcll(sp);
+            uint32_t ic = wave_incl_scan_u32(nc), ip = wave_incl_scan_u32(np);
+            uint32_t ec = basec + ic - nc, ep = basep + ip - np;       // runs started before this word
+            uint64_t o = c & p;
+            while (o) {
+                int b = __builtin_ctzll(o);
+                uint64_t sh = o >> b;
+                int n = (~sh == 0ull) ? 64 : __builtin_ctzll(~sh);
+                uint64_t below = (b + 1 >= 64) ? FULL64 : ((1ull << (b + 1)) - 1ull);   // bits 0..b
+                uint32_t rcur = ec + (uint32_t)__popcll(sc & below) - 1u;
+                uint32_t rprv = ep + (uint32_t)__popcll(sp & below) - 1u;
+                uint32_t cc = rcc[rcur], cd = rcp[rprv];
+                int64_t lo = (int64_t)n * wl, hi = (int64_t)n * wh;
+                unsigned long long key = ((unsigned long long)cc << 32) | cd;
+                uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (CTK_HASH_SLOTS - 1);
+                bool placed = false;
+                for (int q = 0; q < CTK_HASH_PROBES; q++) {
+                    unsigned long long old = atomicCAS(&hkey[h], FULL64, key);
+                    if (old == FULL64 || old == key) {
+                        atomicAdd((unsigned long long *)&hlo[h], (unsigned long long)lo);
+                        atomicAdd((unsigned long long *)&hhi[h], (unsigned long long)hi);
+                        placed = true;
+                        break;
+                    }
+                    h = (h + 1) & (CTK_HASH_SLOTS - 1);
+                }
+                if (!placed) emit_pair(a, (uint32_t)t, cc, cd, lo, hi);
+                o = (n >= 64 - b) ? 0ull : (o & ~(((1ull << n) - 1ull) << b));
+            }
+            basec += __shfl(ic, WAVE - 1);
+            basep += __shfl(ip, WAVE - 1);
+            carryc = shfl_u64(c, wn - 1) >> 63;
+            carryp = shfl_u64(p, wn - 1) >> 63;
+        }
+    }
+    __syncthreads();
+    // flush the table: one contiguous block of records per timestep
+    for (int i0 = 0; i0 < CTK_HASH_SLOTS; i0 += 256) {
+        int i = i0 + tid;
+        uint32_t v = (hkey[i] != FULL64) ? 1u : 0u, tot;
+        uint32_t ex = block_excl_scan(v, sm_scan, &tot);
+        if (tid == 0 && tot) out_base = atomicAdd(&a.counters[CTK_CNT_PAIRS], tot);
+        __syncthreads();
+        if (v) {
+            uint32_t j = out_base + ex;
+            if (j < a.pair_cap) {
+                CtkPair p;
+                p.t = (uint32_t)t; p.c = (uint32_t)(hkey[i] >> 32); p.d = (uint32_t)hkey[i]; p.pad = 0;
+                p.lo = hlo[i]; p.hi = hhi[i];
+                a.pairs[j] = p;
+            } else atomicOr(&a.counters[CTK_CNT_OVERFLOW], CTK_OVF_PAIRS);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-pixel fold of the ordered seam operations (contrack/contrack.py:753-763 semantics, see
+// ctk_resolve.cpp): only used for the rare "complex" components.
+//   oi_hi / oi_idx : op indices sorted by (hi, execution index)
+// ------------------------------------------------------------------------------------------------
+struct FoldArgs {
+    const CtkOp *ops;
+    const int32_t *oi_hi;
+    const int32_t *oi_idx;
+    int32_t nops;
+};
+
+__device__ inline int32_t fold_pixel(const FoldArgs &f, int32_t l, int32_t t, int32_t y, int32_t x)
+{
+    int32_t s = 0;
+    for (;;) {
+        int32_t lo = 0, hi = f.nops;                       // first entry with oi_hi >= l
+        while (lo < hi) { int32_t m = (lo + hi) >> 1; if (f.oi_hi[m] < l) lo = m + 1; else hi = m; }
+        bool moved = false;
+        for (int32_t k = lo; k < f.nops && f.oi_hi[k] == l; k++) {
+            int32_t idx = f.oi_idx[k];
+            if (idx < s) continue;
+            const CtkOp o = f.ops[idx];
+            if (t >= o.t0 && t <= o.t1 && y >= o.y0 && y <= o.y1 && x >= o.x0 && x <= o.x1) {
+                l = o.lo; s = idx + 1; moved = true; break;
+            }
+        }
+        if (!moved) return l;
+    }
+}
+
+// Visit every foreground pixel of row (t, y) with its run index (relative to the timestep).
+// F(x, run) is called by the lane that owns pixel x (lane = x & 63).
+template <typename F>
+__device__ __forceinline__ void for_each_fg_pixel_in_row(const uint64_t *mw, int W, uint32_t rowstart, F f)
+{
+    const int lane = lane_id();
+    uint32_t base = rowstart;
+    uint64_t carry = 0;
+    for (int w0 = 0; w0 < W; w0 += WAVE) {
+        const int wn = min(WAVE, W - w0);
+        uint64_t m = (lane < wn) ? mw[w0 + lane] : 0ull;
+        uint64_t pm = shfl_up_u64(m, 1);
+        uint64_t st = m & ~((m << 1) | ((lane == 0) ? carry : (pm >> 63)));
+        uint32_t n = (uint32_t)__popcll(st);
+        uint32_t inc = wave_incl_scan_u32(n);
+        uint32_t before = base + inc - n;
+        for (int k = 0; k < wn; k++) {
+            uint64_t mk = shfl_u64(m, k);
+            if (mk == 0ull) continue;                                  // wave-uniform
+            uint64_t sk = shfl_u64(st, k);
+            uint32_t bk = __shfl(before, k);
+            if ((mk >> lane) & 1ull) {
+                uint64_t below = (lane == 63) ? FULL64 : ((1ull << (lane + 1)) - 1ull);
+                f((w0 + k) * 64 + lane, bk + (uint32_t)__popcll(sk & below) - 1u);
+            }
+        }
+        base += __shfl(inc, WAVE - 1);
+        carry = shfl_u64(m, wn - 1) >> 63;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5  time extents of the final ids (persistence, contrack/contrack.py:765-772).  One workgroup per
+//     timestep; one atomic min/max per component; complex components fold pixel by pixel.
+//     ext[0..n] = min t, ext[n+1 .. 2n+1] = max t  (global timestep numbers)
+// ------------------------------------------------------------------------------------------------
+struct ExtentArgs {
+    const uint64_t *mask;
+    const uint32_t *rowstart;
+    const uint32_t *run_base;
+    const uint32_t *run_comp;
+    const uint32_t *ncomp;
+    const uint32_t *cprefix;
+    const int32_t *comp_label;     // dense (t,c) order
+    int32_t *ext;
+    int64_t n_labels;
+    int64_t t_begin;
+    FoldArgs fold;
+    int ny, nx, W;
+};
+
+__global__ __launch_bounds__(256) void k_extent(ExtentArgs a)
+{
+    const int t = (int)blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    const uint32_t n = a.ncomp[t], cb = a.cprefix[t];
+    const int32_t tg = (int32_t)(a.t_begin + t);
+    int32_t *tmin = a.ext, *tmax = a.ext + a.n_labels + 1;
+    __shared__ int any_complex;
+    if (tid == 0) any_complex = 0;
+    __syncthreads();
+    for (uint32_t c = tid; c < n; c += 256) {
+        int32_t l = a.comp_label[cb + c];
+        if (l > 0) { atomicMin(&tmin[l], tg); atomicMax(&tmax[l], tg); }
+        else if (l < 0) any_complex = 1;
+    }
+    __syncthreads();
+    if (!any_complex) return;
+    const uint32_t *rc = a.run_comp + a.run_base[t];
+    const int wv = tid >> 6;
+    for (int y = wv; y < a.ny; y += 4) {
+        const uint64_t *mw = a.mask + ((int64_t)t * a.ny + y) * a.W;
+        for_each_fg_pixel_in_row(mw, a.W, a.rowstart[(int64_t)t * a.ny + y], [&](int x, uint32_t run) {
+            int32_t l = a.comp_label[cb + rc[run]];
+            if (l < 0) {
+                int32_t fl = fold_pixel(a.fold, -l, tg, y, x);
+                atomicMin(&tmin[fl], tg);
+                atomicMax(&tmax[fl], tg);
+            }
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6  final value of every run: id if its label survives persistence, 0 otherwise; complex
+//     components keep the negative fresh label (folded per pixel in k_relabel).
+//     mode 0: final values; mode 1/2: debug -- global 2-D ids before / after the seam merge.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_run_values(const uint32_t *__restrict__ run_base, const uint32_t *__restrict__ run_comp,
+                                                    const uint32_t *__restrict__ cprefix, const int32_t *__restrict__ comp_label,
+                                                    const int32_t *__restrict__ ext, int64_t n_labels, int persistence,
+                                                    const uint32_t *__restrict__ d_mrep, int64_t comp_id_base, int mode,
+                                                    int32_t *__restrict__ run_val)
+{
+    const int t = (int)blockIdx.x;
+    const uint32_t rb = run_base[t], n = run_base[t + 1] - rb, cb = cprefix[t];
+    for (uint32_t r = threadIdx.x; r < n; r += blockDim.x) {
+        uint32_t c = run_comp[rb + r];
+        int32_t v;
+        if (mode == 0) {
+            int32_t l = comp_label[cb + c];
+            if (l > 0) v = ((int64_t)ext[n_labels + 1 + l] - (int64_t)ext[l] + 1 < persistence) ? 0 : l;
+            else v = l;
+        } else if (mode == 1) v = (int32_t)(comp_id_base + cb + c + 1);
+        else v = (int32_t)(comp_id_base + cb + d_mrep[cb + c] + 1);
+        run_val[rb + r] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7  relabel pass: writes the int32 flag slab ONCE.       (contrack/contrack.py:776-791 payload)
+// One wave per row.  Lane l writes pixel 64k+l (256 B coalesced stores); a pixel's run index is
+// rowstart + (number of run starts at or left of it) - 1, from popcounts on the mask words.
+// ------------------------------------------------------------------------------------------------
+struct RelabelArgs {
+    const uint64_t *mask;
+    const uint32_t *rowstart;
+    const uint32_t *run_base;
+    const int32_t *run_val;
+    const int32_t *ext;
+    int64_t n_labels;
+    int persistence;
+    int64_t t_begin;
+    FoldArgs fold;
+    int32_t *flag;
+    uint32_t *counters;
+    int64_t nrows;
+    int ny, nx, W;
+};
+
+__global__ __launch_bounds__(256) void k_relabel(RelabelArgs a)
+{
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int W = a.W, nx = a.nx;
+    uint32_t wrote_zero = 0;
+    for (int64_t row = wave; row < a.nrows; row += nwaves) {
+        const int64_t t = row / a.ny;
+        const int y = (int)(row - t * a.ny);
+        const uint64_t *mw = a.mask + row * W;
+        int32_t *dst = a.flag + row * (int64_t)nx;
+        const int32_t *rv = a.run_val + a.run_base[t];
+        uint32_t base = a.rowstart[row];
+        uint64_t carry = 0;
+        for (int w0 = 0; w0 < W; w0 += WAVE) {
+            const int wn = min(WAVE, W - w0);
+            uint64_t m = (lane < wn) ? mw[w0 + lane] : 0ull;
+            uint64_t pm = shfl_up_u64(m, 1);
+            uint64_t st = m & ~((m << 1) | ((lane == 0) ? carry : (pm >> 63)));
+            uint32_t n = (uint32_t)__popcll(st);
+            uint32_t inc = wave_incl_scan_u32(n);
+            uint32_t before = base + inc - n;
+            for (int k = 0; k < wn; k++) {
+                const int x = (w0 + k) * 64 + lane;
+                uint64_t mk = shfl_u64(m, k);
+                int32_t v = 0;
+                if (mk != 0ull) {                                       // wave-uniform
+                    uint64_t sk = shfl_u64(st, k);
+                    uint32_t bk = __shfl(before, k);
+                    if ((mk >> lane) & 1ull) {
+                        uint64_t below = (lane == 63) ? FULL64 : ((1ull << (lane + 1)) - 1ull);
+                        v = rv[bk + (uint32_t)__popcll(sk & below) - 1u];
+                        if (v < 0) {                                    // complex component: fold this pixel
+                            int32_t fl = fold_pixel(a.fold, -v, (int32_t)(a.t_begin + t), y, x);
+                            v = ((int64_t)a.ext[a.n_labels + 1 + fl] - (int64_t)a.ext[fl] + 1 < a.persistence) ? 0 : fl;
+                        }
+                    }
+                }
+                if (x < nx) { dst[x] = v; wrote_zero |= (v == 0); }
+            }
+            base += __shfl(inc, WAVE - 1);
+            carry = shfl_u64(m, wn - 1) >> 63;
+        }
+    }
+    if (__ballot(wrote_zero != 0) && lane == 0) atomicOr(&a.counters[CTK_CNT_WROTE_ZERO], 1u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8  number of ids that are present and survive persistence
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__ ext, int64_t n_labels, int persistence,
+                                                     uint32_t *counters)
+{
+    int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    uint32_t v = 0;
+    if (l <= n_labels) {
+        int64_t lo = ext[l], hi = ext[n_labels + 1 + l];
+        v = (hi >= lo && hi - lo + 1 >= persistence) ? 1u : 0u;
+    }
+    uint32_t s = wave_sum_u32(v);
+    if (lane_id() == 0 && s) atomicAdd(&counters[CTK_CNT_ALIVE], s);
+}
+
+__global__ void k_fill_ext(int32_t *ext, int64_t n_labels)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n_labels) { ext[i] = INT32_MAX; ext[n_labels + 1 + i] = INT32_MIN; }
+}
+
+// mask words -> one byte per pixel (debug / staged parity)
+__global__ void k_expand_mask(const uint64_t *__restrict__ mask, int64_t nrows, int nx, int W, uint8_t *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * nx) return;
+    int64_t row = i / nx;
+    int x = (int)(i - row * nx);
+    out[i] = (uint8_t)((mask[row * W + (x >> 6)] >> (x & 63)) & 1ull);
+}
+
+// halo export: pack {mask row words, rowstart, run_comp} of the LAST timestep into one blob
+__global__ void k_copy_u32(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// deterministic synthetic slab for throughput runs (bench only): a sum of drifting smooth waves,
+// ~10 % of the pixels above 160.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_synth(float *__restrict__ out, int64_t T, int ny, int nx, uint64_t seed)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = T * (int64_t)ny * nx;
+    if (i >= n) return;
+    int x = (int)(i % nx);
+    int y = (int)((i / nx) % ny);
+    int64_t t = i / ((int64_t)nx * ny);
+    float lon = 6.2831853f * (float)x / (float)nx, lat = 3.1415927f * ((float)y / (float)(ny - 1) - 0.5f);
+    float tt = (float)t;
+    float s = 0.f;
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+#pragma unroll 1
+    for (int k = 0; k < 12; k++) {
+        z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+        int kx = 1 + (int)(z % 7), ky = 1 + (int)((z >> 8) % 6);
+        float ph = (float)((z >> 16) % 6283) * 1e-3f, om = ((float)((z >> 32) % 2001) - 1000.f) * 2e-4f;
+        float amp = 60.f / (float)(1 + (k >> 2));
+        s += amp * __sinf((float)kx * lon + ph + om * tt) * __cosf((float)ky * lat * 2.f + ph * 0.7f - om * 0.5f * tt);
+    }
+    out[i] = 35.f + s * __cosf(lat) + 40.f * __sinf(lat * 2.f + 0.01f * tt);
+}
+

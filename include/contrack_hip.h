@@ -1,0 +1,150 @@
+/*
+ * contrack_hip.h -- C ABI of libcontrack_hip.so, the MI355X (gfx950) implementation of ConTrack's
+ * run_contrack hot path.
+ *
+ * What this replaces.  The reference (steidani/ConTrack v0.4.1) has NO FFI/plugin interface: its hot
+ * path is the Python method contrack.run_contrack (contrack/contrack.py:583-796), which calls
+ * scipy.ndimage.label (:684, :748), scipy.ndimage.find_objects (:708, :753, :766) and numpy reductions
+ * (:717-719) on a (time, lat, lon) array.  The entry points below are what a ctypes binding inside
+ * run_contrack binds instead of those calls (INTEGRATION.md shows the stub).  Plain pointers and
+ * sizes only; all buffers are caller-owned and borrowed for the duration of the call; the library owns
+ * its device workspace (inside the opaque handle).  Every function returns 0 on success or a negative
+ * CTK_E_* code; ctk_last_error() returns a thread-local message.  Nothing throws or exits.
+ *
+ * Conventions shared by all entry points
+ *   anom      C-contiguous float32 (T, ny, nx) -- the slab after contrack.py:677-681 put it in
+ *             (time, lat, lon) order.
+ *   thr       T doubles; the compare evaluated is (double)anom[t,y,x] <op> thr[t].  The caller rounds a
+ *             Python-number threshold to float32 first (that is what contrack.py:665 compares against
+ *             for a float32 array); a float64 threshold vector is passed unrounded (contrack.py:650).
+ *   cmp_op    0 '>='/'ge', 1 '<='/'le', 2 '>'/'gt', 3 '<'/'lt'     (contrack.py:649-656, :664-671)
+ *   wrow      ny float32 row weights, computed by the host exactly as contrack.py:703-704 does.
+ *   overlap, persistence, twosided                                   (contrack.py:587-589)
+ *   flag      int32 (T, ny, nx): the ids of contrack.py:776-791, identical to the reference's
+ *             (identity permutation), 0 = background.
+ *   n_tracked len(np.unique(flag)) - 1                               (contrack.py:793)
+ */
+#ifndef CONTRACK_HIP_H
+#define CONTRACK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTK_OK            0
+#define CTK_E_INVALID    -1   /* bad argument (shape, cmp_op, NULL, non-finite weight ...)      */
+#define CTK_E_NODEVICE   -2   /* no usable HIP device / HIP runtime error                        */
+#define CTK_E_NOMEM      -3   /* host or device allocation failed                                */
+#define CTK_E_RANGE      -4   /* weight dynamic range or problem size beyond what the kernels carry */
+#define CTK_E_INTERNAL   -5
+#define CTK_E_STATE      -6   /* staged calls out of order                                       */
+
+typedef struct ctk_handle ctk_handle;
+
+/* ---- library / device ------------------------------------------------------------------------ */
+int         ctk_version(void);
+const char *ctk_last_error(void);
+int         ctk_device_count(void);                       /* <0 on HIP error, 0 if no GPU          */
+int         ctk_create(ctk_handle **h, int device);       /* binds the handle to one GPU + stream  */
+void        ctk_destroy(ctk_handle *h);
+
+/* ---- whole path, one call (replaces contrack.py:646-772 on the (time,lat,lon) slab) ----------- */
+/* host buffers in, host buffers out (H2D + kernels + D2H) */
+int ctk_track_f32(ctk_handle *h, const float *anom, int64_t T, int ny, int nx, const double *thr,
+                  int cmp_op, const float *wrow, double overlap, int persistence, int twosided,
+                  int32_t *flag, int64_t *n_tracked);
+/* device buffers in, device buffers out (anom_dev / flag_dev are HIP device pointers) */
+int ctk_track_f32_dev(ctk_handle *h, const float *anom_dev, int64_t T, int ny, int nx,
+                      const double *thr, int cmp_op, const float *wrow, double overlap,
+                      int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked);
+
+/* ---- staged path (time-sharded multi-GPU; each rank owns timesteps [t_begin, t_begin+T)) ------ */
+/* stage 1: threshold -> bit mask -> 2-D labelling with longitude wrap (contrack.py:646-698) + per
+ *          component areas (contrack.py:717).  has_prev != 0 means a previous shard exists and
+ *          its last timestep will be imported before stage 2.                                    */
+int ctk_shard_label2d(ctk_handle *h, const float *anom_dev, int64_t T, int ny, int nx,
+                      const double *thr, int cmp_op, const float *wrow, int has_prev);
+/* halo: the labelled LAST timestep of this shard, as an opaque device blob for the next rank
+ *       (bit mask + run->component ids; the compressed form of the one-timestep label map).      */
+int ctk_shard_halo_size(ctk_handle *h, size_t *max_bytes);           /* upper bound, same on all ranks */
+int ctk_shard_halo_export(ctk_handle *h, void **blob_dev, size_t *nbytes);
+int ctk_shard_halo_import(ctk_handle *h, const void *blob_dev, size_t nbytes);
+/* stage 2: label co-occurrence histogram between consecutive timesteps (the overlap areas of
+ *          contrack.py:718-719 and the temporal links of contrack.py:748-750).                   */
+int ctk_shard_overlap(ctk_handle *h);
+/* tables: serialised component / pair / seam tables of this shard (host memory owned by the
+ *         handle, valid until the next staged call on it).                                       */
+int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes);
+
+/* resolve: host-side, GPU-free.  Takes the table blobs of ALL shards in time order and evaluates the
+ *          sequential parts of the reference on component tables: overlap filter recurrence
+ *          (contrack.py:706-742), 3-D labelling ids (contrack.py:748-751), bbox-confined seam merges
+ *          (contrack.py:753-763).  Returns an opaque result (free with ctk_result_free).          */
+typedef struct ctk_result ctk_result;
+int  ctk_resolve(const void *const *blobs, const size_t *nbytes, int nshards, double overlap,
+                 int twosided, ctk_result **out);
+void ctk_result_free(ctk_result *r);
+int  ctk_result_info(const ctk_result *r, int64_t *n_labels, int64_t *n_ops, int64_t *n_complex,
+                     int64_t *n_ambiguous, int64_t *n_components);
+
+/* read-only views into a result (valid until ctk_result_free): comp_label[ncomps] in (shard, t, c)
+ * order -- 0 = removed by the overlap filter, L > 0 = final id of every pixel of the component, -L =
+ * the component must be folded pixel by pixel starting from 3-D label L; ops[nops] = the bbox-confined
+ * relabel operations in execution order, 8 int32 each: hi, lo, t0, t1, y0, y1, x0, x1 (inclusive). */
+int  ctk_result_arrays(const ctk_result *r, const int32_t **comp_label, int64_t *ncomps, const void **ops,
+                       int64_t *nops, const int64_t **shard_comp_off, const int64_t **shard_t_off);
+/* exact integer limbs of the float32 row weights: w[y] = (wlo[y] + whi[y] * 2^31) * 2^-wshift */
+int  ctk_weights_to_limbs(const float *wrow, int ny, int32_t *wlo, int32_t *whi, int32_t *wshift);
+
+/* stage 3: apply the result to this shard (index `shard` of the blobs given to ctk_resolve):
+ *          per-label time extents (persistence, contrack.py:765-772), then the relabel pass that
+ *          writes flag.  ext_dev: device int32 [2*(n_labels+1)] (min t | max t); when ranks > 1 the
+ *          caller all-reduces the first half with MIN and the second with MAX between _extents and
+ *          _write.                                                                                */
+int ctk_shard_extents(ctk_handle *h, const ctk_result *r, int shard, int64_t t_begin,
+                      int32_t **ext_dev, int64_t *n_labels);
+int ctk_shard_write(ctk_handle *h, int persistence, int32_t *flag_dev, int64_t *n_alive_local,
+                    int *wrote_background);
+/* number of labels that survive persistence (identical on all ranks after the all-reduce)        */
+int ctk_shard_count_tracked(ctk_handle *h, int64_t *n_alive);
+
+/* ---- staged-parity / debug accessors (host copies) ------------------------------------------- */
+int ctk_debug_mask(ctk_handle *h, uint8_t *mask /* (T,ny,nx) 0/1 */);
+/* 2-D labels exactly as scipy numbers them at contrack.py:684 (before_seam=1) or after the seam merge
+ * of contrack.py:691-698 (before_seam=0): ids are global over time, 1-based, raster order.        */
+int ctk_debug_label2d(ctk_handle *h, int before_seam, int32_t *lab /* (T,ny,nx) */);
+
+/* ---- timing (HIP events on the handle's stream) ----------------------------------------------- */
+#define CTK_K_THRESHOLD 0
+#define CTK_K_SCAN      1
+#define CTK_K_LABEL2D   2
+#define CTK_K_OVERLAP   3
+#define CTK_K_EXTENT    4
+#define CTK_K_RUNLABEL  5
+#define CTK_K_RELABEL   6
+#define CTK_K_COUNT     7
+#define CTK_T_HOST_RESOLVE 8   /* host wall time of ctk_resolve inside ctk_track_*   */
+#define CTK_T_D2H          9   /* table download                                      */
+#define CTK_T_H2D         10   /* result upload                                       */
+#define CTK_T_TOTAL       11
+#define CTK_NTIMERS       12
+int ctk_set_timing(ctk_handle *h, int enable);
+int ctk_get_timings(ctk_handle *h, double *ms /* [CTK_NTIMERS] */);
+
+/* ---- thin device-memory helpers so that a ctypes host needs no other HIP binding -------------- */
+int ctk_dev_malloc(ctk_handle *h, void **p, size_t nbytes);
+int ctk_dev_free(ctk_handle *h, void *p);
+int ctk_memcpy_h2d(ctk_handle *h, void *dst_dev, const void *src, size_t nbytes);
+int ctk_memcpy_d2h(ctk_handle *h, void *dst, const void *src_dev, size_t nbytes);
+int ctk_sync(ctk_handle *h);
+void *ctk_stream(ctk_handle *h);                          /* hipStream_t */
+/* deterministic on-device synthetic slab for throughput runs (bench only; not part of the path) */
+int ctk_synth_fill(ctk_handle *h, float *anom_dev, int64_t T, int ny, int nx, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONTRACK_HIP_H */

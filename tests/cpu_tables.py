@@ -1,0 +1,172 @@
+"""numpy/scipy builder of the component / pair / seam tables (the blob of contrack_amd/csrc/ctk_tables.h)
+from a boolean mask, and a numpy applier of a resolver result.  TEST INFRASTRUCTURE: lets the GPU-free
+host logic (ctk_resolve, shard concatenation, distributed driver) be exercised on CPU, and is the staged
+reference the HIP stage outputs are compared against on the GPU.
+"""
+import struct
+
+import numpy as np
+from scipy import ndimage
+
+MAGIC = 0x314b544e4f43
+S8 = np.ones((3, 3), dtype=np.int32)
+HDR_FMT = "<Qqiiiiqqq"          # CtkBlobHeader: magic, T, ny, nx, wshift, has_prev, ncomps, npairs, nseams
+
+
+def _align8(n):
+    return (n + 7) & ~7
+
+
+def label_step(m2d):
+    """8-connected labels of one plane, ids 1..n in raster order of the first pixel (= scipy's order)."""
+    lab, n = ndimage.label(m2d, structure=S8)
+    return lab.astype(np.int32), int(n)
+
+
+def build_tables(mask, wlo, whi, prev_lab=None):
+    """mask: bool (T,ny,nx).  prev_lab: int32 (ny,nx) no-wrap labels (1-based) of the timestep before
+    this shard, or None.  Returns dict with ncomp, mrep, box, area, pairs, seams, labs (per-step labels)."""
+    T, ny, nx = mask.shape
+    wlo = np.asarray(wlo, dtype=np.int64)
+    whi = np.asarray(whi, dtype=np.int64)
+    ncomp, mrep, box, area, pairs, seams, labs = [], [], [], [], [], [], []
+    ys = np.arange(ny)
+    for t in range(T):
+        lab, n = label_step(mask[t])
+        labs.append(lab)
+        ncomp.append(n)
+        # seam merge -> representative (smallest member) of the merged component
+        par = np.arange(n)
+
+        def find(i):
+            while par[i] != i:
+                par[i] = par[par[i]]
+                i = par[i]
+            return i
+        for y in range(ny):
+            a, b = lab[y, 0], lab[y, nx - 1]
+            if a > 0 and b > 0:
+                seams.append((t, y, a - 1, b - 1))
+                ra, rb = find(a - 1), find(b - 1)
+                if ra != rb:
+                    par[max(ra, rb)] = min(ra, rb)
+        mrep.extend(find(i) for i in range(n))
+        objs = ndimage.find_objects(lab)
+        for c in range(n):
+            sl = objs[c]
+            box.append((sl[0].start, sl[0].stop - 1, sl[1].start, sl[1].stop - 1))
+        if n:
+            cnt = np.zeros((n + 1, ny), dtype=np.int64)
+            np.add.at(cnt, (lab.ravel(), np.repeat(ys, nx)), 1)
+            for c in range(1, n + 1):
+                area.append((int((cnt[c] * wlo).sum()), int((cnt[c] * whi).sum())))
+        prev = labs[t - 1] if t > 0 else prev_lab
+        if prev is not None:
+            both = (lab > 0) & (prev > 0)
+            if both.any():
+                yy, xx = np.nonzero(both)
+                key = (lab[yy, xx].astype(np.int64) - 1) * (int(prev.max()) + 1) + (prev[yy, xx] - 1)
+                uk, inv = np.unique(key, return_inverse=True)
+                lo = np.zeros(len(uk), dtype=np.int64)
+                hi = np.zeros(len(uk), dtype=np.int64)
+                np.add.at(lo, inv, wlo[yy])
+                np.add.at(hi, inv, whi[yy])
+                pm = int(prev.max()) + 1
+                for k, l, h in zip(uk, lo, hi):
+                    pairs.append((t, int(k // pm), int(k % pm), int(l), int(h)))
+    return dict(T=T, ny=ny, nx=nx, ncomp=ncomp, mrep=mrep, box=box, area=area, pairs=pairs, seams=seams, labs=labs)
+
+
+def pack_blob(tb, wshift, has_prev):
+    T, nc, npairs, ns = tb["T"], len(tb["mrep"]), len(tb["pairs"]), len(tb["seams"])
+    out = bytearray()
+    out += struct.pack(HDR_FMT, MAGIC, T, tb["ny"], tb["nx"], wshift, int(bool(has_prev)), nc, npairs, ns)
+    a = np.asarray(tb["ncomp"], dtype=np.uint32).tobytes()
+    out += a + b"\0" * (_align8(len(a)) - len(a))
+    a = np.asarray(tb["mrep"], dtype=np.uint32).tobytes()
+    out += a + b"\0" * (_align8(len(a)) - len(a))
+    a = np.asarray(tb["box"], dtype=np.uint16).reshape(-1).tobytes()
+    out += a + b"\0" * (_align8(len(a)) - len(a))
+    out += np.asarray(tb["area"], dtype=np.int64).reshape(-1).tobytes()
+    for (t, c, d, lo, hi) in tb["pairs"]:
+        out += struct.pack("<IIIIqq", t, c, d, 0, lo, hi)
+    for (t, y, cl, cr) in tb["seams"]:
+        out += struct.pack("<IIII", t, y, cl, cr)
+    return bytes(out)
+
+
+def parse_blob(blob):
+    """Canonical (order-independent, duplicate-merged) view of a blob, for equality checks."""
+    hdr = struct.unpack_from(HDR_FMT, blob, 0)
+    magic, T, ny, nx, wshift, has_prev, nc, npairs, ns = hdr
+    assert magic == MAGIC
+    off = struct.calcsize(HDR_FMT)
+    ncomp = np.frombuffer(blob, dtype=np.uint32, count=T, offset=off); off += _align8(T * 4)
+    mrep = np.frombuffer(blob, dtype=np.uint32, count=nc, offset=off); off += _align8(nc * 4)
+    box = np.frombuffer(blob, dtype=np.uint16, count=nc * 4, offset=off).reshape(nc, 4); off += _align8(nc * 8)
+    area = np.frombuffer(blob, dtype=np.int64, count=nc * 2, offset=off).reshape(nc, 2); off += nc * 16
+    pdt = np.dtype([("t", "<u4"), ("c", "<u4"), ("d", "<u4"), ("pad", "<u4"), ("lo", "<i8"), ("hi", "<i8")])
+    pairs = np.frombuffer(blob, dtype=pdt, count=npairs, offset=off); off += npairs * pdt.itemsize
+    sdt = np.dtype([("t", "<u4"), ("y", "<u4"), ("cl", "<u4"), ("cr", "<u4")])
+    seams = np.frombuffer(blob, dtype=sdt, count=ns, offset=off)
+    pd = {}
+    for p in pairs:
+        k = (int(p["t"]), int(p["c"]), int(p["d"]))
+        lo, hi = pd.get(k, (0, 0))
+        pd[k] = (lo + int(p["lo"]), hi + int(p["hi"]))
+    sd = sorted((int(s["t"]), int(s["y"]), int(s["cl"]), int(s["cr"])) for s in seams)
+    return dict(T=T, ny=ny, nx=nx, wshift=wshift, has_prev=has_prev, ncomp=ncomp.copy(), mrep=mrep.copy(), box=box.copy(),
+                area=area.copy(), pairs=pd, seams=sd)
+
+
+def fold_pixel(ops, ops_of, l, t, y, x):
+    s = 0
+    while True:
+        moved = False
+        for idx in ops_of.get(l, ()):
+            if idx < s:
+                continue
+            o = ops[idx]
+            if o[2] <= t <= o[3] and o[4] <= y <= o[5] and o[6] <= x <= o[7]:
+                l = int(o[1]); s = idx + 1; moved = True
+                break
+        if not moved:
+            return l
+
+
+def apply_result(labs_per_step, comp_label, ops, persistence):
+    """labs_per_step: list over GLOBAL timesteps of int32 (ny,nx) no-wrap labels (1-based);
+    comp_label: int32 per component in (t,c) order; ops: (nops,8).  Returns the int32 flag slab."""
+    T = len(labs_per_step)
+    ny, nx = labs_per_step[0].shape
+    ops_of = {}
+    for i, o in enumerate(ops):
+        ops_of.setdefault(int(o[0]), []).append(i)
+    flag = np.zeros((T, ny, nx), dtype=np.int32)
+    off = 0
+    for t in range(T):
+        lab = labs_per_step[t]
+        n = int(lab.max())
+        lut = np.zeros(n + 1, dtype=np.int32)
+        lut[1:] = comp_label[off:off + n]
+        f = lut[lab]
+        if (lut < 0).any():
+            yy, xx = np.nonzero(f < 0)
+            for y, x in zip(yy, xx):
+                f[y, x] = fold_pixel(ops, ops_of, -int(f[y, x]), t, int(y), int(x))
+        flag[t] = f
+        off += n
+    assert off == len(comp_label)
+    # persistence (contrack.py:765-772) on the merged ids
+    mx = int(flag.max())
+    if mx:
+        tmin = np.full(mx + 1, T, dtype=np.int64)
+        tmax = np.full(mx + 1, -1, dtype=np.int64)
+        for t in range(T):
+            ids = np.unique(flag[t])
+            tmin[ids] = np.minimum(tmin[ids], t)
+            tmax[ids] = np.maximum(tmax[ids], t)
+        dead = (tmax - tmin + 1) < persistence
+        dead[0] = False
+        flag[dead[flag]] = 0
+    return flag

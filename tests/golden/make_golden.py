@@ -112,6 +112,14 @@ case("all_bg", src="syn", T=6, ny=31, nx=60, seed=83, threshold=1e9, gorl=">=", 
      twosided=True, sigma_deg=12.0)
 case("all_fg", src="syn", T=6, ny=31, nx=60, seed=84, threshold=-1e9, gorl=">=", overlap=0.5, persistence=2,
      twosided=True, sigma_deg=12.0)
+# chain events with PARTIAL box containment (found by a randomized search against the oracle): these
+# exercise the per-pixel fold of the bbox-confined seam merges (contrack.py:753-763)
+case("chain_a", src="syn", T=120, ny=31, nx=36, seed=1143, threshold=100.0, gorl=">=", overlap=0.5, persistence=2,
+     twosided=True, sigma_deg=18.0, sigma_t=1.0)
+case("chain_b", src="syn", T=40, ny=31, nx=60, seed=1215, threshold=120.0, gorl=">=", overlap=0.5, persistence=4,
+     twosided=False, sigma_deg=6.0, sigma_t=2.0)
+case("chain_c", src="syn", T=120, ny=21, nx=40, seed=1308, threshold=120.0, gorl=">=", overlap=0.1, persistence=2,
+     twosided=False, sigma_deg=12.0, sigma_t=1.0)
 # irregular (CESM-like) latitudes: the reference needs set_up(force=True); dlat = round(mean, 2)
 case("cesm_like", src="syn", T=40, ny=48, nx=72, seed=90, threshold=150, gorl=">=", overlap=0.5, persistence=3,
      twosided=True, grid="cesm", sigma_deg=10.0)
