@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""bench.py -- timesteps/s labelled+tracked on synthetic ERA5-like Z500 anomaly slabs (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload era5_1deg_djf30|era5_025deg|...]
+
+A "step" is one pass of the hot path (threshold -> 2-D labelling with longitude wrap -> overlap filter ->
+3-D tracking -> persistence -> flag) over one batch: the whole (T, ny, nx) slab of the workload, already
+resident in HBM.  For N > 1 (launched by torch.distributed.run, one rank per GPU) the time axis is sharded
+across ranks (strong scaling: total work fixed) -- see contrack_amd/dist.py.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from contrack_amd import _native, synth  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: ERA5 Z500 anomaly 1 deg, 2707 DJF daily steps, thr 160 gpm, overlap 0.5, persistence 5
+    "era5_1deg_djf30": dict(T=2707, ny=181, nx=360, threshold=160.0, gorl=">=", overlap=0.5, persistence=5, twosided=True),
+    # BASELINE.json configs[0]: the reference's own CPU-runnable case
+    "era5_1deg_90": dict(T=90, ny=181, nx=360, threshold=160.0, gorl=">=", overlap=0.5, persistence=5, twosided=True),
+    # 0.25 deg, 6-hourly (a 480-step window of configs[2]; persistence 20 steps = 5 days)
+    "era5_025deg_480": dict(T=480, ny=721, nx=1440, threshold=160.0, gorl=">=", overlap=0.5, persistence=20, twosided=True),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def row_weights(lat, dlat, dlon):
+    # contrack/contrack.py:703-704
+    weight_lat = np.cos(lat * np.pi / 180)
+    return np.array((111 * dlat * 111 * dlon * weight_lat)).astype(np.float32)
+
+
+def make_slab(wl, seed=0):
+    a = synth.smooth_field(wl["T"], wl["ny"], wl["nx"], seed=seed)
+    lat, lon = synth.grid(wl["ny"], wl["nx"])
+    dlat = np.float32(180.0 / (wl["ny"] - 1))
+    dlon = np.float32(360.0 / wl["nx"])
+    return a, row_weights(lat, dlat, dlon)
+
+
+def cpu_baseline(wl, a, w, budget_s=20.0):
+    """The CPU restatement of the reference path (oracle/scipy_port.py: same scipy.ndimage / numpy call
+    sequence as contrack.py:646-796, one core) timed on a bounded sample of the same workload."""
+    from oracle import scipy_port
+    n = wl["T"] if wl["ny"] * wl["nx"] < 100000 else min(wl["T"], 240)
+    thr = np.float32(wl["threshold"])
+    t0 = time.perf_counter()
+    scipy_port.run_contrack(a[:n], thr, wl["gorl"], w, wl["overlap"], wl["persistence"], wl["twosided"])
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="timesteps/s", cores=1, kind="port",
+                sample="first %d of %d steps of the same slab, scipy.ndimage/numpy port of contrack.py:646-796 "
+                       "(oracle/scipy_port.py), %.2f s" % (n, wl["T"], dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="era5_1deg_djf30")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        from contrack_amd import dist
+        return dist.bench_main(args, wl, WORKLOADS, HBM_PEAK_GBS)
+
+    T, ny, nx = wl["T"], wl["ny"], wl["nx"]
+    a, w = make_slab(wl)
+    thr = np.full(T, np.float64(np.float32(wl["threshold"])))
+    op = _native.CMP_OPS[wl["gorl"]]
+    trk = _native.Tracker(int(os.environ.get("LOCAL_RANK", "0")))
+    d_in = trk.malloc(a.nbytes)
+    d_out = trk.malloc(a.nbytes)
+    trk.h2d(d_in, a)
+    trk.set_timing(True)
+
+    def step():
+        return trk.track_dev(d_in, T, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], d_out)
+
+    for _ in range(args.warmup):
+        n_tracked = step()
+    trk.sync()
+    acc = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_tracked = step()
+        for k, v in trk.timings().items():
+            acc[k] = acc.get(k, 0.0) + v
+    trk.sync()
+    dt = time.perf_counter() - t0
+    ms_per_step = dt * 1e3 / args.steps
+    value = T * args.steps / dt
+    per = {k: v / args.steps for k, v in acc.items()}
+    # roofline of the dominant kernel (by average duration, HIP events on the library's stream)
+    px = T * ny * nx
+    alg_bytes = {"k_threshold": 4.0 * px, "k_relabel": 4.0 * px}          # float32 read once / int32 written once
+    kern = max(alg_bytes, key=lambda k: per.get(k, 0.0))
+    achieved = alg_bytes[kern] / (per[kern] * 1e-3) / 1e9 if per.get(kern, 0) > 0 else 0.0
+    out = dict(metric="timesteps/sec labeled+tracked", value=value, unit="timesteps/s", n_gpus=1, steps=args.steps,
+               warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None,
+               dtype="f32 compare / int32 labels / int64 exact areas", data="synthetic",
+               config=dict(workload="%s: %dx%dx%d float32, threshold %s %g, overlap %g, persistence %d, twosided %s" % (
+                   args.workload, T, ny, nx, wl["gorl"], wl["threshold"], wl["overlap"], wl["persistence"], wl["twosided"]),
+                   parallelism="1 GPU", n_tracked=n_tracked, coverage=float((a >= np.float32(wl["threshold"])).mean())),
+               roofline=dict(bound="hbm", kernel=kern, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                             traffic=None, algorithmic_bytes_per_launch=alg_bytes[kern], avg_kernel_ms=per.get(kern)),
+               kernels_ms=per,
+               path_effective_gbs=8.0 * px / (ms_per_step * 1e-3) / 1e9)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl, a, w)
+    print(json.dumps(out))
+    trk.free(d_in)
+    trk.free(d_out)
+    trk.close()
+
+
+if __name__ == "__main__":
+    main()

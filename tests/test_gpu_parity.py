@@ -1,0 +1,140 @@
+"""HIP path (through the C ABI, contrack_amd/_native.py) against the reference goldens and the CPU
+oracle.  Bit-exact: ids are the reference's ids (identity permutation)."""
+import numpy as np
+import pytest
+
+import cpu_tables
+import golden_util
+from contrack_amd import _native, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def trk():
+    if _native.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu-marked tests must run on the GPU box")
+    t = _native.Tracker(0)
+    yield t
+    t.close()
+
+
+@pytest.mark.parametrize("name", golden_util.case_names())
+def test_hip_matches_reference_golden(trk, name):
+    g = golden_util.load(name)
+    flag, n = trk.track(g["anom"], g["thr"], _native.CMP_OPS[g["gorl"]], g["wrow"], g["overlap"], g["persistence"], g["twosided"])
+    assert flag.dtype == np.int32
+    assert np.array_equal(flag, g["flag"])
+    assert n == len(np.unique(g["flag"])) - 1
+
+
+def _staged(trk, anom, thr, op, wrow):
+    T, ny, nx = anom.shape
+    d = trk.malloc(anom.nbytes)
+    try:
+        trk.h2d(d, anom)
+        trk.shard_label2d(d, T, ny, nx, thr, op, wrow, False)
+        mask = trk.debug_mask(T, ny, nx)
+        lab_nw = trk.debug_label2d(T, ny, nx, True)
+        lab_m = trk.debug_label2d(T, ny, nx, False)
+        trk.shard_overlap()
+        blob = trk.shard_tables()
+    finally:
+        trk.free(d)
+    return mask, lab_nw, lab_m, blob
+
+
+@pytest.mark.parametrize("name", ["refslab_two", "syn2deg_s0", "busy_s1", "noise", "odd_65x130", "odd_9x65", "nan_speckle",
+                                  "thr_vector", "all_fg", "all_bg", "chain_a", "cesm_like"])
+def test_staged_outputs_match_oracle(trk, oracle_lib, name):
+    """threshold mask, scipy-numbered 2-D labels before/after the seam merge (contrack.py:684-698), and the
+    component / pair / seam tables."""
+    g = golden_util.load(name)
+    op = _native.CMP_OPS[g["gorl"]]
+    mask, lab_nw, lab_m, blob = _staged(trk, g["anom"], g["thr"], op, g["wrow"])
+    omask = oracle_lib.threshold_mask(g["anom"], g["thr"], g["gorl"])
+    assert np.array_equal(mask, omask)
+    olab, _ = oracle_lib.label(omask, 0)
+    assert np.array_equal(lab_nw, olab)
+    _, _, stage = oracle_lib.run_contrack(g["anom"], g["thr"], g["gorl"], g["wrow"], g["overlap"], g["persistence"], g["twosided"],
+                                          return_stage=True)
+    assert np.array_equal(lab_m, stage)
+    wlo, whi, wshift = _native.weights_to_limbs(g["wrow"])
+    ref = cpu_tables.parse_blob(cpu_tables.pack_blob(cpu_tables.build_tables(omask.astype(bool), wlo, whi), wshift, False))
+    got = cpu_tables.parse_blob(blob)
+    assert got["T"] == ref["T"] and got["wshift"] == ref["wshift"]
+    assert np.array_equal(got["ncomp"], ref["ncomp"])
+    assert np.array_equal(got["mrep"], ref["mrep"])
+    assert np.array_equal(got["box"], ref["box"])
+    assert np.array_equal(got["area"], ref["area"])
+    assert got["pairs"] == ref["pairs"]
+    assert got["seams"] == ref["seams"]
+
+
+CASES_VS_ORACLE = [
+    # (T, ny, nx, seed, kind, threshold, gorl, overlap, persistence, twosided)
+    (96, 181, 360, 3, "smooth", 160.0, ">=", 0.5, 5, True),          # BASELINE config-1 parameters
+    (64, 181, 360, 4, "smooth", 150.0, ">", 0.5, 5, False),
+    (6, 721, 1440, 5, "smooth", 160.0, ">=", 0.5, 2, True),          # 0.25 deg grid: 23 words per row
+    (8, 181, 360, 6, "noise", 0.8, ">=", 0.5, 2, True),              # ~10^4 runs per step: global-memory labelling variant
+    (5, 192, 288, 7, "smooth", 160.0, ">=", 0.5, 2, True),           # CESM grid
+    (1, 91, 180, 8, "smooth", 150.0, ">=", 0.5, 1, True),            # T = 1 (the reference cannot even set up)
+    (40, 91, 4200, 9, "smooth", 150.0, ">=", 0.5, 3, True),          # more than 64 words per row
+    (12, 2100, 64, 10, "smooth", 150.0, ">=", 0.5, 2, True),         # more rows than the LDS row table
+]
+
+
+@pytest.mark.parametrize("case", CASES_VS_ORACLE, ids=lambda c: "%dx%dx%d_%s" % (c[0], c[1], c[2], c[4]))
+def test_hip_matches_oracle(trk, oracle_lib, case):
+    T, ny, nx, seed, kind, thr, gorl, ov, pers, two = case
+    if kind == "noise":
+        a = np.random.default_rng(seed).standard_normal((T, ny, nx)).astype(np.float32)
+    else:
+        a = synth.smooth_field(T, ny, nx, seed=seed)
+    lat = np.linspace(90, -90, ny).astype(np.float32)
+    w = oracle_lib.row_weights(lat, np.float32(180.0 / (ny - 1)), np.float32(360.0 / nx))
+    thrv = oracle_lib.prepare_thresholds(thr, T)
+    want, nw = oracle_lib.run_contrack(a, thrv, gorl, w, ov, pers, two)
+    got, ng = trk.track(a, thrv, _native.CMP_OPS[gorl], w, ov, pers, two)
+    assert np.array_equal(got, want)
+    assert ng == nw
+
+
+def test_workspace_reuse_and_determinism(trk, oracle_lib):
+    """same handle, different shapes back to back, then the first again: identical output."""
+    g1, g2 = golden_util.load("syn2deg_s1"), golden_util.load("odd_17x64")
+    outs = []
+    for g in (g1, g2, g1, g2):
+        f, _ = trk.track(g["anom"], g["thr"], _native.CMP_OPS[g["gorl"]], g["wrow"], g["overlap"], g["persistence"], g["twosided"])
+        outs.append(f)
+    assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[3])
+    assert np.array_equal(outs[0], g1["flag"]) and np.array_equal(outs[1], g2["flag"])
+
+
+def test_size_independent_properties(trk):
+    """At a size the oracle is not run on (BASELINE config-1 grid, 400 steps):
+    (a) the foreground of flag is a subset of the threshold mask;
+    (b) every id lives at least `persistence` steps and n_tracked counts the distinct ids;
+    (c) idempotence: tracking the output's own foreground with overlap -1 / persistence 1 reproduces the
+        same partition with an order-preserving renumbering (the overlap filter removes nothing -- 0 would not do:
+        the negative pole-row weights make fractions slightly negative -- and the 3-D
+        components and the bbox-confined seam merges of the surviving pixels are unchanged)."""
+    T, ny, nx = 400, 181, 360
+    a = synth.smooth_field(T, ny, nx, seed=21)
+    lat = np.linspace(90, -90, ny).astype(np.float32)
+    w = (111 * np.float32(1.0) * 111 * np.float32(1.0) * np.cos(lat * np.pi / 180)).astype(np.float32)
+    thr = np.full(T, np.float64(np.float32(160.0)))
+    f, n = trk.track(a, thr, 0, w, 0.5, 5, True)
+    assert ((f > 0) <= (a >= np.float32(160.0))).all()
+    ids = np.unique(f)
+    assert n == len(ids) - 1 and n > 10
+    for i in ids[1:][:50]:
+        ts = np.nonzero((f == i).any(axis=(1, 2)))[0]
+        assert ts.max() - ts.min() + 1 >= 5
+    f2, n2 = trk.track((f > 0).astype(np.float32), np.full(T, 0.5), 0, w, -1.0, 1, True)
+    assert n2 == n
+    assert np.array_equal(f2 > 0, f > 0)
+    ids2 = np.unique(f2)
+    lut = np.zeros(int(ids2.max()) + 1, dtype=np.int32)
+    lut[ids2] = ids                      # order-preserving renumbering
+    assert np.array_equal(lut[f2], f)
