@@ -72,7 +72,7 @@ def main():
     wl = WORKLOADS[args.workload]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    if world > 1 or os.environ.get("CTK_FORCE_DIST") == "1":
         from contrack_amd import dist
         return dist.bench_main(args, wl, WORKLOADS, HBM_PEAK_GBS)
 

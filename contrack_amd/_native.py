@@ -22,7 +22,7 @@ EXPORTS = [
     "ctk_version", "ctk_last_error", "ctk_device_count", "ctk_create", "ctk_destroy", "ctk_track_f32",
     "ctk_track_f32_dev", "ctk_shard_label2d", "ctk_shard_halo_size", "ctk_shard_halo_export",
     "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_resolve", "ctk_result_free",
-    "ctk_result_info", "ctk_result_arrays", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
+    "ctk_result_info", "ctk_result_arrays", "ctk_result_nshards", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
     "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_set_timing", "ctk_get_timings",
     "ctk_dev_malloc", "ctk_dev_free", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
     "ctk_synth_fill",
@@ -62,6 +62,7 @@ def lib():
     L.ctk_result_free.restype = None
     L.ctk_result_info.argtypes = [p] + [C.POINTER(i64)] * 5
     L.ctk_result_arrays.argtypes = [p, pp, C.POINTER(i64), pp, C.POINTER(i64), pp, pp]
+    L.ctk_result_nshards.argtypes = [p]
     L.ctk_weights_to_limbs.argtypes = [p, i32, p, p, C.POINTER(C.c_int32)]
     L.ctk_shard_extents.argtypes = [p, p, i32, i64, pp, C.POINTER(i64)]
     L.ctk_shard_write.argtypes = [p, i32, p, C.POINTER(i64), C.POINTER(i32)]
@@ -137,6 +138,16 @@ class Result:
         k = int(nops.value)
         opsa = np.ctypeslib.as_array(C.cast(ops, C.POINTER(C.c_int32)), shape=(max(k, 1) * 8,))[:k * 8].copy().reshape(k, 8)
         return comp_label, opsa
+
+    def shard_offsets(self):
+        """(component offsets, timestep offsets) of every shard inside comp_label: two int64 arrays of nshards+1"""
+        cl, ops, sco, sto = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nc, nops = C.c_int64(0), C.c_int64(0)
+        check(lib().ctk_result_arrays(self._p, C.byref(cl), C.byref(nc), C.byref(ops), C.byref(nops), C.byref(sco), C.byref(sto)))
+        k = int(lib().ctk_result_nshards(self._p)) + 1
+        co = np.ctypeslib.as_array(C.cast(sco, C.POINTER(C.c_int64)), shape=(k,)).copy()
+        to = np.ctypeslib.as_array(C.cast(sto, C.POINTER(C.c_int64)), shape=(k,)).copy()
+        return co, to
 
 
 def resolve(blobs, overlap, twosided):

@@ -397,6 +397,11 @@ extern "C" int ctk_result_arrays(const ctk_result *r, const int32_t **comp_label
     return CTK_OK;
 }
 
+extern "C" int ctk_result_nshards(const ctk_result *r)
+{
+    return r ? r->nshards : ctk_set_error(CTK_E_INVALID, "ctk_result_nshards: null result");
+}
+
 extern "C" int ctk_result_info(const ctk_result *r, int64_t *n_labels, int64_t *n_ops, int64_t *n_complex,
                                int64_t *n_ambiguous, int64_t *n_components)
 {

@@ -96,6 +96,7 @@ int  ctk_result_info(const ctk_result *r, int64_t *n_labels, int64_t *n_ops, int
  * relabel operations in execution order, 8 int32 each: hi, lo, t0, t1, y0, y1, x0, x1 (inclusive). */
 int  ctk_result_arrays(const ctk_result *r, const int32_t **comp_label, int64_t *ncomps, const void **ops,
                        int64_t *nops, const int64_t **shard_comp_off, const int64_t **shard_t_off);
+int  ctk_result_nshards(const ctk_result *r);          /* length-1 of the two offset arrays above */
 /* exact integer limbs of the float32 row weights: w[y] = (wlo[y] + whi[y] * 2^31) * 2^-wshift */
 int  ctk_weights_to_limbs(const float *wrow, int ny, int32_t *wlo, int32_t *whi, int32_t *wshift);
 

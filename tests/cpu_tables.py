@@ -134,15 +134,16 @@ def fold_pixel(ops, ops_of, l, t, y, x):
             return l
 
 
-def apply_result(labs_per_step, comp_label, ops, persistence):
-    """labs_per_step: list over GLOBAL timesteps of int32 (ny,nx) no-wrap labels (1-based);
-    comp_label: int32 per component in (t,c) order; ops: (nops,8).  Returns the int32 flag slab."""
+def fold_ids(labs_per_step, comp_label, ops, t_begin=0):
+    """final ids (before persistence) of the pixels of a shard whose first timestep is GLOBAL step t_begin"""
     T = len(labs_per_step)
+    if T == 0:
+        return np.zeros((0, 0, 0), dtype=np.int32)
     ny, nx = labs_per_step[0].shape
     ops_of = {}
     for i, o in enumerate(ops):
         ops_of.setdefault(int(o[0]), []).append(i)
-    flag = np.zeros((T, ny, nx), dtype=np.int32)
+    ids = np.zeros((T, ny, nx), dtype=np.int32)
     off = 0
     for t in range(T):
         lab = labs_per_step[t]
@@ -153,12 +154,19 @@ def apply_result(labs_per_step, comp_label, ops, persistence):
         if (lut < 0).any():
             yy, xx = np.nonzero(f < 0)
             for y, x in zip(yy, xx):
-                f[y, x] = fold_pixel(ops, ops_of, -int(f[y, x]), t, int(y), int(x))
-        flag[t] = f
+                f[y, x] = fold_pixel(ops, ops_of, -int(f[y, x]), t_begin + t, int(y), int(x))
+        ids[t] = f
         off += n
     assert off == len(comp_label)
-    # persistence (contrack.py:765-772) on the merged ids
-    mx = int(flag.max())
+    return ids
+
+
+def apply_result(labs_per_step, comp_label, ops, persistence):
+    """labs_per_step: list over GLOBAL timesteps of int32 (ny,nx) no-wrap labels (1-based);
+    comp_label: int32 per component in (t,c) order; ops: (nops,8).  Returns the int32 flag slab."""
+    flag = fold_ids(labs_per_step, comp_label, ops, 0)
+    T = flag.shape[0]
+    mx = int(flag.max()) if flag.size else 0
     if mx:
         tmin = np.full(mx + 1, T, dtype=np.int64)
         tmax = np.full(mx + 1, -1, dtype=np.int64)

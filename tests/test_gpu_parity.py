@@ -138,3 +138,57 @@ def test_size_independent_properties(trk):
     lut = np.zeros(int(ids2.max()) + 1, dtype=np.int32)
     lut[ids2] = ids                      # order-preserving renumbering
     assert np.array_equal(lut[f2], f)
+
+
+# ------------------------------------------------------------------------------------------------
+# time-sharded HIP stages: several processes share GPU 0, exchange through gloo (RCCL refuses two ranks
+# on one device; on the 8-GPU node the same driver runs with backend nccl and device-resident buffers)
+# ------------------------------------------------------------------------------------------------
+def _shard_worker(rank, world, port, name, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from contrack_amd import dist as cdist
+        g = golden_util.load(name)
+        T, ny, nx = g["anom"].shape
+        t0, t1 = cdist.shard_bounds(T, world)[rank]
+        trk = _native.Tracker(0)
+        a = np.ascontiguousarray(g["anom"][t0:t1])
+        d_in, d_out = trk.malloc(max(a.nbytes, 8)), trk.malloc(max(a.nbytes, 8))
+        trk.h2d(d_in, a)
+        comm = cdist.TorchComm(device=None)
+        eng = cdist.HipShardEngine(trk, comm, d_in, t1 - t0, ny, nx, g["thr"][t0:t1], _native.CMP_OPS[g["gorl"]], g["wrow"], d_out)
+        n, info = cdist.run_sharded(eng, comm, t0, g["overlap"], g["persistence"], g["twosided"])
+        flag = np.empty((t1 - t0, ny, nx), dtype=np.int32)
+        if flag.size:
+            trk.d2h(flag, d_out)
+        ok = bool(np.array_equal(flag, g["flag"][t0:t1])) and n == len(np.unique(g["flag"])) - 1
+        q.put((rank, ok, n))
+        trk.free(d_in)
+        trk.free(d_out)
+        trk.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("syn2deg_s0", 2), ("chain_a", 3), ("busy_s1", 4), ("noise", 2), ("T3", 4), ("syn1deg", 3)])
+def test_time_sharded_hip_stages(name, world):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert len({n for _, _, n in res}) == 1
