@@ -16,14 +16,14 @@ CMP_OPS = {">=": 0, "ge": 0, "<=": 1, "le": 1, ">": 2, "gt": 2, "<": 3, "lt": 3}
 GORL_ERRMSG = ' Please select from [>, >=, <, >=] for gorl'      # contrack.py:658
 
 TIMER_NAMES = ["k_threshold", "k_scan", "k_label2d", "k_overlap", "k_extent", "k_run_values", "k_relabel",
-               "k_count", "host_resolve", "tables_d2h", "result_h2d", "total"]
+               "k_resolve", "k_resolve_final", "k_count", "host_seam_driver", "d2h", "h2d", "total"]
 
 EXPORTS = [
     "ctk_version", "ctk_last_error", "ctk_device_count", "ctk_create", "ctk_destroy", "ctk_track_f32",
-    "ctk_track_f32_dev", "ctk_shard_label2d", "ctk_shard_halo_size", "ctk_shard_halo_export",
+    "ctk_track_f32_dev", "ctk_track_f64", "ctk_track_f64_dev", "ctk_shard_label2d", "ctk_shard_label2d_f64", "ctk_shard_halo_size", "ctk_shard_halo_export",
     "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_resolve", "ctk_result_free",
     "ctk_result_info", "ctk_result_arrays", "ctk_result_nshards", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
-    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_set_timing", "ctk_get_timings",
+    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_set_timing", "ctk_get_timings", "ctk_set_device_resolve",
     "ctk_dev_malloc", "ctk_dev_free", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
     "ctk_synth_fill",
 ]
@@ -51,7 +51,10 @@ def lib():
     track_args = [p, p, i64, i32, i32, p, i32, p, dbl, i32, i32, p, C.POINTER(i64)]
     L.ctk_track_f32.argtypes = track_args
     L.ctk_track_f32_dev.argtypes = track_args
+    L.ctk_track_f64.argtypes = track_args
+    L.ctk_track_f64_dev.argtypes = track_args
     L.ctk_shard_label2d.argtypes = [p, p, i64, i32, i32, p, i32, p, i32]
+    L.ctk_shard_label2d_f64.argtypes = [p, p, i64, i32, i32, p, i32, p, i32]
     L.ctk_shard_halo_size.argtypes = [p, C.POINTER(sz)]
     L.ctk_shard_halo_export.argtypes = [p, pp, C.POINTER(sz)]
     L.ctk_shard_halo_import.argtypes = [p, p, sz]
@@ -71,6 +74,7 @@ def lib():
     L.ctk_debug_label2d.argtypes = [p, i32, p]
     L.ctk_set_timing.argtypes = [p, i32]
     L.ctk_get_timings.argtypes = [p, p]
+    L.ctk_set_device_resolve.argtypes = [p, i32]
     L.ctk_dev_malloc.argtypes = [p, pp, sz]
     L.ctk_dev_free.argtypes = [p, p]
     L.ctk_memcpy_h2d.argtypes = [p, p, p, sz]
@@ -195,8 +199,8 @@ class Tracker:
         return self._h
 
     # ---- one call, host numpy in / out ------------------------------------------------------
-    def track(self, anom, thr, cmp_op, wrow, overlap, persistence, twosided=True):
-        anom = np.ascontiguousarray(anom, dtype=np.float32)
+    def track(self, anom, thr, cmp_op, wrow, overlap, persistence, twosided=True, f64=False):
+        anom = np.ascontiguousarray(anom, dtype=np.float64 if f64 else np.float32)
         T, ny, nx = anom.shape
         thr = np.ascontiguousarray(thr, dtype=np.float64)
         wrow = np.ascontiguousarray(wrow, dtype=np.float32)
@@ -204,7 +208,8 @@ class Tracker:
             raise ValueError("thr must have shape (T,) and wrow (ny,)")
         flag = np.empty((T, ny, nx), dtype=np.int32)
         n = C.c_int64(0)
-        check(lib().ctk_track_f32(self._h, anom.ctypes.data, T, ny, nx, thr.ctypes.data, int(cmp_op), wrow.ctypes.data,
+        fn = lib().ctk_track_f64 if f64 else lib().ctk_track_f32
+        check(fn(self._h, anom.ctypes.data, T, ny, nx, thr.ctypes.data, int(cmp_op), wrow.ctypes.data,
                                   float(overlap), int(persistence), int(bool(twosided)), flag.ctypes.data, C.byref(n)))
         return flag, int(n.value)
 
@@ -241,6 +246,9 @@ class Tracker:
 
     def set_timing(self, on=True):
         check(lib().ctk_set_timing(self._h, int(bool(on))))
+
+    def set_device_resolve(self, on=True):
+        check(lib().ctk_set_device_resolve(self._h, int(bool(on))))
 
     def timings(self):
         ms = np.zeros(len(TIMER_NAMES), dtype=np.float64)

@@ -1,0 +1,412 @@
+"""Drop-in `contrack` class: the public interface of steidani/ConTrack's `contrack.contrack`
+(contrack/contrack.py:49-949) with `run_contrack` executed by the MI355X HIP path.
+
+Same constructor, `read`, `read_xarray`, `set_up`, `calc_clim`, `calc_anom`, `run_contrack` signatures, the
+same `ValueError` / `IOError` texts, the same INFO log lines and the same `flag` variable (dims of the input
+variable, int32 ids identical to the reference's, same attrs).  Only `run_contrack` is accelerated; the
+pre-processing methods stay thin xarray calls (they are upstream glue).
+
+xarray is imported lazily: the class itself only needs the small part of the Dataset/DataArray API listed in
+tests/minixr.py, so it also works on any duck-typed dataset.  `track_numpy` is the array-level entry.
+
+Stated deviations from the reference:
+  * `flag` is written back with the INVERSE of the (time, lat, lon) permutation; the reference applies the
+    forward permutation twice (contrack.py:778), which is only correct when the permutation is its own
+    inverse -- for every such input (including the tested (time, lat, lon) order) both agree.
+  * ids are int32 (the reference switches to int64 beyond 2^31-2 pixels, sizes it cannot realistically run).
+"""
+import logging
+import os
+
+import numpy as np
+
+from . import _native
+
+logger = logging.getLogger(__name__)
+logging.basicConfig(format='%(levelname)s: %(message)s', level=logging.INFO)
+
+_TRACKERS = {}
+
+
+def _tracker(device=None):
+    dev = int(os.environ.get("CONTRACK_DEVICE", "0")) if device is None else int(device)
+    if dev not in _TRACKERS:
+        _TRACKERS[dev] = _native.Tracker(dev)
+    return _TRACKERS[dev]
+
+
+# ------------------------------------------------------------------------------------------------
+# array-level API
+# ------------------------------------------------------------------------------------------------
+def row_weights(lat, dlat, dlon):
+    """Row weights as contrack.py:703-704 evaluates them: cos(lat*pi/180) in the dtype of `lat`, scaled by
+    111*dlat*111*dlon left to right, cast to float32 (pole rows come out slightly negative in float32)."""
+    weight_lat = np.cos(np.asarray(lat) * np.pi / 180)
+    return np.array((111 * dlat * 111 * dlon * weight_lat)).astype(np.float32).reshape(-1)
+
+
+def prepare_thresholds(threshold, T, data_dtype):
+    """Per-timestep float64 thresholds thr[t] such that (double)x <op> thr[t] is the compare the reference
+    evaluates (contrack.py:650-671 under numpy's promotion rules): a Python number is cast to the array's
+    dtype; a float64 numpy scalar / array promotes the compare to float64."""
+    data_dtype = np.dtype(data_dtype)
+    if isinstance(threshold, (bool, int, float)) and not isinstance(threshold, np.generic):
+        if data_dtype.kind == "f":
+            val = np.asarray(threshold, dtype=data_dtype).astype(np.float64)
+        else:
+            val = np.float64(threshold)
+        return np.full(int(T), val, dtype=np.float64)
+    arr = np.asarray(threshold)
+    if arr.dtype.kind not in "fiub":
+        raise TypeError("threshold must be numeric")
+    if data_dtype == np.float32 and (arr.dtype == np.float32 or arr.dtype == np.float16 or
+                                     (arr.dtype.kind in "iub" and arr.dtype.itemsize <= 2)):
+        arr = arr.astype(np.float32)
+    out = np.broadcast_to(arr.astype(np.float64).reshape(-1) if arr.ndim else arr.astype(np.float64), (int(T),))
+    return np.ascontiguousarray(out, dtype=np.float64)
+
+
+def track_numpy(anom, wrow, threshold, gorl, overlap, persistence, twosided=True, device=None):
+    """run_contrack on a (time, lat, lon) numpy slab.  Returns (flag int32 (T,ny,nx), n_tracked).
+
+    anom float32 (other dtypes are compared exactly in float64 on the device), wrow float32 (ny,) from
+    `row_weights`, threshold scalar or per-timestep vector, gorl in {'>=','<=','>','<','ge','le','gt','lt'}."""
+    if gorl not in _native.CMP_OPS:
+        raise ValueError(_native.GORL_ERRMSG)
+    anom = np.asarray(anom)
+    if anom.ndim != 3:
+        raise ValueError("anom must be (time, lat, lon)")
+    thr = prepare_thresholds(threshold, anom.shape[0], anom.dtype)
+    trk = _tracker(device)
+    if anom.dtype != np.float32:
+        if anom.dtype.kind not in "fiub":
+            raise TypeError("anom must be a real numeric array")
+        return trk.track(anom.astype(np.float64), thr, _native.CMP_OPS[gorl], wrow, overlap, persistence, twosided, f64=True)
+    return trk.track(anom, thr, _native.CMP_OPS[gorl], wrow, overlap, persistence, twosided)
+
+
+# ------------------------------------------------------------------------------------------------
+# the class
+# ------------------------------------------------------------------------------------------------
+def _xr():
+    import xarray as xr
+    return xr
+
+
+class contrack(object):
+    """contrack class -- interface of steidani/ConTrack (contrack/contrack.py:49), HIP-accelerated run_contrack."""
+
+    num_of_contrack = 0
+
+    def __init__(self, filename="", ds=None, **kwargs):
+        """contrack(filename) reads a netCDF file, contrack(ds=dataset) wraps a dataset, contrack() is empty
+        (contrack.py:58-88)."""
+        if not filename:
+            self.ds = None if ds is None else ds
+            return
+        try:
+            self.ds = None
+            self.read(filename, **kwargs)
+        except (OSError, IOError, RuntimeError):
+            try:
+                self.read(filename, **kwargs)
+            except Exception:
+                raise IOError("Unkown fileformat. Known formats are netcdf.")
+        contrack.num_of_contrack += 1
+
+    def __repr__(self):
+        try:
+            return "\
+            Xarray dataset with {} time steps. \n\
+            Available fields: {}".format(self.ntime, ", ".join(self.variables))
+        except AttributeError:
+            return "\
+            Empty contrack container.\n\
+            Hint: use read() to load data."
+
+    def __str__(self):
+        return 'Class {}: \n{}'.format(self.__class__.__name__, self.ds)
+
+    def __len__(self):
+        return len(self.ds)
+
+    def __getattr__(self, attr):
+        if attr in self.__dict__:
+            return getattr(self, attr)
+        if attr == "ds":
+            raise AttributeError(attr)
+        return getattr(self.ds, attr)
+
+    def __getitem__(self, key):
+        return self.ds[key]
+
+    # ---- properties (contrack.py:119-161) ------------------------------------------------------
+    def _dim_size(self, name):
+        dims = self.ds.dims
+        try:
+            return dims[name]
+        except (TypeError, KeyError, IndexError):          # newer xarray: dims of a Dataset may be a plain view
+            return self.ds.sizes[name]
+
+    @property
+    def ntime(self):
+        if len(self.ds.dims) != 3:
+            logger.warning("\nBe careful with the dimensions, you want dims = 3 and shape:\n(latitude, longitude, time)")
+        return self._dim_size(self._get_name_time())
+
+    @property
+    def variables(self):
+        return list(self.ds.data_vars)
+
+    @property
+    def dimensions(self):
+        return list(self.ds.dims)
+
+    @property
+    def grid(self):
+        if len(self.ds.dims) != 3:
+            logger.warning("\nBe careful with the dimensions, you want dims = 3 and shape:\n(latitude, longitude, time)")
+            return None
+        print("\
+        latitude: {} \n\
+        longitude: {}".format(self._dim_size(self._get_name_latitude()), self._dim_size(self._get_name_longitude())))
+
+    @property
+    def dataset(self):
+        return self.ds
+
+    # ---- read (contrack.py:166-199) ---------------------------------------------------------------
+    def read(self, filename, **kwargs):
+        if self.ds is None:
+            self.ds = _xr().open_dataset(filename, **kwargs)
+            logger.debug('read: {}'.format(self.__str__))
+        else:
+            raise ValueError('contrack() is already set!')
+
+    def read_xarray(self, ds):
+        if self.ds is None:
+            try:
+                xr = _xr()
+                ok = isinstance(ds, xr.core.dataset.Dataset)
+            except ImportError:                              # no xarray installed: accept a duck-typed dataset
+                ok = hasattr(ds, "dims") and hasattr(ds, "data_vars")
+            if not ok:
+                raise ValueError('ds has to be a xarray data set!')
+            self.ds = ds
+            logger.debug('read_xarray: {}'.format(self.__str__))
+        else:
+            raise ValueError('contrack() is already set!')
+
+    # ---- set up (contrack.py:204-380) ----------------------------------------------------------------
+    def set_up(self, time_name=None, longitude_name=None, latitude_name=None, force=False, write=True):
+        self._time_name = self._get_name_time() if time_name is None else time_name
+        self._longitude_name = self._get_name_longitude() if longitude_name is None else longitude_name
+        self._latitude_name = self._get_name_latitude() if latitude_name is None else latitude_name
+        if (self._longitude_name and self._latitude_name) is not None:
+            self._dlon = self._get_resolution(self._longitude_name, force=force)
+            self._dlat = self._get_resolution(self._latitude_name, force=force)
+        if self._time_name is not None:
+            self._dtime = self._get_resolution(self._time_name, force=force)
+        if write:
+            self._log_dim_names()
+
+    def _log_dim_names(self):
+        logger.info("\n time: '{}'\n longitude: '{}'\n latitude: '{}'\n".format(
+            self._time_name, self._longitude_name, self._latitude_name))
+
+    def _units_of(self, dim):
+        out = []
+        da = self.ds[dim]
+        for holder in (getattr(da, "attrs", None), getattr(da, "encoding", None)):
+            if holder and 'units' in holder:
+                out.append(holder['units'])
+        return out
+
+    def _get_name_time(self):
+        for dim in self.ds.dims:
+            if any('since' in u for u in self._units_of(dim)) or dim in ['time']:
+                return dim
+        for name in self.ds.variables:
+            data = self.ds[name].data
+            try:
+                first = data[0]
+            except IndexError:
+                first = data
+            if isinstance(first, np.datetime64):
+                return name
+        logger.warning("\n 'time' dimension (dtype='datetime64[ns]') not found.")
+        return None
+
+    def _get_name_longitude(self):
+        for dim in self.ds.dims:
+            attrs = getattr(self.ds[dim], "attrs", {})
+            if attrs.get('units') in ['degree_east', 'degrees_east'] or dim in ['lon', 'longitude', 'x']:
+                return dim
+        logger.warning("\n 'longitude' dimension (unit='degrees_east') not found.")
+        return None
+
+    def _get_name_latitude(self):
+        for dim in self.ds.dims:
+            attrs = getattr(self.ds[dim], "attrs", {})
+            if attrs.get('units') in ['degree_north', 'degrees_north'] or dim in ['lat', 'latitude', 'y']:
+                return dim
+        logger.warning("\n 'latitude' dimension (unit='degrees_north') not found.")
+        return None
+
+    def _get_resolution(self, dim, force=False):
+        """grid spacing in degrees / time step in hours (contrack.py:327-380)"""
+        if dim == self._time_name:
+            try:
+                index = self.ds[dim].to_index()
+                delta = np.unique((index[1:] - index[:-1]).astype('timedelta64[h]'))
+            except AttributeError:
+                attrs = getattr(self.ds[dim], "attrs", {})
+                if 'units' in attrs and 'days' in attrs['units']:
+                    var = self.ds[dim].data
+                    delta = np.unique(var[1:] - var[:-1])
+                else:
+                    raise ValueError('Can not decode time with unit {}'.format(attrs['units']))
+        else:
+            data = self.ds[dim].data
+            delta = abs(np.unique(data[1:] - data[:-1]))
+        if len(delta) > 1:
+            errmsg = 'No regular grid found for dimension {}.\n\
+            Hint: use set_up(force=True).'.format(dim)
+            if force and dim != self._time_name:
+                logging.warning(errmsg)
+                logging.warning(' '.join(['force=True: using mean of non-equidistant', 'grid {}'.format(delta)]))
+                delta = round(delta.mean(), 2)
+            elif dim == self._time_name:
+                logging.warning(errmsg)
+            else:
+                raise ValueError(errmsg)
+        elif delta[0] == 0:
+            raise ValueError('Two equivalent values found for dimension {}.'.format(dim))
+        elif delta[0] < 0:
+            raise ValueError(' '.join(['{} not increasing. This should', 'not happen?!']).format(dim))
+        return delta
+
+    def _ensure_set_up(self):
+        logger.info("Set up dimensions...")
+        if hasattr(self, '_time_name'):
+            self._log_dim_names()
+        else:
+            self.set_up()
+
+    # ---- pre-processing glue (contrack.py:386-581); plain xarray, not accelerated ------------------------
+    def calculate_gph_from_gp(self, gp_name='z', gp_unit='m**2 s**-2', gph_name='z_height'):
+        g = 9.80665
+        if self.ds[gp_name].attrs['units'] != gp_unit:
+            raise ValueError('Geopotential unit should be {} not {}'.format(gp_unit, self.ds[gp_name].attrs['units']))
+        self.ds[gph_name] = (self.ds.variables[gp_name].dims, self.ds.variables[gp_name].data / g,
+                             {'units': 'm', 'long_name': 'Geopotential Height', 'standard_name': 'geopotential height',
+                              'history': 'Calculated from {} with g={}'.format(gp_name, g)})
+        logger.info('Calculating GPH from GP... DONE')
+
+    def calc_mean(self, variable):
+        if not variable:
+            return self['z'].mean(dim="time")
+        if variable not in self.variables:
+            logger.warning("\n Variable '{}' not found. Select from {}.".format(variable, self.variables))
+            return None
+        return self[variable].mean(dim="time")
+
+    def calc_clim(self, variable, window=1, groupby='dayofyear'):
+        clim = self[variable].groupby(self._time_name + '.' + groupby).mean(self._time_name)
+        return clim.rolling(**{groupby: window}, center=True).mean().fillna(clim[-window:].mean(dim=groupby))
+
+    def calc_anom(self, variable, window=1, smooth=1, groupby='dayofyear', clim=None):
+        self._ensure_set_up()
+        if clim is None:
+            logger.info('Calculating climatological mean from {}...'.format(variable))
+            clim_mean = self.calc_clim(variable=variable, window=window, groupby=groupby)
+            clim = 'from {} with running window time steps {}'.format(variable, window)
+        else:
+            logger.info('Reading climatological mean from {}...'.format(clim))
+            clim_mean = _xr().open_dataarray(clim) if isinstance(clim, str) else clim
+            if groupby not in clim_mean.dims:
+                clim_mean = clim_mean.groupby(self._time_name + '.' + groupby)
+            clim_mean = clim_mean.reindex(**{self._latitude_name: self.ds[self._latitude_name],
+                                             self._longitude_name: self.ds[self._longitude_name]}, method='nearest')
+        anom = (self.ds[variable].groupby(self._time_name + '.' + groupby) - clim_mean).rolling(time=smooth, center=True).mean()
+        self.ds['anom'] = _xr().Variable(
+            self.ds[variable].dims, anom,
+            attrs={'units': self.ds[variable].attrs['units'],
+                   'long_name': self.ds[variable].attrs['long_name'] + ' Anomaly',
+                   'standard_name': self.ds[variable].attrs['long_name'] + ' anomaly',
+                   'history': ' '.join(['Calculated from {} with input attributes:', 'smoothing time steps = {},',
+                                        'climatology = {}.']).format(variable, smooth, clim)})
+        logger.info('Calculating Anomaly... DONE')
+
+    # ---- the hot path (contrack.py:583-796) -----------------------------------------------------------------
+    def _dayofyear(self):
+        t = self.ds[self._time_name]
+        try:
+            return np.asarray(t.dt.dayofyear)
+        except AttributeError:
+            v = np.asarray(t.data).astype('datetime64[D]')
+            return (v - v.astype('datetime64[Y]')).astype(int) + 1
+
+    def _thresholds_per_step(self, threshold, T, dtype):
+        """scalar, or a 1-D DataArray over 'dayofyear' (contrack.py:648-661) -> per-timestep values"""
+        if hasattr(threshold, "dims") and hasattr(threshold, "data"):
+            values = np.asarray(threshold.data)
+            if 'dayofyear' in getattr(threshold, "dims", ()):
+                coord = None
+                try:
+                    coord = np.asarray(threshold['dayofyear'].data)
+                except Exception:
+                    pass
+                doy = self._dayofyear()
+                if coord is None:
+                    coord = np.arange(1, len(values) + 1)
+                pos = {int(d): i for i, d in enumerate(coord)}
+                values = np.array([values[pos[int(d)]] for d in doy], dtype=values.dtype)
+            return prepare_thresholds(values, T, dtype)
+        return prepare_thresholds(threshold, T, dtype)
+
+    def run_contrack(self, variable, threshold, gorl, overlap, persistence, twosided=True):
+        """Spatial and temporal tracking of closed contours; adds the integer variable 'flag' to the dataset.
+
+        variable: name of the input field; threshold: number or 1-D DataArray over 'dayofyear'; gorl: one of
+        [>, >=, <, <=, ge, le, gt, lt]; overlap: fraction [0-1] of area overlap between consecutive steps;
+        persistence: minimum life time in time steps; twosided: forward+backward overlap test (True) or forward
+        only."""
+        logger.info("\nRun ConTrack \n########### \n    threshold:    {} {} \n    overlap:      {} \n"
+                    "    persistence:  {} time steps".format(gorl, threshold, overlap, persistence))
+        self._ensure_set_up()
+        logger.info("Find individual contours...")
+        if gorl not in _native.CMP_OPS:
+            raise ValueError(_native.GORL_ERRMSG)
+        da = self.ds[variable]
+        dims = tuple(da.dims)
+        sort = [dims.index(d) for d in (self._time_name, self._latitude_name, self._longitude_name)]
+        slab = np.asarray(da.data).transpose(sort)
+        T = slab.shape[0]
+        thr = self._thresholds_per_step(threshold, T, slab.dtype)
+        lat = self.ds[self._latitude_name].data
+        wrow = row_weights(lat, self._dlat, self._dlon)
+        logger.info("Apply overlap...")
+        logger.info("Apply persistence...")
+        trk = _tracker()
+        if slab.dtype == np.float32:
+            flag, n_tracked = trk.track(np.ascontiguousarray(slab), thr, _native.CMP_OPS[gorl], wrow, overlap, persistence, twosided)
+        else:
+            flag, n_tracked = trk.track(np.ascontiguousarray(slab, dtype=np.float64), thr, _native.CMP_OPS[gorl], wrow, overlap,
+                                        persistence, twosided, f64=True)
+        logger.info("Create new variable 'flag'...")
+        inverse = np.argsort(sort)
+        attrs = {'units': 'flag', 'long_name': 'contrack flag', 'standard_name': 'contrack flag',
+                 'history': ' '.join(['Calculated from {} with input attributes:', 'threshold = {} {},', 'overlap fraction = {},',
+                                      'persistence time steps = {}.', 'twosided = {}']).format(
+                     variable, gorl, threshold, overlap, persistence, twosided),
+                 'reference': 'https://github.com/steidani/ConTrack'}
+        self.ds['flag'] = (dims, flag.transpose(inverse), attrs)
+        logger.info("Running contrack... DONE\n{} contours tracked".format(n_tracked))
+
+    # ---- utility (contrack.py:912-949) ---------------------------------------------------------------------------
+    def greatcircle_dist(self, lon1, lat1, lon2, lat2):
+        """great-circle distance in km between (lon1, lat1) and (lon2, lat2) given in degrees"""
+        a1, a2 = np.deg2rad(lat1), np.deg2rad(lat2)
+        c = np.sin(a1) * np.sin(a2) + np.cos(a1) * np.cos(a2) * np.cos(np.deg2rad(lon1 - lon2))
+        return 6371. * np.arccos(min(1., max(-1., c)))

@@ -2,6 +2,7 @@
 // (include/contrack_hip.h).  The kernels are in ctk_kernels.hip (same translation unit), the GPU-free
 // sequential resolver in ctk_resolve.cpp.
 #include "ctk_kernels.hip"
+#include "ctk_resolve_dev.hip"
 #include "../../include/contrack_hip.h"
 
 #include <chrono>
@@ -55,6 +56,13 @@ struct ctk_handle {
     DevBuf run_comp, run_val, cs_mrep, cs_box, cs_area, d_mrep, d_box, d_area, comp_label;
     DevBuf g_x0, g_x1, g_y, g_parent, g_root, g_idmap, g_rs;
     DevBuf pairs, seams, ext, ops, oi_hi, oi_idx, halo_in, halo_out, dbg;
+    DevBuf seam_cnt, seam_off, d_seams, d_comp_t;
+    // device resolver work space
+    DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lbox,
+        rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_scalars;
+    void *h_cand = nullptr;          // pinned: candidates + boxes download
+    size_t h_cand_cap = 0;
+    int use_device_resolve = 1;
     // host (pinned) buffers
     void *h_blob = nullptr;
     size_t h_blob_cap = 0, h_blob_bytes = 0;
@@ -187,10 +195,14 @@ extern "C" void ctk_destroy(ctk_handle *h)
     DevBuf *bufs[] = {&h->mask, &h->rowcnt, &h->rowstart, &h->tcount, &h->run_base, &h->ncomp, &h->cprefix, &h->thr32, &h->wlo, &h->whi,
                       &h->counters, &h->run_comp, &h->run_val, &h->cs_mrep, &h->cs_box, &h->cs_area, &h->d_mrep, &h->d_box, &h->d_area,
                       &h->comp_label, &h->g_x0, &h->g_x1, &h->g_y, &h->g_parent, &h->g_root, &h->g_idmap, &h->g_rs, &h->pairs, &h->seams,
-                      &h->ext, &h->ops, &h->oi_hi, &h->oi_idx, &h->halo_in, &h->halo_out, &h->dbg};
+                      &h->ext, &h->ops, &h->oi_hi, &h->oi_idx, &h->halo_in, &h->halo_out, &h->dbg, &h->seam_cnt, &h->seam_off, &h->d_seams,
+                      &h->d_comp_t, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
+                      &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
+                      &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_scalars};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
+    if (h->h_cand) (void)hipHostFree(h->h_cand);
     if (h->ev_ready) for (int k = 0; k <= CTK_K_COUNT; k++) { (void)hipEventDestroy(h->ev[k][0]); (void)hipEventDestroy(h->ev[k][1]); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -205,6 +217,13 @@ extern "C" int ctk_set_timing(ctk_handle *h, int enable)
         h->ev_ready = true;
     }
     h->timing = enable;
+    return CTK_OK;
+}
+
+extern "C" int ctk_set_device_resolve(ctk_handle *h, int enable)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    h->use_device_resolve = enable ? 1 : 0;
     return CTK_OK;
 }
 
@@ -230,8 +249,8 @@ extern "C" int ctk_get_timings(ctk_handle *h, double *ms)
 // ------------------------------------------------------------------------------------------------
 // stage 1
 // ------------------------------------------------------------------------------------------------
-extern "C" int ctk_shard_label2d(ctk_handle *h, const float *anom_dev, int64_t T, int ny, int nx, const double *thr,
-                                 int cmp_op, const float *wrow, int has_prev)
+static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t T, int ny, int nx, const double *thr,
+                              int cmp_op, const float *wrow, int has_prev)
 {
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
     if (T < 0 || ny < 1 || nx < 1 || (T > 0 && (!anom_dev || !thr)) || !wrow)
@@ -248,8 +267,9 @@ extern "C" int ctk_shard_label2d(ctk_handle *h, const float *anom_dev, int64_t T
     hipStream_t s = h->stream;
 
     // host-side preparation: thresholds for the float32 compare, exact integer limbs of the row weights
-    std::vector<float> thr32((size_t)std::max<int64_t>(T, 1));
-    for (int64_t t = 0; t < T; t++) thr32[(size_t)t] = adjust_threshold(thr[t], cmp_op);
+    std::vector<double> thr32((size_t)std::max<int64_t>(T, 1));     // float32 thresholds in the first half when !f64
+    if (f64) for (int64_t t = 0; t < T; t++) thr32[(size_t)t] = thr[t];
+    else for (int64_t t = 0; t < T; t++) ((float *)thr32.data())[t] = adjust_threshold(thr[t], cmp_op);
     std::vector<int32_t> wlo((size_t)ny), whi((size_t)ny);
     CTKCHK(ctk_weights_to_limbs(wrow, ny, wlo.data(), whi.data(), &h->wshift));
 
@@ -260,7 +280,7 @@ extern "C" int ctk_shard_label2d(ctk_handle *h, const float *anom_dev, int64_t T
     CTKCHK(ensure(h, h->run_base, (size_t)(T + 1) * 4));
     CTKCHK(ensure(h, h->ncomp, (size_t)T * 4));
     CTKCHK(ensure(h, h->cprefix, (size_t)(T + 1) * 4));
-    CTKCHK(ensure(h, h->thr32, (size_t)T * 4));
+    CTKCHK(ensure(h, h->thr32, (size_t)T * 8));
     CTKCHK(ensure(h, h->wlo, (size_t)ny * 4));
     CTKCHK(ensure(h, h->whi, (size_t)ny * 4));
     CTKCHK(ensure(h, h->counters, CTK_CNT_N * 4));
@@ -269,7 +289,7 @@ extern "C" int ctk_shard_label2d(ctk_handle *h, const float *anom_dev, int64_t T
     HIPCHK(hipMemsetAsync(h->counters.p, 0, CTK_CNT_N * 4, s));
     if (T > 0) {
         HIPCHK(hipMemsetAsync(h->tcount.p, 0, (size_t)T * 4, s));
-        HIPCHK(hipMemcpyAsync(h->thr32.p, thr32.data(), (size_t)T * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->thr32.p, thr32.data(), (size_t)T * (f64 ? 8 : 4), hipMemcpyHostToDevice, s));
     }
     HIPCHK(hipMemcpyAsync(h->wlo.p, wlo.data(), (size_t)ny * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->whi.p, whi.data(), (size_t)ny * 4, hipMemcpyHostToDevice, s));
@@ -278,7 +298,11 @@ extern "C" int ctk_shard_label2d(ctk_handle *h, const float *anom_dev, int64_t T
     if (T > 0) {
         Timer tm(h, CTK_K_THRESHOLD);
         const int g = grid_for_rows(nrows);
-#define LAUNCH_THR(OP) k_threshold<OP><<<g, 256, 0, s>>>(anom_dev, P<float>(h->thr32), nrows, ny, nx, W, P<uint64_t>(h->mask), P<uint16_t>(h->rowcnt), P<uint32_t>(h->tcount))
+#define LAUNCH_THR(OP)                                                                                                                      \
+    do {                                                                                                                                \
+        if (f64) k_threshold<OP, double><<<g, 256, 0, s>>>((const double *)anom_dev, P<double>(h->thr32), nrows, ny, nx, W, P<uint64_t>(h->mask), P<uint16_t>(h->rowcnt), P<uint32_t>(h->tcount)); \
+        else k_threshold<OP, float><<<g, 256, 0, s>>>((const float *)anom_dev, P<float>(h->thr32), nrows, ny, nx, W, P<uint64_t>(h->mask), P<uint16_t>(h->rowcnt), P<uint32_t>(h->tcount)); \
+    } while (0)
         switch (cmp_op) {
         case 0: LAUNCH_THR(0); break;
         case 1: LAUNCH_THR(1); break;
@@ -312,8 +336,12 @@ extern "C" int ctk_shard_label2d(ctk_handle *h, const float *anom_dev, int64_t T
     CTKCHK(ensure(h, h->d_mrep, R * 4));
     CTKCHK(ensure(h, h->d_box, R * 8));
     CTKCHK(ensure(h, h->d_area, R * 16));
-    h->seam_cap = (uint32_t)std::min<int64_t>(nrows, 0x7fffffff);
-    CTKCHK(ensure(h, h->seams, (size_t)h->seam_cap * sizeof(CtkSeam)));
+    if (nrows > 0x7fffffff) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: more than 2^31 rows in one shard");
+    h->seam_cap = (uint32_t)nrows;
+    CTKCHK(ensure(h, h->seams, (size_t)nrows * sizeof(CtkSeam)));
+    CTKCHK(ensure(h, h->seam_cnt, (size_t)T * 4));
+    CTKCHK(ensure(h, h->seam_off, (size_t)(T + 1) * 4));
+    CTKCHK(ensure(h, h->d_comp_t, R * 4));
     if (h->need_glb) {
         CTKCHK(ensure(h, h->g_x0, R * 2)); CTKCHK(ensure(h, h->g_x1, R * 2)); CTKCHK(ensure(h, h->g_y, R * 2));
         CTKCHK(ensure(h, h->g_parent, R * 4)); CTKCHK(ensure(h, h->g_root, R * 4)); CTKCHK(ensure(h, h->g_idmap, R * 4));
@@ -324,7 +352,7 @@ extern "C" int ctk_shard_label2d(ctk_handle *h, const float *anom_dev, int64_t T
         a.mask = P<uint64_t>(h->mask); a.rowcnt = P<uint16_t>(h->rowcnt); a.rowstart = P<uint32_t>(h->rowstart);
         a.run_base = P<uint32_t>(h->run_base); a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp);
         a.cs_mrep = P<uint32_t>(h->cs_mrep); a.cs_box = P<uint32_t>(h->cs_box); a.cs_area = P<int64_t>(h->cs_area);
-        a.seams = P<CtkSeam>(h->seams); a.counters = P<uint32_t>(h->counters); a.seam_cap = h->seam_cap;
+        a.seams = P<CtkSeam>(h->seams); a.seam_cnt = P<uint32_t>(h->seam_cnt); a.counters = P<uint32_t>(h->counters);
         a.wlo = P<int32_t>(h->wlo); a.whi = P<int32_t>(h->whi);
         a.ny = ny; a.nx = nx; a.W = W; a.lds_cap = CTK_LDS_RUNS;
         a.g_x0 = P<uint16_t>(h->g_x0); a.g_x1 = P<uint16_t>(h->g_x1); a.g_y = P<uint16_t>(h->g_y);
@@ -344,12 +372,23 @@ extern "C" int ctk_shard_label2d(ctk_handle *h, const float *anom_dev, int64_t T
         if (T > 0) {
             k_compact_comps<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), P<uint32_t>(h->cprefix), P<uint32_t>(h->cs_mrep),
                                                    P<uint32_t>(h->cs_box), P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box),
-                                                   P<int64_t>(h->d_area));
+                                                   P<int64_t>(h->d_area), P<uint32_t>(h->d_comp_t));
             HIPCHK(hipGetLastError());
         }
     }
     h->state = ST_LABELLED;
     return CTK_OK;
+}
+
+extern "C" int ctk_shard_label2d(ctk_handle *h, const float *anom_dev, int64_t T, int ny, int nx, const double *thr, int cmp_op,
+                                 const float *wrow, int has_prev)
+{
+    return shard_label2d_impl(h, anom_dev, false, T, ny, nx, thr, cmp_op, wrow, has_prev);
+}
+extern "C" int ctk_shard_label2d_f64(ctk_handle *h, const double *anom_dev, int64_t T, int ny, int nx, const double *thr, int cmp_op,
+                                     const float *wrow, int has_prev)
+{
+    return shard_label2d_impl(h, anom_dev, true, T, ny, nx, thr, cmp_op, wrow, has_prev);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -455,14 +494,18 @@ extern "C" int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes
     hipStream_t s = h->stream;
     const double t0 = now_ms();
     uint32_t *hc = (uint32_t *)h->h_small + (h->T + 2);                       // after the run_base copy
-    uint32_t cnt[CTK_CNT_N], ctot = 0;
+    uint32_t cnt[CTK_CNT_N], ctot = 0, stot = 0;
+    // seam rows: row-indexed scratch -> dense (t, y) order
+    k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->seam_cnt), h->T, P<uint32_t>(h->seam_off), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+    HIPCHK(hipGetLastError());
     for (int attempt = 0;; attempt++) {
         HIPCHK(hipMemcpyAsync(hc, h->counters.p, CTK_CNT_N * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(hc + CTK_CNT_N, P<uint32_t>(h->cprefix) + h->T, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hc + CTK_CNT_N + 1, P<uint32_t>(h->seam_off) + h->T, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         memcpy(cnt, hc, sizeof(cnt));
         ctot = hc[CTK_CNT_N];
-        if (cnt[CTK_CNT_OVERFLOW] & CTK_OVF_SEAMS) return ctk_set_error(CTK_E_INTERNAL, "seam table overflow");
+        stot = hc[CTK_CNT_N + 1];
         if (!(cnt[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS)) break;
         if (attempt >= 6) return ctk_set_error(CTK_E_RANGE, "pair table keeps overflowing");
         // grow the pair table to what was asked for and redo the histogram
@@ -478,7 +521,12 @@ extern "C" int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes
         CTKCHK(launch_overlap(h));
     }
     h->total_comps = ctot;
-    const int64_t T = h->T, NC = ctot, NP = cnt[CTK_CNT_PAIRS], NS = cnt[CTK_CNT_SEAMS];
+    const int64_t T = h->T, NC = ctot, NP = cnt[CTK_CNT_PAIRS], NS = stot;
+    if (NS) {
+        CTKCHK(ensure(h, h->d_seams, (size_t)NS * sizeof(CtkSeam)));
+        k_compact_seams<<<(int)T, 256, 0, s>>>(P<CtkSeam>(h->seams), P<uint32_t>(h->seam_cnt), P<uint32_t>(h->seam_off), h->ny, P<CtkSeam>(h->d_seams));
+        HIPCHK(hipGetLastError());
+    }
     const size_t bytes = ctk_blob_bytes(T, NC, NP, NS);
     CTKCHK(ensure_host(&h->h_blob, &h->h_blob_cap, bytes));
     char *p = (char *)h->h_blob;
@@ -496,7 +544,7 @@ extern "C" int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes
     p += (size_t)NC * 16;
     if (NP) HIPCHK(hipMemcpyAsync(p, h->pairs.p, (size_t)NP * sizeof(CtkPair), hipMemcpyDeviceToHost, s));
     p += (size_t)NP * sizeof(CtkPair);
-    if (NS) HIPCHK(hipMemcpyAsync(p, h->seams.p, (size_t)NS * sizeof(CtkSeam), hipMemcpyDeviceToHost, s));
+    if (NS) HIPCHK(hipMemcpyAsync(p, h->d_seams.p, (size_t)NS * sizeof(CtkSeam), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     h->h_blob_bytes = bytes;
     *blob = h->h_blob;
@@ -516,6 +564,45 @@ static FoldArgs fold_args(const ctk_handle *h)
     return f;
 }
 
+static int upload_ops(ctk_handle *h, const CtkOp *ops, int64_t nops)
+{
+    hipStream_t s = h->stream;
+    h->nops = (int32_t)nops;
+    if (!nops) return CTK_OK;
+    std::vector<int32_t> order((size_t)nops), oi_hi((size_t)nops);
+    for (int32_t i = 0; i < (int32_t)nops; i++) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return ops[a].hi < ops[b].hi; });
+    for (size_t i = 0; i < order.size(); i++) oi_hi[i] = ops[order[i]].hi;
+    CTKCHK(ensure(h, h->ops, (size_t)nops * sizeof(CtkOp)));
+    CTKCHK(ensure(h, h->oi_hi, (size_t)nops * 4));
+    CTKCHK(ensure(h, h->oi_idx, (size_t)nops * 4));
+    HIPCHK(hipMemcpyAsync(h->ops.p, ops, (size_t)nops * sizeof(CtkOp), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->oi_hi.p, oi_hi.data(), (size_t)nops * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->oi_idx.p, order.data(), (size_t)nops * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));                                         // staging vectors go out of scope
+    return CTK_OK;
+}
+
+static int launch_extents(ctk_handle *h)
+{
+    hipStream_t s = h->stream;
+    CTKCHK(ensure(h, h->ext, (size_t)(h->n_labels + 1) * 8));
+    Timer tm(h, CTK_K_EXTENT);
+    const int64_t n1 = h->n_labels + 1;
+    k_fill_ext<<<(int)((n1 + 255) / 256), 256, 0, s>>>(P<int32_t>(h->ext), h->n_labels);
+    HIPCHK(hipGetLastError());
+    if (h->T > 0) {
+        ExtentArgs a;
+        a.mask = P<uint64_t>(h->mask); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
+        a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp); a.cprefix = P<uint32_t>(h->cprefix);
+        a.comp_label = P<int32_t>(h->comp_label); a.ext = P<int32_t>(h->ext); a.n_labels = h->n_labels; a.t_begin = h->t_begin;
+        a.fold = fold_args(h); a.ny = h->ny; a.nx = h->nx; a.W = h->W;
+        k_extent<<<(int)h->T, 256, 0, s>>>(a);
+        HIPCHK(hipGetLastError());
+    }
+    return CTK_OK;
+}
+
 extern "C" int ctk_shard_extents(ctk_handle *h, const ctk_result *r, int shard, int64_t t_begin, int32_t **ext_dev, int64_t *n_labels)
 {
     if (!h || !r) return ctk_set_error(CTK_E_INVALID, "null argument");
@@ -527,44 +614,154 @@ extern "C" int ctk_shard_extents(ctk_handle *h, const ctk_result *r, int shard, 
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     const double t0 = now_ms();
-    h->n_labels = r->n_labels; h->t_begin = t_begin; h->nops = (int32_t)r->nops;
+    h->n_labels = r->n_labels; h->t_begin = t_begin;
     CTKCHK(ensure(h, h->comp_label, (size_t)(c1 - c0) * 4));
     if (c1 > c0) HIPCHK(hipMemcpyAsync(h->comp_label.p, r->comp_label + c0, (size_t)(c1 - c0) * 4, hipMemcpyHostToDevice, s));
-    std::vector<int32_t> oi_hi, oi_idx;
-    if (r->nops) {
-        std::vector<int32_t> order((size_t)r->nops);
-        for (int32_t i = 0; i < (int32_t)r->nops; i++) order[(size_t)i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return r->ops[a].hi < r->ops[b].hi; });
-        oi_hi.resize((size_t)r->nops); oi_idx.resize((size_t)r->nops);
-        for (size_t i = 0; i < order.size(); i++) { oi_hi[i] = r->ops[order[i]].hi; oi_idx[i] = order[i]; }
-        CTKCHK(ensure(h, h->ops, (size_t)r->nops * sizeof(CtkOp)));
-        CTKCHK(ensure(h, h->oi_hi, (size_t)r->nops * 4));
-        CTKCHK(ensure(h, h->oi_idx, (size_t)r->nops * 4));
-        HIPCHK(hipMemcpyAsync(h->ops.p, r->ops, (size_t)r->nops * sizeof(CtkOp), hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(h->oi_hi.p, oi_hi.data(), (size_t)r->nops * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(h->oi_idx.p, oi_idx.data(), (size_t)r->nops * 4, hipMemcpyHostToDevice, s));
-    }
-    CTKCHK(ensure(h, h->ext, (size_t)(r->n_labels + 1) * 8));
-    HIPCHK(hipStreamSynchronize(s));                                         // staging vectors go out of scope
+    CTKCHK(upload_ops(h, r->ops, r->nops));
+    HIPCHK(hipStreamSynchronize(s));
     h->ms[CTK_T_H2D] += now_ms() - t0;
-    {
-        Timer tm(h, CTK_K_EXTENT);
-        const int64_t n1 = r->n_labels + 1;
-        k_fill_ext<<<(int)((n1 + 255) / 256), 256, 0, s>>>(P<int32_t>(h->ext), r->n_labels);
-        HIPCHK(hipGetLastError());
-        if (h->T > 0) {
-            ExtentArgs a;
-            a.mask = P<uint64_t>(h->mask); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
-            a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp); a.cprefix = P<uint32_t>(h->cprefix);
-            a.comp_label = P<int32_t>(h->comp_label); a.ext = P<int32_t>(h->ext); a.n_labels = r->n_labels; a.t_begin = t_begin;
-            a.fold = fold_args(h); a.ny = h->ny; a.nx = h->nx; a.W = h->W;
-            k_extent<<<(int)h->T, 256, 0, s>>>(a);
-            HIPCHK(hipGetLastError());
-        }
-    }
+    CTKCHK(launch_extents(h));
     if (ext_dev) *ext_dev = P<int32_t>(h->ext);
     if (n_labels) *n_labels = r->n_labels;
     h->state = ST_EXTENTS;
+    return CTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device resolver (single shard): R1..R5 of ctk_resolve_dev.hip + the host seam driver
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// contrack.py:753-763 on {t, y, label at x=0, label at x=nx-1} records in (t, y) order and the boxes of the
+// fresh labels.  Flat arrays: per label the chain of ops that have it as `hi`, in execution order.
+void seam_driver(const CtkCand *cand, int64_t ncand, const int32_t *lbox, int64_t nlab, int nx, std::vector<CtkOp> &ops)
+{
+    std::vector<int32_t> first((size_t)nlab + 1, -1), last((size_t)nlab + 1, -1), next;
+    auto fold = [&](int32_t l, int32_t t, int32_t y, int32_t x) {
+        int32_t s = 0;
+        for (;;) {
+            bool moved = false;
+            for (int32_t idx = first[(size_t)l]; idx >= 0; idx = next[(size_t)idx]) {
+                if (idx < s) continue;
+                const CtkOp &o = ops[(size_t)idx];
+                if (t >= o.t0 && t <= o.t1 && y >= o.y0 && y <= o.y1 && x >= o.x0 && x <= o.x1) { l = o.lo; s = idx + 1; moved = true; break; }
+            }
+            if (!moved) return l;
+        }
+    };
+    for (int64_t k = 0; k < ncand; k++) {
+        const CtkCand &c = cand[k];
+        if (c.ll == c.lr && first[(size_t)c.ll] < 0) continue;             // same label, never relabelled: nothing can differ
+        const int32_t p0 = first[(size_t)c.ll] < 0 ? c.ll : fold(c.ll, c.t, c.y, 0);
+        const int32_t p1 = first[(size_t)c.lr] < 0 ? c.lr : fold(c.lr, c.t, c.y, nx - 1);
+        if (p0 == p1) continue;
+        const int32_t hi = std::max(p0, p1), lo = std::min(p0, p1);
+        const int32_t *b = lbox + 6 * (int64_t)hi;
+        const int32_t idx = (int32_t)ops.size();
+        ops.push_back(CtkOp{hi, lo, b[0], b[1], b[2], b[3], b[4], b[5]});
+        next.push_back(-1);
+        if (last[(size_t)hi] >= 0) next[(size_t)last[(size_t)hi]] = idx; else first[(size_t)hi] = idx;
+        last[(size_t)hi] = idx;
+    }
+}
+
+}  // namespace
+
+// returns CTK_OK, a negative error, or +1 = "take the host path" (pair table overflow / filter not converged)
+static int device_resolve(ctk_handle *h, double overlap, int twosided)
+{
+    hipStream_t s = h->stream;
+    const size_t R = h->total_runs ? h->total_runs : 1;
+    const size_t PC = h->pair_cap ? h->pair_cap : 1;
+    const int64_t T = h->T;
+    CTKCHK(ensure(h, h->rv_prc, PC * 4)); CTKCHK(ensure(h, h->rv_prd, PC * 4));
+    CTKCHK(ensure(h, h->rv_pgc, PC * 4)); CTKCHK(ensure(h, h->rv_pgd, PC * 4));
+    CTKCHK(ensure(h, h->rv_F, R * 16)); CTKCHK(ensure(h, h->rv_B, R * 16));
+    CTKCHK(ensure(h, h->rv_keep0, R)); CTKCHK(ensure(h, h->rv_keep1, R));
+    CTKCHK(ensure(h, h->rv_changed, (CTK_MAX_JACOBI + 8) * 4));
+    CTKCHK(ensure(h, h->rv_parent, R * 4)); CTKCHK(ensure(h, h->rv_isroot, R * 4)); CTKCHK(ensure(h, h->rv_rank, (R + 1) * 4));
+    CTKCHK(ensure(h, h->rv_lab, R * 4)); CTKCHK(ensure(h, h->rv_lbox, (R + 1) * 24));
+    const int nsb = (int)((R + CTK_SCAN_ITEMS - 1) / CTK_SCAN_ITEMS);
+    CTKCHK(ensure(h, h->rv_bsum, (size_t)nsb * 4)); CTKCHK(ensure(h, h->rv_boff, (size_t)(nsb + 1) * 4));
+    CTKCHK(ensure(h, h->rv_cand_cnt, (size_t)T * 4)); CTKCHK(ensure(h, h->rv_cand_off, (size_t)(T + 1) * 4));
+    CTKCHK(ensure(h, h->rv_cand, (size_t)std::max<int64_t>(T * h->ny, 1) * sizeof(CtkCand)));
+    CTKCHK(ensure(h, h->rv_scalars, 64));
+    CTKCHK(ensure(h, h->comp_label, R * 4));
+
+    ResolveDev r;
+    r.ncomp = P<uint32_t>(h->ncomp); r.cprefix = P<uint32_t>(h->cprefix); r.mrep = P<uint32_t>(h->d_mrep); r.comp_t = P<uint32_t>(h->d_comp_t);
+    r.box = P<uint16_t>(h->d_box); r.A = P<int64_t>(h->d_area); r.pairs = P<CtkPair>(h->pairs); r.counters = P<uint32_t>(h->counters);
+    r.pair_cap = h->pair_cap; r.T = T; r.wshift = h->wshift; r.overlap = overlap; r.twosided = twosided;
+    r.p_rc = P<uint32_t>(h->rv_prc); r.p_rd = P<uint32_t>(h->rv_prd); r.p_gc = P<uint32_t>(h->rv_pgc); r.p_gd = P<uint32_t>(h->rv_pgd);
+    r.F = P<int64_t>(h->rv_F); r.B = P<int64_t>(h->rv_B); r.keep0 = P<uint8_t>(h->rv_keep0); r.keep1 = P<uint8_t>(h->rv_keep1);
+    r.changed = P<uint32_t>(h->rv_changed); r.parent = P<uint32_t>(h->rv_parent); r.isroot = P<uint32_t>(h->rv_isroot);
+    r.rank = P<uint32_t>(h->rv_rank); r.lab = P<int32_t>(h->rv_lab); r.lbox = P<int32_t>(h->rv_lbox);
+
+    const int gc = (int)std::min<size_t>((R + 255) / 256, 2048), gp = (int)std::min<size_t>((PC + 255) / 256, 2048);
+    {
+        Timer tm(h, CTK_K_RESOLVE);
+        k_rs_init<<<gc, 256, 0, s>>>(r);
+        k_rs_pairs<<<gp, 256, 0, s>>>(r);
+        for (int it = 0; it < CTK_MAX_JACOBI; it++) {
+            k_rs_bwd<<<gp, 256, 0, s>>>(r, it);
+            k_rs_decide<<<gc, 256, 0, s>>>(r, it);
+        }
+        k_rs_unite<<<gp, 256, 0, s>>>(r);
+        k_rs_roots<<<gc, 256, 0, s>>>(r);
+        const uint32_t *ncp = P<uint32_t>(h->cprefix) + T;
+        k_scan_blocksum<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_bsum));
+        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_bsum), nsb, P<uint32_t>(h->rv_boff), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+        k_scan_apply<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_boff), r.rank);
+        k_rs_labels<<<gc, 256, 0, s>>>(r);
+        k_rs_boxes<<<gc, 256, 0, s>>>(r, 0);
+        if (T > 0) {
+            k_rs_cand_count<<<(int)T, 256, 0, s>>>(r, P<CtkSeam>(h->seams), P<uint32_t>(h->seam_cnt), h->ny, P<uint32_t>(h->rv_cand_cnt));
+        }
+        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_cand_cnt), T, P<uint32_t>(h->rv_cand_off), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+        if (T > 0) {
+            k_rs_cand_write<<<(int)T, 256, 0, s>>>(r, P<CtkSeam>(h->seams), P<uint32_t>(h->seam_cnt), h->ny, P<uint32_t>(h->rv_cand_off), 0,
+                                                   P<CtkCand>(h->rv_cand));
+        }
+        HIPCHK(hipGetLastError());
+    }
+    // scalars: number of components / labels / candidates, convergence, overflow
+    const double t0 = now_ms();
+    uint32_t *hs = (uint32_t *)h->h_small + (h->T + 2);
+    HIPCHK(hipMemcpyAsync(hs, h->counters.p, CTK_CNT_N * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N, P<uint32_t>(h->cprefix) + T, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 1, P<uint32_t>(h->rv_cand_off) + T, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 2, P<uint32_t>(h->rv_changed) + (CTK_MAX_JACOBI - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 3, P<uint32_t>(h->rv_boff) + nsb, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (hs[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) return 1;                       // the host path regrows the pair table
+    if (hs[CTK_CNT_N + 2] != 0) return 1;                                     // cascade longer than CTK_MAX_JACOBI passes
+    const int64_t NC = hs[CTK_CNT_N], ncand = hs[CTK_CNT_N + 1], nlab = hs[CTK_CNT_N + 3];
+    h->total_comps = (uint32_t)NC;
+    h->n_labels = nlab; h->t_begin = 0;
+    std::vector<CtkOp> ops;
+    if (ncand) {
+        const size_t need = (size_t)ncand * sizeof(CtkCand) + (size_t)(nlab + 1) * 24;
+        CTKCHK(ensure_host(&h->h_cand, &h->h_cand_cap, need));
+        CtkCand *hc = (CtkCand *)h->h_cand;
+        int32_t *hb = (int32_t *)((char *)h->h_cand + (size_t)ncand * sizeof(CtkCand));
+        HIPCHK(hipMemcpyAsync(hc, h->rv_cand.p, (size_t)ncand * sizeof(CtkCand), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hb, h->rv_lbox.p, (size_t)(nlab + 1) * 24, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        h->ms[CTK_T_D2H] += now_ms() - t0;
+        const double t1 = now_ms();
+        seam_driver(hc, ncand, hb, nlab, h->nx, ops);
+        h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t1;
+    } else {
+        h->ms[CTK_T_D2H] += now_ms() - t0;
+    }
+    const double t2 = now_ms();
+    CTKCHK(upload_ops(h, ops.data(), (int64_t)ops.size()));
+    h->ms[CTK_T_H2D] += now_ms() - t2;
+    {
+        Timer tm(h, CTK_K_RESOLVE2);
+        k_rs_final<<<gc, 256, 0, s>>>(r, fold_args(h), 0, P<int32_t>(h->comp_label));
+        HIPCHK(hipGetLastError());
+    }
     return CTK_OK;
 }
 
@@ -628,23 +825,31 @@ extern "C" int ctk_shard_count_tracked(ctk_handle *h, int64_t *n_alive)
 // ------------------------------------------------------------------------------------------------
 // whole path, one GPU
 // ------------------------------------------------------------------------------------------------
-extern "C" int ctk_track_f32_dev(ctk_handle *h, const float *anom_dev, int64_t T, int ny, int nx, const double *thr, int cmp_op,
-                                 const float *wrow, double overlap, int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked)
+static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t T, int ny, int nx, const double *thr, int cmp_op,
+                          const float *wrow, double overlap, int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked)
 {
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
     const double t0 = now_ms();
-    CTKCHK(ctk_shard_label2d(h, anom_dev, T, ny, nx, thr, cmp_op, wrow, 0));
+    CTKCHK(shard_label2d_impl(h, anom_dev, f64, T, ny, nx, thr, cmp_op, wrow, 0));
     CTKCHK(ctk_shard_overlap(h));
-    const void *blob = nullptr;
-    size_t nbytes = 0;
-    CTKCHK(ctk_shard_tables(h, &blob, &nbytes));
-    const double t1 = now_ms();
-    ctk_result *res = nullptr;
-    CTKCHK(ctk_resolve(&blob, &nbytes, 1, overlap, twosided, &res));
-    h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t1;
-    int rc = ctk_shard_extents(h, res, 0, 0, nullptr, nullptr);
-    ctk_result_free(res);
-    CTKCHK(rc);
+    int rv = h->use_device_resolve ? device_resolve(h, overlap, twosided) : 1;
+    if (rv < 0) return rv;
+    if (rv == 0) {
+        CTKCHK(launch_extents(h));
+        h->state = ST_EXTENTS;
+    } else {
+        // host path: download the tables, resolve with the GPU-free reference implementation, upload
+        const void *blob = nullptr;
+        size_t nbytes = 0;
+        CTKCHK(ctk_shard_tables(h, &blob, &nbytes));
+        const double t1 = now_ms();
+        ctk_result *res = nullptr;
+        CTKCHK(ctk_resolve(&blob, &nbytes, 1, overlap, twosided, &res));
+        h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t1;
+        int rc = ctk_shard_extents(h, res, 0, 0, nullptr, nullptr);
+        ctk_result_free(res);
+        CTKCHK(rc);
+    }
     int64_t alive = 0;
     int wrote0 = 0;
     CTKCHK(ctk_shard_write(h, persistence, flag_dev, &alive, &wrote0));
@@ -653,24 +858,24 @@ extern "C" int ctk_track_f32_dev(ctk_handle *h, const float *anom_dev, int64_t T
     return CTK_OK;
 }
 
-extern "C" int ctk_track_f32(ctk_handle *h, const float *anom, int64_t T, int ny, int nx, const double *thr, int cmp_op, const float *wrow,
-                             double overlap, int persistence, int twosided, int32_t *flag, int64_t *n_tracked)
+static int track_host_impl(ctk_handle *h, const void *anom, bool f64, int64_t T, int ny, int nx, const double *thr, int cmp_op, const float *wrow,
+                           double overlap, int persistence, int twosided, int32_t *flag, int64_t *n_tracked)
 {
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
-    if (T < 0 || ny < 1 || nx < 1 || (T > 0 && (!anom || !flag))) return ctk_set_error(CTK_E_INVALID, "ctk_track_f32: bad shape or null pointer");
+    if (T < 0 || ny < 1 || nx < 1 || (T > 0 && (!anom || !flag))) return ctk_set_error(CTK_E_INVALID, "ctk_track: bad shape or null pointer");
     HIPCHK(hipSetDevice(h->device));
-    const size_t n = (size_t)T * ny * nx;
-    float *a_dev = nullptr;
+    const size_t n = (size_t)T * ny * nx, esz = f64 ? 8 : 4;
+    void *a_dev = nullptr;
     int32_t *f_dev = nullptr;
     if (n) {
-        hipError_t e = hipMalloc((void **)&a_dev, n * 4);
-        if (e != hipSuccess) return ctk_set_error(CTK_E_NOMEM, "hipMalloc(%zu) for the input slab failed: %s", n * 4, hipGetErrorString(e));
+        hipError_t e = hipMalloc(&a_dev, n * esz);
+        if (e != hipSuccess) return ctk_set_error(CTK_E_NOMEM, "hipMalloc(%zu) for the input slab failed: %s", n * esz, hipGetErrorString(e));
         e = hipMalloc((void **)&f_dev, n * 4);
         if (e != hipSuccess) { (void)hipFree(a_dev); return ctk_set_error(CTK_E_NOMEM, "hipMalloc(%zu) for the flag slab failed: %s", n * 4, hipGetErrorString(e)); }
-        e = hipMemcpy(a_dev, anom, n * 4, hipMemcpyHostToDevice);
+        e = hipMemcpy(a_dev, anom, n * esz, hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(a_dev); (void)hipFree(f_dev); return ctk_set_error(CTK_E_NODEVICE, "H2D copy failed: %s", hipGetErrorString(e)); }
     }
-    int rc = ctk_track_f32_dev(h, a_dev, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, f_dev, n_tracked);
+    int rc = track_dev_impl(h, a_dev, f64, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, f_dev, n_tracked);
     if (rc == CTK_OK && n) {
         hipError_t e = hipMemcpy(flag, f_dev, n * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = ctk_set_error(CTK_E_NODEVICE, "D2H copy failed: %s", hipGetErrorString(e));
@@ -678,6 +883,27 @@ extern "C" int ctk_track_f32(ctk_handle *h, const float *anom, int64_t T, int ny
     if (a_dev) (void)hipFree(a_dev);
     if (f_dev) (void)hipFree(f_dev);
     return rc;
+}
+
+extern "C" int ctk_track_f32_dev(ctk_handle *h, const float *anom_dev, int64_t T, int ny, int nx, const double *thr, int cmp_op,
+                                 const float *wrow, double overlap, int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked)
+{
+    return track_dev_impl(h, anom_dev, false, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev, n_tracked);
+}
+extern "C" int ctk_track_f64_dev(ctk_handle *h, const double *anom_dev, int64_t T, int ny, int nx, const double *thr, int cmp_op,
+                                 const float *wrow, double overlap, int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked)
+{
+    return track_dev_impl(h, anom_dev, true, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev, n_tracked);
+}
+extern "C" int ctk_track_f32(ctk_handle *h, const float *anom, int64_t T, int ny, int nx, const double *thr, int cmp_op, const float *wrow,
+                             double overlap, int persistence, int twosided, int32_t *flag, int64_t *n_tracked)
+{
+    return track_host_impl(h, anom, false, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag, n_tracked);
+}
+extern "C" int ctk_track_f64(ctk_handle *h, const double *anom, int64_t T, int ny, int nx, const double *thr, int cmp_op, const float *wrow,
+                             double overlap, int persistence, int twosided, int32_t *flag, int64_t *n_tracked)
+{
+    return track_host_impl(h, anom, true, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag, n_tracked);
 }
 
 // ------------------------------------------------------------------------------------------------

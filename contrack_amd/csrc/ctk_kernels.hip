@@ -107,8 +107,8 @@ __device__ __forceinline__ void uf_unite(uint32_t *p, uint32_t a, uint32_t b)
 // thr32[t] is the float32 threshold the host derived so that the float32 compare equals the
 // reference's compare (see ctk_api: adjust_threshold).
 // ------------------------------------------------------------------------------------------------
-template <int OP>
-__device__ __forceinline__ bool cmp_op(float v, float th)
+template <int OP, typename TIN>
+__device__ __forceinline__ bool cmp_op(TIN v, TIN th)
 {
     if (OP == 0) return v >= th;
     if (OP == 1) return v <= th;
@@ -116,8 +116,8 @@ __device__ __forceinline__ bool cmp_op(float v, float th)
     return v < th;
 }
 
-template <int OP>
-__global__ __launch_bounds__(256) void k_threshold(const float *__restrict__ anom, const float *__restrict__ thr32,
+template <int OP, typename TIN>
+__global__ __launch_bounds__(256) void k_threshold(const TIN *__restrict__ anom, const TIN *__restrict__ thr32,
                                                    int64_t nrows, int ny, int nx, int W,
                                                    uint64_t *__restrict__ mask, uint16_t *__restrict__ rowcnt,
                                                    uint32_t *__restrict__ tcount)
@@ -127,8 +127,9 @@ __global__ __launch_bounds__(256) void k_threshold(const float *__restrict__ ano
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     for (int64_t row = wave; row < nrows; row += nwaves) {
         const int64_t t = row / ny;
-        const float th = thr32[t];
-        const float *src = anom + row * (int64_t)nx;
+        const TIN th = thr32[t];
+        const TIN *src = anom + row * (int64_t)nx;
+        const TIN qnan = (TIN)__builtin_nanf("");
         uint64_t carry = 0;          // last pixel of the previous word
         uint32_t nruns = 0;
         for (int w0 = 0; w0 < W; w0 += WAVE) {
@@ -136,22 +137,22 @@ __global__ __launch_bounds__(256) void k_threshold(const float *__restrict__ ano
             uint64_t mine = 0;
             int k = 0;
             for (; k + 8 <= wn; k += 8) {                     // 8 independent loads in flight per lane
-                float v[8];
+                TIN v[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     int x = (w0 + k + j) * 64 + lane;
-                    v[j] = (x < nx) ? src[x] : __builtin_nanf("");
+                    v[j] = (x < nx) ? src[x] : qnan;
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    uint64_t b = __ballot(cmp_op<OP>(v[j], th));
+                    uint64_t b = __ballot(cmp_op<OP, TIN>(v[j], th));
                     if (lane == k + j) mine = b;
                 }
             }
             for (; k < wn; k++) {
                 int x = (w0 + k) * 64 + lane;
-                float v = (x < nx) ? src[x] : __builtin_nanf("");
-                uint64_t b = __ballot(cmp_op<OP>(v, th));
+                TIN v = (x < nx) ? src[x] : qnan;
+                uint64_t b = __ballot(cmp_op<OP, TIN>(v, th));
                 if (lane == k) mine = b;
             }
             uint64_t prev = shfl_up_u64(mine, 1);
@@ -231,9 +232,9 @@ struct Label2dArgs {
     uint32_t *cs_mrep;
     uint32_t *cs_box;              // 4 x uint32 per slot: y0, y1, x0, x1
     int64_t *cs_area;              // 2 per slot
-    CtkSeam *seams;
+    CtkSeam *seams;                // row-indexed scratch [T][ny]
+    uint32_t *seam_cnt;            // [T]
     uint32_t *counters;            // CTK_CNT_*
-    uint32_t seam_cap;
     const int32_t *wlo, *whi;      // [ny] weight limbs
     int ny, nx, W;
     uint32_t lds_cap;              // runs the LDS variant carries
@@ -376,8 +377,9 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
         a.run_comp[rbase + r] = c;
         const int y = yrow[r];
         const int64_t len = (int64_t)x1[r] - (int64_t)x0[r] + 1;
-        atomicAdd((unsigned long long *)&carea[c * 2], (unsigned long long)(len * (int64_t)a.wlo[y]));
-        atomicAdd((unsigned long long *)&carea[c * 2 + 1], (unsigned long long)(len * (int64_t)a.whi[y]));
+        const uint32_t cm = idmap[parent[r]];              // seam-merged component: its area is what contrack.py:717 sums
+        atomicAdd((unsigned long long *)&carea[cm * 2], (unsigned long long)(len * (int64_t)a.wlo[y]));
+        atomicAdd((unsigned long long *)&carea[cm * 2 + 1], (unsigned long long)(len * (int64_t)a.whi[y]));
         atomicMin(&cbox[c * 4 + 0], (uint32_t)y);
         atomicMax(&cbox[c * 4 + 1], (uint32_t)y);
         atomicMin(&cbox[c * 4 + 2], (uint32_t)x0[r]);
@@ -385,8 +387,11 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
         if (rt == r) cmrep[c] = idmap[parent[r]];          // merged root is itself a no-wrap root (smallest run)
     }
     // seam rows: both seam pixels set (also when they are one run / one component: chain events can still
-    // split them)
+    // split them).  Written in y order into the timestep's slice of a row-indexed
+    // scratch (at most ny records per timestep).
     {
+        uint32_t carry = 0;
+        CtkSeam *out = a.seams + (int64_t)t * ny;
         for (int y0 = 0; y0 < ny; y0 += THREADS) {
             int y = y0 + tid;
             uint32_t f = 0, l = 0, v = 0;
@@ -396,19 +401,14 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
             }
             uint32_t tot;
             uint32_t ex = block_excl_scan(v, sm_scan, &tot);
-            __shared__ uint32_t seam_base;
-            if (tid == 0 && tot) seam_base = atomicAdd(&a.counters[CTK_CNT_SEAMS], tot);
-            __syncthreads();
             if (v) {
-                uint32_t i = seam_base + ex;
-                if (i < a.seam_cap) {
-                    CtkSeam q;
-                    q.t = (uint32_t)t; q.y = (uint32_t)y; q.cl = idmap[root[f]]; q.cr = idmap[root[l]];
-                    a.seams[i] = q;
-                } else atomicOr(&a.counters[CTK_CNT_OVERFLOW], CTK_OVF_SEAMS);
+                CtkSeam q;
+                q.t = (uint32_t)t; q.y = (uint32_t)y; q.cl = idmap[root[f]]; q.cr = idmap[root[l]];
+                out[carry + ex] = q;
             }
-            __syncthreads();
+            carry += tot;
         }
+        if (tid == 0) a.seam_cnt[t] = carry;
     }
 }
 
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void k_label2d_lds(Label2dArgs a)
     const uint32_t nruns = a.run_base[t + 1] - a.run_base[t];
     if (nruns > CTK_LDS_RUNS || a.ny > CTK_LDS_NY) return;        // k_label2d_glb takes it
     if (nruns == 0) {
-        if (threadIdx.x == 0) a.ncomp[t] = 0;
+        if (threadIdx.x == 0) { a.ncomp[t] = 0; a.seam_cnt[t] = 0; }
         for (int y = (int)threadIdx.x; y < a.ny; y += 256) a.rowstart[(int64_t)t * a.ny + y] = 0;
         return;
     }
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void k_compact_comps(const uint32_t *__restric
                                                        const uint32_t *__restrict__ cprefix, const uint32_t *__restrict__ cs_mrep,
                                                        const uint32_t *__restrict__ cs_box, const int64_t *__restrict__ cs_area,
                                                        uint32_t *__restrict__ d_mrep, uint16_t *__restrict__ d_box,
-                                                       int64_t *__restrict__ d_area)
+                                                       int64_t *__restrict__ d_area, uint32_t *__restrict__ d_comp_t)
 {
     const int t = (int)blockIdx.x;
     const uint32_t n = ncomp[t], rb = run_base[t], cb = cprefix[t];
@@ -459,7 +459,17 @@ __global__ __launch_bounds__(256) void k_compact_comps(const uint32_t *__restric
         for (int k = 0; k < 4; k++) d_box[(int64_t)(cb + c) * 4 + k] = (uint16_t)cs_box[(int64_t)(rb + c) * 4 + k];
         d_area[(int64_t)(cb + c) * 2] = cs_area[(int64_t)(rb + c) * 2];
         d_area[(int64_t)(cb + c) * 2 + 1] = cs_area[(int64_t)(rb + c) * 2 + 1];
+        d_comp_t[cb + c] = (uint32_t)t;
     }
+}
+
+// dense (t, y)-ordered seam records from the row-indexed scratch
+__global__ __launch_bounds__(256) void k_compact_seams(const CtkSeam *__restrict__ scratch, const uint32_t *__restrict__ seam_cnt,
+                                                       const uint32_t *__restrict__ seam_off, int ny, CtkSeam *__restrict__ out)
+{
+    const int t = (int)blockIdx.x;
+    const uint32_t n = seam_cnt[t], o = seam_off[t];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out[o + i] = scratch[(int64_t)t * ny + i];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,334 @@
+// ctk_resolve_dev.hip -- device-side resolution of the component tables (included by ctk_api.hip).
+//
+// Same semantics as the GPU-free reference implementation in ctk_resolve.cpp (which stays the
+// specification and is what the CPU tests exercise); here every data-parallel part runs as small
+// grid-stride kernels on the tables already resident in HBM, and only the inherently sequential seam-merge
+// driver (contrack.py:753-763, a few thousand candidate rows) runs on the host between two tiny copies.
+//
+//   R1  pair preparation        rep/global ids of both ends, forward overlap F (contrack.py:718)
+//   R2  overlap filter          Jacobi iteration of keep[t] = f(keep[t-1]) (contrack.py:706-742): every pass
+//                               recomputes the backward overlap from the previous pass' keep bits; a pass
+//                               that changes nothing proves the fixed point = the sequential result.
+//   R3  3-D labelling           lock-free union-find over surviving (c@t, d@t-1) links, roots ranked by a
+//                               prefix sum = scipy's raster-order numbering (contrack.py:748-751)
+//   R4  boxes of the fresh labels (find_objects once, contrack.py:753) + surviving seam rows in (t, y) order
+//   --  host: sequential seam driver on {label pair, box} records  ->  ordered op list
+//   R5  final id of every component (fold with box containment; mixed containment -> per-pixel fold later)
+#pragma once
+
+struct ResolveDev {
+    // inputs (dense, (t, c) order)
+    const uint32_t *ncomp, *cprefix;      // [T], [T+1]
+    const uint32_t *mrep, *comp_t;        // [NC]
+    const uint16_t *box;                  // [NC][4]
+    const int64_t *A;                     // [NC][2]  merged area at representatives
+    const CtkPair *pairs;
+    const uint32_t *counters;             // pairs count at CTK_CNT_PAIRS
+    uint32_t pair_cap;
+    int64_t T;
+    int32_t wshift;
+    double overlap;
+    int twosided;
+    // work
+    uint32_t *p_rc, *p_rd, *p_gc, *p_gd;  // [pair_cap]
+    int64_t *F, *B;                       // [NC][2]
+    uint8_t *keep0, *keep1;               // [NC]
+    uint32_t *changed;                    // [CTK_MAX_JACOBI + 1]
+    uint32_t *parent;                     // [NC]
+    uint32_t *isroot, *rank;              // [NC], [NC+1]
+    int32_t *lab;                         // [NC] fresh 3-D label of every component (0 = filtered out)
+    int32_t *lbox;                        // [(NC+1)][6]
+};
+
+#define CTK_MAX_JACOBI 24
+
+__device__ __forceinline__ uint32_t dev_npairs(const ResolveDev &r)
+{
+    uint32_t n = r.counters[CTK_CNT_PAIRS];
+    return n < r.pair_cap ? n : r.pair_cap;
+}
+__device__ __forceinline__ uint32_t dev_ncomps(const ResolveDev &r) { return r.cprefix[r.T]; }
+
+// exact limb sums -> float64, rounded once to nearest-even (identical to limbs_to_double in ctk_resolve.cpp)
+__device__ inline double dev_limbs_to_double(int64_t lo, int64_t hi, int wshift)
+{
+    __int128 v = (__int128)hi * ((__int128)1 << CTK_LIMB_BITS) + (__int128)lo;
+    if (v == 0) return 0.0;
+    const bool neg = v < 0;
+    unsigned __int128 a = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
+    const uint64_t top = (uint64_t)(a >> 64), bot = (uint64_t)a;
+    const int msb = top ? 127 - __builtin_clzll(top) : 63 - __builtin_clzll(bot);
+    double d;
+    if (msb <= 52) {
+        d = (double)bot;
+    } else {
+        const int sh = msb - 52;
+        unsigned __int128 q = a >> sh;
+        const unsigned __int128 rem = a & ((((unsigned __int128)1) << sh) - 1);
+        const unsigned __int128 half = ((unsigned __int128)1) << (sh - 1);
+        if (rem > half || (rem == half && (q & 1))) q += 1;
+        d = ldexp((double)(uint64_t)q, sh);
+    }
+    d = ldexp(d, -wshift);
+    return neg ? -d : d;
+}
+
+__global__ void k_rs_init(ResolveDev r)
+{
+    const uint32_t nc = dev_ncomps(r);
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
+        r.F[2 * (int64_t)g] = 0; r.F[2 * (int64_t)g + 1] = 0;
+        r.B[2 * (int64_t)g] = 0; r.B[2 * (int64_t)g + 1] = 0;
+        r.keep0[g] = 1; r.keep1[g] = 1;
+        r.parent[g] = g;
+    }
+    if (blockIdx.x == 0 && threadIdx.x <= CTK_MAX_JACOBI) r.changed[threadIdx.x] = 0;
+}
+
+__global__ void k_rs_pairs(ResolveDev r)
+{
+    const uint32_t np = dev_npairs(r);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
+        const CtkPair p = r.pairs[i];
+        const uint32_t cb = r.cprefix[p.t], db = r.cprefix[p.t - 1];
+        const uint32_t gc = cb + p.c, gd = db + p.d;
+        const uint32_t rc = cb + r.mrep[gc], rd = db + r.mrep[gd];
+        r.p_gc[i] = gc; r.p_gd[i] = gd; r.p_rc[i] = rc; r.p_rd[i] = rd;
+        // forward overlap of the EARLIER component: plane t is unfiltered when t-1 is visited (contrack.py:718)
+        atomicAdd((unsigned long long *)&r.F[2 * (int64_t)rd], (unsigned long long)p.lo);
+        atomicAdd((unsigned long long *)&r.F[2 * (int64_t)rd + 1], (unsigned long long)p.hi);
+    }
+}
+
+// one Jacobi pass, part 1: backward overlap from the keep bits of the previous pass (contrack.py:719)
+__global__ void k_rs_bwd(ResolveDev r, int it)
+{
+    if (it > 0 && r.changed[it - 1] == 0) return;           // already at the fixed point
+    const uint8_t *kin = (it & 1) ? r.keep1 : r.keep0;
+    const uint32_t np = dev_npairs(r);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
+        if (!kin[r.p_rd[i]]) continue;
+        const CtkPair p = r.pairs[i];
+        const int64_t rc = r.p_rc[i];
+        atomicAdd((unsigned long long *)&r.B[2 * rc], (unsigned long long)p.lo);
+        atomicAdd((unsigned long long *)&r.B[2 * rc + 1], (unsigned long long)p.hi);
+    }
+}
+
+// part 2: the removal rules (contrack.py:721-742) on merged representatives of the inner timesteps
+__global__ void k_rs_decide(ResolveDev r, int it)
+{
+    if (it > 0 && r.changed[it - 1] == 0) return;
+    const uint8_t *kin = (it & 1) ? r.keep1 : r.keep0;
+    uint8_t *kout = (it & 1) ? r.keep0 : r.keep1;
+    const uint32_t nc = dev_ncomps(r);
+    bool any = false;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
+        const uint32_t t = r.comp_t[g];
+        uint8_t k = 1;
+        if (r.cprefix[t] + r.mrep[g] == g && t >= 1 && (int64_t)t <= r.T - 2) {
+            const double areacon = dev_limbs_to_double(r.A[2 * (int64_t)g], r.A[2 * (int64_t)g + 1], r.wshift);
+            const double fwd = dev_limbs_to_double(r.F[2 * (int64_t)g], r.F[2 * (int64_t)g + 1], r.wshift);
+            const double bwd = dev_limbs_to_double(r.B[2 * (int64_t)g], r.B[2 * (int64_t)g + 1], r.wshift);
+            const double inv = 1.0 / areacon;
+            const double fb = inv * bwd, ff = inv * fwd;
+            bool kill = false;
+            if (r.twosided) {
+                if (fb != 0 && ff != 0) { if (fb < r.overlap || ff < r.overlap) kill = true; }
+                if (fb != 0 && ff == 0) { if (fb < r.overlap) kill = true; }
+                if (fb == 0 && ff != 0) { if (ff < r.overlap) kill = true; }
+            } else {
+                if (ff < r.overlap) kill = true;
+            }
+            k = kill ? 0 : 1;
+        }
+        r.B[2 * (int64_t)g] = 0; r.B[2 * (int64_t)g + 1] = 0;       // ready for the next pass
+        kout[g] = k;
+        any |= (k != kin[g]);
+    }
+    if (__ballot(any) && lane_id() == 0) atomicOr(&r.changed[it], 1u);
+}
+
+// keep bits of the last pass land in keep0 (so later kernels need not know how many passes ran)
+__global__ void k_rs_keep_final(ResolveDev r, int passes)
+{
+    // find the last pass that ran: the first it with changed[it] == 0 (it ran and changed nothing) or `passes`
+    int last = passes - 1;
+    for (int it = 0; it < passes; it++) if (r.changed[it] == 0) { last = it; break; }
+    const uint8_t *kfin = (last & 1) ? r.keep0 : r.keep1;      // pass `last` wrote kout = (last&1)?keep0:keep1
+    if (kfin == r.keep0) return;
+    const uint32_t nc = dev_ncomps(r);
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) r.keep0[g] = kfin[g];
+}
+
+__device__ __forceinline__ uint32_t gfind(uint32_t *p, uint32_t i)
+{
+    for (;;) {
+        uint32_t q = __hip_atomic_load(&p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (q == i) return i;
+        i = q;
+    }
+}
+
+__global__ void k_rs_unite(ResolveDev r)
+{
+    const uint32_t np = dev_npairs(r);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
+        if (!r.keep0[r.p_rc[i]] || !r.keep0[r.p_rd[i]]) continue;
+        uint32_t a = r.p_gc[i], b = r.p_gd[i];
+        for (;;) {
+            a = gfind(r.parent, a);
+            b = gfind(r.parent, b);
+            if (a == b) break;
+            if (a < b) { uint32_t s = a; a = b; b = s; }
+            uint32_t old = atomicMin(&r.parent[a], b);
+            if (old == a) break;
+            a = old;
+        }
+    }
+}
+
+__global__ void k_rs_roots(ResolveDev r)
+{
+    const uint32_t nc = dev_ncomps(r);
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
+        const uint32_t t = r.comp_t[g];
+        const bool kept = r.keep0[r.cprefix[t] + r.mrep[g]] != 0;
+        const uint32_t root = gfind(r.parent, g);
+        r.lab[g] = kept ? (int32_t)root : -1;               // temporarily: root index, -1 = filtered out
+        r.isroot[g] = (kept && root == g) ? 1u : 0u;
+    }
+}
+
+// generic multi-block exclusive scan of a uint32 vector whose length lives on the device:
+//   pass 1: per-block sums (2048 items per block)   pass 2: k_scan_u32 over the block sums   pass 3: apply
+#define CTK_SCAN_ITEMS 2048
+__global__ __launch_bounds__(256) void k_scan_blocksum(const uint32_t *__restrict__ in, const uint32_t *n_ptr, uint32_t *__restrict__ bsum)
+{
+    const uint32_t n = *n_ptr;
+    const uint32_t b0 = blockIdx.x * CTK_SCAN_ITEMS;
+    uint32_t s = 0;
+    for (uint32_t i = b0 + threadIdx.x; i < b0 + CTK_SCAN_ITEMS && i < n; i += 256) s += in[i];
+    __shared__ uint32_t sm[8];
+    uint32_t tot;
+    block_excl_scan(s, sm, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__ in, const uint32_t *n_ptr, const uint32_t *__restrict__ boff,
+                                                    uint32_t *__restrict__ out)
+{
+    const uint32_t n = *n_ptr;
+    const uint32_t b0 = blockIdx.x * CTK_SCAN_ITEMS;
+    __shared__ uint32_t sm[8];
+    uint32_t carry = boff[blockIdx.x];
+    for (uint32_t i0 = b0; i0 < b0 + CTK_SCAN_ITEMS; i0 += 256) {
+        const uint32_t i = i0 + threadIdx.x;
+        uint32_t v = (i < n) ? in[i] : 0u, tot;
+        uint32_t ex = block_excl_scan(v, sm, &tot);
+        if (i < n) out[i] = carry + ex;
+        carry += tot;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = boff[gridDim.x];     // grand total
+}
+
+// fresh labels: 1 + rank of the root among surviving roots (raster order); boxes initialised
+__global__ void k_rs_labels(ResolveDev r)
+{
+    const uint32_t nc = dev_ncomps(r);
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
+        const int32_t root = r.lab[g];
+        r.lab[g] = root < 0 ? 0 : (int32_t)r.rank[root] + 1;
+        // box slot g+1 <= number of labels is initialised here (labels <= components)
+        int32_t *b = r.lbox + 6 * (int64_t)(g + 1);
+        b[0] = INT32_MAX; b[1] = -1; b[2] = INT32_MAX; b[3] = -1; b[4] = INT32_MAX; b[5] = -1;
+    }
+}
+
+__global__ void k_rs_boxes(ResolveDev r, int64_t t_begin)
+{
+    const uint32_t nc = dev_ncomps(r);
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
+        const int32_t l = r.lab[g];
+        if (l <= 0) continue;
+        int32_t *b = r.lbox + 6 * (int64_t)l;
+        const uint16_t *q = r.box + 4 * (int64_t)g;
+        const int32_t t = (int32_t)(t_begin + r.comp_t[g]);
+        atomicMin(&b[0], t); atomicMax(&b[1], t);
+        atomicMin(&b[2], (int32_t)q[0]); atomicMax(&b[3], (int32_t)q[1]);
+        atomicMin(&b[4], (int32_t)q[2]); atomicMax(&b[5], (int32_t)q[3]);
+    }
+}
+
+// surviving seam rows of timestep t -> {t, y, label at x=0, label at x=nx-1}, (t, y) order
+struct CtkCand {
+    int32_t t, y, ll, lr;
+};
+__global__ __launch_bounds__(256) void k_rs_cand_count(ResolveDev r, const CtkSeam *__restrict__ scratch, const uint32_t *__restrict__ seam_cnt,
+                                                       int ny, uint32_t *__restrict__ cand_cnt)
+{
+    const int t = (int)blockIdx.x;
+    const uint32_t n = seam_cnt[t], cb = r.cprefix[t];
+    uint32_t s = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const CtkSeam q = scratch[(int64_t)t * ny + i];
+        s += r.keep0[cb + r.mrep[cb + q.cl]] ? 1u : 0u;
+    }
+    __shared__ uint32_t sm[8];
+    uint32_t tot;
+    block_excl_scan(s, sm, &tot);
+    if (threadIdx.x == 0) cand_cnt[t] = tot;
+}
+__global__ __launch_bounds__(256) void k_rs_cand_write(ResolveDev r, const CtkSeam *__restrict__ scratch, const uint32_t *__restrict__ seam_cnt,
+                                                       int ny, const uint32_t *__restrict__ cand_off, int64_t t_begin, CtkCand *__restrict__ out)
+{
+    const int t = (int)blockIdx.x;
+    const uint32_t n = seam_cnt[t], cb = r.cprefix[t];
+    __shared__ uint32_t sm[8];
+    uint32_t carry = cand_off[t];
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        const uint32_t i = i0 + threadIdx.x;
+        CtkSeam q;
+        uint32_t v = 0;
+        if (i < n) { q = scratch[(int64_t)t * ny + i]; v = r.keep0[cb + r.mrep[cb + q.cl]] ? 1u : 0u; }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(v, sm, &tot);
+        if (v) {
+            CtkCand c;
+            c.t = (int32_t)(t_begin + t); c.y = (int32_t)q.y; c.ll = r.lab[cb + q.cl]; c.lr = r.lab[cb + q.cr];
+            out[carry + ex] = c;
+        }
+        carry += tot;
+    }
+}
+
+// R5: final id of every component.  All of a component's pixels move together through an op whose box
+// contains the component's box, none moves when the boxes are disjoint; anything else is resolved per
+// pixel in k_extent / k_relabel (comp_label = -fresh label).
+__global__ void k_rs_final(ResolveDev r, FoldArgs f, int64_t t_begin, int32_t *__restrict__ comp_label)
+{
+    const uint32_t nc = dev_ncomps(r);
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
+        const int32_t l = r.lab[g];
+        if (l <= 0 || f.nops == 0) { comp_label[g] = l; continue; }
+        const uint16_t *q = r.box + 4 * (int64_t)g;
+        const int32_t t = (int32_t)(t_begin + r.comp_t[g]);
+        int32_t cur = l, s = 0;
+        bool cplx = false;
+        for (bool again = true; again && !cplx;) {
+            again = false;
+            int32_t lo = 0, hi = f.nops;
+            while (lo < hi) { int32_t m = (lo + hi) >> 1; if (f.oi_hi[m] < cur) lo = m + 1; else hi = m; }
+            for (int32_t k = lo; k < f.nops && f.oi_hi[k] == cur; k++) {
+                const int32_t idx = f.oi_idx[k];
+                if (idx < s) continue;
+                const CtkOp o = f.ops[idx];
+                const bool t_in = t >= o.t0 && t <= o.t1;
+                const bool inside = t_in && q[0] >= o.y0 && q[1] <= o.y1 && q[2] >= o.x0 && q[3] <= o.x1;
+                const bool disjoint = !t_in || q[1] < o.y0 || q[0] > o.y1 || q[3] < o.x0 || q[2] > o.x1;
+                if (inside) { cur = o.lo; s = idx + 1; again = true; break; }
+                if (!disjoint) { cplx = true; break; }
+            }
+        }
+        comp_label[g] = cplx ? -l : cur;
+    }
+}

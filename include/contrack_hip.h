@@ -61,12 +61,23 @@ int ctk_track_f32_dev(ctk_handle *h, const float *anom_dev, int64_t T, int ny, i
                       const double *thr, int cmp_op, const float *wrow, double overlap,
                       int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked);
 
+/* float64 slabs (xarray often hands float64 anomalies): the compare is evaluated in float64, exactly as
+ * numpy does for a float64 array at contrack.py:665; everything downstream is identical.            */
+int ctk_track_f64(ctk_handle *h, const double *anom, int64_t T, int ny, int nx, const double *thr,
+                  int cmp_op, const float *wrow, double overlap, int persistence, int twosided,
+                  int32_t *flag, int64_t *n_tracked);
+int ctk_track_f64_dev(ctk_handle *h, const double *anom_dev, int64_t T, int ny, int nx,
+                      const double *thr, int cmp_op, const float *wrow, double overlap,
+                      int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked);
+
 /* ---- staged path (time-sharded multi-GPU; each rank owns timesteps [t_begin, t_begin+T)) ------ */
 /* stage 1: threshold -> bit mask -> 2-D labelling with longitude wrap (contrack.py:646-698) + per
  *          component areas (contrack.py:717).  has_prev != 0 means a previous shard exists and
  *          its last timestep will be imported before stage 2.                                    */
 int ctk_shard_label2d(ctk_handle *h, const float *anom_dev, int64_t T, int ny, int nx,
                       const double *thr, int cmp_op, const float *wrow, int has_prev);
+int ctk_shard_label2d_f64(ctk_handle *h, const double *anom_dev, int64_t T, int ny, int nx,
+                          const double *thr, int cmp_op, const float *wrow, int has_prev);
 /* halo: the labelled LAST timestep of this shard, as an opaque device blob for the next rank
  *       (bit mask + run->component ids; the compressed form of the one-timestep label map).      */
 int ctk_shard_halo_size(ctk_handle *h, size_t *max_bytes);           /* upper bound, same on all ranks */
@@ -126,13 +137,17 @@ int ctk_debug_label2d(ctk_handle *h, int before_seam, int32_t *lab /* (T,ny,nx) 
 #define CTK_K_EXTENT    4
 #define CTK_K_RUNLABEL  5
 #define CTK_K_RELABEL   6
-#define CTK_K_COUNT     7
-#define CTK_T_HOST_RESOLVE 8   /* host wall time of ctk_resolve inside ctk_track_*   */
-#define CTK_T_D2H          9   /* table download                                      */
-#define CTK_T_H2D         10   /* result upload                                       */
-#define CTK_T_TOTAL       11
-#define CTK_NTIMERS       12
+#define CTK_K_RESOLVE   7      /* device resolver: filter passes, 3-D union-find, ids, boxes */
+#define CTK_K_RESOLVE2  8      /* device resolver: final id per component                     */
+#define CTK_K_COUNT     9
+#define CTK_T_HOST_RESOLVE 10  /* host: sequential seam driver (or ctk_resolve on the host path) */
+#define CTK_T_D2H          11  /* downloads                                            */
+#define CTK_T_H2D          12  /* uploads                                              */
+#define CTK_T_TOTAL        13
+#define CTK_NTIMERS        14
 int ctk_set_timing(ctk_handle *h, int enable);
+/* 1 (default): ctk_track_* resolve the tables on the device; 0: download + ctk_resolve on the host */
+int ctk_set_device_resolve(ctk_handle *h, int enable);
 int ctk_get_timings(ctk_handle *h, double *ms /* [CTK_NTIMERS] */);
 
 /* ---- thin device-memory helpers so that a ctypes host needs no other HIP binding -------------- */

@@ -115,8 +115,14 @@ def parse_blob(blob):
         lo, hi = pd.get(k, (0, 0))
         pd[k] = (lo + int(p["lo"]), hi + int(p["hi"]))
     sd = sorted((int(s["t"]), int(s["y"]), int(s["cl"]), int(s["cr"])) for s in seams)
+    # areas canonicalised to "area of the seam-merged component, stored at its representative"
+    off = np.concatenate([[0], np.cumsum(ncomp.astype(np.int64))])
+    tcomp = np.repeat(np.arange(T), ncomp)
+    rep = (off[tcomp] + mrep) if nc else np.zeros(0, dtype=np.int64)
+    marea = np.zeros((nc, 2), dtype=np.int64)
+    np.add.at(marea, rep, area)
     return dict(T=T, ny=ny, nx=nx, wshift=wshift, has_prev=has_prev, ncomp=ncomp.copy(), mrep=mrep.copy(), box=box.copy(),
-                area=area.copy(), pairs=pd, seams=sd)
+                area=marea, pairs=pd, seams=sd)
 
 
 def fold_pixel(ops, ops_of, l, t, y, x):

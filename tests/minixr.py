@@ -65,6 +65,12 @@ class DataArray:
     def __lt__(self, o):
         return self._cmp(o, np.less)
 
+    def to_index(self):
+        if self.data.dtype.kind != "M":
+            raise AttributeError("to_index")          # like dates xarray cannot decode
+        import pandas as pd
+        return pd.DatetimeIndex(self.data)
+
     def transpose(self, *dims):
         if len(dims) == 1 and not isinstance(dims[0], str):
             dims = tuple(dims[0])

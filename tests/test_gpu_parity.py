@@ -100,6 +100,20 @@ def test_hip_matches_oracle(trk, oracle_lib, case):
     assert ng == nw
 
 
+@pytest.mark.parametrize("name", ["syn2deg_s0", "busy_s0", "chain_a", "chain_b", "chain_c", "noise", "syn2deg_fwd", "all_fg", "T2"])
+def test_host_and_device_resolver_agree(trk, name):
+    """ctk_track_* with the device resolver (default) and with the GPU-free host resolver give the same flag"""
+    g = golden_util.load(name)
+    args = (g["anom"], g["thr"], _native.CMP_OPS[g["gorl"]], g["wrow"], g["overlap"], g["persistence"], g["twosided"])
+    try:
+        trk.set_device_resolve(False)
+        f_host, n_host = trk.track(*args)
+    finally:
+        trk.set_device_resolve(True)
+    f_dev, n_dev = trk.track(*args)
+    assert np.array_equal(f_host, g["flag"]) and np.array_equal(f_dev, g["flag"]) and n_host == n_dev
+
+
 def test_workspace_reuse_and_determinism(trk, oracle_lib):
     """same handle, different shapes back to back, then the first again: identical output."""
     g1, g2 = golden_util.load("syn2deg_s1"), golden_util.load("odd_17x64")
