@@ -257,8 +257,9 @@ class contrack(object):
         """grid spacing in degrees / time step in hours (contrack.py:327-380)"""
         if dim == self._time_name:
             try:
-                index = self.ds[dim].to_index()
-                delta = np.unique((index[1:] - index[:-1]).astype('timedelta64[h]'))
+                stamps = np.asarray(self.ds[dim].to_index().values)
+                # (numpy arithmetic: pandas >= 2 refuses TimedeltaIndex.astype('timedelta64[h]'))
+                delta = np.unique((stamps[1:] - stamps[:-1]).astype('timedelta64[h]'))
             except AttributeError:
                 attrs = getattr(self.ds[dim], "attrs", {})
                 if 'units' in attrs and 'days' in attrs['units']:

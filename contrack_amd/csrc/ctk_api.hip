@@ -52,14 +52,14 @@ struct ctk_handle {
     uint32_t pair_cap = 0, seam_cap = 0;
     bool need_glb = false;
     // device buffers
-    DevBuf mask, rowcnt, rowstart, tcount, run_base, ncomp, cprefix, thr32, wlo, whi, counters;
+    DevBuf mask, wstart, rowstart, tcount, run_base, ncomp, cprefix, thr32, wlo, whi, counters;
     DevBuf run_comp, run_val, cs_mrep, cs_box, cs_area, d_mrep, d_box, d_area, comp_label;
     DevBuf g_x0, g_x1, g_y, g_parent, g_root, g_idmap, g_rs;
-    DevBuf pairs, seams, ext, ops, oi_hi, oi_idx, halo_in, halo_out, dbg;
+    DevBuf pairs, seams, ext, ops, op_first, op_next, op_stage, halo_in, halo_out, dbg;
     DevBuf seam_cnt, seam_off, d_seams, d_comp_t;
     // device resolver work space
     DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lbox,
-        rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_scalars;
+        rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_scalars, rv_mark;
     void *h_cand = nullptr;          // pinned: candidates + boxes download
     size_t h_cand_cap = 0;
     int use_device_resolve = 1;
@@ -192,13 +192,13 @@ extern "C" void ctk_destroy(ctk_handle *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    DevBuf *bufs[] = {&h->mask, &h->rowcnt, &h->rowstart, &h->tcount, &h->run_base, &h->ncomp, &h->cprefix, &h->thr32, &h->wlo, &h->whi,
+    DevBuf *bufs[] = {&h->mask, &h->wstart, &h->rowstart, &h->tcount, &h->run_base, &h->ncomp, &h->cprefix, &h->thr32, &h->wlo, &h->whi,
                       &h->counters, &h->run_comp, &h->run_val, &h->cs_mrep, &h->cs_box, &h->cs_area, &h->d_mrep, &h->d_box, &h->d_area,
                       &h->comp_label, &h->g_x0, &h->g_x1, &h->g_y, &h->g_parent, &h->g_root, &h->g_idmap, &h->g_rs, &h->pairs, &h->seams,
-                      &h->ext, &h->ops, &h->oi_hi, &h->oi_idx, &h->halo_in, &h->halo_out, &h->dbg, &h->seam_cnt, &h->seam_off, &h->d_seams,
+                      &h->ext, &h->ops, &h->op_first, &h->op_next, &h->op_stage, &h->halo_in, &h->halo_out, &h->dbg, &h->seam_cnt, &h->seam_off, &h->d_seams,
                       &h->d_comp_t, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
                       &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
-                      &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_scalars};
+                      &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_scalars, &h->rv_mark};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -274,7 +274,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     CTKCHK(ctk_weights_to_limbs(wrow, ny, wlo.data(), whi.data(), &h->wshift));
 
     CTKCHK(ensure(h, h->mask, (size_t)nrows * W * 8));
-    CTKCHK(ensure(h, h->rowcnt, (size_t)nrows * 2));
+    CTKCHK(ensure(h, h->wstart, (size_t)nrows * W * 2));
     CTKCHK(ensure(h, h->rowstart, (size_t)nrows * 4));
     CTKCHK(ensure(h, h->tcount, (size_t)T * 4));
     CTKCHK(ensure(h, h->run_base, (size_t)(T + 1) * 4));
@@ -298,10 +298,14 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     if (T > 0) {
         Timer tm(h, CTK_K_THRESHOLD);
         const int g = grid_for_rows(nrows);
+        const int64_t nblk4 = T * ((ny + CTK_RB - 1) / CTK_RB);                       // one workgroup per (timestep, 16 rows)
+        const bool v4 = !f64 && (nx % 4 == 0) && (((uintptr_t)anom_dev & 15) == 0) && nblk4 < 0x7fffffff;
+        const unsigned g4 = (unsigned)nblk4;
 #define LAUNCH_THR(OP)                                                                                                                      \
     do {                                                                                                                                \
-        if (f64) k_threshold<OP, double><<<g, 256, 0, s>>>((const double *)anom_dev, P<double>(h->thr32), nrows, ny, nx, W, P<uint64_t>(h->mask), P<uint16_t>(h->rowcnt), P<uint32_t>(h->tcount)); \
-        else k_threshold<OP, float><<<g, 256, 0, s>>>((const float *)anom_dev, P<float>(h->thr32), nrows, ny, nx, W, P<uint64_t>(h->mask), P<uint16_t>(h->rowcnt), P<uint32_t>(h->tcount)); \
+        if (f64) k_threshold<OP, double><<<g, 256, 0, s>>>((const double *)anom_dev, P<double>(h->thr32), nrows, ny, nx, W, P<uint64_t>(h->mask)); \
+        else if (v4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)anom_dev, P<float>(h->thr32), ny, nx, W, P<uint64_t>(h->mask)); \
+        else k_threshold<OP, float><<<g, 256, 0, s>>>((const float *)anom_dev, P<float>(h->thr32), nrows, ny, nx, W, P<uint64_t>(h->mask)); \
     } while (0)
         switch (cmp_op) {
         case 0: LAUNCH_THR(0); break;
@@ -314,6 +318,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     }
     {
         Timer tm(h, CTK_K_SCAN);
+        if (T > 0) k_rowcount<<<(int)T, 256, 0, s>>>(P<uint64_t>(h->mask), ny, W, P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart), P<uint32_t>(h->tcount));
         k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
         HIPCHK(hipGetLastError());
     }
@@ -349,7 +354,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     }
     if (T > 0) {
         Label2dArgs a;
-        a.mask = P<uint64_t>(h->mask); a.rowcnt = P<uint16_t>(h->rowcnt); a.rowstart = P<uint32_t>(h->rowstart);
+        a.mask = P<uint64_t>(h->mask); a.wstart = P<uint16_t>(h->wstart); a.rowstart = P<uint32_t>(h->rowstart);
         a.run_base = P<uint32_t>(h->run_base); a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp);
         a.cs_mrep = P<uint32_t>(h->cs_mrep); a.cs_box = P<uint32_t>(h->cs_box); a.cs_area = P<int64_t>(h->cs_area);
         a.seams = P<CtkSeam>(h->seams); a.seam_cnt = P<uint32_t>(h->seam_cnt); a.counters = P<uint32_t>(h->counters);
@@ -393,9 +398,10 @@ extern "C" int ctk_shard_label2d_f64(ctk_handle *h, const double *anom_dev, int6
 
 // ------------------------------------------------------------------------------------------------
 // halo (last labelled timestep of this shard, for the next rank)
-//   layout: [uint64 mask[ny*W]] [uint32 rowstart[ny] (padded to 8 B)] [uint32 run_comp[max]]
+//   layout: [uint64 mask[ny*W]] [uint16 wstart[ny*W] (padded to 8 B)] [uint32 rowstart[ny] (padded)] [uint32 run_comp[max]]
 // ------------------------------------------------------------------------------------------------
-static size_t halo_off_rowstart(const ctk_handle *h) { return (size_t)h->ny * h->W * 8; }
+static size_t halo_off_wstart(const ctk_handle *h) { return (size_t)h->ny * h->W * 8; }
+static size_t halo_off_rowstart(const ctk_handle *h) { return halo_off_wstart(h) + ctk_align8((size_t)h->ny * h->W * 2); }
 static size_t halo_off_runcomp(const ctk_handle *h) { return halo_off_rowstart(h) + ctk_align8((size_t)h->ny * 4); }
 static size_t halo_max_bytes(const ctk_handle *h) { return halo_off_runcomp(h) + (size_t)h->ny * ((size_t)h->nx / 2 + 1) * 4; }
 
@@ -420,6 +426,7 @@ extern "C" int ctk_shard_halo_export(ctk_handle *h, void **blob_dev, size_t *nby
         const uint32_t *hb = (const uint32_t *)h->h_small;                    // run_base, downloaded in stage 1
         const uint32_t n = hb[t + 1] - hb[t];
         HIPCHK(hipMemcpyAsync(dst, P<uint64_t>(h->mask) + t * h->ny * h->W, (size_t)h->ny * h->W * 8, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(dst + halo_off_wstart(h), P<uint16_t>(h->wstart) + t * h->ny * h->W, (size_t)h->ny * h->W * 2, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(dst + halo_off_rowstart(h), P<uint32_t>(h->rowstart) + t * h->ny, (size_t)h->ny * 4, hipMemcpyDeviceToDevice, s));
         if (n) HIPCHK(hipMemcpyAsync(dst + halo_off_runcomp(h), P<uint32_t>(h->run_comp) + hb[t], (size_t)n * 4, hipMemcpyDeviceToDevice, s));
         *nbytes = halo_off_runcomp(h) + (size_t)n * 4;
@@ -450,10 +457,11 @@ extern "C" int ctk_shard_halo_import(ctk_handle *h, const void *blob_dev, size_t
 static int launch_overlap(ctk_handle *h)
 {
     OverlapArgs a;
-    a.mask = P<uint64_t>(h->mask); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
+    a.mask = P<uint64_t>(h->mask); a.wstart = P<uint16_t>(h->wstart); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
     a.run_comp = P<uint32_t>(h->run_comp);
     const char *hl = (const char *)h->halo_in.p;
     a.halo_mask = (const uint64_t *)hl;
+    a.halo_wstart = hl ? (const uint16_t *)(hl + halo_off_wstart(h)) : nullptr;
     a.halo_rowstart = hl ? (const uint32_t *)(hl + halo_off_rowstart(h)) : nullptr;
     a.halo_run_comp = hl ? (const uint32_t *)(hl + halo_off_runcomp(h)) : nullptr;
     a.has_prev = (h->has_prev && hl) ? 1 : 0;
@@ -560,25 +568,37 @@ extern "C" int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes
 static FoldArgs fold_args(const ctk_handle *h)
 {
     FoldArgs f;
-    f.ops = P<CtkOp>(h->ops); f.oi_hi = P<int32_t>(h->oi_hi); f.oi_idx = P<int32_t>(h->oi_idx); f.nops = h->nops;
+    f.ops = P<CtkOp>(h->ops); f.first = P<int32_t>(h->op_first); f.next = P<int32_t>(h->op_next); f.nops = h->nops;
     return f;
 }
 
-static int upload_ops(ctk_handle *h, const CtkOp *ops, int64_t nops)
+// ops in execution order -> device, plus the per-label chains (first[label], next[op]) the folds walk
+static int upload_ops(ctk_handle *h, const CtkOp *ops, int64_t nops, int64_t n_labels)
 {
     hipStream_t s = h->stream;
     h->nops = (int32_t)nops;
+    CTKCHK(ensure(h, h->op_first, (size_t)(n_labels + 1) * 4));
+    HIPCHK(hipMemsetAsync(h->op_first.p, 0xff, (size_t)(n_labels + 1) * 4, s));            // all -1
     if (!nops) return CTK_OK;
-    std::vector<int32_t> order((size_t)nops), oi_hi((size_t)nops);
+    // chains: only the labels that occur as `hi` need a first[] entry; scatter those few words on the device
+    std::vector<int32_t> next((size_t)nops, -1), order((size_t)nops), fl_label, fl_idx;
     for (int32_t i = 0; i < (int32_t)nops; i++) order[(size_t)i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return ops[a].hi < ops[b].hi; });
-    for (size_t i = 0; i < order.size(); i++) oi_hi[i] = ops[order[i]].hi;
+    for (size_t i = 0; i < order.size(); i++) {
+        const int32_t idx = order[i];
+        if (i + 1 < order.size() && ops[order[i + 1]].hi == ops[idx].hi) next[(size_t)idx] = order[i + 1];
+        if (i == 0 || ops[order[i - 1]].hi != ops[idx].hi) { fl_label.push_back(ops[idx].hi); fl_idx.push_back(idx); }
+    }
+    const size_t nf = fl_label.size();
     CTKCHK(ensure(h, h->ops, (size_t)nops * sizeof(CtkOp)));
-    CTKCHK(ensure(h, h->oi_hi, (size_t)nops * 4));
-    CTKCHK(ensure(h, h->oi_idx, (size_t)nops * 4));
+    CTKCHK(ensure(h, h->op_next, (size_t)nops * 4));
+    CTKCHK(ensure(h, h->op_stage, nf * 8));
     HIPCHK(hipMemcpyAsync(h->ops.p, ops, (size_t)nops * sizeof(CtkOp), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->oi_hi.p, oi_hi.data(), (size_t)nops * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->oi_idx.p, order.data(), (size_t)nops * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->op_next.p, next.data(), (size_t)nops * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->op_stage.p, fl_label.data(), nf * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(P<int32_t>(h->op_stage) + nf, fl_idx.data(), nf * 4, hipMemcpyHostToDevice, s));
+    k_scatter_i32<<<(int)((nf + 255) / 256), 256, 0, s>>>(P<int32_t>(h->op_stage), P<int32_t>(h->op_stage) + nf, (int)nf, P<int32_t>(h->op_first));
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));                                         // staging vectors go out of scope
     return CTK_OK;
 }
@@ -617,7 +637,7 @@ extern "C" int ctk_shard_extents(ctk_handle *h, const ctk_result *r, int shard, 
     h->n_labels = r->n_labels; h->t_begin = t_begin;
     CTKCHK(ensure(h, h->comp_label, (size_t)(c1 - c0) * 4));
     if (c1 > c0) HIPCHK(hipMemcpyAsync(h->comp_label.p, r->comp_label + c0, (size_t)(c1 - c0) * 4, hipMemcpyHostToDevice, s));
-    CTKCHK(upload_ops(h, r->ops, r->nops));
+    CTKCHK(upload_ops(h, r->ops, r->nops, r->n_labels));
     HIPCHK(hipStreamSynchronize(s));
     h->ms[CTK_T_H2D] += now_ms() - t0;
     CTKCHK(launch_extents(h));
@@ -649,6 +669,12 @@ void seam_driver(const CtkCand *cand, int64_t ncand, const int32_t *lbox, int64_
             if (!moved) return l;
         }
     };
+    // An op (hi -> lo) moves the pixels labelled hi inside box[hi].  Right after one, no such pixel is left, and
+    // new ones can only arrive through a later op whose `lo` is hi.  A seam row that asks for hi -> anything
+    // while nothing has flowed into hi since hi's last op therefore changes no pixel (the reference runs the
+    // same relabel and finds nothing, contrack.py:759/763): it is not recorded.  This keeps the per-label
+    // chains short where a stranded fragment sits on the seam for many rows.
+    std::vector<int32_t> inflow((size_t)nlab + 1, -1);       // index of the last recorded op with lo == label
     for (int64_t k = 0; k < ncand; k++) {
         const CtkCand &c = cand[k];
         if (c.ll == c.lr && first[(size_t)c.ll] < 0) continue;             // same label, never relabelled: nothing can differ
@@ -656,12 +682,14 @@ void seam_driver(const CtkCand *cand, int64_t ncand, const int32_t *lbox, int64_
         const int32_t p1 = first[(size_t)c.lr] < 0 ? c.lr : fold(c.lr, c.t, c.y, nx - 1);
         if (p0 == p1) continue;
         const int32_t hi = std::max(p0, p1), lo = std::min(p0, p1);
+        if (last[(size_t)hi] >= 0 && inflow[(size_t)hi] < last[(size_t)hi]) continue;      // nothing to move
         const int32_t *b = lbox + 6 * (int64_t)hi;
         const int32_t idx = (int32_t)ops.size();
         ops.push_back(CtkOp{hi, lo, b[0], b[1], b[2], b[3], b[4], b[5]});
         next.push_back(-1);
         if (last[(size_t)hi] >= 0) next[(size_t)last[(size_t)hi]] = idx; else first[(size_t)hi] = idx;
         last[(size_t)hi] = idx;
+        inflow[(size_t)lo] = idx;
     }
 }
 
@@ -686,6 +714,7 @@ static int device_resolve(ctk_handle *h, double overlap, int twosided)
     CTKCHK(ensure(h, h->rv_cand_cnt, (size_t)T * 4)); CTKCHK(ensure(h, h->rv_cand_off, (size_t)(T + 1) * 4));
     CTKCHK(ensure(h, h->rv_cand, (size_t)std::max<int64_t>(T * h->ny, 1) * sizeof(CtkCand)));
     CTKCHK(ensure(h, h->rv_scalars, 64));
+    CTKCHK(ensure(h, h->rv_mark, R + 1));
     CTKCHK(ensure(h, h->comp_label, R * 4));
 
     ResolveDev r;
@@ -714,13 +743,15 @@ static int device_resolve(ctk_handle *h, double overlap, int twosided)
         k_scan_apply<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_boff), r.rank);
         k_rs_labels<<<gc, 256, 0, s>>>(r);
         k_rs_boxes<<<gc, 256, 0, s>>>(r, 0);
+        HIPCHK(hipMemsetAsync(h->rv_mark.p, 0, R + 1, s));
         if (T > 0) {
-            k_rs_cand_count<<<(int)T, 256, 0, s>>>(r, P<CtkSeam>(h->seams), P<uint32_t>(h->seam_cnt), h->ny, P<uint32_t>(h->rv_cand_cnt));
+            k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, P<CtkSeam>(h->seams), P<uint32_t>(h->seam_cnt), h->ny, P<uint8_t>(h->rv_mark));
+            k_rs_cand_count<<<(int)T, 256, 0, s>>>(r, P<CtkSeam>(h->seams), P<uint32_t>(h->seam_cnt), h->ny, P<uint8_t>(h->rv_mark), P<uint32_t>(h->rv_cand_cnt));
         }
         k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_cand_cnt), T, P<uint32_t>(h->rv_cand_off), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
         if (T > 0) {
-            k_rs_cand_write<<<(int)T, 256, 0, s>>>(r, P<CtkSeam>(h->seams), P<uint32_t>(h->seam_cnt), h->ny, P<uint32_t>(h->rv_cand_off), 0,
-                                                   P<CtkCand>(h->rv_cand));
+            k_rs_cand_write<<<(int)T, 256, 0, s>>>(r, P<CtkSeam>(h->seams), P<uint32_t>(h->seam_cnt), h->ny, P<uint8_t>(h->rv_mark),
+                                                   P<uint32_t>(h->rv_cand_off), 0, P<CtkCand>(h->rv_cand));
         }
         HIPCHK(hipGetLastError());
     }
@@ -755,7 +786,7 @@ static int device_resolve(ctk_handle *h, double overlap, int twosided)
         h->ms[CTK_T_D2H] += now_ms() - t0;
     }
     const double t2 = now_ms();
-    CTKCHK(upload_ops(h, ops.data(), (int64_t)ops.size()));
+    CTKCHK(upload_ops(h, ops.data(), (int64_t)ops.size(), nlab));
     h->ms[CTK_T_H2D] += now_ms() - t2;
     {
         Timer tm(h, CTK_K_RESOLVE2);
@@ -768,13 +799,20 @@ static int device_resolve(ctk_handle *h, double overlap, int twosided)
 static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, bool with_fold)
 {
     RelabelArgs a;
-    a.mask = P<uint64_t>(h->mask); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
+    a.mask = P<uint64_t>(h->mask); a.wstart = P<uint16_t>(h->wstart); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
     a.run_val = P<int32_t>(h->run_val); a.ext = P<int32_t>(h->ext); a.n_labels = h->n_labels; a.persistence = persistence;
     a.t_begin = h->t_begin;
-    if (with_fold) a.fold = fold_args(h); else { a.fold.ops = nullptr; a.fold.oi_hi = nullptr; a.fold.oi_idx = nullptr; a.fold.nops = 0; }
+    if (with_fold) a.fold = fold_args(h); else { a.fold.ops = nullptr; a.fold.first = nullptr; a.fold.next = nullptr; a.fold.nops = 0; }
     a.flag = flag_dev; a.counters = P<uint32_t>(h->counters);
     a.nrows = h->T * h->ny; a.ny = h->ny; a.nx = h->nx; a.W = h->W;
-    k_relabel<<<grid_for_rows(a.nrows), 256, 0, h->stream>>>(a);
+    const int64_t npl = (int64_t)h->ny * h->nx;
+    const int64_t nblk4 = h->T * ((h->ny + CTK_RB - 1) / CTK_RB);
+    if ((h->nx % 4 == 0) && (((uintptr_t)flag_dev & 15) == 0) && npl < 0x7fffffff && nblk4 < 0x7fffffff && h->T > 0 && h->W <= 64) {
+        const unsigned grid = (unsigned)nblk4;
+        k_relabel_v4<<<grid, 256, 0, h->stream>>>(a);
+    } else {
+        k_relabel<<<grid_for_rows(a.nrows), 256, 0, h->stream>>>(a);
+    }
     HIPCHK(hipGetLastError());
     return CTK_OK;
 }

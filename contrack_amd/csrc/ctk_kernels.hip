@@ -102,10 +102,15 @@ __device__ __forceinline__ void uf_unite(uint32_t *p, uint32_t a, uint32_t b)
 }
 
 // ------------------------------------------------------------------------------------------------
-// K0  threshold -> bit mask + runs per row            (contrack/contrack.py:646-674, NaN -> 0)
-// One wave per row, lane l tests pixel 64k+l, __ballot packs 64 pixels into one mask word.
-// thr32[t] is the float32 threshold the host derived so that the float32 compare equals the
-// reference's compare (see ctk_api: adjust_threshold).
+// K0  threshold -> bit mask                          (contrack/contrack.py:646-674, NaN -> 0)
+// The only kernel that reads the float slab: pure streaming, 4 B/pixel in, 1/8 B/pixel out.
+// thr[t] is the threshold the host derived so that the compare in the slab's dtype equals the
+// reference's compare (ctk_api: adjust_threshold).
+//
+// k_threshold_v4 (float32, nx % 4 == 0, 16-byte aligned slab): one workgroup per (timestep, 16 rows);
+// every lane issues 4 independent non-temporal float4 loads, the 4 compare bits of a lane are ORed across
+// its 16-lane group (64 pixels = one mask word) with 4 cross-lane steps, lane 0 of the group stores the word.
+// k_threshold (generic: any nx, float32 / float64): lane l tests pixel 64k+l, __ballot packs a word.
 // ------------------------------------------------------------------------------------------------
 template <int OP, typename TIN>
 __device__ __forceinline__ bool cmp_op(TIN v, TIN th)
@@ -116,27 +121,63 @@ __device__ __forceinline__ bool cmp_op(TIN v, TIN th)
     return v < th;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define CTK_RB 16                  // rows per workgroup in the two streaming kernels
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_threshold_v4(const float *__restrict__ anom, const float *__restrict__ thr32,
+                                                      int ny, int nx, int W, uint64_t *__restrict__ mask)
+{
+    constexpr int U = 4;                                   // independent 16-byte loads in flight per lane
+    const int nchunk = (ny + CTK_RB - 1) / CTK_RB;
+    const int t = (int)(blockIdx.x / (unsigned)nchunk), y0 = (int)(blockIdx.x - (unsigned)t * nchunk) * CTK_RB, tid = (int)threadIdx.x;
+    const int rows = min(CTK_RB, ny - y0);
+    const float th = thr32[t];
+    const int n4 = nx >> 2, n4p = (n4 + 15) & ~15;         // float4 slots per row, padded to whole 16-lane groups (= words)
+    const int total = rows * n4p;
+    const int64_t row0 = (int64_t)t * ny + y0;
+    const float *base = anom + row0 * (int64_t)nx;
+    const int sub = tid & 15;
+    for (int i0 = 0; i0 < total; i0 += 256 * U) {
+        f32x4 v[U];
+        int rr[U], cc[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * 256 + tid;
+            const int r = i / n4p, c = i - r * n4p;
+            rr[u] = r; cc[u] = c;
+            if (i < total && c < n4) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (int64_t)r * nx) + c);
+            else v[u] = (f32x4)(__builtin_nanf(""));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t nib = (cmp_op<OP, float>(v[u].x, th) ? 1u : 0u) | (cmp_op<OP, float>(v[u].y, th) ? 2u : 0u) |
+                                 (cmp_op<OP, float>(v[u].z, th) ? 4u : 0u) | (cmp_op<OP, float>(v[u].w, th) ? 8u : 0u);
+            // lanes 16g .. 16g+15 hold the 64 pixels of one word: place the nibble, OR across the group
+            uint32_t lo = (sub < 8) ? (nib << (4 * sub)) : 0u, hi = (sub >= 8) ? (nib << (4 * (sub - 8))) : 0u;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) { lo |= __shfl_xor(lo, d); hi |= __shfl_xor(hi, d); }
+            if (sub == 0 && i0 + u * 256 + tid < total) mask[(row0 + rr[u]) * W + (cc[u] >> 4)] = ((uint64_t)hi << 32) | lo;
+        }
+    }
+}
+
 template <int OP, typename TIN>
 __global__ __launch_bounds__(256) void k_threshold(const TIN *__restrict__ anom, const TIN *__restrict__ thr32,
-                                                   int64_t nrows, int ny, int nx, int W,
-                                                   uint64_t *__restrict__ mask, uint16_t *__restrict__ rowcnt,
-                                                   uint32_t *__restrict__ tcount)
+                                                   int64_t nrows, int ny, int nx, int W, uint64_t *__restrict__ mask)
 {
     const int lane = lane_id();
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const TIN qnan = (TIN)__builtin_nanf("");
     for (int64_t row = wave; row < nrows; row += nwaves) {
-        const int64_t t = row / ny;
-        const TIN th = thr32[t];
+        const TIN th = thr32[row / ny];
         const TIN *src = anom + row * (int64_t)nx;
-        const TIN qnan = (TIN)__builtin_nanf("");
-        uint64_t carry = 0;          // last pixel of the previous word
-        uint32_t nruns = 0;
         for (int w0 = 0; w0 < W; w0 += WAVE) {
             const int wn = min(WAVE, W - w0);
             uint64_t mine = 0;
-            int k = 0;
-            for (; k + 8 <= wn; k += 8) {                     // 8 independent loads in flight per lane
+            for (int k = 0; k < wn; k += 8) {                  // 8 independent loads in flight per lane
                 TIN v[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -149,24 +190,43 @@ __global__ __launch_bounds__(256) void k_threshold(const TIN *__restrict__ anom,
                     if (lane == k + j) mine = b;
                 }
             }
-            for (; k < wn; k++) {
-                int x = (w0 + k) * 64 + lane;
-                TIN v = (x < nx) ? src[x] : qnan;
-                uint64_t b = __ballot(cmp_op<OP, TIN>(v, th));
-                if (lane == k) mine = b;
-            }
-            uint64_t prev = shfl_up_u64(mine, 1);
-            uint64_t cin = (lane == 0) ? carry : (prev >> 63);
-            uint64_t starts = mine & ~((mine << 1) | cin);
             if (lane < wn) mask[row * W + w0 + lane] = mine;
-            nruns += wave_sum_u32(lane < wn ? (uint32_t)__popcll(starts) : 0u);
-            carry = shfl_u64(mine, wn - 1) >> 63;
-        }
-        if (lane == 0) {
-            rowcnt[row] = (uint16_t)nruns;
-            if (nruns) atomicAdd(&tcount[t], nruns);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0b runs per row / per word from the mask: one workgroup per timestep, one thread per row.
+//   wstart[row][w] = run starts in words < w of the row      rowstart[t][y] = first run of row y
+//   tcount[t]      = runs of the timestep
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rowcount(const uint64_t *__restrict__ mask, int ny, int W, uint16_t *__restrict__ wstart,
+                                                  uint32_t *__restrict__ rowstart, uint32_t *__restrict__ tcount)
+{
+    const int t = (int)blockIdx.x, tid = (int)threadIdx.x;
+    __shared__ uint32_t sm[8];
+    uint32_t carry_rows = 0;
+    for (int y0 = 0; y0 < ny; y0 += 256) {
+        const int y = y0 + tid;
+        uint32_t n = 0;
+        if (y < ny) {
+            const int64_t row = (int64_t)t * ny + y;
+            const uint64_t *mw = mask + row * W;
+            uint16_t *ws = wstart + row * W;
+            uint64_t carry = 0;
+            for (int w = 0; w < W; w++) {
+                const uint64_t m = mw[w];
+                ws[w] = (uint16_t)n;
+                n += (uint32_t)__popcll(m & ~((m << 1) | carry));
+                carry = m >> 63;
+            }
+        }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(n, sm, &tot);
+        if (y < ny) rowstart[(int64_t)t * ny + y] = carry_rows + ex;
+        carry_rows += tot;
+    }
+    if (tid == 0) tcount[t] = carry_rows;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -212,8 +272,8 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ 
 //
 // One workgroup per timestep.  Run arrays + union-find parents live in LDS (k_label2d_lds) or, for
 // timesteps with more runs than the LDS variant carries, in a global scratch area (k_label2d_glb).
-//   phase 1  rowstart = exclusive scan of runs per row
-//   phase 2  run extraction from the mask words (wave per row, lane per word, ctz over start/end bits)
+//   phase 1  rowstart of the timestep (k_rowcount) -> LDS
+//   phase 2  run extraction from the mask words (thread per word, ctz over start/end bits)
 //   phase 3  union every run with the runs of the previous row it touches (8-connectivity: x0-1..x1+1)
 //   phase 4  flatten -> root of every run; root = smallest run index = the run holding the component's
 //            first raster pixel, so ranking the roots reproduces scipy's label order
@@ -223,8 +283,8 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 struct Label2dArgs {
     const uint64_t *mask;
-    const uint16_t *rowcnt;
-    uint32_t *rowstart;
+    const uint16_t *wstart;        // [T][ny][W] run starts left of each word (k_rowcount)
+    const uint32_t *rowstart;      // [T][ny]
     const uint32_t *run_base;      // [T+1]
     uint32_t *run_comp;
     uint32_t *ncomp;               // [T]
@@ -247,47 +307,35 @@ template <int THREADS>
 __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, const uint32_t nruns,
                                              uint16_t *x0, uint16_t *x1, uint16_t *yrow, uint32_t *parent,
                                              uint32_t *root, uint32_t *idmap, uint32_t *rs /* rowstart, ny+1 */,
-                                             uint32_t *sm_scan)
+                                             uint32_t *sm_scan, const uint64_t *mrow /* the timestep's mask words (LDS or global) */)
 {
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, nwv = THREADS >> 6;
     const int ny = a.ny, nx = a.nx, W = a.W;
-    const uint64_t *mrow = a.mask + (int64_t)t * ny * W;
-    const uint16_t *rc = a.rowcnt + (int64_t)t * ny;
     const uint32_t rbase = a.run_base[t];
 
-    // ---- phase 1: rowstart -------------------------------------------------------------------
-    {
-        uint32_t carry = 0;
-        for (int y0 = 0; y0 < ny; y0 += THREADS) {
-            int y = y0 + tid;
-            uint32_t v = (y < ny) ? rc[y] : 0u, tot;
-            uint32_t ex = block_excl_scan(v, sm_scan, &tot);
-            if (y < ny) { rs[y] = carry + ex; a.rowstart[(int64_t)t * ny + y] = carry + ex; }
-            carry += tot;
-        }
-        if (tid == 0) rs[ny] = carry;
-    }
+    // ---- phase 1: rowstart (computed by k_rowcount) -> LDS/scratch -------------------------------
+    for (int y = tid; y < ny; y += THREADS) rs[y] = a.rowstart[(int64_t)t * ny + y];
+    if (tid == 0) rs[ny] = nruns;
     __syncthreads();
 
-    // ---- phase 2: run extraction ---------------------------------------------------------------
-    for (int y = wv; y < ny; y += nwv) {
-        if (rc[y] == 0) continue;
-        const uint64_t *mw = mrow + (int64_t)y * W;
-        uint32_t sbase = rs[y], ebase = rs[y];
-        uint64_t carry = 0;
-        for (int w0 = 0; w0 < W; w0 += WAVE) {
-            const int wn = min(WAVE, W - w0);
-            uint64_t m = (lane < wn) ? mw[w0 + lane] : 0ull;
-            uint64_t prev = shfl_up_u64(m, 1), next = shfl_down_u64(m, 1);
-            uint64_t cin = (lane == 0) ? carry : (prev >> 63);
-            uint64_t nin;
-            if (lane == wn - 1) nin = (w0 + wn < W) ? (mw[w0 + wn] & 1ull) : 0ull; else nin = next & 1ull;
+    // ---- phase 2: run extraction, one thread per mask word -------------------------------------
+    // the i-th start bit and the i-th end bit of a row delimit its i-th run; the number of starts / ends in the
+    // words to the left comes from k_rowcount's per-word prefix (an open run at the word boundary has started
+    // but not ended yet).
+    {
+        const uint16_t *ws = a.wstart + (int64_t)t * ny * W;
+        const int nwords = ny * W;
+        for (int idx = tid; idx < nwords; idx += THREADS) {
+            const uint64_t m = mrow[idx];
+            if (m == 0ull) continue;
+            const int y = idx / W, w = idx - y * W;
+            const uint64_t cin = (w > 0) ? (mrow[idx - 1] >> 63) : 0ull;
+            const uint64_t nin = (w + 1 < W) ? (mrow[idx + 1] & 1ull) : 0ull;
             uint64_t starts = m & ~((m << 1) | cin);
             uint64_t ends = m & ~((m >> 1) | (nin << 63));
-            uint32_t cs = (uint32_t)__popcll(starts), ce = (uint32_t)__popcll(ends);
-            uint32_t is = wave_incl_scan_u32(cs), ie = wave_incl_scan_u32(ce);
-            uint32_t si = sbase + is - cs, ei = ebase + ie - ce;
-            const int xb = (w0 + lane) * 64;
+            const uint32_t nbefore = rs[y] + ws[idx];
+            uint32_t si = nbefore, ei = nbefore - (uint32_t)(cin & m & 1ull);      // open run: started, not yet ended
+            const int xb = w * 64;
             while (starts) {
                 int b = __builtin_ctzll(starts);
                 starts &= starts - 1;
@@ -302,9 +350,6 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
                 x1[ei] = (uint16_t)(xb + b);
                 ei++;
             }
-            sbase += __shfl(is, WAVE - 1);
-            ebase += __shfl(ie, WAVE - 1);
-            carry = shfl_u64(m, wn - 1) >> 63;
         }
     }
     __syncthreads();
@@ -413,7 +458,8 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
 }
 
 #define CTK_LDS_RUNS 2048
-#define CTK_LDS_NY 2048
+#define CTK_LDS_NY 1024
+#define CTK_LDS_MASKW 1536
 
 __global__ __launch_bounds__(256) void k_label2d_lds(Label2dArgs a)
 {
@@ -422,14 +468,21 @@ __global__ __launch_bounds__(256) void k_label2d_lds(Label2dArgs a)
     if (nruns > CTK_LDS_RUNS || a.ny > CTK_LDS_NY) return;        // k_label2d_glb takes it
     if (nruns == 0) {
         if (threadIdx.x == 0) { a.ncomp[t] = 0; a.seam_cnt[t] = 0; }
-        for (int y = (int)threadIdx.x; y < a.ny; y += 256) a.rowstart[(int64_t)t * a.ny + y] = 0;
         return;
     }
     __shared__ uint16_t x0[CTK_LDS_RUNS], x1[CTK_LDS_RUNS], yrow[CTK_LDS_RUNS];
     __shared__ uint32_t parent[CTK_LDS_RUNS], root[CTK_LDS_RUNS], idmap[CTK_LDS_RUNS];
     __shared__ uint32_t rs[CTK_LDS_NY + 1];
+    __shared__ uint64_t mlds[CTK_LDS_MASKW];
     __shared__ uint32_t sm_scan[8];
-    label2d_body<256>(a, t, nruns, x0, x1, yrow, parent, root, idmap, rs, sm_scan);
+    const int nwords = a.ny * a.W;
+    const uint64_t *mg = a.mask + (int64_t)t * nwords;
+    const uint64_t *mrow = mg;
+    if (nwords <= CTK_LDS_MASKW) {                                  // stage the timestep's mask (8.7 KB at 1 deg)
+        for (int i = (int)threadIdx.x; i < nwords; i += 256) mlds[i] = mg[i];
+        mrow = mlds;
+    }
+    label2d_body<256>(a, t, nruns, x0, x1, yrow, parent, root, idmap, rs, sm_scan, mrow);
 }
 
 __global__ __launch_bounds__(256) void k_label2d_glb(Label2dArgs a, uint32_t *g_rs /* [T][ny+1] scratch */)
@@ -440,7 +493,7 @@ __global__ __launch_bounds__(256) void k_label2d_glb(Label2dArgs a, uint32_t *g_
     if (!(nruns > CTK_LDS_RUNS || a.ny > CTK_LDS_NY)) return;
     __shared__ uint32_t sm_scan[8];
     label2d_body<256>(a, t, nruns, a.g_x0 + rb, a.g_x1 + rb, a.g_y + rb, a.g_parent + rb, a.g_root + rb,
-                      a.g_idmap + rb, g_rs + (int64_t)t * (a.ny + 1), sm_scan);
+                      a.g_idmap + rb, g_rs + (int64_t)t * (a.ny + 1), sm_scan, a.mask + (int64_t)t * a.ny * a.W);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -486,11 +539,13 @@ __global__ __launch_bounds__(256) void k_compact_seams(const CtkSeam *__restrict
 
 struct OverlapArgs {
     const uint64_t *mask;
+    const uint16_t *wstart;
     const uint32_t *rowstart;
     const uint32_t *run_base;
     const uint32_t *run_comp;
     // halo = last timestep of the previous shard (used for t == 0 when has_prev)
     const uint64_t *halo_mask;
+    const uint16_t *halo_wstart;
     const uint32_t *halo_rowstart;
     const uint32_t *halo_run_comp;
     int has_prev;
@@ -515,7 +570,7 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
 {
     const int t = (int)blockIdx.x;
     if (t == 0 && !a.has_prev) return;
-    const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, nwv = 256 >> 6;
+    const int tid = (int)threadIdx.x;
     const int ny = a.ny, W = a.W;
     __shared__ unsigned long long hkey[CTK_HASH_SLOTS];
     __shared__ long long hlo[CTK_HASH_SLOTS], hhi[CTK_HASH_SLOTS];
@@ -524,59 +579,53 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
     for (int i = tid; i < CTK_HASH_SLOTS; i += 256) { hkey[i] = FULL64; hlo[i] = 0; hhi[i] = 0; }
     __syncthreads();
 
-    const uint64_t *mc = a.mask + (int64_t)t * ny * W;
+    const int nwords = ny * W;
+    const uint64_t *mc = a.mask + (int64_t)t * nwords;
+    const uint16_t *wsc = a.wstart + (int64_t)t * nwords;
     const uint32_t *rsc = a.rowstart + (int64_t)t * ny;
     const uint32_t *rcc = a.run_comp + a.run_base[t];
     const uint64_t *mp;
+    const uint16_t *wsp;
     const uint32_t *rsp, *rcp;
-    if (t == 0) { mp = a.halo_mask; rsp = a.halo_rowstart; rcp = a.halo_run_comp; }
-    else { mp = a.mask + (int64_t)(t - 1) * ny * W; rsp = a.rowstart + (int64_t)(t - 1) * ny; rcp = a.run_comp + a.run_base[t - 1]; }
-
-    for (int y = wv; y < ny; y += nwv) {
-        const uint64_t *rowc = mc + (int64_t)y * W, *rowp = mp + (int64_t)y * W;
-        uint32_t basec = rsc[y], basep = rsp[y];
-        uint64_t carryc = 0, carryp = 0;
+    if (t == 0) { mp = a.halo_mask; wsp = a.halo_wstart; rsp = a.halo_rowstart; rcp = a.halo_run_comp; }
+    else {
+        mp = a.mask + (int64_t)(t - 1) * nwords; wsp = a.wstart + (int64_t)(t - 1) * nwords;
+        rsp = a.rowstart + (int64_t)(t - 1) * ny; rcp = a.run_comp + a.run_base[t - 1];
+    }
+    // one thread per mask word; all loads are independent of each other
+    for (int idx = tid; idx < nwords; idx += 256) {
+        const uint64_t c = mc[idx], p = mp[idx];
+        uint64_t o = c & p;
+        if (o == 0ull) continue;
+        const int y = idx / W, w = idx - y * W;
+        const uint64_t cinc = (w > 0) ? (mc[idx - 1] >> 63) : 0ull, cinp = (w > 0) ? (mp[idx - 1] >> 63) : 0ull;
+        const uint64_t sc = c & ~((c << 1) | cinc), sp = p & ~((p << 1) | cinp);
+        const uint32_t ec = rsc[y] + wsc[idx], ep = rsp[y] + wsp[idx];            // runs started left of this word
         const int64_t wl = a.wlo[y], wh = a.whi[y];
-        for (int w0 = 0; w0 < W; w0 += WAVE) {
-            const int wn = min(WAVE, W - w0);
-            uint64_t c = (lane < wn) ? rowc[w0 + lane] : 0ull;
-            uint64_t p = (lane < wn) ? rowp[w0 + lane] : 0ull;
-            uint64_t pc = shfl_up_u64(c, 1), pp = shfl_up_u64(p, 1);
-            uint64_t sc = c & ~((c << 1) | ((lane == 0) ? carryc : (pc >> 63)));
-            uint64_t sp = p & ~((p << 1) | ((lane == 0) ? carryp : (pp >> 63)));
-            uint32_t nc = (uint32_t)__popcll(sc), np = (uint32_t)__popcll(sp);
-            uint32_t ic = wave_incl_scan_u32(nc), ip = wave_incl_scan_u32(np);
-            uint32_t ec = basec + ic - nc, ep = basep + ip - np;       // runs started before this word
-            uint64_t o = c & p;
-            while (o) {
-                int b = __builtin_ctzll(o);
-                uint64_t sh = o >> b;
-                int n = (~sh == 0ull) ? 64 : __builtin_ctzll(~sh);
-                uint64_t below = (b + 1 >= 64) ? FULL64 : ((1ull << (b + 1)) - 1ull);   // bits 0..b
-                uint32_t rcur = ec + (uint32_t)__popcll(sc & below) - 1u;
-                uint32_t rprv = ep + (uint32_t)__popcll(sp & below) - 1u;
-                uint32_t cc = rcc[rcur], cd = rcp[rprv];
-                int64_t lo = (int64_t)n * wl, hi = (int64_t)n * wh;
-                unsigned long long key = ((unsigned long long)cc << 32) | cd;
-                uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (CTK_HASH_SLOTS - 1);
-                bool placed = false;
-                for (int q = 0; q < CTK_HASH_PROBES; q++) {
-                    unsigned long long old = atomicCAS(&hkey[h], FULL64, key);
-                    if (old == FULL64 || old == key) {
-                        atomicAdd((unsigned long long *)&hlo[h], (unsigned long long)lo);
-                        atomicAdd((unsigned long long *)&hhi[h], (unsigned long long)hi);
-                        placed = true;
-                        break;
-                    }
-                    h = (h + 1) & (CTK_HASH_SLOTS - 1);
+        while (o) {
+            const int b = __builtin_ctzll(o);
+            const uint64_t sh = o >> b;
+            const int n = (~sh == 0ull) ? 64 : __builtin_ctzll(~sh);
+            const uint64_t below = (b + 1 >= 64) ? FULL64 : ((1ull << (b + 1)) - 1ull);   // bits 0..b
+            const uint32_t rcur = ec + (uint32_t)__popcll(sc & below) - 1u;
+            const uint32_t rprv = ep + (uint32_t)__popcll(sp & below) - 1u;
+            const uint32_t cc = rcc[rcur], cd = rcp[rprv];
+            const int64_t lo = (int64_t)n * wl, hi = (int64_t)n * wh;
+            const unsigned long long key = ((unsigned long long)cc << 32) | cd;
+            uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (CTK_HASH_SLOTS - 1);
+            bool placed = false;
+            for (int q = 0; q < CTK_HASH_PROBES; q++) {
+                const unsigned long long old = atomicCAS(&hkey[h], FULL64, key);
+                if (old == FULL64 || old == key) {
+                    atomicAdd((unsigned long long *)&hlo[h], (unsigned long long)lo);
+                    atomicAdd((unsigned long long *)&hhi[h], (unsigned long long)hi);
+                    placed = true;
+                    break;
                 }
-                if (!placed) emit_pair(a, (uint32_t)t, cc, cd, lo, hi);
-                o = (n >= 64 - b) ? 0ull : (o & ~(((1ull << n) - 1ull) << b));
+                h = (h + 1) & (CTK_HASH_SLOTS - 1);
             }
-            basec += __shfl(ic, WAVE - 1);
-            basep += __shfl(ip, WAVE - 1);
-            carryc = shfl_u64(c, wn - 1) >> 63;
-            carryp = shfl_u64(p, wn - 1) >> 63;
+            if (!placed) emit_pair(a, (uint32_t)t, cc, cd, lo, hi);
+            o = (n >= 64 - b) ? 0ull : (o & ~(((1ull << n) - 1ull) << b));
         }
     }
     __syncthreads();
@@ -603,12 +652,12 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
 // ------------------------------------------------------------------------------------------------
 // per-pixel fold of the ordered seam operations (contrack/contrack.py:753-763 semantics, see
 // ctk_resolve.cpp): only used for the rare "complex" components.
-//   oi_hi / oi_idx : op indices sorted by (hi, execution index)
+//   first / next : per label, the chain of ops that have it as `hi`, in execution order
 // ------------------------------------------------------------------------------------------------
 struct FoldArgs {
-    const CtkOp *ops;
-    const int32_t *oi_hi;
-    const int32_t *oi_idx;
+    const CtkOp *ops;          // execution order
+    const int32_t *first;      // [n_labels + 1] first op that has the label as `hi` (-1: none)
+    const int32_t *next;       // [nops] next op with the same `hi`
     int32_t nops;
 };
 
@@ -616,11 +665,8 @@ __device__ inline int32_t fold_pixel(const FoldArgs &f, int32_t l, int32_t t, in
 {
     int32_t s = 0;
     for (;;) {
-        int32_t lo = 0, hi = f.nops;                       // first entry with oi_hi >= l
-        while (lo < hi) { int32_t m = (lo + hi) >> 1; if (f.oi_hi[m] < l) lo = m + 1; else hi = m; }
         bool moved = false;
-        for (int32_t k = lo; k < f.nops && f.oi_hi[k] == l; k++) {
-            int32_t idx = f.oi_idx[k];
+        for (int32_t idx = f.first[l]; idx >= 0; idx = f.next[idx]) {
             if (idx < s) continue;
             const CtkOp o = f.ops[idx];
             if (t >= o.t0 && t <= o.t1 && y >= o.y0 && y <= o.y1 && x >= o.x0 && x <= o.x1) {
@@ -747,6 +793,7 @@ __global__ __launch_bounds__(256) void k_run_values(const uint32_t *__restrict__
 // ------------------------------------------------------------------------------------------------
 struct RelabelArgs {
     const uint64_t *mask;
+    const uint16_t *wstart;
     const uint32_t *rowstart;
     const uint32_t *run_base;
     const int32_t *run_val;
@@ -760,6 +807,67 @@ struct RelabelArgs {
     int64_t nrows;
     int ny, nx, W;
 };
+
+// fast path (nx % 4 == 0, 16-byte aligned flag): one workgroup per (timestep, 16 rows).  The rows' mask
+// words, per-word run prefixes, row starts and the final values of their runs are staged in LDS first, so the
+// store stream has no dependent global loads: one lane per 4 consecutive pixels, non-temporal int4 stores.
+#define CTK_RV_LDS 1024
+__global__ __launch_bounds__(256) void k_relabel_v4(RelabelArgs a)
+{
+    const int ny = a.ny, nx = a.nx, W = a.W;
+    const int nchunk = (ny + CTK_RB - 1) / CTK_RB;
+    const int t = (int)(blockIdx.x / (unsigned)nchunk), y0 = (int)(blockIdx.x - (unsigned)t * nchunk) * CTK_RB, tid = (int)threadIdx.x;
+    const int rows = min(CTK_RB, ny - y0);
+    const int64_t row0 = (int64_t)t * ny + y0;
+    __shared__ uint64_t mrow[CTK_RB * 64];                 // W <= 64 on this path
+    __shared__ uint16_t wst[CTK_RB * 64];
+    __shared__ uint32_t rst[CTK_RB + 1];
+    __shared__ int32_t rvs[CTK_RV_LDS];
+    const uint32_t trun = a.run_base[t + 1] - a.run_base[t];
+    for (int i = tid; i < rows * W; i += 256) { mrow[i] = a.mask[row0 * W + i]; wst[i] = a.wstart[row0 * W + i]; }
+    for (int i = tid; i <= rows; i += 256) rst[i] = (y0 + i < ny) ? a.rowstart[row0 + i] : trun;
+    __syncthreads();
+    const uint32_t r0 = rst[0], nr = rst[rows] - r0;
+    const int32_t *rvg = a.run_val + a.run_base[t] + r0;
+    const bool staged = nr <= CTK_RV_LDS;
+    if (staged) for (uint32_t i = tid; i < nr; i += 256) rvs[i] = rvg[i];
+    __syncthreads();
+    const int n4 = nx >> 2, total = rows * n4;
+    i32x4 *dst = reinterpret_cast<i32x4 *>(a.flag + row0 * (int64_t)nx);
+    bool z = false;
+    for (int i = tid; i < total; i += 256) {
+        const int r = i / n4, c = i - r * n4;
+        const int x = c << 2, w = x >> 6, xb = x & 63;
+        const uint64_t m = mrow[r * W + w];
+        const uint32_t nib = (uint32_t)(m >> xb) & 0xfu;
+        i32x4 out = (i32x4)(0);
+        if (nib) {
+            const uint64_t cin = (w > 0) ? (mrow[r * W + w - 1] >> 63) : 0ull;
+            const uint64_t st = m & ~((m << 1) | cin);
+            const uint32_t base = rst[r] - r0 + wst[r * W + w];
+            int32_t v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                v[j] = 0;
+                if ((nib >> j) & 1u) {
+                    const int bit = xb + j;
+                    const uint64_t below = (bit == 63) ? FULL64 : ((1ull << (bit + 1)) - 1ull);
+                    const uint32_t k = base + (uint32_t)__popcll(st & below) - 1u;
+                    int32_t val = staged ? rvs[k] : rvg[k];
+                    if (val < 0) {                                              // complex component: fold this pixel
+                        const int32_t fl = fold_pixel(a.fold, -val, (int32_t)(a.t_begin + t), y0 + r, x + j);
+                        val = ((int64_t)a.ext[a.n_labels + 1 + fl] - (int64_t)a.ext[fl] + 1 < a.persistence) ? 0 : fl;
+                    }
+                    v[j] = val;
+                }
+            }
+            out.x = v[0]; out.y = v[1]; out.z = v[2]; out.w = v[3];
+        }
+        __builtin_nontemporal_store(out, dst + (int64_t)r * n4 + c);
+        z |= (out.x == 0) | (out.y == 0) | (out.z == 0) | (out.w == 0);
+    }
+    if (__ballot(z) && lane_id() == 0 && a.counters[CTK_CNT_WROTE_ZERO] == 0) atomicOr(&a.counters[CTK_CNT_WROTE_ZERO], 1u);
+}
 
 __global__ __launch_bounds__(256) void k_relabel(RelabelArgs a)
 {
@@ -829,6 +937,12 @@ __global__ void k_fill_ext(int32_t *ext, int64_t n_labels)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i <= n_labels) { ext[i] = INT32_MAX; ext[n_labels + 1 + i] = INT32_MIN; }
+}
+
+__global__ void k_scatter_i32(const int32_t *__restrict__ where, const int32_t *__restrict__ what, int n, int32_t *__restrict__ dst)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[where[i]] = what[i];
 }
 
 // mask words -> one byte per pixel (debug / staged parity)

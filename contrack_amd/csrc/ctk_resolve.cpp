@@ -306,6 +306,7 @@ extern "C" int ctk_resolve(const void *const *blobs, const size_t *nbytes, int n
         // of the ops over its fresh label.
         std::vector<CtkOp> ops;
         std::vector<std::vector<int32_t>> ops_of((size_t)nlab + 1);     // op indices by `hi`, ascending
+        std::vector<int32_t> inflow((size_t)nlab + 1, -1);              // last recorded op whose `lo` is the label
         auto fold_pixel = [&](int32_t l, int32_t t, int32_t y, int32_t x) {
             int32_t s = 0;
             for (;;) {
@@ -325,7 +326,11 @@ extern "C" int ctk_resolve(const void *const *blobs, const size_t *nbytes, int n
             int32_t p1 = fold_pixel(lab[(size_t)(coff[(size_t)t] + q.cr)], (int32_t)t, (int32_t)q.y, nx - 1);
             if (p0 == p1) continue;
             int32_t hi = std::max(p0, p1), lo = std::min(p0, p1);
+            // nothing has flowed into hi since its last op: no pixel labelled hi is left inside box[hi], the
+            // relabel of contrack.py:759/763 finds nothing -- not recorded (keeps the chains short)
+            if (!ops_of[(size_t)hi].empty() && inflow[(size_t)hi] < ops_of[(size_t)hi].back()) continue;
             const Box3 &b = bx[(size_t)hi];
+            inflow[(size_t)lo] = (int32_t)ops.size();
             ops_of[(size_t)hi].push_back((int32_t)ops.size());
             ops.push_back(CtkOp{hi, lo, b.t0, b.t1, b.y0, b.y1, b.x0, b.x1});
         }

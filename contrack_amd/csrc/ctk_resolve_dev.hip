@@ -259,19 +259,42 @@ __global__ void k_rs_boxes(ResolveDev r, int64_t t_begin)
     }
 }
 
+// Only labels that occur in some seam row with two DIFFERENT labels can ever take part in a relabel
+// operation (the first op needs such a row; every later `hi`/`lo` is a label of such a row or the `lo` of an
+// earlier op).  Rows with equal labels that are not marked can therefore be dropped before the host driver.
+__global__ __launch_bounds__(256) void k_rs_cand_mark(ResolveDev r, const CtkSeam *__restrict__ scratch, const uint32_t *__restrict__ seam_cnt,
+                                                      int ny, uint8_t *__restrict__ mark)
+{
+    const int t = (int)blockIdx.x;
+    const uint32_t n = seam_cnt[t], cb = r.cprefix[t];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const CtkSeam q = scratch[(int64_t)t * ny + i];
+        if (!r.keep0[cb + r.mrep[cb + q.cl]]) continue;
+        const int32_t ll = r.lab[cb + q.cl], lr = r.lab[cb + q.cr];
+        if (ll != lr) { mark[ll] = 1; mark[lr] = 1; }
+    }
+}
+
+__device__ __forceinline__ bool cand_wanted(const ResolveDev &r, const CtkSeam &q, uint32_t cb, const uint8_t *mark)
+{
+    if (!r.keep0[cb + r.mrep[cb + q.cl]]) return false;
+    const int32_t ll = r.lab[cb + q.cl], lr = r.lab[cb + q.cr];
+    return ll != lr || mark[ll] != 0;
+}
+
 // surviving seam rows of timestep t -> {t, y, label at x=0, label at x=nx-1}, (t, y) order
 struct CtkCand {
     int32_t t, y, ll, lr;
 };
 __global__ __launch_bounds__(256) void k_rs_cand_count(ResolveDev r, const CtkSeam *__restrict__ scratch, const uint32_t *__restrict__ seam_cnt,
-                                                       int ny, uint32_t *__restrict__ cand_cnt)
+                                                       int ny, const uint8_t *__restrict__ mark, uint32_t *__restrict__ cand_cnt)
 {
     const int t = (int)blockIdx.x;
     const uint32_t n = seam_cnt[t], cb = r.cprefix[t];
     uint32_t s = 0;
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const CtkSeam q = scratch[(int64_t)t * ny + i];
-        s += r.keep0[cb + r.mrep[cb + q.cl]] ? 1u : 0u;
+        s += cand_wanted(r, q, cb, mark) ? 1u : 0u;
     }
     __shared__ uint32_t sm[8];
     uint32_t tot;
@@ -279,7 +302,8 @@ __global__ __launch_bounds__(256) void k_rs_cand_count(ResolveDev r, const CtkSe
     if (threadIdx.x == 0) cand_cnt[t] = tot;
 }
 __global__ __launch_bounds__(256) void k_rs_cand_write(ResolveDev r, const CtkSeam *__restrict__ scratch, const uint32_t *__restrict__ seam_cnt,
-                                                       int ny, const uint32_t *__restrict__ cand_off, int64_t t_begin, CtkCand *__restrict__ out)
+                                                       int ny, const uint8_t *__restrict__ mark, const uint32_t *__restrict__ cand_off, int64_t t_begin,
+                                                       CtkCand *__restrict__ out)
 {
     const int t = (int)blockIdx.x;
     const uint32_t n = seam_cnt[t], cb = r.cprefix[t];
@@ -289,7 +313,7 @@ __global__ __launch_bounds__(256) void k_rs_cand_write(ResolveDev r, const CtkSe
         const uint32_t i = i0 + threadIdx.x;
         CtkSeam q;
         uint32_t v = 0;
-        if (i < n) { q = scratch[(int64_t)t * ny + i]; v = r.keep0[cb + r.mrep[cb + q.cl]] ? 1u : 0u; }
+        if (i < n) { q = scratch[(int64_t)t * ny + i]; v = cand_wanted(r, q, cb, mark) ? 1u : 0u; }
         uint32_t tot;
         uint32_t ex = block_excl_scan(v, sm, &tot);
         if (v) {
@@ -316,10 +340,7 @@ __global__ void k_rs_final(ResolveDev r, FoldArgs f, int64_t t_begin, int32_t *_
         bool cplx = false;
         for (bool again = true; again && !cplx;) {
             again = false;
-            int32_t lo = 0, hi = f.nops;
-            while (lo < hi) { int32_t m = (lo + hi) >> 1; if (f.oi_hi[m] < cur) lo = m + 1; else hi = m; }
-            for (int32_t k = lo; k < f.nops && f.oi_hi[k] == cur; k++) {
-                const int32_t idx = f.oi_idx[k];
+            for (int32_t idx = f.first[cur]; idx >= 0; idx = f.next[idx]) {
                 if (idx < s) continue;
                 const CtkOp o = f.ops[idx];
                 const bool t_in = t >= o.t0 && t <= o.t1;
