@@ -116,7 +116,7 @@ def main():
                    parallelism="1 GPU", n_tracked=n_tracked, coverage=float((a >= np.float32(wl["threshold"])).mean())),
                roofline=dict(bound="hbm", kernel=kern, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                              traffic=None, algorithmic_bytes_per_launch=alg_bytes[kern], avg_kernel_ms=per.get(kern)),
-               kernels_ms=per,
+               kernels_ms=per, workload_stats=trk.stats(),
                path_effective_gbs=8.0 * px / (ms_per_step * 1e-3) / 1e9)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, a, w)

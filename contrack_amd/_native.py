@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcontrack_hip.so")
+LIB_PATH = os.environ.get("CTK_LIB", os.path.join(_HERE, "libcontrack_hip.so"))
 _lib = None
 
 CMP_OPS = {">=": 0, "ge": 0, "<=": 1, "le": 1, ">": 2, "gt": 2, "<": 3, "lt": 3}
@@ -23,7 +23,7 @@ EXPORTS = [
     "ctk_track_f32_dev", "ctk_track_f64", "ctk_track_f64_dev", "ctk_shard_label2d", "ctk_shard_label2d_f64", "ctk_shard_halo_size", "ctk_shard_halo_export",
     "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_resolve", "ctk_result_free",
     "ctk_result_info", "ctk_result_arrays", "ctk_result_nshards", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
-    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_set_timing", "ctk_get_timings", "ctk_set_device_resolve",
+    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_set_timing", "ctk_get_timings", "ctk_set_device_resolve", "ctk_get_stats",
     "ctk_dev_malloc", "ctk_dev_free", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
     "ctk_synth_fill",
 ]
@@ -75,6 +75,7 @@ def lib():
     L.ctk_set_timing.argtypes = [p, i32]
     L.ctk_get_timings.argtypes = [p, p]
     L.ctk_set_device_resolve.argtypes = [p, i32]
+    L.ctk_get_stats.argtypes = [p, p]
     L.ctk_dev_malloc.argtypes = [p, pp, sz]
     L.ctk_dev_free.argtypes = [p, p]
     L.ctk_memcpy_h2d.argtypes = [p, p, p, sz]
@@ -246,6 +247,13 @@ class Tracker:
 
     def set_timing(self, on=True):
         check(lib().ctk_set_timing(self._h, int(bool(on))))
+
+    def stats(self):
+        v = np.zeros(12, dtype=np.int64)
+        check(lib().ctk_get_stats(self._h, v.ctypes.data))
+        names = ["runs", "max_runs_per_step", "components", "pairs", "seam_rows_to_driver", "labels_3d", "seam_ops",
+                 "filter_passes", "host_path", "seam_loop_ns", "seam_folds"]
+        return dict(zip(names, v.tolist()))
 
     def set_device_resolve(self, on=True):
         check(lib().ctk_set_device_resolve(self._h, int(bool(on))))

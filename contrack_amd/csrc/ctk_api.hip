@@ -56,13 +56,21 @@ struct ctk_handle {
     DevBuf run_comp, run_val, cs_mrep, cs_box, cs_area, d_mrep, d_box, d_area, comp_label;
     DevBuf g_x0, g_x1, g_y, g_parent, g_root, g_idmap, g_rs;
     DevBuf pairs, seams, ext, ops, op_first, op_next, op_stage, halo_in, halo_out, dbg;
-    DevBuf seam_cnt, seam_off, d_seams, d_comp_t;
+    DevBuf seam_cnt, seam_off, d_seams, d_comp_t, pair_base, pair_cnt, rv_tdirty;
     // device resolver work space
     DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lbox,
         rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_scalars, rv_mark;
     void *h_cand = nullptr;          // pinned: candidates + boxes download
     size_t h_cand_cap = 0;
+    void *h_ops = nullptr;           // pinned: op upload staging
+    size_t h_ops_cap = 0;
+    const int32_t *d_op_next = nullptr;
     int use_device_resolve = 1;
+    // host scratch of the seam driver, kept between calls (fresh 100+ KB vectors would page-fault every call)
+    std::vector<int32_t> sd_first, sd_last, sd_inflow, sd_next;
+    std::vector<uint64_t> sd_hasop;
+    std::vector<CtkOp> sd_ops;
+    int64_t stats[CTK_NSTATS] = {0};
     // host (pinned) buffers
     void *h_blob = nullptr;
     size_t h_blob_cap = 0, h_blob_bytes = 0;
@@ -196,13 +204,14 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->counters, &h->run_comp, &h->run_val, &h->cs_mrep, &h->cs_box, &h->cs_area, &h->d_mrep, &h->d_box, &h->d_area,
                       &h->comp_label, &h->g_x0, &h->g_x1, &h->g_y, &h->g_parent, &h->g_root, &h->g_idmap, &h->g_rs, &h->pairs, &h->seams,
                       &h->ext, &h->ops, &h->op_first, &h->op_next, &h->op_stage, &h->halo_in, &h->halo_out, &h->dbg, &h->seam_cnt, &h->seam_off, &h->d_seams,
-                      &h->d_comp_t, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
+                      &h->d_comp_t, &h->pair_base, &h->pair_cnt, &h->rv_tdirty, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
                       &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_scalars, &h->rv_mark};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
     if (h->h_cand) (void)hipHostFree(h->h_cand);
+    if (h->h_ops) (void)hipHostFree(h->h_ops);
     if (h->ev_ready) for (int k = 0; k <= CTK_K_COUNT; k++) { (void)hipEventDestroy(h->ev[k][0]); (void)hipEventDestroy(h->ev[k][1]); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -217,6 +226,13 @@ extern "C" int ctk_set_timing(ctk_handle *h, int enable)
         h->ev_ready = true;
     }
     h->timing = enable;
+    return CTK_OK;
+}
+
+extern "C" int ctk_get_stats(ctk_handle *h, int64_t *out)
+{
+    if (!h || !out) return ctk_set_error(CTK_E_INVALID, "null argument");
+    memcpy(out, h->stats, sizeof(h->stats));
     return CTK_OK;
 }
 
@@ -284,7 +300,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     CTKCHK(ensure(h, h->wlo, (size_t)ny * 4));
     CTKCHK(ensure(h, h->whi, (size_t)ny * 4));
     CTKCHK(ensure(h, h->counters, CTK_CNT_N * 4));
-    CTKCHK(ensure_host(&h->h_small, &h->h_small_cap, (size_t)(T + 1) * 4 + 256));
+    CTKCHK(ensure_host(&h->h_small, &h->h_small_cap, (size_t)(T + 1) * 4 + 1024));     // run_base copy + scalar downloads
 
     HIPCHK(hipMemsetAsync(h->counters.p, 0, CTK_CNT_N * 4, s));
     if (T > 0) {
@@ -332,6 +348,8 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     h->max_runs_step = 0;
     for (int64_t t = 0; t < T; t++) h->max_runs_step = std::max(h->max_runs_step, hb[t + 1] - hb[t]);
     h->need_glb = (h->max_runs_step > CTK_LDS_RUNS) || (ny > CTK_LDS_NY);
+    memset(h->stats, 0, sizeof(h->stats));
+    h->stats[CTK_S_RUNS] = h->total_runs; h->stats[CTK_S_MAX_RUNS_STEP] = h->max_runs_step;
     const size_t R = h->total_runs;
     CTKCHK(ensure(h, h->run_comp, R * 4));
     CTKCHK(ensure(h, h->run_val, R * 4));
@@ -466,6 +484,7 @@ static int launch_overlap(ctk_handle *h)
     a.halo_run_comp = hl ? (const uint32_t *)(hl + halo_off_runcomp(h)) : nullptr;
     a.has_prev = (h->has_prev && hl) ? 1 : 0;
     a.pairs = P<CtkPair>(h->pairs); a.pair_cap = h->pair_cap; a.counters = P<uint32_t>(h->counters);
+    a.pair_base = P<uint32_t>(h->pair_base); a.pair_cnt = P<uint32_t>(h->pair_cnt);
     a.wlo = P<int32_t>(h->wlo); a.whi = P<int32_t>(h->whi);
     a.ny = h->ny; a.nx = h->nx; a.W = h->W;
     Timer tm(h, CTK_K_OVERLAP);
@@ -486,6 +505,8 @@ extern "C" int ctk_shard_overlap(ctk_handle *h)
         CTKCHK(ensure(h, h->pairs, want * sizeof(CtkPair)));
         h->pair_cap = (uint32_t)std::min<size_t>(h->pairs.cap / sizeof(CtkPair), 0x7fffffffull);
     }
+    CTKCHK(ensure(h, h->pair_base, (size_t)h->T * 4));
+    CTKCHK(ensure(h, h->pair_cnt, (size_t)h->T * 4));
     if (h->T > 0) CTKCHK(launch_overlap(h));
     h->state = ST_OVERLAPPED;
     return CTK_OK;
@@ -514,22 +535,23 @@ extern "C" int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes
         memcpy(cnt, hc, sizeof(cnt));
         ctot = hc[CTK_CNT_N];
         stot = hc[CTK_CNT_N + 1];
-        if (!(cnt[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS)) break;
+        if (!(cnt[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) && (uint64_t)cnt[CTK_CNT_PAIRS] + cnt[CTK_CNT_UPAIRS] <= h->pair_cap) break;
         if (attempt >= 6) return ctk_set_error(CTK_E_RANGE, "pair table keeps overflowing");
         // grow the pair table to what was asked for and redo the histogram
-        size_t want = std::max<size_t>((size_t)cnt[CTK_CNT_PAIRS] + 1024, (size_t)h->pair_cap * 2);
+        size_t want = std::max<size_t>((size_t)cnt[CTK_CNT_PAIRS] + cnt[CTK_CNT_UPAIRS] + 1024, (size_t)h->pair_cap * 2);
         if (want > 0xfffffff0ull) return ctk_set_error(CTK_E_RANGE, "pair table beyond 2^32 records");
         CTKCHK(ensure(h, h->pairs, want * sizeof(CtkPair)));
         h->pair_cap = (uint32_t)std::min<size_t>(h->pairs.cap / sizeof(CtkPair), 0xfffffff0ull);
         uint32_t zero[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(P<uint32_t>(h->counters) + CTK_CNT_PAIRS, zero, 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(P<uint32_t>(h->counters) + CTK_CNT_UPAIRS, zero, 4, hipMemcpyHostToDevice, s));
         uint32_t ovf = cnt[CTK_CNT_OVERFLOW] & ~CTK_OVF_PAIRS;
         HIPCHK(hipMemcpyAsync(P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, &ovf, 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
         CTKCHK(launch_overlap(h));
     }
     h->total_comps = ctot;
-    const int64_t T = h->T, NC = ctot, NP = cnt[CTK_CNT_PAIRS], NS = stot;
+    const int64_t T = h->T, NC = ctot, NPG = cnt[CTK_CNT_PAIRS], NPU = cnt[CTK_CNT_UPAIRS], NP = NPG + NPU, NS = stot;
     if (NS) {
         CTKCHK(ensure(h, h->d_seams, (size_t)NS * sizeof(CtkSeam)));
         k_compact_seams<<<(int)T, 256, 0, s>>>(P<CtkSeam>(h->seams), P<uint32_t>(h->seam_cnt), P<uint32_t>(h->seam_off), h->ny, P<CtkSeam>(h->d_seams));
@@ -550,7 +572,9 @@ extern "C" int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes
     p += ctk_align8((size_t)NC * 8);
     if (NC) HIPCHK(hipMemcpyAsync(p, h->d_area.p, (size_t)NC * 16, hipMemcpyDeviceToHost, s));
     p += (size_t)NC * 16;
-    if (NP) HIPCHK(hipMemcpyAsync(p, h->pairs.p, (size_t)NP * sizeof(CtkPair), hipMemcpyDeviceToHost, s));
+    if (NPG) HIPCHK(hipMemcpyAsync(p, h->pairs.p, (size_t)NPG * sizeof(CtkPair), hipMemcpyDeviceToHost, s));
+    if (NPU) HIPCHK(hipMemcpyAsync(p + (size_t)NPG * sizeof(CtkPair), P<CtkPair>(h->pairs) + (h->pair_cap - NPU), (size_t)NPU * sizeof(CtkPair),
+                                   hipMemcpyDeviceToHost, s));
     p += (size_t)NP * sizeof(CtkPair);
     if (NS) HIPCHK(hipMemcpyAsync(p, h->d_seams.p, (size_t)NS * sizeof(CtkSeam), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -568,38 +592,44 @@ extern "C" int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes
 static FoldArgs fold_args(const ctk_handle *h)
 {
     FoldArgs f;
-    f.ops = P<CtkOp>(h->ops); f.first = P<int32_t>(h->op_first); f.next = P<int32_t>(h->op_next); f.nops = h->nops;
+    f.ops = P<CtkOp>(h->ops); f.first = P<int32_t>(h->op_first); f.next = h->d_op_next; f.nops = h->nops;
     return f;
 }
 
-// ops in execution order -> device, plus the per-label chains (first[label], next[op]) the folds walk
+// ops in execution order -> device, plus the per-label chains (first[label], next[op]) the folds walk.
+// One pinned staging block, one H2D copy: [CtkOp ops[n]] [int32 next[n]] [int32 hi_label[nf]] [int32 first_op[nf]]
+static int prepare_op_first(ctk_handle *h, int64_t n_labels)
+{
+    CTKCHK(ensure(h, h->op_first, (size_t)(n_labels + 1) * 4));
+    HIPCHK(hipMemsetAsync(h->op_first.p, 0xff, (size_t)(n_labels + 1) * 4, h->stream));    // all -1
+    return CTK_OK;
+}
+
 static int upload_ops(ctk_handle *h, const CtkOp *ops, int64_t nops, int64_t n_labels)
 {
     hipStream_t s = h->stream;
     h->nops = (int32_t)nops;
-    CTKCHK(ensure(h, h->op_first, (size_t)(n_labels + 1) * 4));
-    HIPCHK(hipMemsetAsync(h->op_first.p, 0xff, (size_t)(n_labels + 1) * 4, s));            // all -1
     if (!nops) return CTK_OK;
-    // chains: only the labels that occur as `hi` need a first[] entry; scatter those few words on the device
-    std::vector<int32_t> next((size_t)nops, -1), order((size_t)nops), fl_label, fl_idx;
-    for (int32_t i = 0; i < (int32_t)nops; i++) order[(size_t)i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return ops[a].hi < ops[b].hi; });
-    for (size_t i = 0; i < order.size(); i++) {
-        const int32_t idx = order[i];
-        if (i + 1 < order.size() && ops[order[i + 1]].hi == ops[idx].hi) next[(size_t)idx] = order[i + 1];
-        if (i == 0 || ops[order[i - 1]].hi != ops[idx].hi) { fl_label.push_back(ops[idx].hi); fl_idx.push_back(idx); }
+    const size_t bytes = (size_t)nops * (sizeof(CtkOp) + 4 + 8);
+    CTKCHK(ensure_host(&h->h_ops, &h->h_ops_cap, bytes));
+    CTKCHK(ensure(h, h->ops, bytes));
+    CtkOp *s_ops = (CtkOp *)h->h_ops;
+    int32_t *s_next = (int32_t *)(s_ops + nops), *s_label = s_next + nops, *s_first = s_label + nops;
+    memcpy(s_ops, ops, (size_t)nops * sizeof(CtkOp));
+    std::vector<int32_t> &last = h->sd_last;                                   // scratch: last op seen per `hi`
+    last.assign((size_t)n_labels + 1, -1);
+    size_t nf = 0;
+    for (int32_t i = 0; i < (int32_t)nops; i++) {
+        const int32_t hi = ops[i].hi;
+        s_next[i] = -1;
+        if (last[(size_t)hi] >= 0) s_next[last[(size_t)hi]] = i; else { s_label[nf] = hi; s_first[nf] = i; nf++; }
+        last[(size_t)hi] = i;
     }
-    const size_t nf = fl_label.size();
-    CTKCHK(ensure(h, h->ops, (size_t)nops * sizeof(CtkOp)));
-    CTKCHK(ensure(h, h->op_next, (size_t)nops * 4));
-    CTKCHK(ensure(h, h->op_stage, nf * 8));
-    HIPCHK(hipMemcpyAsync(h->ops.p, ops, (size_t)nops * sizeof(CtkOp), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->op_next.p, next.data(), (size_t)nops * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->op_stage.p, fl_label.data(), nf * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(P<int32_t>(h->op_stage) + nf, fl_idx.data(), nf * 4, hipMemcpyHostToDevice, s));
-    k_scatter_i32<<<(int)((nf + 255) / 256), 256, 0, s>>>(P<int32_t>(h->op_stage), P<int32_t>(h->op_stage) + nf, (int)nf, P<int32_t>(h->op_first));
+    HIPCHK(hipMemcpyAsync(h->ops.p, h->h_ops, bytes, hipMemcpyHostToDevice, s));
+    const int32_t *d_next = (const int32_t *)(P<CtkOp>(h->ops) + nops);
+    h->d_op_next = d_next;
+    k_scatter_i32<<<(int)((nf + 255) / 256), 256, 0, s>>>(d_next + nops, d_next + 2 * nops, (int)nf, P<int32_t>(h->op_first));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));                                         // staging vectors go out of scope
     return CTK_OK;
 }
 
@@ -637,6 +667,7 @@ extern "C" int ctk_shard_extents(ctk_handle *h, const ctk_result *r, int shard, 
     h->n_labels = r->n_labels; h->t_begin = t_begin;
     CTKCHK(ensure(h, h->comp_label, (size_t)(c1 - c0) * 4));
     if (c1 > c0) HIPCHK(hipMemcpyAsync(h->comp_label.p, r->comp_label + c0, (size_t)(c1 - c0) * 4, hipMemcpyHostToDevice, s));
+    CTKCHK(prepare_op_first(h, r->n_labels));
     CTKCHK(upload_ops(h, r->ops, r->nops, r->n_labels));
     HIPCHK(hipStreamSynchronize(s));
     h->ms[CTK_T_H2D] += now_ms() - t0;
@@ -654,9 +685,12 @@ namespace {
 
 // contrack.py:753-763 on {t, y, label at x=0, label at x=nx-1} records in (t, y) order and the boxes of the
 // fresh labels.  Flat arrays: per label the chain of ops that have it as `hi`, in execution order.
-void seam_driver(const CtkCand *cand, int64_t ncand, const int32_t *lbox, int64_t nlab, int nx, std::vector<CtkOp> &ops)
+void seam_driver(ctk_handle *h, const CtkCand *cand, int64_t ncand, const int32_t *lbox, int64_t nlab, int nx, std::vector<CtkOp> &ops)
 {
-    std::vector<int32_t> first((size_t)nlab + 1, -1), last((size_t)nlab + 1, -1), next;
+    std::vector<int32_t> &first = h->sd_first, &last = h->sd_last, &next = h->sd_next;
+    first.assign((size_t)nlab + 1, -1);
+    last.assign((size_t)nlab + 1, -1);
+    next.clear();
     auto fold = [&](int32_t l, int32_t t, int32_t y, int32_t x) {
         int32_t s = 0;
         for (;;) {
@@ -674,12 +708,20 @@ void seam_driver(const CtkCand *cand, int64_t ncand, const int32_t *lbox, int64_
     // while nothing has flowed into hi since hi's last op therefore changes no pixel (the reference runs the
     // same relabel and finds nothing, contrack.py:759/763): it is not recorded.  This keeps the per-label
     // chains short where a stranded fragment sits on the seam for many rows.
-    std::vector<int32_t> inflow((size_t)nlab + 1, -1);       // index of the last recorded op with lo == label
+    std::vector<int32_t> &inflow = h->sd_inflow;             // index of the last recorded op with lo == label
+    inflow.assign((size_t)nlab + 1, -1);
+    std::vector<uint64_t> &hasop = h->sd_hasop;              // bit per label: is `hi` of some op (4 KB: stays in L1)
+    hasop.assign(((size_t)nlab >> 6) + 1, 0);
+    const double t_loop = now_ms();
+    int64_t nfold = 0;
+    auto touched = [&](int32_t l) { return (hasop[(size_t)l >> 6] >> (l & 63)) & 1ull; };
     for (int64_t k = 0; k < ncand; k++) {
         const CtkCand &c = cand[k];
-        if (c.ll == c.lr && first[(size_t)c.ll] < 0) continue;             // same label, never relabelled: nothing can differ
-        const int32_t p0 = first[(size_t)c.ll] < 0 ? c.ll : fold(c.ll, c.t, c.y, 0);
-        const int32_t p1 = first[(size_t)c.lr] < 0 ? c.lr : fold(c.lr, c.t, c.y, nx - 1);
+        const bool tl = touched(c.ll), tr = touched(c.lr);
+        if (c.ll == c.lr && !tl) continue;                                 // same label, never relabelled: nothing can differ
+        const int32_t p0 = tl ? fold(c.ll, c.t, c.y, 0) : c.ll;
+        const int32_t p1 = tr ? fold(c.lr, c.t, c.y, nx - 1) : c.lr;
+        nfold += (tl ? 1 : 0) + (tr ? 1 : 0);
         if (p0 == p1) continue;
         const int32_t hi = std::max(p0, p1), lo = std::min(p0, p1);
         if (last[(size_t)hi] >= 0 && inflow[(size_t)hi] < last[(size_t)hi]) continue;      // nothing to move
@@ -690,7 +732,10 @@ void seam_driver(const CtkCand *cand, int64_t ncand, const int32_t *lbox, int64_
         if (last[(size_t)hi] >= 0) next[(size_t)last[(size_t)hi]] = idx; else first[(size_t)hi] = idx;
         last[(size_t)hi] = idx;
         inflow[(size_t)lo] = idx;
+        hasop[(size_t)hi >> 6] |= 1ull << (hi & 63);
     }
+    h->stats[9] = (int64_t)((now_ms() - t_loop) * 1e6);       // ns spent in the candidate loop
+    h->stats[10] = nfold;
 }
 
 }  // namespace
@@ -714,6 +759,7 @@ static int device_resolve(ctk_handle *h, double overlap, int twosided)
     CTKCHK(ensure(h, h->rv_cand_cnt, (size_t)T * 4)); CTKCHK(ensure(h, h->rv_cand_off, (size_t)(T + 1) * 4));
     CTKCHK(ensure(h, h->rv_cand, (size_t)std::max<int64_t>(T * h->ny, 1) * sizeof(CtkCand)));
     CTKCHK(ensure(h, h->rv_scalars, 64));
+    CTKCHK(ensure(h, h->rv_tdirty, (size_t)2 * (T > 0 ? T : 1)));
     CTKCHK(ensure(h, h->rv_mark, R + 1));
     CTKCHK(ensure(h, h->comp_label, R * 4));
 
@@ -727,14 +773,21 @@ static int device_resolve(ctk_handle *h, double overlap, int twosided)
     r.rank = P<uint32_t>(h->rv_rank); r.lab = P<int32_t>(h->rv_lab); r.lbox = P<int32_t>(h->rv_lbox);
 
     const int gc = (int)std::min<size_t>((R + 255) / 256, 2048), gp = (int)std::min<size_t>((PC + 255) / 256, 2048);
-    {
+    uint32_t *hs = (uint32_t *)h->h_small + (h->T + 2);
+    const double t0 = now_ms();
+    int it_done = 0;
+    for (;;) {
         Timer tm(h, CTK_K_RESOLVE);
-        k_rs_init<<<gc, 256, 0, s>>>(r);
-        k_rs_pairs<<<gp, 256, 0, s>>>(r);
-        for (int it = 0; it < CTK_MAX_JACOBI; it++) {
-            k_rs_bwd<<<gp, 256, 0, s>>>(r, it);
-            k_rs_decide<<<gc, 256, 0, s>>>(r, it);
+        if (it_done == 0) {
+            k_rs_init<<<gc, 256, 0, s>>>(r);
+            k_rs_pairs<<<gp, 256, 0, s>>>(r);
         }
+        // overlap filter: a round of Jacobi passes (passes after the fixed point return at once)
+        if (T > 2)
+            for (int it = it_done; it < it_done + CTK_JACOBI_ROUND; it++)
+                k_rs_pass<<<(int)(T - 2), 64, 0, s>>>(r, it, P<uint32_t>(h->pair_base), P<uint32_t>(h->pair_cnt), P<uint8_t>(h->rv_tdirty));
+        it_done += CTK_JACOBI_ROUND;
+        k_rs_parent_init<<<gc, 256, 0, s>>>(r);
         k_rs_unite<<<gp, 256, 0, s>>>(r);
         k_rs_roots<<<gc, 256, 0, s>>>(r);
         const uint32_t *ncp = P<uint32_t>(h->cprefix) + T;
@@ -754,22 +807,27 @@ static int device_resolve(ctk_handle *h, double overlap, int twosided)
                                                    P<uint32_t>(h->rv_cand_off), 0, P<CtkCand>(h->rv_cand));
         }
         HIPCHK(hipGetLastError());
+        // scalars: number of components / labels / candidates, convergence, overflow
+        HIPCHK(hipMemcpyAsync(hs, h->counters.p, CTK_CNT_N * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N, P<uint32_t>(h->cprefix) + T, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 1, P<uint32_t>(h->rv_cand_off) + T, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 3, P<uint32_t>(h->rv_boff) + nsb, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 4, P<uint32_t>(h->rv_changed) + (it_done - CTK_JACOBI_ROUND), CTK_JACOBI_ROUND * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if ((hs[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) || (uint64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS] > h->pair_cap)
+            return 1;                                                         // the host path regrows the pair table
+        int conv = -1;
+        for (int k = 0; k < CTK_JACOBI_ROUND; k++) if (hs[CTK_CNT_N + 4 + k] == 0) { conv = it_done - CTK_JACOBI_ROUND + k; break; }
+        if (conv >= 0) { h->stats[CTK_S_FILTER_PASSES] = conv + 1; break; }
+        if (it_done + CTK_JACOBI_ROUND > CTK_MAX_JACOBI) return 1;            // very long removal cascade: host resolver
     }
-    // scalars: number of components / labels / candidates, convergence, overflow
-    const double t0 = now_ms();
-    uint32_t *hs = (uint32_t *)h->h_small + (h->T + 2);
-    HIPCHK(hipMemcpyAsync(hs, h->counters.p, CTK_CNT_N * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N, P<uint32_t>(h->cprefix) + T, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 1, P<uint32_t>(h->rv_cand_off) + T, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 2, P<uint32_t>(h->rv_changed) + (CTK_MAX_JACOBI - 1), 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 3, P<uint32_t>(h->rv_boff) + nsb, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (hs[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) return 1;                       // the host path regrows the pair table
-    if (hs[CTK_CNT_N + 2] != 0) return 1;                                     // cascade longer than CTK_MAX_JACOBI passes
     const int64_t NC = hs[CTK_CNT_N], ncand = hs[CTK_CNT_N + 1], nlab = hs[CTK_CNT_N + 3];
     h->total_comps = (uint32_t)NC;
     h->n_labels = nlab; h->t_begin = 0;
-    std::vector<CtkOp> ops;
+    CTKCHK(prepare_op_first(h, nlab));                                        // overlaps the host driver
+    h->stats[CTK_S_COMPONENTS] = NC; h->stats[CTK_S_PAIRS] = (int64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS]; h->stats[CTK_S_SEAM_ROWS] = ncand; h->stats[CTK_S_LABELS] = nlab;
+    std::vector<CtkOp> &ops = h->sd_ops;
+    ops.clear();
     if (ncand) {
         const size_t need = (size_t)ncand * sizeof(CtkCand) + (size_t)(nlab + 1) * 24;
         CTKCHK(ensure_host(&h->h_cand, &h->h_cand_cap, need));
@@ -780,12 +838,13 @@ static int device_resolve(ctk_handle *h, double overlap, int twosided)
         HIPCHK(hipStreamSynchronize(s));
         h->ms[CTK_T_D2H] += now_ms() - t0;
         const double t1 = now_ms();
-        seam_driver(hc, ncand, hb, nlab, h->nx, ops);
+        seam_driver(h, hc, ncand, hb, nlab, h->nx, ops);
         h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t1;
     } else {
         h->ms[CTK_T_D2H] += now_ms() - t0;
     }
     const double t2 = now_ms();
+    h->stats[CTK_S_OPS] = (int64_t)ops.size();
     CTKCHK(upload_ops(h, ops.data(), (int64_t)ops.size(), nlab));
     h->ms[CTK_T_H2D] += now_ms() - t2;
     {
@@ -877,6 +936,7 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
         h->state = ST_EXTENTS;
     } else {
         // host path: download the tables, resolve with the GPU-free reference implementation, upload
+        h->stats[CTK_S_HOST_PATH] = 1;
         const void *blob = nullptr;
         size_t nbytes = 0;
         CTKCHK(ctk_shard_tables(h, &blob, &nbytes));

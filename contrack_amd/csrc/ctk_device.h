@@ -8,6 +8,7 @@
 #define CTK_CNT_OVERFLOW   2
 #define CTK_CNT_WROTE_ZERO 3
 #define CTK_CNT_ALIVE      4
+#define CTK_CNT_UPAIRS     5   /* co-occurrence records that bypassed the LDS hash table */
 #define CTK_CNT_N          8
 
 // overflow bits

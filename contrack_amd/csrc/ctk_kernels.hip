@@ -281,6 +281,9 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ 
 //            (same-row pairs only, contrack.py:693-698); second flatten -> merged component
 //   phase 6  component ids, per-component bbox and exact area limbs, seam-row records
 // ------------------------------------------------------------------------------------------------
+#define CTK_LDS_COMPS 512
+#define CTK_LDS_MASKW (CTK_LDS_COMPS * 4)        // mask staging and component tables share this LDS area (16 KB)
+
 struct Label2dArgs {
     const uint64_t *mask;
     const uint16_t *wstart;        // [T][ny][W] run starts left of each word (k_rowcount)
@@ -307,7 +310,8 @@ template <int THREADS>
 __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, const uint32_t nruns,
                                              uint16_t *x0, uint16_t *x1, uint16_t *yrow, uint32_t *parent,
                                              uint32_t *root, uint32_t *idmap, uint32_t *rs /* rowstart, ny+1 */,
-                                             uint32_t *sm_scan, const uint64_t *mrow /* the timestep's mask words (LDS or global) */)
+                                             uint32_t *sm_scan, const uint64_t *mrow /* the timestep's mask words (LDS or global) */,
+                                             void *lds_tab /* CTK_LDS_COMPS x 32 B of LDS for the component tables, or nullptr */)
 {
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, nwv = THREADS >> 6;
     const int ny = a.ny, nx = a.nx, W = a.W;
@@ -409,8 +413,13 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
     __syncthreads();
     if (tid == 0) a.ncomp[t] = ncomp;
     uint32_t *cmrep = a.cs_mrep + rbase;
-    uint32_t *cbox = a.cs_box + (int64_t)rbase * 4;
-    int64_t *carea = a.cs_area + (int64_t)rbase * 2;
+    uint32_t *gbox = a.cs_box + (int64_t)rbase * 4;
+    int64_t *garea = a.cs_area + (int64_t)rbase * 2;
+    // per-component bbox / exact area: accumulated with LDS atomics when the timestep's components fit the
+    // LDS table (the staged mask words are dead by now and lend their space), else with global atomics
+    const bool tab_lds = lds_tab != nullptr && ncomp <= CTK_LDS_COMPS;
+    int64_t *carea = tab_lds ? (int64_t *)lds_tab : garea;
+    uint32_t *cbox = tab_lds ? (uint32_t *)((int64_t *)lds_tab + 2 * CTK_LDS_COMPS) : gbox;
     for (uint32_t c = tid; c < ncomp; c += THREADS) {
         cbox[c * 4 + 0] = 0xffffu; cbox[c * 4 + 1] = 0u; cbox[c * 4 + 2] = 0xffffu; cbox[c * 4 + 3] = 0u;
         carea[c * 2] = 0; carea[c * 2 + 1] = 0;
@@ -430,6 +439,11 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
         atomicMin(&cbox[c * 4 + 2], (uint32_t)x0[r]);
         atomicMax(&cbox[c * 4 + 3], (uint32_t)x1[r]);
         if (rt == r) cmrep[c] = idmap[parent[r]];          // merged root is itself a no-wrap root (smallest run)
+    }
+    if (tab_lds) {
+        __syncthreads();
+        for (uint32_t i = tid; i < ncomp * 4; i += THREADS) gbox[i] = cbox[i];
+        for (uint32_t i = tid; i < ncomp * 2; i += THREADS) garea[i] = carea[i];
     }
     // seam rows: both seam pixels set (also when they are one run / one component: chain events can still
     // split them).  Written in y order into the timestep's slice of a row-indexed
@@ -459,7 +473,6 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
 
 #define CTK_LDS_RUNS 2048
 #define CTK_LDS_NY 1024
-#define CTK_LDS_MASKW 1536
 
 __global__ __launch_bounds__(256) void k_label2d_lds(Label2dArgs a)
 {
@@ -482,7 +495,7 @@ __global__ __launch_bounds__(256) void k_label2d_lds(Label2dArgs a)
         for (int i = (int)threadIdx.x; i < nwords; i += 256) mlds[i] = mg[i];
         mrow = mlds;
     }
-    label2d_body<256>(a, t, nruns, x0, x1, yrow, parent, root, idmap, rs, sm_scan, mrow);
+    label2d_body<256>(a, t, nruns, x0, x1, yrow, parent, root, idmap, rs, sm_scan, mrow, mlds);
 }
 
 __global__ __launch_bounds__(256) void k_label2d_glb(Label2dArgs a, uint32_t *g_rs /* [T][ny+1] scratch */)
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(256) void k_label2d_glb(Label2dArgs a, uint32_t *g_
     if (!(nruns > CTK_LDS_RUNS || a.ny > CTK_LDS_NY)) return;
     __shared__ uint32_t sm_scan[8];
     label2d_body<256>(a, t, nruns, a.g_x0 + rb, a.g_x1 + rb, a.g_y + rb, a.g_parent + rb, a.g_root + rb,
-                      a.g_idmap + rb, g_rs + (int64_t)t * (a.ny + 1), sm_scan, a.mask + (int64_t)t * a.ny * a.W);
+                      a.g_idmap + rb, g_rs + (int64_t)t * (a.ny + 1), sm_scan, a.mask + (int64_t)t * a.ny * a.W, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -549,27 +562,32 @@ struct OverlapArgs {
     const uint32_t *halo_rowstart;
     const uint32_t *halo_run_comp;
     int has_prev;
-    CtkPair *pairs;
+    CtkPair *pairs;                // grouped records: pairs[pair_base[t] .. +pair_cnt[t]) belong to timestep t
     uint32_t pair_cap;
-    uint32_t *counters;
+    uint32_t *pair_base, *pair_cnt; // [T]
+    uint32_t *counters;            // records that found no hash slot are stored from the END of `pairs` downwards
+                                   // (pairs[pair_cap-1-i]), counted by CTK_CNT_UPAIRS
     const int32_t *wlo, *whi;
     int ny, nx, W;
 };
 
 __device__ __forceinline__ void emit_pair(const OverlapArgs &a, uint32_t t, uint32_t c, uint32_t d, int64_t lo, int64_t hi)
 {
-    uint32_t i = atomicAdd(&a.counters[CTK_CNT_PAIRS], 1u);
+    uint32_t i = atomicAdd(&a.counters[CTK_CNT_UPAIRS], 1u);
     if (i < a.pair_cap) {
         CtkPair p;
         p.t = t; p.c = c; p.d = d; p.pad = 0; p.lo = lo; p.hi = hi;
-        a.pairs[i] = p;
+        a.pairs[a.pair_cap - 1u - i] = p;
     } else atomicOr(&a.counters[CTK_CNT_OVERFLOW], CTK_OVF_PAIRS);
 }
 
 __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
 {
     const int t = (int)blockIdx.x;
-    if (t == 0 && !a.has_prev) return;
+    if (t == 0 && !a.has_prev) {
+        if (threadIdx.x == 0) { a.pair_base[t] = 0; a.pair_cnt[t] = 0; }
+        return;
+    }
     const int tid = (int)threadIdx.x;
     const int ny = a.ny, W = a.W;
     __shared__ unsigned long long hkey[CTK_HASH_SLOTS];
@@ -629,23 +647,30 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
         }
     }
     __syncthreads();
-    // flush the table: one contiguous block of records per timestep
-    for (int i0 = 0; i0 < CTK_HASH_SLOTS; i0 += 256) {
-        int i = i0 + tid;
-        uint32_t v = (hkey[i] != FULL64) ? 1u : 0u, tot;
-        uint32_t ex = block_excl_scan(v, sm_scan, &tot);
-        if (tid == 0 && tot) out_base = atomicAdd(&a.counters[CTK_CNT_PAIRS], tot);
+    // flush the table: ONE contiguous block of records per timestep (pair_base[t], pair_cnt[t])
+    {
+        uint32_t mine = 0;
+        for (int i = tid; i < CTK_HASH_SLOTS; i += 256) mine += (hkey[i] != FULL64) ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(mine, sm_scan, &tot);
+        if (tid == 0) {
+            out_base = tot ? atomicAdd(&a.counters[CTK_CNT_PAIRS], tot) : 0u;
+            a.pair_base[t] = out_base;
+            a.pair_cnt[t] = (tot && out_base + tot <= a.pair_cap) ? tot : 0u;
+            if (tot && out_base + tot > a.pair_cap) atomicOr(&a.counters[CTK_CNT_OVERFLOW], CTK_OVF_PAIRS);
+        }
         __syncthreads();
-        if (v) {
-            uint32_t j = out_base + ex;
+        uint32_t j = out_base + ex;
+        for (int i = tid; i < CTK_HASH_SLOTS; i += 256) {
+            if (hkey[i] == FULL64) continue;
             if (j < a.pair_cap) {
                 CtkPair p;
                 p.t = (uint32_t)t; p.c = (uint32_t)(hkey[i] >> 32); p.d = (uint32_t)hkey[i]; p.pad = 0;
                 p.lo = hlo[i]; p.hi = hhi[i];
                 a.pairs[j] = p;
-            } else atomicOr(&a.counters[CTK_CNT_OVERFLOW], CTK_OVF_PAIRS);
+            }
+            j++;
         }
-        __syncthreads();
     }
 }
 

@@ -40,12 +40,29 @@ struct ResolveDev {
     int32_t *lbox;                        // [(NC+1)][6]
 };
 
-#define CTK_MAX_JACOBI 24
+#define CTK_MAX_JACOBI 240          // hard cap of filter passes on the device (then: host resolver)
+#define CTK_JACOBI_ROUND 10         // passes launched per round before convergence is checked
 
-__device__ __forceinline__ uint32_t dev_npairs(const ResolveDev &r)
+// pair records: k in [0, ng) are the grouped ones pairs[k]; k in [ng, ng+nu) the ungrouped ones stored from the
+// end of the buffer downwards (k_overlap)
+__device__ __forceinline__ uint32_t dev_ngrouped(const ResolveDev &r)
 {
     uint32_t n = r.counters[CTK_CNT_PAIRS];
     return n < r.pair_cap ? n : r.pair_cap;
+}
+__device__ __forceinline__ uint32_t dev_nungrouped(const ResolveDev &r)
+{
+    uint32_t n = r.counters[CTK_CNT_UPAIRS];
+    return n < r.pair_cap ? n : r.pair_cap;
+}
+__device__ __forceinline__ uint32_t dev_npairs(const ResolveDev &r)
+{
+    uint32_t n = dev_ngrouped(r) + dev_nungrouped(r);
+    return n < r.pair_cap ? n : r.pair_cap;
+}
+__device__ __forceinline__ const CtkPair &pair_at(const ResolveDev &r, uint32_t k, uint32_t ng)
+{
+    return k < ng ? r.pairs[k] : r.pairs[r.pair_cap - 1u - (k - ng)];
 }
 __device__ __forceinline__ uint32_t dev_ncomps(const ResolveDev &r) { return r.cprefix[r.T]; }
 
@@ -80,16 +97,21 @@ __global__ void k_rs_init(ResolveDev r)
         r.F[2 * (int64_t)g] = 0; r.F[2 * (int64_t)g + 1] = 0;
         r.B[2 * (int64_t)g] = 0; r.B[2 * (int64_t)g + 1] = 0;
         r.keep0[g] = 1; r.keep1[g] = 1;
-        r.parent[g] = g;
     }
-    if (blockIdx.x == 0 && threadIdx.x <= CTK_MAX_JACOBI) r.changed[threadIdx.x] = 0;
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i <= CTK_MAX_JACOBI; i += blockDim.x) r.changed[i] = 0;
+}
+
+__global__ void k_rs_parent_init(ResolveDev r)
+{
+    const uint32_t nc = dev_ncomps(r);
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) r.parent[g] = g;
 }
 
 __global__ void k_rs_pairs(ResolveDev r)
 {
-    const uint32_t np = dev_npairs(r);
+    const uint32_t np = dev_npairs(r), ng = dev_ngrouped(r);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
-        const CtkPair p = r.pairs[i];
+        const CtkPair p = pair_at(r, i, ng);
         const uint32_t cb = r.cprefix[p.t], db = r.cprefix[p.t - 1];
         const uint32_t gc = cb + p.c, gd = db + p.d;
         const uint32_t rc = cb + r.mrep[gc], rd = db + r.mrep[gd];
@@ -105,10 +127,10 @@ __global__ void k_rs_bwd(ResolveDev r, int it)
 {
     if (it > 0 && r.changed[it - 1] == 0) return;           // already at the fixed point
     const uint8_t *kin = (it & 1) ? r.keep1 : r.keep0;
-    const uint32_t np = dev_npairs(r);
+    const uint32_t np = dev_npairs(r), ng = dev_ngrouped(r);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
         if (!kin[r.p_rd[i]]) continue;
-        const CtkPair p = r.pairs[i];
+        const CtkPair p = pair_at(r, i, ng);
         const int64_t rc = r.p_rc[i];
         atomicAdd((unsigned long long *)&r.B[2 * rc], (unsigned long long)p.lo);
         atomicAdd((unsigned long long *)&r.B[2 * rc + 1], (unsigned long long)p.hi);
@@ -149,16 +171,89 @@ __global__ void k_rs_decide(ResolveDev r, int it)
     if (__ballot(any) && lane_id() == 0) atomicOr(&r.changed[it], 1u);
 }
 
-// keep bits of the last pass land in keep0 (so later kernels need not know how many passes ran)
-__global__ void k_rs_keep_final(ResolveDev r, int passes)
+// ------------------------------------------------------------------------------------------------
+// Fused filter pass: one 64-thread workgroup per timestep.  keep[] is updated IN PLACE (chaotic iteration:
+// a workgroup may read its predecessor's bits from this pass or the previous one -- both are valid iterates,
+// and a pass that changes nothing anywhere is the fixed point of keep[t] = f(keep[t-1]), i.e. the sequential
+// result).  A timestep whose predecessor did not change in the previous pass is skipped.
+//   tdirty[(it&1)][t] = keep bits of t changed in pass `it`
+// Backward overlaps are accumulated in LDS (<= CTK_PASS_COMPS components per timestep) or, for larger
+// timesteps, in the global scratch r.B.
+// ------------------------------------------------------------------------------------------------
+#define CTK_PASS_COMPS 512
+__global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_cnt,
+                                                uint8_t *__restrict__ tdirty)
 {
-    // find the last pass that ran: the first it with changed[it] == 0 (it ran and changed nothing) or `passes`
-    int last = passes - 1;
-    for (int it = 0; it < passes; it++) if (r.changed[it] == 0) { last = it; break; }
-    const uint8_t *kfin = (last & 1) ? r.keep0 : r.keep1;      // pass `last` wrote kout = (last&1)?keep0:keep1
-    if (kfin == r.keep0) return;
-    const uint32_t nc = dev_ncomps(r);
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) r.keep0[g] = kfin[g];
+    const int t = (int)blockIdx.x + 1;                         // timesteps 1 .. T-2 are filtered
+    const int64_t T = r.T;
+    uint8_t *dcur = tdirty + (size_t)(it & 1) * (size_t)T, *dprev = tdirty + (size_t)((it & 1) ^ 1) * (size_t)T;
+    const int lane = (int)threadIdx.x;
+    if (it > 0) {
+        if (r.changed[it - 1] == 0) return;                    // fixed point reached in an earlier pass
+        if (!dprev[t - 1]) { if (lane == 0) dcur[t] = 0; return; }
+    }
+    const uint32_t cb = r.cprefix[t], nct = r.cprefix[t + 1] - cb;
+    __shared__ long long Bl[2 * CTK_PASS_COMPS];
+    const bool lds = nct <= CTK_PASS_COMPS;
+    long long *B = lds ? Bl : (long long *)(r.B + 2 * (int64_t)cb);
+    if (lds) for (uint32_t c = lane; c < 2 * nct; c += 64) Bl[c] = 0;
+    __syncthreads();
+    uint8_t *keep = r.keep0;
+    const uint32_t pb = pair_base[t], pn = pair_cnt[t];
+    for (uint32_t i = lane; i < pn; i += 64) {
+        const uint32_t k = pb + i;
+        if (!__hip_atomic_load(&keep[r.p_rd[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+        const CtkPair p = r.pairs[k];
+        const uint32_t c = r.p_rc[k] - cb;
+        atomicAdd((unsigned long long *)&B[2 * c], (unsigned long long)p.lo);
+        atomicAdd((unsigned long long *)&B[2 * c + 1], (unsigned long long)p.hi);
+    }
+    const uint32_t nu = dev_nungrouped(r);
+    if (nu) {                                                   // records that bypassed the hash table (rare)
+        const uint32_t ng = dev_ngrouped(r);
+        for (uint32_t i = lane; i < nu; i += 64) {
+            const CtkPair p = r.pairs[r.pair_cap - 1u - i];
+            if ((int)p.t != t) continue;
+            if (!__hip_atomic_load(&keep[r.p_rd[ng + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+            const uint32_t c = r.p_rc[ng + i] - cb;
+            atomicAdd((unsigned long long *)&B[2 * c], (unsigned long long)p.lo);
+            atomicAdd((unsigned long long *)&B[2 * c + 1], (unsigned long long)p.hi);
+        }
+    }
+    __syncthreads();
+    bool any = false;
+    for (uint32_t c = lane; c < nct; c += 64) {
+        const uint32_t g = cb + c;
+        long long blo, bhi;
+        if (lds) { blo = Bl[2 * c]; bhi = Bl[2 * c + 1]; }
+        else {
+            blo = __hip_atomic_load(&B[2 * c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bhi = __hip_atomic_load(&B[2 * c + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&B[2 * c], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&B[2 * c + 1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (r.mrep[g] != c) continue;                           // representatives only
+        const double areacon = dev_limbs_to_double(r.A[2 * (int64_t)g], r.A[2 * (int64_t)g + 1], r.wshift);
+        const double fwd = dev_limbs_to_double(r.F[2 * (int64_t)g], r.F[2 * (int64_t)g + 1], r.wshift);
+        const double bwd = dev_limbs_to_double(blo, bhi, r.wshift);
+        const double inv = 1.0 / areacon;
+        const double fb = inv * bwd, ff = inv * fwd;
+        bool kill = false;
+        if (r.twosided) {
+            if (fb != 0 && ff != 0) { if (fb < r.overlap || ff < r.overlap) kill = true; }
+            if (fb != 0 && ff == 0) { if (fb < r.overlap) kill = true; }
+            if (fb == 0 && ff != 0) { if (ff < r.overlap) kill = true; }
+        } else {
+            if (ff < r.overlap) kill = true;
+        }
+        const uint8_t k = kill ? 0 : 1;
+        if (k != keep[g]) { __hip_atomic_store(&keep[g], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); any = true; }
+    }
+    const bool wave_any = __ballot(any) != 0ull;
+    if (lane == 0) {
+        dcur[t] = wave_any ? 1 : 0;
+        if (wave_any) atomicOr(&r.changed[it], 1u);
+    }
 }
 
 __device__ __forceinline__ uint32_t gfind(uint32_t *p, uint32_t i)

@@ -146,6 +146,18 @@ int ctk_debug_label2d(ctk_handle *h, int before_seam, int32_t *lab /* (T,ny,nx) 
 #define CTK_T_TOTAL        13
 #define CTK_NTIMERS        14
 int ctk_set_timing(ctk_handle *h, int enable);
+/* workload statistics of the last call (for bench reports: cost depends on them) */
+#define CTK_S_RUNS          0   /* foreground runs in the shard                         */
+#define CTK_S_MAX_RUNS_STEP 1   /* most runs in one timestep                            */
+#define CTK_S_COMPONENTS    2   /* 2-D components (no wrap)                             */
+#define CTK_S_PAIRS         3   /* co-occurrence records                                */
+#define CTK_S_SEAM_ROWS     4   /* seam rows handed to the sequential driver            */
+#define CTK_S_LABELS        5   /* fresh 3-D labels                                     */
+#define CTK_S_OPS           6   /* recorded bbox-confined relabel operations            */
+#define CTK_S_FILTER_PASSES 7   /* passes of the overlap-filter iteration that ran      */
+#define CTK_S_HOST_PATH     8   /* 1 if the call fell back to the host resolver         */
+#define CTK_NSTATS          12
+int ctk_get_stats(ctk_handle *h, int64_t *out /* [CTK_NSTATS] */);
 /* 1 (default): ctk_track_* resolve the tables on the device; 0: download + ctk_resolve on the host */
 int ctk_set_device_resolve(ctk_handle *h, int enable);
 int ctk_get_timings(ctk_handle *h, double *ms /* [CTK_NTIMERS] */);
