@@ -56,7 +56,8 @@ struct ctk_handle {
     DevBuf run_comp, run_val, cs_mrep, cs_box, cs_area, d_mrep, d_box, d_area, comp_label;
     DevBuf g_x0, g_x1, g_y, g_parent, g_root, g_idmap, g_rs;
     DevBuf pairs, seams, ext, ops, op_first, op_next, op_stage, halo_in, halo_out, dbg;
-    DevBuf seam_cnt, seam_off, d_seams, d_comp_t, pair_base, pair_cnt, rv_tdirty;
+    DevBuf seam_cnt, seam_off, d_seams, d_comp_t, pair_base, pair_cnt, rv_tdirty, d_blob, seam_rowoff;
+    DevBuf g_ncomp, g_cprefix, g_mrep, g_box, g_area, g_comp_t, g_pairs, g_pair_base, g_pair_cnt, g_seams, g_seam_cnt, g_seam_off, g_counters, g_label;
     // device resolver work space
     DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lbox,
         rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_scalars, rv_mark;
@@ -204,7 +205,9 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->counters, &h->run_comp, &h->run_val, &h->cs_mrep, &h->cs_box, &h->cs_area, &h->d_mrep, &h->d_box, &h->d_area,
                       &h->comp_label, &h->g_x0, &h->g_x1, &h->g_y, &h->g_parent, &h->g_root, &h->g_idmap, &h->g_rs, &h->pairs, &h->seams,
                       &h->ext, &h->ops, &h->op_first, &h->op_next, &h->op_stage, &h->halo_in, &h->halo_out, &h->dbg, &h->seam_cnt, &h->seam_off, &h->d_seams,
-                      &h->d_comp_t, &h->pair_base, &h->pair_cnt, &h->rv_tdirty, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
+                      &h->d_comp_t, &h->pair_base, &h->pair_cnt, &h->rv_tdirty, &h->d_blob, &h->seam_rowoff, &h->g_ncomp, &h->g_cprefix, &h->g_mrep, &h->g_box,
+                      &h->g_area, &h->g_comp_t, &h->g_pairs, &h->g_pair_base, &h->g_pair_cnt, &h->g_seams, &h->g_seam_cnt, &h->g_seam_off, &h->g_counters,
+                      &h->g_label, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
                       &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_scalars, &h->rv_mark};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
@@ -515,7 +518,7 @@ extern "C" int ctk_shard_overlap(ctk_handle *h)
 // ------------------------------------------------------------------------------------------------
 // tables: download into the blob layout of ctk_tables.h
 // ------------------------------------------------------------------------------------------------
-extern "C" int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes)
+static int build_tables_blob(ctk_handle *h, bool to_device, const void **blob, size_t *nbytes)
 {
     if (!h || !blob || !nbytes) return ctk_set_error(CTK_E_INVALID, "null argument");
     if (h->state != ST_OVERLAPPED) return ctk_set_error(CTK_E_STATE, "ctk_shard_tables needs ctk_shard_overlap first");
@@ -558,33 +561,43 @@ extern "C" int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes
         HIPCHK(hipGetLastError());
     }
     const size_t bytes = ctk_blob_bytes(T, NC, NP, NS);
-    CTKCHK(ensure_host(&h->h_blob, &h->h_blob_cap, bytes));
-    char *p = (char *)h->h_blob;
-    CtkBlobHeader *hd = (CtkBlobHeader *)p;
-    hd->magic = CTK_BLOB_MAGIC; hd->T = T; hd->ny = h->ny; hd->nx = h->nx; hd->wshift = h->wshift; hd->has_prev = (h->has_prev && h->halo_in.p) ? 1 : 0;
-    hd->ncomps = NC; hd->npairs = NP; hd->nseams = NS;
+    char *p;
+    if (to_device) { CTKCHK(ensure(h, h->d_blob, bytes)); p = (char *)h->d_blob.p; }
+    else { CTKCHK(ensure_host(&h->h_blob, &h->h_blob_cap, bytes)); p = (char *)h->h_blob; }
+    const hipMemcpyKind kind = to_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    CtkBlobHeader hdr;
+    memset(&hdr, 0, sizeof(hdr));
+    hdr.magic = CTK_BLOB_MAGIC; hdr.T = T; hdr.ny = h->ny; hdr.nx = h->nx; hdr.wshift = h->wshift; hdr.has_prev = (h->has_prev && h->halo_in.p) ? 1 : 0;
+    hdr.ncomps = NC; hdr.npairs = NP; hdr.nseams = NS; hdr.npairs_grouped = NPG;
+    if (to_device) HIPCHK(hipMemcpyAsync(p, &hdr, sizeof(hdr), hipMemcpyHostToDevice, s)); else memcpy(p, &hdr, sizeof(hdr));
     p += sizeof(CtkBlobHeader);
-    if (T) HIPCHK(hipMemcpyAsync(p, h->ncomp.p, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+    if (T) HIPCHK(hipMemcpyAsync(p, h->ncomp.p, (size_t)T * 4, kind, s));
     p += ctk_align8((size_t)T * 4);
-    if (NC) HIPCHK(hipMemcpyAsync(p, h->d_mrep.p, (size_t)NC * 4, hipMemcpyDeviceToHost, s));
+    if (NC) HIPCHK(hipMemcpyAsync(p, h->d_mrep.p, (size_t)NC * 4, kind, s));
     p += ctk_align8((size_t)NC * 4);
-    if (NC) HIPCHK(hipMemcpyAsync(p, h->d_box.p, (size_t)NC * 8, hipMemcpyDeviceToHost, s));
+    if (NC) HIPCHK(hipMemcpyAsync(p, h->d_box.p, (size_t)NC * 8, kind, s));
     p += ctk_align8((size_t)NC * 8);
-    if (NC) HIPCHK(hipMemcpyAsync(p, h->d_area.p, (size_t)NC * 16, hipMemcpyDeviceToHost, s));
+    if (NC) HIPCHK(hipMemcpyAsync(p, h->d_area.p, (size_t)NC * 16, kind, s));
     p += (size_t)NC * 16;
-    if (NPG) HIPCHK(hipMemcpyAsync(p, h->pairs.p, (size_t)NPG * sizeof(CtkPair), hipMemcpyDeviceToHost, s));
-    if (NPU) HIPCHK(hipMemcpyAsync(p + (size_t)NPG * sizeof(CtkPair), P<CtkPair>(h->pairs) + (h->pair_cap - NPU), (size_t)NPU * sizeof(CtkPair),
-                                   hipMemcpyDeviceToHost, s));
+    if (NPG) HIPCHK(hipMemcpyAsync(p, h->pairs.p, (size_t)NPG * sizeof(CtkPair), kind, s));
+    if (NPU) HIPCHK(hipMemcpyAsync(p + (size_t)NPG * sizeof(CtkPair), P<CtkPair>(h->pairs) + (h->pair_cap - NPU), (size_t)NPU * sizeof(CtkPair), kind, s));
     p += (size_t)NP * sizeof(CtkPair);
-    if (NS) HIPCHK(hipMemcpyAsync(p, h->d_seams.p, (size_t)NS * sizeof(CtkSeam), hipMemcpyDeviceToHost, s));
+    if (NS) HIPCHK(hipMemcpyAsync(p, h->d_seams.p, (size_t)NS * sizeof(CtkSeam), kind, s));
+    p += (size_t)NS * sizeof(CtkSeam);
+    if (T) HIPCHK(hipMemcpyAsync(p, h->pair_base.p, (size_t)T * 4, kind, s));
+    p += ctk_align8((size_t)T * 4);
+    if (T) HIPCHK(hipMemcpyAsync(p, h->pair_cnt.p, (size_t)T * 4, kind, s));
     HIPCHK(hipStreamSynchronize(s));
     h->h_blob_bytes = bytes;
-    *blob = h->h_blob;
+    *blob = to_device ? h->d_blob.p : h->h_blob;
     *nbytes = bytes;
     h->ms[CTK_T_D2H] += now_ms() - t0;
     h->state = ST_TABLES;
     return CTK_OK;
 }
+
+extern "C" int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes) { return build_tables_blob(h, false, blob, nbytes); }
+extern "C" int ctk_shard_tables_dev(ctk_handle *h, const void **blob_dev, size_t *nbytes) { return build_tables_blob(h, true, blob_dev, nbytes); }
 
 // ------------------------------------------------------------------------------------------------
 // stage 3
@@ -740,13 +753,30 @@ void seam_driver(ctk_handle *h, const CtkCand *cand, int64_t ncand, const int32_
 
 }  // namespace
 
+// Tables the device resolver works on: the shard's own (single GPU) or the concatenation of all shards'.
+struct ResolveIn {
+    int64_t T;                                   // timesteps covered by the tables
+    size_t R;                                    // upper bound of the number of components
+    const uint32_t *ncomp, *cprefix, *mrep, *comp_t;
+    const uint16_t *box;
+    const int64_t *area;
+    const CtkPair *pairs;
+    uint32_t pair_cap;
+    const uint32_t *counters;                    // [CTK_CNT_PAIRS] grouped, [CTK_CNT_UPAIRS] ungrouped, [CTK_CNT_OVERFLOW]
+    const uint32_t *pair_base, *pair_cnt;
+    const CtkSeam *seams;
+    const uint32_t *seam_cnt, *seam_off;         // record i of timestep t: seams[seam_off[t] + i]
+    int64_t seam_cap;                            // upper bound of the surviving seam rows
+    int32_t *comp_label;                         // out: [components]
+};
+
 // returns CTK_OK, a negative error, or +1 = "take the host path" (pair table overflow / filter not converged)
-static int device_resolve(ctk_handle *h, double overlap, int twosided)
+static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, int twosided)
 {
     hipStream_t s = h->stream;
-    const size_t R = h->total_runs ? h->total_runs : 1;
-    const size_t PC = h->pair_cap ? h->pair_cap : 1;
-    const int64_t T = h->T;
+    const size_t R = in.R ? in.R : 1;
+    const size_t PC = in.pair_cap ? in.pair_cap : 1;
+    const int64_t T = in.T;
     CTKCHK(ensure(h, h->rv_prc, PC * 4)); CTKCHK(ensure(h, h->rv_prd, PC * 4));
     CTKCHK(ensure(h, h->rv_pgc, PC * 4)); CTKCHK(ensure(h, h->rv_pgd, PC * 4));
     CTKCHK(ensure(h, h->rv_F, R * 16)); CTKCHK(ensure(h, h->rv_B, R * 16));
@@ -757,16 +787,15 @@ static int device_resolve(ctk_handle *h, double overlap, int twosided)
     const int nsb = (int)((R + CTK_SCAN_ITEMS - 1) / CTK_SCAN_ITEMS);
     CTKCHK(ensure(h, h->rv_bsum, (size_t)nsb * 4)); CTKCHK(ensure(h, h->rv_boff, (size_t)(nsb + 1) * 4));
     CTKCHK(ensure(h, h->rv_cand_cnt, (size_t)T * 4)); CTKCHK(ensure(h, h->rv_cand_off, (size_t)(T + 1) * 4));
-    CTKCHK(ensure(h, h->rv_cand, (size_t)std::max<int64_t>(T * h->ny, 1) * sizeof(CtkCand)));
+    CTKCHK(ensure(h, h->rv_cand, (size_t)std::max<int64_t>(in.seam_cap, 1) * sizeof(CtkCand)));
     CTKCHK(ensure(h, h->rv_scalars, 64));
     CTKCHK(ensure(h, h->rv_tdirty, (size_t)2 * (T > 0 ? T : 1)));
     CTKCHK(ensure(h, h->rv_mark, R + 1));
-    CTKCHK(ensure(h, h->comp_label, R * 4));
 
     ResolveDev r;
-    r.ncomp = P<uint32_t>(h->ncomp); r.cprefix = P<uint32_t>(h->cprefix); r.mrep = P<uint32_t>(h->d_mrep); r.comp_t = P<uint32_t>(h->d_comp_t);
-    r.box = P<uint16_t>(h->d_box); r.A = P<int64_t>(h->d_area); r.pairs = P<CtkPair>(h->pairs); r.counters = P<uint32_t>(h->counters);
-    r.pair_cap = h->pair_cap; r.T = T; r.wshift = h->wshift; r.overlap = overlap; r.twosided = twosided;
+    r.ncomp = in.ncomp; r.cprefix = in.cprefix; r.mrep = in.mrep; r.comp_t = in.comp_t;
+    r.box = in.box; r.A = in.area; r.pairs = in.pairs; r.counters = in.counters;
+    r.pair_cap = in.pair_cap; r.T = T; r.wshift = h->wshift; r.overlap = overlap; r.twosided = twosided;
     r.p_rc = P<uint32_t>(h->rv_prc); r.p_rd = P<uint32_t>(h->rv_prd); r.p_gc = P<uint32_t>(h->rv_pgc); r.p_gd = P<uint32_t>(h->rv_pgd);
     r.F = P<int64_t>(h->rv_F); r.B = P<int64_t>(h->rv_B); r.keep0 = P<uint8_t>(h->rv_keep0); r.keep1 = P<uint8_t>(h->rv_keep1);
     r.changed = P<uint32_t>(h->rv_changed); r.parent = P<uint32_t>(h->rv_parent); r.isroot = P<uint32_t>(h->rv_isroot);
@@ -782,15 +811,15 @@ static int device_resolve(ctk_handle *h, double overlap, int twosided)
             k_rs_init<<<gc, 256, 0, s>>>(r);
             k_rs_pairs<<<gp, 256, 0, s>>>(r);
         }
-        // overlap filter: a round of Jacobi passes (passes after the fixed point return at once)
+        // overlap filter: a round of passes (passes after the fixed point return at once)
         if (T > 2)
             for (int it = it_done; it < it_done + CTK_JACOBI_ROUND; it++)
-                k_rs_pass<<<(int)(T - 2), 64, 0, s>>>(r, it, P<uint32_t>(h->pair_base), P<uint32_t>(h->pair_cnt), P<uint8_t>(h->rv_tdirty));
+                k_rs_pass<<<(int)(T - 2), 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
         it_done += CTK_JACOBI_ROUND;
         k_rs_parent_init<<<gc, 256, 0, s>>>(r);
         k_rs_unite<<<gp, 256, 0, s>>>(r);
         k_rs_roots<<<gc, 256, 0, s>>>(r);
-        const uint32_t *ncp = P<uint32_t>(h->cprefix) + T;
+        const uint32_t *ncp = in.cprefix + T;
         k_scan_blocksum<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_bsum));
         k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_bsum), nsb, P<uint32_t>(h->rv_boff), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
         k_scan_apply<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_boff), r.rank);
@@ -798,23 +827,23 @@ static int device_resolve(ctk_handle *h, double overlap, int twosided)
         k_rs_boxes<<<gc, 256, 0, s>>>(r, 0);
         HIPCHK(hipMemsetAsync(h->rv_mark.p, 0, R + 1, s));
         if (T > 0) {
-            k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, P<CtkSeam>(h->seams), P<uint32_t>(h->seam_cnt), h->ny, P<uint8_t>(h->rv_mark));
-            k_rs_cand_count<<<(int)T, 256, 0, s>>>(r, P<CtkSeam>(h->seams), P<uint32_t>(h->seam_cnt), h->ny, P<uint8_t>(h->rv_mark), P<uint32_t>(h->rv_cand_cnt));
+            k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<uint8_t>(h->rv_mark));
+            k_rs_cand_count<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<uint8_t>(h->rv_mark), P<uint32_t>(h->rv_cand_cnt));
         }
         k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_cand_cnt), T, P<uint32_t>(h->rv_cand_off), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
         if (T > 0) {
-            k_rs_cand_write<<<(int)T, 256, 0, s>>>(r, P<CtkSeam>(h->seams), P<uint32_t>(h->seam_cnt), h->ny, P<uint8_t>(h->rv_mark),
-                                                   P<uint32_t>(h->rv_cand_off), 0, P<CtkCand>(h->rv_cand));
+            k_rs_cand_write<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<uint8_t>(h->rv_mark), P<uint32_t>(h->rv_cand_off), 0,
+                                                   P<CtkCand>(h->rv_cand));
         }
         HIPCHK(hipGetLastError());
         // scalars: number of components / labels / candidates, convergence, overflow
-        HIPCHK(hipMemcpyAsync(hs, h->counters.p, CTK_CNT_N * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N, P<uint32_t>(h->cprefix) + T, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hs, in.counters, CTK_CNT_N * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N, in.cprefix + T, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 1, P<uint32_t>(h->rv_cand_off) + T, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 3, P<uint32_t>(h->rv_boff) + nsb, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 4, P<uint32_t>(h->rv_changed) + (it_done - CTK_JACOBI_ROUND), CTK_JACOBI_ROUND * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        if ((hs[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) || (uint64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS] > h->pair_cap)
+        if ((hs[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) || (uint64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS] > in.pair_cap)
             return 1;                                                         // the host path regrows the pair table
         int conv = -1;
         for (int k = 0; k < CTK_JACOBI_ROUND; k++) if (hs[CTK_CNT_N + 4 + k] == 0) { conv = it_done - CTK_JACOBI_ROUND + k; break; }
@@ -822,8 +851,7 @@ static int device_resolve(ctk_handle *h, double overlap, int twosided)
         if (it_done + CTK_JACOBI_ROUND > CTK_MAX_JACOBI) return 1;            // very long removal cascade: host resolver
     }
     const int64_t NC = hs[CTK_CNT_N], ncand = hs[CTK_CNT_N + 1], nlab = hs[CTK_CNT_N + 3];
-    h->total_comps = (uint32_t)NC;
-    h->n_labels = nlab; h->t_begin = 0;
+    h->n_labels = nlab;
     CTKCHK(prepare_op_first(h, nlab));                                        // overlaps the host driver
     h->stats[CTK_S_COMPONENTS] = NC; h->stats[CTK_S_PAIRS] = (int64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS]; h->stats[CTK_S_SEAM_ROWS] = ncand; h->stats[CTK_S_LABELS] = nlab;
     std::vector<CtkOp> &ops = h->sd_ops;
@@ -849,9 +877,133 @@ static int device_resolve(ctk_handle *h, double overlap, int twosided)
     h->ms[CTK_T_H2D] += now_ms() - t2;
     {
         Timer tm(h, CTK_K_RESOLVE2);
-        k_rs_final<<<gc, 256, 0, s>>>(r, fold_args(h), 0, P<int32_t>(h->comp_label));
+        k_rs_final<<<gc, 256, 0, s>>>(r, fold_args(h), 0, in.comp_label);
         HIPCHK(hipGetLastError());
     }
+    return CTK_OK;
+}
+
+// the shard's own tables (single GPU)
+static int device_resolve_local(ctk_handle *h, double overlap, int twosided)
+{
+    const size_t R = h->total_runs ? h->total_runs : 1;
+    CTKCHK(ensure(h, h->comp_label, R * 4));
+    CTKCHK(ensure(h, h->seam_rowoff, (size_t)(h->T + 1) * 4));
+    if (h->T > 0) k_iota_mul<<<(int)((h->T + 255) / 256), 256, 0, h->stream>>>(P<uint32_t>(h->seam_rowoff), (uint32_t)h->T, (uint32_t)h->ny);
+    ResolveIn in;
+    in.T = h->T; in.R = R;
+    in.ncomp = P<uint32_t>(h->ncomp); in.cprefix = P<uint32_t>(h->cprefix); in.mrep = P<uint32_t>(h->d_mrep); in.comp_t = P<uint32_t>(h->d_comp_t);
+    in.box = P<uint16_t>(h->d_box); in.area = P<int64_t>(h->d_area);
+    in.pairs = P<CtkPair>(h->pairs); in.pair_cap = h->pair_cap; in.counters = P<uint32_t>(h->counters);
+    in.pair_base = P<uint32_t>(h->pair_base); in.pair_cnt = P<uint32_t>(h->pair_cnt);
+    in.seams = P<CtkSeam>(h->seams); in.seam_cnt = P<uint32_t>(h->seam_cnt); in.seam_off = P<uint32_t>(h->seam_rowoff);
+    in.seam_cap = h->T * h->ny;
+    in.comp_label = P<int32_t>(h->comp_label);
+    int rv = device_resolve(h, in, overlap, twosided);
+    if (rv == 0) { h->total_comps = (uint32_t)h->stats[CTK_S_COMPONENTS]; h->t_begin = 0; }
+    return rv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU: device resolver on the table blobs of ALL shards (all-gathered into this GPU's memory)
+// ------------------------------------------------------------------------------------------------
+extern "C" int ctk_shard_resolve_dev(ctk_handle *h, const void *const *blobs_dev, const size_t *nbytes, int nshards, int my_shard, int64_t t_begin,
+                                     double overlap, int twosided, int32_t **ext_dev, int64_t *n_labels)
+{
+    if (!h || !blobs_dev || !nbytes || nshards < 1 || my_shard < 0 || my_shard >= nshards) return ctk_set_error(CTK_E_INVALID, "ctk_shard_resolve_dev: bad arguments");
+    if (h->state != ST_TABLES) return ctk_set_error(CTK_E_STATE, "ctk_shard_resolve_dev needs ctk_shard_tables[_dev] first");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    std::vector<CtkBlobHeader> hd((size_t)nshards);
+    int64_t T = 0, NC = 0, NPG = 0, NPU = 0, NS = 0;
+    for (int k = 0; k < nshards; k++) {
+        if (nbytes[k] < sizeof(CtkBlobHeader)) return ctk_set_error(CTK_E_INVALID, "blob %d too small", k);
+        HIPCHK(hipMemcpy(&hd[(size_t)k], blobs_dev[k], sizeof(CtkBlobHeader), hipMemcpyDeviceToHost));
+        const CtkBlobHeader &q = hd[(size_t)k];
+        if (q.magic != CTK_BLOB_MAGIC || q.T < 0 || q.ncomps < 0 || q.npairs < 0 || q.nseams < 0 || q.npairs_grouped < 0 || q.npairs_grouped > q.npairs ||
+            ctk_blob_bytes(q.T, q.ncomps, q.npairs, q.nseams) > nbytes[k] || q.ny != h->ny || q.nx != h->nx || q.wshift != h->wshift)
+            return ctk_set_error(CTK_E_INVALID, "blob %d is malformed or belongs to another grid", k);
+        T += q.T; NC += q.ncomps; NPG += q.npairs_grouped; NPU += q.npairs - q.npairs_grouped; NS += q.nseams;
+    }
+    if (hd[(size_t)my_shard].T != h->T || hd[(size_t)my_shard].ncomps != (int64_t)h->total_comps) return ctk_set_error(CTK_E_INVALID, "blob %d is not this shard's", my_shard);
+    const int64_t NP = NPG + NPU;
+    if (NC > 0xfffffff0ll || NP > 0xfffffff0ll || T > 0x7ffffff0ll) return ctk_set_error(CTK_E_RANGE, "gathered tables exceed 32-bit indices");
+    CTKCHK(ensure(h, h->g_ncomp, (size_t)T * 4)); CTKCHK(ensure(h, h->g_cprefix, (size_t)(T + 1) * 4));
+    CTKCHK(ensure(h, h->g_mrep, (size_t)NC * 4)); CTKCHK(ensure(h, h->g_box, (size_t)NC * 8)); CTKCHK(ensure(h, h->g_area, (size_t)NC * 16));
+    CTKCHK(ensure(h, h->g_comp_t, (size_t)NC * 4)); CTKCHK(ensure(h, h->g_pairs, (size_t)std::max<int64_t>(NP, 1) * sizeof(CtkPair)));
+    CTKCHK(ensure(h, h->g_pair_base, (size_t)T * 4)); CTKCHK(ensure(h, h->g_pair_cnt, (size_t)T * 4));
+    CTKCHK(ensure(h, h->g_seams, (size_t)std::max<int64_t>(NS, 1) * sizeof(CtkSeam)));
+    CTKCHK(ensure(h, h->g_seam_cnt, (size_t)T * 4)); CTKCHK(ensure(h, h->g_seam_off, (size_t)(T + 1) * 4));
+    CTKCHK(ensure(h, h->g_counters, CTK_CNT_N * 4)); CTKCHK(ensure(h, h->g_label, (size_t)std::max<int64_t>(NC, 1) * 4));
+    if (T) HIPCHK(hipMemsetAsync(h->g_seam_cnt.p, 0, (size_t)T * 4, s));
+    int64_t t_off = 0, c_off = 0, pg_off = 0, pu_off = 0, s_off = 0, my_c_off = 0;
+    for (int k = 0; k < nshards; k++) {
+        const CtkBlobHeader &q = hd[(size_t)k];
+        const char *p = (const char *)blobs_dev[k] + sizeof(CtkBlobHeader);
+        const int64_t npg = q.npairs_grouped, npu = q.npairs - q.npairs_grouped;
+        if (k == my_shard) my_c_off = c_off;
+        if (q.T) HIPCHK(hipMemcpyAsync(P<uint32_t>(h->g_ncomp) + t_off, p, (size_t)q.T * 4, hipMemcpyDeviceToDevice, s));
+        p += ctk_align8((size_t)q.T * 4);
+        if (q.ncomps) HIPCHK(hipMemcpyAsync(P<uint32_t>(h->g_mrep) + c_off, p, (size_t)q.ncomps * 4, hipMemcpyDeviceToDevice, s));
+        p += ctk_align8((size_t)q.ncomps * 4);
+        if (q.ncomps) HIPCHK(hipMemcpyAsync(P<uint16_t>(h->g_box) + 4 * c_off, p, (size_t)q.ncomps * 8, hipMemcpyDeviceToDevice, s));
+        p += ctk_align8((size_t)q.ncomps * 8);
+        if (q.ncomps) HIPCHK(hipMemcpyAsync(P<int64_t>(h->g_area) + 2 * c_off, p, (size_t)q.ncomps * 16, hipMemcpyDeviceToDevice, s));
+        p += (size_t)q.ncomps * 16;
+        CtkPair *gp = P<CtkPair>(h->g_pairs);
+        if (npg) {
+            HIPCHK(hipMemcpyAsync(gp + pg_off, p, (size_t)npg * sizeof(CtkPair), hipMemcpyDeviceToDevice, s));
+            k_add_t_pairs<<<(int)((npg + 255) / 256), 256, 0, s>>>(gp + pg_off, (uint32_t)npg, (uint32_t)t_off);
+        }
+        if (npu) {                                                   // ungrouped records live at the END of the table
+            CtkPair *dst = gp + (NP - pu_off - npu);
+            HIPCHK(hipMemcpyAsync(dst, p + (size_t)npg * sizeof(CtkPair), (size_t)npu * sizeof(CtkPair), hipMemcpyDeviceToDevice, s));
+            k_add_t_pairs<<<(int)((npu + 255) / 256), 256, 0, s>>>(dst, (uint32_t)npu, (uint32_t)t_off);
+        }
+        p += (size_t)q.npairs * sizeof(CtkPair);
+        if (q.nseams) {
+            HIPCHK(hipMemcpyAsync(P<CtkSeam>(h->g_seams) + s_off, p, (size_t)q.nseams * sizeof(CtkSeam), hipMemcpyDeviceToDevice, s));
+            k_add_t_seams<<<(int)((q.nseams + 255) / 256), 256, 0, s>>>(P<CtkSeam>(h->g_seams) + s_off, (uint32_t)q.nseams, (uint32_t)t_off, P<uint32_t>(h->g_seam_cnt));
+        }
+        p += (size_t)q.nseams * sizeof(CtkSeam);
+        if (q.T) {
+            HIPCHK(hipMemcpyAsync(P<uint32_t>(h->g_pair_base) + t_off, p, (size_t)q.T * 4, hipMemcpyDeviceToDevice, s));
+            k_add_u32<<<(int)((q.T + 255) / 256), 256, 0, s>>>(P<uint32_t>(h->g_pair_base) + t_off, (uint32_t)q.T, (uint32_t)pg_off);
+            p += ctk_align8((size_t)q.T * 4);
+            HIPCHK(hipMemcpyAsync(P<uint32_t>(h->g_pair_cnt) + t_off, p, (size_t)q.T * 4, hipMemcpyDeviceToDevice, s));
+        }
+        t_off += q.T; c_off += q.ncomps; pg_off += npg; pu_off += npu; s_off += q.nseams;
+    }
+    uint32_t cnt[CTK_CNT_N];
+    memset(cnt, 0, sizeof(cnt));
+    cnt[CTK_CNT_PAIRS] = (uint32_t)NPG; cnt[CTK_CNT_UPAIRS] = (uint32_t)NPU;
+    HIPCHK(hipMemcpyAsync(h->g_counters.p, cnt, sizeof(cnt), hipMemcpyHostToDevice, s));
+    k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->g_ncomp), T, P<uint32_t>(h->g_cprefix), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+    k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->g_seam_cnt), T, P<uint32_t>(h->g_seam_off), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+    if (T) k_fill_comp_t<<<(int)T, 128, 0, s>>>(P<uint32_t>(h->g_ncomp), P<uint32_t>(h->g_cprefix), P<uint32_t>(h->g_comp_t));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));                                          // `cnt` leaves scope
+    ResolveIn in;
+    in.T = T; in.R = (size_t)std::max<int64_t>(NC, 1);
+    in.ncomp = P<uint32_t>(h->g_ncomp); in.cprefix = P<uint32_t>(h->g_cprefix); in.mrep = P<uint32_t>(h->g_mrep); in.comp_t = P<uint32_t>(h->g_comp_t);
+    in.box = P<uint16_t>(h->g_box); in.area = P<int64_t>(h->g_area);
+    in.pairs = P<CtkPair>(h->g_pairs); in.pair_cap = (uint32_t)NP; in.counters = P<uint32_t>(h->g_counters);
+    in.pair_base = P<uint32_t>(h->g_pair_base); in.pair_cnt = P<uint32_t>(h->g_pair_cnt);
+    in.seams = P<CtkSeam>(h->g_seams); in.seam_cnt = P<uint32_t>(h->g_seam_cnt); in.seam_off = P<uint32_t>(h->g_seam_off);
+    in.seam_cap = NS;
+    in.comp_label = P<int32_t>(h->g_label);
+    const int64_t my_nc = h->total_comps;
+    int rv = device_resolve(h, in, overlap, twosided);
+    if (rv < 0) return rv;
+    if (rv > 0) return ctk_set_error(CTK_E_RANGE, "ctk_shard_resolve_dev: overlap filter did not converge within %d passes; use ctk_resolve on the host tables", CTK_MAX_JACOBI);
+    CTKCHK(ensure(h, h->comp_label, (size_t)std::max<int64_t>(my_nc, 1) * 4));
+    if (my_nc) HIPCHK(hipMemcpyAsync(h->comp_label.p, P<int32_t>(h->g_label) + my_c_off, (size_t)my_nc * 4, hipMemcpyDeviceToDevice, s));
+    h->total_comps = (uint32_t)my_nc;
+    h->t_begin = t_begin;
+    CTKCHK(launch_extents(h));
+    if (ext_dev) *ext_dev = P<int32_t>(h->ext);
+    if (n_labels) *n_labels = h->n_labels;
+    h->state = ST_EXTENTS;
     return CTK_OK;
 }
 
@@ -929,7 +1081,7 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
     const double t0 = now_ms();
     CTKCHK(shard_label2d_impl(h, anom_dev, f64, T, ny, nx, thr, cmp_op, wrow, 0));
     CTKCHK(ctk_shard_overlap(h));
-    int rv = h->use_device_resolve ? device_resolve(h, overlap, twosided) : 1;
+    int rv = h->use_device_resolve ? device_resolve_local(h, overlap, twosided) : 1;
     if (rv < 0) return rv;
     if (rv == 0) {
         CTKCHK(launch_extents(h));

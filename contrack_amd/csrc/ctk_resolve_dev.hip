@@ -357,13 +357,14 @@ __global__ void k_rs_boxes(ResolveDev r, int64_t t_begin)
 // Only labels that occur in some seam row with two DIFFERENT labels can ever take part in a relabel
 // operation (the first op needs such a row; every later `hi`/`lo` is a label of such a row or the `lo` of an
 // earlier op).  Rows with equal labels that are not marked can therefore be dropped before the host driver.
-__global__ __launch_bounds__(256) void k_rs_cand_mark(ResolveDev r, const CtkSeam *__restrict__ scratch, const uint32_t *__restrict__ seam_cnt,
-                                                      int ny, uint8_t *__restrict__ mark)
+__global__ __launch_bounds__(256) void k_rs_cand_mark(ResolveDev r, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
+                                                      const uint32_t *__restrict__ seam_off, uint8_t *__restrict__ mark)
 {
     const int t = (int)blockIdx.x;
     const uint32_t n = seam_cnt[t], cb = r.cprefix[t];
+    const CtkSeam *scratch = seams + seam_off[t];
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const CtkSeam q = scratch[(int64_t)t * ny + i];
+        const CtkSeam q = scratch[i];
         if (!r.keep0[cb + r.mrep[cb + q.cl]]) continue;
         const int32_t ll = r.lab[cb + q.cl], lr = r.lab[cb + q.cr];
         if (ll != lr) { mark[ll] = 1; mark[lr] = 1; }
@@ -381,14 +382,16 @@ __device__ __forceinline__ bool cand_wanted(const ResolveDev &r, const CtkSeam &
 struct CtkCand {
     int32_t t, y, ll, lr;
 };
-__global__ __launch_bounds__(256) void k_rs_cand_count(ResolveDev r, const CtkSeam *__restrict__ scratch, const uint32_t *__restrict__ seam_cnt,
-                                                       int ny, const uint8_t *__restrict__ mark, uint32_t *__restrict__ cand_cnt)
+__global__ __launch_bounds__(256) void k_rs_cand_count(ResolveDev r, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
+                                                       const uint32_t *__restrict__ seam_off, const uint8_t *__restrict__ mark,
+                                                       uint32_t *__restrict__ cand_cnt)
 {
     const int t = (int)blockIdx.x;
     const uint32_t n = seam_cnt[t], cb = r.cprefix[t];
+    const CtkSeam *scratch = seams + seam_off[t];
     uint32_t s = 0;
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const CtkSeam q = scratch[(int64_t)t * ny + i];
+        const CtkSeam q = scratch[i];
         s += cand_wanted(r, q, cb, mark) ? 1u : 0u;
     }
     __shared__ uint32_t sm[8];
@@ -396,19 +399,20 @@ __global__ __launch_bounds__(256) void k_rs_cand_count(ResolveDev r, const CtkSe
     block_excl_scan(s, sm, &tot);
     if (threadIdx.x == 0) cand_cnt[t] = tot;
 }
-__global__ __launch_bounds__(256) void k_rs_cand_write(ResolveDev r, const CtkSeam *__restrict__ scratch, const uint32_t *__restrict__ seam_cnt,
-                                                       int ny, const uint8_t *__restrict__ mark, const uint32_t *__restrict__ cand_off, int64_t t_begin,
-                                                       CtkCand *__restrict__ out)
+__global__ __launch_bounds__(256) void k_rs_cand_write(ResolveDev r, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
+                                                       const uint32_t *__restrict__ seam_off, const uint8_t *__restrict__ mark,
+                                                       const uint32_t *__restrict__ cand_off, int64_t t_begin, CtkCand *__restrict__ out)
 {
     const int t = (int)blockIdx.x;
     const uint32_t n = seam_cnt[t], cb = r.cprefix[t];
+    const CtkSeam *scratch = seams + seam_off[t];
     __shared__ uint32_t sm[8];
     uint32_t carry = cand_off[t];
     for (uint32_t i0 = 0; i0 < n; i0 += 256) {
         const uint32_t i = i0 + threadIdx.x;
         CtkSeam q;
         uint32_t v = 0;
-        if (i < n) { q = scratch[(int64_t)t * ny + i]; v = cand_wanted(r, q, cb, mark) ? 1u : 0u; }
+        if (i < n) { q = scratch[i]; v = cand_wanted(r, q, cb, mark) ? 1u : 0u; }
         uint32_t tot;
         uint32_t ex = block_excl_scan(v, sm, &tot);
         if (v) {
@@ -447,4 +451,32 @@ __global__ void k_rs_final(ResolveDev r, FoldArgs f, int64_t t_begin, int32_t *_
         }
         comp_label[g] = cplx ? -l : cur;
     }
+}
+
+
+// ---- helpers for tables gathered from several shards -------------------------------------------------------
+__global__ void k_add_t_pairs(CtkPair *p, uint32_t n, uint32_t dt)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i].t += dt;
+}
+__global__ void k_add_t_seams(CtkSeam *p, uint32_t n, uint32_t dt, uint32_t *seam_cnt /* global, zeroed */)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { p[i].t += dt; atomicAdd(&seam_cnt[p[i].t], 1u); }
+}
+__global__ void k_add_u32(uint32_t *p, uint32_t n, uint32_t d)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] += d;
+}
+__global__ void k_fill_comp_t(const uint32_t *__restrict__ ncomp, const uint32_t *__restrict__ cprefix, uint32_t *__restrict__ comp_t)
+{
+    const uint32_t t = blockIdx.x, n = ncomp[t], cb = cprefix[t];
+    for (uint32_t c = threadIdx.x; c < n; c += blockDim.x) comp_t[cb + c] = t;
+}
+__global__ void k_iota_mul(uint32_t *p, uint32_t n, uint32_t mul)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i * mul;
 }

@@ -38,13 +38,15 @@ struct CtkBlobHeader {
     int32_t wshift;
     int32_t has_prev;
     int64_t ncomps, npairs, nseams;
+    int64_t npairs_grouped;   // the first npairs_grouped pair records are grouped per timestep (pair_base / pair_cnt)
     // followed (each section 8-byte aligned) by
     //   uint32_t ncomp[T]
     //   uint32_t comp_mrep[ncomps]     id (within the timestep) of the smallest member of the seam-merged component
     //   uint16_t comp_box[ncomps][4]   y0, y1, x0, x1 (inclusive)
     //   int64_t  comp_area[ncomps][2]  limb sums of the component's own area
     //   CtkPair  pairs[npairs]
-    //   CtkSeam  seams[nseams]
+    //   CtkSeam  seams[nseams]         (t, y) order
+    //   uint32_t pair_base[T], pair_cnt[T]   records of timestep t: pairs[pair_base[t] .. +pair_cnt[t]) (grouped part)
 };
 
 static inline size_t ctk_align8(size_t n) { return (n + 7) & ~(size_t)7; }
@@ -53,7 +55,7 @@ static inline size_t ctk_blob_bytes(int64_t T, int64_t ncomps, int64_t npairs, i
 {
     return sizeof(CtkBlobHeader) + ctk_align8((size_t)T * 4) + ctk_align8((size_t)ncomps * 4) +
            ctk_align8((size_t)ncomps * 8) + (size_t)ncomps * 16 + (size_t)npairs * sizeof(CtkPair) +
-           (size_t)nseams * sizeof(CtkSeam);
+           (size_t)nseams * sizeof(CtkSeam) + 2 * ctk_align8((size_t)T * 4);
 }
 
 struct ctk_result {

@@ -88,6 +88,26 @@ class TorchComm:
         dist.all_gather(out, buf)
         return [bytes(o[:s].cpu().numpy().tobytes()) for o, s in zip(out, sizes)]
 
+    def allgather_device(self, tensor):
+        """tensor: uint8 (device tensor with nccl, CPU tensor with gloo), sizes may differ between ranks.
+        Returns (list of uint8 tensors, list of byte counts); the tensors are padded to the largest size."""
+        torch, dist = self.torch, self.dist
+        n = torch.tensor([tensor.numel()], dtype=torch.int64, device=self._dev())
+        sizes = [torch.zeros(1, dtype=torch.int64, device=self._dev()) for _ in range(self.world)]
+        dist.all_gather(sizes, n)
+        sizes = [int(x.item()) for x in sizes]
+        mx = max(max(sizes), 1)
+        if tensor.numel() == mx:
+            buf = tensor
+        else:
+            buf = torch.zeros(mx, dtype=torch.uint8, device=self._dev())
+            buf[:tensor.numel()] = tensor
+        out = [torch.empty(mx, dtype=torch.uint8, device=self._dev()) for _ in range(self.world)]
+        dist.all_gather(out, buf)
+        if self.device is not None:
+            torch.cuda.synchronize(self.device)
+        return out, sizes
+
     def ring_shift(self, send, recv_like):
         """rank r -> r+1 (no wrap).  `send`: uint8 tensor or None (last rank); returns the received uint8
         tensor or None (rank 0).  Fixed size on every rank."""
@@ -170,6 +190,49 @@ class HipShardEngine:
     def tables(self):
         return self.trk.shard_tables()
 
+    def resolve_gathered(self, shard, t_begin, overlap, twosided):
+        """device path: table blob stays in HBM, all-gathered over the communicator, resolved on the device"""
+        ptr, nbytes = self.trk.shard_tables_dev()
+        if self.on_device:
+            mine = self.comm.device_bytes(ptr.value, nbytes)
+        else:
+            host = np.empty(nbytes, dtype=np.uint8)
+            self.trk.d2h(host, ptr)
+            mine = self.comm.torch.from_numpy(host)
+        blobs, sizes = self.comm.allgather_device(mine)
+        self._gathered = blobs                                   # keep alive until the resolver is done
+        stage = []
+        if self.on_device:
+            ptrs = [b.data_ptr() for b in blobs]
+        else:
+            ptrs = []
+            for b, n in zip(blobs, sizes):
+                d = self.trk.malloc(max(n, 8))
+                self.trk.h2d(d, b.numpy()[:n])
+                stage.append(d)
+                ptrs.append(d.value)
+        try:
+            ext, n = self.trk.shard_resolve_dev(ptrs, sizes, shard, t_begin, overlap, twosided)
+        finally:
+            for d in stage:
+                self.trk.free(d)
+        self.trk.sync()
+        return self._wrap_ext(ext, n)
+
+    def _wrap_ext(self, ptr, n):
+        self._ext = (ptr, n)
+        if self.on_device:
+            ext = self.comm.device_i32(ptr.value, 2 * (n + 1))
+        else:
+            host = np.empty(2 * (n + 1), dtype=np.int32)
+            self.trk.d2h(host, ptr)
+            ext = self.comm.torch.from_numpy(host)
+            self._keep = ext
+        return ext[:n + 1], ext[n + 1:]
+
+    def stats(self):
+        return self.trk.stats()
+
     def extents(self, result, shard, t_begin):
         ptr, n = self.trk.shard_extents(result, shard, t_begin)
         self.trk.sync()
@@ -192,7 +255,7 @@ class HipShardEngine:
 # ------------------------------------------------------------------------------------------------
 # the driver
 # ------------------------------------------------------------------------------------------------
-def run_sharded(engine, comm, t_begin, overlap, persistence, twosided):
+def run_sharded(engine, comm, t_begin, overlap, persistence, twosided, device_resolve=True):
     """Runs the whole path for this rank's shard.  Returns (n_tracked, info) -- identical on all ranks."""
     rank, world = comm.rank, comm.world
     engine.label2d(has_prev=rank > 0)
@@ -202,15 +265,20 @@ def run_sharded(engine, comm, t_begin, overlap, persistence, twosided):
         if rank > 0:
             engine.halo_import(recv)
     engine.overlap()
-    blob = engine.tables()
-    blobs = comm.allgather_bytes(blob) if world > 1 else [blob]
-    result = _native.resolve(blobs, overlap, twosided)
-    tmin, tmax = engine.extents(result, rank, t_begin)
+    if device_resolve and hasattr(engine, "resolve_gathered"):
+        # tables stay in HBM: all-gather of the device blobs, resolver replicated on every GPU
+        tmin, tmax = engine.resolve_gathered(rank, t_begin, overlap, twosided)
+        info = engine.stats()
+    else:
+        blob = engine.tables()
+        blobs = comm.allgather_bytes(blob) if world > 1 else [blob]
+        result = _native.resolve(blobs, overlap, twosided)
+        tmin, tmax = engine.extents(result, rank, t_begin)
+        info = result.info()
+        result.free()
     if world > 1:
         comm.allreduce_min_max(tmin, tmax)
     n_alive, wrote_bg = engine.write(persistence)
-    info = result.info()
-    result.free()
     bg = comm.max_float(1.0 if wrote_bg else 0.0) > 0 if world > 1 else wrote_bg
     return n_alive + (1 if bg else 0) - 1, info            # len(np.unique(flag)) - 1, contrack.py:793
 
@@ -277,6 +345,10 @@ def bench_main(args, wl, workloads, hbm_peak):
                                  traffic=None, algorithmic_bytes_per_launch=alg[kern], avg_kernel_ms=per.get(kern),
                                  note="rank 0's shard"),
                    kernels_ms=per)
+        try:                                     # RCCL prints its version banner through C stdio: flush it first, so that
+            C.CDLL(None).fflush(None)            # the JSON line is the last line on stdout
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     trk.free(d_in)
     trk.free(d_out)

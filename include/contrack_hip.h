@@ -90,6 +90,15 @@ int ctk_shard_overlap(ctk_handle *h);
  *         handle, valid until the next staged call on it).                                       */
 int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes);
 
+/* the same tables as one blob in DEVICE memory (for an all-gather over RCCL), owned by the handle       */
+int ctk_shard_tables_dev(ctk_handle *h, const void **blob_dev, size_t *nbytes);
+/* device resolver on the device blobs of ALL shards (time order), replicated on every rank; replaces
+ * ctk_shard_tables + ctk_resolve + ctk_shard_extents: on return the per-id extents are computed (all-reduce
+ * them MIN/MAX as described at ctk_shard_extents) and ctk_shard_write may follow.                          */
+int ctk_shard_resolve_dev(ctk_handle *h, const void *const *blobs_dev, const size_t *nbytes, int nshards,
+                          int my_shard, int64_t t_begin, double overlap, int twosided, int32_t **ext_dev,
+                          int64_t *n_labels);
+
 /* resolve: host-side, GPU-free.  Takes the table blobs of ALL shards in time order and evaluates the
  *          sequential parts of the reference on component tables: overlap filter recurrence
  *          (contrack.py:706-742), 3-D labelling ids (contrack.py:748-751), bbox-confined seam merges

@@ -10,7 +10,7 @@ from scipy import ndimage
 
 MAGIC = 0x314b544e4f43
 S8 = np.ones((3, 3), dtype=np.int32)
-HDR_FMT = "<Qqiiiiqqq"          # CtkBlobHeader: magic, T, ny, nx, wshift, has_prev, ncomps, npairs, nseams
+HDR_FMT = "<Qqiiiiqqqq"         # CtkBlobHeader: magic, T, ny, nx, wshift, has_prev, ncomps, npairs, nseams, npairs_grouped
 
 
 def _align8(n):
@@ -80,7 +80,7 @@ def build_tables(mask, wlo, whi, prev_lab=None):
 def pack_blob(tb, wshift, has_prev):
     T, nc, npairs, ns = tb["T"], len(tb["mrep"]), len(tb["pairs"]), len(tb["seams"])
     out = bytearray()
-    out += struct.pack(HDR_FMT, MAGIC, T, tb["ny"], tb["nx"], wshift, int(bool(has_prev)), nc, npairs, ns)
+    out += struct.pack(HDR_FMT, MAGIC, T, tb["ny"], tb["nx"], wshift, int(bool(has_prev)), nc, npairs, ns, 0)
     a = np.asarray(tb["ncomp"], dtype=np.uint32).tobytes()
     out += a + b"\0" * (_align8(len(a)) - len(a))
     a = np.asarray(tb["mrep"], dtype=np.uint32).tobytes()
@@ -92,13 +92,14 @@ def pack_blob(tb, wshift, has_prev):
         out += struct.pack("<IIIIqq", t, c, d, 0, lo, hi)
     for (t, y, cl, cr) in tb["seams"]:
         out += struct.pack("<IIII", t, y, cl, cr)
+    out += b"\0" * (2 * _align8(T * 4))          # pair_base / pair_cnt: nothing is grouped in a CPU-built blob
     return bytes(out)
 
 
 def parse_blob(blob):
     """Canonical (order-independent, duplicate-merged) view of a blob, for equality checks."""
     hdr = struct.unpack_from(HDR_FMT, blob, 0)
-    magic, T, ny, nx, wshift, has_prev, nc, npairs, ns = hdr
+    magic, T, ny, nx, wshift, has_prev, nc, npairs, ns, _ngrouped = hdr
     assert magic == MAGIC
     off = struct.calcsize(HDR_FMT)
     ncomp = np.frombuffer(blob, dtype=np.uint32, count=T, offset=off); off += _align8(T * 4)

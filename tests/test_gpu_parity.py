@@ -158,7 +158,7 @@ def test_size_independent_properties(trk):
 # time-sharded HIP stages: several processes share GPU 0, exchange through gloo (RCCL refuses two ranks
 # on one device; on the 8-GPU node the same driver runs with backend nccl and device-resident buffers)
 # ------------------------------------------------------------------------------------------------
-def _shard_worker(rank, world, port, name, q):
+def _shard_worker(rank, world, port, name, q, device_resolve=True):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -175,7 +175,7 @@ def _shard_worker(rank, world, port, name, q):
         trk.h2d(d_in, a)
         comm = cdist.TorchComm(device=None)
         eng = cdist.HipShardEngine(trk, comm, d_in, t1 - t0, ny, nx, g["thr"][t0:t1], _native.CMP_OPS[g["gorl"]], g["wrow"], d_out)
-        n, info = cdist.run_sharded(eng, comm, t0, g["overlap"], g["persistence"], g["twosided"])
+        n, info = cdist.run_sharded(eng, comm, t0, g["overlap"], g["persistence"], g["twosided"], device_resolve=device_resolve)
         flag = np.empty((t1 - t0, ny, nx), dtype=np.int32)
         if flag.size:
             trk.d2h(flag, d_out)
@@ -188,8 +188,9 @@ def _shard_worker(rank, world, port, name, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("device_resolve", [True, False], ids=["devres", "hostres"])
 @pytest.mark.parametrize("name,world", [("syn2deg_s0", 2), ("chain_a", 3), ("busy_s1", 4), ("noise", 2), ("T3", 4), ("syn1deg", 3)])
-def test_time_sharded_hip_stages(name, world):
+def test_time_sharded_hip_stages(name, world, device_resolve):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -198,7 +199,7 @@ def test_time_sharded_hip_stages(name, world):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, name, q)) for r in range(world)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, name, q, device_resolve)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
