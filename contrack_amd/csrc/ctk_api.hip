@@ -384,7 +384,9 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         a.g_x0 = P<uint16_t>(h->g_x0); a.g_x1 = P<uint16_t>(h->g_x1); a.g_y = P<uint16_t>(h->g_y);
         a.g_parent = P<uint32_t>(h->g_parent); a.g_root = P<uint32_t>(h->g_root); a.g_idmap = P<uint32_t>(h->g_idmap);
         Timer tm(h, CTK_K_LABEL2D);
-        k_label2d_lds<<<(int)T, 256, 0, s>>>(a);
+        // nruns == 0 timesteps are handled by the small variant (RUNS_BELOW = -1)
+        k_label2d_lds<1024, 288, -1><<<(int)T, 256, 0, s>>>(a);
+        if (h->max_runs_step > 1024) k_label2d_lds<2048, 512, 1024><<<(int)T, 256, 0, s>>>(a);
         HIPCHK(hipGetLastError());
         if (h->need_glb) {
             k_label2d_glb<<<(int)T, 256, 0, s>>>(a, P<uint32_t>(h->g_rs));
@@ -704,17 +706,32 @@ void seam_driver(ctk_handle *h, const CtkCand *cand, int64_t ncand, const int32_
     first.assign((size_t)nlab + 1, -1);
     last.assign((size_t)nlab + 1, -1);
     next.clear();
-    auto fold = [&](int32_t l, int32_t t, int32_t y, int32_t x) {
-        int32_t s = 0;
+    // fold of the ops over a seam pixel.  Consecutive seam rows of one blob ask the same question with y+1; the
+    // answer is reused while it provably cannot change: same label / timestep / side, no op recorded since, and
+    // y inside the interval over which every box test taken on the way gives the same outcome.
+    struct Memo { int32_t l = -1, t = -1, ylo = 0, yhi = -1, res = 0; size_t epoch = (size_t)-1; };
+    Memo memo[2];
+    auto fold = [&](int side, int32_t l0, int32_t t, int32_t y, int32_t x) {
+        Memo &m = memo[side];
+        if (m.l == l0 && m.t == t && m.epoch == ops.size() && y >= m.ylo && y <= m.yhi) return m.res;
+        int32_t l = l0, s = 0, ylo = INT32_MIN, yhi = INT32_MAX;
         for (;;) {
             bool moved = false;
             for (int32_t idx = first[(size_t)l]; idx >= 0; idx = next[(size_t)idx]) {
                 if (idx < s) continue;
                 const CtkOp &o = ops[(size_t)idx];
-                if (t >= o.t0 && t <= o.t1 && y >= o.y0 && y <= o.y1 && x >= o.x0 && x <= o.x1) { l = o.lo; s = idx + 1; moved = true; break; }
+                const bool tx_in = t >= o.t0 && t <= o.t1 && x >= o.x0 && x <= o.x1;
+                if (!tx_in) continue;                                   // outside for every y
+                if (y >= o.y0 && y <= o.y1) {                           // inside: stays inside for y in [y0, y1]
+                    ylo = std::max(ylo, o.y0); yhi = std::min(yhi, o.y1);
+                    l = o.lo; s = idx + 1; moved = true; break;
+                }
+                if (y < o.y0) yhi = std::min(yhi, o.y0 - 1); else ylo = std::max(ylo, o.y1 + 1);   // outside because of y only
             }
-            if (!moved) return l;
+            if (!moved) break;
         }
+        m.l = l0; m.t = t; m.ylo = ylo; m.yhi = yhi; m.res = l; m.epoch = ops.size();
+        return l;
     };
     // An op (hi -> lo) moves the pixels labelled hi inside box[hi].  Right after one, no such pixel is left, and
     // new ones can only arrive through a later op whose `lo` is hi.  A seam row that asks for hi -> anything
@@ -732,8 +749,8 @@ void seam_driver(ctk_handle *h, const CtkCand *cand, int64_t ncand, const int32_
         const CtkCand &c = cand[k];
         const bool tl = touched(c.ll), tr = touched(c.lr);
         if (c.ll == c.lr && !tl) continue;                                 // same label, never relabelled: nothing can differ
-        const int32_t p0 = tl ? fold(c.ll, c.t, c.y, 0) : c.ll;
-        const int32_t p1 = tr ? fold(c.lr, c.t, c.y, nx - 1) : c.lr;
+        const int32_t p0 = tl ? fold(0, c.ll, c.t, c.y, 0) : c.ll;
+        const int32_t p1 = tr ? fold(1, c.lr, c.t, c.y, nx - 1) : c.lr;
         nfold += (tl ? 1 : 0) + (tr ? 1 : 0);
         if (p0 == p1) continue;
         const int32_t hi = std::max(p0, p1), lo = std::min(p0, p1);
@@ -1017,10 +1034,15 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
     a.flag = flag_dev; a.counters = P<uint32_t>(h->counters);
     a.nrows = h->T * h->ny; a.ny = h->ny; a.nx = h->nx; a.W = h->W;
     const int64_t npl = (int64_t)h->ny * h->nx;
-    const int64_t nblk4 = h->T * ((h->ny + CTK_RB - 1) / CTK_RB);
-    if ((h->nx % 4 == 0) && (((uintptr_t)flag_dev & 15) == 0) && npl < 0x7fffffff && nblk4 < 0x7fffffff && h->T > 0 && h->W <= 64) {
+    // rows per workgroup: about 16 KB of output each (measured best on MI355X: 8-16 rows at nx = 360), at least 4 rows
+    int rb = (int)std::max<int64_t>(4, std::min<int64_t>(64, 16384 / ((int64_t)h->nx * 4)));
+    rb = std::min(rb, h->ny);
+    const int rvcap = 2048;
+    const size_t lds = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) + (size_t)rvcap * 4;
+    const int64_t nblk4 = h->T * ((h->ny + rb - 1) / rb);
+    if ((h->nx % 4 == 0) && (((uintptr_t)flag_dev & 15) == 0) && npl < 0x7fffffff && nblk4 < 0x7fffffff && h->T > 0 && lds <= 60 * 1024) {
         const unsigned grid = (unsigned)nblk4;
-        k_relabel_v4<<<grid, 256, 0, h->stream>>>(a);
+        k_relabel_v4<<<grid, 256, lds, h->stream>>>(a, rb, rvcap);
     } else {
         k_relabel<<<grid_for_rows(a.nrows), 256, 0, h->stream>>>(a);
     }

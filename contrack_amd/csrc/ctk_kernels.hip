@@ -281,9 +281,6 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ 
 //            (same-row pairs only, contrack.py:693-698); second flatten -> merged component
 //   phase 6  component ids, per-component bbox and exact area limbs, seam-row records
 // ------------------------------------------------------------------------------------------------
-#define CTK_LDS_COMPS 512
-#define CTK_LDS_MASKW (CTK_LDS_COMPS * 4)        // mask staging and component tables share this LDS area (16 KB)
-
 struct Label2dArgs {
     const uint64_t *mask;
     const uint16_t *wstart;        // [T][ny][W] run starts left of each word (k_rowcount)
@@ -306,10 +303,10 @@ struct Label2dArgs {
     uint32_t *g_parent, *g_root, *g_idmap;
 };
 
-template <int THREADS>
+template <int THREADS, typename IT /* uint16_t when run / component indices fit, else uint32_t */, int LDS_COMPS>
 __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, const uint32_t nruns,
                                              uint16_t *x0, uint16_t *x1, uint16_t *yrow, uint32_t *parent,
-                                             uint32_t *root, uint32_t *idmap, uint32_t *rs /* rowstart, ny+1 */,
+                                             IT *root, IT *idmap, uint32_t *rs /* rowstart, ny+1 */,
                                              uint32_t *sm_scan, const uint64_t *mrow /* the timestep's mask words (LDS or global) */,
                                              void *lds_tab /* CTK_LDS_COMPS x 32 B of LDS for the component tables, or nullptr */)
 {
@@ -376,7 +373,7 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
     __syncthreads();
 
     // ---- phase 4: flatten (no-wrap components) --------------------------------------------------
-    for (uint32_t r = tid; r < nruns; r += THREADS) root[r] = uf_find(parent, r);
+    for (uint32_t r = tid; r < nruns; r += THREADS) root[r] = (IT)uf_find(parent, r);
     __syncthreads();
     for (uint32_t r = tid; r < nruns; r += THREADS) parent[r] = root[r];
     __syncthreads();
@@ -391,7 +388,7 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
     __syncthreads();
     for (uint32_t r = tid; r < nruns; r += THREADS) {
         uint32_t m = uf_find(parent, r);
-        idmap[r] = m;                      // temporarily: merged root of r
+        idmap[r] = (IT)m;                  // temporarily: merged root of r
     }
     __syncthreads();
     for (uint32_t r = tid; r < nruns; r += THREADS) parent[r] = idmap[r];
@@ -405,7 +402,7 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
             uint32_t r = r0 + tid;
             uint32_t v = (r < nruns && root[r] == r) ? 1u : 0u, tot;
             uint32_t ex = block_excl_scan(v, sm_scan, &tot);
-            if (r < nruns) idmap[r] = carry + ex;          // meaningful at roots only
+            if (r < nruns) idmap[r] = (IT)(carry + ex);    // meaningful at roots only
             carry += tot;
         }
         ncomp = carry;
@@ -417,9 +414,9 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
     int64_t *garea = a.cs_area + (int64_t)rbase * 2;
     // per-component bbox / exact area: accumulated with LDS atomics when the timestep's components fit the
     // LDS table (the staged mask words are dead by now and lend their space), else with global atomics
-    const bool tab_lds = lds_tab != nullptr && ncomp <= CTK_LDS_COMPS;
+    const bool tab_lds = lds_tab != nullptr && ncomp <= (uint32_t)LDS_COMPS;
     int64_t *carea = tab_lds ? (int64_t *)lds_tab : garea;
-    uint32_t *cbox = tab_lds ? (uint32_t *)((int64_t *)lds_tab + 2 * CTK_LDS_COMPS) : gbox;
+    uint32_t *cbox = tab_lds ? (uint32_t *)((int64_t *)lds_tab + 2 * LDS_COMPS) : gbox;
     for (uint32_t c = tid; c < ncomp; c += THREADS) {
         cbox[c * 4 + 0] = 0xffffu; cbox[c * 4 + 1] = 0u; cbox[c * 4 + 2] = 0xffffu; cbox[c * 4 + 3] = 0u;
         carea[c * 2] = 0; carea[c * 2 + 1] = 0;
@@ -474,28 +471,33 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
 #define CTK_LDS_RUNS 2048
 #define CTK_LDS_NY 1024
 
+// LDS variants: RUNS = most runs per timestep carried, COMPS = components whose bbox/area tables live in LDS
+// (the table area doubles as the staging area of the timestep's mask words, COMPS*4 words).
+//   <1024, 288>: 27 KB -> 5 workgroups per CU (typical 1 deg Z500 timestep: 500 runs, 40 components)
+//   <2048, 512>: 46 KB -> 3 workgroups per CU
+template <int RUNS, int COMPS, int RUNS_BELOW>
 __global__ __launch_bounds__(256) void k_label2d_lds(Label2dArgs a)
 {
     const int t = (int)blockIdx.x;
     const uint32_t nruns = a.run_base[t + 1] - a.run_base[t];
-    if (nruns > CTK_LDS_RUNS || a.ny > CTK_LDS_NY) return;        // k_label2d_glb takes it
+    if (nruns > RUNS || (int64_t)nruns <= (int64_t)RUNS_BELOW || a.ny > CTK_LDS_NY) return;        // another variant takes it
     if (nruns == 0) {
         if (threadIdx.x == 0) { a.ncomp[t] = 0; a.seam_cnt[t] = 0; }
         return;
     }
-    __shared__ uint16_t x0[CTK_LDS_RUNS], x1[CTK_LDS_RUNS], yrow[CTK_LDS_RUNS];
-    __shared__ uint32_t parent[CTK_LDS_RUNS], root[CTK_LDS_RUNS], idmap[CTK_LDS_RUNS];
+    __shared__ uint16_t x0[RUNS], x1[RUNS], yrow[RUNS], root[RUNS], idmap[RUNS];
+    __shared__ uint32_t parent[RUNS];
     __shared__ uint32_t rs[CTK_LDS_NY + 1];
-    __shared__ uint64_t mlds[CTK_LDS_MASKW];
+    __shared__ uint64_t mlds[COMPS * 4];
     __shared__ uint32_t sm_scan[8];
     const int nwords = a.ny * a.W;
     const uint64_t *mg = a.mask + (int64_t)t * nwords;
     const uint64_t *mrow = mg;
-    if (nwords <= CTK_LDS_MASKW) {                                  // stage the timestep's mask (8.7 KB at 1 deg)
+    if (nwords <= COMPS * 4) {                                      // stage the timestep's mask (8.7 KB at 1 deg)
         for (int i = (int)threadIdx.x; i < nwords; i += 256) mlds[i] = mg[i];
         mrow = mlds;
     }
-    label2d_body<256>(a, t, nruns, x0, x1, yrow, parent, root, idmap, rs, sm_scan, mrow, mlds);
+    label2d_body<256, uint16_t, COMPS>(a, t, nruns, x0, x1, yrow, parent, root, idmap, rs, sm_scan, mrow, mlds);
 }
 
 __global__ __launch_bounds__(256) void k_label2d_glb(Label2dArgs a, uint32_t *g_rs /* [T][ny+1] scratch */)
@@ -505,8 +507,8 @@ __global__ __launch_bounds__(256) void k_label2d_glb(Label2dArgs a, uint32_t *g_
     const uint32_t nruns = a.run_base[t + 1] - rb;
     if (!(nruns > CTK_LDS_RUNS || a.ny > CTK_LDS_NY)) return;
     __shared__ uint32_t sm_scan[8];
-    label2d_body<256>(a, t, nruns, a.g_x0 + rb, a.g_x1 + rb, a.g_y + rb, a.g_parent + rb, a.g_root + rb,
-                      a.g_idmap + rb, g_rs + (int64_t)t * (a.ny + 1), sm_scan, a.mask + (int64_t)t * a.ny * a.W, nullptr);
+    label2d_body<256, uint32_t, 1>(a, t, nruns, a.g_x0 + rb, a.g_x1 + rb, a.g_y + rb, a.g_parent + rb, a.g_root + rb,
+                                   a.g_idmap + rb, g_rs + (int64_t)t * (a.ny + 1), sm_scan, a.mask + (int64_t)t * a.ny * a.W, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -836,25 +838,27 @@ struct RelabelArgs {
 // fast path (nx % 4 == 0, 16-byte aligned flag): one workgroup per (timestep, 16 rows).  The rows' mask
 // words, per-word run prefixes, row starts and the final values of their runs are staged in LDS first, so the
 // store stream has no dependent global loads: one lane per 4 consecutive pixels, non-temporal int4 stores.
-#define CTK_RV_LDS 1024
-__global__ __launch_bounds__(256) void k_relabel_v4(RelabelArgs a)
+// rb rows per workgroup and rvcap staged run values are launch parameters (dynamic LDS:
+// rb*W*8 + rb*W*2 (padded to 8) + (rb+1)*4 (padded to 8) + rvcap*4 bytes).
+__global__ __launch_bounds__(256) void k_relabel_v4(RelabelArgs a, int rb, int rvcap)
 {
     const int ny = a.ny, nx = a.nx, W = a.W;
-    const int nchunk = (ny + CTK_RB - 1) / CTK_RB;
-    const int t = (int)(blockIdx.x / (unsigned)nchunk), y0 = (int)(blockIdx.x - (unsigned)t * nchunk) * CTK_RB, tid = (int)threadIdx.x;
-    const int rows = min(CTK_RB, ny - y0);
+    const int nchunk = (ny + rb - 1) / rb;
+    const int t = (int)(blockIdx.x / (unsigned)nchunk), y0 = (int)(blockIdx.x - (unsigned)t * nchunk) * rb, tid = (int)threadIdx.x;
+    const int rows = min(rb, ny - y0);
     const int64_t row0 = (int64_t)t * ny + y0;
-    __shared__ uint64_t mrow[CTK_RB * 64];                 // W <= 64 on this path
-    __shared__ uint16_t wst[CTK_RB * 64];
-    __shared__ uint32_t rst[CTK_RB + 1];
-    __shared__ int32_t rvs[CTK_RV_LDS];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *mrow = reinterpret_cast<uint64_t *>(smem);
+    uint16_t *wst = reinterpret_cast<uint16_t *>(smem + (size_t)rb * W * 8);
+    uint32_t *rst = reinterpret_cast<uint32_t *>(smem + (size_t)rb * W * 8 + (((size_t)rb * W * 2 + 7) & ~(size_t)7));
+    int32_t *rvs = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(rst) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7));
     const uint32_t trun = a.run_base[t + 1] - a.run_base[t];
     for (int i = tid; i < rows * W; i += 256) { mrow[i] = a.mask[row0 * W + i]; wst[i] = a.wstart[row0 * W + i]; }
     for (int i = tid; i <= rows; i += 256) rst[i] = (y0 + i < ny) ? a.rowstart[row0 + i] : trun;
     __syncthreads();
     const uint32_t r0 = rst[0], nr = rst[rows] - r0;
     const int32_t *rvg = a.run_val + a.run_base[t] + r0;
-    const bool staged = nr <= CTK_RV_LDS;
+    const bool staged = nr <= (uint32_t)rvcap;
     if (staged) for (uint32_t i = tid; i < nr; i += 256) rvs[i] = rvg[i];
     __syncthreads();
     const int n4 = nx >> 2, total = rows * n4;
