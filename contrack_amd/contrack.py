@@ -405,6 +405,62 @@ class contrack(object):
         self.ds['flag'] = (dims, flag.transpose(inverse), attrs)
         logger.info("Running contrack... DONE\n{} contours tracked".format(n_tracked))
 
+    # ---- life cycle (contrack.py:799-907); host numpy/scipy, consumer of `flag` ------------------
+    def _time_labels(self):
+        """'%Y%m%d_%H' per timestep (contrack.py:862)"""
+        t = self.ds[self._time_name]
+        try:
+            return [str(v) for v in np.asarray(t.dt.strftime('%Y%m%d_%H').values)]
+        except AttributeError:
+            vals = np.asarray(t.data)
+            if vals.dtype.kind == "M":
+                import pandas as pd
+                return [pd.Timestamp(v).strftime('%Y%m%d_%H') for v in vals]
+            return [str(v) for v in vals]
+
+    def run_lifecycle(self, flag, variable):
+        """Intensity, size and centre of mass of every flagged contour at every time step.
+
+        flag: name of the flag variable (output of run_contrack); variable: field used for intensity and centre of
+        mass.  Returns a pandas DataFrame ['Flag', 'Date', 'Longitude', 'Latitude', 'Intensity', 'Size'] sorted by
+        (Flag, Date) -- one row per (time step, flag id)."""
+        import pandas as pd
+        from scipy import ndimage
+        logger.info("\nRun Lifecycle \n########### \n    flag:    {}\n    variable:    {}".format(flag, variable))
+        self._ensure_set_up()
+        names = (self._time_name, self._latitude_name, self._longitude_name)
+
+        def slab(name):
+            da = self.ds[name]
+            return np.asarray(da.data).transpose([tuple(da.dims).index(d) for d in names])
+
+        flags, field = slab(flag), slab(variable)
+        lat = np.asarray(self.ds[self._latitude_name].data)
+        lon = np.asarray(self.ds[self._longitude_name].data)
+        wgrid = np.ones((len(lat), len(lon))) * row_weights(lat, self._dlat, self._dlon)[:, None]       # contrack.py:847-848
+        dates = self._time_labels()
+        rows = []
+        for i in range(flags.shape[0]):
+            plane, values = flags[i], field[i]
+            ids = np.unique(plane)
+            for ident in ids[ids != 0]:
+                member = plane == ident
+                area = np.sum(wgrid[member])                                                           # :874
+                intensity = np.sum(wgrid[member] * values[member]) / area                              # :875-876
+                lon_axis = lon
+                if ident in plane[:, 0] and ident in plane[:, -1]:                                     # split at the seam (:880-889)
+                    cols = np.unique(np.nonzero(member)[1])
+                    shift = cols[np.argmax(np.diff(cols)) + 1]                                          # western edge of the contour
+                    plane_r, values_r = np.roll(plane, -shift, axis=1), np.roll(values, -shift, axis=1)
+                    lon_axis = np.roll(lon, -shift)
+                    com = ndimage.center_of_mass(values_r * wgrid, plane_r, [ident])
+                else:
+                    com = ndimage.center_of_mass(values * wgrid, plane, [ident])                        # :892
+                rows.append((ident, dates[i], int(lon_axis[int(com[0][1])]), int(lat[int(com[0][0])]),
+                             round(intensity, 2), round(area, 2)))
+        return pd.DataFrame(sorted(rows, key=lambda r: (r[0], r[1])),
+                            columns=['Flag', 'Date', 'Longitude', 'Latitude', 'Intensity', 'Size'])
+
     # ---- utility (contrack.py:912-949) ---------------------------------------------------------------------------
     def greatcircle_dist(self, lon1, lat1, lon2, lat2):
         """great-circle distance in km between (lon1, lat1) and (lon2, lat2) given in degrees"""

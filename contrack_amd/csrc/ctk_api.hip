@@ -43,6 +43,8 @@ enum State { ST_IDLE = 0, ST_LABELLED, ST_OVERLAPPED, ST_TABLES, ST_EXTENTS };
 struct ctk_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side[2] = {nullptr, nullptr};      // the labelling variants of one shard run concurrently
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     State state = ST_IDLE;
     // geometry of the current shard
     int64_t T = 0;
@@ -60,7 +62,7 @@ struct ctk_handle {
     DevBuf g_ncomp, g_cprefix, g_mrep, g_box, g_area, g_comp_t, g_pairs, g_pair_base, g_pair_cnt, g_seams, g_seam_cnt, g_seam_off, g_counters, g_label;
     // device resolver work space
     DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lbox,
-        rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_scalars, rv_mark;
+        rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_scalars, rv_mark, rv_inv, rv_ff;
     void *h_cand = nullptr;          // pinned: candidates + boxes download
     size_t h_cand_cap = 0;
     void *h_ops = nullptr;           // pinned: op upload staging
@@ -191,6 +193,11 @@ extern "C" int ctk_create(ctk_handle **out, int device)
     if (!h) return ctk_set_error(CTK_E_NOMEM, "ctk_create: out of memory");
     h->device = device;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return ctk_set_error(CTK_E_NODEVICE, "hipStreamCreate failed"); }
+    for (int k = 0; k < 2; k++) {
+        if (hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming) != hipSuccess) { ctk_destroy(h); return ctk_set_error(CTK_E_NODEVICE, "hipStreamCreate failed"); }
+    }
+    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) { ctk_destroy(h); return ctk_set_error(CTK_E_NODEVICE, "hipEventCreate failed"); }
     memset(h->ms, 0, sizeof(h->ms));
     memset(h->ev_used, 0, sizeof(h->ev_used));
     *out = h;
@@ -209,13 +216,15 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->g_area, &h->g_comp_t, &h->g_pairs, &h->g_pair_base, &h->g_pair_cnt, &h->g_seams, &h->g_seam_cnt, &h->g_seam_off, &h->g_counters,
                       &h->g_label, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
                       &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
-                      &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_scalars, &h->rv_mark};
+                      &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
     if (h->h_cand) (void)hipHostFree(h->h_cand);
     if (h->h_ops) (void)hipHostFree(h->h_ops);
     if (h->ev_ready) for (int k = 0; k <= CTK_K_COUNT; k++) { (void)hipEventDestroy(h->ev[k][0]); (void)hipEventDestroy(h->ev[k][1]); }
+    for (int k = 0; k < 2; k++) { if (h->side[k]) (void)hipStreamDestroy(h->side[k]); if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -231,6 +240,13 @@ extern "C" int ctk_set_timing(ctk_handle *h, int enable)
     h->timing = enable;
     return CTK_OK;
 }
+
+#ifdef CTK_PHASE_TIMING
+extern "C" int ctk_debug_phase_times(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_t), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int ctk_get_stats(ctk_handle *h, int64_t *out)
 {
@@ -384,9 +400,23 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         a.g_x0 = P<uint16_t>(h->g_x0); a.g_x1 = P<uint16_t>(h->g_x1); a.g_y = P<uint16_t>(h->g_y);
         a.g_parent = P<uint32_t>(h->g_parent); a.g_root = P<uint32_t>(h->g_root); a.g_idmap = P<uint32_t>(h->g_idmap);
         Timer tm(h, CTK_K_LABEL2D);
-        // nruns == 0 timesteps are handled by the small variant (RUNS_BELOW = -1)
-        k_label2d_lds<1024, 288, -1><<<(int)T, 256, 0, s>>>(a);
-        if (h->max_runs_step > 1024) k_label2d_lds<2048, 512, 1024><<<(int)T, 256, 0, s>>>(a);
+        // The variants take disjoint sets of timesteps (by run count): launch them on concurrent streams.
+        // nruns == 0 timesteps are handled by the small variant (RUNS_BELOW = -1).
+        const bool v2 = h->max_runs_step > 1024, v3 = h->max_runs_step > 2048;
+        if (v2 || v3) HIPCHK(hipEventRecord(h->ev_fork, s));
+        k_label2d_lds<1024, 288, -1, 256><<<(int)T, 256, 0, s>>>(a);
+        if (v2) {
+            HIPCHK(hipStreamWaitEvent(h->side[0], h->ev_fork, 0));
+            k_label2d_lds<2048, 512, 1024, 512><<<(int)T, 512, 0, h->side[0]>>>(a);
+            HIPCHK(hipEventRecord(h->ev_join[0], h->side[0]));
+        }
+        if (v3) {
+            HIPCHK(hipStreamWaitEvent(h->side[1], h->ev_fork, 0));
+            k_label2d_lds<4096, 512, 2048, 1024><<<(int)T, 1024, 0, h->side[1]>>>(a);
+            HIPCHK(hipEventRecord(h->ev_join[1], h->side[1]));
+        }
+        if (v2) HIPCHK(hipStreamWaitEvent(s, h->ev_join[0], 0));
+        if (v3) HIPCHK(hipStreamWaitEvent(s, h->ev_join[1], 0));
         HIPCHK(hipGetLastError());
         if (h->need_glb) {
             k_label2d_glb<<<(int)T, 256, 0, s>>>(a, P<uint32_t>(h->g_rs));
@@ -808,6 +838,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     CTKCHK(ensure(h, h->rv_scalars, 64));
     CTKCHK(ensure(h, h->rv_tdirty, (size_t)2 * (T > 0 ? T : 1)));
     CTKCHK(ensure(h, h->rv_mark, R + 1));
+    CTKCHK(ensure(h, h->rv_inv, R * 8)); CTKCHK(ensure(h, h->rv_ff, R * 8));
 
     ResolveDev r;
     r.ncomp = in.ncomp; r.cprefix = in.cprefix; r.mrep = in.mrep; r.comp_t = in.comp_t;
@@ -817,6 +848,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     r.F = P<int64_t>(h->rv_F); r.B = P<int64_t>(h->rv_B); r.keep0 = P<uint8_t>(h->rv_keep0); r.keep1 = P<uint8_t>(h->rv_keep1);
     r.changed = P<uint32_t>(h->rv_changed); r.parent = P<uint32_t>(h->rv_parent); r.isroot = P<uint32_t>(h->rv_isroot);
     r.rank = P<uint32_t>(h->rv_rank); r.lab = P<int32_t>(h->rv_lab); r.lbox = P<int32_t>(h->rv_lbox);
+    r.mark = P<uint8_t>(h->rv_mark); r.inv = P<double>(h->rv_inv); r.ff = P<double>(h->rv_ff);
 
     const int gc = (int)std::min<size_t>((R + 255) / 256, 2048), gp = (int)std::min<size_t>((PC + 255) / 256, 2048);
     uint32_t *hs = (uint32_t *)h->h_small + (h->T + 2);
@@ -827,6 +859,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         if (it_done == 0) {
             k_rs_init<<<gc, 256, 0, s>>>(r);
             k_rs_pairs<<<gp, 256, 0, s>>>(r);
+            k_rs_prep<<<gc, 256, 0, s>>>(r);
         }
         // overlap filter: a round of passes (passes after the fixed point return at once)
         if (T > 2)
@@ -840,9 +873,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         k_scan_blocksum<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_bsum));
         k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_bsum), nsb, P<uint32_t>(h->rv_boff), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
         k_scan_apply<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_boff), r.rank);
-        k_rs_labels<<<gc, 256, 0, s>>>(r);
-        k_rs_boxes<<<gc, 256, 0, s>>>(r, 0);
-        HIPCHK(hipMemsetAsync(h->rv_mark.p, 0, R + 1, s));
+        k_rs_labels<<<gc, 256, 0, s>>>(r, 0);
         if (T > 0) {
             k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<uint8_t>(h->rv_mark));
             k_rs_cand_count<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<uint8_t>(h->rv_mark), P<uint32_t>(h->rv_cand_cnt));

@@ -80,12 +80,19 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *sm, ui
 }
 
 // lock-free union-find with "smaller index wins" hooking (root = smallest index of the set)
+// find with intermediate pointer jumping: every visited node is re-pointed to its grandparent.  Parents only
+// ever decrease and always stay inside the set, so the racing writes of other lanes are harmless.
 __device__ __forceinline__ uint32_t uf_find(uint32_t *p, uint32_t i)
 {
+    uint32_t cur = __hip_atomic_load(&p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (cur == i) return i;
+    uint32_t prev = i;
     for (;;) {
-        uint32_t q = __hip_atomic_load(&p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (q == i) return i;
-        i = q;
+        const uint32_t next = __hip_atomic_load(&p[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (next == cur) return cur;
+        __hip_atomic_store(&p[prev], next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        prev = cur;
+        cur = next;
     }
 }
 __device__ __forceinline__ void uf_unite(uint32_t *p, uint32_t a, uint32_t b)
@@ -303,58 +310,88 @@ struct Label2dArgs {
     uint32_t *g_parent, *g_root, *g_idmap;
 };
 
+#ifdef CTK_PHASE_TIMING
+__device__ unsigned long long g_phase_t[16];
+#define PHASE_MARK(k) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_phase_t[k] = wall_clock64(); } while (0)
+#else
+#define PHASE_MARK(k) do { } while (0)
+#endif
+
 template <int THREADS, typename IT /* uint16_t when run / component indices fit, else uint32_t */, int LDS_COMPS>
 __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, const uint32_t nruns,
                                              uint16_t *x0, uint16_t *x1, uint16_t *yrow, uint32_t *parent,
                                              IT *root, IT *idmap, uint32_t *rs /* rowstart, ny+1 */,
                                              uint32_t *sm_scan, const uint64_t *mrow /* the timestep's mask words (LDS or global) */,
-                                             void *lds_tab /* CTK_LDS_COMPS x 32 B of LDS for the component tables, or nullptr */)
+                                             const bool mrow_staged /* mrow is the whole timestep in LDS */,
+                                             void *lds_tab /* LDS_COMPS x 32 B of LDS: band staging, then the component tables; or nullptr */)
 {
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, nwv = THREADS >> 6;
     const int ny = a.ny, nx = a.nx, W = a.W;
     const uint32_t rbase = a.run_base[t];
 
+    PHASE_MARK(0);
     // ---- phase 1: rowstart (computed by k_rowcount) -> LDS/scratch -------------------------------
     for (int y = tid; y < ny; y += THREADS) rs[y] = a.rowstart[(int64_t)t * ny + y];
     if (tid == 0) rs[ny] = nruns;
     __syncthreads();
 
+    PHASE_MARK(1);
     // ---- phase 2: run extraction, one thread per mask word -------------------------------------
     // the i-th start bit and the i-th end bit of a row delimit its i-th run; the number of starts / ends in the
     // words to the left comes from k_rowcount's per-word prefix (an open run at the word boundary has started
-    // but not ended yet).
+    // but not ended yet).  The mask words are read from LDS: either the whole timestep was staged by the caller
+    // (mrow_staged) or bands of rows are staged here through the table area.
     {
-        const uint16_t *ws = a.wstart + (int64_t)t * ny * W;
-        const int nwords = ny * W;
-        for (int idx = tid; idx < nwords; idx += THREADS) {
-            const uint64_t m = mrow[idx];
-            if (m == 0ull) continue;
-            const int y = idx / W, w = idx - y * W;
-            const uint64_t cin = (w > 0) ? (mrow[idx - 1] >> 63) : 0ull;
-            const uint64_t nin = (w + 1 < W) ? (mrow[idx + 1] & 1ull) : 0ull;
-            uint64_t starts = m & ~((m << 1) | cin);
-            uint64_t ends = m & ~((m >> 1) | (nin << 63));
-            const uint32_t nbefore = rs[y] + ws[idx];
-            uint32_t si = nbefore, ei = nbefore - (uint32_t)(cin & m & 1ull);      // open run: started, not yet ended
-            const int xb = w * 64;
-            while (starts) {
-                int b = __builtin_ctzll(starts);
-                starts &= starts - 1;
-                x0[si] = (uint16_t)(xb + b);
-                yrow[si] = (uint16_t)y;
-                parent[si] = si;
-                si++;
+        const uint16_t *wglob = a.wstart + (int64_t)t * ny * W;
+        const uint64_t *mglob = a.mask + (int64_t)t * ny * W;
+        // band buffer in the table area: rows x W mask words followed by rows x W 16-bit prefixes
+        uint64_t *band = (uint64_t *)lds_tab;
+        const bool banded = !mrow_staged && lds_tab != nullptr && W * 10 <= LDS_COMPS * 32;
+        const int band_rows = banded ? max(1, (LDS_COMPS * 32) / (W * 10)) : ny;
+        uint16_t *wband = banded ? (uint16_t *)(band + (size_t)band_rows * W) : nullptr;
+        for (int yb = 0; yb < ny; yb += band_rows) {
+            const int rows = min(band_rows, ny - yb);
+            const uint64_t *src = mrow_staged ? mrow + (int64_t)yb * W : mglob + (int64_t)yb * W;    // word (y, w) at src[(y - yb) * W + w]
+            const uint16_t *ws = wglob + (int64_t)yb * W;
+            if (banded) {
+                __syncthreads();                                      // previous band fully consumed
+                for (int i = tid; i < rows * W; i += THREADS) { band[i] = mglob[(int64_t)yb * W + i]; wband[i] = wglob[(int64_t)yb * W + i]; }
+                __syncthreads();
+                src = band;
+                ws = wband;
             }
-            while (ends) {
-                int b = __builtin_ctzll(ends);
-                ends &= ends - 1;
-                x1[ei] = (uint16_t)(xb + b);
-                ei++;
+            const int nwords = rows * W;
+            for (int k = tid; k < nwords; k += THREADS) {
+                const uint64_t m = src[k];
+                if (m == 0ull) continue;
+                const int yl = k / W, w = k - yl * W, y = yb + yl;
+                const uint64_t cin = (w > 0) ? (src[k - 1] >> 63) : 0ull;
+                const uint64_t nin = (w + 1 < W) ? (src[k + 1] & 1ull) : 0ull;
+                uint64_t starts = m & ~((m << 1) | cin);
+                uint64_t ends = m & ~((m >> 1) | (nin << 63));
+                const uint32_t nbefore = rs[y] + ws[k];
+                uint32_t si = nbefore, ei = nbefore - (uint32_t)(cin & m & 1ull);      // open run: started, not yet ended
+                const int xb = w * 64;
+                while (starts) {
+                    int b = __builtin_ctzll(starts);
+                    starts &= starts - 1;
+                    x0[si] = (uint16_t)(xb + b);
+                    yrow[si] = (uint16_t)y;
+                    parent[si] = si;
+                    si++;
+                }
+                while (ends) {
+                    int b = __builtin_ctzll(ends);
+                    ends &= ends - 1;
+                    x1[ei] = (uint16_t)(xb + b);
+                    ei++;
+                }
             }
         }
     }
     __syncthreads();
 
+    PHASE_MARK(2);
     // ---- phase 3: unions with the previous row ------------------------------------------------
     for (uint32_t r = tid; r < nruns; r += THREADS) {
         const int y = yrow[r];
@@ -372,12 +409,14 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
     }
     __syncthreads();
 
+    PHASE_MARK(3);
     // ---- phase 4: flatten (no-wrap components) --------------------------------------------------
     for (uint32_t r = tid; r < nruns; r += THREADS) root[r] = (IT)uf_find(parent, r);
     __syncthreads();
     for (uint32_t r = tid; r < nruns; r += THREADS) parent[r] = root[r];
     __syncthreads();
 
+    PHASE_MARK(4);
     // ---- phase 5: seam unions on top, second flatten (kept in `parent`) ----------------------------
     for (int y = tid; y < ny; y += THREADS) {
         uint32_t f = rs[y], l = rs[y + 1];
@@ -394,6 +433,7 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
     for (uint32_t r = tid; r < nruns; r += THREADS) parent[r] = idmap[r];
     __syncthreads();
 
+    PHASE_MARK(5);
     // ---- phase 6: ids, tables ------------------------------------------------------------------------
     uint32_t ncomp = 0;
     {
@@ -408,6 +448,7 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
         ncomp = carry;
     }
     __syncthreads();
+    PHASE_MARK(6);
     if (tid == 0) a.ncomp[t] = ncomp;
     uint32_t *cmrep = a.cs_mrep + rbase;
     uint32_t *gbox = a.cs_box + (int64_t)rbase * 4;
@@ -442,6 +483,7 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
         for (uint32_t i = tid; i < ncomp * 4; i += THREADS) gbox[i] = cbox[i];
         for (uint32_t i = tid; i < ncomp * 2; i += THREADS) garea[i] = carea[i];
     }
+    PHASE_MARK(7);
     // seam rows: both seam pixels set (also when they are one run / one component: chain events can still
     // split them).  Written in y order into the timestep's slice of a row-indexed
     // scratch (at most ny records per timestep).
@@ -466,17 +508,19 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
         }
         if (tid == 0) a.seam_cnt[t] = carry;
     }
+    PHASE_MARK(8);
 }
 
-#define CTK_LDS_RUNS 2048
+#define CTK_LDS_RUNS 4096
 #define CTK_LDS_NY 1024
 
 // LDS variants: RUNS = most runs per timestep carried, COMPS = components whose bbox/area tables live in LDS
 // (the table area doubles as the staging area of the timestep's mask words, COMPS*4 words).
 //   <1024, 288>: 27 KB -> 5 workgroups per CU (typical 1 deg Z500 timestep: 500 runs, 40 components)
 //   <2048, 512>: 46 KB -> 3 workgroups per CU
-template <int RUNS, int COMPS, int RUNS_BELOW>
-__global__ __launch_bounds__(256) void k_label2d_lds(Label2dArgs a)
+//   <4096, 512>: 76 KB -> 2 workgroups per CU (0.25 deg timesteps: ~1600 runs, mask words read through L2)
+template <int RUNS, int COMPS, int RUNS_BELOW, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_label2d_lds(Label2dArgs a)
 {
     const int t = (int)blockIdx.x;
     const uint32_t nruns = a.run_base[t + 1] - a.run_base[t];
@@ -489,15 +533,16 @@ __global__ __launch_bounds__(256) void k_label2d_lds(Label2dArgs a)
     __shared__ uint32_t parent[RUNS];
     __shared__ uint32_t rs[CTK_LDS_NY + 1];
     __shared__ uint64_t mlds[COMPS * 4];
-    __shared__ uint32_t sm_scan[8];
+    __shared__ uint32_t sm_scan[THREADS / 64 + 1];
     const int nwords = a.ny * a.W;
     const uint64_t *mg = a.mask + (int64_t)t * nwords;
     const uint64_t *mrow = mg;
-    if (nwords <= COMPS * 4) {                                      // stage the timestep's mask (8.7 KB at 1 deg)
-        for (int i = (int)threadIdx.x; i < nwords; i += 256) mlds[i] = mg[i];
+    const bool staged = nwords <= COMPS * 4;
+    if (staged) {                                                   // stage the timestep's mask (8.7 KB at 1 deg)
+        for (int i = (int)threadIdx.x; i < nwords; i += THREADS) mlds[i] = mg[i];
         mrow = mlds;
     }
-    label2d_body<256, uint16_t, COMPS>(a, t, nruns, x0, x1, yrow, parent, root, idmap, rs, sm_scan, mrow, mlds);
+    label2d_body<THREADS, uint16_t, COMPS>(a, t, nruns, x0, x1, yrow, parent, root, idmap, rs, sm_scan, mrow, staged, mlds);
 }
 
 __global__ __launch_bounds__(256) void k_label2d_glb(Label2dArgs a, uint32_t *g_rs /* [T][ny+1] scratch */)
@@ -508,7 +553,7 @@ __global__ __launch_bounds__(256) void k_label2d_glb(Label2dArgs a, uint32_t *g_
     if (!(nruns > CTK_LDS_RUNS || a.ny > CTK_LDS_NY)) return;
     __shared__ uint32_t sm_scan[8];
     label2d_body<256, uint32_t, 1>(a, t, nruns, a.g_x0 + rb, a.g_x1 + rb, a.g_y + rb, a.g_parent + rb, a.g_root + rb,
-                                   a.g_idmap + rb, g_rs + (int64_t)t * (a.ny + 1), sm_scan, a.mask + (int64_t)t * a.ny * a.W, nullptr);
+                                   a.g_idmap + rb, g_rs + (int64_t)t * (a.ny + 1), sm_scan, a.mask + (int64_t)t * a.ny * a.W, false, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -32,12 +32,14 @@ struct ResolveDev {
     // work
     uint32_t *p_rc, *p_rd, *p_gc, *p_gd;  // [pair_cap]
     int64_t *F, *B;                       // [NC][2]
+    double *inv, *ff;                     // [NC] 1/areacon and forward fraction of every representative (contrack.py:721-722)
     uint8_t *keep0, *keep1;               // [NC]
     uint32_t *changed;                    // [CTK_MAX_JACOBI + 1]
     uint32_t *parent;                     // [NC]
     uint32_t *isroot, *rank;              // [NC], [NC+1]
     int32_t *lab;                         // [NC] fresh 3-D label of every component (0 = filtered out)
     int32_t *lbox;                        // [(NC+1)][6]
+    uint8_t *mark;                        // [NC+1] label occurs in a seam row with two different labels
 };
 
 #define CTK_MAX_JACOBI 240          // hard cap of filter passes on the device (then: host resolver)
@@ -119,6 +121,19 @@ __global__ void k_rs_pairs(ResolveDev r)
         // forward overlap of the EARLIER component: plane t is unfiltered when t-1 is visited (contrack.py:718)
         atomicAdd((unsigned long long *)&r.F[2 * (int64_t)rd], (unsigned long long)p.lo);
         atomicAdd((unsigned long long *)&r.F[2 * (int64_t)rd + 1], (unsigned long long)p.hi);
+    }
+}
+
+// 1/areacon and the forward fraction do not change between passes
+__global__ void k_rs_prep(ResolveDev r)
+{
+    const uint32_t nc = dev_ncomps(r);
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
+        const double areacon = dev_limbs_to_double(r.A[2 * (int64_t)g], r.A[2 * (int64_t)g + 1], r.wshift);
+        const double fwd = dev_limbs_to_double(r.F[2 * (int64_t)g], r.F[2 * (int64_t)g + 1], r.wshift);
+        const double inv = 1.0 / areacon;                     // reciprocal, then multiply -- as the reference does
+        r.inv[g] = inv;
+        r.ff[g] = inv * fwd;
     }
 }
 
@@ -233,11 +248,8 @@ __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint
             __hip_atomic_store(&B[2 * c + 1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (r.mrep[g] != c) continue;                           // representatives only
-        const double areacon = dev_limbs_to_double(r.A[2 * (int64_t)g], r.A[2 * (int64_t)g + 1], r.wshift);
-        const double fwd = dev_limbs_to_double(r.F[2 * (int64_t)g], r.F[2 * (int64_t)g + 1], r.wshift);
         const double bwd = dev_limbs_to_double(blo, bhi, r.wshift);
-        const double inv = 1.0 / areacon;
-        const double fb = inv * bwd, ff = inv * fwd;
+        const double fb = r.inv[g] * bwd, ff = r.ff[g];
         bool kill = false;
         if (r.twosided) {
             if (fb != 0 && ff != 0) { if (fb < r.overlap || ff < r.overlap) kill = true; }
@@ -292,6 +304,10 @@ __global__ void k_rs_roots(ResolveDev r)
         const uint32_t root = gfind(r.parent, g);
         r.lab[g] = kept ? (int32_t)root : -1;               // temporarily: root index, -1 = filtered out
         r.isroot[g] = (kept && root == g) ? 1u : 0u;
+        // labels <= components: box slot and candidate mark g+1 are initialised here
+        int32_t *b = r.lbox + 6 * (int64_t)(g + 1);
+        b[0] = INT32_MAX; b[1] = -1; b[2] = INT32_MAX; b[3] = -1; b[4] = INT32_MAX; b[5] = -1;
+        r.mark[g + 1] = 0;
     }
 }
 
@@ -326,24 +342,15 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = boff[gridDim.x];     // grand total
 }
 
-// fresh labels: 1 + rank of the root among surviving roots (raster order); boxes initialised
-__global__ void k_rs_labels(ResolveDev r)
+// fresh labels: 1 + rank of the root among surviving roots (raster order), and their boxes (find_objects ONCE,
+// contrack.py:753): union of the members' boxes
+__global__ void k_rs_labels(ResolveDev r, int64_t t_begin)
 {
     const uint32_t nc = dev_ncomps(r);
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
         const int32_t root = r.lab[g];
-        r.lab[g] = root < 0 ? 0 : (int32_t)r.rank[root] + 1;
-        // box slot g+1 <= number of labels is initialised here (labels <= components)
-        int32_t *b = r.lbox + 6 * (int64_t)(g + 1);
-        b[0] = INT32_MAX; b[1] = -1; b[2] = INT32_MAX; b[3] = -1; b[4] = INT32_MAX; b[5] = -1;
-    }
-}
-
-__global__ void k_rs_boxes(ResolveDev r, int64_t t_begin)
-{
-    const uint32_t nc = dev_ncomps(r);
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
-        const int32_t l = r.lab[g];
+        const int32_t l = root < 0 ? 0 : (int32_t)r.rank[root] + 1;
+        r.lab[g] = l;
         if (l <= 0) continue;
         int32_t *b = r.lbox + 6 * (int64_t)l;
         const uint16_t *q = r.box + 4 * (int64_t)g;

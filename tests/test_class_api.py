@@ -132,3 +132,24 @@ def test_run_contrack_float64_and_dayofyear_threshold():
     c.set_up(time_name="time", longitude_name="longitude", latitude_name="latitude")
     c.run_contrack(variable='anom', threshold=thr, gorl=g["gorl"], overlap=g["overlap"], persistence=g["persistence"], twosided=g["twosided"])
     assert np.array_equal(np.asarray(c.flag), g["flag"])
+
+
+def test_run_lifecycle_known_answer():
+    """tests/test_contrack.py:93-103: 3 flags, 28 rows on the reference's test slab (flag taken from the golden,
+    so this runs without a GPU); numeric columns cross-checked against a direct evaluation."""
+    ds, g = _dataset("refslab_fwd")
+    ds["flag"] = minixr.DataArray(g["flag"], ("time", "latitude", "longitude"))
+    c = contrack(ds=ds)
+    df = c.run_lifecycle(flag="flag", variable="anom")
+    assert list(df.columns) == ['Flag', 'Date', 'Longitude', 'Latitude', 'Intensity', 'Size']
+    assert len(df.Flag.unique()) == 3 and len(df) == 28
+    assert list(df.Flag) == sorted(df.Flag)
+    w = g["wrow"].astype(np.float64)[:, None] * np.ones((1, 360))
+    for _, r in df.iterrows():
+        t = int(r.Date)                      # the stand-in's time coordinate is the integer day
+        m = g["flag"][t] == r.Flag
+        assert abs(r.Size - w[m].sum()) < 0.01 + 1e-9 * abs(w[m].sum())
+        assert abs(r.Intensity - (w[m] * g["anom"][t][m]).sum() / w[m].sum()) < 0.006
+        assert 0 <= r.Longitude < 360 and -90 <= r.Latitude <= 90
+        ys, xs = np.nonzero(m)
+        assert g["lat"][ys].min() - 1 <= r.Latitude <= g["lat"][ys].max() + 1
