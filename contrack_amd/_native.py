@@ -254,7 +254,7 @@ class Tracker:
         v = np.zeros(12, dtype=np.int64)
         check(lib().ctk_get_stats(self._h, v.ctypes.data))
         names = ["runs", "max_runs_per_step", "components", "pairs", "seam_rows_to_driver", "labels_3d", "seam_ops",
-                 "filter_passes", "host_path", "seam_loop_ns", "seam_folds"]
+                 "filter_passes", "host_path", "seam_loop_ns", "seam_folds", "seam_copy_ns"]
         return dict(zip(names, v.tolist()))
 
     def set_device_resolve(self, on=True):

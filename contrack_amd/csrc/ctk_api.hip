@@ -62,7 +62,7 @@ struct ctk_handle {
     DevBuf g_ncomp, g_cprefix, g_mrep, g_box, g_area, g_comp_t, g_pairs, g_pair_base, g_pair_cnt, g_seams, g_seam_cnt, g_seam_off, g_counters, g_label;
     // device resolver work space
     DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lbox,
-        rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_scalars, rv_mark, rv_inv, rv_ff;
+        rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff;
     void *h_cand = nullptr;          // pinned: candidates + boxes download
     size_t h_cand_cap = 0;
     void *h_ops = nullptr;           // pinned: op upload staging
@@ -73,6 +73,7 @@ struct ctk_handle {
     std::vector<int32_t> sd_first, sd_last, sd_inflow, sd_next;
     std::vector<uint64_t> sd_hasop;
     std::vector<CtkOp> sd_ops;
+    std::vector<unsigned char> sd_cand;
     int64_t stats[CTK_NSTATS] = {0};
     // host (pinned) buffers
     void *h_blob = nullptr;
@@ -216,7 +217,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->g_area, &h->g_comp_t, &h->g_pairs, &h->g_pair_base, &h->g_pair_cnt, &h->g_seams, &h->g_seam_cnt, &h->g_seam_off, &h->g_counters,
                       &h->g_label, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
                       &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
-                      &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff};
+                      &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -777,22 +778,32 @@ void seam_driver(ctk_handle *h, const CtkCand *cand, int64_t ncand, const int32_
     auto touched = [&](int32_t l) { return (hasop[(size_t)l >> 6] >> (l & 63)) & 1ull; };
     for (int64_t k = 0; k < ncand; k++) {
         const CtkCand &c = cand[k];
-        const bool tl = touched(c.ll), tr = touched(c.lr);
-        if (c.ll == c.lr && !tl) continue;                                 // same label, never relabelled: nothing can differ
-        const int32_t p0 = tl ? fold(0, c.ll, c.t, c.y, 0) : c.ll;
-        const int32_t p1 = tr ? fold(1, c.lr, c.t, c.y, nx - 1) : c.lr;
-        nfold += (tl ? 1 : 0) + (tr ? 1 : 0);
-        if (p0 == p1) continue;
-        const int32_t hi = std::max(p0, p1), lo = std::min(p0, p1);
-        if (last[(size_t)hi] >= 0 && inflow[(size_t)hi] < last[(size_t)hi]) continue;      // nothing to move
-        const int32_t *b = lbox + 6 * (int64_t)hi;
-        const int32_t idx = (int32_t)ops.size();
-        ops.push_back(CtkOp{hi, lo, b[0], b[1], b[2], b[3], b[4], b[5]});
-        next.push_back(-1);
-        if (last[(size_t)hi] >= 0) next[(size_t)last[(size_t)hi]] = idx; else first[(size_t)hi] = idx;
-        last[(size_t)hi] = idx;
-        inflow[(size_t)lo] = idx;
-        hasop[(size_t)hi >> 6] |= 1ull << (hi & 63);
+        const int32_t y_last = (int32_t)((uint32_t)c.yy >> 16);
+        // rows y0..y_last of timestep c.t carry the same pair of fresh labels; visit them in order, skipping the rows
+        // for which the previous evaluation provably still holds
+        for (int32_t y = c.yy & 0xffff; y <= y_last;) {
+            const bool tl = touched(c.ll), tr = touched(c.lr);
+            if (c.ll == c.lr && !tl) break;                                // same label, never relabelled: nothing can differ
+            int32_t same_until = y_last;
+            const int32_t p0 = tl ? fold(0, c.ll, c.t, y, 0) : c.ll;
+            const int32_t p1 = tr ? fold(1, c.lr, c.t, y, nx - 1) : c.lr;
+            nfold += (tl ? 1 : 0) + (tr ? 1 : 0);
+            if (tl) same_until = std::min(same_until, memo[0].yhi);
+            if (tr) same_until = std::min(same_until, memo[1].yhi);
+            if (p0 == p1) { y = same_until + 1; continue; }                // nothing happens on these rows
+            const int32_t hi = std::max(p0, p1), lo = std::min(p0, p1);
+            if (last[(size_t)hi] >= 0 && inflow[(size_t)hi] < last[(size_t)hi]) { y = same_until + 1; continue; }   // nothing to move, and
+                                                                           // nothing changes until an op is recorded
+            const int32_t *b = lbox + 6 * (int64_t)hi;
+            const int32_t idx = (int32_t)ops.size();
+            ops.push_back(CtkOp{hi, lo, b[0], b[1], b[2], b[3], b[4], b[5]});
+            next.push_back(-1);
+            if (last[(size_t)hi] >= 0) next[(size_t)last[(size_t)hi]] = idx; else first[(size_t)hi] = idx;
+            last[(size_t)hi] = idx;
+            inflow[(size_t)lo] = idx;
+            hasop[(size_t)hi >> 6] |= 1ull << (hi & 63);
+            y++;                                                           // the next row sees the new op
+        }
     }
     h->stats[9] = (int64_t)((now_ms() - t_loop) * 1e6);       // ns spent in the candidate loop
     h->stats[10] = nfold;
@@ -835,6 +846,8 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     CTKCHK(ensure(h, h->rv_bsum, (size_t)nsb * 4)); CTKCHK(ensure(h, h->rv_boff, (size_t)(nsb + 1) * 4));
     CTKCHK(ensure(h, h->rv_cand_cnt, (size_t)T * 4)); CTKCHK(ensure(h, h->rv_cand_off, (size_t)(T + 1) * 4));
     CTKCHK(ensure(h, h->rv_cand, (size_t)std::max<int64_t>(in.seam_cap, 1) * sizeof(CtkCand)));
+    CTKCHK(ensure(h, h->rv_cand_scratch, (size_t)std::max<int64_t>(T * h->ny, 1) * sizeof(CtkCand)));
+    CTKCHK(ensure(h, h->rv_seam_res, (size_t)std::max<int64_t>(T * h->ny, 1) * 8));
     CTKCHK(ensure(h, h->rv_scalars, 64));
     CTKCHK(ensure(h, h->rv_tdirty, (size_t)2 * (T > 0 ? T : 1)));
     CTKCHK(ensure(h, h->rv_mark, R + 1));
@@ -875,13 +888,14 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         k_scan_apply<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_boff), r.rank);
         k_rs_labels<<<gc, 256, 0, s>>>(r, 0);
         if (T > 0) {
-            k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<uint8_t>(h->rv_mark));
-            k_rs_cand_count<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<uint8_t>(h->rv_mark), P<uint32_t>(h->rv_cand_cnt));
+            k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, h->ny, P<uint8_t>(h->rv_mark), P<int2>(h->rv_seam_res));
+            k_rs_cand_groups<<<(int)((T + 63) / 64), 64, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), P<uint8_t>(h->rv_mark),
+                                                                 h->ny, 0, P<uint32_t>(h->rv_cand_cnt), P<CtkCand>(h->rv_cand_scratch));
         }
         k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_cand_cnt), T, P<uint32_t>(h->rv_cand_off), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
         if (T > 0) {
-            k_rs_cand_write<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<uint8_t>(h->rv_mark), P<uint32_t>(h->rv_cand_off), 0,
-                                                   P<CtkCand>(h->rv_cand));
+            k_compact_cands<<<(int)T, 64, 0, s>>>(P<CtkCand>(h->rv_cand_scratch), P<uint32_t>(h->rv_cand_cnt), P<uint32_t>(h->rv_cand_off), h->ny,
+                                                  P<CtkCand>(h->rv_cand));
         }
         HIPCHK(hipGetLastError());
         // scalars: number of components / labels / candidates, convergence, overflow
@@ -914,6 +928,12 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         HIPCHK(hipStreamSynchronize(s));
         h->ms[CTK_T_D2H] += now_ms() - t0;
         const double t1 = now_ms();
+        // work on pageable copies: reads from the pinned download buffer are several times slower on this host
+        h->sd_cand.resize((size_t)ncand * sizeof(CtkCand) + (size_t)(nlab + 1) * 24);
+        memcpy(h->sd_cand.data(), h->h_cand, h->sd_cand.size());
+        h->stats[11] = (int64_t)((now_ms() - t1) * 1e6);
+        hc = (CtkCand *)h->sd_cand.data();
+        hb = (int32_t *)(h->sd_cand.data() + (size_t)ncand * sizeof(CtkCand));
         seam_driver(h, hc, ncand, hb, nlab, h->nx, ops);
         h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t1;
     } else {

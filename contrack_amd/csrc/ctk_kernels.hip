@@ -128,6 +128,22 @@ __device__ __forceinline__ bool cmp_op(TIN v, TIN th)
     return v < th;
 }
 
+// OR of v across the 16 lanes of a DPP row, left in every lane: quad swaps, then half-row and row mirrors
+// (full-rate VALU with DPP operands; no LDS crossbar traffic, unlike __shfl_xor = ds_bpermute)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_or(uint32_t v)
+{
+    return v | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t row16_or(uint32_t v)
+{
+    v = dpp_or<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_or<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_or<0x141>(v);     // row_half_mirror
+    v = dpp_or<0x140>(v);     // row_mirror
+    return v;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define CTK_RB 16                  // rows per workgroup in the two streaming kernels
@@ -163,8 +179,8 @@ __global__ __launch_bounds__(256) void k_threshold_v4(const float *__restrict__ 
                                  (cmp_op<OP, float>(v[u].z, th) ? 4u : 0u) | (cmp_op<OP, float>(v[u].w, th) ? 8u : 0u);
             // lanes 16g .. 16g+15 hold the 64 pixels of one word: place the nibble, OR across the group
             uint32_t lo = (sub < 8) ? (nib << (4 * sub)) : 0u, hi = (sub >= 8) ? (nib << (4 * (sub - 8))) : 0u;
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) { lo |= __shfl_xor(lo, d); hi |= __shfl_xor(hi, d); }
+            lo = row16_or(lo);
+            hi = row16_or(hi);
             if (sub == 0 && i0 + u * 256 + tid < total) mask[(row0 + rr[u]) * W + (cc[u] >> 4)] = ((uint64_t)hi << 32) | lo;
         }
     }

@@ -365,70 +365,65 @@ __global__ void k_rs_labels(ResolveDev r, int64_t t_begin)
 // operation (the first op needs such a row; every later `hi`/`lo` is a label of such a row or the `lo` of an
 // earlier op).  Rows with equal labels that are not marked can therefore be dropped before the host driver.
 __global__ __launch_bounds__(256) void k_rs_cand_mark(ResolveDev r, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
-                                                      const uint32_t *__restrict__ seam_off, uint8_t *__restrict__ mark)
+                                                      const uint32_t *__restrict__ seam_off, int ny, uint8_t *__restrict__ mark,
+                                                      int2 *__restrict__ res /* [T][ny]: fresh labels of the row's two seam pixels, x < 0: filtered out */)
 {
     const int t = (int)blockIdx.x;
     const uint32_t n = seam_cnt[t], cb = r.cprefix[t];
     const CtkSeam *scratch = seams + seam_off[t];
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const CtkSeam q = scratch[i];
-        if (!r.keep0[cb + r.mrep[cb + q.cl]]) continue;
-        const int32_t ll = r.lab[cb + q.cl], lr = r.lab[cb + q.cr];
-        if (ll != lr) { mark[ll] = 1; mark[lr] = 1; }
-    }
-}
-
-__device__ __forceinline__ bool cand_wanted(const ResolveDev &r, const CtkSeam &q, uint32_t cb, const uint8_t *mark)
-{
-    if (!r.keep0[cb + r.mrep[cb + q.cl]]) return false;
-    const int32_t ll = r.lab[cb + q.cl], lr = r.lab[cb + q.cr];
-    return ll != lr || mark[ll] != 0;
-}
-
-// surviving seam rows of timestep t -> {t, y, label at x=0, label at x=nx-1}, (t, y) order
-struct CtkCand {
-    int32_t t, y, ll, lr;
-};
-__global__ __launch_bounds__(256) void k_rs_cand_count(ResolveDev r, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
-                                                       const uint32_t *__restrict__ seam_off, const uint8_t *__restrict__ mark,
-                                                       uint32_t *__restrict__ cand_cnt)
-{
-    const int t = (int)blockIdx.x;
-    const uint32_t n = seam_cnt[t], cb = r.cprefix[t];
-    const CtkSeam *scratch = seams + seam_off[t];
-    uint32_t s = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const CtkSeam q = scratch[i];
-        s += cand_wanted(r, q, cb, mark) ? 1u : 0u;
-    }
-    __shared__ uint32_t sm[8];
-    uint32_t tot;
-    block_excl_scan(s, sm, &tot);
-    if (threadIdx.x == 0) cand_cnt[t] = tot;
-}
-__global__ __launch_bounds__(256) void k_rs_cand_write(ResolveDev r, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
-                                                       const uint32_t *__restrict__ seam_off, const uint8_t *__restrict__ mark,
-                                                       const uint32_t *__restrict__ cand_off, int64_t t_begin, CtkCand *__restrict__ out)
-{
-    const int t = (int)blockIdx.x;
-    const uint32_t n = seam_cnt[t], cb = r.cprefix[t];
-    const CtkSeam *scratch = seams + seam_off[t];
-    __shared__ uint32_t sm[8];
-    uint32_t carry = cand_off[t];
-    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
-        const uint32_t i = i0 + threadIdx.x;
-        CtkSeam q;
-        uint32_t v = 0;
-        if (i < n) { q = scratch[i]; v = cand_wanted(r, q, cb, mark) ? 1u : 0u; }
-        uint32_t tot;
-        uint32_t ex = block_excl_scan(v, sm, &tot);
-        if (v) {
-            CtkCand c;
-            c.t = (int32_t)(t_begin + t); c.y = (int32_t)q.y; c.ll = r.lab[cb + q.cl]; c.lr = r.lab[cb + q.cr];
-            out[carry + ex] = c;
+        int2 v = make_int2(-1, -1);
+        if (r.keep0[cb + r.mrep[cb + q.cl]]) {
+            v.x = r.lab[cb + q.cl]; v.y = r.lab[cb + q.cr];
+            if (v.x != v.y) { mark[v.x] = 1; mark[v.y] = 1; }
         }
-        carry += tot;
+        res[(int64_t)t * ny + i] = v;
     }
+}
+
+// surviving seam rows of timestep t, run-length grouped: consecutive rows (y, y+1, ...) with the same pair of
+// labels become ONE record {t, y0 | y1 << 16, label at x=0, label at x=nx-1}; (t, y) order.  One thread per
+// timestep walks its (few) seam rows and writes its groups into a row-indexed scratch; a scan + gather makes
+// them dense.
+struct CtkCand {
+    int32_t t, yy, ll, lr;
+};
+__global__ __launch_bounds__(256) void k_rs_cand_groups(ResolveDev r, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
+                                                        const uint32_t *__restrict__ seam_off, const int2 *__restrict__ res,
+                                                        const uint8_t *__restrict__ mark, int ny, int64_t t_begin, uint32_t *__restrict__ cand_cnt,
+                                                        CtkCand *__restrict__ scratch /* [T][ny] */)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= r.T) return;
+    const uint32_t n = seam_cnt[t];
+    const CtkSeam *sc = seams + seam_off[t];
+    const int2 *rs = res + t * ny;
+    CtkCand *dst = scratch + t * ny;                      // at most one group per seam row
+    uint32_t ng = 0;
+    CtkCand g;
+    g.t = (int32_t)(t_begin + t); g.yy = 0; g.ll = 0; g.lr = 0;
+    int32_t gy0 = 0, gy1 = -2;
+    bool open = false;
+    for (uint32_t i = 0; i < n; i++) {
+        const int2 v = rs[i];
+        if (v.x < 0 || (v.x == v.y && !mark[v.x])) continue;          // filtered out, or can never take part in an op
+        const int32_t y = (int32_t)sc[i].y;
+        if (open && v.x == g.ll && v.y == g.lr && y == gy1 + 1) { gy1 = y; continue; }
+        if (open) { g.yy = gy0 | (gy1 << 16); dst[ng++] = g; }
+        open = true; g.ll = v.x; g.lr = v.y; gy0 = y; gy1 = y;
+    }
+    if (open) { g.yy = gy0 | (gy1 << 16); dst[ng++] = g; }
+    cand_cnt[t] = ng;
+}
+
+// dense (t, y)-ordered group records from the row-indexed scratch
+__global__ __launch_bounds__(256) void k_compact_cands(const CtkCand *__restrict__ scratch, const uint32_t *__restrict__ cand_cnt,
+                                                       const uint32_t *__restrict__ cand_off, int ny, CtkCand *__restrict__ out)
+{
+    const int t = (int)blockIdx.x;
+    const uint32_t n = cand_cnt[t], o = cand_off[t];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out[o + i] = scratch[(int64_t)t * ny + i];
 }
 
 // R5: final id of every component.  All of a component's pixels move together through an op whose box
