@@ -30,6 +30,9 @@ WORKLOADS = {
     # 0.25 deg, 6-hourly (a 480-step window of configs[2]; persistence 20 steps = 5 days)
     "era5_025deg_480": dict(T=480, ny=721, nx=1440, threshold=160.0, gorl=">=", overlap=0.5, persistence=20, twosided=True),
 }
+WORKLOADS["era5_025deg_10yr"] = dict(T=14600, ny=721, nx=1440, threshold=160.0, gorl=">=", overlap=0.5, persistence=20, twosided=True,
+                                     device_fill=True)      # BASELINE.json configs[2]: 60.6 GB in + 60.6 GB out, generated on the device
+WORKLOADS["era5_025deg_2k"] = dict(T=2000, ny=721, nx=1440, threshold=160.0, gorl=">=", overlap=0.5, persistence=20, twosided=True, device_fill=True)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -96,13 +99,22 @@ def main():
         return dist.bench_main(args, wl, WORKLOADS, HBM_PEAK_GBS)
 
     T, ny, nx = wl["T"], wl["ny"], wl["nx"]
-    a, w = make_slab(wl)
     thr = np.full(T, np.float64(np.float32(wl["threshold"])))
     op = _native.CMP_OPS[wl["gorl"]]
     trk = _native.Tracker(int(os.environ.get("LOCAL_RANK", "0")))
-    d_in = trk.malloc(a.nbytes)
-    d_out = trk.malloc(a.nbytes)
-    trk.h2d(d_in, a)
+    nbytes = T * ny * nx * 4
+    d_in = trk.malloc(nbytes)
+    d_out = trk.malloc(nbytes)
+    if wl.get("device_fill"):
+        # slabs beyond host RAM: deterministic on-device generator (ctk_synth_fill), no CPU baseline / coverage
+        a = None
+        lat, _ = synth.grid(ny, nx)
+        w = row_weights(lat, np.float32(180.0 / (ny - 1)), np.float32(360.0 / nx))
+        trk.synth_fill(d_in, T, ny, nx, seed=0)
+        args.no_cpu_baseline = True
+    else:
+        a, w = make_slab(wl)
+        trk.h2d(d_in, a)
     trk.set_timing(True)
 
     def step():
@@ -133,7 +145,8 @@ def main():
                dtype="f32 compare / int32 labels / int64 exact areas", data="synthetic",
                config=dict(workload="%s: %dx%dx%d float32, threshold %s %g, overlap %g, persistence %d, twosided %s" % (
                    args.workload, T, ny, nx, wl["gorl"], wl["threshold"], wl["overlap"], wl["persistence"], wl["twosided"]),
-                   parallelism="1 GPU", n_tracked=n_tracked, coverage=float((a >= np.float32(wl["threshold"])).mean())),
+                   parallelism="1 GPU", n_tracked=n_tracked,
+                   coverage=float((a >= np.float32(wl["threshold"])).mean()) if a is not None else None),
                roofline=dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                              traffic=pmc_traffic(kname, args.workload), algorithmic_bytes_per_launch=alg_bytes[kern],
                              avg_kernel_ms=per.get(kern),

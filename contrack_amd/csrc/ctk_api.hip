@@ -293,7 +293,8 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         return ctk_set_error(CTK_E_INVALID, "ctk_shard_label2d: bad shape (T=%lld ny=%d nx=%d) or null pointer", (long long)T, ny, nx);
     if (cmp_op < 0 || cmp_op > 3) return ctk_set_error(CTK_E_INVALID, "ctk_shard_label2d: cmp_op %d not in 0..3", cmp_op);
     if (nx > 65535 || ny > 65535) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: grid %dx%d exceeds 65535 per axis", ny, nx);
-    if (T > 0x7ffffff0ll) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: T too large");
+    // one workgroup of up to 1024 threads per timestep in several kernels; a HIP grid carries < 2^32 work-items
+    if (T > 4000000ll) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: more than 4 000 000 timesteps in one shard");
     HIPCHK(hipSetDevice(h->device));
     memset(h->ms, 0, sizeof(h->ms));
     h->state = ST_IDLE;
@@ -335,7 +336,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         Timer tm(h, CTK_K_THRESHOLD);
         const int g = grid_for_rows(nrows);
         const int64_t nblk4 = T * ((ny + CTK_RB - 1) / CTK_RB);                       // one workgroup per (timestep, 16 rows)
-        const bool v4 = !f64 && (nx % 4 == 0) && (((uintptr_t)anom_dev & 15) == 0) && nblk4 < 0x7fffffff;
+        const bool v4 = !f64 && (nx % 4 == 0) && (((uintptr_t)anom_dev & 15) == 0) && nblk4 < (1 << 24);     // < 2^32 work-items
         const unsigned g4 = (unsigned)nblk4;
 #define LAUNCH_THR(OP)                                                                                                                      \
     do {                                                                                                                                \
@@ -1091,7 +1092,7 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
     const int rvcap = 2048;
     const size_t lds = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) + (size_t)rvcap * 4;
     const int64_t nblk4 = h->T * ((h->ny + rb - 1) / rb);
-    if ((h->nx % 4 == 0) && (((uintptr_t)flag_dev & 15) == 0) && npl < 0x7fffffff && nblk4 < 0x7fffffff && h->T > 0 && lds <= 60 * 1024) {
+    if ((h->nx % 4 == 0) && (((uintptr_t)flag_dev & 15) == 0) && npl < 0x7fffffff && nblk4 < (1 << 24) && h->T > 0 && lds <= 60 * 1024) {
         const unsigned grid = (unsigned)nblk4;
         k_relabel_v4<<<grid, 256, lds, h->stream>>>(a, rb, rvcap);
     } else {
@@ -1240,7 +1241,7 @@ extern "C" int ctk_debug_mask(ctk_handle *h, uint8_t *mask)
     const int64_t n = h->T * h->ny * (int64_t)h->nx;
     if (n == 0) return CTK_OK;
     CTKCHK(ensure(h, h->dbg, (size_t)n));
-    k_expand_mask<<<(int)((n + 255) / 256), 256, 0, h->stream>>>(P<uint64_t>(h->mask), h->T * h->ny, h->nx, h->W, P<uint8_t>(h->dbg));
+    k_expand_mask<<<(int)std::min<int64_t>((n + 255) / 256, 1 << 20), 256, 0, h->stream>>>(P<uint64_t>(h->mask), h->T * h->ny, h->nx, h->W, P<uint8_t>(h->dbg));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(mask, h->dbg.p, (size_t)n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1316,8 +1317,7 @@ extern "C" int ctk_synth_fill(ctk_handle *h, float *anom_dev, int64_t T, int ny,
     HIPCHK(hipSetDevice(h->device));
     const int64_t n = T * (int64_t)ny * nx;
     if (n > 0) {
-        const int64_t blocks = (n + 255) / 256;
-        if (blocks > 0x7fffffff) return ctk_set_error(CTK_E_RANGE, "slab too large for ctk_synth_fill");
+        const int64_t blocks = std::min<int64_t>((n + 255) / 256, 1 << 20);      // grid-stride beyond 2^28 pixels
         k_synth<<<(int)blocks, 256, 0, h->stream>>>(anom_dev, T, ny, nx, seed);
         HIPCHK(hipGetLastError());
     }
