@@ -23,7 +23,7 @@ EXPORTS = [
     "ctk_track_f32_dev", "ctk_track_f64", "ctk_track_f64_dev", "ctk_shard_label2d", "ctk_shard_label2d_f64", "ctk_shard_halo_size", "ctk_shard_halo_export",
     "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_shard_tables_dev", "ctk_shard_resolve_dev", "ctk_resolve", "ctk_result_free",
     "ctk_result_info", "ctk_result_arrays", "ctk_result_nshards", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
-    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_set_timing", "ctk_get_timings", "ctk_set_device_resolve", "ctk_get_stats",
+    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_set_timing", "ctk_get_timings", "ctk_set_device_resolve", "ctk_set_filter_round", "ctk_get_stats",
     "ctk_dev_malloc", "ctk_dev_free", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
     "ctk_synth_fill",
 ]
@@ -74,10 +74,12 @@ def lib():
     L.ctk_shard_count_tracked.argtypes = [p, C.POINTER(i64)]
     L.ctk_debug_mask.argtypes = [p, p]
     L.ctk_debug_label2d.argtypes = [p, i32, p]
+    L.ctk_debug_set_pair_capacity.argtypes = [p, C.c_uint32]
     L.ctk_set_timing.argtypes = [p, i32]
     L.ctk_get_timings.argtypes = [p, p]
     L.ctk_set_device_resolve.argtypes = [p, i32]
     L.ctk_get_stats.argtypes = [p, p]
+    L.ctk_set_filter_round.argtypes = [p, i32]
     L.ctk_dev_malloc.argtypes = [p, pp, sz]
     L.ctk_dev_free.argtypes = [p, p]
     L.ctk_memcpy_h2d.argtypes = [p, p, p, sz]
@@ -251,11 +253,17 @@ class Tracker:
         check(lib().ctk_set_timing(self._h, int(bool(on))))
 
     def stats(self):
-        v = np.zeros(12, dtype=np.int64)
+        v = np.zeros(16, dtype=np.int64)
         check(lib().ctk_get_stats(self._h, v.ctypes.data))
         names = ["runs", "max_runs_per_step", "components", "pairs", "seam_rows_to_driver", "labels_3d", "seam_ops",
-                 "filter_passes", "host_path", "seam_loop_ns", "seam_folds", "seam_copy_ns"]
+                 "filter_passes", "host_path", "seam_loop_ns", "seam_folds", "seam_copy_ns", "ungrouped_pairs", "pair_table_regrows", "filter_rounds"]
         return dict(zip(names, v.tolist()))
+
+    def debug_set_pair_capacity(self, records):
+        check(lib().ctk_debug_set_pair_capacity(self._h, int(records)))
+
+    def set_filter_round(self, passes):
+        check(lib().ctk_set_filter_round(self._h, int(passes)))
 
     def set_device_resolve(self, on=True):
         check(lib().ctk_set_device_resolve(self._h, int(bool(on))))

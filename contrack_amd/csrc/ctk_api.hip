@@ -69,6 +69,8 @@ struct ctk_handle {
     size_t h_ops_cap = 0;
     const int32_t *d_op_next = nullptr;
     int use_device_resolve = 1;
+    int filter_round = CTK_JACOBI_ROUND;          // filter passes launched before convergence is checked
+    uint32_t debug_pair_cap = 0;                  // test hook: pretend the pair table holds only this many records
     // host scratch of the seam driver, kept between calls (fresh 100+ KB vectors would page-fault every call)
     std::vector<int32_t> sd_first, sd_last, sd_inflow, sd_next;
     std::vector<uint64_t> sd_hasop;
@@ -253,6 +255,20 @@ extern "C" int ctk_get_stats(ctk_handle *h, int64_t *out)
 {
     if (!h || !out) return ctk_set_error(CTK_E_INVALID, "null argument");
     memcpy(out, h->stats, sizeof(h->stats));
+    return CTK_OK;
+}
+
+extern "C" int ctk_debug_set_pair_capacity(ctk_handle *h, uint32_t records)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    h->debug_pair_cap = records;
+    return CTK_OK;
+}
+
+extern "C" int ctk_set_filter_round(ctk_handle *h, int passes)
+{
+    if (!h || passes < 1 || passes > 32) return ctk_set_error(CTK_E_INVALID, "ctk_set_filter_round: 1..32 passes per round");
+    h->filter_round = passes;
     return CTK_OK;
 }
 
@@ -542,6 +558,7 @@ extern "C" int ctk_shard_overlap(ctk_handle *h)
         CTKCHK(ensure(h, h->pairs, want * sizeof(CtkPair)));
         h->pair_cap = (uint32_t)std::min<size_t>(h->pairs.cap / sizeof(CtkPair), 0x7fffffffull);
     }
+    if (h->debug_pair_cap) { h->pair_cap = std::min(h->pair_cap, h->debug_pair_cap); h->debug_pair_cap = 0; }
     CTKCHK(ensure(h, h->pair_base, (size_t)h->T * 4));
     CTKCHK(ensure(h, h->pair_cnt, (size_t)h->T * 4));
     if (h->T > 0) CTKCHK(launch_overlap(h));
@@ -574,6 +591,7 @@ static int build_tables_blob(ctk_handle *h, bool to_device, const void **blob, s
         stot = hc[CTK_CNT_N + 1];
         if (!(cnt[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) && (uint64_t)cnt[CTK_CNT_PAIRS] + cnt[CTK_CNT_UPAIRS] <= h->pair_cap) break;
         if (attempt >= 6) return ctk_set_error(CTK_E_RANGE, "pair table keeps overflowing");
+        h->stats[CTK_S_PAIR_REGROW]++;
         // grow the pair table to what was asked for and redo the histogram
         size_t want = std::max<size_t>((size_t)cnt[CTK_CNT_PAIRS] + cnt[CTK_CNT_UPAIRS] + 1024, (size_t)h->pair_cap * 2);
         if (want > 0xfffffff0ull) return ctk_set_error(CTK_E_RANGE, "pair table beyond 2^32 records");
@@ -868,6 +886,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     uint32_t *hs = (uint32_t *)h->h_small + (h->T + 2);
     const double t0 = now_ms();
     int it_done = 0;
+    const int ROUND = h->filter_round;
     for (;;) {
         Timer tm(h, CTK_K_RESOLVE);
         if (it_done == 0) {
@@ -877,9 +896,9 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         }
         // overlap filter: a round of passes (passes after the fixed point return at once)
         if (T > 2)
-            for (int it = it_done; it < it_done + CTK_JACOBI_ROUND; it++)
+            for (int it = it_done; it < it_done + ROUND; it++)
                 k_rs_pass<<<(int)(T - 2), 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
-        it_done += CTK_JACOBI_ROUND;
+        it_done += ROUND;
         k_rs_parent_init<<<gc, 256, 0, s>>>(r);
         k_rs_unite<<<gp, 256, 0, s>>>(r);
         k_rs_roots<<<gc, 256, 0, s>>>(r);
@@ -904,19 +923,20 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N, in.cprefix + T, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 1, P<uint32_t>(h->rv_cand_off) + T, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 3, P<uint32_t>(h->rv_boff) + nsb, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 4, P<uint32_t>(h->rv_changed) + (it_done - CTK_JACOBI_ROUND), CTK_JACOBI_ROUND * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 4, P<uint32_t>(h->rv_changed) + (it_done - ROUND), (size_t)ROUND * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         if ((hs[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) || (uint64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS] > in.pair_cap)
             return 1;                                                         // the host path regrows the pair table
         int conv = -1;
-        for (int k = 0; k < CTK_JACOBI_ROUND; k++) if (hs[CTK_CNT_N + 4 + k] == 0) { conv = it_done - CTK_JACOBI_ROUND + k; break; }
-        if (conv >= 0) { h->stats[CTK_S_FILTER_PASSES] = conv + 1; break; }
-        if (it_done + CTK_JACOBI_ROUND > CTK_MAX_JACOBI) return 1;            // very long removal cascade: host resolver
+        for (int k = 0; k < ROUND; k++) if (hs[CTK_CNT_N + 4 + k] == 0) { conv = it_done - ROUND + k; break; }
+        if (conv >= 0) { h->stats[CTK_S_FILTER_PASSES] = conv + 1; h->stats[CTK_S_FILTER_ROUNDS] = it_done / ROUND; break; }
+        if (it_done + ROUND > CTK_MAX_JACOBI) return 1;                       // very long removal cascade: host resolver
     }
     const int64_t NC = hs[CTK_CNT_N], ncand = hs[CTK_CNT_N + 1], nlab = hs[CTK_CNT_N + 3];
     h->n_labels = nlab;
     CTKCHK(prepare_op_first(h, nlab));                                        // overlaps the host driver
     h->stats[CTK_S_COMPONENTS] = NC; h->stats[CTK_S_PAIRS] = (int64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS]; h->stats[CTK_S_SEAM_ROWS] = ncand; h->stats[CTK_S_LABELS] = nlab;
+    h->stats[CTK_S_UPAIRS] = hs[CTK_CNT_UPAIRS];
     std::vector<CtkOp> &ops = h->sd_ops;
     ops.clear();
     if (ncand) {

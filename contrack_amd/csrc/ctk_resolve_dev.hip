@@ -57,10 +57,17 @@ __device__ __forceinline__ uint32_t dev_nungrouped(const ResolveDev &r)
     uint32_t n = r.counters[CTK_CNT_UPAIRS];
     return n < r.pair_cap ? n : r.pair_cap;
 }
+// The pair table overflowed (records were dropped or collided): its contents must not be interpreted.  Every
+// resolver kernel returns at once; the host sees the same condition at its next sync and regrows the table.
+__device__ __forceinline__ bool dev_tables_bad(const ResolveDev &r)
+{
+    return (r.counters[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) != 0u ||
+           (uint64_t)r.counters[CTK_CNT_PAIRS] + (uint64_t)r.counters[CTK_CNT_UPAIRS] > (uint64_t)r.pair_cap;
+}
 __device__ __forceinline__ uint32_t dev_npairs(const ResolveDev &r)
 {
-    uint32_t n = dev_ngrouped(r) + dev_nungrouped(r);
-    return n < r.pair_cap ? n : r.pair_cap;
+    if (dev_tables_bad(r)) return 0;
+    return dev_ngrouped(r) + dev_nungrouped(r);
 }
 __device__ __forceinline__ const CtkPair &pair_at(const ResolveDev &r, uint32_t k, uint32_t ng)
 {
@@ -199,6 +206,7 @@ __global__ void k_rs_decide(ResolveDev r, int it)
 __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_cnt,
                                                 uint8_t *__restrict__ tdirty)
 {
+    if (dev_tables_bad(r)) return;
     const int t = (int)blockIdx.x + 1;                         // timesteps 1 .. T-2 are filtered
     const int64_t T = r.T;
     uint8_t *dcur = tdirty + (size_t)(it & 1) * (size_t)T, *dprev = tdirty + (size_t)((it & 1) ^ 1) * (size_t)T;

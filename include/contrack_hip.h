@@ -138,6 +138,9 @@ int ctk_debug_mask(ctk_handle *h, uint8_t *mask /* (T,ny,nx) 0/1 */);
  * of contrack.py:691-698 (before_seam=0): ids are global over time, 1-based, raster order.        */
 int ctk_debug_label2d(ctk_handle *h, int before_seam, int32_t *lab /* (T,ny,nx) */);
 
+/* test hook: the NEXT call behaves as if the pair table held only `records` entries (exercises regrowth) */
+int ctk_debug_set_pair_capacity(ctk_handle *h, uint32_t records);
+
 /* ---- timing (HIP events on the handle's stream) ----------------------------------------------- */
 #define CTK_K_THRESHOLD 0
 #define CTK_K_SCAN      1
@@ -165,8 +168,13 @@ int ctk_set_timing(ctk_handle *h, int enable);
 #define CTK_S_OPS           6   /* recorded bbox-confined relabel operations            */
 #define CTK_S_FILTER_PASSES 7   /* passes of the overlap-filter iteration that ran      */
 #define CTK_S_HOST_PATH     8   /* 1 if the call fell back to the host resolver         */
-#define CTK_NSTATS          12
+#define CTK_S_UPAIRS        12  /* co-occurrence records that bypassed the LDS hash table   */
+#define CTK_S_PAIR_REGROW   13  /* times the pair table had to be regrown (host path)       */
+#define CTK_S_FILTER_ROUNDS 14  /* rounds of filter passes (convergence is checked per round) */
+#define CTK_NSTATS          16
 int ctk_get_stats(ctk_handle *h, int64_t *out /* [CTK_NSTATS] */);
+/* filter passes launched per round before convergence is checked on the host (default 10, 1..32)   */
+int ctk_set_filter_round(ctk_handle *h, int passes);
 /* 1 (default): ctk_track_* resolve the tables on the device; 0: download + ctk_resolve on the host */
 int ctk_set_device_resolve(ctk_handle *h, int enable);
 int ctk_get_timings(ctk_handle *h, double *ms /* [CTK_NTIMERS] */);

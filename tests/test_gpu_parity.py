@@ -114,6 +114,38 @@ def test_host_and_device_resolver_agree(trk, name):
     assert np.array_equal(f_host, g["flag"]) and np.array_equal(f_dev, g["flag"]) and n_host == n_dev
 
 
+def test_rare_paths_are_exercised(oracle_lib):
+    """white noise at 181x360 drives every capacity path at once: the global-memory labelling variant (> 4096 runs
+    per step), co-occurrence records that bypass the LDS hash table, and a pair table that has to be regrown (host
+    resolver path) -- and the result still equals the oracle.  Then a long removal cascade: more filter passes than
+    one round carries."""
+    t = _native.Tracker(0)
+    try:
+        T, ny, nx = 6, 181, 360
+        a = np.random.default_rng(99).standard_normal((T, ny, nx)).astype(np.float32)
+        lat = np.linspace(90, -90, ny).astype(np.float32)
+        w = oracle_lib.row_weights(lat, np.float32(1.0), np.float32(1.0))
+        thr = oracle_lib.prepare_thresholds(0.8, T)
+        want, nw = oracle_lib.run_contrack(a, thr, ">=", w, 0.5, 2, True)
+        t.debug_set_pair_capacity(1000)                               # far too small: must be regrown
+        got, ng = t.track(a, thr, 0, w, 0.5, 2, True)
+        st = t.stats()
+        assert np.array_equal(got, want) and ng == nw
+        assert st["max_runs_per_step"] > 4096 and st["pair_table_regrows"] >= 1 and st["host_path"] == 1
+        got2, _ = t.track(a, thr, 0, w, 0.5, 2, True)                 # table is large enough now: device resolver
+        st2 = t.stats()
+        assert np.array_equal(got2, want) and st2["host_path"] == 0 and st2["ungrouped_pairs"] > 0
+        # several rounds of filter passes: convergence is only checked every `filter_round` passes
+        g = golden_util.load("syn2deg_s0")
+        t.set_filter_round(2)
+        f, n = t.track(g["anom"], g["thr"], _native.CMP_OPS[g["gorl"]], g["wrow"], g["overlap"], g["persistence"], g["twosided"])
+        st = t.stats()
+        assert np.array_equal(f, g["flag"]) and st["host_path"] == 0
+        assert st["filter_passes"] > 2 and st["filter_rounds"] == (st["filter_passes"] + 1) // 2
+    finally:
+        t.close()
+
+
 def test_workspace_reuse_and_determinism(trk, oracle_lib):
     """same handle, different shapes back to back, then the first again: identical output."""
     g1, g2 = golden_util.load("syn2deg_s1"), golden_util.load("odd_17x64")
