@@ -572,7 +572,7 @@ extern "C" int ctk_shard_overlap(ctk_handle *h)
 static int build_tables_blob(ctk_handle *h, bool to_device, const void **blob, size_t *nbytes)
 {
     if (!h || !blob || !nbytes) return ctk_set_error(CTK_E_INVALID, "null argument");
-    if (h->state != ST_OVERLAPPED) return ctk_set_error(CTK_E_STATE, "ctk_shard_tables needs ctk_shard_overlap first");
+    if (h->state != ST_OVERLAPPED && h->state != ST_TABLES) return ctk_set_error(CTK_E_STATE, "ctk_shard_tables needs ctk_shard_overlap first");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     const double t0 = now_ms();

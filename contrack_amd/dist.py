@@ -265,11 +265,18 @@ def run_sharded(engine, comm, t_begin, overlap, persistence, twosided, device_re
         if rank > 0:
             engine.halo_import(recv)
     engine.overlap()
+    done = False
     if device_resolve and hasattr(engine, "resolve_gathered"):
         # tables stay in HBM: all-gather of the device blobs, resolver replicated on every GPU
-        tmin, tmax = engine.resolve_gathered(rank, t_begin, overlap, twosided)
-        info = engine.stats()
-    else:
+        try:
+            tmin, tmax = engine.resolve_gathered(rank, t_begin, overlap, twosided)
+            info = engine.stats()
+            done = True
+        except ValueError:
+            # the device resolver gave up (removal cascade longer than its pass budget).  The condition is a
+            # function of the gathered tables, identical on every rank: all ranks fall back together.
+            done = False
+    if not done:
         blob = engine.tables()
         blobs = comm.allgather_bytes(blob) if world > 1 else [blob]
         result = _native.resolve(blobs, overlap, twosided)
@@ -290,6 +297,10 @@ def bench_main(args, wl, workloads, hbm_peak):
     import torch
     import torch.distributed as dist
     from . import synth
+    # Keep stdout clean for the ONE JSON line: RCCL prints a version banner through C stdio at communicator
+    # creation.  Everything written to fd 1 until the result is ready goes to stderr instead.
+    sys_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
@@ -315,8 +326,15 @@ def bench_main(args, wl, workloads, hbm_peak):
     def step():
         return run_sharded(eng, comm, t0, wl["overlap"], wl["persistence"], wl["twosided"])
 
+    # communicator warm-up (not a step): collectives and point-to-point channels are created lazily by RCCL
+    comm.barrier()
+    comm.allgather_bytes(b"x")
+    comm.ring_shift(torch.zeros(8, dtype=torch.uint8, device=comm._dev()) if rank + 1 < world else None,
+                    torch.zeros(8, dtype=torch.uint8, device=comm._dev()))
     for _ in range(args.warmup):
         n_tracked, info = step()
+    if args.warmup == 0:
+        n_tracked, info = None, None
     comm.barrier()
     trk.sync()
     acc = {}
@@ -345,10 +363,11 @@ def bench_main(args, wl, workloads, hbm_peak):
                                  traffic=None, algorithmic_bytes_per_launch=alg[kern], avg_kernel_ms=per.get(kern),
                                  note="rank 0's shard"),
                    kernels_ms=per)
-        try:                                     # RCCL prints its version banner through C stdio: flush it first, so that
-            C.CDLL(None).fflush(None)            # the JSON line is the last line on stdout
+        try:
+            C.CDLL(None).fflush(None)            # drain C stdio (RCCL banner) into stderr before stdout is restored
         except Exception:
             pass
+        os.dup2(sys_stdout_fd, 1)
         print(json.dumps(out), flush=True)
     trk.free(d_in)
     trk.free(d_out)

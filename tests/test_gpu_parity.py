@@ -146,6 +146,37 @@ def test_rare_paths_are_exercised(oracle_lib):
         t.close()
 
 
+@pytest.mark.parametrize("shape", [(5, 1, 7), (5, 7, 1), (3, 2, 2), (4, 3, 64), (4, 3, 65), (2, 5, 128), (6, 4, 4), (9, 33, 3), (1, 1, 1),
+                                   (7, 2, 4100)], ids=str)
+def test_degenerate_grids(trk, oracle_lib, shape):
+    """single rows / columns, widths below one store quad, exactly one / just over one mask word, > 64 words"""
+    T, ny, nx = shape
+    rng = np.random.default_rng(ny * 1000 + nx)
+    a = (rng.random((T, ny, nx)) < 0.55).astype(np.float32)
+    lat = np.linspace(60, -60, ny).astype(np.float32) if ny > 1 else np.array([10.0], dtype=np.float32)
+    w = oracle_lib.row_weights(lat, np.float32(1.5), np.float32(2.0))
+    thr = oracle_lib.prepare_thresholds(0.5, T)
+    for two in (True, False):
+        want, nw = oracle_lib.run_contrack(a, thr, ">=", w, 0.4, 2, two)
+        got, ng = trk.track(a, thr, 0, w, 0.4, 2, two)
+        assert np.array_equal(got, want) and ng == nw
+
+
+def test_empty_slab(trk):
+    f, n = trk.track(np.zeros((0, 5, 8), dtype=np.float32), np.zeros(0), 0, np.ones(5, dtype=np.float32), 0.5, 2, True)
+    assert f.shape == (0, 5, 8) and n == -1                  # len(np.unique([])) - 1
+
+
+def test_bad_arguments_raise(trk):
+    a = np.zeros((2, 3, 4), dtype=np.float32)
+    with pytest.raises(ValueError):
+        trk.track(a, np.zeros(2), 7, np.ones(3, dtype=np.float32), 0.5, 2, True)              # cmp_op out of range
+    with pytest.raises(ValueError):
+        trk.track(a, np.zeros(2), 0, np.array([1.0, np.inf, 1.0], dtype=np.float32), 0.5, 2, True)   # non-finite weight
+    with pytest.raises(ValueError):
+        trk.track(a, np.zeros(3), 0, np.ones(3, dtype=np.float32), 0.5, 2, True)              # thr has the wrong length
+
+
 def test_workspace_reuse_and_determinism(trk, oracle_lib):
     """same handle, different shapes back to back, then the first again: identical output."""
     g1, g2 = golden_util.load("syn2deg_s1"), golden_util.load("odd_17x64")
