@@ -115,12 +115,14 @@ int ensure(ctk_handle *h, DevBuf &b, size_t need)
     return CTK_OK;
 }
 
-int ensure_host(void **p, size_t *cap, size_t need)
+// non_coherent: coarse-grained pinned memory -- cached on the CPU (the default, fine-grained mapping makes CPU
+// reads several times slower); its contents are valid for the host after a stream synchronisation.
+int ensure_host(void **p, size_t *cap, size_t need, bool non_coherent = false)
 {
     if (*cap >= need && *p) return CTK_OK;
     if (*p) { (void)hipHostFree(*p); *p = nullptr; *cap = 0; }
     size_t c = need + need / 4 + 4096;
-    hipError_t e = hipHostMalloc(p, c, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(p, c, non_coherent ? hipHostMallocNonCoherent : hipHostMallocDefault);
     if (e != hipSuccess) { *p = nullptr; return ctk_set_error(CTK_E_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", c, hipGetErrorString(e)); }
     *cap = c;
     return CTK_OK;
@@ -941,7 +943,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     ops.clear();
     if (ncand) {
         const size_t need = (size_t)ncand * sizeof(CtkCand) + (size_t)(nlab + 1) * 24;
-        CTKCHK(ensure_host(&h->h_cand, &h->h_cand_cap, need));
+        CTKCHK(ensure_host(&h->h_cand, &h->h_cand_cap, need, true));
         CtkCand *hc = (CtkCand *)h->h_cand;
         int32_t *hb = (int32_t *)((char *)h->h_cand + (size_t)ncand * sizeof(CtkCand));
         HIPCHK(hipMemcpyAsync(hc, h->rv_cand.p, (size_t)ncand * sizeof(CtkCand), hipMemcpyDeviceToHost, s));
@@ -949,7 +951,8 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         HIPCHK(hipStreamSynchronize(s));
         h->ms[CTK_T_D2H] += now_ms() - t0;
         const double t1 = now_ms();
-        // work on pageable copies: reads from the pinned download buffer are several times slower on this host
+        // work on a pageable copy: CPU reads of pinned memory are uncached (fine-grained) or slow (coarse-grained) on
+        // this platform -- measured 173 / 111 us for the candidate loop vs 20 us + 20 us for copy + loop
         h->sd_cand.resize((size_t)ncand * sizeof(CtkCand) + (size_t)(nlab + 1) * 24);
         memcpy(h->sd_cand.data(), h->h_cand, h->sd_cand.size());
         h->stats[11] = (int64_t)((now_ms() - t1) * 1e6);
