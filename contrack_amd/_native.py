@@ -26,7 +26,12 @@ EXPORTS = [
     "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_set_timing", "ctk_get_timings", "ctk_set_device_resolve", "ctk_set_filter_round", "ctk_get_stats",
     "ctk_dev_malloc", "ctk_dev_free", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
     "ctk_synth_fill",
+    "ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev", "ctk_lifecycle_rows",
 ]
+
+# ctk_life_row (include/contrack_hip.h)
+LIFE_ROW = np.dtype([("t", "<i4"), ("label", "<i4"), ("shift", "<i4"), ("pad", "<i4"),
+                     ("area", "<f8"), ("swv", "<f8"), ("swvy", "<f8"), ("swvx", "<f8")])
 
 
 class ContrackHipError(RuntimeError):
@@ -88,6 +93,9 @@ def lib():
     L.ctk_stream.argtypes = [p]
     L.ctk_stream.restype = p
     L.ctk_synth_fill.argtypes = [p, p, i64, i32, i32, C.c_uint64]
+    for name in ("ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev"):
+        getattr(L, name).argtypes = [p, p, p, i64, i32, i32, p, C.POINTER(i64)]
+    L.ctk_lifecycle_rows.argtypes = [p, p, i64]
     _lib = L
     return L
 
@@ -248,6 +256,35 @@ class Tracker:
         check(lib().ctk_track_f32_dev(self._h, anom_dev, T, ny, nx, thr.ctypes.data, int(cmp_op), wrow.ctypes.data,
                                       float(overlap), int(persistence), int(bool(twosided)), flag_dev, C.byref(n)))
         return int(n.value)
+
+    # ---- run_lifecycle reductions ------------------------------------------------------------------------
+    def _life_rows(self, n):
+        rows = np.empty(n, dtype=LIFE_ROW)
+        check(lib().ctk_lifecycle_rows(self._h, rows.ctypes.data, n))
+        return rows
+
+    def lifecycle(self, flag, field, wrow):
+        """flag (T, ny, nx) int32, field float32/float64 of the same shape -> LIFE_ROW records sorted by (label, t)"""
+        flag = np.ascontiguousarray(flag, dtype=np.int32)
+        f64 = np.asarray(field).dtype == np.float64
+        field = np.ascontiguousarray(field, dtype=np.float64 if f64 else np.float32)
+        if flag.ndim != 3 or field.shape != flag.shape:
+            raise ValueError("flag and field must share one (time, lat, lon) shape")
+        T, ny, nx = flag.shape
+        wrow = np.ascontiguousarray(wrow, dtype=np.float32)
+        if wrow.shape != (ny,):
+            raise ValueError("wrow must have shape (ny,)")
+        n = C.c_int64(0)
+        fn = lib().ctk_lifecycle_f64 if f64 else lib().ctk_lifecycle_f32
+        check(fn(self._h, flag.ctypes.data, field.ctypes.data, T, ny, nx, wrow.ctypes.data, C.byref(n)))
+        return self._life_rows(int(n.value))
+
+    def lifecycle_dev(self, flag_dev, field_dev, T, ny, nx, wrow, f64=False):
+        wrow = np.ascontiguousarray(wrow, dtype=np.float32)
+        n = C.c_int64(0)
+        fn = lib().ctk_lifecycle_f64_dev if f64 else lib().ctk_lifecycle_f32_dev
+        check(fn(self._h, flag_dev, field_dev, T, ny, nx, wrow.ctypes.data, C.byref(n)))
+        return self._life_rows(int(n.value))
 
     def set_timing(self, on=True):
         check(lib().ctk_set_timing(self._h, int(bool(on))))

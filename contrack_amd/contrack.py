@@ -88,6 +88,31 @@ def track_numpy(anom, wrow, threshold, gorl, overlap, persistence, twosided=True
 # ------------------------------------------------------------------------------------------------
 # the class
 # ------------------------------------------------------------------------------------------------
+
+def lifecycle_frame(rows, lat, lon, dates):
+    """ctk_life_row records -> the reference's rows (contrack.py:876-906): (Flag, Date, Longitude, Latitude,
+    Intensity, Size) sorted by (Flag, Date)."""
+    nx, ny = len(lon), len(lat)
+    if (rows["shift"] == -2).any():
+        raise ValueError("attempt to get argmax of an empty sequence")                                  # np.argmax(np.diff(.)), :883
+    with np.errstate(divide="ignore", invalid="ignore"):
+        intensity = rows["swv"] / rows["area"]                                                          # :876
+        com_y, com_x = rows["swvy"] / rows["swv"], rows["swvx"] / rows["swv"]                           # ndimage.center_of_mass
+    if not (np.isfinite(com_y).all() and np.isfinite(com_x).all()):
+        raise ValueError("cannot convert float NaN to integer")                                         # int(center_of_mass[..]), :886
+    iy, ix = np.trunc(com_y).astype(np.int64), np.trunc(com_x).astype(np.int64)
+    if ((iy < -ny) | (iy >= ny) | (ix < -nx) | (ix >= nx)).any():
+        raise IndexError("centre of mass outside the grid")
+    shift = np.where(rows["shift"] > 0, rows["shift"], 0)
+    ix = np.where(ix < 0, ix + nx, ix)                                                                  # Python indexing of the rolled axis
+    lon_of = lon[(ix + shift) % nx]                                                                     # np.roll(lon, -shift)[ix], :884-887
+    lat_of = lat[iy]
+    # round() of numpy float64 scalars, like the reference's (np.round semantics, not Python's decimal rounding)
+    out = [(int(r["label"]), dates[int(r["t"])], int(lo), int(la), round(it, 2), round(r["area"], 2))
+           for r, lo, la, it in zip(rows, lon_of, lat_of, intensity)]
+    return sorted(out, key=lambda r: (r[0], r[1]))
+
+
 def _xr():
     import xarray as xr
     return xr
@@ -405,13 +430,13 @@ class contrack(object):
         self.ds['flag'] = (dims, flag.transpose(inverse), attrs)
         logger.info("Running contrack... DONE\n{} contours tracked".format(n_tracked))
 
-    # ---- life cycle (contrack.py:799-907); host numpy/scipy, consumer of `flag` ------------------
+    # ---- life cycle (contrack.py:798-906), consumer of `flag` ----------------------------
     def _time_labels(self):
         """'%Y%m%d_%H' per timestep (contrack.py:862)"""
         t = self.ds[self._time_name]
         try:
             return [str(v) for v in np.asarray(t.dt.strftime('%Y%m%d_%H').values)]
-        except AttributeError:
+        except (AttributeError, TypeError):
             vals = np.asarray(t.data)
             if vals.dtype.kind == "M":
                 import pandas as pd
@@ -423,9 +448,12 @@ class contrack(object):
 
         flag: name of the flag variable (output of run_contrack); variable: field used for intensity and centre of
         mass.  Returns a pandas DataFrame ['Flag', 'Date', 'Longitude', 'Latitude', 'Intensity', 'Size'] sorted by
-        (Flag, Date) -- one row per (time step, flag id)."""
+        (Flag, Date) -- one row per (time step, flag id).
+
+        The per-(time step, id) sums run on the GPU (ctk_lifecycle_*, include/contrack_hip.h); the divisions,
+        int() truncations, coordinate look-ups and rounding of contrack.py:876-901 are done here on the few
+        resulting rows."""
         import pandas as pd
-        from scipy import ndimage
         logger.info("\nRun Lifecycle \n########### \n    flag:    {}\n    variable:    {}".format(flag, variable))
         self._ensure_set_up()
         names = (self._time_name, self._latitude_name, self._longitude_name)
@@ -435,31 +463,18 @@ class contrack(object):
             return np.asarray(da.data).transpose([tuple(da.dims).index(d) for d in names])
 
         flags, field = slab(flag), slab(variable)
+        if flags.dtype.kind not in "iub":
+            raise ValueError("flag variable {!r} is not an integer field".format(flag))
+        if flags.size and (flags.max() > np.iinfo(np.int32).max or flags.min() < np.iinfo(np.int32).min):
+            raise ValueError("flag ids beyond int32")
+        if field.dtype != np.float64:
+            field = field.astype(np.float32, copy=False)
         lat = np.asarray(self.ds[self._latitude_name].data)
         lon = np.asarray(self.ds[self._longitude_name].data)
-        wgrid = np.ones((len(lat), len(lon))) * row_weights(lat, self._dlat, self._dlon)[:, None]       # contrack.py:847-848
-        dates = self._time_labels()
-        rows = []
-        for i in range(flags.shape[0]):
-            plane, values = flags[i], field[i]
-            ids = np.unique(plane)
-            for ident in ids[ids != 0]:
-                member = plane == ident
-                area = np.sum(wgrid[member])                                                           # :874
-                intensity = np.sum(wgrid[member] * values[member]) / area                              # :875-876
-                lon_axis = lon
-                if ident in plane[:, 0] and ident in plane[:, -1]:                                     # split at the seam (:880-889)
-                    cols = np.unique(np.nonzero(member)[1])
-                    shift = cols[np.argmax(np.diff(cols)) + 1]                                          # western edge of the contour
-                    plane_r, values_r = np.roll(plane, -shift, axis=1), np.roll(values, -shift, axis=1)
-                    lon_axis = np.roll(lon, -shift)
-                    com = ndimage.center_of_mass(values_r * wgrid, plane_r, [ident])
-                else:
-                    com = ndimage.center_of_mass(values * wgrid, plane, [ident])                        # :892
-                rows.append((ident, dates[i], int(lon_axis[int(com[0][1])]), int(lat[int(com[0][0])]),
-                             round(intensity, 2), round(area, 2)))
-        return pd.DataFrame(sorted(rows, key=lambda r: (r[0], r[1])),
-                            columns=['Flag', 'Date', 'Longitude', 'Latitude', 'Intensity', 'Size'])
+        wrow = row_weights(lat, self._dlat, self._dlon)                                                 # contrack.py:847-848
+        rows = _tracker().lifecycle(flags, field, wrow)
+        frame = lifecycle_frame(rows, lat, lon, self._time_labels())
+        return pd.DataFrame(frame, columns=['Flag', 'Date', 'Longitude', 'Latitude', 'Intensity', 'Size'])
 
     # ---- utility (contrack.py:912-949) ---------------------------------------------------------------------------
     def greatcircle_dist(self, lon1, lat1, lon2, lat2):

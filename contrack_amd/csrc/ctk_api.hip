@@ -3,6 +3,7 @@
 // sequential resolver in ctk_resolve.cpp.
 #include "ctk_kernels.hip"
 #include "ctk_resolve_dev.hip"
+#include "ctk_lifecycle.hip"
 #include "../../include/contrack_hip.h"
 
 #include <chrono>
@@ -63,6 +64,9 @@ struct ctk_handle {
     // device resolver work space
     DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lbox,
         rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff;
+    // run_lifecycle reductions
+    DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w;
+    std::vector<ctk_life_row> lc_host;
     void *h_cand = nullptr;          // pinned: candidates + boxes download
     size_t h_cand_cap = 0;
     void *h_ops = nullptr;           // pinned: op upload staging
@@ -221,7 +225,8 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->g_area, &h->g_comp_t, &h->g_pairs, &h->g_pair_base, &h->g_pair_cnt, &h->g_seams, &h->g_seam_cnt, &h->g_seam_off, &h->g_counters,
                       &h->g_label, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
                       &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
-                      &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff};
+                      &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
+                      &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -1293,6 +1298,115 @@ extern "C" int ctk_debug_label2d(ctk_handle *h, int before_seam, int32_t *lab)
 }
 
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// run_lifecycle reductions (contrack.py:798-906): one row per (time step, flag id)
+// ------------------------------------------------------------------------------------------------
+static_assert(sizeof(ctk_life_row) == sizeof(CtkLifeRowDev), "row layouts must agree");
+
+static int lifecycle_dev_impl(ctk_handle *h, const int32_t *flag_dev, const void *field_dev, bool f64, int64_t T, int ny, int nx, const float *wrow,
+                              int64_t *nrows)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    if (T < 0 || ny < 1 || nx < 1 || !wrow || (T > 0 && (!flag_dev || !field_dev)))
+        return ctk_set_error(CTK_E_INVALID, "ctk_lifecycle: bad shape or null pointer");
+    if (ny > 65535 || nx > 65535 || T > 4000000) return ctk_set_error(CTK_E_RANGE, "ctk_lifecycle: grid %d x %d x %lld beyond the supported size", ny, nx, (long long)T);
+    HIPCHK(hipSetDevice(h->device));
+    h->lc_host.clear();
+    if (nrows) *nrows = 0;
+    if (T == 0) return CTK_OK;
+    std::vector<int32_t> wlo(ny), whi(ny);
+    int32_t wshift = 0;
+    CTKCHK(ctk_weights_to_limbs(wrow, ny, wlo.data(), whi.data(), &wshift));
+    CTKCHK(ensure(h, h->lc_wlo, (size_t)ny * 4));
+    CTKCHK(ensure(h, h->lc_whi, (size_t)ny * 4));
+    CTKCHK(ensure(h, h->lc_w, (size_t)ny * 4));
+    CTKCHK(ensure(h, h->lc_cnt, 16));
+    HIPCHK(hipMemcpyAsync(h->lc_wlo.p, wlo.data(), (size_t)ny * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->lc_whi.p, whi.data(), (size_t)ny * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->lc_w.p, wrow, (size_t)ny * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));          // wlo / whi are stack-lifetime vectors
+    const int nxw = (nx + 31) / 32;
+    const int ks = std::max(1, std::min(32, 32768 / (nxw * 4)));
+    size_t cap = std::max<size_t>(h->lc_rows.cap / sizeof(CtkLifeRowDev), (size_t)T * 16 + 1024);
+    unsigned long long cnt[2] = {0, 0};
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        CTKCHK(ensure(h, h->lc_rows, cap * sizeof(CtkLifeRowDev)));
+        cap = h->lc_rows.cap / sizeof(CtkLifeRowDev);
+        HIPCHK(hipMemsetAsync(h->lc_cnt.p, 0, 16, h->stream));
+        if (f64)
+            k_lifecycle<double><<<(unsigned)T, LC_THREADS, (size_t)ks * nxw * 4, h->stream>>>(flag_dev, (const double *)field_dev, ny, nx, nxw, ks, P<int32_t>(h->lc_wlo),
+                                                                                           P<int32_t>(h->lc_whi), P<float>(h->lc_w), wshift,
+                                                                                           P<CtkLifeRowDev>(h->lc_rows), cap, P<unsigned long long>(h->lc_cnt));
+        else
+            k_lifecycle<float><<<(unsigned)T, LC_THREADS, (size_t)ks * nxw * 4, h->stream>>>(flag_dev, (const float *)field_dev, ny, nx, nxw, ks, P<int32_t>(h->lc_wlo),
+                                                                                          P<int32_t>(h->lc_whi), P<float>(h->lc_w), wshift,
+                                                                                          P<CtkLifeRowDev>(h->lc_rows), cap, P<unsigned long long>(h->lc_cnt));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(cnt, h->lc_cnt.p, 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (cnt[1] & LC_ERR_LABELS) return ctk_set_error(CTK_E_RANGE, "ctk_lifecycle: a time step holds more than %d distinct flag ids", LC_NL);
+        if (cnt[1] & LC_ERR_SEAM) return ctk_set_error(CTK_E_RANGE, "ctk_lifecycle: a time step holds more than %d flag ids that cross the longitude seam", ks);
+        if (cnt[0] <= cap) break;
+        if (attempt == 1) return ctk_set_error(CTK_E_INTERNAL, "ctk_lifecycle: row count changed between passes");
+        cap = (size_t)cnt[0];
+    }
+    const size_t n = (size_t)cnt[0];
+    h->lc_host.resize(n);
+    if (n) HIPCHK(hipMemcpy(h->lc_host.data(), h->lc_rows.p, n * sizeof(ctk_life_row), hipMemcpyDeviceToHost));
+    // rows leave the device in arbitrary order; the reference's frame is sorted by (Flag, Date) (contrack.py:906)
+    std::sort(h->lc_host.begin(), h->lc_host.end(), [](const ctk_life_row &a, const ctk_life_row &b) { return a.label != b.label ? a.label < b.label : a.t < b.t; });
+    if (nrows) *nrows = (int64_t)n;
+    return CTK_OK;
+}
+
+static int lifecycle_host_impl(ctk_handle *h, const int32_t *flag, const void *field, bool f64, int64_t T, int ny, int nx, const float *wrow, int64_t *nrows)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    if (T < 0 || ny < 1 || nx < 1 || (T > 0 && (!flag || !field))) return ctk_set_error(CTK_E_INVALID, "ctk_lifecycle: bad shape or null pointer");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = (size_t)T * ny * nx, esz = f64 ? 8 : 4;
+    void *f_dev = nullptr, *v_dev = nullptr;
+    int rc = CTK_OK;
+    if (n) {
+        hipError_t e = hipMalloc(&f_dev, n * 4);
+        if (e == hipSuccess) e = hipMalloc(&v_dev, n * esz);
+        if (e != hipSuccess) rc = ctk_set_error(CTK_E_NOMEM, "hipMalloc for the flag / field slabs failed: %s", hipGetErrorString(e));
+        if (rc == CTK_OK) {
+            e = hipMemcpy(f_dev, flag, n * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(v_dev, field, n * esz, hipMemcpyHostToDevice);
+            if (e != hipSuccess) rc = ctk_set_error(CTK_E_NODEVICE, "H2D copy failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (rc == CTK_OK) rc = lifecycle_dev_impl(h, (const int32_t *)f_dev, v_dev, f64, T, ny, nx, wrow, nrows);
+    if (f_dev) (void)hipFree(f_dev);
+    if (v_dev) (void)hipFree(v_dev);
+    return rc;
+}
+
+extern "C" int ctk_lifecycle_f32_dev(ctk_handle *h, const int32_t *flag_dev, const float *field_dev, int64_t T, int ny, int nx, const float *wrow, int64_t *nrows)
+{
+    return lifecycle_dev_impl(h, flag_dev, field_dev, false, T, ny, nx, wrow, nrows);
+}
+extern "C" int ctk_lifecycle_f64_dev(ctk_handle *h, const int32_t *flag_dev, const double *field_dev, int64_t T, int ny, int nx, const float *wrow, int64_t *nrows)
+{
+    return lifecycle_dev_impl(h, flag_dev, field_dev, true, T, ny, nx, wrow, nrows);
+}
+extern "C" int ctk_lifecycle_f32(ctk_handle *h, const int32_t *flag, const float *field, int64_t T, int ny, int nx, const float *wrow, int64_t *nrows)
+{
+    return lifecycle_host_impl(h, flag, field, false, T, ny, nx, wrow, nrows);
+}
+extern "C" int ctk_lifecycle_f64(ctk_handle *h, const int32_t *flag, const double *field, int64_t T, int ny, int nx, const float *wrow, int64_t *nrows)
+{
+    return lifecycle_host_impl(h, flag, field, true, T, ny, nx, wrow, nrows);
+}
+extern "C" int ctk_lifecycle_rows(ctk_handle *h, ctk_life_row *rows, int64_t cap)
+{
+    if (!h || (cap > 0 && !rows)) return ctk_set_error(CTK_E_INVALID, "null argument");
+    if ((size_t)cap < h->lc_host.size()) return ctk_set_error(CTK_E_INVALID, "ctk_lifecycle_rows: room for %lld rows, %zu held", (long long)cap, h->lc_host.size());
+    if (!h->lc_host.empty()) memcpy(rows, h->lc_host.data(), h->lc_host.size() * sizeof(ctk_life_row));
+    return CTK_OK;
+}
+
 // device-memory helpers for a ctypes host
 // ------------------------------------------------------------------------------------------------
 extern "C" int ctk_dev_malloc(ctk_handle *h, void **p, size_t nbytes)

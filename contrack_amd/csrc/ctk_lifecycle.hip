@@ -1,0 +1,199 @@
+// ctk_lifecycle.hip -- per (time step, flag id) reductions of contrack.run_lifecycle (contrack/contrack.py:798-906):
+// size, intensity numerator and the centre-of-mass sums of every flagged contour, one workgroup per time step.
+// Included by ctk_api.hip (uses dev_limbs_to_double of ctk_resolve_dev.hip).
+//
+// The reference loops over time steps and, inside, over np.unique(flag[t]); per label it evaluates
+//   areacon      = np.sum(weight_grid[flag == label])                                   (:874)
+//   intensitycon = np.sum(weight_grid[...] * variable[...]) / areacon                   (:875-876)
+//   center_of_mass(variable * weight_grid, flag, [label])                               (:892)
+// and, when the label touches both x = 0 and x = nx-1, rolls the plane so that the contour's western edge
+// (the column right of the widest gap in the occupied columns, :882-883) becomes column 0 before taking the
+// centre of mass (:884-889).  All of that is four sums per label plus a column-occupancy bit set:
+//   area  (exact: integer limbs of the float32 row weights, rounded once)
+//   swv   = sum w*v          swvy = sum (w*v)*y          swvx = sum (w*v)*x'      x' = (x - shift) mod nx
+// in float64 (LDS atomics: the summation order differs from numpy's, the products are the same).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LC_HASH 2048      // hash slots for the flag ids of one time step
+#define LC_NL 512         // distinct flag ids one time step may hold
+#define LC_THREADS 256
+#define LC_ERR_LABELS 1u  // more than LC_NL ids in one time step
+#define LC_ERR_SEAM 2u    // more seam-crossing ids in one time step than column bit sets fit
+
+struct CtkLifeRowDev {
+    int32_t t, label, shift, pad;    // shift: roll applied before the centre of mass (-1: none, -2: undefined, single column)
+    double area, swv, swvy, swvx;
+};
+
+__device__ inline uint32_t lc_hash(int32_t label) { return ((uint32_t)label * 2654435761u) >> 21; }   // 11 bits
+
+// slot of `label` in the table (insert = false: the label is known to be present)
+template <bool INSERT>
+__device__ inline int lc_slot(int32_t *hkey, int32_t label)
+{
+    uint32_t s = lc_hash(label) & (LC_HASH - 1);
+    for (int probe = 0; probe < LC_HASH; ++probe) {
+        const int32_t k = hkey[s];
+        if (k == label) return (int)s;
+        if (INSERT && k == 0) {
+            const int32_t old = atomicCAS(&hkey[s], 0, label);
+            if (old == 0 || old == label) return (int)s;
+        }
+        s = (s + 1) & (LC_HASH - 1);
+    }
+    return -1;
+}
+
+template <typename VT>
+__global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restrict__ flag, const VT *__restrict__ field, int ny, int nx, int nxw,
+                                                          int ks, const int32_t *__restrict__ wlo, const int32_t *__restrict__ whi,
+                                                          const float *__restrict__ wrow, int wshift, CtkLifeRowDev *rows,
+                                                          unsigned long long cap_rows, unsigned long long *counters)
+{
+    __shared__ int32_t hkey[LC_HASH];
+    __shared__ unsigned hedge[LC_HASH];          // bit 0: id seen at x = 0, bit 1: at x = nx-1
+    __shared__ uint16_t hidx[LC_HASH];
+    __shared__ int32_t dlabel[LC_NL], dshift[LC_NL], dseam[LC_NL];
+    __shared__ long long alo[LC_NL], ahi[LC_NL];
+    __shared__ double swv[LC_NL], swvy[LC_NL], swvx[LC_NL];
+    __shared__ int seam_idx[64];
+    __shared__ int nlab, nseam;
+    __shared__ unsigned err;
+    __shared__ unsigned long long base;
+    extern __shared__ unsigned colbits[];        // [ks][nxw] occupied columns of the seam-crossing ids
+
+    const int tid = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    const int64_t npx = (int64_t)ny * nx;
+    const int32_t *fp = flag + t * npx;
+    const VT *vp = field + t * npx;
+
+    for (int s = tid; s < LC_HASH; s += LC_THREADS) { hkey[s] = 0; hedge[s] = 0; }
+    if (tid == 0) { nlab = 0; nseam = 0; err = 0; }
+    __syncthreads();
+
+    // ---- A: the ids present, and which of them touch the two seam columns
+    for (int64_t p0 = (int64_t)tid * 4; p0 < npx; p0 += LC_THREADS * 4) {
+        int32_t prev = 0;
+        int prev_slot = -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t p = p0 + k;
+            if (p >= npx) break;
+            const int32_t l = fp[p];
+            if (l == 0) continue;
+            int s = (l == prev) ? prev_slot : lc_slot<true>(hkey, l);
+            if (s < 0) { err = LC_ERR_LABELS; continue; }
+            prev = l; prev_slot = s;
+            const int x = (int)(p % nx);
+            unsigned e = (x == 0 ? 1u : 0u) | (x == nx - 1 ? 2u : 0u);
+            if (e && (hedge[s] & e) != e) atomicOr(&hedge[s], e);
+        }
+    }
+    __syncthreads();
+
+    // ---- B: dense index per id, accumulators
+    for (int s = tid; s < LC_HASH; s += LC_THREADS) {
+        if (hkey[s] == 0) continue;
+        const int i = atomicAdd(&nlab, 1);
+        if (i >= LC_NL) continue;
+        hidx[s] = (uint16_t)i;
+        dlabel[i] = hkey[s];
+        dshift[i] = -1;
+        dseam[i] = -1;
+        alo[i] = 0; ahi[i] = 0;
+        swv[i] = 0.0; swvy[i] = 0.0; swvx[i] = 0.0;
+        if (hedge[s] == 3u) {
+            const int q = atomicAdd(&nseam, 1);
+            if (q < ks) { dseam[i] = q; seam_idx[q] = i; }
+        }
+    }
+    for (int w = tid; w < ks * nxw; w += LC_THREADS) colbits[w] = 0;
+    __syncthreads();
+    if (nlab > LC_NL || nseam > ks || err) {
+        if (tid == 0) atomicOr((unsigned *)&counters[1], err | (nlab > LC_NL ? LC_ERR_LABELS : 0u) | (nseam > ks ? LC_ERR_SEAM : 0u));
+        return;
+    }
+    const int n = nlab;
+    if (n == 0) return;
+
+    // ---- C: western edge of the ids that cross the seam
+    if (nseam > 0) {
+        for (int64_t p = tid; p < npx; p += LC_THREADS) {
+            const int32_t l = fp[p];
+            if (l == 0) continue;
+            const int q = dseam[hidx[lc_slot<false>(hkey, l)]];
+            if (q < 0) continue;
+            const int x = (int)(p % nx);
+            const unsigned bit = 1u << (x & 31);
+            unsigned *wp = &colbits[q * nxw + (x >> 5)];
+            if (!(*wp & bit)) atomicOr(wp, bit);
+        }
+        __syncthreads();
+        if (tid < nseam) {
+            const unsigned *cb = &colbits[tid * nxw];
+            int prev = -1, best = 0, sh = -2;            // np.argmax(np.diff(cols)): first largest gap (:883)
+            for (int x = 0; x < nx; ++x) {
+                if (!((cb[x >> 5] >> (x & 31)) & 1u)) continue;
+                if (prev >= 0 && x - prev > best) { best = x - prev; sh = x; }
+                prev = x;
+            }
+            dshift[seam_idx[tid]] = sh;
+        }
+        __syncthreads();
+    }
+
+    // ---- D: the sums
+    for (int64_t p0 = (int64_t)tid * 4; p0 < npx; p0 += LC_THREADS * 4) {
+        int32_t cur = 0;
+        int ci = -1, cy = -1, cnt = 0, csh = 0;
+        double a_wv = 0.0, a_wvy = 0.0, a_wvx = 0.0;
+        auto flush = [&]() {
+            if (ci < 0) return;
+            atomicAdd((unsigned long long *)&alo[ci], (unsigned long long)((long long)cnt * wlo[cy]));
+            atomicAdd((unsigned long long *)&ahi[ci], (unsigned long long)((long long)cnt * whi[cy]));
+            atomicAdd(&swv[ci], a_wv);
+            atomicAdd(&swvy[ci], a_wvy);
+            atomicAdd(&swvx[ci], a_wvx);
+            ci = -1;
+        };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t p = p0 + k;
+            if (p >= npx) break;
+            const int32_t l = fp[p];
+            if (l == 0) { flush(); cur = 0; continue; }
+            const int y = (int)(p / nx), x = (int)(p - (int64_t)y * nx);
+            if (l != cur || y != cy) {
+                flush();
+                cur = l; cy = y; cnt = 0;
+                ci = hidx[lc_slot<false>(hkey, l)];
+                csh = dshift[ci];
+                a_wv = a_wvy = a_wvx = 0.0;
+            }
+            const double wv = (double)vp[p] * (double)wrow[y];          // variable * weight_grid (:892), float64
+            int xr = x;
+            if (csh > 0) { xr = x - csh; if (xr < 0) xr += nx; }
+            cnt += 1;
+            // the partial sums of up to four pixels are formed here and added once: same products, another order
+            a_wv += wv;
+            a_wvy += wv * (double)y;
+            a_wvx += wv * (double)xr;
+        }
+        flush();
+    }
+    __syncthreads();
+
+    if (tid == 0) base = atomicAdd(&counters[0], (unsigned long long)n);
+    __syncthreads();
+    if (base + (unsigned long long)n > cap_rows) return;
+    for (int i = tid; i < n; i += LC_THREADS) {
+        CtkLifeRowDev r;
+        r.t = (int32_t)t; r.label = dlabel[i]; r.shift = dshift[i]; r.pad = 0;
+        r.area = dev_limbs_to_double(alo[i], ahi[i], wshift);
+        r.swv = swv[i]; r.swvy = swvy[i]; r.swvx = swvx[i];
+        rows[base + i] = r;
+    }
+}

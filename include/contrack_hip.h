@@ -189,6 +189,28 @@ void *ctk_stream(ctk_handle *h);                          /* hipStream_t */
 /* deterministic on-device synthetic slab for throughput runs (bench only; not part of the path) */
 int ctk_synth_fill(ctk_handle *h, float *anom_dev, int64_t T, int ny, int nx, uint64_t seed);
 
+/* ---- next row N1: contrack.run_lifecycle reductions (contrack/contrack.py:798-906) --------------------------
+ * One row per (time step, flag id != 0) of an int32 flag slab (time, lat, lon) and a field of the same shape:
+ *   area  = np.sum(weight_grid[flag == id])                       contrack.py:874   (exact, rounded once)
+ *   swv   = np.sum(weight_grid[...] * field[...])                 contrack.py:875   (float64)
+ *   swvy, swvx = the two numerators of ndimage.center_of_mass(field * weight_grid, flag, [id])   contrack.py:892
+ *   shift = column that becomes x = 0 when the id touches both seam columns (np.roll by -shift,
+ *           contrack.py:880-889; swvx is taken in the rolled frame); -1 if not rolled; -2 if the id occupies a
+ *           single column (the reference's argmax of an empty diff raises there)
+ * The host finishes with  intensity = swv / area,  com = (swvy / swv, swvx / swv),  int() and the coordinate
+ * look-ups (contrack.py:886-895).  ctk_lifecycle_* computes and keeps the rows in the handle (sorted by
+ * (label, t) like the reference's frame, contrack.py:906) and returns their number; ctk_lifecycle_rows copies
+ * them out.  wrow: float32 row weights, contrack.py:847-848.  Limits: 512 ids per time step. */
+typedef struct ctk_life_row {
+    int32_t t, label, shift, pad;
+    double area, swv, swvy, swvx;
+} ctk_life_row;
+int ctk_lifecycle_f32_dev(ctk_handle *h, const int32_t *flag_dev, const float *field_dev, int64_t T, int ny, int nx, const float *wrow, int64_t *nrows);
+int ctk_lifecycle_f64_dev(ctk_handle *h, const int32_t *flag_dev, const double *field_dev, int64_t T, int ny, int nx, const float *wrow, int64_t *nrows);
+int ctk_lifecycle_f32(ctk_handle *h, const int32_t *flag, const float *field, int64_t T, int ny, int nx, const float *wrow, int64_t *nrows);
+int ctk_lifecycle_f64(ctk_handle *h, const int32_t *flag, const double *field, int64_t T, int ny, int nx, const float *wrow, int64_t *nrows);
+int ctk_lifecycle_rows(ctk_handle *h, ctk_life_row *rows, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

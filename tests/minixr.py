@@ -81,6 +81,46 @@ class DataArray:
         ax = self.dims.index(dim)
         return DataArray(self.data.mean(axis=ax), tuple(d for d in self.dims if d != dim))
 
+    # the part of the API the reference's run_lifecycle touches (contrack.py:862-895) ----------------------
+    def isel(self, **indexers):
+        data, dims, coords = self.data, list(self.dims), dict(self.coords)
+        for name, i in indexers.items():
+            ax = dims.index(name)
+            data = np.take(data, i, axis=ax)
+            dims.pop(ax)
+            if name in coords:
+                coords[name] = DataArray(np.take(coords[name].data, i, axis=0), ())
+        return DataArray(data, dims, coords, self.attrs)
+
+    def roll(self, roll_coords=False, **shifts):
+        data, coords = self.data, dict(self.coords)
+        for name, k in shifts.items():
+            data = np.roll(data, k, axis=self.dims.index(name))
+            if roll_coords and name in coords:
+                coords[name] = DataArray(np.roll(coords[name].data, k), (name,), attrs=coords[name].attrs)
+        return DataArray(data, self.dims, coords, self.attrs)
+
+    @property
+    def dt(self):
+        if self.data.dtype.kind != "M":
+            raise TypeError("'.dt' accessor only available for DataArray with datetime64 timedelta64 dtype")
+        return _DatetimeAccessor(self)
+
+
+class _DatetimeAccessor:
+    def __init__(self, da):
+        self._da = da
+
+    def strftime(self, fmt):
+        import pandas as pd
+        flat = [pd.Timestamp(v).strftime(fmt) for v in np.asarray(self._da.data).reshape(-1)]
+        return DataArray(np.array(flat, dtype=object).reshape(self._da.data.shape), self._da.dims)
+
+    @property
+    def dayofyear(self):
+        import pandas as pd
+        return DataArray(pd.DatetimeIndex(np.asarray(self._da.data).reshape(-1)).dayofyear.values, self._da.dims)
+
 
 class Variable(DataArray):
     def __init__(self, dims, data, attrs=None):

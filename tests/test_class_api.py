@@ -134,9 +134,10 @@ def test_run_contrack_float64_and_dayofyear_threshold():
     assert np.array_equal(np.asarray(c.flag), g["flag"])
 
 
+@pytest.mark.gpu
 def test_run_lifecycle_known_answer():
-    """tests/test_contrack.py:93-103: 3 flags, 28 rows on the reference's test slab (flag taken from the golden,
-    so this runs without a GPU); numeric columns cross-checked against a direct evaluation."""
+    """tests/test_contrack.py:93-103: 3 flags, 28 rows on the reference's test slab (integer time axis);
+    numeric columns cross-checked against a direct evaluation (tests/test_lifecycle.py holds the reference's values)."""
     ds, g = _dataset("refslab_fwd")
     ds["flag"] = minixr.DataArray(g["flag"], ("time", "latitude", "longitude"))
     c = contrack(ds=ds)
