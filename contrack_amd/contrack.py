@@ -89,9 +89,9 @@ def track_numpy(anom, wrow, threshold, gorl, overlap, persistence, twosided=True
 # the class
 # ------------------------------------------------------------------------------------------------
 
-def lifecycle_frame(rows, lat, lon, dates):
-    """ctk_life_row records -> the reference's rows (contrack.py:876-906): (Flag, Date, Longitude, Latitude,
-    Intensity, Size) sorted by (Flag, Date)."""
+def lifecycle_columns(rows, lat, lon, dates):
+    """ctk_life_row records -> the columns of the reference's frame (contrack.py:876-906), rows sorted by (Flag, Date):
+    dict of arrays Flag, Date, Longitude, Latitude, Intensity, Size."""
     nx, ny = len(lon), len(lat)
     if (rows["shift"] == -2).any():
         raise ValueError("attempt to get argmax of an empty sequence")                                  # np.argmax(np.diff(.)), :883
@@ -105,12 +105,24 @@ def lifecycle_frame(rows, lat, lon, dates):
         raise IndexError("centre of mass outside the grid")
     shift = np.where(rows["shift"] > 0, rows["shift"], 0)
     ix = np.where(ix < 0, ix + nx, ix)                                                                  # Python indexing of the rolled axis
-    lon_of = lon[(ix + shift) % nx]                                                                     # np.roll(lon, -shift)[ix], :884-887
-    lat_of = lat[iy]
-    # round() of numpy float64 scalars, like the reference's (np.round semantics, not Python's decimal rounding)
-    out = [(int(r["label"]), dates[int(r["t"])], int(lo), int(la), round(it, 2), round(r["area"], 2))
-           for r, lo, la, it in zip(rows, lon_of, lat_of, intensity)]
-    return sorted(out, key=lambda r: (r[0], r[1]))
+    lon_of = np.asarray(lon)[(ix + shift) % nx]                                                         # np.roll(lon, -shift)[ix], :884-887
+    lat_of = np.asarray(lat)[iy]
+    date = np.asarray(dates, dtype=object)[rows["t"]] if len(rows) else np.empty(0, dtype=object)
+    cols = dict(Flag=rows["label"].astype(np.int64), Date=date,
+                Longitude=np.trunc(lon_of).astype(np.int64), Latitude=np.trunc(lat_of).astype(np.int64),           # int(), :886-895
+                Intensity=np.round(intensity, 2), Size=np.round(rows["area"], 2))                       # round(np.float64, 2), :899-900
+    # the library returns (label, t) order; the reference sorts by the date STRING, which differs when the time axis
+    # is not increasing
+    order = sorted(range(len(rows)), key=lambda i: (cols["Flag"][i], cols["Date"][i])) \
+        if any(a > b for a, b in zip(dates, dates[1:])) else None
+    return cols if order is None else {k: v[order] for k, v in cols.items()}
+
+
+def lifecycle_frame(rows, lat, lon, dates):
+    """the same as a list of (Flag, Date, Longitude, Latitude, Intensity, Size) tuples"""
+    c = lifecycle_columns(rows, lat, lon, dates)
+    return [(int(f), d, int(lo), int(la), float(it), float(sz)) for f, d, lo, la, it, sz in
+            zip(c["Flag"], c["Date"], c["Longitude"], c["Latitude"], c["Intensity"], c["Size"])]
 
 
 def _xr():
@@ -473,8 +485,8 @@ class contrack(object):
         lon = np.asarray(self.ds[self._longitude_name].data)
         wrow = row_weights(lat, self._dlat, self._dlon)                                                 # contrack.py:847-848
         rows = _tracker().lifecycle(flags, field, wrow)
-        frame = lifecycle_frame(rows, lat, lon, self._time_labels())
-        return pd.DataFrame(frame, columns=['Flag', 'Date', 'Longitude', 'Latitude', 'Intensity', 'Size'])
+        return pd.DataFrame(lifecycle_columns(rows, lat, lon, self._time_labels()),
+                            columns=['Flag', 'Date', 'Longitude', 'Latitude', 'Intensity', 'Size'])
 
     # ---- utility (contrack.py:912-949) ---------------------------------------------------------------------------
     def greatcircle_dist(self, lon1, lat1, lon2, lat2):

@@ -66,7 +66,8 @@ struct ctk_handle {
         rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff;
     // run_lifecycle reductions
     DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w;
-    std::vector<ctk_life_row> lc_host;
+    std::vector<ctk_life_row> lc_host, lc_tmp;
+    std::vector<std::pair<uint64_t, uint32_t>> lc_keys;
     void *h_cand = nullptr;          // pinned: candidates + boxes download
     size_t h_cand_cap = 0;
     void *h_ops = nullptr;           // pinned: op upload staging
@@ -1351,10 +1352,17 @@ static int lifecycle_dev_impl(ctk_handle *h, const int32_t *flag_dev, const void
         cap = (size_t)cnt[0];
     }
     const size_t n = (size_t)cnt[0];
+    // rows leave the device in arbitrary order; the reference's frame is sorted by (Flag, Date) (contrack.py:906):
+    // sort (label, t) keys, then gather the 48-byte records once
+    h->lc_tmp.resize(n);
+    if (n) HIPCHK(hipMemcpy(h->lc_tmp.data(), h->lc_rows.p, n * sizeof(ctk_life_row), hipMemcpyDeviceToHost));
+    std::vector<std::pair<uint64_t, uint32_t>> &keys = h->lc_keys;
+    keys.resize(n);
+    for (size_t i = 0; i < n; ++i)
+        keys[i] = {((uint64_t)((uint32_t)h->lc_tmp[i].label ^ 0x80000000u) << 32) | (uint32_t)h->lc_tmp[i].t, (uint32_t)i};
+    std::sort(keys.begin(), keys.end());
     h->lc_host.resize(n);
-    if (n) HIPCHK(hipMemcpy(h->lc_host.data(), h->lc_rows.p, n * sizeof(ctk_life_row), hipMemcpyDeviceToHost));
-    // rows leave the device in arbitrary order; the reference's frame is sorted by (Flag, Date) (contrack.py:906)
-    std::sort(h->lc_host.begin(), h->lc_host.end(), [](const ctk_life_row &a, const ctk_life_row &b) { return a.label != b.label ? a.label < b.label : a.t < b.t; });
+    for (size_t i = 0; i < n; ++i) h->lc_host[i] = h->lc_tmp[keys[i].second];
     if (nrows) *nrows = (int64_t)n;
     return CTK_OK;
 }

@@ -341,7 +341,7 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
                                              const bool mrow_staged /* mrow is the whole timestep in LDS */,
                                              void *lds_tab /* LDS_COMPS x 32 B of LDS: band staging, then the component tables; or nullptr */)
 {
-    const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, nwv = THREADS >> 6;
+    const int tid = (int)threadIdx.x;
     const int ny = a.ny, nx = a.nx, W = a.W;
     const uint32_t rbase = a.run_base[t];
 

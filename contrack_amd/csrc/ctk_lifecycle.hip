@@ -18,7 +18,7 @@
 
 #define LC_HASH 2048      // hash slots for the flag ids of one time step
 #define LC_NL 512         // distinct flag ids one time step may hold
-#define LC_THREADS 256
+#define LC_THREADS 512
 #define LC_ERR_LABELS 1u  // more than LC_NL ids in one time step
 #define LC_ERR_SEAM 2u    // more seam-crossing ids in one time step than column bit sets fit
 
@@ -66,29 +66,41 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
 
     const int tid = threadIdx.x;
     const int64_t t = blockIdx.x;
-    const int64_t npx = (int64_t)ny * nx;
-    const int32_t *fp = flag + t * npx;
-    const VT *vp = field + t * npx;
+    const uint32_t npx = (uint32_t)ny * (uint32_t)nx;            // ny, nx <= 65535 (checked by the host)
+    const int32_t *fp = flag + t * (int64_t)npx;
+    const VT *vp = field + t * (int64_t)npx;
+    const bool vec = (npx & 3u) == 0 && (((uintptr_t)flag) & 15u) == 0;      // every plane starts 16-byte aligned
 
     for (int s = tid; s < LC_HASH; s += LC_THREADS) { hkey[s] = 0; hedge[s] = 0; }
     if (tid == 0) { nlab = 0; nseam = 0; err = 0; }
     __syncthreads();
 
+    // four consecutive pixels of the plane (zeros beyond its end)
+    auto load4 = [&](uint32_t p0, int32_t l[4]) {
+        if (vec) {
+            const int4 q = *(const int4 *)(fp + p0);
+            l[0] = q.x; l[1] = q.y; l[2] = q.z; l[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) l[k] = (p0 + k < npx) ? fp[p0 + k] : 0;
+        }
+    };
+
     // ---- A: the ids present, and which of them touch the two seam columns
-    for (int64_t p0 = (int64_t)tid * 4; p0 < npx; p0 += LC_THREADS * 4) {
+    for (uint32_t p0 = (uint32_t)tid * 4; p0 < npx; p0 += LC_THREADS * 4) {
+        int32_t l[4];
+        load4(p0, l);
+        if ((l[0] | l[1] | l[2] | l[3]) == 0) continue;
         int32_t prev = 0;
         int prev_slot = -1;
+        uint32_t x = p0 % (uint32_t)nx;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t p = p0 + k;
-            if (p >= npx) break;
-            const int32_t l = fp[p];
-            if (l == 0) continue;
-            int s = (l == prev) ? prev_slot : lc_slot<true>(hkey, l);
+        for (int k = 0; k < 4; ++k, x = (x + 1 == (uint32_t)nx) ? 0 : x + 1) {
+            if (l[k] == 0) continue;
+            const int s = (l[k] == prev) ? prev_slot : lc_slot<true>(hkey, l[k]);
             if (s < 0) { err = LC_ERR_LABELS; continue; }
-            prev = l; prev_slot = s;
-            const int x = (int)(p % nx);
-            unsigned e = (x == 0 ? 1u : 0u) | (x == nx - 1 ? 2u : 0u);
+            prev = l[k]; prev_slot = s;
+            const unsigned e = (x == 0 ? 1u : 0u) | (x == (uint32_t)nx - 1 ? 2u : 0u);
             if (e && (hedge[s] & e) != e) atomicOr(&hedge[s], e);
         }
     }
@@ -121,15 +133,20 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
 
     // ---- C: western edge of the ids that cross the seam
     if (nseam > 0) {
-        for (int64_t p = tid; p < npx; p += LC_THREADS) {
-            const int32_t l = fp[p];
-            if (l == 0) continue;
-            const int q = dseam[hidx[lc_slot<false>(hkey, l)]];
-            if (q < 0) continue;
-            const int x = (int)(p % nx);
-            const unsigned bit = 1u << (x & 31);
-            unsigned *wp = &colbits[q * nxw + (x >> 5)];
-            if (!(*wp & bit)) atomicOr(wp, bit);
+        for (uint32_t p0 = (uint32_t)tid * 4; p0 < npx; p0 += LC_THREADS * 4) {
+            int32_t l[4];
+            load4(p0, l);
+            if ((l[0] | l[1] | l[2] | l[3]) == 0) continue;
+            uint32_t x = p0 % (uint32_t)nx;
+#pragma unroll
+            for (int k = 0; k < 4; ++k, x = (x + 1 == (uint32_t)nx) ? 0 : x + 1) {
+                if (l[k] == 0) continue;
+                const int q = dseam[hidx[lc_slot<false>(hkey, l[k])]];
+                if (q < 0) continue;
+                const unsigned bit = 1u << (x & 31);
+                unsigned *wp = &colbits[q * nxw + (x >> 5)];
+                if (!(*wp & bit)) atomicOr(wp, bit);
+            }
         }
         __syncthreads();
         if (tid < nseam) {
@@ -146,10 +163,13 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
     }
 
     // ---- D: the sums
-    for (int64_t p0 = (int64_t)tid * 4; p0 < npx; p0 += LC_THREADS * 4) {
+    for (uint32_t p0 = (uint32_t)tid * 4; p0 < npx; p0 += LC_THREADS * 4) {
+        int32_t l[4];
+        load4(p0, l);
+        if ((l[0] | l[1] | l[2] | l[3]) == 0) continue;
         int32_t cur = 0;
         int ci = -1, cy = -1, cnt = 0, csh = 0;
-        double a_wv = 0.0, a_wvy = 0.0, a_wvx = 0.0;
+        double a_wv = 0.0, a_wvy = 0.0, a_wvx = 0.0, wy = 0.0;
         auto flush = [&]() {
             if (ci < 0) return;
             atomicAdd((unsigned long long *)&alo[ci], (unsigned long long)((long long)cnt * wlo[cy]));
@@ -159,28 +179,30 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
             atomicAdd(&swvx[ci], a_wvx);
             ci = -1;
         };
+        int y = (int)(p0 / (uint32_t)nx), x = (int)(p0 - (uint32_t)y * (uint32_t)nx);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t p = p0 + k;
-            if (p >= npx) break;
-            const int32_t l = fp[p];
-            if (l == 0) { flush(); cur = 0; continue; }
-            const int y = (int)(p / nx), x = (int)(p - (int64_t)y * nx);
-            if (l != cur || y != cy) {
-                flush();
-                cur = l; cy = y; cnt = 0;
-                ci = hidx[lc_slot<false>(hkey, l)];
-                csh = dshift[ci];
-                a_wv = a_wvy = a_wvx = 0.0;
+            if (l[k] == 0) {
+                flush(); cur = 0;
+            } else {
+                if (l[k] != cur || y != cy) {
+                    flush();
+                    cur = l[k]; cy = y; cnt = 0;
+                    ci = hidx[lc_slot<false>(hkey, cur)];
+                    csh = dshift[ci];
+                    wy = (double)wrow[y];
+                    a_wv = a_wvy = a_wvx = 0.0;
+                }
+                const double wv = (double)vp[p0 + k] * wy;                  // variable * weight_grid (:892), float64
+                int xr = x;
+                if (csh > 0) { xr = x - csh; if (xr < 0) xr += nx; }
+                cnt += 1;
+                // the partial sums of up to four pixels are formed here and added once: same products, another order
+                a_wv += wv;
+                a_wvy += wv * (double)y;
+                a_wvx += wv * (double)xr;
             }
-            const double wv = (double)vp[p] * (double)wrow[y];          // variable * weight_grid (:892), float64
-            int xr = x;
-            if (csh > 0) { xr = x - csh; if (xr < 0) xr += nx; }
-            cnt += 1;
-            // the partial sums of up to four pixels are formed here and added once: same products, another order
-            a_wv += wv;
-            a_wvy += wv * (double)y;
-            a_wvx += wv * (double)xr;
+            if (++x == nx) { x = 0; ++y; }
         }
         flush();
     }

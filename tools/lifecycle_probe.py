@@ -8,7 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from contrack_amd import _native, synth  # noqa: E402
-from contrack_amd.contrack import row_weights, lifecycle_frame  # noqa: E402
+from contrack_amd.contrack import row_weights, lifecycle_frame, lifecycle_columns  # noqa: E402
 
 T, ny, nx = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (2707, 181, 360)
 lat, lon = synth.grid(ny, nx)
@@ -25,9 +25,11 @@ with _native.Tracker(0) as trk:
     for _ in range(reps):
         rows = trk.lifecycle_dev(f, a, T, ny, nx, wrow)
     dt = (time.perf_counter() - t0) / reps
+    dates = ["%06d" % t for t in range(T)]
     t1 = time.perf_counter()
-    frame = lifecycle_frame(rows, lat, lon, ["%06d" % t for t in range(T)])
+    cols = lifecycle_columns(rows, lat, lon, dates)
     dt_frame = time.perf_counter() - t1
+    frame = lifecycle_frame(rows, lat, lon, dates)
     print("tracked %d contours; lifecycle rows %d (%d rolled); device reductions + download + sort %.3f ms (%.0f timesteps/s); host finish %.1f ms"
           % (tracked, len(rows), int((rows["shift"] > 0).sum()), dt * 1e3, T / dt, dt_frame * 1e3))
     Ts = min(T, 40)
