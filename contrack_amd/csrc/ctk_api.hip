@@ -63,7 +63,7 @@ struct ctk_handle {
     DevBuf g_ncomp, g_cprefix, g_mrep, g_box, g_area, g_comp_t, g_pairs, g_pair_base, g_pair_cnt, g_seams, g_seam_cnt, g_seam_off, g_counters, g_label;
     // device resolver work space
     DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lbox,
-        rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff;
+        rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff, rv_dmap, rv_dorig, rv_dbox;
     // run_lifecycle reductions
     DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w;
     std::vector<ctk_life_row> lc_host, lc_tmp;
@@ -71,14 +71,15 @@ struct ctk_handle {
     void *h_cand = nullptr;          // pinned: candidates + boxes download
     size_t h_cand_cap = 0;
     void *h_ops = nullptr;           // pinned: op upload staging
+    void *h_mail = nullptr;          // pinned: device-written mailbox of the resolver (scalars, candidates, dense tables)
+    size_t mail_cap_c = 0, mail_cap_d = 0, mail_want_c = 0, mail_want_d = 0;
     size_t h_ops_cap = 0;
     const int32_t *d_op_next = nullptr;
     int use_device_resolve = 1;
     int filter_round = CTK_JACOBI_ROUND;          // filter passes launched before convergence is checked
     uint32_t debug_pair_cap = 0;                  // test hook: pretend the pair table holds only this many records
     // host scratch of the seam driver, kept between calls (fresh 100+ KB vectors would page-fault every call)
-    std::vector<int32_t> sd_first, sd_last, sd_inflow, sd_next;
-    std::vector<uint64_t> sd_hasop;
+    std::vector<int32_t> sd_first, sd_last, sd_inflow, sd_next, sd_lo;
     std::vector<CtkOp> sd_ops;
     std::vector<unsigned char> sd_cand;
     int64_t stats[CTK_NSTATS] = {0};
@@ -227,12 +228,13 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->g_label, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
                       &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
-                      &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w};
+                      &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
     if (h->h_cand) (void)hipHostFree(h->h_cand);
     if (h->h_ops) (void)hipHostFree(h->h_ops);
+    if (h->h_mail) (void)hipHostFree(h->h_mail);
     if (h->ev_ready) for (int k = 0; k <= CTK_K_COUNT; k++) { (void)hipEventDestroy(h->ev[k][0]); (void)hipEventDestroy(h->ev[k][1]); }
     for (int k = 0; k < 2; k++) { if (h->side[k]) (void)hipStreamDestroy(h->side[k]); if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -706,6 +708,32 @@ static int upload_ops(ctk_handle *h, const CtkOp *ops, int64_t nops, int64_t n_l
     return CTK_OK;
 }
 
+// Same for the device-resolver path: the seam driver already holds the chains (dense first[] / next[]).  The staging
+// block is read by the ingest kernel straight from pinned host memory (no copy command).
+static int upload_ops_dense(ctk_handle *h, const std::vector<CtkOp> &ops, const int32_t *orig, int64_t nd)
+{
+    hipStream_t s = h->stream;
+    const int64_t nops = (int64_t)ops.size();
+    h->nops = (int32_t)nops;
+    if (!nops) return CTK_OK;
+    const size_t bytes = (size_t)nops * (sizeof(CtkOp) + 4 + 8);
+    CTKCHK(ensure_host(&h->h_ops, &h->h_ops_cap, bytes));
+    CTKCHK(ensure(h, h->ops, bytes));
+    CtkOp *s_ops = (CtkOp *)h->h_ops;
+    int32_t *s_next = (int32_t *)(s_ops + nops), *s_label = s_next + nops, *s_first = s_label + nops;
+    memcpy(s_ops, ops.data(), (size_t)nops * sizeof(CtkOp));
+    memcpy(s_next, h->sd_next.data(), (size_t)nops * 4);
+    int32_t nf = 0;
+    for (int64_t d = 0; d < nd; d++)
+        if (h->sd_first[(size_t)d] >= 0) { s_label[nf] = orig[d]; s_first[nf] = h->sd_first[(size_t)d]; nf++; }
+    int32_t *d_next = (int32_t *)(P<CtkOp>(h->ops) + nops);
+    h->d_op_next = d_next;
+    const int64_t words = nops * 9;
+    k_ops_ingest<<<(int)std::min<int64_t>((words + 255) / 256, 1024), 256, 0, s>>>((const int32_t *)h->h_ops, nops, nf, P<int32_t>(h->ops), P<int32_t>(h->op_first));
+    HIPCHK(hipGetLastError());
+    return CTK_OK;
+}
+
 static int launch_extents(ctk_handle *h)
 {
     hipStream_t s = h->stream;
@@ -756,14 +784,18 @@ extern "C" int ctk_shard_extents(ctk_handle *h, const ctk_result *r, int shard, 
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-// contrack.py:753-763 on {t, y, label at x=0, label at x=nx-1} records in (t, y) order and the boxes of the
-// fresh labels.  Flat arrays: per label the chain of ops that have it as `hi`, in execution order.
-void seam_driver(ctk_handle *h, const CtkCand *cand, int64_t ncand, const int32_t *lbox, int64_t nlab, int nx, std::vector<CtkOp> &ops)
+// contrack.py:753-763 on {t, y, label at x=0, label at x=nx-1} records in (t, y) order.  Labels are DENSE ids of the
+// labels that occur in the records (orig[id] = fresh label, box[id] = its box): every table of the driver has a few
+// thousand entries and stays in the CPU's L1/L2, whatever the number of fresh labels.  Flat arrays: per label the
+// chain of ops that have it as `hi`, in execution order.  `ops` receives the ops with the fresh labels.
+void seam_driver(ctk_handle *h, const CtkCand *cand, int64_t ncand, const int32_t *orig, const int32_t *box, int64_t nd, int nx,
+                 std::vector<CtkOp> &ops)
 {
-    std::vector<int32_t> &first = h->sd_first, &last = h->sd_last, &next = h->sd_next;
-    first.assign((size_t)nlab + 1, -1);
-    last.assign((size_t)nlab + 1, -1);
+    std::vector<int32_t> &first = h->sd_first, &last = h->sd_last, &next = h->sd_next, &lo_d = h->sd_lo;
+    first.assign((size_t)nd + 1, -1);
+    last.assign((size_t)nd + 1, -1);
     next.clear();
+    lo_d.clear();                                             // dense id of ops[i].lo
     // fold of the ops over a seam pixel.  Consecutive seam rows of one blob ask the same question with y+1; the
     // answer is reused while it provably cannot change: same label / timestep / side, no op recorded since, and
     // y inside the interval over which every box test taken on the way gives the same outcome.
@@ -782,7 +814,7 @@ void seam_driver(ctk_handle *h, const CtkCand *cand, int64_t ncand, const int32_
                 if (!tx_in) continue;                                   // outside for every y
                 if (y >= o.y0 && y <= o.y1) {                           // inside: stays inside for y in [y0, y1]
                     ylo = std::max(ylo, o.y0); yhi = std::min(yhi, o.y1);
-                    l = o.lo; s = idx + 1; moved = true; break;
+                    l = lo_d[(size_t)idx]; s = idx + 1; moved = true; break;
                 }
                 if (y < o.y0) yhi = std::min(yhi, o.y0 - 1); else ylo = std::max(ylo, o.y1 + 1);   // outside because of y only
             }
@@ -797,19 +829,16 @@ void seam_driver(ctk_handle *h, const CtkCand *cand, int64_t ncand, const int32_
     // same relabel and finds nothing, contrack.py:759/763): it is not recorded.  This keeps the per-label
     // chains short where a stranded fragment sits on the seam for many rows.
     std::vector<int32_t> &inflow = h->sd_inflow;             // index of the last recorded op with lo == label
-    inflow.assign((size_t)nlab + 1, -1);
-    std::vector<uint64_t> &hasop = h->sd_hasop;              // bit per label: is `hi` of some op (4 KB: stays in L1)
-    hasop.assign(((size_t)nlab >> 6) + 1, 0);
+    inflow.assign((size_t)nd + 1, -1);
     const double t_loop = now_ms();
     int64_t nfold = 0;
-    auto touched = [&](int32_t l) { return (hasop[(size_t)l >> 6] >> (l & 63)) & 1ull; };
     for (int64_t k = 0; k < ncand; k++) {
         const CtkCand &c = cand[k];
         const int32_t y_last = (int32_t)((uint32_t)c.yy >> 16);
         // rows y0..y_last of timestep c.t carry the same pair of fresh labels; visit them in order, skipping the rows
         // for which the previous evaluation provably still holds
         for (int32_t y = c.yy & 0xffff; y <= y_last;) {
-            const bool tl = touched(c.ll), tr = touched(c.lr);
+            const bool tl = first[(size_t)c.ll] >= 0, tr = first[(size_t)c.lr] >= 0;    // is `hi` of some op
             if (c.ll == c.lr && !tl) break;                                // same label, never relabelled: nothing can differ
             int32_t same_until = y_last;
             const int32_t p0 = tl ? fold(0, c.ll, c.t, y, 0) : c.ll;
@@ -818,17 +847,18 @@ void seam_driver(ctk_handle *h, const CtkCand *cand, int64_t ncand, const int32_
             if (tl) same_until = std::min(same_until, memo[0].yhi);
             if (tr) same_until = std::min(same_until, memo[1].yhi);
             if (p0 == p1) { y = same_until + 1; continue; }                // nothing happens on these rows
-            const int32_t hi = std::max(p0, p1), lo = std::min(p0, p1);
+            const bool p0_hi = orig[p0] > orig[p1];                        // the larger FRESH label becomes the smaller (:759/763)
+            const int32_t hi = p0_hi ? p0 : p1, lo = p0_hi ? p1 : p0;
             if (last[(size_t)hi] >= 0 && inflow[(size_t)hi] < last[(size_t)hi]) { y = same_until + 1; continue; }   // nothing to move, and
                                                                            // nothing changes until an op is recorded
-            const int32_t *b = lbox + 6 * (int64_t)hi;
+            const int32_t *b = box + 6 * (int64_t)hi;
             const int32_t idx = (int32_t)ops.size();
-            ops.push_back(CtkOp{hi, lo, b[0], b[1], b[2], b[3], b[4], b[5]});
+            ops.push_back(CtkOp{orig[hi], orig[lo], b[0], b[1], b[2], b[3], b[4], b[5]});
+            lo_d.push_back(lo);
             next.push_back(-1);
             if (last[(size_t)hi] >= 0) next[(size_t)last[(size_t)hi]] = idx; else first[(size_t)hi] = idx;
             last[(size_t)hi] = idx;
             inflow[(size_t)lo] = idx;
-            hasop[(size_t)hi >> 6] |= 1ull << (hi & 63);
             y++;                                                           // the next row sees the new op
         }
     }
@@ -868,7 +898,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     CTKCHK(ensure(h, h->rv_keep0, R)); CTKCHK(ensure(h, h->rv_keep1, R));
     CTKCHK(ensure(h, h->rv_changed, (CTK_MAX_JACOBI + 8) * 4));
     CTKCHK(ensure(h, h->rv_parent, R * 4)); CTKCHK(ensure(h, h->rv_isroot, R * 4)); CTKCHK(ensure(h, h->rv_rank, (R + 1) * 4));
-    CTKCHK(ensure(h, h->rv_lab, R * 4)); CTKCHK(ensure(h, h->rv_lbox, (R + 1) * 24));
+    CTKCHK(ensure(h, h->rv_lab, R * 4));
     const int nsb = (int)((R + CTK_SCAN_ITEMS - 1) / CTK_SCAN_ITEMS);
     CTKCHK(ensure(h, h->rv_bsum, (size_t)nsb * 4)); CTKCHK(ensure(h, h->rv_boff, (size_t)(nsb + 1) * 4));
     CTKCHK(ensure(h, h->rv_cand_cnt, (size_t)T * 4)); CTKCHK(ensure(h, h->rv_cand_off, (size_t)(T + 1) * 4));
@@ -879,6 +909,8 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     CTKCHK(ensure(h, h->rv_tdirty, (size_t)2 * (T > 0 ? T : 1)));
     CTKCHK(ensure(h, h->rv_mark, R + 1));
     CTKCHK(ensure(h, h->rv_inv, R * 8)); CTKCHK(ensure(h, h->rv_ff, R * 8));
+    const size_t DC = std::min<size_t>(R + 1, (size_t)2 * std::max<int64_t>(in.seam_cap, 1));       // labels in candidate records
+    CTKCHK(ensure(h, h->rv_dmap, (R + 1) * 4)); CTKCHK(ensure(h, h->rv_dorig, DC * 4)); CTKCHK(ensure(h, h->rv_dbox, DC * 24));
 
     ResolveDev r;
     r.ncomp = in.ncomp; r.cprefix = in.cprefix; r.mrep = in.mrep; r.comp_t = in.comp_t;
@@ -887,11 +919,28 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     r.p_rc = P<uint32_t>(h->rv_prc); r.p_rd = P<uint32_t>(h->rv_prd); r.p_gc = P<uint32_t>(h->rv_pgc); r.p_gd = P<uint32_t>(h->rv_pgd);
     r.F = P<int64_t>(h->rv_F); r.B = P<int64_t>(h->rv_B); r.keep0 = P<uint8_t>(h->rv_keep0); r.keep1 = P<uint8_t>(h->rv_keep1);
     r.changed = P<uint32_t>(h->rv_changed); r.parent = P<uint32_t>(h->rv_parent); r.isroot = P<uint32_t>(h->rv_isroot);
-    r.rank = P<uint32_t>(h->rv_rank); r.lab = P<int32_t>(h->rv_lab); r.lbox = P<int32_t>(h->rv_lbox);
+    r.rank = P<uint32_t>(h->rv_rank); r.lab = P<int32_t>(h->rv_lab);
     r.mark = P<uint8_t>(h->rv_mark); r.inv = P<double>(h->rv_inv); r.ff = P<double>(h->rv_ff);
+    r.dmap = P<uint32_t>(h->rv_dmap); r.dorig = P<int32_t>(h->rv_dorig); r.dbox = P<int32_t>(h->rv_dbox); r.dcount = P<uint32_t>(h->rv_scalars);
 
     const int gc = (int)std::min<size_t>((R + 255) / 256, 2048), gp = (int)std::min<size_t>((PC + 255) / 256, 2048);
-    uint32_t *hs = (uint32_t *)h->h_small + (h->T + 2);
+    // mailbox in pinned host memory: the last resolver kernel writes scalars, candidate records and dense label tables
+    // there itself -- one stream synchronisation, no copy commands.  Capacities follow the previous calls; a call that
+    // needs more falls back to explicit copies and enlarges the mailbox for the next one.
+    if (h->mail_want_c > h->mail_cap_c || h->mail_want_d > h->mail_cap_d || !h->h_mail) {
+        h->mail_cap_c = std::max<size_t>(std::max<size_t>(h->mail_want_c, h->mail_cap_c), 4096);
+        h->mail_cap_d = std::max<size_t>(std::max<size_t>(h->mail_want_d, h->mail_cap_d), 8192);
+        size_t cap = 0;
+        if (h->h_mail) { (void)hipHostFree(h->h_mail); h->h_mail = nullptr; }
+        CTKCHK(ensure_host(&h->h_mail, &cap, CTK_MAIL_SCALARS * 4 + h->mail_cap_c * sizeof(CtkCand) + h->mail_cap_d * 28, true));
+    }
+    CandMail mail;
+    mail.scal = (uint32_t *)h->h_mail;
+    mail.cand = (CtkCand *)((char *)h->h_mail + CTK_MAIL_SCALARS * 4);
+    mail.dorig = (int32_t *)((char *)mail.cand + h->mail_cap_c * sizeof(CtkCand));
+    mail.dbox = mail.dorig + h->mail_cap_d;
+    mail.cap_c = (uint32_t)h->mail_cap_c; mail.cap_d = (uint32_t)h->mail_cap_d;
+    uint32_t hs[CTK_MAIL_SCALARS];
     const double t0 = now_ms();
     int it_done = 0;
     const int ROUND = h->filter_round;
@@ -914,65 +963,72 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         k_scan_blocksum<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_bsum));
         k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_bsum), nsb, P<uint32_t>(h->rv_boff), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
         k_scan_apply<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_boff), r.rank);
-        k_rs_labels<<<gc, 256, 0, s>>>(r, 0);
+        k_rs_labels<<<gc, 256, 0, s>>>(r);
         if (T > 0) {
             k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, h->ny, P<uint8_t>(h->rv_mark), P<int2>(h->rv_seam_res));
-            k_rs_cand_groups<<<(int)((T + 63) / 64), 64, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), P<uint8_t>(h->rv_mark),
-                                                                 h->ny, 0, P<uint32_t>(h->rv_cand_cnt), P<CtkCand>(h->rv_cand_scratch));
+            k_rs_cand_groups<<<(int)T, 64, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), P<uint8_t>(h->rv_mark),
+                                                   h->ny, 0, P<uint32_t>(h->rv_cand_cnt), P<CtkCand>(h->rv_cand_scratch));
         }
         k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_cand_cnt), T, P<uint32_t>(h->rv_cand_off), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
-        if (T > 0) {
-            k_compact_cands<<<(int)T, 64, 0, s>>>(P<CtkCand>(h->rv_cand_scratch), P<uint32_t>(h->rv_cand_cnt), P<uint32_t>(h->rv_cand_off), h->ny,
-                                                  P<CtkCand>(h->rv_cand));
-        }
+        k_compact_cands<<<(int)std::max<int64_t>(T, 1), 64, 0, s>>>(r, P<CtkCand>(h->rv_cand_scratch), P<uint32_t>(h->rv_cand_cnt), P<uint32_t>(h->rv_cand_off),
+                                                                    h->ny, P<CtkCand>(h->rv_cand), P<uint32_t>(h->rv_boff) + nsb, it_done - ROUND, ROUND, mail);
         HIPCHK(hipGetLastError());
-        // scalars: number of components / labels / candidates, convergence, overflow
-        HIPCHK(hipMemcpyAsync(hs, in.counters, CTK_CNT_N * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N, in.cprefix + T, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 1, P<uint32_t>(h->rv_cand_off) + T, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 3, P<uint32_t>(h->rv_boff) + nsb, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hs + CTK_CNT_N + 4, P<uint32_t>(h->rv_changed) + (it_done - ROUND), (size_t)ROUND * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        memcpy(hs, mail.scal, sizeof(hs));
         if ((hs[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) || (uint64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS] > in.pair_cap)
             return 1;                                                         // the host path regrows the pair table
         int conv = -1;
-        for (int k = 0; k < ROUND; k++) if (hs[CTK_CNT_N + 4 + k] == 0) { conv = it_done - ROUND + k; break; }
+        for (int k = 0; k < ROUND; k++) if (hs[CTK_MAIL_CHANGED + k] == 0) { conv = it_done - ROUND + k; break; }
         if (conv >= 0) { h->stats[CTK_S_FILTER_PASSES] = conv + 1; h->stats[CTK_S_FILTER_ROUNDS] = it_done / ROUND; break; }
         if (it_done + ROUND > CTK_MAX_JACOBI) return 1;                       // very long removal cascade: host resolver
     }
-    const int64_t NC = hs[CTK_CNT_N], ncand = hs[CTK_CNT_N + 1], nlab = hs[CTK_CNT_N + 3];
+    const int64_t NC = hs[CTK_MAIL_NC], ncand = hs[CTK_MAIL_NCAND], nlab = hs[CTK_MAIL_NLAB];
+    const size_t nd = hs[CTK_MAIL_ND];                                        // labels on surviving seam rows (dense ids)
     h->n_labels = nlab;
     CTKCHK(prepare_op_first(h, nlab));                                        // overlaps the host driver
     h->stats[CTK_S_COMPONENTS] = NC; h->stats[CTK_S_PAIRS] = (int64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS]; h->stats[CTK_S_SEAM_ROWS] = ncand; h->stats[CTK_S_LABELS] = nlab;
     h->stats[CTK_S_UPAIRS] = hs[CTK_CNT_UPAIRS];
+    h->mail_want_c = std::max<size_t>(h->mail_want_c, (size_t)ncand + (size_t)ncand / 2);
+    h->mail_want_d = std::max<size_t>(h->mail_want_d, nd + nd / 2);
     std::vector<CtkOp> &ops = h->sd_ops;
     ops.clear();
     if (ncand) {
-        const size_t need = (size_t)ncand * sizeof(CtkCand) + (size_t)(nlab + 1) * 24;
-        CTKCHK(ensure_host(&h->h_cand, &h->h_cand_cap, need, true));
-        CtkCand *hc = (CtkCand *)h->h_cand;
-        int32_t *hb = (int32_t *)((char *)h->h_cand + (size_t)ncand * sizeof(CtkCand));
-        HIPCHK(hipMemcpyAsync(hc, h->rv_cand.p, (size_t)ncand * sizeof(CtkCand), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hb, h->rv_lbox.p, (size_t)(nlab + 1) * 24, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        h->ms[CTK_T_D2H] += now_ms() - t0;
+        const size_t cb = (size_t)ncand * sizeof(CtkCand), need = cb + nd * 28;
+        h->sd_cand.resize(need);
+        char *dst = (char *)h->sd_cand.data();
+        if ((size_t)ncand <= h->mail_cap_c && nd <= h->mail_cap_d) {
+            h->ms[CTK_T_D2H] += now_ms() - t0;
+            // work on a pageable copy: CPU reads of pinned memory are uncached (fine-grained) or slow (coarse-grained) on
+            // this platform -- measured 173 / 111 us for the candidate loop vs 20 us + 20 us for copy + loop
+            const double tc = now_ms();
+            memcpy(dst, mail.cand, cb);
+            memcpy(dst + cb, mail.dorig, nd * 4);
+            memcpy(dst + cb + nd * 4, mail.dbox, nd * 24);
+            h->stats[11] = (int64_t)((now_ms() - tc) * 1e6);
+        } else {
+            // the mailbox was too small for this call: explicit copies from the device arrays
+            HIPCHK(hipMemcpyAsync(dst, h->rv_cand.p, cb, hipMemcpyDeviceToHost, s));
+            if (nd) {
+                HIPCHK(hipMemcpyAsync(dst + cb, h->rv_dorig.p, nd * 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipMemcpyAsync(dst + cb + nd * 4, h->rv_dbox.p, nd * 24, hipMemcpyDeviceToHost, s));
+            }
+            HIPCHK(hipStreamSynchronize(s));
+            h->ms[CTK_T_D2H] += now_ms() - t0;
+        }
         const double t1 = now_ms();
-        // work on a pageable copy: CPU reads of pinned memory are uncached (fine-grained) or slow (coarse-grained) on
-        // this platform -- measured 173 / 111 us for the candidate loop vs 20 us + 20 us for copy + loop
-        h->sd_cand.resize((size_t)ncand * sizeof(CtkCand) + (size_t)(nlab + 1) * 24);
-        memcpy(h->sd_cand.data(), h->h_cand, h->sd_cand.size());
-        h->stats[11] = (int64_t)((now_ms() - t1) * 1e6);
-        hc = (CtkCand *)h->sd_cand.data();
-        hb = (int32_t *)(h->sd_cand.data() + (size_t)ncand * sizeof(CtkCand));
-        seam_driver(h, hc, ncand, hb, nlab, h->nx, ops);
+        const CtkCand *hc = (const CtkCand *)dst;
+        const int32_t *ho = (const int32_t *)(dst + cb), *hb = ho + nd;
+        seam_driver(h, hc, ncand, ho, hb, (int64_t)nd, h->nx, ops);
         h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t1;
+        const double t2 = now_ms();
+        h->stats[CTK_S_OPS] = (int64_t)ops.size();
+        CTKCHK(upload_ops_dense(h, ops, ho, (int64_t)nd));
+        h->ms[CTK_T_H2D] += now_ms() - t2;
     } else {
         h->ms[CTK_T_D2H] += now_ms() - t0;
+        h->stats[CTK_S_OPS] = 0;
+        h->nops = 0;
     }
-    const double t2 = now_ms();
-    h->stats[CTK_S_OPS] = (int64_t)ops.size();
-    CTKCHK(upload_ops(h, ops.data(), (int64_t)ops.size(), nlab));
-    h->ms[CTK_T_H2D] += now_ms() - t2;
     {
         Timer tm(h, CTK_K_RESOLVE2);
         k_rs_final<<<gc, 256, 0, s>>>(r, fold_args(h), 0, in.comp_label);

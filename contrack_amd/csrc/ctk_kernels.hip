@@ -1029,6 +1029,18 @@ __global__ void k_fill_ext(int32_t *ext, int64_t n_labels)
     if (i <= n_labels) { ext[i] = INT32_MAX; ext[n_labels + 1 + i] = INT32_MIN; }
 }
 
+// op staging block [CtkOp ops[n]] [int32 next[n]] [int32 hi_label[n], nf used] [int32 first_op[n], nf used] in pinned host memory ->
+// device copy of ops + next (same layout) and first[label]
+__global__ void k_ops_ingest(const int32_t *__restrict__ staging, int64_t nops, int32_t nf, int32_t *__restrict__ dst, int32_t *__restrict__ op_first)
+{
+    const int64_t words = nops * 9;
+    const int32_t *lab = staging + words, *first = lab + nops;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words + nf; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < words) dst[i] = staging[i];
+        else op_first[lab[i - words]] = first[i - words];
+    }
+}
+
 __global__ void k_scatter_i32(const int32_t *__restrict__ where, const int32_t *__restrict__ what, int n, int32_t *__restrict__ dst)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

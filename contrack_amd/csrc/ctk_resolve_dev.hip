@@ -38,8 +38,13 @@ struct ResolveDev {
     uint32_t *parent;                     // [NC]
     uint32_t *isroot, *rank;              // [NC], [NC+1]
     int32_t *lab;                         // [NC] fresh 3-D label of every component (0 = filtered out)
-    int32_t *lbox;                        // [(NC+1)][6]
     uint8_t *mark;                        // [NC+1] label occurs in a seam row with two different labels
+    // labels that occur in candidate records get dense ids (claim order), so that the host seam driver works on
+    // tables of a few thousand entries instead of one slot per fresh label
+    uint32_t *dmap;                       // [NC+1] 0 = not a candidate label, else dense id + 1
+    int32_t *dorig;                       // [dense] fresh label of the dense id
+    int32_t *dbox;                        // [dense][6] its box
+    uint32_t *dcount;                     // number of dense ids
 };
 
 #define CTK_MAX_JACOBI 240          // hard cap of filter passes on the device (then: host resolver)
@@ -312,10 +317,10 @@ __global__ void k_rs_roots(ResolveDev r)
         const uint32_t root = gfind(r.parent, g);
         r.lab[g] = kept ? (int32_t)root : -1;               // temporarily: root index, -1 = filtered out
         r.isroot[g] = (kept && root == g) ? 1u : 0u;
-        // labels <= components: box slot and candidate mark g+1 are initialised here
-        int32_t *b = r.lbox + 6 * (int64_t)(g + 1);
-        b[0] = INT32_MAX; b[1] = -1; b[2] = INT32_MAX; b[3] = -1; b[4] = INT32_MAX; b[5] = -1;
+        // labels <= components: candidate mark / dense-id slot g+1 are initialised here
         r.mark[g + 1] = 0;
+        r.dmap[g + 1] = 0;
+        if (g == 0) *r.dcount = 0;
     }
 }
 
@@ -350,25 +355,28 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = boff[gridDim.x];     // grand total
 }
 
-// fresh labels: 1 + rank of the root among surviving roots (raster order), and their boxes (find_objects ONCE,
-// contrack.py:753): union of the members' boxes
-__global__ void k_rs_labels(ResolveDev r, int64_t t_begin)
+// fresh labels: 1 + rank of the root among surviving roots (raster order)
+__global__ void k_rs_labels(ResolveDev r)
 {
     const uint32_t nc = dev_ncomps(r);
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
         const int32_t root = r.lab[g];
-        const int32_t l = root < 0 ? 0 : (int32_t)r.rank[root] + 1;
-        r.lab[g] = l;
-        if (l <= 0) continue;
-        int32_t *b = r.lbox + 6 * (int64_t)l;
-        const uint16_t *q = r.box + 4 * (int64_t)g;
-        const int32_t t = (int32_t)(t_begin + r.comp_t[g]);
-        atomicMin(&b[0], t); atomicMax(&b[1], t);
-        atomicMin(&b[2], (int32_t)q[0]); atomicMax(&b[3], (int32_t)q[1]);
-        atomicMin(&b[4], (int32_t)q[2]); atomicMax(&b[5], (int32_t)q[3]);
+        r.lab[g] = root < 0 ? 0 : (int32_t)r.rank[root] + 1;
     }
 }
 
+struct CtkCand {
+    int32_t t, yy, ll, lr;
+};
+__device__ inline void cand_claim(const ResolveDev &r, int32_t l)
+{
+    if (r.dmap[l] != 0 || atomicCAS(&r.dmap[l], 0u, 0xffffffffu) != 0u) return;
+    const uint32_t id = atomicAdd(r.dcount, 1u);
+    r.dorig[id] = l;
+    int32_t *d = r.dbox + 6 * (int64_t)id;                // box of the label (find_objects ONCE, contrack.py:753): filled
+    d[0] = INT32_MAX; d[1] = -1; d[2] = INT32_MAX; d[3] = -1; d[4] = INT32_MAX; d[5] = -1;    // by k_rs_cand_groups
+    r.dmap[l] = id + 1;                                   // read by later launches
+}
 // Only labels that occur in some seam row with two DIFFERENT labels can ever take part in a relabel
 // operation (the first op needs such a row; every later `hi`/`lo` is a label of such a row or the `lo` of an
 // earlier op).  Rows with equal labels that are not marked can therefore be dropped before the host driver.
@@ -385,53 +393,125 @@ __global__ __launch_bounds__(256) void k_rs_cand_mark(ResolveDev r, const CtkSea
         if (r.keep0[cb + r.mrep[cb + q.cl]]) {
             v.x = r.lab[cb + q.cl]; v.y = r.lab[cb + q.cr];
             if (v.x != v.y) { mark[v.x] = 1; mark[v.y] = 1; }
+            // dense ids for every label on a surviving seam row (a superset of the labels in candidate records:
+            // claiming here, one thread per row, keeps the latency chain out of the one-thread-per-timestep walk)
+            cand_claim(r, v.x);
+            if (v.y != v.x) cand_claim(r, v.y);
         }
         res[(int64_t)t * ny + i] = v;
     }
 }
 
 // surviving seam rows of timestep t, run-length grouped: consecutive rows (y, y+1, ...) with the same pair of
-// labels become ONE record {t, y0 | y1 << 16, label at x=0, label at x=nx-1}; (t, y) order.  One thread per
-// timestep walks its (few) seam rows and writes its groups into a row-indexed scratch; a scan + gather makes
-// them dense.
-struct CtkCand {
-    int32_t t, yy, ll, lr;
-};
-__global__ __launch_bounds__(256) void k_rs_cand_groups(ResolveDev r, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
-                                                        const uint32_t *__restrict__ seam_off, const int2 *__restrict__ res,
-                                                        const uint8_t *__restrict__ mark, int ny, int64_t t_begin, uint32_t *__restrict__ cand_cnt,
-                                                        CtkCand *__restrict__ scratch /* [T][ny] */)
+// labels become ONE record {t, y0 | y1 << 16, label at x=0, label at x=nx-1}; (t, y) order.  One wave per
+// timestep: the rows are staged in LDS in parallel (their loads are the latency), lane 0 walks them and writes
+// the groups into a row-indexed scratch; a scan + gather makes them dense.  The same wave adds the boxes of
+// the timestep's components to the boxes of the labels that have a dense id (the only boxes anyone needs).
+#define CTK_CAND_CHUNK 512
+__global__ __launch_bounds__(64) void k_rs_cand_groups(ResolveDev r, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
+                                                       const uint32_t *__restrict__ seam_off, const int2 *__restrict__ res,
+                                                       const uint8_t *__restrict__ mark, int ny, int64_t t_begin, uint32_t *__restrict__ cand_cnt,
+                                                       CtkCand *__restrict__ scratch /* [T][ny] */)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= r.T) return;
+    const int64_t t = blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    const uint32_t cb = r.cprefix[t], nct = r.cprefix[t + 1] - cb;
+    for (uint32_t c = lane; c < nct; c += 64) {
+        const uint32_t g = cb + c;
+        const int32_t l = r.lab[g];
+        if (l <= 0) continue;
+        const uint32_t d = r.dmap[l];
+        if (d == 0) continue;
+        int32_t *b = r.dbox + 6 * (int64_t)(d - 1);
+        const uint16_t *q = r.box + 4 * (int64_t)g;
+        const int32_t tt = (int32_t)(t_begin + t);
+        atomicMin(&b[0], tt); atomicMax(&b[1], tt);
+        atomicMin(&b[2], (int32_t)q[0]); atomicMax(&b[3], (int32_t)q[1]);
+        atomicMin(&b[4], (int32_t)q[2]); atomicMax(&b[5], (int32_t)q[3]);
+    }
     const uint32_t n = seam_cnt[t];
     const CtkSeam *sc = seams + seam_off[t];
     const int2 *rs = res + t * ny;
     CtkCand *dst = scratch + t * ny;                      // at most one group per seam row
+    __shared__ int2 sv[CTK_CAND_CHUNK];
+    __shared__ int32_t sy[CTK_CAND_CHUNK];
     uint32_t ng = 0;
     CtkCand g;
     g.t = (int32_t)(t_begin + t); g.yy = 0; g.ll = 0; g.lr = 0;
     int32_t gy0 = 0, gy1 = -2;
     bool open = false;
-    for (uint32_t i = 0; i < n; i++) {
-        const int2 v = rs[i];
-        if (v.x < 0 || (v.x == v.y && !mark[v.x])) continue;          // filtered out, or can never take part in an op
-        const int32_t y = (int32_t)sc[i].y;
-        if (open && v.x == g.ll && v.y == g.lr && y == gy1 + 1) { gy1 = y; continue; }
-        if (open) { g.yy = gy0 | (gy1 << 16); dst[ng++] = g; }
-        open = true; g.ll = v.x; g.lr = v.y; gy0 = y; gy1 = y;
+    for (uint32_t base = 0; base < n; base += CTK_CAND_CHUNK) {
+        const uint32_t m = min((uint32_t)CTK_CAND_CHUNK, n - base);
+        for (uint32_t i = lane; i < m; i += 64) {
+            int2 v = rs[base + i];
+            if (v.x < 0 || (v.x == v.y && !mark[v.x])) v.x = -1;      // filtered out, or can never take part in an op
+            sv[i] = v;
+            sy[i] = (int32_t)sc[base + i].y;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            for (uint32_t i = 0; i < m; i++) {
+                const int2 v = sv[i];
+                if (v.x < 0) continue;
+                const int32_t y = sy[i];
+                if (open && v.x == g.ll && v.y == g.lr && y == gy1 + 1) { gy1 = y; continue; }
+                if (open) { g.yy = gy0 | (gy1 << 16); dst[ng++] = g; }
+                open = true; g.ll = v.x; g.lr = v.y; gy0 = y; gy1 = y;
+            }
+        }
+        __syncthreads();
     }
-    if (open) { g.yy = gy0 | (gy1 << 16); dst[ng++] = g; }
-    cand_cnt[t] = ng;
+    if (lane == 0) {
+        if (open) { g.yy = gy0 | (gy1 << 16); dst[ng++] = g; }
+        cand_cnt[t] = ng;
+    }
 }
 
-// dense (t, y)-ordered group records from the row-indexed scratch
-__global__ __launch_bounds__(256) void k_compact_cands(const CtkCand *__restrict__ scratch, const uint32_t *__restrict__ cand_cnt,
-                                                       const uint32_t *__restrict__ cand_off, int ny, CtkCand *__restrict__ out)
+// What the host needs after the resolver kernels, written by the device straight into pinned host memory (no copy
+// commands, one stream synchronisation): scalars, the candidate records, the dense label tables.
+struct CandMail {
+    uint32_t *scal;                 // [CTK_MAIL_SCALARS]
+    CtkCand *cand;                  // [cap_c]
+    int32_t *dorig, *dbox;          // [cap_d], [cap_d][6]
+    uint32_t cap_c, cap_d;
+};
+#define CTK_MAIL_SCALARS 64
+#define CTK_MAIL_NC 8
+#define CTK_MAIL_NCAND 9
+#define CTK_MAIL_ND 10
+#define CTK_MAIL_NLAB 11
+#define CTK_MAIL_CHANGED 12         // .. + passes of the round (<= 32)
+
+// dense (t, y)-ordered group records from the row-indexed scratch, labels replaced by their dense ids; mailbox
+__global__ __launch_bounds__(64) void k_compact_cands(ResolveDev r, const CtkCand *__restrict__ scratch, const uint32_t *__restrict__ cand_cnt,
+                                                      const uint32_t *__restrict__ cand_off, int ny, CtkCand *__restrict__ out,
+                                                      const uint32_t *__restrict__ nlab_ptr, int it0, int round, CandMail m)
 {
-    const int t = (int)blockIdx.x;
-    const uint32_t n = cand_cnt[t], o = cand_off[t];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out[o + i] = scratch[(int64_t)t * ny + i];
+    const int64_t t = blockIdx.x;
+    if (t < r.T) {
+        const uint32_t n = cand_cnt[t], o = cand_off[t];
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            CtkCand c = scratch[t * ny + i];
+            c.ll = (int32_t)r.dmap[c.ll] - 1;
+            c.lr = (int32_t)r.dmap[c.lr] - 1;
+            out[o + i] = c;
+            if (o + i < m.cap_c) m.cand[o + i] = c;
+        }
+    }
+    const uint32_t nd = min(*r.dcount, m.cap_d);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += gridDim.x * blockDim.x) {
+        m.dorig[i] = r.dorig[i];
+#pragma unroll
+        for (int k = 0; k < 6; k++) m.dbox[6 * (int64_t)i + k] = r.dbox[6 * (int64_t)i + k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < CTK_CNT_N) m.scal[threadIdx.x] = r.counters[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        m.scal[CTK_MAIL_NC] = r.cprefix[r.T];
+        m.scal[CTK_MAIL_NCAND] = r.T > 0 ? cand_off[r.T] : 0u;
+        m.scal[CTK_MAIL_ND] = *r.dcount;
+        m.scal[CTK_MAIL_NLAB] = *nlab_ptr;
+        for (int k = 0; k < round; k++) m.scal[CTK_MAIL_CHANGED + k] = r.changed[it0 + k];
+    }
 }
 
 // R5: final id of every component.  All of a component's pixels move together through an op whose box

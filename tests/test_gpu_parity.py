@@ -114,6 +114,29 @@ def test_host_and_device_resolver_agree(trk, name):
     assert np.array_equal(f_host, g["flag"]) and np.array_equal(f_dev, g["flag"]) and n_host == n_dev
 
 
+@pytest.mark.parametrize("seed,T", [(3, 1500), (11, 2707)])
+def test_host_and_device_resolver_agree_on_long_slabs(seed, T):
+    """thousands of seam operations, labels that are `hi` of several of them (op chains), candidate tables beyond
+    the first mailbox size: device resolver (fresh handle and warmed-up handle) against the host resolver"""
+    from contrack_amd import synth
+    from contrack_amd.contrack import row_weights
+    ny, nx = 91, 180
+    anom = synth.smooth_field(T, ny, nx, seed=seed)
+    lat, _ = synth.grid(ny, nx)
+    wrow = row_weights(lat, np.float32(2.0), np.float32(2.0))
+    args = (anom, np.full(T, 120.0), 0, wrow, 0.5, 3, True)
+    with _native.Tracker(0) as t:
+        t.set_device_resolve(False)
+        f_host, n_host = t.track(*args)
+    with _native.Tracker(0) as t:
+        f_dev, n_dev = t.track(*args)
+        st = t.stats()
+        f_dev2, n_dev2 = t.track(*args)
+    assert st["host_path"] == 0 and st["seam_ops"] > 300
+    assert n_host == n_dev == n_dev2
+    assert np.array_equal(f_host, f_dev) and np.array_equal(f_host, f_dev2)
+
+
 def test_rare_paths_are_exercised(oracle_lib):
     """white noise at 181x360 drives every capacity path at once: the global-memory labelling variant (> 4096 runs
     per step), co-occurrence records that bypass the LDS hash table, and a pair table that has to be regrown (host
