@@ -72,6 +72,11 @@ struct ctk_handle {
     size_t h_cand_cap = 0;
     void *h_ops = nullptr;           // pinned: op upload staging
     void *h_mail = nullptr;          // pinned: device-written mailbox of the resolver (scalars, candidates, dense tables)
+    uint32_t *h_mail1 = nullptr;     // pinned, device-written: [0..3] run scan of stage 1, [8..9] alive ids / background written
+    void *h_stage = nullptr;         // pinned: thresholds + weight limbs on their way to the device
+    size_t h_stage_cap = 0;
+    uint32_t rb_last = 0, rb_total = 0;   // run_base[T-1], run_base[T]
+    int64_t last_alive = 0;
     size_t mail_cap_c = 0, mail_cap_d = 0, mail_want_c = 0, mail_want_d = 0;
     size_t h_ops_cap = 0;
     const int32_t *d_op_next = nullptr;
@@ -209,6 +214,8 @@ extern "C" int ctk_create(ctk_handle **out, int device)
             hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming) != hipSuccess) { ctk_destroy(h); return ctk_set_error(CTK_E_NODEVICE, "hipStreamCreate failed"); }
     }
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) { ctk_destroy(h); return ctk_set_error(CTK_E_NODEVICE, "hipEventCreate failed"); }
+    if (hipHostMalloc((void **)&h->h_mail1, 256, hipHostMallocDefault) != hipSuccess) { ctk_destroy(h); return ctk_set_error(CTK_E_NOMEM, "hipHostMalloc failed"); }
+    memset(h->h_mail1, 0, 256);
     memset(h->ms, 0, sizeof(h->ms));
     memset(h->ev_used, 0, sizeof(h->ev_used));
     *out = h;
@@ -235,6 +242,8 @@ extern "C" void ctk_destroy(ctk_handle *h)
     if (h->h_cand) (void)hipHostFree(h->h_cand);
     if (h->h_ops) (void)hipHostFree(h->h_ops);
     if (h->h_mail) (void)hipHostFree(h->h_mail);
+    if (h->h_mail1) (void)hipHostFree(h->h_mail1);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->ev_ready) for (int k = 0; k <= CTK_K_COUNT; k++) { (void)hipEventDestroy(h->ev[k][0]); (void)hipEventDestroy(h->ev[k][1]); }
     for (int k = 0; k < 2; k++) { if (h->side[k]) (void)hipStreamDestroy(h->side[k]); if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -329,12 +338,15 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     const int64_t nrows = T * ny;
     hipStream_t s = h->stream;
 
-    // host-side preparation: thresholds for the float32 compare, exact integer limbs of the row weights
-    std::vector<double> thr32((size_t)std::max<int64_t>(T, 1));     // float32 thresholds in the first half when !f64
-    if (f64) for (int64_t t = 0; t < T; t++) thr32[(size_t)t] = thr[t];
-    else for (int64_t t = 0; t < T; t++) ((float *)thr32.data())[t] = adjust_threshold(thr[t], cmp_op);
-    std::vector<int32_t> wlo((size_t)ny), whi((size_t)ny);
-    CTKCHK(ctk_weights_to_limbs(wrow, ny, wlo.data(), whi.data(), &h->wshift));
+    // host-side preparation: thresholds for the float32 compare, exact integer limbs of the row weights -- staged in
+    // pinned memory, so that the uploads are asynchronous and nothing has to be waited for before the first kernel
+    const size_t thr_bytes = (size_t)std::max<int64_t>(T, 1) * 8;
+    CTKCHK(ensure_host(&h->h_stage, &h->h_stage_cap, thr_bytes + (size_t)ny * 8));
+    double *thr32 = (double *)h->h_stage;                             // float32 thresholds in the first half when !f64
+    if (f64) for (int64_t t = 0; t < T; t++) thr32[t] = thr[t];
+    else for (int64_t t = 0; t < T; t++) ((float *)thr32)[t] = adjust_threshold(thr[t], cmp_op);
+    int32_t *wlo = (int32_t *)((char *)h->h_stage + thr_bytes), *whi = wlo + ny;
+    CTKCHK(ctk_weights_to_limbs(wrow, ny, wlo, whi, &h->wshift));
 
     CTKCHK(ensure(h, h->mask, (size_t)nrows * W * 8));
     CTKCHK(ensure(h, h->wstart, (size_t)nrows * W * 2));
@@ -344,19 +356,16 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     CTKCHK(ensure(h, h->ncomp, (size_t)T * 4));
     CTKCHK(ensure(h, h->cprefix, (size_t)(T + 1) * 4));
     CTKCHK(ensure(h, h->thr32, (size_t)T * 8));
-    CTKCHK(ensure(h, h->wlo, (size_t)ny * 4));
-    CTKCHK(ensure(h, h->whi, (size_t)ny * 4));
+    CTKCHK(ensure(h, h->wlo, (size_t)ny * 8));                        // wlo[ny] whi[ny] in one allocation
     CTKCHK(ensure(h, h->counters, CTK_CNT_N * 4));
     CTKCHK(ensure_host(&h->h_small, &h->h_small_cap, (size_t)(T + 1) * 4 + 1024));     // run_base copy + scalar downloads
 
     HIPCHK(hipMemsetAsync(h->counters.p, 0, CTK_CNT_N * 4, s));
     if (T > 0) {
         HIPCHK(hipMemsetAsync(h->tcount.p, 0, (size_t)T * 4, s));
-        HIPCHK(hipMemcpyAsync(h->thr32.p, thr32.data(), (size_t)T * (f64 ? 8 : 4), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->thr32.p, thr32, (size_t)T * (f64 ? 8 : 4), hipMemcpyHostToDevice, s));
     }
-    HIPCHK(hipMemcpyAsync(h->wlo.p, wlo.data(), (size_t)ny * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->whi.p, whi.data(), (size_t)ny * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));        // the staging vectors above are stack/heap temporaries
+    HIPCHK(hipMemcpyAsync(h->wlo.p, wlo, (size_t)ny * 8, hipMemcpyHostToDevice, s));       // wlo and whi are adjacent on both sides
 
     if (T > 0) {
         Timer tm(h, CTK_K_THRESHOLD);
@@ -382,18 +391,17 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     {
         Timer tm(h, CTK_K_SCAN);
         if (T > 0) k_rowcount<<<(int)T, 256, 0, s>>>(P<uint64_t>(h->mask), ny, W, P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart), P<uint32_t>(h->tcount));
-        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, h->h_mail1);
         HIPCHK(hipGetLastError());
     }
-    // runs per timestep decide the workspace size and whether the global-memory variant is needed
-    uint32_t *hb = (uint32_t *)h->h_small;
-    HIPCHK(hipMemcpyAsync(hb, h->run_base.p, (size_t)(T + 1) * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hb + T + 1, P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, 4, hipMemcpyDeviceToHost, s));
+    // runs per timestep decide the workspace size and whether the global-memory variant is needed: the scan kernel
+    // wrote total / maximum / overflow / last count into the pinned mailbox
     HIPCHK(hipStreamSynchronize(s));
-    if (hb[T + 1] & CTK_OVF_RUNS) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: more than 2^32-1 runs in one shard");
-    h->total_runs = hb[T];
-    h->max_runs_step = 0;
-    for (int64_t t = 0; t < T; t++) h->max_runs_step = std::max(h->max_runs_step, hb[t + 1] - hb[t]);
+    const uint32_t m_total = h->h_mail1[0], m_max = h->h_mail1[1], m_ovf = h->h_mail1[2], m_last = h->h_mail1[3];
+    if (m_ovf & CTK_OVF_RUNS) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: more than 2^32-1 runs in one shard");
+    h->total_runs = m_total;
+    h->max_runs_step = m_max;
+    h->rb_total = m_total; h->rb_last = m_total - m_last;
     h->need_glb = (h->max_runs_step > CTK_LDS_RUNS) || (ny > CTK_LDS_NY);
     memset(h->stats, 0, sizeof(h->stats));
     h->stats[CTK_S_RUNS] = h->total_runs; h->stats[CTK_S_MAX_RUNS_STEP] = h->max_runs_step;
@@ -423,7 +431,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         a.run_base = P<uint32_t>(h->run_base); a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp);
         a.cs_mrep = P<uint32_t>(h->cs_mrep); a.cs_box = P<uint32_t>(h->cs_box); a.cs_area = P<int64_t>(h->cs_area);
         a.seams = P<CtkSeam>(h->seams); a.seam_cnt = P<uint32_t>(h->seam_cnt); a.counters = P<uint32_t>(h->counters);
-        a.wlo = P<int32_t>(h->wlo); a.whi = P<int32_t>(h->whi);
+        a.wlo = P<int32_t>(h->wlo); a.whi = P<int32_t>(h->wlo) + h->ny;
         a.ny = ny; a.nx = nx; a.W = W; a.lds_cap = CTK_LDS_RUNS;
         a.g_x0 = P<uint16_t>(h->g_x0); a.g_x1 = P<uint16_t>(h->g_x1); a.g_y = P<uint16_t>(h->g_y);
         a.g_parent = P<uint32_t>(h->g_parent); a.g_root = P<uint32_t>(h->g_root); a.g_idmap = P<uint32_t>(h->g_idmap);
@@ -504,12 +512,11 @@ extern "C" int ctk_shard_halo_export(ctk_handle *h, void **blob_dev, size_t *nby
     hipStream_t s = h->stream;
     if (h->T > 0) {
         const int64_t t = h->T - 1;
-        const uint32_t *hb = (const uint32_t *)h->h_small;                    // run_base, downloaded in stage 1
-        const uint32_t n = hb[t + 1] - hb[t];
+        const uint32_t hb_t = h->rb_last, n = h->rb_total - h->rb_last;       // run_base[T-1], runs of the last timestep
         HIPCHK(hipMemcpyAsync(dst, P<uint64_t>(h->mask) + t * h->ny * h->W, (size_t)h->ny * h->W * 8, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(dst + halo_off_wstart(h), P<uint16_t>(h->wstart) + t * h->ny * h->W, (size_t)h->ny * h->W * 2, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(dst + halo_off_rowstart(h), P<uint32_t>(h->rowstart) + t * h->ny, (size_t)h->ny * 4, hipMemcpyDeviceToDevice, s));
-        if (n) HIPCHK(hipMemcpyAsync(dst + halo_off_runcomp(h), P<uint32_t>(h->run_comp) + hb[t], (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        if (n) HIPCHK(hipMemcpyAsync(dst + halo_off_runcomp(h), P<uint32_t>(h->run_comp) + hb_t, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
         *nbytes = halo_off_runcomp(h) + (size_t)n * 4;
     } else {
         HIPCHK(hipMemsetAsync(dst, 0, halo_off_runcomp(h), s));
@@ -548,7 +555,7 @@ static int launch_overlap(ctk_handle *h)
     a.has_prev = (h->has_prev && hl) ? 1 : 0;
     a.pairs = P<CtkPair>(h->pairs); a.pair_cap = h->pair_cap; a.counters = P<uint32_t>(h->counters);
     a.pair_base = P<uint32_t>(h->pair_base); a.pair_cnt = P<uint32_t>(h->pair_cnt);
-    a.wlo = P<int32_t>(h->wlo); a.whi = P<int32_t>(h->whi);
+    a.wlo = P<int32_t>(h->wlo); a.whi = P<int32_t>(h->wlo) + h->ny;
     a.ny = h->ny; a.nx = h->nx; a.W = h->W;
     Timer tm(h, CTK_K_OVERLAP);
     k_overlap<<<(int)h->T, 256, 0, h->stream>>>(a);
@@ -715,33 +722,37 @@ static int upload_ops_dense(ctk_handle *h, const std::vector<CtkOp> &ops, const 
     hipStream_t s = h->stream;
     const int64_t nops = (int64_t)ops.size();
     h->nops = (int32_t)nops;
-    if (!nops) return CTK_OK;
-    const size_t bytes = (size_t)nops * (sizeof(CtkOp) + 4 + 8);
+    const size_t bytes = (size_t)std::max<int64_t>(nops, 1) * (sizeof(CtkOp) + 4 + 8);
     CTKCHK(ensure_host(&h->h_ops, &h->h_ops_cap, bytes));
     CTKCHK(ensure(h, h->ops, bytes));
     CtkOp *s_ops = (CtkOp *)h->h_ops;
     int32_t *s_next = (int32_t *)(s_ops + nops), *s_label = s_next + nops, *s_first = s_label + nops;
-    memcpy(s_ops, ops.data(), (size_t)nops * sizeof(CtkOp));
-    memcpy(s_next, h->sd_next.data(), (size_t)nops * 4);
     int32_t nf = 0;
-    for (int64_t d = 0; d < nd; d++)
-        if (h->sd_first[(size_t)d] >= 0) { s_label[nf] = orig[d]; s_first[nf] = h->sd_first[(size_t)d]; nf++; }
+    if (nops) {
+        memcpy(s_ops, ops.data(), (size_t)nops * sizeof(CtkOp));
+        memcpy(s_next, h->sd_next.data(), (size_t)nops * 4);
+        for (int64_t d = 0; d < nd; d++)
+            if (h->sd_first[(size_t)d] >= 0) { s_label[nf] = orig[d]; s_first[nf] = h->sd_first[(size_t)d]; nf++; }
+    }
     int32_t *d_next = (int32_t *)(P<CtkOp>(h->ops) + nops);
     h->d_op_next = d_next;
-    const int64_t words = nops * 9;
-    k_ops_ingest<<<(int)std::min<int64_t>((words + 255) / 256, 1024), 256, 0, s>>>((const int32_t *)h->h_ops, nops, nf, P<int32_t>(h->ops), P<int32_t>(h->op_first));
+    const int64_t work = std::max<int64_t>(nops * 9, h->n_labels + 1);
+    k_ops_ingest<<<(int)std::min<int64_t>((work + 255) / 256, 1024), 256, 0, s>>>((const int32_t *)h->h_ops, nops, nf, P<int32_t>(h->ops), P<int32_t>(h->op_first),
+                                                                                  P<int32_t>(h->ext), h->n_labels, P<uint32_t>(h->counters));
     HIPCHK(hipGetLastError());
     return CTK_OK;
 }
 
-static int launch_extents(ctk_handle *h)
+static int launch_extents(ctk_handle *h, bool ext_filled = false)
 {
     hipStream_t s = h->stream;
     CTKCHK(ensure(h, h->ext, (size_t)(h->n_labels + 1) * 8));
     Timer tm(h, CTK_K_EXTENT);
     const int64_t n1 = h->n_labels + 1;
-    k_fill_ext<<<(int)((n1 + 255) / 256), 256, 0, s>>>(P<int32_t>(h->ext), h->n_labels);
-    HIPCHK(hipGetLastError());
+    if (!ext_filled) {                                            // (the device-resolver path did it in k_ops_ingest)
+        k_fill_ext<<<(int)std::min<int64_t>((n1 + 255) / 256, 4096), 256, 0, s>>>(P<int32_t>(h->ext), h->n_labels, P<uint32_t>(h->counters));
+        HIPCHK(hipGetLastError());
+    }
     if (h->T > 0) {
         ExtentArgs a;
         a.mask = P<uint64_t>(h->mask); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
@@ -911,6 +922,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     CTKCHK(ensure(h, h->rv_inv, R * 8)); CTKCHK(ensure(h, h->rv_ff, R * 8));
     const size_t DC = std::min<size_t>(R + 1, (size_t)2 * std::max<int64_t>(in.seam_cap, 1));       // labels in candidate records
     CTKCHK(ensure(h, h->rv_dmap, (R + 1) * 4)); CTKCHK(ensure(h, h->rv_dorig, DC * 4)); CTKCHK(ensure(h, h->rv_dbox, DC * 24));
+    CTKCHK(ensure(h, h->op_first, (R + 1) * 4));
 
     ResolveDev r;
     r.ncomp = in.ncomp; r.cprefix = in.cprefix; r.mrep = in.mrep; r.comp_t = in.comp_t;
@@ -921,7 +933,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     r.changed = P<uint32_t>(h->rv_changed); r.parent = P<uint32_t>(h->rv_parent); r.isroot = P<uint32_t>(h->rv_isroot);
     r.rank = P<uint32_t>(h->rv_rank); r.lab = P<int32_t>(h->rv_lab);
     r.mark = P<uint8_t>(h->rv_mark); r.inv = P<double>(h->rv_inv); r.ff = P<double>(h->rv_ff);
-    r.dmap = P<uint32_t>(h->rv_dmap); r.dorig = P<int32_t>(h->rv_dorig); r.dbox = P<int32_t>(h->rv_dbox); r.dcount = P<uint32_t>(h->rv_scalars);
+    r.dmap = P<uint32_t>(h->rv_dmap); r.dorig = P<int32_t>(h->rv_dorig); r.dbox = P<int32_t>(h->rv_dbox); r.dcount = P<uint32_t>(h->rv_scalars); r.op_first = P<int32_t>(h->op_first);
 
     const int gc = (int)std::min<size_t>((R + 255) / 256, 2048), gp = (int)std::min<size_t>((PC + 255) / 256, 2048);
     // mailbox in pinned host memory: the last resolver kernel writes scalars, candidate records and dense label tables
@@ -985,7 +997,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     const int64_t NC = hs[CTK_MAIL_NC], ncand = hs[CTK_MAIL_NCAND], nlab = hs[CTK_MAIL_NLAB];
     const size_t nd = hs[CTK_MAIL_ND];                                        // labels on surviving seam rows (dense ids)
     h->n_labels = nlab;
-    CTKCHK(prepare_op_first(h, nlab));                                        // overlaps the host driver
+    CTKCHK(ensure(h, h->ext, (size_t)(nlab + 1) * 8));
     h->stats[CTK_S_COMPONENTS] = NC; h->stats[CTK_S_PAIRS] = (int64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS]; h->stats[CTK_S_SEAM_ROWS] = ncand; h->stats[CTK_S_LABELS] = nlab;
     h->stats[CTK_S_UPAIRS] = hs[CTK_CNT_UPAIRS];
     h->mail_want_c = std::max<size_t>(h->mail_want_c, (size_t)ncand + (size_t)ncand / 2);
@@ -1027,7 +1039,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     } else {
         h->ms[CTK_T_D2H] += now_ms() - t0;
         h->stats[CTK_S_OPS] = 0;
-        h->nops = 0;
+        CTKCHK(upload_ops_dense(h, ops, nullptr, 0));                         // no ops: the launch still prepares ext / counters
     }
     {
         Timer tm(h, CTK_K_RESOLVE2);
@@ -1154,7 +1166,7 @@ extern "C" int ctk_shard_resolve_dev(ctk_handle *h, const void *const *blobs_dev
     if (my_nc) HIPCHK(hipMemcpyAsync(h->comp_label.p, P<int32_t>(h->g_label) + my_c_off, (size_t)my_nc * 4, hipMemcpyDeviceToDevice, s));
     h->total_comps = (uint32_t)my_nc;
     h->t_begin = t_begin;
-    CTKCHK(launch_extents(h));
+    CTKCHK(launch_extents(h, true));
     if (ext_dev) *ext_dev = P<int32_t>(h->ext);
     if (n_labels) *n_labels = h->n_labels;
     h->state = ST_EXTENTS;
@@ -1193,8 +1205,6 @@ extern "C" int ctk_shard_write(ctk_handle *h, int persistence, int32_t *flag_dev
     if (h->state != ST_EXTENTS) return ctk_set_error(CTK_E_STATE, "ctk_shard_write needs ctk_shard_extents first");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    uint32_t zero2[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(P<uint32_t>(h->counters) + CTK_CNT_WROTE_ZERO, zero2, 8, hipMemcpyHostToDevice, s));
     if (h->T > 0) {
         {
             Timer tm(h, CTK_K_RUNLABEL);
@@ -1209,14 +1219,15 @@ extern "C" int ctk_shard_write(ctk_handle *h, int persistence, int32_t *flag_dev
     }
     {
         Timer tm(h, CTK_K_COUNT);
-        k_count_alive<<<(int)((h->n_labels + 255) / 256 + 1), 256, 0, s>>>(P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->counters));
+        // (the counters were zeroed by k_fill_ext / k_ops_ingest; the last workgroup writes the results to pinned memory)
+        k_count_alive<<<(int)((h->n_labels + 255) / 256 + 1), 256, 0, s>>>(P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->counters),
+                                                                           h->h_mail1 + 8);
         HIPCHK(hipGetLastError());
     }
-    uint32_t *hc = (uint32_t *)h->h_small + (h->T + 2);
-    HIPCHK(hipMemcpyAsync(hc, h->counters.p, CTK_CNT_N * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (n_alive_local) *n_alive_local = hc[CTK_CNT_ALIVE];
-    if (wrote_background) *wrote_background = hc[CTK_CNT_WROTE_ZERO] ? 1 : 0;
+    h->last_alive = h->h_mail1[8];
+    if (n_alive_local) *n_alive_local = h->last_alive;
+    if (wrote_background) *wrote_background = h->h_mail1[9] ? 1 : 0;
     collect_event_times(h);
     h->state = ST_TABLES;           // extents may be recomputed (e.g. another persistence) from the same tables
     return CTK_OK;
@@ -1225,8 +1236,7 @@ extern "C" int ctk_shard_write(ctk_handle *h, int persistence, int32_t *flag_dev
 extern "C" int ctk_shard_count_tracked(ctk_handle *h, int64_t *n_alive)
 {
     if (!h || !n_alive) return ctk_set_error(CTK_E_INVALID, "null argument");
-    const uint32_t *hc = (const uint32_t *)h->h_small + (h->T + 2);
-    *n_alive = hc[CTK_CNT_ALIVE];
+    *n_alive = h->last_alive;
     return CTK_OK;
 }
 
@@ -1243,7 +1253,7 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
     int rv = h->use_device_resolve ? device_resolve_local(h, overlap, twosided) : 1;
     if (rv < 0) return rv;
     if (rv == 0) {
-        CTKCHK(launch_extents(h));
+        CTKCHK(launch_extents(h, true));
         h->state = ST_EXTENTS;
     } else {
         // host path: download the tables, resolve with the GPU-free reference implementation, upload

@@ -9,6 +9,7 @@
 #define CTK_CNT_WROTE_ZERO 3
 #define CTK_CNT_ALIVE      4
 #define CTK_CNT_UPAIRS     5   /* co-occurrence records that bypassed the LDS hash table */
+#define CTK_CNT_TICKET     6   /* workgroups of k_count_alive that have finished */
 #define CTK_CNT_N          8
 
 // overflow bits

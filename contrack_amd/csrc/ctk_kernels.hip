@@ -268,16 +268,22 @@ __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v)
 }
 
 __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ in, int64_t n,
-                                                   uint32_t *__restrict__ out, uint32_t *ovf)
+                                                   uint32_t *__restrict__ out, uint32_t *ovf, uint32_t *mail = nullptr)
 {
     __shared__ uint64_t wsum[16];
+    __shared__ uint32_t wmax[16];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const int64_t per = (n + 1023) / 1024;
     const int64_t b = min(n, (int64_t)tid * per), e = min(n, b + per);
     uint64_t s = 0;
-    for (int64_t i = b; i < e; i++) s += in[i];
+    uint32_t mx = 0;
+    for (int64_t i = b; i < e; i++) { const uint32_t v = in[i]; s += v; mx = max(mx, v); }
     uint64_t inc = wave_incl_scan_u64(s);
     if (lane == WAVE - 1) wsum[wv] = inc;
+    if (mail) {
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+        if (lane == 0) wmax[wv] = mx;
+    }
     __syncthreads();
     uint64_t base = 0;
     for (int i = 0; i < wv; i++) base += wsum[i];
@@ -286,6 +292,13 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ 
     if (tid == 1023) {
         out[n] = (uint32_t)run;
         if (run > 0xffffffffull) atomicOr(ovf, CTK_OVF_RUNS);
+        if (mail) {
+            // the host's view of the scan, written straight into pinned host memory: total, largest item, overflow,
+            // and the last item (total - last = out[n-1])
+            uint32_t m = 0;
+            for (int i = 0; i < 16; i++) m = max(m, wmax[i]);
+            mail[0] = (uint32_t)run; mail[1] = m; mail[2] = run > 0xffffffffull ? CTK_OVF_RUNS : 0u; mail[3] = n > 0 ? in[n - 1] : 0u;
+        }
     }
 }
 
@@ -1011,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_relabel(RelabelArgs a)
 // K8  number of ids that are present and survive persistence
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__ ext, int64_t n_labels, int persistence,
-                                                     uint32_t *counters)
+                                                     uint32_t *counters, uint32_t *mail)
 {
     int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
     uint32_t v = 0;
@@ -1021,17 +1034,32 @@ __global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__
     }
     uint32_t s = wave_sum_u32(v);
     if (lane_id() == 0 && s) atomicAdd(&counters[CTK_CNT_ALIVE], s);
+    // the last workgroup to finish publishes the results in pinned host memory (no copy command)
+    __shared__ bool last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&counters[CTK_CNT_TICKET], 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        mail[0] = __hip_atomic_load(&counters[CTK_CNT_ALIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mail[1] = __hip_atomic_load(&counters[CTK_CNT_WROTE_ZERO], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-__global__ void k_fill_ext(int32_t *ext, int64_t n_labels)
+// time extents of the ids start empty; the counters of the write stage start at zero
+__global__ void k_fill_ext(int32_t *ext, int64_t n_labels, uint32_t *counters)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= n_labels) { ext[i] = INT32_MAX; ext[n_labels + 1 + i] = INT32_MIN; }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_labels; i += (int64_t)gridDim.x * blockDim.x) {
+        ext[i] = INT32_MAX; ext[n_labels + 1 + i] = INT32_MIN;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { counters[CTK_CNT_WROTE_ZERO] = 0; counters[CTK_CNT_ALIVE] = 0; counters[CTK_CNT_TICKET] = 0; }
 }
 
 // op staging block [CtkOp ops[n]] [int32 next[n]] [int32 hi_label[n], nf used] [int32 first_op[n], nf used] in pinned host memory ->
 // device copy of ops + next (same layout) and first[label]
-__global__ void k_ops_ingest(const int32_t *__restrict__ staging, int64_t nops, int32_t nf, int32_t *__restrict__ dst, int32_t *__restrict__ op_first)
+// ... and what k_fill_ext does (one launch on the critical path between the host seam driver and the relabel)
+__global__ void k_ops_ingest(const int32_t *__restrict__ staging, int64_t nops, int32_t nf, int32_t *__restrict__ dst, int32_t *__restrict__ op_first,
+                             int32_t *__restrict__ ext, int64_t n_labels, uint32_t *counters)
 {
     const int64_t words = nops * 9;
     const int32_t *lab = staging + words, *first = lab + nops;
@@ -1039,6 +1067,10 @@ __global__ void k_ops_ingest(const int32_t *__restrict__ staging, int64_t nops, 
         if (i < words) dst[i] = staging[i];
         else op_first[lab[i - words]] = first[i - words];
     }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_labels; i += (int64_t)gridDim.x * blockDim.x) {
+        ext[i] = INT32_MAX; ext[n_labels + 1 + i] = INT32_MIN;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { counters[CTK_CNT_WROTE_ZERO] = 0; counters[CTK_CNT_ALIVE] = 0; counters[CTK_CNT_TICKET] = 0; }
 }
 
 __global__ void k_scatter_i32(const int32_t *__restrict__ where, const int32_t *__restrict__ what, int n, int32_t *__restrict__ dst)

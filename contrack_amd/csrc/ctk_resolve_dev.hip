@@ -45,6 +45,7 @@ struct ResolveDev {
     int32_t *dorig;                       // [dense] fresh label of the dense id
     int32_t *dbox;                        // [dense][6] its box
     uint32_t *dcount;                     // number of dense ids
+    int32_t *op_first;                    // [NC+1] first op per label: reset to -1 here, filled by k_ops_ingest
 };
 
 #define CTK_MAX_JACOBI 240          // hard cap of filter passes on the device (then: host resolver)
@@ -320,7 +321,8 @@ __global__ void k_rs_roots(ResolveDev r)
         // labels <= components: candidate mark / dense-id slot g+1 are initialised here
         r.mark[g + 1] = 0;
         r.dmap[g + 1] = 0;
-        if (g == 0) *r.dcount = 0;
+        r.op_first[g + 1] = -1;
+        if (g == 0) { *r.dcount = 0; r.op_first[0] = -1; }
     }
 }
 
