@@ -286,8 +286,9 @@ class Tracker:
         check(fn(self._h, flag_dev, field_dev, T, ny, nx, wrow.ctypes.data, C.byref(n)))
         return self._life_rows(int(n.value))
 
-    def set_timing(self, on=True):
-        check(lib().ctk_set_timing(self._h, int(bool(on))))
+    def set_timing(self, level=2):
+        """0: off; 1: HIP events around k_threshold / k_relabel only; 2 (or True): around every kernel group"""
+        check(lib().ctk_set_timing(self._h, 2 if level is True else int(level)))
 
     def stats(self):
         v = np.zeros(16, dtype=np.int64)

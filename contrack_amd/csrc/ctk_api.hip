@@ -145,13 +145,16 @@ T *P(const DevBuf &b) { return (T *)b.p; }
 struct Timer {
     ctk_handle *h;
     int k;
+    // level 1: only the two pixel-streaming kernels carry events (an event record is a command of its own, ~5 us on
+    // the stream: twenty of them would stretch the pass they are supposed to measure); level 2: every group
+    bool on() const { return h->ev_ready && (h->timing >= 2 || (h->timing == 1 && (k == CTK_K_THRESHOLD || k == CTK_K_RELABEL))); }
     Timer(ctk_handle *h_, int k_) : h(h_), k(k_)
     {
-        if (h->timing && h->ev_ready) { (void)hipEventRecord(h->ev[k][0], h->stream); }
+        if (on()) { (void)hipEventRecord(h->ev[k][0], h->stream); }
     }
     ~Timer()
     {
-        if (h->timing && h->ev_ready) { (void)hipEventRecord(h->ev[k][1], h->stream); h->ev_used[k] = true; }
+        if (on()) { (void)hipEventRecord(h->ev[k][1], h->stream); h->ev_used[k] = true; }
     }
 };
 
@@ -253,7 +256,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
 
 extern "C" int ctk_set_timing(ctk_handle *h, int enable)
 {
-    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    if (!h || enable < 0 || enable > 2) return ctk_set_error(CTK_E_INVALID, "ctk_set_timing: null handle or level not in 0..2");
     HIPCHK(hipSetDevice(h->device));
     if (enable && !h->ev_ready) {
         for (int k = 0; k <= CTK_K_COUNT; k++) { HIPCHK(hipEventCreate(&h->ev[k][0])); HIPCHK(hipEventCreate(&h->ev[k][1])); }
