@@ -6,7 +6,10 @@
 A "step" is one pass of the hot path (threshold -> 2-D labelling with longitude wrap -> overlap filter ->
 3-D tracking -> persistence -> flag) over one batch: the whole (T, ny, nx) slab of the workload, already
 resident in HBM.  For N > 1 (launched by torch.distributed.run, one rank per GPU) the time axis is sharded
-across ranks (strong scaling: total work fixed) -- see contrack_amd/dist.py.
+across ranks -- weak scaling by default: every GPU holds one member of the workload (2707 steps at 1 deg), the members
+are concatenated on the time axis (BASELINE.json configs[4] layout) and tracked as ONE slab of N x T steps with the
+one-timestep halo exchange and the table all-gather; `--scaling strong` splits the single-GPU slab instead -- see
+contrack_amd/dist.py.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -90,6 +93,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="era5_1deg_djf30")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = one member of the workload per GPU, concatenated on the time axis (default); "
+                         "strong = the single-GPU slab split over the GPUs")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     rank = int(os.environ.get("RANK", "0"))
@@ -152,7 +158,7 @@ def main():
     achieved = alg_bytes[kern] / (per[kern] * 1e-3) / 1e9 if per.get(kern, 0) > 0 else 0.0
     kname = {"k_threshold": "k_threshold_v4", "k_relabel": "k_relabel_v4"}[kern]
     out = dict(metric="timesteps/sec labeled+tracked", value=value, unit="timesteps/s", n_gpus=1, steps=args.steps,
-               warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None,
+               warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f32 compare / int32 labels / int64 exact areas", data="synthetic",
                config=dict(workload="%s: %dx%dx%d float32, threshold %s %g, overlap %g, persistence %d, twosided %s" % (
                    args.workload, T, ny, nx, wl["gorl"], wl["threshold"], wl["overlap"], wl["persistence"], wl["twosided"]),

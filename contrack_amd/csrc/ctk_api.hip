@@ -30,6 +30,11 @@ extern "C" int ctk_weights_to_limbs(const float *wrow, int ny, int32_t *wlo, int
         if (r_ != CTK_OK) return r_; \
     } while (0)
 
+static int g_ht = -1; static double g_ht0 = 0;
+static double now_ms_fwd() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define HT(name) do { if (g_ht < 0) g_ht = getenv("CTK_HOSTTRACE") ? 1 : 0; if (g_ht) { double t_ = now_ms_fwd(); fprintf(stderr, "HT %-28s %9.1f us\n", name, (t_ - g_ht0) * 1e3); } } while (0)
+#define HT0() do { if (g_ht < 0) g_ht = getenv("CTK_HOSTTRACE") ? 1 : 0; if (g_ht) g_ht0 = now_ms_fwd(); } while (0)
+
 namespace {
 
 struct DevBuf {
@@ -76,6 +81,9 @@ struct ctk_handle {
     void *h_stage = nullptr;         // pinned: thresholds + weight limbs on their way to the device
     size_t h_stage_cap = 0;
     uint32_t rb_last = 0, rb_total = 0;   // run_base[T-1], run_base[T]
+    // what the device copies of thresholds / weight limbs were made from
+    std::vector<double> c_thr; std::vector<float> c_w;
+    int64_t c_T = -1; bool c_f64 = false, c_thr_valid = false, c_w_valid = false; int c_cmp = -1;
     int64_t last_alive = 0;
     size_t mail_cap_c = 0, mail_cap_d = 0, mail_want_c = 0, mail_want_d = 0;
     size_t h_ops_cap = 0;
@@ -342,14 +350,30 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     hipStream_t s = h->stream;
 
     // host-side preparation: thresholds for the float32 compare, exact integer limbs of the row weights -- staged in
-    // pinned memory, so that the uploads are asynchronous and nothing has to be waited for before the first kernel
+    // pinned memory, so that the uploads are asynchronous and nothing has to be waited for before the first kernel.
+    // Thresholds / weights equal to the previous call's are already on the device: nothing is converted or uploaded.
     const size_t thr_bytes = (size_t)std::max<int64_t>(T, 1) * 8;
-    CTKCHK(ensure_host(&h->h_stage, &h->h_stage_cap, thr_bytes + (size_t)ny * 8));
-    double *thr32 = (double *)h->h_stage;                             // float32 thresholds in the first half when !f64
-    if (f64) for (int64_t t = 0; t < T; t++) thr32[t] = thr[t];
-    else for (int64_t t = 0; t < T; t++) ((float *)thr32)[t] = adjust_threshold(thr[t], cmp_op);
-    int32_t *wlo = (int32_t *)((char *)h->h_stage + thr_bytes), *whi = wlo + ny;
-    CTKCHK(ctk_weights_to_limbs(wrow, ny, wlo, whi, &h->wshift));
+    const bool same_thr = h->c_thr_valid && h->c_T == T && h->c_f64 == f64 && h->c_cmp == cmp_op && (T == 0 || memcmp(h->c_thr.data(), thr, (size_t)T * 8) == 0);
+    const bool same_w = h->c_w_valid && (int)h->c_w.size() == ny && memcmp(h->c_w.data(), wrow, (size_t)ny * 4) == 0;
+    double *thr32 = nullptr;
+    int32_t *wlo = nullptr;
+    if (!same_thr || !same_w) {
+        CTKCHK(ensure_host(&h->h_stage, &h->h_stage_cap, thr_bytes + (size_t)ny * 8));
+        thr32 = (double *)h->h_stage;                                 // float32 thresholds in the first half when !f64
+        wlo = (int32_t *)((char *)h->h_stage + thr_bytes);
+    }
+    if (!same_thr) {
+        h->c_thr_valid = false;
+        if (f64) for (int64_t t = 0; t < T; t++) thr32[t] = thr[t];
+        else for (int64_t t = 0; t < T; t++) ((float *)thr32)[t] = adjust_threshold(thr[t], cmp_op);
+        h->c_thr.assign(thr, thr + T);
+        h->c_T = T; h->c_f64 = f64; h->c_cmp = cmp_op;
+    }
+    if (!same_w) {
+        h->c_w_valid = false;
+        CTKCHK(ctk_weights_to_limbs(wrow, ny, wlo, wlo + ny, &h->wshift));
+        h->c_w.assign(wrow, wrow + ny);
+    }
 
     CTKCHK(ensure(h, h->mask, (size_t)nrows * W * 8));
     CTKCHK(ensure(h, h->wstart, (size_t)nrows * W * 2));
@@ -366,9 +390,10 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     HIPCHK(hipMemsetAsync(h->counters.p, 0, CTK_CNT_N * 4, s));
     if (T > 0) {
         HIPCHK(hipMemsetAsync(h->tcount.p, 0, (size_t)T * 4, s));
-        HIPCHK(hipMemcpyAsync(h->thr32.p, thr32, (size_t)T * (f64 ? 8 : 4), hipMemcpyHostToDevice, s));
+        if (!same_thr) { HIPCHK(hipMemcpyAsync(h->thr32.p, thr32, (size_t)T * (f64 ? 8 : 4), hipMemcpyHostToDevice, s)); h->c_thr_valid = true; }
     }
-    HIPCHK(hipMemcpyAsync(h->wlo.p, wlo, (size_t)ny * 8, hipMemcpyHostToDevice, s));       // wlo and whi are adjacent on both sides
+    if (!same_w) { HIPCHK(hipMemcpyAsync(h->wlo.p, wlo, (size_t)ny * 8, hipMemcpyHostToDevice, s)); h->c_w_valid = true; }    // wlo and whi are adjacent on both sides
+    HT("uploads queued");
 
     if (T > 0) {
         Timer tm(h, CTK_K_THRESHOLD);
@@ -399,8 +424,10 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     }
     // runs per timestep decide the workspace size and whether the global-memory variant is needed: the scan kernel
     // wrote total / maximum / overflow / last count into the pinned mailbox
+    HT("thr+scan launched");
     HIPCHK(hipStreamSynchronize(s));
     const uint32_t m_total = h->h_mail1[0], m_max = h->h_mail1[1], m_ovf = h->h_mail1[2], m_last = h->h_mail1[3];
+    HT("sync1 done");
     if (m_ovf & CTK_OVF_RUNS) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: more than 2^32-1 runs in one shard");
     h->total_runs = m_total;
     h->max_runs_step = m_max;
@@ -439,6 +466,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         a.g_x0 = P<uint16_t>(h->g_x0); a.g_x1 = P<uint16_t>(h->g_x1); a.g_y = P<uint16_t>(h->g_y);
         a.g_parent = P<uint32_t>(h->g_parent); a.g_root = P<uint32_t>(h->g_root); a.g_idmap = P<uint32_t>(h->g_idmap);
         Timer tm(h, CTK_K_LABEL2D);
+        HT("before label2d launch");
         // The variants take disjoint sets of timesteps (by run count): launch them on concurrent streams.
         // nruns == 0 timesteps are handled by the small variant (RUNS_BELOW = -1).
         const bool v2 = h->max_runs_step > 1024, v3 = h->max_runs_step > 2048;
@@ -988,7 +1016,9 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         k_compact_cands<<<(int)std::max<int64_t>(T, 1), 64, 0, s>>>(r, P<CtkCand>(h->rv_cand_scratch), P<uint32_t>(h->rv_cand_cnt), P<uint32_t>(h->rv_cand_off),
                                                                     h->ny, P<CtkCand>(h->rv_cand), P<uint32_t>(h->rv_boff) + nsb, it_done - ROUND, ROUND, mail);
         HIPCHK(hipGetLastError());
+        HT("resolver launched");
         HIPCHK(hipStreamSynchronize(s));
+        HT("sync2 done");
         memcpy(hs, mail.scal, sizeof(hs));
         if ((hs[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) || (uint64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS] > in.pair_cap)
             return 1;                                                         // the host path regrows the pair table
@@ -1030,15 +1060,18 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
             HIPCHK(hipStreamSynchronize(s));
             h->ms[CTK_T_D2H] += now_ms() - t0;
         }
+        HT("mail copied");
         const double t1 = now_ms();
         const CtkCand *hc = (const CtkCand *)dst;
         const int32_t *ho = (const int32_t *)(dst + cb), *hb = ho + nd;
         seam_driver(h, hc, ncand, ho, hb, (int64_t)nd, h->nx, ops);
         h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t1;
+        HT("driver done");
         const double t2 = now_ms();
         h->stats[CTK_S_OPS] = (int64_t)ops.size();
         CTKCHK(upload_ops_dense(h, ops, ho, (int64_t)nd));
         h->ms[CTK_T_H2D] += now_ms() - t2;
+        HT("ingest launched");
     } else {
         h->ms[CTK_T_D2H] += now_ms() - t0;
         h->stats[CTK_S_OPS] = 0;
@@ -1227,7 +1260,9 @@ extern "C" int ctk_shard_write(ctk_handle *h, int persistence, int32_t *flag_dev
                                                                            h->h_mail1 + 8);
         HIPCHK(hipGetLastError());
     }
+    HT("tail launched");
     HIPCHK(hipStreamSynchronize(s));
+    HT("sync3 done");
     h->last_alive = h->h_mail1[8];
     if (n_alive_local) *n_alive_local = h->last_alive;
     if (wrote_background) *wrote_background = h->h_mail1[9] ? 1 : 0;
@@ -1251,8 +1286,11 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
 {
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
     const double t0 = now_ms();
+    HT0();
     CTKCHK(shard_label2d_impl(h, anom_dev, f64, T, ny, nx, thr, cmp_op, wrow, 0));
+    HT("label2d stage done");
     CTKCHK(ctk_shard_overlap(h));
+    HT("overlap launched");
     int rv = h->use_device_resolve ? device_resolve_local(h, overlap, twosided) : 1;
     if (rv < 0) return rv;
     if (rv == 0) {
