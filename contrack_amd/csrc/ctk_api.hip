@@ -85,6 +85,7 @@ struct ctk_handle {
     std::vector<double> c_thr; std::vector<float> c_w;
     int64_t c_T = -1; bool c_f64 = false, c_thr_valid = false, c_w_valid = false; int c_cmp = -1;
     int64_t last_alive = 0;
+    int64_t rowoff_T = -1; int rowoff_ny = -1; void *rowoff_p = nullptr;     // what seam_rowoff currently holds
     size_t mail_cap_c = 0, mail_cap_d = 0, mail_want_c = 0, mail_want_d = 0;
     size_t h_ops_cap = 0;
     const int32_t *d_op_next = nullptr;
@@ -999,7 +1000,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
             for (int it = it_done; it < it_done + ROUND; it++)
                 k_rs_pass<<<(int)(T - 2), 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
         it_done += ROUND;
-        k_rs_parent_init<<<gc, 256, 0, s>>>(r);
+        if (it_done > ROUND) k_rs_parent_init<<<gc, 256, 0, s>>>(r);          // the first round's parents were set by k_rs_init
         k_rs_unite<<<gp, 256, 0, s>>>(r);
         k_rs_roots<<<gc, 256, 0, s>>>(r);
         const uint32_t *ncp = in.cprefix + T;
@@ -1091,7 +1092,10 @@ static int device_resolve_local(ctk_handle *h, double overlap, int twosided)
     const size_t R = h->total_runs ? h->total_runs : 1;
     CTKCHK(ensure(h, h->comp_label, R * 4));
     CTKCHK(ensure(h, h->seam_rowoff, (size_t)(h->T + 1) * 4));
-    if (h->T > 0) k_iota_mul<<<(int)((h->T + 255) / 256), 256, 0, h->stream>>>(P<uint32_t>(h->seam_rowoff), (uint32_t)h->T, (uint32_t)h->ny);
+    if (h->T > 0 && (h->rowoff_T != h->T || h->rowoff_ny != h->ny || h->rowoff_p != h->seam_rowoff.p)) {      // t * ny: unchanged between calls on one grid
+        k_iota_mul<<<(int)((h->T + 255) / 256), 256, 0, h->stream>>>(P<uint32_t>(h->seam_rowoff), (uint32_t)h->T, (uint32_t)h->ny);
+        h->rowoff_T = h->T; h->rowoff_ny = h->ny; h->rowoff_p = h->seam_rowoff.p;
+    }
     ResolveIn in;
     in.T = h->T; in.R = R;
     in.ncomp = P<uint32_t>(h->ncomp); in.cprefix = P<uint32_t>(h->cprefix); in.mrep = P<uint32_t>(h->d_mrep); in.comp_t = P<uint32_t>(h->d_comp_t);
@@ -1219,9 +1223,15 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
     a.flag = flag_dev; a.counters = P<uint32_t>(h->counters);
     a.nrows = h->T * h->ny; a.ny = h->ny; a.nx = h->nx; a.W = h->W;
     const int64_t npl = (int64_t)h->ny * h->nx;
-    // rows per workgroup: about 16 KB of output each (measured best on MI355X: 8-16 rows at nx = 360), at least 4 rows
-    int rb = (int)std::max<int64_t>(4, std::min<int64_t>(64, 16384 / ((int64_t)h->nx * 4)));
-    rb = std::min(rb, h->ny);
+    // rows per workgroup, measured on MI355X (k_relabel_v4, ms):
+    //   2707 x 181 x 360:    990 int4 stores per workgroup (11 rows) 0.147 | 720: 0.159 | 1440: 0.168 | 540: 0.182
+    //   480 x 721 x 1440:    720 (2 rows) 0.337 | 2880 (8 rows) 0.343 | 2160: 0.359 | 1440: 0.366
+    //   14600 x 721 x 1440:  2880 (8 rows, 1.3 M workgroups) 10.9 | 5760: 11.6 | 1440 (2.6 M): 14.0 | 720 (5.3 M): 17.1
+    // -> at most 1024 stores (four per thread) while that keeps the grid below a million workgroups, else at most 3072.
+    const int n4r = std::max(1, h->nx / 4);
+    int rb = std::min(h->ny, std::max(1, std::min(64, 1024 / n4r)));
+    if (h->T * ((h->ny + rb - 1) / rb) > 1000000) rb = std::min(h->ny, std::max(rb, std::min(64, 3072 / n4r)));
+    while (rb < h->ny && h->T * ((h->ny + rb - 1) / rb) >= (1 << 24)) rb++;
     const int rvcap = 2048;
     const size_t lds = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) + (size_t)rvcap * 4;
     const int64_t nblk4 = h->T * ((h->ny + rb - 1) / rb);

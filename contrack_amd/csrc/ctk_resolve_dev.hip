@@ -112,6 +112,7 @@ __global__ void k_rs_init(ResolveDev r)
         r.F[2 * (int64_t)g] = 0; r.F[2 * (int64_t)g + 1] = 0;
         r.B[2 * (int64_t)g] = 0; r.B[2 * (int64_t)g + 1] = 0;
         r.keep0[g] = 1; r.keep1[g] = 1;
+        r.parent[g] = g;                                   // (k_rs_parent_init, for the first round)
     }
     if (blockIdx.x == 0) for (int i = threadIdx.x; i <= CTK_MAX_JACOBI; i += blockDim.x) r.changed[i] = 0;
 }

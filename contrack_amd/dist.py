@@ -92,21 +92,29 @@ class TorchComm:
         """tensor: uint8 (device tensor with nccl, CPU tensor with gloo), sizes may differ between ranks.
         Returns (list of uint8 tensors, list of byte counts); the tensors are padded to the largest size."""
         torch, dist = self.torch, self.dist
+        if self.world == 1:
+            return [tensor], [tensor.numel()]
+        # sizes: one collective, one host read
         n = torch.tensor([tensor.numel()], dtype=torch.int64, device=self._dev())
-        sizes = [torch.zeros(1, dtype=torch.int64, device=self._dev()) for _ in range(self.world)]
-        dist.all_gather(sizes, n)
-        sizes = [int(x.item()) for x in sizes]
+        sizes_t = torch.empty(self.world, dtype=torch.int64, device=self._dev())
+        dist.all_gather_into_tensor(sizes_t, n)
+        sizes = [int(x) for x in sizes_t.tolist()]
         mx = max(max(sizes), 1)
         if tensor.numel() == mx:
             buf = tensor
         else:
             buf = torch.zeros(mx, dtype=torch.uint8, device=self._dev())
             buf[:tensor.numel()] = tensor
-        out = [torch.empty(mx, dtype=torch.uint8, device=self._dev()) for _ in range(self.world)]
-        dist.all_gather(out, buf)
+        # one receive buffer, kept between calls while it is large enough (a fresh allocation per step would cost
+        # more than the collective at these sizes)
+        need = mx * self.world
+        if getattr(self, "_gather_buf", None) is None or self._gather_buf.numel() < need or self._gather_buf.device != buf.device:
+            self._gather_buf = torch.empty(need + need // 4, dtype=torch.uint8, device=self._dev())
+        flat = self._gather_buf[:need]
+        dist.all_gather_into_tensor(flat, buf)
         if self.device is not None:
             torch.cuda.synchronize(self.device)
-        return out, sizes
+        return [flat[r * mx:(r + 1) * mx] for r in range(self.world)], sizes
 
     def ring_shift(self, send, recv_like):
         """rank r -> r+1 (no wrap).  `send`: uint8 tensor or None (last rank); returns the received uint8
