@@ -332,6 +332,14 @@ extern "C" int ctk_get_timings(ctk_handle *h, double *ms)
 // ------------------------------------------------------------------------------------------------
 // stage 1
 // ------------------------------------------------------------------------------------------------
+// rows per workgroup of k_threshold_v4.  Swept on MI355X: 2707 x 181 x 360: 8..64 rows 0.128-0.137 ms (4 rows 0.195);
+// 480 x 721 x 1440: 2..32 rows 0.345-0.366 ms -- flat, 16 it is.
+static int threshold_rows(int ny, int nx, int64_t T)
+{
+    (void)nx; (void)T;
+    return std::min(ny, 16);
+}
+
 static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t T, int ny, int nx, const double *thr,
                               int cmp_op, const float *wrow, int has_prev)
 {
@@ -399,13 +407,14 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     if (T > 0) {
         Timer tm(h, CTK_K_THRESHOLD);
         const int g = grid_for_rows(nrows);
-        const int64_t nblk4 = T * ((ny + CTK_RB - 1) / CTK_RB);                       // one workgroup per (timestep, 16 rows)
+        const int rbt = threshold_rows(ny, nx, T);
+        const int64_t nblk4 = T * ((ny + rbt - 1) / rbt);                             // one workgroup per (timestep, rbt rows)
         const bool v4 = !f64 && (nx % 4 == 0) && (((uintptr_t)anom_dev & 15) == 0) && nblk4 < (1 << 24);     // < 2^32 work-items
         const unsigned g4 = (unsigned)nblk4;
 #define LAUNCH_THR(OP)                                                                                                                      \
     do {                                                                                                                                \
         if (f64) k_threshold<OP, double><<<g, 256, 0, s>>>((const double *)anom_dev, P<double>(h->thr32), nrows, ny, nx, W, P<uint64_t>(h->mask)); \
-        else if (v4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)anom_dev, P<float>(h->thr32), ny, nx, W, P<uint64_t>(h->mask)); \
+        else if (v4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)anom_dev, P<float>(h->thr32), ny, nx, W, P<uint64_t>(h->mask), rbt); \
         else k_threshold<OP, float><<<g, 256, 0, s>>>((const float *)anom_dev, P<float>(h->thr32), nrows, ny, nx, W, P<uint64_t>(h->mask)); \
     } while (0)
         switch (cmp_op) {

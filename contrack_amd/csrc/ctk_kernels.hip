@@ -150,12 +150,12 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <int OP>
 __global__ __launch_bounds__(256) void k_threshold_v4(const float *__restrict__ anom, const float *__restrict__ thr32,
-                                                      int ny, int nx, int W, uint64_t *__restrict__ mask)
+                                                      int ny, int nx, int W, uint64_t *__restrict__ mask, int rb)
 {
     constexpr int U = 4;                                   // independent 16-byte loads in flight per lane
-    const int nchunk = (ny + CTK_RB - 1) / CTK_RB;
-    const int t = (int)(blockIdx.x / (unsigned)nchunk), y0 = (int)(blockIdx.x - (unsigned)t * nchunk) * CTK_RB, tid = (int)threadIdx.x;
-    const int rows = min(CTK_RB, ny - y0);
+    const int nchunk = (ny + rb - 1) / rb;
+    const int t = (int)(blockIdx.x / (unsigned)nchunk), y0 = (int)(blockIdx.x - (unsigned)t * nchunk) * rb, tid = (int)threadIdx.x;
+    const int rows = min(rb, ny - y0);
     const float th = thr32[t];
     const int n4 = nx >> 2, n4p = (n4 + 15) & ~15;         // float4 slots per row, padded to whole 16-lane groups (= words)
     const int total = rows * n4p;
