@@ -948,7 +948,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     CTKCHK(ensure(h, h->rv_pgc, PC * 4)); CTKCHK(ensure(h, h->rv_pgd, PC * 4));
     CTKCHK(ensure(h, h->rv_F, R * 16)); CTKCHK(ensure(h, h->rv_B, R * 16));
     CTKCHK(ensure(h, h->rv_keep0, R)); CTKCHK(ensure(h, h->rv_keep1, R));
-    CTKCHK(ensure(h, h->rv_changed, (CTK_MAX_JACOBI + 8) * 4));
+    CTKCHK(ensure(h, h->rv_changed, (size_t)(CTK_MAX_JACOBI + 8) * CTK_CHG_SLOTS * 4));
     CTKCHK(ensure(h, h->rv_parent, R * 4)); CTKCHK(ensure(h, h->rv_isroot, R * 4)); CTKCHK(ensure(h, h->rv_rank, (R + 1) * 4));
     CTKCHK(ensure(h, h->rv_lab, R * 4));
     const int nsb = (int)((R + CTK_SCAN_ITEMS - 1) / CTK_SCAN_ITEMS);

@@ -34,7 +34,7 @@ struct ResolveDev {
     int64_t *F, *B;                       // [NC][2]
     double *inv, *ff;                     // [NC] 1/areacon and forward fraction of every representative (contrack.py:721-722)
     uint8_t *keep0, *keep1;               // [NC]
-    uint32_t *changed;                    // [CTK_MAX_JACOBI + 1]
+    uint32_t *changed;                    // [CTK_MAX_JACOBI + 1][CTK_CHG_SLOTS]: some keep bit flipped in that pass
     uint32_t *parent;                     // [NC]
     uint32_t *isroot, *rank;              // [NC], [NC+1]
     int32_t *lab;                         // [NC] fresh 3-D label of every component (0 = filtered out)
@@ -48,6 +48,7 @@ struct ResolveDev {
     int32_t *op_first;                    // [NC+1] first op per label: reset to -1 here, filled by k_ops_ingest
 };
 
+#define CTK_CHG_SLOTS 64            // 'changed' words per filter pass (= wave width: one ballot reads them)
 #define CTK_MAX_JACOBI 240          // hard cap of filter passes on the device (then: host resolver)
 #define CTK_JACOBI_ROUND 10         // passes launched per round before convergence is checked
 
@@ -114,7 +115,7 @@ __global__ void k_rs_init(ResolveDev r)
         r.keep0[g] = 1; r.keep1[g] = 1;
         r.parent[g] = g;                                   // (k_rs_parent_init, for the first round)
     }
-    if (blockIdx.x == 0) for (int i = threadIdx.x; i <= CTK_MAX_JACOBI; i += blockDim.x) r.changed[i] = 0;
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < (CTK_MAX_JACOBI + 1) * CTK_CHG_SLOTS; i += blockDim.x) r.changed[i] = 0;
 }
 
 __global__ void k_rs_parent_init(ResolveDev r)
@@ -151,55 +152,6 @@ __global__ void k_rs_prep(ResolveDev r)
     }
 }
 
-// one Jacobi pass, part 1: backward overlap from the keep bits of the previous pass (contrack.py:719)
-__global__ void k_rs_bwd(ResolveDev r, int it)
-{
-    if (it > 0 && r.changed[it - 1] == 0) return;           // already at the fixed point
-    const uint8_t *kin = (it & 1) ? r.keep1 : r.keep0;
-    const uint32_t np = dev_npairs(r), ng = dev_ngrouped(r);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
-        if (!kin[r.p_rd[i]]) continue;
-        const CtkPair p = pair_at(r, i, ng);
-        const int64_t rc = r.p_rc[i];
-        atomicAdd((unsigned long long *)&r.B[2 * rc], (unsigned long long)p.lo);
-        atomicAdd((unsigned long long *)&r.B[2 * rc + 1], (unsigned long long)p.hi);
-    }
-}
-
-// part 2: the removal rules (contrack.py:721-742) on merged representatives of the inner timesteps
-__global__ void k_rs_decide(ResolveDev r, int it)
-{
-    if (it > 0 && r.changed[it - 1] == 0) return;
-    const uint8_t *kin = (it & 1) ? r.keep1 : r.keep0;
-    uint8_t *kout = (it & 1) ? r.keep0 : r.keep1;
-    const uint32_t nc = dev_ncomps(r);
-    bool any = false;
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
-        const uint32_t t = r.comp_t[g];
-        uint8_t k = 1;
-        if (r.cprefix[t] + r.mrep[g] == g && t >= 1 && (int64_t)t <= r.T - 2) {
-            const double areacon = dev_limbs_to_double(r.A[2 * (int64_t)g], r.A[2 * (int64_t)g + 1], r.wshift);
-            const double fwd = dev_limbs_to_double(r.F[2 * (int64_t)g], r.F[2 * (int64_t)g + 1], r.wshift);
-            const double bwd = dev_limbs_to_double(r.B[2 * (int64_t)g], r.B[2 * (int64_t)g + 1], r.wshift);
-            const double inv = 1.0 / areacon;
-            const double fb = inv * bwd, ff = inv * fwd;
-            bool kill = false;
-            if (r.twosided) {
-                if (fb != 0 && ff != 0) { if (fb < r.overlap || ff < r.overlap) kill = true; }
-                if (fb != 0 && ff == 0) { if (fb < r.overlap) kill = true; }
-                if (fb == 0 && ff != 0) { if (ff < r.overlap) kill = true; }
-            } else {
-                if (ff < r.overlap) kill = true;
-            }
-            k = kill ? 0 : 1;
-        }
-        r.B[2 * (int64_t)g] = 0; r.B[2 * (int64_t)g + 1] = 0;       // ready for the next pass
-        kout[g] = k;
-        any |= (k != kin[g]);
-    }
-    if (__ballot(any) && lane_id() == 0) atomicOr(&r.changed[it], 1u);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Fused filter pass: one 64-thread workgroup per timestep.  keep[] is updated IN PLACE (chaotic iteration:
 // a workgroup may read its predecessor's bits from this pass or the previous one -- both are valid iterates,
@@ -210,6 +162,9 @@ __global__ void k_rs_decide(ResolveDev r, int it)
 // timesteps, in the global scratch r.B.
 // ------------------------------------------------------------------------------------------------
 #define CTK_PASS_COMPS 512
+// The workgroup's work is a chain of dependent loads; independent ones are issued together (three global-memory
+// round trips instead of nine): [everything indexed by t] -> [pair records and component constants of the first 64
+// pairs / components] -> [keep bits of the pairs' predecessors].
 __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_cnt,
                                                 uint8_t *__restrict__ tdirty)
 {
@@ -218,19 +173,38 @@ __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint
     const int64_t T = r.T;
     uint8_t *dcur = tdirty + (size_t)(it & 1) * (size_t)T, *dprev = tdirty + (size_t)((it & 1) ^ 1) * (size_t)T;
     const int lane = (int)threadIdx.x;
-    if (it > 0) {
-        if (r.changed[it - 1] == 0) return;                    // fixed point reached in an earlier pass
-        if (!dprev[t - 1]) { if (lane == 0) dcur[t] = 0; return; }
-    }
-    const uint32_t cb = r.cprefix[t], nct = r.cprefix[t + 1] - cb;
+    // round trip 1
+    const uint32_t ch_prev = it > 0 ? (__ballot(r.changed[(it - 1) * CTK_CHG_SLOTS + lane] != 0u) != 0ull ? 1u : 0u) : 1u;
+    const uint8_t d_prev = it > 0 ? dprev[t - 1] : (uint8_t)1;
+    const uint32_t cb = r.cprefix[t], ce = r.cprefix[t + 1];
+    const uint32_t pb = pair_base[t], pn = pair_cnt[t];
+    const uint32_t nu = dev_nungrouped(r);
+    if (ch_prev == 0) return;                                  // fixed point reached in an earlier pass
+    if (!d_prev) { if (lane == 0) dcur[t] = 0; return; }
+    const uint32_t nct = ce - cb;
     __shared__ long long Bl[2 * CTK_PASS_COMPS];
     const bool lds = nct <= CTK_PASS_COMPS;
     long long *B = lds ? Bl : (long long *)(r.B + 2 * (int64_t)cb);
     if (lds) for (uint32_t c = lane; c < 2 * nct; c += 64) Bl[c] = 0;
-    __syncthreads();
+    // round trip 2: first pair and first component of this lane
     uint8_t *keep = r.keep0;
-    const uint32_t pb = pair_base[t], pn = pair_cnt[t];
-    for (uint32_t i = lane; i < pn; i += 64) {
+    const bool has_p = (uint32_t)lane < pn, has_c = (uint32_t)lane < nct;
+    const uint32_t k0 = pb + lane, g0 = cb + lane;
+    const uint32_t rd0 = has_p ? r.p_rd[k0] : 0u, rc0 = has_p ? r.p_rc[k0] : 0u;
+    CtkPair p0;
+    if (has_p) p0 = r.pairs[k0]; else { p0.lo = 0; p0.hi = 0; }
+    const uint32_t mrep0 = has_c ? r.mrep[g0] : 0xffffffffu;
+    const double inv0 = has_c ? r.inv[g0] : 0.0, ff0 = has_c ? r.ff[g0] : 0.0;
+    const uint8_t kold0 = has_c ? __hip_atomic_load(&keep[g0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
+    // round trip 3
+    const uint8_t kd0 = has_p ? __hip_atomic_load(&keep[rd0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
+    __syncthreads();
+    if (has_p && kd0) {
+        const uint32_t c = rc0 - cb;
+        atomicAdd((unsigned long long *)&B[2 * c], (unsigned long long)p0.lo);
+        atomicAdd((unsigned long long *)&B[2 * c + 1], (unsigned long long)p0.hi);
+    }
+    for (uint32_t i = lane + 64; i < pn; i += 64) {            // timesteps with more than 64 pair records
         const uint32_t k = pb + i;
         if (!__hip_atomic_load(&keep[r.p_rd[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
         const CtkPair p = r.pairs[k];
@@ -238,7 +212,6 @@ __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint
         atomicAdd((unsigned long long *)&B[2 * c], (unsigned long long)p.lo);
         atomicAdd((unsigned long long *)&B[2 * c + 1], (unsigned long long)p.hi);
     }
-    const uint32_t nu = dev_nungrouped(r);
     if (nu) {                                                   // records that bypassed the hash table (rare)
         const uint32_t ng = dev_ngrouped(r);
         for (uint32_t i = lane; i < nu; i += 64) {
@@ -254,6 +227,7 @@ __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint
     bool any = false;
     for (uint32_t c = lane; c < nct; c += 64) {
         const uint32_t g = cb + c;
+        const bool first = c == (uint32_t)lane;
         long long blo, bhi;
         if (lds) { blo = Bl[2 * c]; bhi = Bl[2 * c + 1]; }
         else {
@@ -262,9 +236,9 @@ __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint
             __hip_atomic_store(&B[2 * c], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&B[2 * c + 1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (r.mrep[g] != c) continue;                           // representatives only
+        if ((first ? mrep0 : r.mrep[g]) != c) continue;         // representatives only
         const double bwd = dev_limbs_to_double(blo, bhi, r.wshift);
-        const double fb = r.inv[g] * bwd, ff = r.ff[g];
+        const double fb = (first ? inv0 : r.inv[g]) * bwd, ff = first ? ff0 : r.ff[g];
         bool kill = false;
         if (r.twosided) {
             if (fb != 0 && ff != 0) { if (fb < r.overlap || ff < r.overlap) kill = true; }
@@ -274,12 +248,15 @@ __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint
             if (ff < r.overlap) kill = true;
         }
         const uint8_t k = kill ? 0 : 1;
-        if (k != keep[g]) { __hip_atomic_store(&keep[g], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); any = true; }
+        const uint8_t kold = first ? kold0 : keep[g];           // only this workgroup writes the bits of timestep t
+        if (k != kold) { __hip_atomic_store(&keep[g], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); any = true; }
     }
     const bool wave_any = __ballot(any) != 0ull;
     if (lane == 0) {
         dcur[t] = wave_any ? 1 : 0;
-        if (wave_any) atomicOr(&r.changed[it], 1u);
+        // "some bit flipped in pass it": a plain store into one of 64 slots.  (One atomicOr per workgroup on a single word
+        // serialised in L2: 2705 of them were 32 of pass 0's 35 us.)
+        if (wave_any) r.changed[it * CTK_CHG_SLOTS + (t & (CTK_CHG_SLOTS - 1))] = 1u;
     }
 }
 
@@ -513,7 +490,12 @@ __global__ __launch_bounds__(64) void k_compact_cands(ResolveDev r, const CtkCan
         m.scal[CTK_MAIL_NCAND] = r.T > 0 ? cand_off[r.T] : 0u;
         m.scal[CTK_MAIL_ND] = *r.dcount;
         m.scal[CTK_MAIL_NLAB] = *nlab_ptr;
-        for (int k = 0; k < round; k++) m.scal[CTK_MAIL_CHANGED + k] = r.changed[it0 + k];
+    }
+    if (blockIdx.x == 0) {                                   // (the workgroup is one wave)
+        for (int k = 0; k < round; k++) {
+            const bool any = __ballot(r.changed[(it0 + k) * CTK_CHG_SLOTS + threadIdx.x] != 0u) != 0ull;
+            if (threadIdx.x == 0) m.scal[CTK_MAIL_CHANGED + k] = any ? 1u : 0u;
+        }
     }
 }
 
