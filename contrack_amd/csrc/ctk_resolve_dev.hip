@@ -348,15 +348,21 @@ __global__ void k_rs_labels(ResolveDev r)
 struct CtkCand {
     int32_t t, yy, ll, lr;
 };
-__device__ inline void cand_claim(const ResolveDev &r, int32_t l)
+// Dense ids for the labels on surviving seam rows (claim order).  A label sits on many consecutive rows and
+// timesteps: only the first row of a stretch tries (compare with the previous lane), the CAS on dmap[l] elects one
+// winner per label, and the winners of a wave take their ids with ONE atomicAdd (same-address atomics serialise).
+__device__ inline bool cand_try_claim(const ResolveDev &r, int32_t l)
 {
-    if (r.dmap[l] != 0 || atomicCAS(&r.dmap[l], 0u, 0xffffffffu) != 0u) return;
-    const uint32_t id = atomicAdd(r.dcount, 1u);
+    return r.dmap[l] == 0u && atomicCAS(&r.dmap[l], 0u, 0xffffffffu) == 0u;
+}
+__device__ inline void cand_publish(const ResolveDev &r, int32_t l, uint32_t id)
+{
     r.dorig[id] = l;
     int32_t *d = r.dbox + 6 * (int64_t)id;                // box of the label (find_objects ONCE, contrack.py:753): filled
     d[0] = INT32_MAX; d[1] = -1; d[2] = INT32_MAX; d[3] = -1; d[4] = INT32_MAX; d[5] = -1;    // by k_rs_cand_groups
     r.dmap[l] = id + 1;                                   // read by later launches
 }
+
 // Only labels that occur in some seam row with two DIFFERENT labels can ever take part in a relabel
 // operation (the first op needs such a row; every later `hi`/`lo` is a label of such a row or the `lo` of an
 // earlier op).  Rows with equal labels that are not marked can therefore be dropped before the host driver.
@@ -367,18 +373,33 @@ __global__ __launch_bounds__(256) void k_rs_cand_mark(ResolveDev r, const CtkSea
     const int t = (int)blockIdx.x;
     const uint32_t n = seam_cnt[t], cb = r.cprefix[t];
     const CtkSeam *scratch = seams + seam_off[t];
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const CtkSeam q = scratch[i];
+    const int lane = lane_id();
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {                     // whole waves enter together (shuffles / ballots below)
+        const uint32_t i = i0 + threadIdx.x;
         int2 v = make_int2(-1, -1);
-        if (r.keep0[cb + r.mrep[cb + q.cl]]) {
-            v.x = r.lab[cb + q.cl]; v.y = r.lab[cb + q.cr];
-            if (v.x != v.y) { mark[v.x] = 1; mark[v.y] = 1; }
-            // dense ids for every label on a surviving seam row (a superset of the labels in candidate records:
-            // claiming here, one thread per row, keeps the latency chain out of the one-thread-per-timestep walk)
-            cand_claim(r, v.x);
-            if (v.y != v.x) cand_claim(r, v.y);
+        if (i < n) {
+            const CtkSeam q = scratch[i];
+            if (r.keep0[cb + r.mrep[cb + q.cl]]) {
+                v.x = r.lab[cb + q.cl]; v.y = r.lab[cb + q.cr];
+                if (v.x != v.y) { mark[v.x] = 1; mark[v.y] = 1; }
+            }
+            res[(int64_t)t * ny + i] = v;
         }
-        res[(int64_t)t * ny + i] = v;
+        const int px = __shfl_up(v.x, 1), py = __shfl_up(v.y, 1);
+        const bool try_x = v.x >= 0 && !(lane > 0 && px == v.x);
+        const bool try_y = v.x >= 0 && v.y != v.x && !(lane > 0 && py == v.y);
+        const bool won_x = try_x && cand_try_claim(r, v.x);
+        const bool won_y = try_y && cand_try_claim(r, v.y);
+        const uint64_t bx = __ballot(won_x), by = __ballot(won_y);
+        const uint32_t nxw = (uint32_t)__popcll(bx), nyw = (uint32_t)__popcll(by);
+        if (nxw + nyw) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(r.dcount, nxw + nyw);
+            base = (uint32_t)__shfl((int)base, 0);
+            const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            if (won_x) cand_publish(r, v.x, base + (uint32_t)__popcll(bx & below));
+            if (won_y) cand_publish(r, v.y, base + nxw + (uint32_t)__popcll(by & below));
+        }
     }
 }
 
