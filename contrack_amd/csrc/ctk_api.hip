@@ -51,6 +51,7 @@ struct ctk_handle {
     hipStream_t stream = nullptr;
     hipStream_t side[2] = {nullptr, nullptr};      // the labelling variants of one shard run concurrently
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipEvent_t ev_scan = nullptr;                 // after the run scan of stage 1 (the host waits for it, not for the stream)
     State state = ST_IDLE;
     // geometry of the current shard
     int64_t T = 0;
@@ -86,6 +87,10 @@ struct ctk_handle {
     int64_t c_T = -1; bool c_f64 = false, c_thr_valid = false, c_w_valid = false; int c_cmp = -1;
     int64_t last_alive = 0;
     int64_t rowoff_T = -1; int rowoff_ny = -1; void *rowoff_p = nullptr;     // what seam_rowoff currently holds
+    // speculative launch of the 2-D labelling: capacity (in runs) of the run-indexed buffers, the previous call's variants
+    uint32_t runs_cap = 0;
+    struct { bool v1 = false, v2 = false, v3 = false, glb = false; } spec_set;
+    int spec_ny = -1, spec_nx = -1; int64_t spec_T = -1;
     size_t mail_cap_c = 0, mail_cap_d = 0, mail_want_c = 0, mail_want_d = 0;
     size_t h_ops_cap = 0;
     const int32_t *d_op_next = nullptr;
@@ -225,7 +230,8 @@ extern "C" int ctk_create(ctk_handle **out, int device)
         if (hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming) != hipSuccess) { ctk_destroy(h); return ctk_set_error(CTK_E_NODEVICE, "hipStreamCreate failed"); }
     }
-    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) { ctk_destroy(h); return ctk_set_error(CTK_E_NODEVICE, "hipEventCreate failed"); }
+    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_scan, hipEventDisableTiming) != hipSuccess) { ctk_destroy(h); return ctk_set_error(CTK_E_NODEVICE, "hipEventCreate failed"); }
     if (hipHostMalloc((void **)&h->h_mail1, 256, hipHostMallocDefault) != hipSuccess) { ctk_destroy(h); return ctk_set_error(CTK_E_NOMEM, "hipHostMalloc failed"); }
     memset(h->h_mail1, 0, 256);
     memset(h->ms, 0, sizeof(h->ms));
@@ -259,6 +265,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
     if (h->ev_ready) for (int k = 0; k <= CTK_K_COUNT; k++) { (void)hipEventDestroy(h->ev[k][0]); (void)hipEventDestroy(h->ev[k][1]); }
     for (int k = 0; k < 2; k++) { if (h->side[k]) (void)hipStreamDestroy(h->side[k]); if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_scan) (void)hipEventDestroy(h->ev_scan);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -432,10 +439,56 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, h->h_mail1);
         HIPCHK(hipGetLastError());
     }
-    // runs per timestep decide the workspace size and whether the global-memory variant is needed: the scan kernel
-    // wrote total / maximum / overflow / last count into the pinned mailbox
+    HIPCHK(hipEventRecord(h->ev_scan, s));
+    // 2-D labelling.  The variants take disjoint sets of timesteps (by run count; nruns == 0 goes to the small one) and
+    // run on concurrent streams.  Which variants are needed and how large the run-indexed buffers must be is known only
+    // after the run scan -- but a call on the same kind of data as the previous one needs the same: the launch is made
+    // SPECULATIVELY with the previous call's buffers and variant set before the host waits for the scan (every workgroup
+    // checks its runs against the buffers' capacity), and only what turns out to be missing is launched afterwards.
+    struct VariantSet { bool v1, v2, v3, glb; };
+    auto launch_label2d = [&](const VariantSet &vs, uint32_t cap_runs) -> int {
+        Label2dArgs a;
+        a.mask = P<uint64_t>(h->mask); a.wstart = P<uint16_t>(h->wstart); a.rowstart = P<uint32_t>(h->rowstart);
+        a.run_base = P<uint32_t>(h->run_base); a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp);
+        a.cs_mrep = P<uint32_t>(h->cs_mrep); a.cs_box = P<uint32_t>(h->cs_box); a.cs_area = P<int64_t>(h->cs_area);
+        a.seams = P<CtkSeam>(h->seams); a.seam_cnt = P<uint32_t>(h->seam_cnt); a.counters = P<uint32_t>(h->counters);
+        a.wlo = P<int32_t>(h->wlo); a.whi = P<int32_t>(h->wlo) + h->ny;
+        a.ny = ny; a.nx = nx; a.W = W; a.lds_cap = CTK_LDS_RUNS; a.cap_runs = cap_runs;
+        a.g_x0 = P<uint16_t>(h->g_x0); a.g_x1 = P<uint16_t>(h->g_x1); a.g_y = P<uint16_t>(h->g_y);
+        a.g_parent = P<uint32_t>(h->g_parent); a.g_root = P<uint32_t>(h->g_root); a.g_idmap = P<uint32_t>(h->g_idmap);
+        if (vs.v2 || vs.v3) HIPCHK(hipEventRecord(h->ev_fork, s));
+        if (vs.v1) k_label2d_lds<1024, 288, -1, 256><<<(int)T, 256, 0, s>>>(a);
+        if (vs.v2) {
+            HIPCHK(hipStreamWaitEvent(h->side[0], h->ev_fork, 0));
+            k_label2d_lds<2048, 512, 1024, 512><<<(int)T, 512, 0, h->side[0]>>>(a);
+            HIPCHK(hipEventRecord(h->ev_join[0], h->side[0]));
+        }
+        if (vs.v3) {
+            HIPCHK(hipStreamWaitEvent(h->side[1], h->ev_fork, 0));
+            k_label2d_lds<4096, 512, 2048, 1024><<<(int)T, 1024, 0, h->side[1]>>>(a);
+            HIPCHK(hipEventRecord(h->ev_join[1], h->side[1]));
+        }
+        if (vs.v2) HIPCHK(hipStreamWaitEvent(s, h->ev_join[0], 0));
+        if (vs.v3) HIPCHK(hipStreamWaitEvent(s, h->ev_join[1], 0));
+        if (vs.glb) k_label2d_glb<<<(int)T, 256, 0, s>>>(a, P<uint32_t>(h->g_rs));
+        HIPCHK(hipGetLastError());
+        return CTK_OK;
+    };
+    if (nrows > 0x7fffffff) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: more than 2^31 rows in one shard");
+    h->seam_cap = (uint32_t)nrows;
+    CTKCHK(ensure(h, h->seams, (size_t)nrows * sizeof(CtkSeam)));
+    CTKCHK(ensure(h, h->seam_cnt, (size_t)T * 4));
+    CTKCHK(ensure(h, h->seam_off, (size_t)(T + 1) * 4));
+    const bool spec = T > 0 && h->runs_cap > 0 && h->spec_ny == ny && h->spec_nx == nx && (!h->spec_set.glb || h->spec_T >= T);
+    VariantSet launched = {false, false, false, false};
+    if (spec) {
+        Timer tm(h, CTK_K_LABEL2D);
+        launched = {h->spec_set.v1, h->spec_set.v2, h->spec_set.v3, h->spec_set.glb};
+        CTKCHK(launch_label2d(launched, h->runs_cap));
+    }
+    // the scan kernel wrote total / maximum / overflow / last count into the pinned mailbox
     HT("thr+scan launched");
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipEventSynchronize(h->ev_scan));                      // not the stream: the speculative labelling may still be running
     const uint32_t m_total = h->h_mail1[0], m_max = h->h_mail1[1], m_ovf = h->h_mail1[2], m_last = h->h_mail1[3];
     HT("sync1 done");
     if (m_ovf & CTK_OVF_RUNS) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: more than 2^32-1 runs in one shard");
@@ -446,59 +499,42 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     memset(h->stats, 0, sizeof(h->stats));
     h->stats[CTK_S_RUNS] = h->total_runs; h->stats[CTK_S_MAX_RUNS_STEP] = h->max_runs_step;
     const size_t R = h->total_runs;
-    CTKCHK(ensure(h, h->run_comp, R * 4));
-    CTKCHK(ensure(h, h->run_val, R * 4));
-    CTKCHK(ensure(h, h->cs_mrep, R * 4));
-    CTKCHK(ensure(h, h->cs_box, R * 16));
-    CTKCHK(ensure(h, h->cs_area, R * 16));
-    CTKCHK(ensure(h, h->d_mrep, R * 4));
-    CTKCHK(ensure(h, h->d_box, R * 8));
-    CTKCHK(ensure(h, h->d_area, R * 16));
-    if (nrows > 0x7fffffff) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: more than 2^31 rows in one shard");
-    h->seam_cap = (uint32_t)nrows;
-    CTKCHK(ensure(h, h->seams, (size_t)nrows * sizeof(CtkSeam)));
-    CTKCHK(ensure(h, h->seam_cnt, (size_t)T * 4));
-    CTKCHK(ensure(h, h->seam_off, (size_t)(T + 1) * 4));
-    CTKCHK(ensure(h, h->d_comp_t, R * 4));
+    const bool fits = spec && R <= h->runs_cap;
+    if (!fits) {
+        // run-indexed buffers with head room, so that the next calls on similar data can launch speculatively
+        const size_t Rc = R + R / 8 + 1024;
+        CTKCHK(ensure(h, h->run_comp, Rc * 4));
+        CTKCHK(ensure(h, h->run_val, Rc * 4));
+        CTKCHK(ensure(h, h->cs_mrep, Rc * 4));
+        CTKCHK(ensure(h, h->cs_box, Rc * 16));
+        CTKCHK(ensure(h, h->cs_area, Rc * 16));
+        CTKCHK(ensure(h, h->d_mrep, Rc * 4));
+        CTKCHK(ensure(h, h->d_box, Rc * 8));
+        CTKCHK(ensure(h, h->d_area, Rc * 16));
+        CTKCHK(ensure(h, h->d_comp_t, Rc * 4));
+        if (h->need_glb || h->spec_set.glb) {
+            CTKCHK(ensure(h, h->g_x0, Rc * 2)); CTKCHK(ensure(h, h->g_x1, Rc * 2)); CTKCHK(ensure(h, h->g_y, Rc * 2));
+            CTKCHK(ensure(h, h->g_parent, Rc * 4)); CTKCHK(ensure(h, h->g_root, Rc * 4)); CTKCHK(ensure(h, h->g_idmap, Rc * 4));
+        }
+        h->runs_cap = (uint32_t)std::min<size_t>(Rc, 0xffffffffu);
+        launched = {false, false, false, false};                  // whatever ran speculatively ran on too small buffers
+    }
     if (h->need_glb) {
-        CTKCHK(ensure(h, h->g_x0, R * 2)); CTKCHK(ensure(h, h->g_x1, R * 2)); CTKCHK(ensure(h, h->g_y, R * 2));
-        CTKCHK(ensure(h, h->g_parent, R * 4)); CTKCHK(ensure(h, h->g_root, R * 4)); CTKCHK(ensure(h, h->g_idmap, R * 4));
+        const size_t Rc = h->runs_cap;
+        CTKCHK(ensure(h, h->g_x0, Rc * 2)); CTKCHK(ensure(h, h->g_x1, Rc * 2)); CTKCHK(ensure(h, h->g_y, Rc * 2));
+        CTKCHK(ensure(h, h->g_parent, Rc * 4)); CTKCHK(ensure(h, h->g_root, Rc * 4)); CTKCHK(ensure(h, h->g_idmap, Rc * 4));
         CTKCHK(ensure(h, h->g_rs, (size_t)T * (ny + 1) * 4));
     }
     if (T > 0) {
-        Label2dArgs a;
-        a.mask = P<uint64_t>(h->mask); a.wstart = P<uint16_t>(h->wstart); a.rowstart = P<uint32_t>(h->rowstart);
-        a.run_base = P<uint32_t>(h->run_base); a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp);
-        a.cs_mrep = P<uint32_t>(h->cs_mrep); a.cs_box = P<uint32_t>(h->cs_box); a.cs_area = P<int64_t>(h->cs_area);
-        a.seams = P<CtkSeam>(h->seams); a.seam_cnt = P<uint32_t>(h->seam_cnt); a.counters = P<uint32_t>(h->counters);
-        a.wlo = P<int32_t>(h->wlo); a.whi = P<int32_t>(h->wlo) + h->ny;
-        a.ny = ny; a.nx = nx; a.W = W; a.lds_cap = CTK_LDS_RUNS;
-        a.g_x0 = P<uint16_t>(h->g_x0); a.g_x1 = P<uint16_t>(h->g_x1); a.g_y = P<uint16_t>(h->g_y);
-        a.g_parent = P<uint32_t>(h->g_parent); a.g_root = P<uint32_t>(h->g_root); a.g_idmap = P<uint32_t>(h->g_idmap);
-        Timer tm(h, CTK_K_LABEL2D);
-        HT("before label2d launch");
-        // The variants take disjoint sets of timesteps (by run count): launch them on concurrent streams.
-        // nruns == 0 timesteps are handled by the small variant (RUNS_BELOW = -1).
-        const bool v2 = h->max_runs_step > 1024, v3 = h->max_runs_step > 2048;
-        if (v2 || v3) HIPCHK(hipEventRecord(h->ev_fork, s));
-        k_label2d_lds<1024, 288, -1, 256><<<(int)T, 256, 0, s>>>(a);
-        if (v2) {
-            HIPCHK(hipStreamWaitEvent(h->side[0], h->ev_fork, 0));
-            k_label2d_lds<2048, 512, 1024, 512><<<(int)T, 512, 0, h->side[0]>>>(a);
-            HIPCHK(hipEventRecord(h->ev_join[0], h->side[0]));
+        const VariantSet need = {true, h->max_runs_step > 1024, h->max_runs_step > 2048, h->need_glb};
+        const VariantSet missing = {need.v1 && !launched.v1, need.v2 && !launched.v2, need.v3 && !launched.v3, need.glb && !launched.glb};
+        if (missing.v1 || missing.v2 || missing.v3 || missing.glb) {
+            HT("before label2d launch");
+            Timer tm(h, CTK_K_LABEL2D);
+            CTKCHK(launch_label2d(missing, h->runs_cap));
         }
-        if (v3) {
-            HIPCHK(hipStreamWaitEvent(h->side[1], h->ev_fork, 0));
-            k_label2d_lds<4096, 512, 2048, 1024><<<(int)T, 1024, 0, h->side[1]>>>(a);
-            HIPCHK(hipEventRecord(h->ev_join[1], h->side[1]));
-        }
-        if (v2) HIPCHK(hipStreamWaitEvent(s, h->ev_join[0], 0));
-        if (v3) HIPCHK(hipStreamWaitEvent(s, h->ev_join[1], 0));
-        HIPCHK(hipGetLastError());
-        if (h->need_glb) {
-            k_label2d_glb<<<(int)T, 256, 0, s>>>(a, P<uint32_t>(h->g_rs));
-            HIPCHK(hipGetLastError());
-        }
+        h->spec_set.v1 = true; h->spec_set.v2 = need.v2; h->spec_set.v3 = need.v3; h->spec_set.glb = need.glb;
+        h->spec_ny = ny; h->spec_nx = nx; h->spec_T = T;
     }
     {
         Timer tm(h, CTK_K_SCAN);

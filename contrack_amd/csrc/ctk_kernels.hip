@@ -334,6 +334,7 @@ struct Label2dArgs {
     const int32_t *wlo, *whi;      // [ny] weight limbs
     int ny, nx, W;
     uint32_t lds_cap;              // runs the LDS variant carries
+    uint32_t cap_runs;             // runs the run-indexed buffers hold (a speculative launch may precede the size check)
     // global scratch for the fallback variant (indexed by run_base[t] + r)
     uint16_t *g_x0, *g_x1, *g_y;
     uint32_t *g_parent, *g_root, *g_idmap;
@@ -554,6 +555,7 @@ __global__ __launch_bounds__(THREADS) void k_label2d_lds(Label2dArgs a)
     const int t = (int)blockIdx.x;
     const uint32_t nruns = a.run_base[t + 1] - a.run_base[t];
     if (nruns > RUNS || (int64_t)nruns <= (int64_t)RUNS_BELOW || a.ny > CTK_LDS_NY) return;        // another variant takes it
+    if (a.run_base[t + 1] > a.cap_runs) return;                    // buffers too small: the host relaunches after growing them
     if (nruns == 0) {
         if (threadIdx.x == 0) { a.ncomp[t] = 0; a.seam_cnt[t] = 0; }
         return;
@@ -580,6 +582,7 @@ __global__ __launch_bounds__(256) void k_label2d_glb(Label2dArgs a, uint32_t *g_
     const uint32_t rb = a.run_base[t];
     const uint32_t nruns = a.run_base[t + 1] - rb;
     if (!(nruns > CTK_LDS_RUNS || a.ny > CTK_LDS_NY)) return;
+    if (a.run_base[t + 1] > a.cap_runs) return;
     __shared__ uint32_t sm_scan[8];
     label2d_body<256, uint32_t, 1>(a, t, nruns, a.g_x0 + rb, a.g_x1 + rb, a.g_y + rb, a.g_parent + rb, a.g_root + rb,
                                    a.g_idmap + rb, g_rs + (int64_t)t * (a.ny + 1), sm_scan, a.mask + (int64_t)t * a.ny * a.W, false, nullptr);
