@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="era5_1deg_djf30")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed passes that time every kernel group (profiling runs)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = one member of the workload per GPU, concatenated on the time axis (default); "
                          "strong = the single-GPU slab split over the GPUs")
@@ -143,7 +144,7 @@ def main():
     # per-group kernel times of the small kernels: a few extra, untimed passes with events around every group (each
     # event record is a command of its own and would stretch the timed passes)
     trk.set_timing(2)
-    extra, acc2 = 5, {}
+    extra, acc2 = (0 if args.no_extra else 5), {}
     for _ in range(extra):
         step()
         for k, v in trk.timings().items():

@@ -46,6 +46,8 @@ enum State { ST_IDLE = 0, ST_LABELLED, ST_OVERLAPPED, ST_TABLES, ST_EXTENTS };
 
 }  // namespace
 
+#define CTK_KI_ROWCOUNT (CTK_K_COUNT + 1)
+
 struct ctk_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -112,8 +114,8 @@ struct ctk_handle {
     int32_t nops = 0;
     // timing
     int timing = 0;
-    hipEvent_t ev[CTK_K_COUNT + 1][2];
-    bool ev_used[CTK_K_COUNT + 1];
+    hipEvent_t ev[CTK_K_COUNT + 2][2];           // + one internal pair: stage-1 row count / run scan, reported inside CTK_K_SCAN
+    bool ev_used[CTK_K_COUNT + 2];
     double ms[CTK_NTIMERS];
     bool ev_ready = false;
 };
@@ -262,7 +264,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
     if (h->h_mail) (void)hipHostFree(h->h_mail);
     if (h->h_mail1) (void)hipHostFree(h->h_mail1);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
-    if (h->ev_ready) for (int k = 0; k <= CTK_K_COUNT; k++) { (void)hipEventDestroy(h->ev[k][0]); (void)hipEventDestroy(h->ev[k][1]); }
+    if (h->ev_ready) for (int k = 0; k <= CTK_KI_ROWCOUNT; k++) { (void)hipEventDestroy(h->ev[k][0]); (void)hipEventDestroy(h->ev[k][1]); }
     for (int k = 0; k < 2; k++) { if (h->side[k]) (void)hipStreamDestroy(h->side[k]); if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_scan) (void)hipEventDestroy(h->ev_scan);
@@ -275,7 +277,7 @@ extern "C" int ctk_set_timing(ctk_handle *h, int enable)
     if (!h || enable < 0 || enable > 2) return ctk_set_error(CTK_E_INVALID, "ctk_set_timing: null handle or level not in 0..2");
     HIPCHK(hipSetDevice(h->device));
     if (enable && !h->ev_ready) {
-        for (int k = 0; k <= CTK_K_COUNT; k++) { HIPCHK(hipEventCreate(&h->ev[k][0])); HIPCHK(hipEventCreate(&h->ev[k][1])); }
+        for (int k = 0; k <= CTK_KI_ROWCOUNT; k++) { HIPCHK(hipEventCreate(&h->ev[k][0])); HIPCHK(hipEventCreate(&h->ev[k][1])); }
         h->ev_ready = true;
     }
     h->timing = enable;
@@ -320,10 +322,10 @@ extern "C" int ctk_set_device_resolve(ctk_handle *h, int enable)
 static int collect_event_times(ctk_handle *h)
 {
     if (!h->timing || !h->ev_ready) return CTK_OK;
-    for (int k = 0; k <= CTK_K_COUNT; k++) {
+    for (int k = 0; k <= CTK_KI_ROWCOUNT; k++) {
         if (!h->ev_used[k]) continue;
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->ev[k][0], h->ev[k][1]) == hipSuccess) h->ms[k] += ms;
+        if (hipEventElapsedTime(&ms, h->ev[k][0], h->ev[k][1]) == hipSuccess) h->ms[k == CTK_KI_ROWCOUNT ? CTK_K_SCAN : k] += ms;
         h->ev_used[k] = false;
     }
     return CTK_OK;
@@ -434,7 +436,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         HIPCHK(hipGetLastError());
     }
     {
-        Timer tm(h, CTK_K_SCAN);
+        Timer tm(h, CTK_KI_ROWCOUNT);
         if (T > 0) k_rowcount<<<(int)T, 256, 0, s>>>(P<uint64_t>(h->mask), ny, W, P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart), P<uint32_t>(h->tcount));
         k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, h->h_mail1);
         HIPCHK(hipGetLastError());
@@ -834,7 +836,7 @@ static int launch_extents(ctk_handle *h, bool ext_filled = false)
         ExtentArgs a;
         a.mask = P<uint64_t>(h->mask); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
         a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp); a.cprefix = P<uint32_t>(h->cprefix);
-        a.comp_label = P<int32_t>(h->comp_label); a.ext = P<int32_t>(h->ext); a.n_labels = h->n_labels; a.t_begin = h->t_begin;
+        a.comp_label = P<int32_t>(h->comp_label); a.box = P<uint16_t>(h->d_box); a.ext = P<int32_t>(h->ext); a.n_labels = h->n_labels; a.t_begin = h->t_begin;
         a.fold = fold_args(h); a.ny = h->ny; a.nx = h->nx; a.W = h->W;
         k_extent<<<(int)h->T, 256, 0, s>>>(a);
         HIPCHK(hipGetLastError());

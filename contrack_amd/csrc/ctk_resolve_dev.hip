@@ -405,10 +405,9 @@ __global__ __launch_bounds__(256) void k_rs_cand_mark(ResolveDev r, const CtkSea
 
 // surviving seam rows of timestep t, run-length grouped: consecutive rows (y, y+1, ...) with the same pair of
 // labels become ONE record {t, y0 | y1 << 16, label at x=0, label at x=nx-1}; (t, y) order.  One wave per
-// timestep: the rows are staged in LDS in parallel (their loads are the latency), lane 0 walks them and writes
-// the groups into a row-indexed scratch; a scan + gather makes them dense.  The same wave adds the boxes of
-// the timestep's components to the boxes of the labels that have a dense id (the only boxes anyone needs).
-#define CTK_CAND_CHUNK 512
+// timestep, one row per lane, group boundaries from ballots; the groups go into a row-indexed scratch, a scan +
+// gather makes them dense.  The same wave adds the boxes of the timestep's components to the boxes of the labels
+// that have a dense id (the only boxes anyone needs).
 __global__ __launch_bounds__(64) void k_rs_cand_groups(ResolveDev r, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
                                                        const uint32_t *__restrict__ seam_off, const int2 *__restrict__ res,
                                                        const uint8_t *__restrict__ mark, int ny, int64_t t_begin, uint32_t *__restrict__ cand_cnt,
@@ -434,36 +433,43 @@ __global__ __launch_bounds__(64) void k_rs_cand_groups(ResolveDev r, const CtkSe
     const CtkSeam *sc = seams + seam_off[t];
     const int2 *rs = res + t * ny;
     CtkCand *dst = scratch + t * ny;                      // at most one group per seam row
-    __shared__ int2 sv[CTK_CAND_CHUNK];
-    __shared__ int32_t sy[CTK_CAND_CHUNK];
+    // 64 rows per step, one per lane.  A row STARTS a group unless the previous row is valid, carries the same pair of
+    // labels and is the row right above; the group's record is written by its first row (y1 = y0) and its last row
+    // overwrites the y1 half.  State carried between steps: the last row of the previous step.
     uint32_t ng = 0;
-    CtkCand g;
-    g.t = (int32_t)(t_begin + t); g.yy = 0; g.ll = 0; g.lr = 0;
-    int32_t gy0 = 0, gy1 = -2;
-    bool open = false;
-    for (uint32_t base = 0; base < n; base += CTK_CAND_CHUNK) {
-        const uint32_t m = min((uint32_t)CTK_CAND_CHUNK, n - base);
-        for (uint32_t i = lane; i < m; i += 64) {
-            int2 v = rs[base + i];
-            if (v.x < 0 || (v.x == v.y && !mark[v.x])) v.x = -1;      // filtered out, or can never take part in an op
-            sv[i] = v;
-            sy[i] = (int32_t)sc[base + i].y;
+    bool c_valid = false;
+    int32_t c_ll = 0, c_lr = 0, c_y = 0;
+    const int32_t tt = (int32_t)(t_begin + t);
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        int2 v = make_int2(-1, -1);
+        int32_t y = 0;
+        if (i < n) {
+            v = rs[i];
+            if (v.x >= 0 && v.x == v.y && !mark[v.x]) v.x = -1;      // can never take part in an op
+            y = (int32_t)sc[i].y;
         }
-        __syncthreads();
-        if (lane == 0) {
-            for (uint32_t i = 0; i < m; i++) {
-                const int2 v = sv[i];
-                if (v.x < 0) continue;
-                const int32_t y = sy[i];
-                if (open && v.x == g.ll && v.y == g.lr && y == gy1 + 1) { gy1 = y; continue; }
-                if (open) { g.yy = gy0 | (gy1 << 16); dst[ng++] = g; }
-                open = true; g.ll = v.x; g.lr = v.y; gy0 = y; gy1 = y;
-            }
+        const bool valid = v.x >= 0;
+        int32_t pll = __shfl_up(v.x, 1), plr = __shfl_up(v.y, 1), py = __shfl_up(y, 1);
+        bool pvalid = pll >= 0;
+        if (lane == 0) { pll = c_ll; plr = c_lr; py = c_y; pvalid = c_valid; }
+        const bool start = valid && !(pvalid && pll == v.x && plr == v.y && y == py + 1);
+        const uint64_t S = __ballot(start), V = __ballot(valid);
+        const uint64_t upto = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+        const uint32_t idx = ng + (uint32_t)__popcll(S & upto) - 1u;          // record of this row's group
+        if (start) { CtkCand g; g.t = tt; g.yy = y | (y << 16); g.ll = v.x; g.lr = v.y; dst[idx] = g; }
+        // the previous step's last row ended its group if this step's first row does not continue it
+        if (lane == 0 && c_valid && (!valid || start)) reinterpret_cast<uint16_t *>(&dst[ng - 1u].yy)[1] = (uint16_t)c_y;
+        if (valid && lane < 63) {
+            const bool next_valid = (V >> (lane + 1)) & 1ull, next_start = (S >> (lane + 1)) & 1ull;
+            if ((!next_valid || next_start) && !start) reinterpret_cast<uint16_t *>(&dst[idx].yy)[1] = (uint16_t)y;
         }
-        __syncthreads();
+        ng += (uint32_t)__popcll(S);
+        c_valid = (V >> 63) & 1ull;
+        c_ll = __shfl(v.x, 63); c_lr = __shfl(v.y, 63); c_y = __shfl(y, 63);
     }
     if (lane == 0) {
-        if (open) { g.yy = gy0 | (gy1 << 16); dst[ng++] = g; }
+        if (c_valid) reinterpret_cast<uint16_t *>(&dst[ng - 1u].yy)[1] = (uint16_t)c_y;
         cand_cnt[t] = ng;
     }
 }
