@@ -863,6 +863,15 @@ struct ExtentArgs {
     int ny, nx, W;
 };
 
+// time extent of an id: look before the atomic (a long-lived id gets one update per timestep -- or per pixel -- and
+// same-address atomics serialise)
+__device__ inline void ext_update(int32_t *tmin, int32_t *tmax, int32_t l, int32_t tg)
+{
+    // plain loads: a stale bound is looser than the true one -- at worst a superfluous atomic
+    if (tg < tmin[l]) atomicMin(&tmin[l], tg);
+    if (tg > tmax[l]) atomicMax(&tmax[l], tg);
+}
+
 __global__ __launch_bounds__(256) void k_extent(ExtentArgs a)
 {
     const int t = (int)blockIdx.x;
@@ -875,7 +884,7 @@ __global__ __launch_bounds__(256) void k_extent(ExtentArgs a)
     __syncthreads();
     for (uint32_t c = tid; c < n; c += 256) {
         int32_t l = a.comp_label[cb + c];
-        if (l > 0) { atomicMin(&tmin[l], tg); atomicMax(&tmax[l], tg); }
+        if (l > 0) { ext_update(tmin, tmax, l, tg); }
         else if (l < 0) { atomicMin(&ylo, (int)a.box[4 * (int64_t)(cb + c)]); atomicMax(&yhi, (int)a.box[4 * (int64_t)(cb + c) + 1]); }
     }
     __syncthreads();
@@ -888,8 +897,7 @@ __global__ __launch_bounds__(256) void k_extent(ExtentArgs a)
             int32_t l = a.comp_label[cb + rc[run]];
             if (l < 0) {
                 int32_t fl = fold_pixel(a.fold, -l, tg, y, x);
-                atomicMin(&tmin[fl], tg);
-                atomicMax(&tmax[fl], tg);
+                ext_update(tmin, tmax, fl, tg);
             }
         });
     }
