@@ -99,6 +99,7 @@ struct ctk_handle {
     int use_device_resolve = 1;
     int filter_round = CTK_JACOBI_ROUND;          // filter passes launched before convergence is checked
     uint32_t debug_pair_cap = 0;                  // test hook: pretend the pair table holds only this many records
+    uint32_t debug_mail_c = 0, debug_mail_d = 0;  // test hook: pretend the resolver mailbox holds only this many records / labels
     // host scratch of the seam driver, kept between calls (fresh 100+ KB vectors would page-fault every call)
     std::vector<int32_t> sd_first, sd_last, sd_inflow, sd_next, sd_lo;
     std::vector<CtkOp> sd_ops;
@@ -302,6 +303,13 @@ extern "C" int ctk_debug_set_pair_capacity(ctk_handle *h, uint32_t records)
 {
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
     h->debug_pair_cap = records;
+    return CTK_OK;
+}
+
+extern "C" int ctk_debug_set_mailbox(ctk_handle *h, uint32_t cand_records, uint32_t labels)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    h->debug_mail_c = cand_records; h->debug_mail_d = labels;
     return CTK_OK;
 }
 
@@ -1031,6 +1039,8 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     mail.dorig = (int32_t *)((char *)mail.cand + h->mail_cap_c * sizeof(CtkCand));
     mail.dbox = mail.dorig + h->mail_cap_d;
     mail.cap_c = (uint32_t)h->mail_cap_c; mail.cap_d = (uint32_t)h->mail_cap_d;
+    if (h->debug_mail_c) mail.cap_c = std::min(mail.cap_c, h->debug_mail_c);
+    if (h->debug_mail_d) mail.cap_d = std::min(mail.cap_d, h->debug_mail_d);
     uint32_t hs[CTK_MAIL_SCALARS];
     const double t0 = now_ms();
     int it_done = 0;
@@ -1089,7 +1099,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         const size_t cb = (size_t)ncand * sizeof(CtkCand), need = cb + nd * 28;
         h->sd_cand.resize(need);
         char *dst = (char *)h->sd_cand.data();
-        if ((size_t)ncand <= h->mail_cap_c && nd <= h->mail_cap_d) {
+        if ((size_t)ncand <= mail.cap_c && nd <= mail.cap_d) {
             h->ms[CTK_T_D2H] += now_ms() - t0;
             // work on a pageable copy: CPU reads of pinned memory are uncached (fine-grained) or slow (coarse-grained) on
             // this platform -- measured 173 / 111 us for the candidate loop vs 20 us + 20 us for copy + loop

@@ -140,6 +140,8 @@ int ctk_debug_label2d(ctk_handle *h, int before_seam, int32_t *lab /* (T,ny,nx) 
 
 /* test hook: the NEXT call behaves as if the pair table held only `records` entries (exercises regrowth) */
 int ctk_debug_set_pair_capacity(ctk_handle *h, uint32_t records);
+/* test hook: cap the device-written mailbox of the resolver hand-off (0 = no cap), so that the explicit-copy path runs */
+int ctk_debug_set_mailbox(ctk_handle *h, uint32_t cand_records, uint32_t labels);
 
 /* ---- timing (HIP events on the handle's stream) ----------------------------------------------- */
 #define CTK_K_THRESHOLD 0

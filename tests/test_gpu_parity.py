@@ -137,6 +137,18 @@ def test_host_and_device_resolver_agree_on_long_slabs(seed, T):
     assert np.array_equal(f_host, f_dev) and np.array_equal(f_host, f_dev2)
 
 
+@pytest.mark.parametrize("caps", [(2, 100000), (100000, 3), (1, 1)])
+def test_resolver_mailbox_too_small(caps):
+    """candidate records / label tables that do not fit the device-written mailbox travel by explicit copies"""
+    with _native.Tracker(0) as t:
+        t.debug_set_mailbox(*caps)
+        for name in ("chain_a", "chain_b", "syn2deg_s0", "busy_s0"):
+            g = golden_util.load(name)
+            f, n = t.track(g["anom"], g["thr"], _native.CMP_OPS[g["gorl"]], g["wrow"], g["overlap"], g["persistence"], g["twosided"])
+            assert t.stats()["host_path"] == 0 and t.stats()["seam_rows_to_driver"] > 3          # more than the caps hold
+            assert np.array_equal(f, g["flag"]), name
+
+
 def test_rare_paths_are_exercised(oracle_lib):
     """white noise at 181x360 drives every capacity path at once: the global-memory labelling variant (> 4096 runs
     per step), co-occurrence records that bypass the LDS hash table, and a pair table that has to be regrown (host
