@@ -830,7 +830,7 @@ static int upload_ops_dense(ctk_handle *h, const std::vector<CtkOp> &ops, const 
     return CTK_OK;
 }
 
-static int launch_extents(ctk_handle *h, bool ext_filled = false)
+static int launch_extents(ctk_handle *h, bool ext_filled = false, bool with_final = false)
 {
     hipStream_t s = h->stream;
     CTKCHK(ensure(h, h->ext, (size_t)(h->n_labels + 1) * 8));
@@ -844,7 +844,8 @@ static int launch_extents(ctk_handle *h, bool ext_filled = false)
         ExtentArgs a;
         a.mask = P<uint64_t>(h->mask); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
         a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp); a.cprefix = P<uint32_t>(h->cprefix);
-        a.comp_label = P<int32_t>(h->comp_label); a.box = P<uint16_t>(h->d_box); a.ext = P<int32_t>(h->ext); a.n_labels = h->n_labels; a.t_begin = h->t_begin;
+        a.comp_label = P<int32_t>(h->comp_label); a.lab = with_final ? P<int32_t>(h->rv_lab) : nullptr; a.comp_label_w = P<int32_t>(h->comp_label);
+        a.box = P<uint16_t>(h->d_box); a.ext = P<int32_t>(h->ext); a.n_labels = h->n_labels; a.t_begin = h->t_begin;
         a.fold = fold_args(h); a.ny = h->ny; a.nx = h->nx; a.W = h->W;
         k_extent<<<(int)h->T, 256, 0, s>>>(a);
         HIPCHK(hipGetLastError());
@@ -984,7 +985,7 @@ struct ResolveIn {
 };
 
 // returns CTK_OK, a negative error, or +1 = "take the host path" (pair table overflow / filter not converged)
-static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, int twosided)
+static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, int twosided, bool final_in_extent = false)
 {
     hipStream_t s = h->stream;
     const size_t R = in.R ? in.R : 1;
@@ -1135,7 +1136,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         h->stats[CTK_S_OPS] = 0;
         CTKCHK(upload_ops_dense(h, ops, nullptr, 0));                         // no ops: the launch still prepares ext / counters
     }
-    {
+    if (!final_in_extent) {                                                   // (single GPU: k_extent does it, see launch_extents)
         Timer tm(h, CTK_K_RESOLVE2);
         k_rs_final<<<gc, 256, 0, s>>>(r, fold_args(h), 0, in.comp_label);
         HIPCHK(hipGetLastError());
@@ -1162,7 +1163,7 @@ static int device_resolve_local(ctk_handle *h, double overlap, int twosided)
     in.seams = P<CtkSeam>(h->seams); in.seam_cnt = P<uint32_t>(h->seam_cnt); in.seam_off = P<uint32_t>(h->seam_rowoff);
     in.seam_cap = h->T * h->ny;
     in.comp_label = P<int32_t>(h->comp_label);
-    int rv = device_resolve(h, in, overlap, twosided);
+    int rv = device_resolve(h, in, overlap, twosided, true);
     if (rv == 0) { h->total_comps = (uint32_t)h->stats[CTK_S_COMPONENTS]; h->t_begin = 0; }
     return rv;
 }
@@ -1361,7 +1362,7 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
     int rv = h->use_device_resolve ? device_resolve_local(h, overlap, twosided) : 1;
     if (rv < 0) return rv;
     if (rv == 0) {
-        CTKCHK(launch_extents(h, true));
+        CTKCHK(launch_extents(h, true, true));                  // + the final id of every component (k_rs_final's work)
         h->state = ST_EXTENTS;
     } else {
         // host path: download the tables, resolve with the GPU-free reference implementation, upload

@@ -847,6 +847,28 @@ __device__ __forceinline__ void for_each_fg_pixel_in_row(const uint64_t *mw, int
 //     timestep; one atomic min/max per component; complex components fold pixel by pixel.
 //     ext[0..n] = min t, ext[n+1 .. 2n+1] = max t  (global timestep numbers)
 // ------------------------------------------------------------------------------------------------
+// R5: final id of a component with fresh label l (> 0), box q = {y0, y1, x0, x1}, at timestep t.  All of a component's
+// pixels move together through an op whose box contains the component's box, none moves when the boxes are disjoint;
+// anything else is resolved per pixel (returns -l).
+__device__ inline int32_t comp_final_label(const FoldArgs &f, int32_t l, int32_t t, const uint16_t *q)
+{
+    if (f.nops == 0) return l;
+    int32_t cur = l, s = 0;
+    for (;;) {
+        bool again = false;
+        for (int32_t idx = f.first[cur]; idx >= 0; idx = f.next[idx]) {
+            if (idx < s) continue;
+            const CtkOp o = f.ops[idx];
+            const bool t_in = t >= o.t0 && t <= o.t1;
+            const bool inside = t_in && q[0] >= o.y0 && q[1] <= o.y1 && q[2] >= o.x0 && q[3] <= o.x1;
+            const bool disjoint = !t_in || q[1] < o.y0 || q[0] > o.y1 || q[3] < o.x0 || q[2] > o.x1;
+            if (inside) { cur = o.lo; s = idx + 1; again = true; break; }
+            if (!disjoint) return -l;
+        }
+        if (!again) return cur;
+    }
+}
+
 struct ExtentArgs {
     const uint64_t *mask;
     const uint32_t *rowstart;
@@ -855,6 +877,8 @@ struct ExtentArgs {
     const uint32_t *ncomp;
     const uint32_t *cprefix;
     const int32_t *comp_label;     // dense (t,c) order
+    const int32_t *lab;            // if set: fresh labels -- the final id is computed here and written to comp_label_w
+    int32_t *comp_label_w;
     const uint16_t *box;           // [NC][4] y0, y1, x0, x1 of every component (rows of the per-pixel pass)
     int32_t *ext;
     int64_t n_labels;
@@ -883,7 +907,12 @@ __global__ __launch_bounds__(256) void k_extent(ExtentArgs a)
     if (tid == 0) { ylo = 0x7fffffff; yhi = -1; }
     __syncthreads();
     for (uint32_t c = tid; c < n; c += 256) {
-        int32_t l = a.comp_label[cb + c];
+        int32_t l;
+        if (a.lab) {                                       // single-GPU path: k_rs_final's work, one launch less
+            l = a.lab[cb + c];
+            if (l > 0) l = comp_final_label(a.fold, l, tg, a.box + 4 * (int64_t)(cb + c));
+            a.comp_label_w[cb + c] = l;
+        } else l = a.comp_label[cb + c];
         if (l > 0) { ext_update(tmin, tmax, l, tg); }
         else if (l < 0) { atomicMin(&ylo, (int)a.box[4 * (int64_t)(cb + c)]); atomicMax(&yhi, (int)a.box[4 * (int64_t)(cb + c) + 1]); }
     }

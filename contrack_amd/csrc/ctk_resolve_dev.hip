@@ -542,24 +542,7 @@ __global__ void k_rs_final(ResolveDev r, FoldArgs f, int64_t t_begin, int32_t *_
     const uint32_t nc = dev_ncomps(r);
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
         const int32_t l = r.lab[g];
-        if (l <= 0 || f.nops == 0) { comp_label[g] = l; continue; }
-        const uint16_t *q = r.box + 4 * (int64_t)g;
-        const int32_t t = (int32_t)(t_begin + r.comp_t[g]);
-        int32_t cur = l, s = 0;
-        bool cplx = false;
-        for (bool again = true; again && !cplx;) {
-            again = false;
-            for (int32_t idx = f.first[cur]; idx >= 0; idx = f.next[idx]) {
-                if (idx < s) continue;
-                const CtkOp o = f.ops[idx];
-                const bool t_in = t >= o.t0 && t <= o.t1;
-                const bool inside = t_in && q[0] >= o.y0 && q[1] <= o.y1 && q[2] >= o.x0 && q[3] <= o.x1;
-                const bool disjoint = !t_in || q[1] < o.y0 || q[0] > o.y1 || q[3] < o.x0 || q[2] > o.x1;
-                if (inside) { cur = o.lo; s = idx + 1; again = true; break; }
-                if (!disjoint) { cplx = true; break; }
-            }
-        }
-        comp_label[g] = cplx ? -l : cur;
+        comp_label[g] = l <= 0 ? l : comp_final_label(f, l, (int32_t)(t_begin + r.comp_t[g]), r.box + 4 * (int64_t)g);
     }
 }
 
