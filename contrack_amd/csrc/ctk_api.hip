@@ -1324,8 +1324,11 @@ extern "C" int ctk_shard_write(ctk_handle *h, int persistence, int32_t *flag_dev
     {
         Timer tm(h, CTK_K_COUNT);
         // (the counters were zeroed by k_fill_ext / k_ops_ingest; the last workgroup writes the results to pinned memory)
-        k_count_alive<<<(int)((h->n_labels + 255) / 256 + 1), 256, 0, s>>>(P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->counters),
-                                                                           h->h_mail1 + 8);
+        if (h->n_labels <= 262144)
+            k_count_alive_1<<<1, 1024, 0, s>>>(P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->counters), h->h_mail1 + 8);
+        else
+            k_count_alive<<<(int)((h->n_labels + 255) / 256 + 1), 256, 0, s>>>(P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->counters),
+                                                                               h->h_mail1 + 8);
         HIPCHK(hipGetLastError());
     }
     HT("tail launched");

@@ -1117,6 +1117,28 @@ __global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__
     }
 }
 
+// the same in ONE workgroup (up to a few hundred thousand ids): no atomics, no ticket
+__global__ __launch_bounds__(1024) void k_count_alive_1(const int32_t *__restrict__ ext, int64_t n_labels, int persistence,
+                                                        uint32_t *counters, uint32_t *mail)
+{
+    uint32_t v = 0;
+    for (int64_t l = threadIdx.x + 1; l <= n_labels; l += 1024) {
+        const int64_t lo = ext[l], hi = ext[n_labels + 1 + l];
+        v += (hi >= lo && hi - lo + 1 >= persistence) ? 1u : 0u;
+    }
+    __shared__ uint32_t sm[16];
+    const uint32_t s = wave_sum_u32(v);
+    if (lane_id() == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int i = 0; i < 16; i++) tot += sm[i];
+        counters[CTK_CNT_ALIVE] = tot;
+        mail[0] = tot;
+        mail[1] = __hip_atomic_load(&counters[CTK_CNT_WROTE_ZERO], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // time extents of the ids start empty; the counters of the write stage start at zero
 __global__ void k_fill_ext(int32_t *ext, int64_t n_labels, uint32_t *counters)
 {
