@@ -380,7 +380,7 @@ __device__ unsigned long long g_phase_t[16];
 template <int THREADS, typename IT /* uint16_t when run / component indices fit, else uint32_t */, int LDS_COMPS>
 __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, const uint32_t nruns,
                                              uint16_t *x0, uint16_t *x1, uint16_t *yrow, uint32_t *parent,
-                                             IT *root, IT *idmap, uint32_t *rs /* rowstart, ny+1 */,
+                                             IT *root, IT *idmap, IT *rs /* rowstart within the timestep, ny+1 */,
                                              uint32_t *sm_scan, const uint64_t *mrow /* the timestep's mask words (LDS or global) */,
                                              const bool mrow_staged /* mrow is the whole timestep in LDS */,
                                              void *lds_tab /* LDS_COMPS x 32 B of LDS: band staging, then the component tables; or nullptr */)
@@ -391,8 +391,8 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
 
     PHASE_MARK(0);
     // ---- phase 1: rowstart (computed by k_rowcount) -> LDS/scratch -------------------------------
-    for (int y = tid; y < ny; y += THREADS) rs[y] = a.rowstart[(int64_t)t * ny + y];
-    if (tid == 0) rs[ny] = nruns;
+    for (int y = tid; y < ny; y += THREADS) rs[y] = (IT)a.rowstart[(int64_t)t * ny + y];
+    if (tid == 0) rs[ny] = (IT)nruns;
     __syncthreads();
 
     PHASE_MARK(1);
@@ -576,7 +576,7 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
 
 // LDS variants: RUNS = most runs per timestep carried, COMPS = components whose bbox/area tables live in LDS
 // (the table area doubles as the staging area of the timestep's mask words, COMPS*4 words).
-//   <1024, 288>: 27 KB -> 5 workgroups per CU (typical 1 deg Z500 timestep: 500 runs, 40 components)
+//   <1024, 288>: 25.6 KB -> 6 workgroups per CU (typical 1 deg Z500 timestep: 500 runs, 40 components)
 //   <2048, 512>: 46 KB -> 3 workgroups per CU
 //   <4096, 512>: 76 KB -> 2 workgroups per CU (0.25 deg timesteps: ~1600 runs, mask words read through L2)
 template <int RUNS, int COMPS, int RUNS_BELOW, int THREADS>
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(THREADS) void k_label2d_lds(Label2dArgs a)
     }
     __shared__ uint16_t x0[RUNS], x1[RUNS], yrow[RUNS], root[RUNS], idmap[RUNS];
     __shared__ uint32_t parent[RUNS];
-    __shared__ uint32_t rs[CTK_LDS_NY + 1];
+    __shared__ uint16_t rs[CTK_LDS_NY + 2];
     __shared__ uint64_t mlds[COMPS * 4];
     __shared__ uint32_t sm_scan[THREADS / 64 + 1];
     const int nwords = a.ny * a.W;
