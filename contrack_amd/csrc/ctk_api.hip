@@ -76,6 +76,7 @@ struct ctk_handle {
     DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w;
     std::vector<ctk_life_row> lc_host, lc_tmp;
     std::vector<std::pair<uint64_t, uint32_t>> lc_keys;
+    std::vector<uint32_t> lc_cnt_host;
     void *h_cand = nullptr;          // pinned: candidates + boxes download
     size_t h_cand_cap = 0;
     void *h_ops = nullptr;           // pinned: op upload staging
@@ -1530,17 +1531,34 @@ static int lifecycle_dev_impl(ctk_handle *h, const int32_t *flag_dev, const void
         cap = (size_t)cnt[0];
     }
     const size_t n = (size_t)cnt[0];
-    // rows leave the device in arbitrary order; the reference's frame is sorted by (Flag, Date) (contrack.py:906):
-    // sort (label, t) keys, then gather the 48-byte records once
+    // rows leave the device in arbitrary order; the reference's frame is sorted by (Flag, Date) (contrack.py:906).
+    // Two stable counting sorts (by t, then by label) when the label range is small, else a comparison sort of keys.
+    CTKCHK(ensure_host(&h->h_cand, &h->h_cand_cap, std::max<size_t>(n, 1) * sizeof(ctk_life_row), true));     // pinned landing area
+    ctk_life_row *land = (ctk_life_row *)h->h_cand;
+    if (n) HIPCHK(hipMemcpy(land, h->lc_rows.p, n * sizeof(ctk_life_row), hipMemcpyDeviceToHost));
     h->lc_tmp.resize(n);
-    if (n) HIPCHK(hipMemcpy(h->lc_tmp.data(), h->lc_rows.p, n * sizeof(ctk_life_row), hipMemcpyDeviceToHost));
-    std::vector<std::pair<uint64_t, uint32_t>> &keys = h->lc_keys;
-    keys.resize(n);
-    for (size_t i = 0; i < n; ++i)
-        keys[i] = {((uint64_t)((uint32_t)h->lc_tmp[i].label ^ 0x80000000u) << 32) | (uint32_t)h->lc_tmp[i].t, (uint32_t)i};
-    std::sort(keys.begin(), keys.end());
     h->lc_host.resize(n);
-    for (size_t i = 0; i < n; ++i) h->lc_host[i] = h->lc_tmp[keys[i].second];
+    int32_t lmin = INT32_MAX, lmax = INT32_MIN;
+    for (size_t i = 0; i < n; ++i) { lmin = std::min(lmin, land[i].label); lmax = std::max(lmax, land[i].label); }
+    const uint64_t lrange = n ? (uint64_t)((int64_t)lmax - (int64_t)lmin) + 1 : 0;
+    if (n && lrange <= 8 * (uint64_t)n + 65536) {
+        std::vector<uint32_t> &cnt = h->lc_cnt_host;
+        cnt.assign((size_t)T + 1, 0);
+        for (size_t i = 0; i < n; ++i) cnt[(size_t)land[i].t + 1]++;
+        for (int64_t t = 0; t < T; ++t) cnt[(size_t)t + 1] += cnt[(size_t)t];
+        for (size_t i = 0; i < n; ++i) h->lc_tmp[cnt[(size_t)land[i].t]++] = land[i];                  // by t
+        cnt.assign((size_t)lrange + 1, 0);
+        for (size_t i = 0; i < n; ++i) cnt[(size_t)((int64_t)h->lc_tmp[i].label - lmin) + 1]++;
+        for (uint64_t k = 0; k < lrange; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
+        for (size_t i = 0; i < n; ++i) h->lc_host[cnt[(size_t)((int64_t)h->lc_tmp[i].label - lmin)]++] = h->lc_tmp[i];   // by label, stable
+    } else {
+        std::vector<std::pair<uint64_t, uint32_t>> &keys = h->lc_keys;
+        keys.resize(n);
+        for (size_t i = 0; i < n; ++i)
+            keys[i] = {((uint64_t)((uint32_t)land[i].label ^ 0x80000000u) << 32) | (uint32_t)land[i].t, (uint32_t)i};
+        std::sort(keys.begin(), keys.end());
+        for (size_t i = 0; i < n; ++i) h->lc_host[i] = land[keys[i].second];
+    }
     if (nrows) *nrows = (int64_t)n;
     return CTK_OK;
 }

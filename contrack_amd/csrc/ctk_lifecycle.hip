@@ -16,7 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define LC_HASH 2048      // hash slots for the flag ids of one time step
+#define LC_HASH 1024      // hash slots for the flag ids of one time step (<= LC_NL ids: load factor <= 0.5)
 #define LC_NL 512         // distinct flag ids one time step may hold
 #define LC_THREADS 512
 #define LC_ERR_LABELS 1u  // more than LC_NL ids in one time step
@@ -27,7 +27,7 @@ struct CtkLifeRowDev {
     double area, swv, swvy, swvx;
 };
 
-__device__ inline uint32_t lc_hash(int32_t label) { return ((uint32_t)label * 2654435761u) >> 21; }   // 11 bits
+__device__ inline uint32_t lc_hash(int32_t label) { return ((uint32_t)label * 2654435761u) >> 22; }   // 10 bits
 
 // slot of `label` in the table (insert = false: the label is known to be present)
 template <bool INSERT>
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
                                                           unsigned long long cap_rows, unsigned long long *counters)
 {
     __shared__ int32_t hkey[LC_HASH];
-    __shared__ unsigned hedge[LC_HASH];          // bit 0: id seen at x = 0, bit 1: at x = nx-1
+    __shared__ unsigned hedge[LC_HASH / 4];      // per slot one byte: bit 0: id seen at x = 0, bit 1: at x = nx-1
     __shared__ uint16_t hidx[LC_HASH];
     __shared__ int32_t dlabel[LC_NL], dshift[LC_NL], dseam[LC_NL];
     __shared__ long long alo[LC_NL], ahi[LC_NL];
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
     const VT *vp = field + t * (int64_t)npx;
     const bool vec = (npx & 3u) == 0 && (((uintptr_t)flag) & 15u) == 0;      // every plane starts 16-byte aligned
 
-    for (int s = tid; s < LC_HASH; s += LC_THREADS) { hkey[s] = 0; hedge[s] = 0; }
+    for (int s = tid; s < LC_HASH; s += LC_THREADS) { hkey[s] = 0; if (s < LC_HASH / 4) hedge[s] = 0; }
     if (tid == 0) { nlab = 0; nseam = 0; err = 0; }
     __syncthreads();
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
             if (s < 0) { err = LC_ERR_LABELS; continue; }
             prev = l[k]; prev_slot = s;
             const unsigned e = (x == 0 ? 1u : 0u) | (x == (uint32_t)nx - 1 ? 2u : 0u);
-            if (e && (hedge[s] & e) != e) atomicOr(&hedge[s], e);
+            if (e && ((hedge[s >> 2] >> (8 * (s & 3))) & e) != e) atomicOr(&hedge[s >> 2], e << (8 * (s & 3)));
         }
     }
     __syncthreads();
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
         dseam[i] = -1;
         alo[i] = 0; ahi[i] = 0;
         swv[i] = 0.0; swvy[i] = 0.0; swvx[i] = 0.0;
-        if (hedge[s] == 3u) {
+        if (((hedge[s >> 2] >> (8 * (s & 3))) & 3u) == 3u) {
             const int q = atomicAdd(&nseam, 1);
             if (q < ks) { dseam[i] = q; seam_idx[q] = i; }
         }
@@ -162,49 +162,90 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
         __syncthreads();
     }
 
-    // ---- D: the sums
-    for (uint32_t p0 = (uint32_t)tid * 4; p0 < npx; p0 += LC_THREADS * 4) {
-        int32_t l[4];
-        load4(p0, l);
-        if ((l[0] | l[1] | l[2] | l[3]) == 0) continue;
-        int32_t cur = 0;
-        int ci = -1, cy = -1, cnt = 0, csh = 0;
-        double a_wv = 0.0, a_wvy = 0.0, a_wvx = 0.0, wy = 0.0;
-        auto flush = [&]() {
-            if (ci < 0) return;
-            atomicAdd((unsigned long long *)&alo[ci], (unsigned long long)((long long)cnt * wlo[cy]));
-            atomicAdd((unsigned long long *)&ahi[ci], (unsigned long long)((long long)cnt * whi[cy]));
-            atomicAdd(&swv[ci], a_wv);
-            atomicAdd(&swvy[ci], a_wvy);
-            atomicAdd(&swvx[ci], a_wvx);
-            ci = -1;
-        };
-        int y = (int)(p0 / (uint32_t)nx), x = (int)(p0 - (uint32_t)y * (uint32_t)nx);
+    // ---- D: the sums.  A wave covers 256 consecutive pixels per step: the contributions of its lanes are combined per
+    // flag id (usually one or two ids) before they reach the LDS accumulators -- same-address LDS atomics serialise.
+    const int lane = tid & 63;
+    const uint32_t per_step = LC_THREADS * 4, steps = (npx + per_step - 1) / per_step;
+    for (uint32_t st = 0; st < steps; ++st) {                 // uniform loop: whole waves take part in the ballots below
+        const uint32_t p0 = st * per_step + (uint32_t)tid * 4;
+        int32_t l[4] = {0, 0, 0, 0};
+        if (p0 < npx) load4(p0, l);
+        const bool anyfg = (l[0] | l[1] | l[2] | l[3]) != 0;
+        if (__ballot(anyfg) == 0ull) continue;
+        // this lane's contribution to ONE id (s_*); a second id within its four pixels (rare) goes to LDS directly
+        int s_ci = -1;
+        long long s_lo = 0, s_hi = 0;
+        double s_wv = 0.0, s_wvy = 0.0, s_wvx = 0.0;
+        if (anyfg) {
+            double v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (l[k] == 0) {
-                flush(); cur = 0;
-            } else {
-                if (l[k] != cur || y != cy) {
-                    flush();
-                    cur = l[k]; cy = y; cnt = 0;
-                    ci = hidx[lc_slot<false>(hkey, cur)];
-                    csh = dshift[ci];
-                    wy = (double)wrow[y];
-                    a_wv = a_wvy = a_wvx = 0.0;
+            for (int k = 0; k < 4; ++k) v[k] = (l[k] != 0) ? (double)vp[p0 + k] : 0.0;
+            int32_t cur = 0;
+            int ci = -1, cy = -1, cnt = 0, csh = 0;
+            double a_wv = 0.0, a_wvy = 0.0, a_wvx = 0.0, wy = 0.0;
+            auto flush = [&]() {
+                if (ci < 0) return;
+                const long long lo = (long long)cnt * wlo[cy], hi = (long long)cnt * whi[cy];
+                if (s_ci < 0 || s_ci == ci) {
+                    s_ci = ci; s_lo += lo; s_hi += hi; s_wv += a_wv; s_wvy += a_wvy; s_wvx += a_wvx;
+                } else {
+                    atomicAdd((unsigned long long *)&alo[ci], (unsigned long long)lo);
+                    atomicAdd((unsigned long long *)&ahi[ci], (unsigned long long)hi);
+                    atomicAdd(&swv[ci], a_wv);
+                    atomicAdd(&swvy[ci], a_wvy);
+                    atomicAdd(&swvx[ci], a_wvx);
                 }
-                const double wv = (double)vp[p0 + k] * wy;                  // variable * weight_grid (:892), float64
-                int xr = x;
-                if (csh > 0) { xr = x - csh; if (xr < 0) xr += nx; }
-                cnt += 1;
-                // the partial sums of up to four pixels are formed here and added once: same products, another order
-                a_wv += wv;
-                a_wvy += wv * (double)y;
-                a_wvx += wv * (double)xr;
+                ci = -1;
+            };
+            int y = (int)(p0 / (uint32_t)nx), x = (int)(p0 - (uint32_t)y * (uint32_t)nx);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (l[k] == 0) {
+                    flush(); cur = 0;
+                } else {
+                    if (l[k] != cur || y != cy) {
+                        flush();
+                        cur = l[k]; cy = y; cnt = 0;
+                        ci = hidx[lc_slot<false>(hkey, cur)];
+                        csh = dshift[ci];
+                        wy = (double)wrow[y];
+                        a_wv = a_wvy = a_wvx = 0.0;
+                    }
+                    const double wv = v[k] * wy;                        // variable * weight_grid (:892), float64
+                    int xr = x;
+                    if (csh > 0) { xr = x - csh; if (xr < 0) xr += nx; }
+                    cnt += 1;
+                    // partial sums are formed in registers and added once: same products as the reference, another order
+                    a_wv += wv;
+                    a_wvy += wv * (double)y;
+                    a_wvx += wv * (double)xr;
+                }
+                if (++x == nx) { x = 0; ++y; }
             }
-            if (++x == nx) { x = 0; ++y; }
+            flush();
         }
-        flush();
+        // combine across the wave, one id at a time
+        uint64_t todo = __ballot(s_ci >= 0);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            const int L = __shfl(s_ci, src);
+            const bool mine = s_ci == L;
+            double r_wv = mine ? s_wv : 0.0, r_wvy = mine ? s_wvy : 0.0, r_wvx = mine ? s_wvx : 0.0;
+            long long r_lo = mine ? s_lo : 0ll, r_hi = mine ? s_hi : 0ll;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                r_wv += __shfl_xor(r_wv, o); r_wvy += __shfl_xor(r_wvy, o); r_wvx += __shfl_xor(r_wvx, o);
+                r_lo += __shfl_xor(r_lo, o); r_hi += __shfl_xor(r_hi, o);
+            }
+            if (lane == 0) {
+                atomicAdd((unsigned long long *)&alo[L], (unsigned long long)r_lo);
+                atomicAdd((unsigned long long *)&ahi[L], (unsigned long long)r_hi);
+                atomicAdd(&swv[L], r_wv);
+                atomicAdd(&swvy[L], r_wvy);
+                atomicAdd(&swvx[L], r_wvx);
+            }
+            todo &= ~__ballot(mine);
+        }
     }
     __syncthreads();
 
