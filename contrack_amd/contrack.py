@@ -440,6 +440,10 @@ class contrack(object):
                      variable, gorl, threshold, overlap, persistence, twosided),
                  'reference': 'https://github.com/steidani/ConTrack'}
         self.ds['flag'] = (dims, flag.transpose(inverse), attrs)
+        if _tracker().stats().get("ambiguous_decisions", 0):
+            # components touching a pole row have area sums that must be rounded; numpy rounds them in another order
+            logger.warning("an overlap decision lies within rounding distance of overlap = {}: ids may differ from the "
+                           "scipy path's for components that touch a pole row (see DESIGN.md, exact areas)".format(overlap))
         logger.info("Running contrack... DONE\n{} contours tracked".format(n_tracked))
 
     # ---- life cycle (contrack.py:798-906), consumer of `flag` ----------------------------

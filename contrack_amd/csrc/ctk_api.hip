@@ -71,7 +71,7 @@ struct ctk_handle {
     DevBuf g_ncomp, g_cprefix, g_mrep, g_box, g_area, g_comp_t, g_pairs, g_pair_base, g_pair_cnt, g_seams, g_seam_cnt, g_seam_off, g_counters, g_label;
     // device resolver work space
     DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lbox,
-        rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff, rv_dmap, rv_dorig, rv_dbox;
+        rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff, rv_dmap, rv_dorig, rv_dbox, rv_inex;
     // run_lifecycle reductions
     DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w;
     std::vector<ctk_life_row> lc_host, lc_tmp;
@@ -257,7 +257,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->g_label, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
                       &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
-                      &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox};
+                      &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -1012,6 +1012,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     const size_t DC = std::min<size_t>(R + 1, (size_t)2 * std::max<int64_t>(in.seam_cap, 1));       // labels in candidate records
     CTKCHK(ensure(h, h->rv_dmap, (R + 1) * 4)); CTKCHK(ensure(h, h->rv_dorig, DC * 4)); CTKCHK(ensure(h, h->rv_dbox, DC * 24));
     CTKCHK(ensure(h, h->op_first, (R + 1) * 4));
+    CTKCHK(ensure(h, h->rv_inex, R));
 
     ResolveDev r;
     r.ncomp = in.ncomp; r.cprefix = in.cprefix; r.mrep = in.mrep; r.comp_t = in.comp_t;
@@ -1023,6 +1024,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     r.rank = P<uint32_t>(h->rv_rank); r.lab = P<int32_t>(h->rv_lab);
     r.mark = P<uint8_t>(h->rv_mark); r.inv = P<double>(h->rv_inv); r.ff = P<double>(h->rv_ff);
     r.dmap = P<uint32_t>(h->rv_dmap); r.dorig = P<int32_t>(h->rv_dorig); r.dbox = P<int32_t>(h->rv_dbox); r.dcount = P<uint32_t>(h->rv_scalars); r.op_first = P<int32_t>(h->op_first);
+    r.inex = P<uint8_t>(h->rv_inex); r.ambig = P<uint32_t>(h->rv_scalars) + 1;
 
     const int gc = (int)std::min<size_t>((R + 255) / 256, 2048), gp = (int)std::min<size_t>((PC + 255) / 256, 2048);
     // mailbox in pinned host memory: the last resolver kernel writes scalars, candidate records and dense label tables
@@ -1093,6 +1095,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     CTKCHK(ensure(h, h->ext, (size_t)(nlab + 1) * 8));
     h->stats[CTK_S_COMPONENTS] = NC; h->stats[CTK_S_PAIRS] = (int64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS]; h->stats[CTK_S_SEAM_ROWS] = ncand; h->stats[CTK_S_LABELS] = nlab;
     h->stats[CTK_S_UPAIRS] = hs[CTK_CNT_UPAIRS];
+    h->stats[CTK_S_AMBIGUOUS] = hs[CTK_MAIL_AMBIG];
     h->mail_want_c = std::max<size_t>(h->mail_want_c, (size_t)ncand + (size_t)ncand / 2);
     h->mail_want_d = std::max<size_t>(h->mail_want_d, nd + nd / 2);
     std::vector<CtkOp> &ops = h->sd_ops;
@@ -1378,6 +1381,7 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
         ctk_result *res = nullptr;
         CTKCHK(ctk_resolve(&blob, &nbytes, 1, overlap, twosided, &res));
         h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t1;
+        h->stats[CTK_S_AMBIGUOUS] = res->n_ambiguous;
         int rc = ctk_shard_extents(h, res, 0, 0, nullptr, nullptr);
         ctk_result_free(res);
         CTKCHK(rc);

@@ -266,7 +266,7 @@ extern "C" int ctk_resolve(const void *const *blobs, const size_t *nbytes, int n
                     // a rounded sum could differ from numpy's pairwise result by a few ulp: report decisions
                     // that sit that close to the threshold (never observed; DESIGN.md "exact areas")
                     double tol = 8 * 2.220446049250313e-16 * std::fabs(overlap);
-                    if (std::fabs(ff - overlap) <= tol || (twosided && std::fabs(fb - overlap) <= tol)) n_ambiguous++;
+                    if ((ff != 0 && std::fabs(ff - overlap) <= tol) || (twosided && fb != 0 && std::fabs(fb - overlap) <= tol)) n_ambiguous++;    // (a zero sum is exact)
                 }
                 if (kill) keep[(size_t)g] = 0;
             }

@@ -46,6 +46,8 @@ struct ResolveDev {
     int32_t *dbox;                        // [dense][6] its box
     uint32_t *dcount;                     // number of dense ids
     int32_t *op_first;                    // [NC+1] first op per label: reset to -1 here, filled by k_ops_ingest
+    uint8_t *inex;                        // [NC] the component's own area or forward overlap is a rounded sum
+    uint32_t *ambig;                      // set when a decision with a rounded sum lies within rounding distance of the threshold
 };
 
 #define CTK_CHG_SLOTS 64            // 'changed' words per filter pass (= wave width: one ballot reads them)
@@ -83,7 +85,7 @@ __device__ __forceinline__ const CtkPair &pair_at(const ResolveDev &r, uint32_t 
 __device__ __forceinline__ uint32_t dev_ncomps(const ResolveDev &r) { return r.cprefix[r.T]; }
 
 // exact limb sums -> float64, rounded once to nearest-even (identical to limbs_to_double in ctk_resolve.cpp)
-__device__ inline double dev_limbs_to_double(int64_t lo, int64_t hi, int wshift)
+__device__ inline double dev_limbs_to_double(int64_t lo, int64_t hi, int wshift, bool *inexact = nullptr)
 {
     __int128 v = (__int128)hi * ((__int128)1 << CTK_LIMB_BITS) + (__int128)lo;
     if (v == 0) return 0.0;
@@ -100,6 +102,7 @@ __device__ inline double dev_limbs_to_double(int64_t lo, int64_t hi, int wshift)
         const unsigned __int128 rem = a & ((((unsigned __int128)1) << sh) - 1);
         const unsigned __int128 half = ((unsigned __int128)1) << (sh - 1);
         if (rem > half || (rem == half && (q & 1))) q += 1;
+        if (inexact && rem != 0) *inexact = true;
         d = ldexp((double)(uint64_t)q, sh);
     }
     d = ldexp(d, -wshift);
@@ -116,6 +119,7 @@ __global__ void k_rs_init(ResolveDev r)
         r.parent[g] = g;                                   // (k_rs_parent_init, for the first round)
     }
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < (CTK_MAX_JACOBI + 1) * CTK_CHG_SLOTS; i += blockDim.x) r.changed[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *r.ambig = 0;
 }
 
 __global__ void k_rs_parent_init(ResolveDev r)
@@ -144,8 +148,10 @@ __global__ void k_rs_prep(ResolveDev r)
 {
     const uint32_t nc = dev_ncomps(r);
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
-        const double areacon = dev_limbs_to_double(r.A[2 * (int64_t)g], r.A[2 * (int64_t)g + 1], r.wshift);
-        const double fwd = dev_limbs_to_double(r.F[2 * (int64_t)g], r.F[2 * (int64_t)g + 1], r.wshift);
+        bool inexact = false;
+        const double areacon = dev_limbs_to_double(r.A[2 * (int64_t)g], r.A[2 * (int64_t)g + 1], r.wshift, &inexact);
+        const double fwd = dev_limbs_to_double(r.F[2 * (int64_t)g], r.F[2 * (int64_t)g + 1], r.wshift, &inexact);
+        r.inex[g] = inexact ? 1 : 0;
         const double inv = 1.0 / areacon;                     // reciprocal, then multiply -- as the reference does
         r.inv[g] = inv;
         r.ff[g] = inv * fwd;
@@ -237,8 +243,15 @@ __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint
             __hip_atomic_store(&B[2 * c + 1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if ((first ? mrep0 : r.mrep[g]) != c) continue;         // representatives only
-        const double bwd = dev_limbs_to_double(blo, bhi, r.wshift);
+        bool inexact = r.inex[g] != 0;
+        const double bwd = dev_limbs_to_double(blo, bhi, r.wshift, &inexact);
         const double fb = (first ? inv0 : r.inv[g]) * bwd, ff = first ? ff0 : r.ff[g];
+        if (inexact) {
+            // numpy sums these float64 values pairwise; a rounded sum can differ from this exact-then-rounded one by a few
+            // ulp: flag decisions that sit that close to the threshold (same rule as ctk_resolve.cpp, DESIGN.md "exact areas")
+            const double tol = 8 * 2.220446049250313e-16 * fabs(r.overlap);
+            if ((ff != 0 && fabs(ff - r.overlap) <= tol) || (r.twosided && fb != 0 && fabs(fb - r.overlap) <= tol)) *r.ambig = 1u;    // (a zero sum is exact)
+        }
         bool kill = false;
         if (r.twosided) {
             if (fb != 0 && ff != 0) { if (fb < r.overlap || ff < r.overlap) kill = true; }
@@ -496,6 +509,7 @@ struct CandMail {
 #define CTK_MAIL_ND 10
 #define CTK_MAIL_NLAB 11
 #define CTK_MAIL_CHANGED 12         // .. + passes of the round (<= 32)
+#define CTK_MAIL_AMBIG 50
 
 // dense (t, y)-ordered group records from the row-indexed scratch, labels replaced by their dense ids; mailbox
 __global__ __launch_bounds__(64) void k_compact_cands(ResolveDev r, const CtkCand *__restrict__ scratch, const uint32_t *__restrict__ cand_cnt,
@@ -525,6 +539,7 @@ __global__ __launch_bounds__(64) void k_compact_cands(ResolveDev r, const CtkCan
         m.scal[CTK_MAIL_NCAND] = r.T > 0 ? cand_off[r.T] : 0u;
         m.scal[CTK_MAIL_ND] = *r.dcount;
         m.scal[CTK_MAIL_NLAB] = *nlab_ptr;
+        m.scal[CTK_MAIL_AMBIG] = *r.ambig;
     }
     if (blockIdx.x == 0) {                                   // (the workgroup is one wave)
         for (int k = 0; k < round; k++) {
