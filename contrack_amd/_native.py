@@ -292,11 +292,11 @@ class Tracker:
         check(lib().ctk_set_timing(self._h, 2 if level is True else int(level)))
 
     def stats(self):
-        v = np.zeros(16, dtype=np.int64)
+        v = np.zeros(24, dtype=np.int64)
         check(lib().ctk_get_stats(self._h, v.ctypes.data))
         names = ["runs", "max_runs_per_step", "components", "pairs", "seam_rows_to_driver", "labels_3d", "seam_ops",
                  "filter_passes", "host_path", "seam_loop_ns", "seam_folds", "seam_copy_ns", "ungrouped_pairs", "pair_table_regrows", "filter_rounds",
-                 "ambiguous_decisions"]
+                 "ambiguous_decisions", "exact_fixups"]
         return dict(zip(names, v.tolist()))
 
     def debug_set_pair_capacity(self, records):

@@ -16,6 +16,9 @@
 
 int ctk_set_error(int code, const char *fmt, ...);            // ctk_resolve.cpp
 extern "C" int ctk_weights_to_limbs(const float *wrow, int ny, int32_t *wlo, int32_t *whi, int32_t *wshift);
+int ctk_resolve_ex(const void *const *blobs, const size_t *nbytes, int nshards, double overlap, int twosided, CtkExactAreas *exact,
+                   ctk_result **out);                              // ctk_resolve.cpp
+double ctk_np_sum(const double *a, size_t n);
 
 #define HIPCHK(expr)                                                                                          \
     do {                                                                                                      \
@@ -986,7 +989,7 @@ struct ResolveIn {
 };
 
 // returns CTK_OK, a negative error, or +1 = "take the host path" (pair table overflow / filter not converged)
-static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, int twosided, bool final_in_extent = false)
+static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, int twosided, bool final_in_extent = false, bool local = false)
 {
     hipStream_t s = h->stream;
     const size_t R = in.R ? in.R : 1;
@@ -1096,6 +1099,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     h->stats[CTK_S_COMPONENTS] = NC; h->stats[CTK_S_PAIRS] = (int64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS]; h->stats[CTK_S_SEAM_ROWS] = ncand; h->stats[CTK_S_LABELS] = nlab;
     h->stats[CTK_S_UPAIRS] = hs[CTK_CNT_UPAIRS];
     h->stats[CTK_S_AMBIGUOUS] = hs[CTK_MAIL_AMBIG];
+    if (hs[CTK_MAIL_AMBIG] && local) return 1;         // single GPU: the host resolver re-evaluates those decisions in numpy's order
     h->mail_want_c = std::max<size_t>(h->mail_want_c, (size_t)ncand + (size_t)ncand / 2);
     h->mail_want_d = std::max<size_t>(h->mail_want_d, nd + nd / 2);
     std::vector<CtkOp> &ops = h->sd_ops;
@@ -1148,6 +1152,91 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     return CTK_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// numpy-order area sums of one merged component, from the tables and mask of the current shard (host resolver
+// path, single GPU).  Only called for decisions flagged ambiguous (exact areas): a handful of
+// small downloads, a scan of three mask planes on the host.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct ExactFromDevice : CtkExactAreas {
+    ctk_handle *h;
+    std::vector<uint32_t> run_base, cprefix;
+    struct Step {
+        int64_t t = -1;
+        std::vector<uint64_t> mask;
+        std::vector<uint16_t> wstart;
+        std::vector<uint32_t> rowstart, run_comp, mrep;
+    };
+    Step cache[3];
+    bool ok = true;
+    explicit ExactFromDevice(ctk_handle *h_) : h(h_) {}
+    bool fetch(int64_t t, Step *&out)
+    {
+        Step &s = cache[t % 3];
+        out = &s;
+        if (s.t == t) return true;
+        const size_t nw = (size_t)h->ny * h->W;
+        if (run_base.empty()) {
+            run_base.resize((size_t)h->T + 1); cprefix.resize((size_t)h->T + 1);
+            if (hipMemcpy(run_base.data(), h->run_base.p, run_base.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+            if (hipMemcpy(cprefix.data(), h->cprefix.p, cprefix.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        }
+        const uint32_t nr = run_base[(size_t)t + 1] - run_base[(size_t)t], nc = cprefix[(size_t)t + 1] - cprefix[(size_t)t];
+        s.mask.resize(nw); s.wstart.resize(nw); s.rowstart.resize((size_t)h->ny); s.run_comp.resize(nr); s.mrep.resize(nc);
+        bool good = hipMemcpy(s.mask.data(), P<uint64_t>(h->mask) + (size_t)t * nw, nw * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+                    hipMemcpy(s.wstart.data(), P<uint16_t>(h->wstart) + (size_t)t * nw, nw * 2, hipMemcpyDeviceToHost) == hipSuccess &&
+                    hipMemcpy(s.rowstart.data(), P<uint32_t>(h->rowstart) + (size_t)t * h->ny, (size_t)h->ny * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        if (good && nr) good = hipMemcpy(s.run_comp.data(), P<uint32_t>(h->run_comp) + run_base[(size_t)t], (size_t)nr * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        if (good && nc) good = hipMemcpy(s.mrep.data(), P<uint32_t>(h->d_mrep) + cprefix[(size_t)t], (size_t)nc * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        s.t = good ? t : -1;
+        return good;
+    }
+    // no-wrap component of pixel (y, x), or -1
+    int64_t comp_at(const Step &s, int y, int x) const
+    {
+        const int W = h->W, w = x >> 6, b = x & 63;
+        const uint64_t m = s.mask[(size_t)y * W + w];
+        if (!((m >> b) & 1ull)) return -1;
+        const uint64_t carry = w > 0 ? s.mask[(size_t)y * W + w - 1] >> 63 : 0ull;
+        const uint64_t starts = m & ~((m << 1) | carry);
+        const uint64_t below = b == 63 ? ~0ull : ((1ull << (b + 1)) - 1ull);
+        const uint32_t k = s.rowstart[(size_t)y] + s.wstart[(size_t)y * W + w] + (uint32_t)__builtin_popcountll(starts & below) - 1u;
+        return k < s.run_comp.size() ? (int64_t)s.run_comp[k] : -1;
+    }
+    bool sums(int64_t t, uint32_t comp, const std::function<bool(uint32_t)> &kept_prev, double out[3]) override
+    {
+        if (!ok || t < 1 || t + 1 >= h->T || (int)h->c_w.size() != h->ny) return false;
+        Step *cur, *prv, *nxt;
+        if (!fetch(t, cur) || !fetch(t - 1, prv) || !fetch(t + 1, nxt)) { ok = false; return false; }
+        const int ny = h->ny, nx = h->nx, W = h->W;
+        std::vector<double> sa, sf, sb;                       // the gathered weights, raster order (contrack.py:717-719)
+        for (int y = 0; y < ny; y++) {
+            const double wy = (double)h->c_w[(size_t)y];
+            for (int w = 0; w < W; w++) {
+                uint64_t m = cur->mask[(size_t)y * W + w];
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int x = w * 64 + b;
+                    if (x >= nx) break;
+                    const int64_t c = comp_at(*cur, y, x);
+                    if (c < 0 || (size_t)c >= cur->mrep.size() || cur->mrep[(size_t)c] != comp) continue;
+                    sa.push_back(wy);
+                    if ((nxt->mask[(size_t)y * W + w] >> b) & 1ull) sf.push_back(wy);
+                    const int64_t d = comp_at(*prv, y, x);
+                    if (d >= 0 && kept_prev((uint32_t)d)) sb.push_back(wy);
+                }
+            }
+        }
+        out[0] = ctk_np_sum(sa.data(), sa.size());
+        out[1] = ctk_np_sum(sf.data(), sf.size());
+        out[2] = ctk_np_sum(sb.data(), sb.size());
+        return true;
+    }
+};
+}  // namespace
+
 // the shard's own tables (single GPU)
 static int device_resolve_local(ctk_handle *h, double overlap, int twosided)
 {
@@ -1167,7 +1256,7 @@ static int device_resolve_local(ctk_handle *h, double overlap, int twosided)
     in.seams = P<CtkSeam>(h->seams); in.seam_cnt = P<uint32_t>(h->seam_cnt); in.seam_off = P<uint32_t>(h->seam_rowoff);
     in.seam_cap = h->T * h->ny;
     in.comp_label = P<int32_t>(h->comp_label);
-    int rv = device_resolve(h, in, overlap, twosided, true);
+    int rv = device_resolve(h, in, overlap, twosided, true, true);
     if (rv == 0) { h->total_comps = (uint32_t)h->stats[CTK_S_COMPONENTS]; h->t_begin = 0; }
     return rv;
 }
@@ -1379,9 +1468,11 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
         CTKCHK(ctk_shard_tables(h, &blob, &nbytes));
         const double t1 = now_ms();
         ctk_result *res = nullptr;
-        CTKCHK(ctk_resolve(&blob, &nbytes, 1, overlap, twosided, &res));
+        ExactFromDevice exact(h);                                 // numpy-order sums for decisions flagged ambiguous
+        CTKCHK(ctk_resolve_ex(&blob, &nbytes, 1, overlap, twosided, &exact, &res));
         h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t1;
         h->stats[CTK_S_AMBIGUOUS] = res->n_ambiguous;
+        h->stats[CTK_S_EXACT_FIXUPS] = res->n_exact;
         int rc = ctk_shard_extents(h, res, 0, 0, nullptr, nullptr);
         ctk_result_free(res);
         CTKCHK(rc);

@@ -124,8 +124,48 @@ inline bool in_box(const CtkOp &o, int32_t t, int32_t y, int32_t x)
 
 }  // namespace
 
+// numpy's float64 add.reduce over a contiguous 1-D array (numpy/_core/src/umath/loops_utils.h.src, *_pairwise_sum, and
+// the 8192-element inner-loop chunks of the reduction machinery), restated: eight running sums over blocks of up to 128
+// elements, halving above that, chunk results added to the accumulator in order.
+static double np_pairwise(const double *a, size_t n)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (size_t i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        size_t i = 8;
+        for (; i + 8 <= n; i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    size_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+}
+double ctk_np_sum(const double *a, size_t n)
+{
+    double res = 0.0;
+    for (size_t i = 0; i < n; i += 8192) res += np_pairwise(a + i, std::min<size_t>(8192, n - i));
+    return res;
+}
+
+int ctk_resolve_ex(const void *const *blobs, const size_t *nbytes, int nshards, double overlap, int twosided, CtkExactAreas *exact,
+                   ctk_result **out);
+
 extern "C" int ctk_resolve(const void *const *blobs, const size_t *nbytes, int nshards, double overlap,
                            int twosided, ctk_result **out)
+{
+    return ctk_resolve_ex(blobs, nbytes, nshards, overlap, twosided, nullptr, out);
+}
+
+int ctk_resolve_ex(const void *const *blobs, const size_t *nbytes, int nshards, double overlap, int twosided, CtkExactAreas *exact,
+                   ctk_result **out)
 {
     if (!blobs || !nbytes || nshards <= 0 || !out) return ctk_set_error(CTK_E_INVALID, "ctk_resolve: bad arguments");
     *out = nullptr;
@@ -234,7 +274,7 @@ extern "C" int ctk_resolve(const void *const *blobs, const size_t *nbytes, int n
                 F[(size_t)r * 2 + 1] += p.hi;
             }
         std::vector<uint8_t> keep((size_t)NC, 1);          // per merged representative; members look it up
-        int64_t n_ambiguous = 0;
+        int64_t n_ambiguous = 0, n_exact_fixups = 0;
         auto rep_of = [&](int64_t t, uint32_t c) { return coff[(size_t)t] + mrep[(size_t)(coff[(size_t)t] + c)]; };
         for (int64_t t = 1; t < T - 1; t++) {
             // backward overlap: co-occurrences with components of t-1 that SURVIVED the filter (contrack.py:719)
@@ -254,6 +294,21 @@ extern "C" int ctk_resolve(const void *const *blobs, const size_t *nbytes, int n
                 double inv = 1.0 / areacon;                 // contrack.py:721-722: reciprocal, then multiply
                 double fb = inv * bwd;
                 double ff = inv * fwd;
+                if (inexact) {
+                    // a rounded sum can differ from numpy's pairwise result by a few ulp: for decisions that sit that close
+                    // to the threshold, take numpy's sums from the provider (single shard), else report them
+                    // (DESIGN.md "exact areas"; a zero sum is exact)
+                    double tol = CTK_AMBIG_ULPS * 2.220446049250313e-16 * std::fabs(overlap);
+                    if ((ff != 0 && std::fabs(ff - overlap) <= tol) || (twosided && fb != 0 && std::fabs(fb - overlap) <= tol)) {
+                        double s3[3];
+                        if (exact && nshards == 1 &&
+                            exact->sums(t, (uint32_t)(g - coff[(size_t)t]), [&](uint32_t d) { return keep[(size_t)rep_of(t - 1, d)] != 0; }, s3)) {
+                            areacon = s3[0]; fwd = s3[1]; bwd = s3[2];
+                            inv = 1.0 / areacon; fb = inv * bwd; ff = inv * fwd;
+                            n_exact_fixups++;
+                        } else n_ambiguous++;
+                    }
+                }
                 bool kill = false;
                 if (twosided) {
                     if (fb != 0 && ff != 0) { if (fb < overlap || ff < overlap) kill = true; }
@@ -261,12 +316,6 @@ extern "C" int ctk_resolve(const void *const *blobs, const size_t *nbytes, int n
                     if (fb == 0 && ff != 0) { if (ff < overlap) kill = true; }
                 } else {
                     if (ff < overlap) kill = true;
-                }
-                if (inexact) {
-                    // a rounded sum could differ from numpy's pairwise result by a few ulp: report decisions
-                    // that sit that close to the threshold (never observed; DESIGN.md "exact areas")
-                    double tol = 8 * 2.220446049250313e-16 * std::fabs(overlap);
-                    if ((ff != 0 && std::fabs(ff - overlap) <= tol) || (twosided && fb != 0 && std::fabs(fb - overlap) <= tol)) n_ambiguous++;    // (a zero sum is exact)
                 }
                 if (kill) keep[(size_t)g] = 0;
             }
@@ -338,7 +387,7 @@ extern "C" int ctk_resolve(const void *const *blobs, const size_t *nbytes, int n
         // ---- final id per component: fold with the component's box; mixed containment => per pixel --
         ctk_result *res = new ctk_result();
         memset(res, 0, sizeof(*res));
-        res->nshards = nshards; res->T = T; res->ncomps = NC; res->n_labels = nlab; res->n_ambiguous = n_ambiguous;
+        res->nshards = nshards; res->T = T; res->ncomps = NC; res->n_labels = nlab; res->n_ambiguous = n_ambiguous; res->n_exact = n_exact_fixups;
         res->shard_comp_off = (int64_t *)malloc(sizeof(int64_t) * ((size_t)nshards + 1));
         res->shard_t_off = (int64_t *)malloc(sizeof(int64_t) * ((size_t)nshards + 1));
         res->comp_label = (int32_t *)malloc(sizeof(int32_t) * (size_t)(NC > 0 ? NC : 1));

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint
         if (inexact) {
             // numpy sums these float64 values pairwise; a rounded sum can differ from this exact-then-rounded one by a few
             // ulp: flag decisions that sit that close to the threshold (same rule as ctk_resolve.cpp, DESIGN.md "exact areas")
-            const double tol = 8 * 2.220446049250313e-16 * fabs(r.overlap);
+            const double tol = CTK_AMBIG_ULPS * 2.220446049250313e-16 * fabs(r.overlap);
             if ((ff != 0 && fabs(ff - r.overlap) <= tol) || (r.twosided && fb != 0 && fabs(fb - r.overlap) <= tol)) *r.ambig = 1u;    // (a zero sum is exact)
         }
         bool kill = false;

@@ -6,6 +6,7 @@
 
 #define CTK_BLOB_MAGIC 0x314b544e4f43ull /* "CONTK1" */
 #define CTK_LIMB_BITS 31
+#define CTK_AMBIG_ULPS 64       /* a rounded area sum whose fraction lies this close to `overlap` is re-evaluated in numpy's order */
 
 // One record per (component at t, component at t-1) co-occurrence; duplicates of the same (t,c,d) may
 // occur (partial sums) and are additive.  lo/hi are the two limb sums of  sum_y n(y) * W[y]  with
@@ -58,12 +59,26 @@ static inline size_t ctk_blob_bytes(int64_t T, int64_t ncomps, int64_t npairs, i
            (size_t)nseams * sizeof(CtkSeam) + 2 * ctk_align8((size_t)T * 4);
 }
 
+// Provider of numpy-order area sums for ONE seam-merged component (host resolver, single shard): used for the rare overlap
+// decisions whose exactly accumulated sums had to be rounded AND land within rounding distance of the threshold
+// (exact areas).  `comp` is the component's representative id within timestep t; kept_prev(d) tells whether the
+// (no-wrap) component d of timestep t-1 survived the filter.  out = {areacon, areaover_forward, areaover_backward}
+// as np.sum returns them (contrack.py:717-719).
+#ifdef __cplusplus
+#include <functional>
+struct CtkExactAreas {
+    virtual ~CtkExactAreas() {}
+    virtual bool sums(int64_t t, uint32_t comp, const std::function<bool(uint32_t)> &kept_prev, double out[3]) = 0;
+};
+#endif
+
 struct ctk_result {
     int nshards;
     int64_t T;                 // total timesteps
     int64_t ncomps;            // total no-wrap components
     int64_t n_labels;          // labels of the fresh 3-D labelling (contrack.py:748)
     int64_t n_complex, n_ambiguous;
+    int64_t n_exact;           // decisions re-evaluated with numpy-order sums (CtkExactAreas)
     int64_t *shard_comp_off;   // [nshards+1] offsets into comp_label
     int64_t *shard_t_off;      // [nshards+1]
     int32_t *comp_label;       // [ncomps]  0 = filtered out; L>0 = final id; -L = needs per-pixel fold from 3-D label L

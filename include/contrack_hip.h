@@ -175,11 +175,12 @@ int ctk_set_timing(ctk_handle *h, int level);
 #define CTK_S_UPAIRS        12  /* co-occurrence records that bypassed the LDS hash table   */
 #define CTK_S_PAIR_REGROW   13  /* times the pair table had to be regrown (host path)       */
 #define CTK_S_FILTER_ROUNDS 14  /* rounds of filter passes (convergence is checked per round) */
+#define CTK_S_EXACT_FIXUPS  16  /* overlap decisions re-evaluated with numpy-order sums on the host (see CTK_S_AMBIGUOUS)  */
 #define CTK_S_AMBIGUOUS     15  /* > 0: an overlap decision used an area sum that had to be ROUNDED (components touching a pole row,
                                    whose weight is ~2^-20 of the others) and came out within 8 ulp of the threshold; numpy's pairwise
                                    float64 summation may land on the other side there (only with exact ties: blocky test fields,
                                    overlap = 1.0).  Device path: 0/1 flag; host resolver: the number of such decisions. */
-#define CTK_NSTATS          16
+#define CTK_NSTATS          24
 int ctk_get_stats(ctk_handle *h, int64_t *out /* [CTK_NSTATS] */);
 /* filter passes launched per round before convergence is checked on the host (default 10, 1..32)   */
 int ctk_set_filter_round(ctk_handle *h, int passes);
