@@ -91,6 +91,7 @@ struct ctk_handle {
     // what the device copies of thresholds / weight limbs were made from
     std::vector<double> c_thr; std::vector<float> c_w;
     int64_t c_T = -1; bool c_f64 = false, c_thr_valid = false, c_w_valid = false; int c_cmp = -1;
+    int w_minlsb = 0;                            // lowest set bit over the integer row weights
     int64_t last_alive = 0;
     int64_t rowoff_T = -1; int rowoff_ny = -1; void *rowoff_p = nullptr;     // what seam_rowoff currently holds
     // speculative launch of the 2-D labelling: capacity (in runs) of the run-indexed buffers, the previous call's variants
@@ -403,6 +404,11 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         h->c_w_valid = false;
         CTKCHK(ctk_weights_to_limbs(wrow, ny, wlo, wlo + ny, &h->wshift));
         h->c_w.assign(wrow, wrow + ny);
+        h->w_minlsb = 62;
+        for (int y = 0; y < ny; y++) {
+            const int64_t wi = (int64_t)wlo[y] + ((int64_t)wlo[ny + y] << CTK_LIMB_BITS);
+            if (wi) h->w_minlsb = std::min(h->w_minlsb, __builtin_ctzll((unsigned long long)(wi < 0 ? -wi : wi)));
+        }
     }
 
     CTKCHK(ensure(h, h->mask, (size_t)nrows * W * 8));
@@ -1027,7 +1033,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     r.rank = P<uint32_t>(h->rv_rank); r.lab = P<int32_t>(h->rv_lab);
     r.mark = P<uint8_t>(h->rv_mark); r.inv = P<double>(h->rv_inv); r.ff = P<double>(h->rv_ff);
     r.dmap = P<uint32_t>(h->rv_dmap); r.dorig = P<int32_t>(h->rv_dorig); r.dbox = P<int32_t>(h->rv_dbox); r.dcount = P<uint32_t>(h->rv_scalars); r.op_first = P<int32_t>(h->op_first);
-    r.inex = P<uint8_t>(h->rv_inex); r.ambig = P<uint32_t>(h->rv_scalars) + 1;
+    r.inex = P<uint8_t>(h->rv_inex); r.ambig = P<uint32_t>(h->rv_scalars) + 1; r.minlsb = h->w_minlsb;
 
     const int gc = (int)std::min<size_t>((R + 255) / 256, 2048), gp = (int)std::min<size_t>((PC + 255) / 256, 2048);
     // mailbox in pinned host memory: the last resolver kernel writes scalars, candidate records and dense label tables
@@ -1204,6 +1210,7 @@ struct ExactFromDevice : CtkExactAreas {
         const uint32_t k = s.rowstart[(size_t)y] + s.wstart[(size_t)y * W + w] + (uint32_t)__builtin_popcountll(starts & below) - 1u;
         return k < s.run_comp.size() ? (int64_t)s.run_comp[k] : -1;
     }
+    int min_lsb() const override { return h->w_minlsb; }
     bool sums(int64_t t, uint32_t comp, const std::function<bool(uint32_t)> &kept_prev, double out[3]) override
     {
         if (!ok || t < 1 || t + 1 >= h->T || (int)h->c_w.size() != h->ny) return false;

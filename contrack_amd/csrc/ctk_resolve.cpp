@@ -294,6 +294,15 @@ int ctk_resolve_ex(const void *const *blobs, const size_t *nbytes, int nshards, 
                 double inv = 1.0 / areacon;                 // contrack.py:721-722: reciprocal, then multiply
                 double fb = inv * bwd;
                 double ff = inv * fwd;
+                if (exact && !inexact) {
+                    // numpy can round INSIDE its reduction even when the total is representable: any sum that spans more than
+                    // 53 bits above the smallest weight bit (components with pole-row pixels) counts as rounded
+                    __int128 v = (__int128)A[(size_t)g * 2 + 1] * ((__int128)1 << CTK_LIMB_BITS) + (__int128)A[(size_t)g * 2];
+                    unsigned __int128 m = v < 0 ? (unsigned __int128)(-v) : (unsigned __int128)v;
+                    int bl = 0;
+                    while (m) { bl++; m >>= 1; }
+                    if (bl + 1 - exact->min_lsb() > 53) inexact = true;
+                }
                 if (inexact) {
                     // a rounded sum can differ from numpy's pairwise result by a few ulp: for decisions that sit that close
                     // to the threshold, take numpy's sums from the provider (single shard), else report them

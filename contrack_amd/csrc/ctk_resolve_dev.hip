@@ -48,6 +48,8 @@ struct ResolveDev {
     int32_t *op_first;                    // [NC+1] first op per label: reset to -1 here, filled by k_ops_ingest
     uint8_t *inex;                        // [NC] the component's own area or forward overlap is a rounded sum
     uint32_t *ambig;                      // set when a decision with a rounded sum lies within rounding distance of the threshold
+    int minlsb;                           // lowest set bit over the integer row weights (numpy can round inside its reduction when a sum
+                                          // spans more than 53 bits above it, even if the total is representable)
 };
 
 #define CTK_CHG_SLOTS 64            // 'changed' words per filter pass (= wave width: one ballot reads them)
@@ -151,6 +153,13 @@ __global__ void k_rs_prep(ResolveDev r)
         bool inexact = false;
         const double areacon = dev_limbs_to_double(r.A[2 * (int64_t)g], r.A[2 * (int64_t)g + 1], r.wshift, &inexact);
         const double fwd = dev_limbs_to_double(r.F[2 * (int64_t)g], r.F[2 * (int64_t)g + 1], r.wshift, &inexact);
+        {
+            const __int128 v = (__int128)r.A[2 * (int64_t)g + 1] * ((__int128)1 << CTK_LIMB_BITS) + (__int128)r.A[2 * (int64_t)g];
+            const unsigned __int128 m = v < 0 ? (unsigned __int128)(-v) : (unsigned __int128)v;
+            const uint64_t top = (uint64_t)(m >> 64), bot = (uint64_t)m;
+            const int bl = top ? 128 - __builtin_clzll(top) : (bot ? 64 - __builtin_clzll(bot) : 0);
+            if (bl + 1 - r.minlsb > 53) inexact = true;
+        }
         r.inex[g] = inexact ? 1 : 0;
         const double inv = 1.0 / areacon;                     // reciprocal, then multiply -- as the reference does
         r.inv[g] = inv;

@@ -69,6 +69,9 @@ static inline size_t ctk_blob_bytes(int64_t T, int64_t ncomps, int64_t npairs, i
 struct CtkExactAreas {
     virtual ~CtkExactAreas() {}
     virtual bool sums(int64_t t, uint32_t comp, const std::function<bool(uint32_t)> &kept_prev, double out[3]) = 0;
+    // lowest set bit over the integer row weights (ctk_weights_to_limbs scale): a sum whose integer needs more than
+    // 53 bits above it can be rounded somewhere inside numpy's reduction even if its total is representable
+    virtual int min_lsb() const = 0;
 };
 #endif
 
