@@ -128,6 +128,33 @@ def _random_case(i):
     return a, thr, gorl, overlap, persistence, twosided
 
 
+def _edge_case(i):
+    """tiny grids, T = 1..4, NaNs, thresholds that equal data values, zonal bands, per-step thresholds"""
+    rng = np.random.default_rng(50000 + i)
+    T = int(rng.integers(1, 9)); ny = int(rng.integers(2, 24)); nx = int(rng.choice([4, 5, 8, 12, 63, 64, 65, 100, 128, 129]))
+    levels = rng.integers(-3, 4, size=(T, ny, nx)).astype(np.float32)            # few distinct values: ties with the threshold
+    if rng.random() < 0.5:
+        levels = np.repeat(np.repeat(levels[:, ::2, ::2], 2, axis=1), 2, axis=2)[:, :ny, :nx].copy()
+    if rng.random() < 0.3:
+        levels[:, int(rng.integers(0, ny)), :] = 3                                   # a zonal band: wraps around the seam
+    if rng.random() < 0.3:
+        levels[rng.random(levels.shape) < 0.05] = np.nan
+    thr = rng.integers(-1, 3, size=T).astype(np.float64) if rng.random() < 0.5 else float(rng.integers(-1, 3))
+    return levels, thr, str(rng.choice([">=", ">", "<=", "<"])), float(rng.choice([0.0, 0.5, 1.0, 0.3])), int(rng.integers(1, 4)), bool(rng.integers(0, 2))
+
+
+@pytest.mark.parametrize("i", range(40))
+def test_randomized_edge_cases_against_oracle(trk, oracle_lib, i):
+    a, thr, gorl, ov, pers, two = _edge_case(i)
+    T, ny, nx = a.shape
+    lat = np.linspace(90, -90, ny).astype(np.float32)
+    w = oracle_lib.row_weights(lat, np.float32(180.0 / max(ny - 1, 1)), np.float32(360.0 / nx))
+    thrv = oracle_lib.prepare_thresholds(thr, T)
+    want, nw = oracle_lib.run_contrack(a, thrv, gorl, w, ov, pers, two)
+    got, ng = trk.track(a, thrv, _native.CMP_OPS[gorl], w, ov, pers, two)
+    assert np.array_equal(got, want) and ng == nw and trk.stats()["ambiguous_decisions"] == 0
+
+
 @pytest.mark.parametrize("i", range(36))
 def test_randomized_against_oracle(trk, oracle_lib, i):
     """random grids (incl. nx not a multiple of 4 / 64), fields, comparators, overlaps, persistences: bit-exact ids"""

@@ -9,13 +9,15 @@ from oracle import cpu_oracle
 spec = importlib.util.spec_from_file_location("tgp", os.path.join(ROOT, "tests", "test_gpu_parity.py"))
 m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
 first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (100, 200)
+EDGE = len(sys.argv) > 3 and sys.argv[3] == "edge"
+
 bad, fix, amb = [], 0, 0
 with _native.Tracker(0) as t:
     for i in range(first, first + count):
-        a, thr, gorl, ov, pers, two = m._random_case(i)
+        a, thr, gorl, ov, pers, two = m._edge_case(i) if EDGE else m._random_case(i)
         T, ny, nx = a.shape
         lat = np.linspace(90, -90, ny).astype(np.float32)
-        w = cpu_oracle.row_weights(lat, np.float32(180.0 / (ny - 1)), np.float32(360.0 / nx))
+        w = cpu_oracle.row_weights(lat, np.float32(180.0 / max(ny - 1, 1)), np.float32(360.0 / nx))
         thrv = cpu_oracle.prepare_thresholds(thr, T)
         want, nw = cpu_oracle.run_contrack(a, thrv, gorl, w, ov, pers, two)
         got, ng = t.track(a, thrv, _native.CMP_OPS[gorl], w, ov, pers, two)
