@@ -1,0 +1,96 @@
+"""The staged (time-sharded) C API driven in ONE process: N handles on one GPU play N ranks, the exchanges are plain
+device pointers / numpy reductions.  Random cases, random shard boundaries (shards of one step included), device and
+host resolver, compared with the single-call result.  python tools/fuzz_sharded.py [first] [count]"""
+import ctypes as C
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from contrack_amd import _native  # noqa: E402
+from oracle import cpu_oracle  # noqa: E402
+
+spec = importlib.util.spec_from_file_location("tgp", os.path.join(ROOT, "tests", "test_gpu_parity.py"))
+m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 100)
+
+
+def sharded(trks, a, thrv, op, w, ov, pers, two, cuts, device_resolve):
+    T, ny, nx = a.shape
+    n = len(cuts) - 1
+    bufs = []
+    for r in range(n):
+        t0, t1 = cuts[r], cuts[r + 1]
+        d_in, d_out = trks[r].malloc(max((t1 - t0) * ny * nx * 4, 8)), trks[r].malloc(max((t1 - t0) * ny * nx * 4, 8))
+        trks[r].h2d(d_in, np.ascontiguousarray(a[t0:t1]))
+        bufs.append((d_in, d_out))
+        trks[r].shard_label2d(d_in, t1 - t0, ny, nx, thrv[t0:t1], op, w, r > 0)
+    for r in range(n - 1):
+        p, sz = trks[r].halo_export()
+        trks[r].sync()
+        trks[r + 1].halo_import(p, sz)
+    for r in range(n):
+        trks[r].shard_overlap()
+    exts = []
+    if device_resolve:
+        blobs = [trks[r].shard_tables_dev() for r in range(n)]
+        for r in range(n):
+            trks[r].sync()
+        for r in range(n):
+            ext, nl = trks[r].shard_resolve_dev([b[0].value for b in blobs], [b[1] for b in blobs], r, cuts[r], ov, two)
+            trks[r].sync()
+            exts.append((ext, nl))
+    else:
+        host = [trks[r].shard_tables() for r in range(n)]
+        res = _native.resolve(host, ov, two)
+        for r in range(n):
+            exts.append(trks[r].shard_extents(res, r, cuts[r]))
+            trks[r].sync()
+    nl = exts[0][1]
+    arrs = []
+    for r in range(n):
+        e = np.empty(2 * (nl + 1), np.int32)
+        trks[r].d2h(e, exts[r][0])
+        arrs.append(e)
+    tmin = np.min([e[:nl + 1] for e in arrs], axis=0); tmax = np.max([e[nl + 1:] for e in arrs], axis=0)
+    red = np.concatenate([tmin, tmax]).astype(np.int32)
+    out, alive, bg = [], None, False
+    for r in range(n):
+        trks[r].h2d(exts[r][0], red)
+        na, z = trks[r].shard_write(pers, bufs[r][1])
+        f = np.empty((cuts[r + 1] - cuts[r], ny, nx), np.int32)
+        trks[r].d2h(f, bufs[r][1])
+        out.append(f); alive = na; bg = bg or z
+        trks[r].free(bufs[r][0]); trks[r].free(bufs[r][1])
+    return np.concatenate(out, axis=0), alive + (1 if bg else 0) - 1
+
+
+bad = []
+trks = [_native.Tracker(0) for _ in range(6)]
+ref = _native.Tracker(0)
+for i in range(first, first + count):
+    a, thr, gorl, ov, pers, two = m._random_case(i) if i % 3 else m._edge_case(i)
+    T, ny, nx = a.shape
+    if T < 2:
+        continue
+    rng = np.random.default_rng(7000 + i)
+    n = int(rng.integers(2, min(6, T) + 1))
+    inner = np.sort(rng.choice(np.arange(1, T), size=n - 1, replace=False))
+    cuts = [0] + [int(v) for v in inner] + [T]
+    lat = np.linspace(90, -90, ny).astype(np.float32)
+    w = cpu_oracle.row_weights(lat, np.float32(180.0 / max(ny - 1, 1)), np.float32(360.0 / nx))
+    thrv = cpu_oracle.prepare_thresholds(thr, T)
+    op = _native.CMP_OPS[gorl]
+    want, nw = ref.track(a, thrv, op, w, ov, pers, two)
+    fixups = ref.stats()["exact_fixups"]
+    for dev in (True, False):
+        try:
+            got, ng = sharded(trks, a, thrv, op, w, ov, pers, two, cuts, dev)
+        except Exception as e:                                    # noqa: BLE001
+            bad.append((i, cuts, dev, "EXC " + str(e)[:80])); continue
+        if not (np.array_equal(got, want) and ng == nw) and not fixups:
+            bad.append((i, a.shape, cuts, "dev" if dev else "host", ov))
+print("sharded fuzz %d..%d: problems %d %s" % (first, first + count - 1, len(bad), bad[:6]))
