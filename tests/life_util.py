@@ -54,3 +54,30 @@ def numpy_rows(flags, field, wrow):
             out.append((t, int(ident), shift, 0, w[m].sum(), wv[m].sum(), (wv * yy)[m].sum(), (wv * xr)[m].sum()))
     rows = np.array(out, dtype=LIFE_ROW) if out else np.empty(0, dtype=LIFE_ROW)
     return rows[np.lexsort((rows["t"], rows["label"]))]
+
+
+def random_life_case(i):
+    """random label planes (blobs, some joined across the seam, ids not contiguous, sometimes negative) and a positive
+    field: (flag, field, lat, lon, wrow, dates)"""
+    from scipy import ndimage
+    from contrack_amd.contrack import row_weights
+    rng = np.random.default_rng(90000 + i)
+    T = int(rng.integers(1, 7)); ny = int(rng.integers(3, 40)); nx = int(rng.choice([4, 7, 16, 33, 64, 65, 100, 130]))
+    # labelled blobs: threshold a smooth-ish random field, label with wrap-unaware scipy, then join ids across the seam at random
+    f = ndimage.uniform_filter(rng.standard_normal((T, ny, nx)), size=(1, 3, 5), mode=("nearest", "nearest", "wrap"))
+    flag = np.zeros((T, ny, nx), np.int32)
+    for t in range(T):
+        lab, n = ndimage.label(f[t] > 0.15)
+        perm = rng.permutation(np.arange(1, n + 1)) * int(rng.choice([1, 1, 7])) if n else np.array([], int)
+        flag[t] = np.where(lab > 0, np.concatenate([[0], perm])[lab], 0)
+        for y in range(ny):                                  # merge across the seam sometimes
+            if flag[t, y, 0] and flag[t, y, -1] and rng.random() < 0.7:
+                flag[t][flag[t] == flag[t, y, -1]] = flag[t, y, 0]
+    if rng.random() < 0.2:
+        flag[flag == flag.max()] = -5                            # a negative id
+    f64 = bool(rng.integers(0, 2))
+    field = (rng.random((T, ny, nx)) * 50 + 100).astype(np.float64 if f64 else np.float32)
+    lat = np.linspace(90, -90, ny).astype(np.float32); lon = (np.arange(nx) * (360.0 / nx)).astype(np.float32)
+    wrow = row_weights(lat, 180.0 / (ny - 1), 360.0 / nx)
+    dates = ["%02d" % t for t in range(T)]
+    return flag, field, lat, lon, wrow, dates

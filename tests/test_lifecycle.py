@@ -155,6 +155,17 @@ def test_hip_lifecycle_device_resident_and_empty(tracker):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("i", range(40))
+def test_hip_lifecycle_random_frames(tracker, i):
+    """random label planes (thin contours whose centre of mass is an integer up to rounding included): the frame equals
+    the scipy port's in every column, digit for digit"""
+    flag, field, lat, lon, wrow, dates = life_util.random_life_case(i)
+    rows = tracker.lifecycle(flag, field, wrow)
+    got = lifecycle_frame(rows, lat, lon, dates, flag, field, wrow)
+    assert got == lifecycle_port.run_lifecycle(flag, field, lat, lon, wrow, dates)
+
+
+@pytest.mark.gpu
 def test_hip_lifecycle_limits(tracker):
     ny, nx = 40, 64
     wrow = row_weights(np.linspace(60, 21, ny, dtype=np.float32), 1.0, 1.0)
