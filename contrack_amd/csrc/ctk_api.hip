@@ -77,6 +77,7 @@ struct ctk_handle {
         rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff, rv_dmap, rv_dorig, rv_dbox, rv_inex;
     // run_lifecycle reductions
     DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w;
+    DevBuf io_in, io_out;                          // device copies of host-array calls (ctk_track_f32 / _f64)
     std::vector<ctk_life_row> lc_host, lc_tmp;
     std::vector<std::pair<uint64_t, uint32_t>> lc_keys;
     std::vector<uint32_t> lc_cnt_host;
@@ -261,7 +262,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->g_label, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
                       &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
-                      &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex};
+                      &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->io_in, &h->io_out};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -1502,20 +1503,18 @@ static int track_host_impl(ctk_handle *h, const void *anom, bool f64, int64_t T,
     void *a_dev = nullptr;
     int32_t *f_dev = nullptr;
     if (n) {
-        hipError_t e = hipMalloc(&a_dev, n * esz);
-        if (e != hipSuccess) return ctk_set_error(CTK_E_NOMEM, "hipMalloc(%zu) for the input slab failed: %s", n * esz, hipGetErrorString(e));
-        e = hipMalloc((void **)&f_dev, n * 4);
-        if (e != hipSuccess) { (void)hipFree(a_dev); return ctk_set_error(CTK_E_NOMEM, "hipMalloc(%zu) for the flag slab failed: %s", n * 4, hipGetErrorString(e)); }
-        e = hipMemcpy(a_dev, anom, n * esz, hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(a_dev); (void)hipFree(f_dev); return ctk_set_error(CTK_E_NODEVICE, "H2D copy failed: %s", hipGetErrorString(e)); }
+        // device copies of the caller's slab and of the result live in the handle (grow-only), like every other buffer
+        CTKCHK(ensure(h, h->io_in, n * esz));
+        CTKCHK(ensure(h, h->io_out, n * 4));
+        a_dev = h->io_in.p; f_dev = P<int32_t>(h->io_out);
+        hipError_t e = hipMemcpy(a_dev, anom, n * esz, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return ctk_set_error(CTK_E_NODEVICE, "H2D copy failed: %s", hipGetErrorString(e));
     }
     int rc = track_dev_impl(h, a_dev, f64, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, f_dev, n_tracked);
     if (rc == CTK_OK && n) {
         hipError_t e = hipMemcpy(flag, f_dev, n * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = ctk_set_error(CTK_E_NODEVICE, "D2H copy failed: %s", hipGetErrorString(e));
     }
-    if (a_dev) (void)hipFree(a_dev);
-    if (f_dev) (void)hipFree(f_dev);
     return rc;
 }
 
