@@ -13,6 +13,8 @@
 #include <cstring>
 #include <algorithm>
 #include <vector>
+#include <atomic>
+#include <thread>
 
 int ctk_set_error(int code, const char *fmt, ...);            // ctk_resolve.cpp
 extern "C" int ctk_weights_to_limbs(const float *wrow, int ny, int32_t *wlo, int32_t *whi, int32_t *wshift);
@@ -51,6 +53,39 @@ enum State { ST_IDLE = 0, ST_LABELLED, ST_OVERLAPPED, ST_TABLES, ST_EXTENTS };
 
 #define CTK_KI_ROWCOUNT (CTK_K_COUNT + 1)
 
+// pinned bounce buffers of the host-array entries (bounce_copy)
+struct BounceLane {
+    void *pin[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+constexpr int kLanes = 4;
+constexpr size_t kBounce = (size_t)8 << 20;
+
+struct BouncePool {
+    BounceLane lane[kLanes];
+    bool ready = false;
+    bool init()
+    {
+        if (ready) return true;
+        for (int i = 0; i < kLanes; i++) {
+            for (int b = 0; b < 2; b++)
+                if (hipHostMalloc(&lane[i].pin[b], kBounce, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&lane[i].ev[b], hipEventDisableTiming) != hipSuccess) return false;
+            if (hipStreamCreateWithFlags(&lane[i].st, hipStreamNonBlocking) != hipSuccess) return false;
+        }
+        ready = true;
+        return true;
+    }
+    void destroy()
+    {
+        for (int i = 0; i < kLanes; i++) {
+            for (int b = 0; b < 2; b++) { if (lane[i].pin[b]) (void)hipHostFree(lane[i].pin[b]); if (lane[i].ev[b]) (void)hipEventDestroy(lane[i].ev[b]); }
+            if (lane[i].st) (void)hipStreamDestroy(lane[i].st);
+        }
+        ready = false;
+    }
+};
+
 struct ctk_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -78,6 +113,7 @@ struct ctk_handle {
     // run_lifecycle reductions
     DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w;
     DevBuf io_in, io_out;                          // device copies of host-array calls (ctk_track_f32 / _f64)
+    BouncePool *bounce = nullptr;                  // created on first use
     std::vector<ctk_life_row> lc_host, lc_tmp;
     std::vector<std::pair<uint64_t, uint32_t>> lc_keys;
     std::vector<uint32_t> lc_cnt_host;
@@ -269,6 +305,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
     if (h->h_cand) (void)hipHostFree(h->h_cand);
     if (h->h_ops) (void)hipHostFree(h->h_ops);
     if (h->h_mail) (void)hipHostFree(h->h_mail);
+    if (h->bounce) { h->bounce->destroy(); delete h->bounce; }
     if (h->h_mail1) (void)hipHostFree(h->h_mail1);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->ev_ready) for (int k = 0; k <= CTK_KI_ROWCOUNT; k++) { (void)hipEventDestroy(h->ev[k][0]); (void)hipEventDestroy(h->ev[k][1]); }
@@ -1493,6 +1530,54 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
     return CTK_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// host <-> device copies of pageable caller memory.  hipMemcpy stages such memory through one pinned buffer with one
+// CPU thread (~20 GB/s here); several threads, each with its own pinned bounce buffers and stream, keep more of the
+// link busy.  Used by the host-array entries only (ctk_track_f32 / _f64).
+// ------------------------------------------------------------------------------------------------
+namespace {
+// to_device: host -> device, else device -> host.  Lane i moves the chunks i, i + kLanes, ...
+bool bounce_copy(BouncePool &pool, int device, void *dev, void *host, size_t bytes, bool to_device)
+{
+    if (bytes < 4 * kBounce || !pool.init()) return false;                      // small copies: plain hipMemcpy
+    const size_t nchunk = (bytes + kBounce - 1) / kBounce;
+    std::atomic<bool> ok(true);
+    auto work = [&](int li) {
+        if (hipSetDevice(device) != hipSuccess) { ok = false; return; }
+        BounceLane &L = pool.lane[li];
+        int b = 0;
+        size_t pending[2] = {(size_t)-1, (size_t)-1};
+        auto drain = [&](int bb) {                                               // device -> host: finish the copy out of buffer bb
+            if (pending[bb] == (size_t)-1) return;
+            if (hipEventSynchronize(L.ev[bb]) != hipSuccess) ok = false;
+            if (!to_device) {
+                const size_t off = pending[bb] * kBounce, len = std::min(kBounce, bytes - off);
+                memcpy((char *)host + off, L.pin[bb], len);
+            }
+            pending[bb] = (size_t)-1;
+        };
+        for (size_t c = (size_t)li; c < nchunk && ok; c += kLanes, b ^= 1) {
+            drain(b);                                                             // the buffer is free again
+            const size_t off = c * kBounce, len = std::min(kBounce, bytes - off);
+            if (to_device) {
+                memcpy(L.pin[b], (const char *)host + off, len);
+                if (hipMemcpyAsync((char *)dev + off, L.pin[b], len, hipMemcpyHostToDevice, L.st) != hipSuccess) ok = false;
+            } else {
+                if (hipMemcpyAsync(L.pin[b], (const char *)dev + off, len, hipMemcpyDeviceToHost, L.st) != hipSuccess) ok = false;
+            }
+            if (hipEventRecord(L.ev[b], L.st) != hipSuccess) ok = false;
+            pending[b] = c;
+        }
+        drain(0); drain(1);
+    };
+    std::thread th[kLanes];
+    for (int i = 0; i < kLanes; i++) th[i] = std::thread(work, i);
+    for (int i = 0; i < kLanes; i++) th[i].join();
+    return ok;
+}
+}  // namespace
+
 static int track_host_impl(ctk_handle *h, const void *anom, bool f64, int64_t T, int ny, int nx, const double *thr, int cmp_op, const float *wrow,
                            double overlap, int persistence, int twosided, int32_t *flag, int64_t *n_tracked)
 {
@@ -1507,13 +1592,18 @@ static int track_host_impl(ctk_handle *h, const void *anom, bool f64, int64_t T,
         CTKCHK(ensure(h, h->io_in, n * esz));
         CTKCHK(ensure(h, h->io_out, n * 4));
         a_dev = h->io_in.p; f_dev = P<int32_t>(h->io_out);
-        hipError_t e = hipMemcpy(a_dev, anom, n * esz, hipMemcpyHostToDevice);
-        if (e != hipSuccess) return ctk_set_error(CTK_E_NODEVICE, "H2D copy failed: %s", hipGetErrorString(e));
+        if (!h->bounce) h->bounce = new (std::nothrow) BouncePool();
+        if (!h->bounce || !bounce_copy(*h->bounce, h->device, a_dev, const_cast<void *>(anom), n * esz, true)) {
+            hipError_t e = hipMemcpy(a_dev, anom, n * esz, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return ctk_set_error(CTK_E_NODEVICE, "H2D copy failed: %s", hipGetErrorString(e));
+        }
     }
     int rc = track_dev_impl(h, a_dev, f64, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, f_dev, n_tracked);
     if (rc == CTK_OK && n) {
-        hipError_t e = hipMemcpy(flag, f_dev, n * 4, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = ctk_set_error(CTK_E_NODEVICE, "D2H copy failed: %s", hipGetErrorString(e));
+        if (!h->bounce || !bounce_copy(*h->bounce, h->device, f_dev, flag, n * 4, false)) {
+            hipError_t e = hipMemcpy(flag, f_dev, n * 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) rc = ctk_set_error(CTK_E_NODEVICE, "D2H copy failed: %s", hipGetErrorString(e));
+        }
     }
     return rc;
 }
