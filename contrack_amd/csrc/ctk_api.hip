@@ -1761,21 +1761,17 @@ static int lifecycle_host_impl(ctk_handle *h, const int32_t *flag, const void *f
     HIPCHK(hipSetDevice(h->device));
     const size_t n = (size_t)T * ny * nx, esz = f64 ? 8 : 4;
     void *f_dev = nullptr, *v_dev = nullptr;
-    int rc = CTK_OK;
     if (n) {
-        hipError_t e = hipMalloc(&f_dev, n * 4);
-        if (e == hipSuccess) e = hipMalloc(&v_dev, n * esz);
-        if (e != hipSuccess) rc = ctk_set_error(CTK_E_NOMEM, "hipMalloc for the flag / field slabs failed: %s", hipGetErrorString(e));
-        if (rc == CTK_OK) {
-            e = hipMemcpy(f_dev, flag, n * 4, hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMemcpy(v_dev, field, n * esz, hipMemcpyHostToDevice);
-            if (e != hipSuccess) rc = ctk_set_error(CTK_E_NODEVICE, "H2D copy failed: %s", hipGetErrorString(e));
-        }
+        CTKCHK(ensure(h, h->io_out, n * 4));                     // the flag slab (the tracker's own result buffer, if it ran here)
+        CTKCHK(ensure(h, h->io_in, n * esz));
+        f_dev = h->io_out.p; v_dev = h->io_in.p;
+        if (!h->bounce) h->bounce = new (std::nothrow) BouncePool();
+        if (!h->bounce || !bounce_copy(*h->bounce, h->device, f_dev, const_cast<int32_t *>(flag), n * 4, true))
+            HIPCHK(hipMemcpy(f_dev, flag, n * 4, hipMemcpyHostToDevice));
+        if (!h->bounce || !bounce_copy(*h->bounce, h->device, v_dev, const_cast<void *>(field), n * esz, true))
+            HIPCHK(hipMemcpy(v_dev, field, n * esz, hipMemcpyHostToDevice));
     }
-    if (rc == CTK_OK) rc = lifecycle_dev_impl(h, (const int32_t *)f_dev, v_dev, f64, T, ny, nx, wrow, nrows);
-    if (f_dev) (void)hipFree(f_dev);
-    if (v_dev) (void)hipFree(v_dev);
-    return rc;
+    return lifecycle_dev_impl(h, (const int32_t *)f_dev, v_dev, f64, T, ny, nx, wrow, nrows);
 }
 
 extern "C" int ctk_lifecycle_f32_dev(ctk_handle *h, const int32_t *flag_dev, const float *field_dev, int64_t T, int ny, int nx, const float *wrow, int64_t *nrows)
