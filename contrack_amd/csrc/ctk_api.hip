@@ -13,6 +13,7 @@
 #include <cstring>
 #include <algorithm>
 #include <vector>
+#include <sys/mman.h>
 #include <atomic>
 #include <thread>
 
@@ -1600,6 +1601,11 @@ static int track_host_impl(ctk_handle *h, const void *anom, bool f64, int64_t T,
     }
     int rc = track_dev_impl(h, a_dev, f64, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, f_dev, n_tracked);
     if (rc == CTK_OK && n) {
+        // the result usually lands in freshly allocated, never touched memory: ask for huge pages (fewer first-touch faults)
+        {
+            const uintptr_t a0 = ((uintptr_t)flag + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1), a1 = ((uintptr_t)flag + n * 4) & ~(((uintptr_t)2 << 20) - 1);
+            if (a1 > a0) (void)madvise((void *)a0, a1 - a0, MADV_HUGEPAGE);
+        }
         if (!h->bounce || !bounce_copy(*h->bounce, h->device, f_dev, flag, n * 4, false)) {
             hipError_t e = hipMemcpy(flag, f_dev, n * 4, hipMemcpyDeviceToHost);
             if (e != hipSuccess) rc = ctk_set_error(CTK_E_NODEVICE, "D2H copy failed: %s", hipGetErrorString(e));
