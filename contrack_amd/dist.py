@@ -315,9 +315,18 @@ def bench_main(args, wl, workloads, hbm_peak):
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
     local = int(os.environ.get("LOCAL_RANK", rank))
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    comm = TorchComm(device=local)
+    backend = os.environ.get("CTK_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        comm = TorchComm(device=local)
+    else:
+        # plumbing check on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device): all ranks share
+        # GPU 0, the small exchanged buffers travel through gloo on the host.  Timings are meaningless then.
+        local = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+        comm = TorchComm(device=None)
     T, ny, nx = wl["T"], wl["ny"], wl["nx"]
     weak = getattr(args, "scaling", "weak") == "weak"
     if weak:

@@ -1,0 +1,36 @@
+"""bench.py's N > 1 leg end to end on ONE GPU: two ranks under torch.distributed.run, gloo instead of RCCL
+(CTK_DIST_BACKEND=gloo: RCCL refuses two ranks on one device), weak scaling = two members concatenated on the time
+axis.  The tracked count must equal the one-call result on the concatenated slab."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_weak_scaling():
+    env = dict(os.environ, CTK_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "era5_1deg_90"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]                       # ONE JSON line on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "timesteps/s"
+    assert out["config"]["total_timesteps"] == 180 and out["value"] > 0
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
+
+    from contrack_amd import _native, synth
+    from contrack_amd.contrack import row_weights
+    a = np.concatenate([synth.smooth_field(90, 181, 360, seed=r) for r in range(2)], axis=0)
+    lat, _ = synth.grid(181, 360)
+    w = row_weights(lat, np.float32(1.0), np.float32(1.0))
+    with _native.Tracker(0) as t:
+        _, n = t.track(a, np.full(180, 160.0), 0, w, 0.5, 5, True)
+    assert out["config"]["n_tracked"] == n
