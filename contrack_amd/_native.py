@@ -23,7 +23,7 @@ EXPORTS = [
     "ctk_track_f32_dev", "ctk_track_f64", "ctk_track_f64_dev", "ctk_shard_label2d", "ctk_shard_label2d_f64", "ctk_shard_halo_size", "ctk_shard_halo_export",
     "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_shard_tables_dev", "ctk_shard_resolve_dev", "ctk_resolve", "ctk_result_free",
     "ctk_result_info", "ctk_result_arrays", "ctk_result_nshards", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
-    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_set_timing", "ctk_get_timings", "ctk_set_device_resolve", "ctk_set_filter_round", "ctk_get_stats",
+    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_np_sum", "ctk_set_timing", "ctk_get_timings", "ctk_set_device_resolve", "ctk_set_filter_round", "ctk_get_stats",
     "ctk_dev_malloc", "ctk_dev_free", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
     "ctk_synth_fill",
     "ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev", "ctk_lifecycle_rows",
@@ -81,6 +81,8 @@ def lib():
     L.ctk_debug_label2d.argtypes = [p, i32, p]
     L.ctk_debug_set_pair_capacity.argtypes = [p, C.c_uint32]
     L.ctk_debug_set_mailbox.argtypes = [p, C.c_uint32, C.c_uint32]
+    L.ctk_debug_np_sum.argtypes = [p, sz]
+    L.ctk_debug_np_sum.restype = dbl
     L.ctk_set_timing.argtypes = [p, i32]
     L.ctk_get_timings.argtypes = [p, p]
     L.ctk_set_device_resolve.argtypes = [p, i32]

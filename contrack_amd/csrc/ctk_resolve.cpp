@@ -158,6 +158,9 @@ double ctk_np_sum(const double *a, size_t n)
 int ctk_resolve_ex(const void *const *blobs, const size_t *nbytes, int nshards, double overlap, int twosided, CtkExactAreas *exact,
                    ctk_result **out);
 
+// test hook (GPU-free): the numpy-order sum used for decisions on rounded area sums
+extern "C" double ctk_debug_np_sum(const double *a, size_t n) { return ctk_np_sum(a, n); }
+
 extern "C" int ctk_resolve(const void *const *blobs, const size_t *nbytes, int nshards, double overlap,
                            int twosided, ctk_result **out)
 {

@@ -140,6 +140,9 @@ int ctk_debug_label2d(ctk_handle *h, int before_seam, int32_t *lab /* (T,ny,nx) 
 
 /* test hook: the NEXT call behaves as if the pair table held only `records` entries (exercises regrowth) */
 int ctk_debug_set_pair_capacity(ctk_handle *h, uint32_t records);
+/* test hook, GPU-free: numpy's float64 add.reduce order (what np.sum(weight_grid[...]) computes, contrack.py:717-719), used to
+ * re-evaluate overlap decisions whose exactly accumulated area sums had to be rounded */
+double ctk_debug_np_sum(const double *a, size_t n);
 /* test hook: cap the device-written mailbox of the resolver hand-off (0 = no cap), so that the explicit-copy path runs */
 int ctk_debug_set_mailbox(ctk_handle *h, uint32_t cand_records, uint32_t labels);
 

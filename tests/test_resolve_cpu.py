@@ -66,3 +66,20 @@ def test_weight_limbs_exact_and_range():
         assert (int(lo[i]) + int(hi[i]) * 2 ** 31) / 2.0 ** sh == float(w[i])
     with pytest.raises(ValueError):
         _native.weights_to_limbs(np.array([1.0, np.inf], dtype=np.float32))
+
+
+def test_numpy_order_sum_matches_numpy():
+    """ctk_np_sum (the resolver's restatement of numpy's pairwise float64 add.reduce) against np.sum itself, on weights of
+    very different magnitude (pole rows next to ordinary rows) and lengths across the 8 / 128 / 8192 block boundaries"""
+    import numpy as np
+    from contrack_amd import _native
+    L = _native.lib()
+    rng = np.random.default_rng(5)
+    for n in [0, 1, 7, 8, 9, 127, 128, 129, 255, 1000, 8191, 8192, 8193, 20000, 70001]:
+        for _ in range(3):
+            big = rng.choice(np.float32([25784.098, 450.2, 12873.4, 3.0e4]).astype(np.float64), size=n)
+            tiny = np.float64(np.float32(-1.6157e-2))
+            a = np.where(rng.random(n) < 0.3, tiny, big).astype(np.float64)
+            a = np.ascontiguousarray(np.sort(a) if rng.random() < 0.3 else a)
+            got = L.ctk_debug_np_sum(a.ctypes.data, n)
+            assert got == float(np.sum(a)), n
