@@ -73,7 +73,7 @@ def lib():
     L.ctk_result_info.argtypes = [p] + [C.POINTER(i64)] * 5
     L.ctk_result_arrays.argtypes = [p, pp, C.POINTER(i64), pp, C.POINTER(i64), pp, pp]
     L.ctk_result_nshards.argtypes = [p]
-    L.ctk_weights_to_limbs.argtypes = [p, i32, p, p, C.POINTER(C.c_int32)]
+    L.ctk_weights_to_limbs.argtypes = [p, i32, i64, p, p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ctk_shard_extents.argtypes = [p, p, i32, i64, pp, C.POINTER(i64)]
     L.ctk_shard_write.argtypes = [p, i32, p, C.POINTER(i64), C.POINTER(i32)]
     L.ctk_shard_count_tracked.argtypes = [p, C.POINTER(i64)]
@@ -117,13 +117,15 @@ def device_count():
     return int(lib().ctk_device_count())
 
 
-def weights_to_limbs(wrow):
+def weights_to_limbs(wrow, npix=1 << 16, with_bits=False):
+    """exact integer limbs of float32 row weights: w[y] = (lo[y] + hi[y] * 2**bits) / 2**shift.  npix = ny * nx of the grid
+    (only matters when the weights span more than 62 bits).  Returns (lo, hi, shift) or (lo, hi, shift, bits)."""
     wrow = np.ascontiguousarray(wrow, dtype=np.float32)
-    lo = np.empty(wrow.shape[0], dtype=np.int32)
-    hi = np.empty(wrow.shape[0], dtype=np.int32)
-    sh = C.c_int32(0)
-    check(lib().ctk_weights_to_limbs(wrow.ctypes.data, wrow.shape[0], lo.ctypes.data, hi.ctypes.data, C.byref(sh)))
-    return lo, hi, int(sh.value)
+    lo = np.empty(wrow.shape[0], dtype=np.int64)
+    hi = np.empty(wrow.shape[0], dtype=np.int64)
+    sh, lb = C.c_int32(0), C.c_int32(0)
+    check(lib().ctk_weights_to_limbs(wrow.ctypes.data, wrow.shape[0], int(npix), lo.ctypes.data, hi.ctypes.data, C.byref(sh), C.byref(lb)))
+    return (lo, hi, int(sh.value), int(lb.value)) if with_bits else (lo, hi, int(sh.value))
 
 
 class Result:

@@ -18,7 +18,7 @@
 #include <thread>
 
 int ctk_set_error(int code, const char *fmt, ...);            // ctk_resolve.cpp
-extern "C" int ctk_weights_to_limbs(const float *wrow, int ny, int32_t *wlo, int32_t *whi, int32_t *wshift);
+extern "C" int ctk_weights_to_limbs(const float *wrow, int ny, int64_t npix, int64_t *wlo, int64_t *whi, int32_t *wshift, int32_t *limb_bits);
 int ctk_resolve_ex(const void *const *blobs, const size_t *nbytes, int nshards, double overlap, int twosided, CtkExactAreas *exact,
                    ctk_result **out);                              // ctk_resolve.cpp
 double ctk_np_sum(const double *a, size_t n);
@@ -97,7 +97,7 @@ struct ctk_handle {
     // geometry of the current shard
     int64_t T = 0;
     int ny = 0, nx = 0, W = 0, has_prev = 0, cmp_op = 0;
-    int32_t wshift = 0;
+    int32_t wshift = 0, limb_bits = CTK_LIMB_BITS_MIN;
     uint32_t total_runs = 0, max_runs_step = 0, total_comps = 0;
     uint32_t pair_cap = 0, seam_cap = 0;
     bool need_glb = false;
@@ -110,7 +110,7 @@ struct ctk_handle {
     DevBuf g_ncomp, g_cprefix, g_mrep, g_box, g_area, g_comp_t, g_pairs, g_pair_base, g_pair_cnt, g_seams, g_seam_cnt, g_seam_off, g_counters, g_label;
     // device resolver work space
     DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lbox,
-        rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff, rv_dmap, rv_dorig, rv_dbox, rv_inex;
+        rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff, rv_dmap, rv_dorig, rv_dbox, rv_inex, rv_touch;
     // run_lifecycle reductions
     DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w;
     DevBuf io_in, io_out;                          // device copies of host-array calls (ctk_track_f32 / _f64)
@@ -128,7 +128,7 @@ struct ctk_handle {
     uint32_t rb_last = 0, rb_total = 0;   // run_base[T-1], run_base[T]
     // what the device copies of thresholds / weight limbs were made from
     std::vector<double> c_thr; std::vector<float> c_w;
-    int64_t c_T = -1; bool c_f64 = false, c_thr_valid = false, c_w_valid = false; int c_cmp = -1;
+    int64_t c_T = -1; bool c_f64 = false, c_thr_valid = false, c_w_valid = false; int c_cmp = -1, c_w_nx = -1;
     int w_minlsb = 0;                            // lowest set bit over the integer row weights
     int64_t last_alive = 0;
     int64_t rowoff_T = -1; int rowoff_ny = -1; void *rowoff_p = nullptr;     // what seam_rowoff currently holds
@@ -299,7 +299,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->g_label, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
                       &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
-                      &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->io_in, &h->io_out};
+                      &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -424,13 +424,14 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     // Thresholds / weights equal to the previous call's are already on the device: nothing is converted or uploaded.
     const size_t thr_bytes = (size_t)std::max<int64_t>(T, 1) * 8;
     const bool same_thr = h->c_thr_valid && h->c_T == T && h->c_f64 == f64 && h->c_cmp == cmp_op && (T == 0 || memcmp(h->c_thr.data(), thr, (size_t)T * 8) == 0);
-    const bool same_w = h->c_w_valid && (int)h->c_w.size() == ny && memcmp(h->c_w.data(), wrow, (size_t)ny * 4) == 0;
+    const bool same_w = h->c_w_valid && (int)h->c_w.size() == ny && h->c_w_nx == nx && memcmp(h->c_w.data(), wrow, (size_t)ny * 4) == 0;
     double *thr32 = nullptr;
-    int32_t *wlo = nullptr;
+    int64_t *wlo = nullptr;
+    const size_t w_bytes = (size_t)ny * 16 + ((size_t)ny + 2) * 4;    // wlo[ny] whi[ny] (int64) next_tiny[ny+1] (int32)
     if (!same_thr || !same_w) {
-        CTKCHK(ensure_host(&h->h_stage, &h->h_stage_cap, thr_bytes + (size_t)ny * 8));
+        CTKCHK(ensure_host(&h->h_stage, &h->h_stage_cap, thr_bytes + w_bytes));
         thr32 = (double *)h->h_stage;                                 // float32 thresholds in the first half when !f64
-        wlo = (int32_t *)((char *)h->h_stage + thr_bytes);
+        wlo = (int64_t *)((char *)h->h_stage + thr_bytes);
     }
     if (!same_thr) {
         h->c_thr_valid = false;
@@ -441,13 +442,32 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     }
     if (!same_w) {
         h->c_w_valid = false;
-        CTKCHK(ctk_weights_to_limbs(wrow, ny, wlo, wlo + ny, &h->wshift));
+        CTKCHK(ctk_weights_to_limbs(wrow, ny, (int64_t)ny * nx, wlo, wlo + ny, &h->wshift, &h->limb_bits));
         h->c_w.assign(wrow, wrow + ny);
-        h->w_minlsb = 62;
+        h->c_w_nx = nx;
+        // Lowest set bit of every integer row weight.  A float64 partial sum of rows whose lowest bits are all >= L is exact in
+        // ANY order while it stays below 2^(L+53).  No area sum exceeds max|W| * ny * nx: rows with bits below that bound - 53
+        // (the pole rows) are the only ones that can make numpy's pairwise sum differ from the exact sum rounded once.
+        std::vector<int> lsb((size_t)ny, 127);
+        int maxbl = 0;
+        h->w_minlsb = 127;
         for (int y = 0; y < ny; y++) {
-            const int64_t wi = (int64_t)wlo[y] + ((int64_t)wlo[ny + y] << CTK_LIMB_BITS);
-            if (wi) h->w_minlsb = std::min(h->w_minlsb, __builtin_ctzll((unsigned long long)(wi < 0 ? -wi : wi)));
+            const __int128 wi = (__int128)wlo[y] + ((__int128)wlo[ny + y] << h->limb_bits);
+            if (wi == 0) continue;
+            unsigned __int128 m = wi < 0 ? (unsigned __int128)(-wi) : (unsigned __int128)wi;
+            int l = 0, bl = 0;
+            while (!((m >> l) & 1)) l++;
+            for (unsigned __int128 q = m; q; q >>= 1) bl++;
+            lsb[(size_t)y] = l;
+            maxbl = std::max(maxbl, bl);
+            h->w_minlsb = std::min(h->w_minlsb, l);
         }
+        if (h->w_minlsb == 127) h->w_minlsb = 0;
+        int lg = 0;
+        while (((int64_t)1 << lg) < (int64_t)ny * nx) lg++;
+        int32_t *next_tiny = (int32_t *)(wlo + 2 * (size_t)ny);
+        next_tiny[ny] = ny;
+        for (int y = ny - 1; y >= 0; y--) next_tiny[y] = (lsb[(size_t)y] < maxbl + lg - 53) ? y : next_tiny[y + 1];
     }
 
     CTKCHK(ensure(h, h->mask, (size_t)nrows * W * 8));
@@ -458,7 +478,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     CTKCHK(ensure(h, h->ncomp, (size_t)T * 4));
     CTKCHK(ensure(h, h->cprefix, (size_t)(T + 1) * 4));
     CTKCHK(ensure(h, h->thr32, (size_t)T * 8));
-    CTKCHK(ensure(h, h->wlo, (size_t)ny * 8));                        // wlo[ny] whi[ny] in one allocation
+    CTKCHK(ensure(h, h->wlo, w_bytes));                               // wlo[ny] whi[ny] next_tiny[ny+1] in one allocation
     CTKCHK(ensure(h, h->counters, CTK_CNT_N * 4));
     CTKCHK(ensure_host(&h->h_small, &h->h_small_cap, (size_t)(T + 1) * 4 + 1024));     // run_base copy + scalar downloads
 
@@ -467,7 +487,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         HIPCHK(hipMemsetAsync(h->tcount.p, 0, (size_t)T * 4, s));
         if (!same_thr) { HIPCHK(hipMemcpyAsync(h->thr32.p, thr32, (size_t)T * (f64 ? 8 : 4), hipMemcpyHostToDevice, s)); h->c_thr_valid = true; }
     }
-    if (!same_w) { HIPCHK(hipMemcpyAsync(h->wlo.p, wlo, (size_t)ny * 8, hipMemcpyHostToDevice, s)); h->c_w_valid = true; }    // wlo and whi are adjacent on both sides
+    if (!same_w) { HIPCHK(hipMemcpyAsync(h->wlo.p, wlo, w_bytes, hipMemcpyHostToDevice, s)); h->c_w_valid = true; }    // same layout on both sides
     HT("uploads queued");
 
     if (T > 0) {
@@ -511,7 +531,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         a.run_base = P<uint32_t>(h->run_base); a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp);
         a.cs_mrep = P<uint32_t>(h->cs_mrep); a.cs_box = P<uint32_t>(h->cs_box); a.cs_area = P<int64_t>(h->cs_area);
         a.seams = P<CtkSeam>(h->seams); a.seam_cnt = P<uint32_t>(h->seam_cnt); a.counters = P<uint32_t>(h->counters);
-        a.wlo = P<int32_t>(h->wlo); a.whi = P<int32_t>(h->wlo) + h->ny;
+        a.wlo = P<int64_t>(h->wlo); a.whi = P<int64_t>(h->wlo) + h->ny;
         a.ny = ny; a.nx = nx; a.W = W; a.lds_cap = CTK_LDS_RUNS; a.cap_runs = cap_runs;
         a.g_x0 = P<uint16_t>(h->g_x0); a.g_x1 = P<uint16_t>(h->g_x1); a.g_y = P<uint16_t>(h->g_y);
         a.g_parent = P<uint32_t>(h->g_parent); a.g_root = P<uint32_t>(h->g_root); a.g_idmap = P<uint32_t>(h->g_idmap);
@@ -691,7 +711,7 @@ static int launch_overlap(ctk_handle *h)
     a.has_prev = (h->has_prev && hl) ? 1 : 0;
     a.pairs = P<CtkPair>(h->pairs); a.pair_cap = h->pair_cap; a.counters = P<uint32_t>(h->counters);
     a.pair_base = P<uint32_t>(h->pair_base); a.pair_cnt = P<uint32_t>(h->pair_cnt);
-    a.wlo = P<int32_t>(h->wlo); a.whi = P<int32_t>(h->wlo) + h->ny;
+    a.wlo = P<int64_t>(h->wlo); a.whi = P<int64_t>(h->wlo) + h->ny;
     a.ny = h->ny; a.nx = h->nx; a.W = h->W;
     Timer tm(h, CTK_K_OVERLAP);
     k_overlap<<<(int)h->T, 256, 0, h->stream>>>(a);
@@ -772,7 +792,7 @@ static int build_tables_blob(ctk_handle *h, bool to_device, const void **blob, s
     const hipMemcpyKind kind = to_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     CtkBlobHeader hdr;
     memset(&hdr, 0, sizeof(hdr));
-    hdr.magic = CTK_BLOB_MAGIC; hdr.T = T; hdr.ny = h->ny; hdr.nx = h->nx; hdr.wshift = h->wshift; hdr.has_prev = (h->has_prev && h->halo_in.p) ? 1 : 0;
+    hdr.magic = CTK_BLOB_MAGIC; hdr.T = T; hdr.ny = h->ny; hdr.nx = h->nx; hdr.wshift = h->wshift; hdr.limb_bits = h->limb_bits; hdr.has_prev = (h->has_prev && h->halo_in.p) ? 1 : 0;
     hdr.ncomps = NC; hdr.npairs = NP; hdr.nseams = NS; hdr.npairs_grouped = NPG;
     if (to_device) HIPCHK(hipMemcpyAsync(p, &hdr, sizeof(hdr), hipMemcpyHostToDevice, s)); else memcpy(p, &hdr, sizeof(hdr));
     p += sizeof(CtkBlobHeader);
@@ -1061,11 +1081,12 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     CTKCHK(ensure(h, h->rv_dmap, (R + 1) * 4)); CTKCHK(ensure(h, h->rv_dorig, DC * 4)); CTKCHK(ensure(h, h->rv_dbox, DC * 24));
     CTKCHK(ensure(h, h->op_first, (R + 1) * 4));
     CTKCHK(ensure(h, h->rv_inex, R));
+    CTKCHK(ensure(h, h->rv_touch, R * 4));
 
     ResolveDev r;
     r.ncomp = in.ncomp; r.cprefix = in.cprefix; r.mrep = in.mrep; r.comp_t = in.comp_t;
     r.box = in.box; r.A = in.area; r.pairs = in.pairs; r.counters = in.counters;
-    r.pair_cap = in.pair_cap; r.T = T; r.wshift = h->wshift; r.overlap = overlap; r.twosided = twosided;
+    r.pair_cap = in.pair_cap; r.T = T; r.wshift = h->wshift; r.limb_bits = h->limb_bits; r.overlap = overlap; r.twosided = twosided;
     r.p_rc = P<uint32_t>(h->rv_prc); r.p_rd = P<uint32_t>(h->rv_prd); r.p_gc = P<uint32_t>(h->rv_pgc); r.p_gd = P<uint32_t>(h->rv_pgd);
     r.F = P<int64_t>(h->rv_F); r.B = P<int64_t>(h->rv_B); r.keep0 = P<uint8_t>(h->rv_keep0); r.keep1 = P<uint8_t>(h->rv_keep1);
     r.changed = P<uint32_t>(h->rv_changed); r.parent = P<uint32_t>(h->rv_parent); r.isroot = P<uint32_t>(h->rv_isroot);
@@ -1073,6 +1094,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     r.mark = P<uint8_t>(h->rv_mark); r.inv = P<double>(h->rv_inv); r.ff = P<double>(h->rv_ff);
     r.dmap = P<uint32_t>(h->rv_dmap); r.dorig = P<int32_t>(h->rv_dorig); r.dbox = P<int32_t>(h->rv_dbox); r.dcount = P<uint32_t>(h->rv_scalars); r.op_first = P<int32_t>(h->op_first);
     r.inex = P<uint8_t>(h->rv_inex); r.ambig = P<uint32_t>(h->rv_scalars) + 1; r.minlsb = h->w_minlsb;
+    r.next_tiny = (const int32_t *)(P<int64_t>(h->wlo) + 2 * (size_t)h->ny); r.touch = P<uint32_t>(h->rv_touch);
 
     const int gc = (int)std::min<size_t>((R + 255) / 256, 2048), gp = (int)std::min<size_t>((PC + 255) / 256, 2048);
     // mailbox in pinned host memory: the last resolver kernel writes scalars, candidate records and dense label tables
@@ -1324,7 +1346,7 @@ extern "C" int ctk_shard_resolve_dev(ctk_handle *h, const void *const *blobs_dev
         HIPCHK(hipMemcpy(&hd[(size_t)k], blobs_dev[k], sizeof(CtkBlobHeader), hipMemcpyDeviceToHost));
         const CtkBlobHeader &q = hd[(size_t)k];
         if (q.magic != CTK_BLOB_MAGIC || q.T < 0 || q.ncomps < 0 || q.npairs < 0 || q.nseams < 0 || q.npairs_grouped < 0 || q.npairs_grouped > q.npairs ||
-            ctk_blob_bytes(q.T, q.ncomps, q.npairs, q.nseams) > nbytes[k] || q.ny != h->ny || q.nx != h->nx || q.wshift != h->wshift)
+            ctk_blob_bytes(q.T, q.ncomps, q.npairs, q.nseams) > nbytes[k] || q.ny != h->ny || q.nx != h->nx || q.wshift != h->wshift || q.limb_bits != h->limb_bits)
             return ctk_set_error(CTK_E_INVALID, "blob %d is malformed or belongs to another grid", k);
         T += q.T; NC += q.ncomps; NPG += q.npairs_grouped; NPU += q.npairs - q.npairs_grouped; NS += q.nseams;
     }
@@ -1691,15 +1713,15 @@ static int lifecycle_dev_impl(ctk_handle *h, const int32_t *flag_dev, const void
     h->lc_host.clear();
     if (nrows) *nrows = 0;
     if (T == 0) return CTK_OK;
-    std::vector<int32_t> wlo(ny), whi(ny);
-    int32_t wshift = 0;
-    CTKCHK(ctk_weights_to_limbs(wrow, ny, wlo.data(), whi.data(), &wshift));
-    CTKCHK(ensure(h, h->lc_wlo, (size_t)ny * 4));
-    CTKCHK(ensure(h, h->lc_whi, (size_t)ny * 4));
+    std::vector<int64_t> wlo(ny), whi(ny);
+    int32_t wshift = 0, limb_bits = 0;
+    CTKCHK(ctk_weights_to_limbs(wrow, ny, (int64_t)ny * nx, wlo.data(), whi.data(), &wshift, &limb_bits));
+    CTKCHK(ensure(h, h->lc_wlo, (size_t)ny * 8));
+    CTKCHK(ensure(h, h->lc_whi, (size_t)ny * 8));
     CTKCHK(ensure(h, h->lc_w, (size_t)ny * 4));
     CTKCHK(ensure(h, h->lc_cnt, 16));
-    HIPCHK(hipMemcpyAsync(h->lc_wlo.p, wlo.data(), (size_t)ny * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->lc_whi.p, whi.data(), (size_t)ny * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->lc_wlo.p, wlo.data(), (size_t)ny * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->lc_whi.p, whi.data(), (size_t)ny * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->lc_w.p, wrow, (size_t)ny * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));          // wlo / whi are stack-lifetime vectors
     const int nxw = (nx + 31) / 32;
@@ -1711,12 +1733,12 @@ static int lifecycle_dev_impl(ctk_handle *h, const int32_t *flag_dev, const void
         cap = h->lc_rows.cap / sizeof(CtkLifeRowDev);
         HIPCHK(hipMemsetAsync(h->lc_cnt.p, 0, 16, h->stream));
         if (f64)
-            k_lifecycle<double><<<(unsigned)T, LC_THREADS, (size_t)ks * nxw * 4, h->stream>>>(flag_dev, (const double *)field_dev, ny, nx, nxw, ks, P<int32_t>(h->lc_wlo),
-                                                                                           P<int32_t>(h->lc_whi), P<float>(h->lc_w), wshift,
+            k_lifecycle<double><<<(unsigned)T, LC_THREADS, (size_t)ks * nxw * 4, h->stream>>>(flag_dev, (const double *)field_dev, ny, nx, nxw, ks, P<int64_t>(h->lc_wlo),
+                                                                                           P<int64_t>(h->lc_whi), P<float>(h->lc_w), wshift, limb_bits,
                                                                                            P<CtkLifeRowDev>(h->lc_rows), cap, P<unsigned long long>(h->lc_cnt));
         else
-            k_lifecycle<float><<<(unsigned)T, LC_THREADS, (size_t)ks * nxw * 4, h->stream>>>(flag_dev, (const float *)field_dev, ny, nx, nxw, ks, P<int32_t>(h->lc_wlo),
-                                                                                          P<int32_t>(h->lc_whi), P<float>(h->lc_w), wshift,
+            k_lifecycle<float><<<(unsigned)T, LC_THREADS, (size_t)ks * nxw * 4, h->stream>>>(flag_dev, (const float *)field_dev, ny, nx, nxw, ks, P<int64_t>(h->lc_wlo),
+                                                                                          P<int64_t>(h->lc_whi), P<float>(h->lc_w), wshift, limb_bits,
                                                                                           P<CtkLifeRowDev>(h->lc_rows), cap, P<unsigned long long>(h->lc_cnt));
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(cnt, h->lc_cnt.p, 16, hipMemcpyDeviceToHost, h->stream));

@@ -361,7 +361,7 @@ struct Label2dArgs {
     CtkSeam *seams;                // row-indexed scratch [T][ny]
     uint32_t *seam_cnt;            // [T]
     uint32_t *counters;            // CTK_CNT_*
-    const int32_t *wlo, *whi;      // [ny] weight limbs
+    const int64_t *wlo, *whi;      // [ny] weight limbs
     int ny, nx, W;
     uint32_t lds_cap;              // runs the LDS variant carries
     uint32_t cap_runs;             // runs the run-indexed buffers hold (a speculative launch may precede the size check)
@@ -530,8 +530,8 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
         const int y = yrow[r];
         const int64_t len = (int64_t)x1[r] - (int64_t)x0[r] + 1;
         const uint32_t cm = idmap[parent[r]];              // seam-merged component: its area is what contrack.py:717 sums
-        atomicAdd((unsigned long long *)&carea[cm * 2], (unsigned long long)(len * (int64_t)a.wlo[y]));
-        atomicAdd((unsigned long long *)&carea[cm * 2 + 1], (unsigned long long)(len * (int64_t)a.whi[y]));
+        atomicAdd((unsigned long long *)&carea[cm * 2], (unsigned long long)(len * a.wlo[y]));
+        atomicAdd((unsigned long long *)&carea[cm * 2 + 1], (unsigned long long)(len * a.whi[y]));
         atomicMin(&cbox[c * 4 + 0], (uint32_t)y);
         atomicMax(&cbox[c * 4 + 1], (uint32_t)y);
         atomicMin(&cbox[c * 4 + 2], (uint32_t)x0[r]);
@@ -676,7 +676,7 @@ struct OverlapArgs {
     uint32_t *pair_base, *pair_cnt; // [T]
     uint32_t *counters;            // records that found no hash slot are stored from the END of `pairs` downwards
                                    // (pairs[pair_cap-1-i]), counted by CTK_CNT_UPAIRS
-    const int32_t *wlo, *whi;
+    const int64_t *wlo, *whi;
     int ny, nx, W;
 };
 

@@ -48,8 +48,8 @@ __device__ inline int lc_slot(int32_t *hkey, int32_t label)
 
 template <typename VT>
 __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restrict__ flag, const VT *__restrict__ field, int ny, int nx, int nxw,
-                                                          int ks, const int32_t *__restrict__ wlo, const int32_t *__restrict__ whi,
-                                                          const float *__restrict__ wrow, int wshift, CtkLifeRowDev *rows,
+                                                          int ks, const int64_t *__restrict__ wlo, const int64_t *__restrict__ whi,
+                                                          const float *__restrict__ wrow, int wshift, int limb_bits, CtkLifeRowDev *rows,
                                                           unsigned long long cap_rows, unsigned long long *counters)
 {
     __shared__ int32_t hkey[LC_HASH];
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
     for (int i = tid; i < n; i += LC_THREADS) {
         CtkLifeRowDev r;
         r.t = (int32_t)t; r.label = dlabel[i]; r.shift = dshift[i]; r.pad = 0;
-        r.area = dev_limbs_to_double(alo[i], ahi[i], wshift);
+        r.area = dev_limbs_to_double(alo[i], ahi[i], wshift, limb_bits);
         r.swv = swv[i]; r.swvy = swvy[i]; r.swvx = swvx[i];
         rows[base + i] = r;
     }

@@ -38,14 +38,14 @@ int ctk_set_error(int code, const char *fmt, ...)
 }
 
 // ---------------------------------------------------------------------------------------------
-// exact limb sums -> float64.  value = (hi * 2^31 + lo) * 2^-wshift, rounded ONCE to nearest-even.
+// exact limb sums -> float64.  value = (hi * 2^lb + lo) * 2^-wshift, rounded ONCE to nearest-even.
 // numpy evaluates the same sum pairwise in float64 (contrack.py:717-719); both agree whenever the
 // exact sum is representable, which holds for every component whose fraction can tie with the
 // overlap threshold in practice (DESIGN.md "exact areas").  *inexact reports a rounded result.
 // ---------------------------------------------------------------------------------------------
-static double limbs_to_double(int64_t lo, int64_t hi, int wshift, bool *inexact)
+static double limbs_to_double(int64_t lo, int64_t hi, int wshift, int lb, bool *inexact)
 {
-    __int128 v = (__int128)hi * ((__int128)1 << CTK_LIMB_BITS) + (__int128)lo;
+    __int128 v = (__int128)hi * ((__int128)1 << lb) + (__int128)lo;
     if (v == 0) return 0.0;
     bool neg = v < 0;
     unsigned __int128 a = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
@@ -178,12 +178,13 @@ int ctk_resolve_ex(const void *const *blobs, const size_t *nbytes, int nshards, 
         for (int s = 0; s < nshards; s++) {
             if (!parse(blobs[s], nbytes[s], sv[(size_t)s])) return ctk_set_error(CTK_E_INVALID, "ctk_resolve: blob %d is malformed", s);
             const CtkBlobHeader *h = sv[(size_t)s].h;
-            if (h->ny != sv[0].h->ny || h->nx != sv[0].h->nx || h->wshift != sv[0].h->wshift)
+            if (h->ny != sv[0].h->ny || h->nx != sv[0].h->nx || h->wshift != sv[0].h->wshift || h->limb_bits != sv[0].h->limb_bits)
                 return ctk_set_error(CTK_E_INVALID, "ctk_resolve: shards disagree on grid / weight scale");
             T += h->T; NC += h->ncomps; NP += h->npairs; NS += h->nseams;
         }
         const int nx = sv[0].h->nx;
-        const int wshift = sv[0].h->wshift;
+        const int wshift = sv[0].h->wshift, lb = sv[0].h->limb_bits;
+        if (lb < CTK_LIMB_BITS_MIN || lb > CTK_LIMB_BITS_MAX) return ctk_set_error(CTK_E_INVALID, "ctk_resolve: limb width %d out of range", lb);
         if (NC >= ((int64_t)1 << 31) - 2) return ctk_set_error(CTK_E_RANGE, "ctk_resolve: %lld components exceed int32 ids", (long long)NC);
 
         // ---- flatten: global timestep index, component offsets ---------------------------------
@@ -291,16 +292,16 @@ int ctk_resolve_ex(const void *const *blobs, const size_t *nbytes, int nshards, 
             for (int64_t g = coff[(size_t)t]; g < coff[(size_t)t + 1]; g++) {
                 if ((int64_t)(coff[(size_t)t] + mrep[(size_t)g]) != g) continue;       // representatives only
                 bool inexact = false;
-                double areacon = limbs_to_double(A[(size_t)g * 2], A[(size_t)g * 2 + 1], wshift, &inexact);
-                double fwd = limbs_to_double(F[(size_t)g * 2], F[(size_t)g * 2 + 1], wshift, &inexact);
-                double bwd = limbs_to_double(B[(size_t)g * 2], B[(size_t)g * 2 + 1], wshift, &inexact);
+                double areacon = limbs_to_double(A[(size_t)g * 2], A[(size_t)g * 2 + 1], wshift, lb, &inexact);
+                double fwd = limbs_to_double(F[(size_t)g * 2], F[(size_t)g * 2 + 1], wshift, lb, &inexact);
+                double bwd = limbs_to_double(B[(size_t)g * 2], B[(size_t)g * 2 + 1], wshift, lb, &inexact);
                 double inv = 1.0 / areacon;                 // contrack.py:721-722: reciprocal, then multiply
                 double fb = inv * bwd;
                 double ff = inv * fwd;
                 if (exact && !inexact) {
                     // numpy can round INSIDE its reduction even when the total is representable: any sum that spans more than
                     // 53 bits above the smallest weight bit (components with pole-row pixels) counts as rounded
-                    __int128 v = (__int128)A[(size_t)g * 2 + 1] * ((__int128)1 << CTK_LIMB_BITS) + (__int128)A[(size_t)g * 2];
+                    __int128 v = (__int128)A[(size_t)g * 2 + 1] * ((__int128)1 << lb) + (__int128)A[(size_t)g * 2];
                     unsigned __int128 m = v < 0 ? (unsigned __int128)(-v) : (unsigned __int128)v;
                     int bl = 0;
                     while (m) { bl++; m >>= 1; }
@@ -482,14 +483,16 @@ extern "C" int ctk_result_info(const ctk_result *r, int64_t *n_labels, int64_t *
 
 // ---------------------------------------------------------------------------------------------
 // Row weights -> exact integers.  Every finite float32 w[y] is m * 2^e with a 24-bit integer m; with
-// S = -min e all weights become integers W[y] = w[y] * 2^S, split into two signed limbs of 31 bits
-// (W = lo + hi * 2^31, both limbs carry the sign).  Sums  sum_y n(y) * W[y]  of up to 2^32 pixels then
-// fit int64 per limb and are exact.  The float32 values are the ones the host computed as
-// contrack.py:703-704 does (including the slightly negative pole rows).
+// S = -min e all weights become integers W[y] = w[y] * 2^S, split into two signed limbs
+// (W = lo + hi * 2^L, both limbs carry the sign).  L = 31 whenever the weights span at most 62 bits: sums
+// sum_y n(y) * W[y]  of up to 2^31 pixels then fit int64 per limb and are exact.  Latitudes held in float64 with exact
+// poles give pole-row weights of ~1e-13 next to ~1e4 (cos(pi/2) = 6e-17 in float64): ~78 bits.  Then L = ceil(span / 2),
+// which is possible because no area sum ever covers more than npix = ny * nx pixels: L + ceil(log2 npix) <= 62.
+// The float32 values are the ones the host computed as contrack.py:703-704 does (including slightly negative pole rows).
 // ---------------------------------------------------------------------------------------------
-extern "C" int ctk_weights_to_limbs(const float *wrow, int ny, int32_t *wlo, int32_t *whi, int32_t *wshift)
+extern "C" int ctk_weights_to_limbs(const float *wrow, int ny, int64_t npix, int64_t *wlo, int64_t *whi, int32_t *wshift, int32_t *limb_bits)
 {
-    if (!wrow || !wlo || !whi || !wshift || ny < 1) return ctk_set_error(CTK_E_INVALID, "ctk_weights_to_limbs: bad arguments");
+    if (!wrow || !wlo || !whi || !wshift || !limb_bits || ny < 1 || npix < 1) return ctk_set_error(CTK_E_INVALID, "ctk_weights_to_limbs: bad arguments");
     std::vector<uint32_t> mant((size_t)ny);
     std::vector<int> ex((size_t)ny);
     int emin = INT32_MAX;
@@ -508,18 +511,30 @@ extern "C" int ctk_weights_to_limbs(const float *wrow, int ny, int32_t *wlo, int
         emin = std::min(emin, e);
     }
     if (emin == INT32_MAX) emin = 0;                     // all weights zero
+    int span = 0, span_row = 0;
+    for (int y = 0; y < ny; y++) {
+        if (mant[(size_t)y] == 0) continue;
+        const int bitlen = 32 - __builtin_clz(mant[(size_t)y]) + (ex[(size_t)y] - emin);
+        if (bitlen > span) { span = bitlen; span_row = y; }
+    }
+    int lb = CTK_LIMB_BITS_MIN;
+    if (span > 2 * CTK_LIMB_BITS_MIN) {
+        int lg = 0;
+        while (((int64_t)1 << lg) < npix) lg++;
+        lb = (span + 1) / 2;
+        if (lb > CTK_LIMB_BITS_MAX || lb + lg > 62)
+            return ctk_set_error(CTK_E_RANGE, "row weights span %d bits (row %d): two %d-bit limbs cannot sum %lld pixels exactly in int64",
+                                 span, span_row, lb, (long long)npix);
+    }
     for (int y = 0; y < ny; y++) {
         if (mant[(size_t)y] == 0) { wlo[y] = 0; whi[y] = 0; continue; }
-        int sh = ex[(size_t)y] - emin;
-        int bitlen = 32 - __builtin_clz(mant[(size_t)y]) + sh;
-        if (bitlen > 2 * CTK_LIMB_BITS)
-            return ctk_set_error(CTK_E_RANGE, "row weights span %d bits (row %d); the exact-area limbs carry %d", bitlen, y, 2 * CTK_LIMB_BITS);
-        uint64_t W = (uint64_t)mant[(size_t)y] << sh;
-        int32_t lo = (int32_t)(W & ((1ull << CTK_LIMB_BITS) - 1)), hi = (int32_t)(W >> CTK_LIMB_BITS);
-        bool neg = std::signbit(wrow[y]);
+        const unsigned __int128 W = (unsigned __int128)mant[(size_t)y] << (ex[(size_t)y] - emin);
+        const int64_t lo = (int64_t)(uint64_t)(W & ((((unsigned __int128)1) << lb) - 1)), hi = (int64_t)(uint64_t)(W >> lb);
+        const bool neg = std::signbit(wrow[y]);
         wlo[y] = neg ? -lo : lo;
         whi[y] = neg ? -hi : hi;
     }
     *wshift = -emin;
+    *limb_bits = lb;
     return CTK_OK;
 }

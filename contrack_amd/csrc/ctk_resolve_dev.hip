@@ -26,7 +26,7 @@ struct ResolveDev {
     const uint32_t *counters;             // pairs count at CTK_CNT_PAIRS
     uint32_t pair_cap;
     int64_t T;
-    int32_t wshift;
+    int32_t wshift, limb_bits;
     double overlap;
     int twosided;
     // work
@@ -50,6 +50,10 @@ struct ResolveDev {
     uint32_t *ambig;                      // set when a decision with a rounded sum lies within rounding distance of the threshold
     int minlsb;                           // lowest set bit over the integer row weights (numpy can round inside its reduction when a sum
                                           // spans more than 53 bits above it, even if the total is representable)
+    const int32_t *next_tiny;             // [ny+1] first row >= y whose weight has bits so low that a float64 partial sum of it with other
+                                          // rows can be inexact (pole rows); ny if none.  Components that touch no such row sum exactly in
+                                          // ANY order: only the others are subject to the minlsb rule.
+    uint32_t *touch;                      // [NC] at representatives: some member's box holds such a row
 };
 
 #define CTK_CHG_SLOTS 64            // 'changed' words per filter pass (= wave width: one ballot reads them)
@@ -87,9 +91,9 @@ __device__ __forceinline__ const CtkPair &pair_at(const ResolveDev &r, uint32_t 
 __device__ __forceinline__ uint32_t dev_ncomps(const ResolveDev &r) { return r.cprefix[r.T]; }
 
 // exact limb sums -> float64, rounded once to nearest-even (identical to limbs_to_double in ctk_resolve.cpp)
-__device__ inline double dev_limbs_to_double(int64_t lo, int64_t hi, int wshift, bool *inexact = nullptr)
+__device__ inline double dev_limbs_to_double(int64_t lo, int64_t hi, int wshift, int lb, bool *inexact = nullptr)
 {
-    __int128 v = (__int128)hi * ((__int128)1 << CTK_LIMB_BITS) + (__int128)lo;
+    __int128 v = (__int128)hi * ((__int128)1 << lb) + (__int128)lo;
     if (v == 0) return 0.0;
     const bool neg = v < 0;
     unsigned __int128 a = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
@@ -118,6 +122,7 @@ __global__ void k_rs_init(ResolveDev r)
         r.F[2 * (int64_t)g] = 0; r.F[2 * (int64_t)g + 1] = 0;
         r.B[2 * (int64_t)g] = 0; r.B[2 * (int64_t)g + 1] = 0;
         r.keep0[g] = 1; r.keep1[g] = 1;
+        r.touch[g] = 0;
         r.parent[g] = g;                                   // (k_rs_parent_init, for the first round)
     }
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < (CTK_MAX_JACOBI + 1) * CTK_CHG_SLOTS; i += blockDim.x) r.changed[i] = 0;
@@ -143,6 +148,15 @@ __global__ void k_rs_pairs(ResolveDev r)
         atomicAdd((unsigned long long *)&r.F[2 * (int64_t)rd], (unsigned long long)p.lo);
         atomicAdd((unsigned long long *)&r.F[2 * (int64_t)rd + 1], (unsigned long long)p.hi);
     }
+    // seam-merged components that hold a row with very low weight bits (see ResolveDev::next_tiny)
+    const uint32_t nc = dev_tables_bad(r) ? 0u : dev_ncomps(r);
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
+        const uint16_t *q = r.box + 4 * (int64_t)g;
+        if (r.next_tiny[q[0]] <= (int32_t)q[1]) {
+            const uint32_t rep = r.cprefix[r.comp_t[g]] + r.mrep[g];
+            if (r.touch[rep] == 0u) atomicOr(&r.touch[rep], 1u);
+        }
+    }
 }
 
 // 1/areacon and the forward fraction do not change between passes
@@ -151,10 +165,10 @@ __global__ void k_rs_prep(ResolveDev r)
     const uint32_t nc = dev_ncomps(r);
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
         bool inexact = false;
-        const double areacon = dev_limbs_to_double(r.A[2 * (int64_t)g], r.A[2 * (int64_t)g + 1], r.wshift, &inexact);
-        const double fwd = dev_limbs_to_double(r.F[2 * (int64_t)g], r.F[2 * (int64_t)g + 1], r.wshift, &inexact);
-        {
-            const __int128 v = (__int128)r.A[2 * (int64_t)g + 1] * ((__int128)1 << CTK_LIMB_BITS) + (__int128)r.A[2 * (int64_t)g];
+        const double areacon = dev_limbs_to_double(r.A[2 * (int64_t)g], r.A[2 * (int64_t)g + 1], r.wshift, r.limb_bits, &inexact);
+        const double fwd = dev_limbs_to_double(r.F[2 * (int64_t)g], r.F[2 * (int64_t)g + 1], r.wshift, r.limb_bits, &inexact);
+        if (r.touch[g]) {
+            const __int128 v = (__int128)r.A[2 * (int64_t)g + 1] * ((__int128)1 << r.limb_bits) + (__int128)r.A[2 * (int64_t)g];
             const unsigned __int128 m = v < 0 ? (unsigned __int128)(-v) : (unsigned __int128)v;
             const uint64_t top = (uint64_t)(m >> 64), bot = (uint64_t)m;
             const int bl = top ? 128 - __builtin_clzll(top) : (bot ? 64 - __builtin_clzll(bot) : 0);
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint
         }
         if ((first ? mrep0 : r.mrep[g]) != c) continue;         // representatives only
         bool inexact = r.inex[g] != 0;
-        const double bwd = dev_limbs_to_double(blo, bhi, r.wshift, &inexact);
+        const double bwd = dev_limbs_to_double(blo, bhi, r.wshift, r.limb_bits, &inexact);
         const double fb = (first ? inv0 : r.inv[g]) * bwd, ff = first ? ff0 : r.ff[g];
         if (inexact) {
             // numpy sums these float64 values pairwise; a rounded sum can differ from this exact-then-rounded one by a few

@@ -5,12 +5,14 @@
 #include <stddef.h>
 
 #define CTK_BLOB_MAGIC 0x314b544e4f43ull /* "CONTK1" */
-#define CTK_LIMB_BITS 31
+#define CTK_LIMB_BITS_MIN 31     /* limb width when the row weights span <= 62 bits (every float32-latitude grid) */
+#define CTK_LIMB_BITS_MAX 46     /* widest limb: n * limb with n <= 65535 pixels of a run must stay below 2^62 */
 #define CTK_AMBIG_ULPS 64       /* a rounded area sum whose fraction lies this close to `overlap` is re-evaluated in numpy's order */
 
 // One record per (component at t, component at t-1) co-occurrence; duplicates of the same (t,c,d) may
 // occur (partial sums) and are additive.  lo/hi are the two limb sums of  sum_y n(y) * W[y]  with
-// W[y] = wlo[y] + (whi[y] << 31) the row weight scaled to an integer (see weights_to_limbs).
+// W[y] = wlo[y] + (whi[y] << limb_bits) the row weight scaled to an integer (see ctk_weights_to_limbs: limb_bits is 31
+// unless the weights span more than 62 bits -- float64 latitudes with exact poles -- and is then chosen per grid).
 struct CtkPair {
     uint32_t t;      // timestep of c (shard-local in blobs, global inside the resolver)
     uint32_t c;      // no-wrap 2-D component id at t   (0-based, raster order within the timestep)
@@ -38,6 +40,8 @@ struct CtkBlobHeader {
     int32_t ny, nx;
     int32_t wshift;
     int32_t has_prev;
+    int32_t limb_bits;         // width of the low limb of every area sum in this blob
+    int32_t pad0;
     int64_t ncomps, npairs, nseams;
     int64_t npairs_grouped;   // the first npairs_grouped pair records are grouped per timestep (pair_base / pair_cnt)
     // followed (each section 8-byte aligned) by

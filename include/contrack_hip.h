@@ -117,8 +117,11 @@ int  ctk_result_info(const ctk_result *r, int64_t *n_labels, int64_t *n_ops, int
 int  ctk_result_arrays(const ctk_result *r, const int32_t **comp_label, int64_t *ncomps, const void **ops,
                        int64_t *nops, const int64_t **shard_comp_off, const int64_t **shard_t_off);
 int  ctk_result_nshards(const ctk_result *r);          /* length-1 of the two offset arrays above */
-/* exact integer limbs of the float32 row weights: w[y] = (wlo[y] + whi[y] * 2^31) * 2^-wshift */
-int  ctk_weights_to_limbs(const float *wrow, int ny, int32_t *wlo, int32_t *whi, int32_t *wshift);
+/* exact integer limbs of the float32 row weights: w[y] = (wlo[y] + whi[y] * 2^limb_bits) * 2^-wshift.  limb_bits is 31
+ * unless the weights span more than 62 bits (float64 latitudes with exact poles: cos(pi/2) = 6e-17 next to 1); then it
+ * is ceil(span / 2), which needs limb_bits + ceil(log2 npix) <= 62 with npix = ny * nx, the most pixels any area sum
+ * covers (CTK_E_RANGE otherwise). */
+int  ctk_weights_to_limbs(const float *wrow, int ny, int64_t npix, int64_t *wlo, int64_t *whi, int32_t *wshift, int32_t *limb_bits);
 
 /* stage 3: apply the result to this shard (index `shard` of the blobs given to ctk_resolve):
  *          per-label time extents (persistence, contrack.py:765-772), then the relabel pass that

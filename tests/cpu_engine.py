@@ -14,7 +14,7 @@ class CpuShardEngine:
         self.anom, self.thr, self.gorl, self.wrow = anom, thr, gorl, wrow
         self.T, self.ny, self.nx = anom.shape
         self.prev_lab = None
-        self.wlo, self.whi, self.wshift = _native.weights_to_limbs(wrow)
+        self.wlo, self.whi, self.wshift, self.limb_bits = _native.weights_to_limbs(wrow, npix=self.ny * self.nx, with_bits=True)
 
     def label2d(self, has_prev):
         self.has_prev = has_prev
@@ -40,7 +40,7 @@ class CpuShardEngine:
         self.tb = cpu_tables.build_tables(self.mask, self.wlo, self.whi, prev_lab=self.prev_lab if self.has_prev else None)
 
     def tables(self):
-        return cpu_tables.pack_blob(self.tb, self.wshift, self.has_prev and self.prev_lab is not None)
+        return cpu_tables.pack_blob(self.tb, self.wshift, self.has_prev and self.prev_lab is not None, limb_bits=self.limb_bits)
 
     def extents(self, result, shard, t_begin):
         comp_label, ops = result.arrays()

@@ -10,7 +10,7 @@ from scipy import ndimage
 
 MAGIC = 0x314b544e4f43
 S8 = np.ones((3, 3), dtype=np.int32)
-HDR_FMT = "<Qqiiiiqqqq"         # CtkBlobHeader: magic, T, ny, nx, wshift, has_prev, ncomps, npairs, nseams, npairs_grouped
+HDR_FMT = "<Qqiiiiiiqqqq"       # CtkBlobHeader: magic, T, ny, nx, wshift, has_prev, limb_bits, pad, ncomps, npairs, nseams, npairs_grouped
 
 
 def _align8(n):
@@ -77,10 +77,10 @@ def build_tables(mask, wlo, whi, prev_lab=None):
     return dict(T=T, ny=ny, nx=nx, ncomp=ncomp, mrep=mrep, box=box, area=area, pairs=pairs, seams=seams, labs=labs)
 
 
-def pack_blob(tb, wshift, has_prev):
+def pack_blob(tb, wshift, has_prev, limb_bits=31):
     T, nc, npairs, ns = tb["T"], len(tb["mrep"]), len(tb["pairs"]), len(tb["seams"])
     out = bytearray()
-    out += struct.pack(HDR_FMT, MAGIC, T, tb["ny"], tb["nx"], wshift, int(bool(has_prev)), nc, npairs, ns, 0)
+    out += struct.pack(HDR_FMT, MAGIC, T, tb["ny"], tb["nx"], wshift, int(bool(has_prev)), limb_bits, 0, nc, npairs, ns, 0)
     a = np.asarray(tb["ncomp"], dtype=np.uint32).tobytes()
     out += a + b"\0" * (_align8(len(a)) - len(a))
     a = np.asarray(tb["mrep"], dtype=np.uint32).tobytes()
@@ -99,7 +99,7 @@ def pack_blob(tb, wshift, has_prev):
 def parse_blob(blob):
     """Canonical (order-independent, duplicate-merged) view of a blob, for equality checks."""
     hdr = struct.unpack_from(HDR_FMT, blob, 0)
-    magic, T, ny, nx, wshift, has_prev, nc, npairs, ns, _ngrouped = hdr
+    magic, T, ny, nx, wshift, has_prev, _limb_bits, _pad, nc, npairs, ns, _ngrouped = hdr
     assert magic == MAGIC
     off = struct.calcsize(HDR_FMT)
     ncomp = np.frombuffer(blob, dtype=np.uint32, count=T, offset=off); off += _align8(T * 4)

@@ -5,7 +5,7 @@ installable here) on seeded inputs.  Build container only; the fixtures it write
 (inputs + the reference's outputs), committed so that the GPU box -- which has no /root/reference
 -- can check both the CPU oracle and the HIP path against the reference's own results.
 
-    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py [case ...] # rewrites tests/golden/*.npz (or only the named cases)
 
 Each .npz holds: anom (float32, or anom_q int16 + q_scale), lat, lon, dlat, dlon, wrow (float32 row
 weights, contrack.py:703-704), thr (float64 per step, already rounded the way the reference's
@@ -123,6 +123,14 @@ case("chain_c", src="syn", T=120, ny=21, nx=40, seed=1308, threshold=120.0, gorl
 # irregular (CESM-like) latitudes: the reference needs set_up(force=True); dlat = round(mean, 2)
 case("cesm_like", src="syn", T=40, ny=48, nx=72, seed=90, threshold=150, gorl=">=", overlap=0.5, persistence=3,
      twosided=True, grid="cesm", sigma_deg=10.0)
+# float64 latitudes holding the poles exactly (CESM, MERRA2, new-CDS ERA5, any np.linspace grid): cos(pi/2) = 6e-17 in
+# float64, so the pole rows weigh ~1e-13 next to ~1e4 -- row weights spanning ~78 bits, area sums numpy cannot hold exactly
+case("f64pole_syn", src="syn", T=40, ny=91, nx=180, seed=95, threshold=120, gorl=">=", overlap=0.5, persistence=3,
+     twosided=True, grid="f64", sigma_deg=14.0)
+case("f64pole_blocky", src="blocky", T=24, ny=37, nx=72, seed=96, threshold=0.3, gorl=">=", overlap=1.0, persistence=2,
+     twosided=True, grid="f64")
+case("f64pole_blocky5", src="blocky", T=24, ny=46, nx=96, seed=97, threshold=0.5, gorl=">", overlap=0.5, persistence=1,
+     twosided=False, grid="f64")
 
 
 def levels_for(thr64, gorl):
@@ -171,6 +179,8 @@ def build_input(kw):
     if kw.get("grid") == "cesm":
         lat, lon = cesm_grid(ny, nx)
         force = True
+    elif kw.get("grid") == "f64":
+        lat, lon, force = np.linspace(90.0, -90.0, ny), np.arange(nx) * (360.0 / nx), False
     else:
         lat, lon = synth.grid(ny, nx)
         if "dlon" in kw:
@@ -178,6 +188,11 @@ def build_input(kw):
         force = False
     if src == "noise":
         a = np.random.default_rng(kw["seed"]).standard_normal((T, ny, nx)).astype(np.float32)
+        return dict(anom=quantise(a, 64.0)), lat, lon, force
+    if src == "blocky":
+        # coarse random field repeated over 3x3 pixels and two steps: plateaus that reach the pole rows, exact overlap ties
+        c = np.random.default_rng(kw["seed"]).standard_normal(((T + 1) // 2, (ny + 2) // 3, (nx + 2) // 3)).astype(np.float32)
+        a = np.repeat(np.repeat(np.repeat(c, 2, axis=0), 3, axis=1), 3, axis=2)[:T, :ny, :nx].copy()
         return dict(anom=quantise(a, 64.0)), lat, lon, force
     a = synth.smooth_field(T, ny, nx, seed=kw["seed"], offset=kw.get("offset", 35.0),
                            sigma_t=kw.get("sigma_t", 2.0), sigma_deg=kw.get("sigma_deg", 6.0))
@@ -208,10 +223,14 @@ def vector_threshold(T):
 
 def main():
     total = 0
+    only = set(sys.argv[1:])                 # optional: names of the cases to (re)write
     raw, _, _ = ref_slab()
-    np.savez_compressed(os.path.join(HERE, "refslab_input.npz"), anom=raw)
+    if not only:
+        np.savez_compressed(os.path.join(HERE, "refslab_input.npz"), anom=raw)
     total += os.path.getsize(os.path.join(HERE, "refslab_input.npz"))
     for name, kw in CASES:
+        if only and name not in only:
+            continue
         coding, lat, lon, force = build_input(kw)
         a = decode_input(coding)
         T = a.shape[0]

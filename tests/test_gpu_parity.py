@@ -59,8 +59,8 @@ def test_staged_outputs_match_oracle(trk, oracle_lib, name):
     _, _, stage = oracle_lib.run_contrack(g["anom"], g["thr"], g["gorl"], g["wrow"], g["overlap"], g["persistence"], g["twosided"],
                                           return_stage=True)
     assert np.array_equal(lab_m, stage)
-    wlo, whi, wshift = _native.weights_to_limbs(g["wrow"])
-    ref = cpu_tables.parse_blob(cpu_tables.pack_blob(cpu_tables.build_tables(omask.astype(bool), wlo, whi), wshift, False))
+    wlo, whi, wshift, lb = _native.weights_to_limbs(g["wrow"], npix=omask.shape[1] * omask.shape[2], with_bits=True)
+    ref = cpu_tables.parse_blob(cpu_tables.pack_blob(cpu_tables.build_tables(omask.astype(bool), wlo, whi), wshift, False, limb_bits=lb))
     got = cpu_tables.parse_blob(blob)
     assert got["T"] == ref["T"] and got["wshift"] == ref["wshift"]
     assert np.array_equal(got["ncomp"], ref["ncomp"])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/summarize_profile.py <gpurun_out/TAG> <profiles/PREFIX>
+"""tools/summarize_profile.py <gpurun_out/TAG> <profiles/PREFIX> [workload name]
 Condenses a tools/profile.sh capture into committed files: PREFIX_kernel_stats.csv (rocprofv3 --stats),
 PREFIX_pmc.json / .md (FETCH_SIZE / WRITE_SIZE per kernel, per launch, with the gfx950 correction of
 /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE counts wide coalesced reads at half their bytes)."""
@@ -10,6 +10,7 @@ import shutil
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else "era5_1deg_djf30 2707x181x360"
 shutil.copy(src + "/trace/r_kernel_stats.csv", dst + "_kernel_stats.csv")
 
 
@@ -31,7 +32,7 @@ for k in set(f) | set(w):
                   fetch_bytes_corrected=2.0 * 1024 * sum(fs) / len(fs), write_bytes=1024.0 * sum(ws) / max(1, len(ws)),
                   avg_ns=float(stats[k]["AverageNs"]) if k in stats else None)
 json.dump(dict(note="per launch; fetch_bytes_corrected = FETCH_SIZE*1024*2 (gfx950 counts wide coalesced reads at half), "
-                    "write_bytes = WRITE_SIZE*1024 (uncalibrated); workload era5_1deg_djf30 2707x181x360",
+                    "write_bytes = WRITE_SIZE*1024 (uncalibrated); workload " + workload,
                kernels=out), open(dst + "_pmc.json", "w"), indent=1, sort_keys=True)
 with open(dst + "_pmc.md", "w") as fh:
     fh.write("| kernel | launches | avg us | FETCH_SIZE KB | x2 corrected MB | WRITE_SIZE KB | MB |\n|---|---|---|---|---|---|---|\n")
