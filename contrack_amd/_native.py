@@ -26,6 +26,9 @@ EXPORTS = [
     "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_np_sum", "ctk_set_timing", "ctk_get_timings", "ctk_set_device_resolve", "ctk_set_filter_round", "ctk_get_stats",
     "ctk_dev_malloc", "ctk_dev_free", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
     "ctk_synth_fill",
+    "ctk_comm_unique_id", "ctk_comm_init_rccl", "ctk_comm_group_create", "ctk_comm_group_destroy", "ctk_comm_init_local", "ctk_comm_init_shm",
+    "ctk_comm_destroy", "ctk_comm_rank", "ctk_comm_world", "ctk_comm_barrier", "ctk_comm_allgather_host", "ctk_comm_ops",
+    "ctk_track_sharded_f32_dev", "ctk_track_sharded_f64_dev",
     "ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev", "ctk_lifecycle_rows",
 ]
 
@@ -99,6 +102,23 @@ def lib():
     for name in ("ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev"):
         getattr(L, name).argtypes = [p, p, p, i64, i32, i32, p, C.POINTER(i64)]
     L.ctk_lifecycle_rows.argtypes = [p, p, i64]
+    L.ctk_comm_unique_id.argtypes = [p]
+    L.ctk_comm_init_rccl.argtypes = [p, p, i32, i32, pp]
+    L.ctk_comm_group_create.argtypes = [i32, pp]
+    L.ctk_comm_group_destroy.argtypes = [p]
+    L.ctk_comm_group_destroy.restype = None
+    L.ctk_comm_init_local.argtypes = [p, p, i32, pp]
+    L.ctk_comm_init_shm.argtypes = [p, C.c_char_p, i32, i32, pp]
+    L.ctk_comm_destroy.argtypes = [p]
+    L.ctk_comm_destroy.restype = None
+    L.ctk_comm_rank.argtypes = [p]
+    L.ctk_comm_world.argtypes = [p]
+    L.ctk_comm_barrier.argtypes = [p]
+    L.ctk_comm_allgather_host.argtypes = [p, p, p, sz]
+    L.ctk_comm_ops.argtypes = [p, C.POINTER(i64), C.POINTER(i64)]
+    sharded_args = [p, p, p, i64, i64, i64, i32, i32, p, i32, p, dbl, i32, i32, p, C.POINTER(i64)]
+    L.ctk_track_sharded_f32_dev.argtypes = sharded_args
+    L.ctk_track_sharded_f64_dev.argtypes = sharded_args
     _lib = L
     return L
 
@@ -191,6 +211,93 @@ def resolve(blobs, overlap, twosided):
     return Result(out)
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 opaque bytes (ncclGetUniqueId) made on rank 0; every rank passes them to Comm.rccl"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    check(lib().ctk_comm_unique_id(buf))
+    return buf.raw
+
+
+class CommGroup:
+    """Several ranks inside one process (one host thread per rank): ctk_comm_group"""
+
+    def __init__(self, world):
+        self._g = C.c_void_p()
+        self.world = int(world)
+        check(lib().ctk_comm_group_create(self.world, C.byref(self._g)))
+
+    def close(self):
+        if getattr(self, "_g", None):
+            lib().ctk_comm_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        self.close()
+
+
+class Comm:
+    """The communicator of the time-sharded path (ctk_comm), bound to one Tracker."""
+
+    def __init__(self, ptr, keep=None):
+        self._c, self._keep = ptr, keep
+
+    @classmethod
+    def rccl(cls, tracker, unique_id, rank, world):
+        c = C.c_void_p()
+        check(lib().ctk_comm_init_rccl(tracker.handle, unique_id, int(rank), int(world), C.byref(c)))
+        return cls(c)
+
+    @classmethod
+    def local(cls, tracker, group, rank):
+        c = C.c_void_p()
+        check(lib().ctk_comm_init_local(tracker.handle, group._g, int(rank), C.byref(c)))
+        return cls(c, keep=group)
+
+    @classmethod
+    def shm(cls, tracker, name, rank, world):
+        c = C.c_void_p()
+        check(lib().ctk_comm_init_shm(tracker.handle, name.encode(), int(rank), int(world), C.byref(c)))
+        return cls(c)
+
+    @property
+    def ptr(self):
+        return self._c
+
+    @property
+    def rank(self):
+        return int(lib().ctk_comm_rank(self._c))
+
+    @property
+    def world(self):
+        return int(lib().ctk_comm_world(self._c))
+
+    def barrier(self):
+        check(lib().ctk_comm_barrier(self._c))
+
+    def allgather(self, arr):
+        """small host array (<= 4096 bytes) from every rank -> array (world, ...)"""
+        arr = np.ascontiguousarray(arr)
+        out = np.empty((self.world,) + arr.shape, dtype=arr.dtype)
+        check(lib().ctk_comm_allgather_host(self._c, arr.ctypes.data, out.ctypes.data, arr.nbytes))
+        return out
+
+    def ops(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(lib().ctk_comm_ops(self._c, C.byref(a), C.byref(b)))
+        return dict(neighbour_exchanges=int(a.value), allgathers=int(b.value))
+
+    def close(self):
+        if getattr(self, "_c", None):
+            lib().ctk_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        self.close()
+
+
 class Tracker:
     """One GPU + stream + reusable device workspace (ctk_handle)."""
 
@@ -262,6 +369,19 @@ class Tracker:
                                       float(overlap), int(persistence), int(bool(twosided)), flag_dev, C.byref(n)))
         return int(n.value)
 
+    def track_sharded_dev(self, comm, anom_dev, T_local, t_begin, T_total, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev,
+                          f64=False):
+        """the whole path on the time shard [t_begin, t_begin + T_local) of T_total steps; every rank of `comm` must call"""
+        thr = np.ascontiguousarray(thr, dtype=np.float64)
+        wrow = np.ascontiguousarray(wrow, dtype=np.float32)
+        if thr.shape != (T_local,):
+            raise ValueError("thr must hold one value per local timestep")
+        n = C.c_int64(0)
+        fn = lib().ctk_track_sharded_f64_dev if f64 else lib().ctk_track_sharded_f32_dev
+        check(fn(self._h, comm.ptr, anom_dev, int(T_local), int(t_begin), int(T_total), ny, nx, thr.ctypes.data, int(cmp_op), wrow.ctypes.data,
+                 float(overlap), int(persistence), int(bool(twosided)), flag_dev, C.byref(n)))
+        return int(n.value)
+
     # ---- run_lifecycle reductions ------------------------------------------------------------------------
     def _life_rows(self, n):
         rows = np.empty(n, dtype=LIFE_ROW)
@@ -300,7 +420,7 @@ class Tracker:
         check(lib().ctk_get_stats(self._h, v.ctypes.data))
         names = ["runs", "max_runs_per_step", "components", "pairs", "seam_rows_to_driver", "labels_3d", "seam_ops",
                  "filter_passes", "host_path", "seam_loop_ns", "seam_folds", "seam_copy_ns", "ungrouped_pairs", "pair_table_regrows", "filter_rounds",
-                 "ambiguous_decisions", "exact_fixups"]
+                 "ambiguous_decisions", "exact_fixups", "shared_seam_rows"]
         return dict(zip(names, v.tolist()))
 
     def debug_set_pair_capacity(self, records):

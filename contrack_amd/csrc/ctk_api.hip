@@ -4,6 +4,7 @@
 #include "ctk_kernels.hip"
 #include "ctk_resolve_dev.hip"
 #include "ctk_lifecycle.hip"
+#include "ctk_seam.h"
 #include "../../include/contrack_hip.h"
 
 #include <chrono>
@@ -40,6 +41,9 @@ static int g_ht = -1; static double g_ht0 = 0;
 static double now_ms_fwd() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define HT(name) do { if (g_ht < 0) g_ht = getenv("CTK_HOSTTRACE") ? 1 : 0; if (g_ht) { double t_ = now_ms_fwd(); fprintf(stderr, "HT %-28s %9.1f us\n", name, (t_ - g_ht0) * 1e3); } } while (0)
 #define HT0() do { if (g_ht < 0) g_ht = getenv("CTK_HOSTTRACE") ? 1 : 0; if (g_ht) g_ht0 = now_ms_fwd(); } while (0)
+
+struct ShardScratch;
+static void shard_scratch_free(ShardScratch *s);            // ctk_sharded.hip
 
 namespace {
 
@@ -114,6 +118,15 @@ struct ctk_handle {
     // run_lifecycle reductions
     DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w;
     DevBuf io_in, io_out;                          // device copies of host-array calls (ctk_track_f32 / _f64)
+    // time-sharded path (ctk_sharded.hip)
+    DevBuf sh_mask_next, sh_send, sh_recv, sh_prev, sh_elist, sh_ovr_slot, sh_ovr_val, sh_amb_list, sh_counts;
+    struct ShardScratch *shard = nullptr;
+    uint32_t *h_mail2 = nullptr;                   // pinned, device-written scalars
+    void *h_shard = nullptr, *h_lab = nullptr, *h_seam = nullptr;        // pinned: gathered boundary records / label tables / shared seam groups
+    size_t h_shard_cap = 0, h_lab_cap = 0, h_seam_cap = 0;
+    uint32_t sh_capB = 0, sh_capC = 0, sh_capD = 0;     // agreed capacities of the exchanged records (grow-only)
+    std::vector<std::pair<int32_t, int32_t>> sh_pairs;
+    bool halo_valid = false, halo_v2 = false;
     BouncePool *bounce = nullptr;                  // created on first use
     std::vector<ctk_life_row> lc_host, lc_tmp;
     std::vector<std::pair<uint64_t, uint32_t>> lc_keys;
@@ -144,7 +157,8 @@ struct ctk_handle {
     uint32_t debug_pair_cap = 0;                  // test hook: pretend the pair table holds only this many records
     uint32_t debug_mail_c = 0, debug_mail_d = 0;  // test hook: pretend the resolver mailbox holds only this many records / labels
     // host scratch of the seam driver, kept between calls (fresh 100+ KB vectors would page-fault every call)
-    std::vector<int32_t> sd_first, sd_last, sd_inflow, sd_next, sd_lo;
+    SeamDriver sd, sd_glob;                       // sd_glob: candidate groups shared between time shards (ctk_sharded.hip)
+    std::vector<int32_t> sd_last;
     std::vector<CtkOp> sd_ops;
     std::vector<unsigned char> sd_cand;
     int64_t stats[CTK_NSTATS] = {0};
@@ -201,6 +215,9 @@ int ensure_host(void **p, size_t *cap, size_t need, bool non_coherent = false)
 
 template <typename T>
 T *P(const DevBuf &b) { return (T *)b.p; }
+// component prefix of the shard's timesteps; CPX(h)[-1] = 0 is where the components of the previous shard's last timestep
+// (the halo of the time-sharded path) start, CPX(h)[0] their number
+inline uint32_t *CPX(const ctk_handle *h) { return (uint32_t *)h->cprefix.p + 1; }
 
 struct Timer {
     ctk_handle *h;
@@ -299,7 +316,9 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->g_label, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
                       &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
-                      &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out};
+                      &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
+                      &h->sh_mask_next, &h->sh_send, &h->sh_recv, &h->sh_prev, &h->sh_elist, &h->sh_ovr_slot, &h->sh_ovr_val,
+                      &h->sh_amb_list, &h->sh_counts};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -309,6 +328,11 @@ extern "C" void ctk_destroy(ctk_handle *h)
     if (h->bounce) { h->bounce->destroy(); delete h->bounce; }
     if (h->h_mail1) (void)hipHostFree(h->h_mail1);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h_mail2) (void)hipHostFree(h->h_mail2);
+    if (h->h_shard) (void)hipHostFree(h->h_shard);
+    if (h->h_lab) (void)hipHostFree(h->h_lab);
+    if (h->h_seam) (void)hipHostFree(h->h_seam);
+    shard_scratch_free(h->shard);
     if (h->ev_ready) for (int k = 0; k <= CTK_KI_ROWCOUNT; k++) { (void)hipEventDestroy(h->ev[k][0]); (void)hipEventDestroy(h->ev[k][1]); }
     for (int k = 0; k < 2; k++) { if (h->side[k]) (void)hipStreamDestroy(h->side[k]); if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -401,8 +425,10 @@ static int threshold_rows(int ny, int nx, int64_t T)
     return std::min(ny, 16);
 }
 
+// defer_compact (time-sharded path): the dense component tables are built after the halo has arrived, because the halo's
+// components come first in them
 static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t T, int ny, int nx, const double *thr,
-                              int cmp_op, const float *wrow, int has_prev)
+                              int cmp_op, const float *wrow, int has_prev, bool defer_compact = false)
 {
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
     if (T < 0 || ny < 1 || nx < 1 || (T > 0 && (!anom_dev || !thr)) || !wrow)
@@ -414,6 +440,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     HIPCHK(hipSetDevice(h->device));
     memset(h->ms, 0, sizeof(h->ms));
     h->state = ST_IDLE;
+    h->halo_valid = false; h->halo_v2 = defer_compact;
     h->T = T; h->ny = ny; h->nx = nx; h->W = (nx + 63) / 64; h->has_prev = has_prev ? 1 : 0; h->cmp_op = cmp_op;
     const int W = h->W;
     const int64_t nrows = T * ny;
@@ -476,7 +503,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     CTKCHK(ensure(h, h->tcount, (size_t)T * 4));
     CTKCHK(ensure(h, h->run_base, (size_t)(T + 1) * 4));
     CTKCHK(ensure(h, h->ncomp, (size_t)T * 4));
-    CTKCHK(ensure(h, h->cprefix, (size_t)(T + 1) * 4));
+    CTKCHK(ensure(h, h->cprefix, (size_t)(T + 2) * 4));                  // [-1] = 0: the halo components of a time shard come first
     CTKCHK(ensure(h, h->thr32, (size_t)T * 8));
     CTKCHK(ensure(h, h->wlo, w_bytes));                               // wlo[ny] whi[ny] next_tiny[ny+1] in one allocation
     CTKCHK(ensure(h, h->counters, CTK_CNT_N * 4));
@@ -598,6 +625,11 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         h->runs_cap = (uint32_t)std::min<size_t>(Rc, 0xffffffffu);
         launched = {false, false, false, false};                  // whatever ran speculatively ran on too small buffers
     }
+    if (defer_compact) {
+        // room for the halo's components in front of the shard's own (at most one per two pixels of a row)
+        const size_t Rd = (size_t)h->runs_cap + (size_t)ny * ((size_t)nx / 2 + 1);
+        CTKCHK(ensure(h, h->d_mrep, Rd * 4)); CTKCHK(ensure(h, h->d_box, Rd * 8)); CTKCHK(ensure(h, h->d_area, Rd * 16)); CTKCHK(ensure(h, h->d_comp_t, Rd * 4));
+    }
     if (h->need_glb) {
         const size_t Rc = h->runs_cap;
         CTKCHK(ensure(h, h->g_x0, Rc * 2)); CTKCHK(ensure(h, h->g_x1, Rc * 2)); CTKCHK(ensure(h, h->g_y, Rc * 2));
@@ -615,12 +647,12 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         h->spec_set.v1 = true; h->spec_set.v2 = need.v2; h->spec_set.v3 = need.v3; h->spec_set.glb = need.glb;
         h->spec_ny = ny; h->spec_nx = nx; h->spec_T = T;
     }
-    {
+    if (!defer_compact) {
         Timer tm(h, CTK_K_SCAN);
-        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->ncomp), T, P<uint32_t>(h->cprefix), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->ncomp), T, CPX(h), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
         HIPCHK(hipGetLastError());
         if (T > 0) {
-            k_compact_comps<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), P<uint32_t>(h->cprefix), P<uint32_t>(h->cs_mrep),
+            k_compact_comps<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep),
                                                    P<uint32_t>(h->cs_box), P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box),
                                                    P<int64_t>(h->d_area), P<uint32_t>(h->d_comp_t));
             HIPCHK(hipGetLastError());
@@ -692,6 +724,7 @@ extern "C" int ctk_shard_halo_import(ctk_handle *h, const void *blob_dev, size_t
     CTKCHK(ensure(h, h->halo_in, halo_max_bytes(h)));
     HIPCHK(hipMemcpyAsync(h->halo_in.p, blob_dev, nbytes, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->halo_valid = true;
     return CTK_OK;
 }
 
@@ -704,10 +737,11 @@ static int launch_overlap(ctk_handle *h)
     a.mask = P<uint64_t>(h->mask); a.wstart = P<uint16_t>(h->wstart); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
     a.run_comp = P<uint32_t>(h->run_comp);
     const char *hl = (const char *)h->halo_in.p;
-    a.halo_mask = (const uint64_t *)hl;
-    a.halo_wstart = hl ? (const uint16_t *)(hl + halo_off_wstart(h)) : nullptr;
-    a.halo_rowstart = hl ? (const uint32_t *)(hl + halo_off_rowstart(h)) : nullptr;
-    a.halo_run_comp = hl ? (const uint32_t *)(hl + halo_off_runcomp(h)) : nullptr;
+    const size_t o0 = h->halo_v2 ? 16 : 0;                               // (HaloHeader of ctk_sharded.hip)
+    a.halo_mask = (const uint64_t *)(hl ? hl + o0 : nullptr);
+    a.halo_wstart = hl ? (const uint16_t *)(hl + o0 + halo_off_wstart(h)) : nullptr;
+    a.halo_rowstart = hl ? (const uint32_t *)(hl + o0 + halo_off_rowstart(h)) : nullptr;
+    a.halo_run_comp = hl ? (const uint32_t *)(hl + o0 + halo_off_runcomp(h)) : nullptr;
     a.has_prev = (h->has_prev && hl) ? 1 : 0;
     a.pairs = P<CtkPair>(h->pairs); a.pair_cap = h->pair_cap; a.counters = P<uint32_t>(h->counters);
     a.pair_base = P<uint32_t>(h->pair_base); a.pair_cnt = P<uint32_t>(h->pair_cnt);
@@ -724,7 +758,8 @@ extern "C" int ctk_shard_overlap(ctk_handle *h)
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
     if (h->state != ST_LABELLED) return ctk_set_error(CTK_E_STATE, "ctk_shard_overlap needs ctk_shard_label2d first");
     HIPCHK(hipSetDevice(h->device));
-    if (h->has_prev && !h->halo_in.p) return ctk_set_error(CTK_E_STATE, "ctk_shard_overlap: has_prev set but no halo imported");
+    if (h->has_prev && (!h->halo_in.p || !h->halo_valid))
+        return ctk_set_error(CTK_E_STATE, "ctk_shard_overlap: has_prev set but no halo imported since ctk_shard_label2d");
     size_t want = (size_t)h->total_runs / 2 + (size_t)h->T * 8 + 4096;
     if (want > 0x7fffffffull) want = 0x7fffffffull;
     if (h->pair_cap < want || !h->pairs.p) {
@@ -756,7 +791,7 @@ static int build_tables_blob(ctk_handle *h, bool to_device, const void **blob, s
     HIPCHK(hipGetLastError());
     for (int attempt = 0;; attempt++) {
         HIPCHK(hipMemcpyAsync(hc, h->counters.p, CTK_CNT_N * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(hc + CTK_CNT_N, P<uint32_t>(h->cprefix) + h->T, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hc + CTK_CNT_N, CPX(h) + h->T, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(hc + CTK_CNT_N + 1, P<uint32_t>(h->seam_off) + h->T, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         memcpy(cnt, hc, sizeof(cnt));
@@ -886,9 +921,9 @@ static int upload_ops_dense(ctk_handle *h, const std::vector<CtkOp> &ops, const 
     int32_t nf = 0;
     if (nops) {
         memcpy(s_ops, ops.data(), (size_t)nops * sizeof(CtkOp));
-        memcpy(s_next, h->sd_next.data(), (size_t)nops * 4);
+        memcpy(s_next, h->sd.next.data(), (size_t)nops * 4);
         for (int64_t d = 0; d < nd; d++)
-            if (h->sd_first[(size_t)d] >= 0) { s_label[nf] = orig[d]; s_first[nf] = h->sd_first[(size_t)d]; nf++; }
+            if (h->sd.first[(size_t)d] >= 0) { s_label[nf] = orig[d]; s_first[nf] = h->sd.first[(size_t)d]; nf++; }
     }
     int32_t *d_next = (int32_t *)(P<CtkOp>(h->ops) + nops);
     h->d_op_next = d_next;
@@ -912,7 +947,7 @@ static int launch_extents(ctk_handle *h, bool ext_filled = false, bool with_fina
     if (h->T > 0) {
         ExtentArgs a;
         a.mask = P<uint64_t>(h->mask); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
-        a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp); a.cprefix = P<uint32_t>(h->cprefix);
+        a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp); a.cprefix = CPX(h);
         a.comp_label = P<int32_t>(h->comp_label); a.lab = with_final ? P<int32_t>(h->rv_lab) : nullptr; a.comp_label_w = P<int32_t>(h->comp_label);
         a.box = P<uint16_t>(h->d_box); a.ext = P<int32_t>(h->ext); a.n_labels = h->n_labels; a.t_begin = h->t_begin;
         a.fold = fold_args(h); a.ny = h->ny; a.nx = h->nx; a.W = h->W;
@@ -950,92 +985,6 @@ extern "C" int ctk_shard_extents(ctk_handle *h, const ctk_result *r, int shard, 
 // ------------------------------------------------------------------------------------------------
 // device resolver (single shard): R1..R5 of ctk_resolve_dev.hip + the host seam driver
 // ------------------------------------------------------------------------------------------------
-namespace {
-
-// contrack.py:753-763 on {t, y, label at x=0, label at x=nx-1} records in (t, y) order.  Labels are DENSE ids of the
-// labels that occur in the records (orig[id] = fresh label, box[id] = its box): every table of the driver has a few
-// thousand entries and stays in the CPU's L1/L2, whatever the number of fresh labels.  Flat arrays: per label the
-// chain of ops that have it as `hi`, in execution order.  `ops` receives the ops with the fresh labels.
-void seam_driver(ctk_handle *h, const CtkCand *cand, int64_t ncand, const int32_t *orig, const int32_t *box, int64_t nd, int nx,
-                 std::vector<CtkOp> &ops)
-{
-    std::vector<int32_t> &first = h->sd_first, &last = h->sd_last, &next = h->sd_next, &lo_d = h->sd_lo;
-    first.assign((size_t)nd + 1, -1);
-    last.assign((size_t)nd + 1, -1);
-    next.clear();
-    lo_d.clear();                                             // dense id of ops[i].lo
-    // fold of the ops over a seam pixel.  Consecutive seam rows of one blob ask the same question with y+1; the
-    // answer is reused while it provably cannot change: same label / timestep / side, no op recorded since, and
-    // y inside the interval over which every box test taken on the way gives the same outcome.
-    struct Memo { int32_t l = -1, t = -1, ylo = 0, yhi = -1, res = 0; size_t epoch = (size_t)-1; };
-    Memo memo[2];
-    auto fold = [&](int side, int32_t l0, int32_t t, int32_t y, int32_t x) {
-        Memo &m = memo[side];
-        if (m.l == l0 && m.t == t && m.epoch == ops.size() && y >= m.ylo && y <= m.yhi) return m.res;
-        int32_t l = l0, s = 0, ylo = INT32_MIN, yhi = INT32_MAX;
-        for (;;) {
-            bool moved = false;
-            for (int32_t idx = first[(size_t)l]; idx >= 0; idx = next[(size_t)idx]) {
-                if (idx < s) continue;
-                const CtkOp &o = ops[(size_t)idx];
-                const bool tx_in = t >= o.t0 && t <= o.t1 && x >= o.x0 && x <= o.x1;
-                if (!tx_in) continue;                                   // outside for every y
-                if (y >= o.y0 && y <= o.y1) {                           // inside: stays inside for y in [y0, y1]
-                    ylo = std::max(ylo, o.y0); yhi = std::min(yhi, o.y1);
-                    l = lo_d[(size_t)idx]; s = idx + 1; moved = true; break;
-                }
-                if (y < o.y0) yhi = std::min(yhi, o.y0 - 1); else ylo = std::max(ylo, o.y1 + 1);   // outside because of y only
-            }
-            if (!moved) break;
-        }
-        m.l = l0; m.t = t; m.ylo = ylo; m.yhi = yhi; m.res = l; m.epoch = ops.size();
-        return l;
-    };
-    // An op (hi -> lo) moves the pixels labelled hi inside box[hi].  Right after one, no such pixel is left, and
-    // new ones can only arrive through a later op whose `lo` is hi.  A seam row that asks for hi -> anything
-    // while nothing has flowed into hi since hi's last op therefore changes no pixel (the reference runs the
-    // same relabel and finds nothing, contrack.py:759/763): it is not recorded.  This keeps the per-label
-    // chains short where a stranded fragment sits on the seam for many rows.
-    std::vector<int32_t> &inflow = h->sd_inflow;             // index of the last recorded op with lo == label
-    inflow.assign((size_t)nd + 1, -1);
-    const double t_loop = now_ms();
-    int64_t nfold = 0;
-    for (int64_t k = 0; k < ncand; k++) {
-        const CtkCand &c = cand[k];
-        const int32_t y_last = (int32_t)((uint32_t)c.yy >> 16);
-        // rows y0..y_last of timestep c.t carry the same pair of fresh labels; visit them in order, skipping the rows
-        // for which the previous evaluation provably still holds
-        for (int32_t y = c.yy & 0xffff; y <= y_last;) {
-            const bool tl = first[(size_t)c.ll] >= 0, tr = first[(size_t)c.lr] >= 0;    // is `hi` of some op
-            if (c.ll == c.lr && !tl) break;                                // same label, never relabelled: nothing can differ
-            int32_t same_until = y_last;
-            const int32_t p0 = tl ? fold(0, c.ll, c.t, y, 0) : c.ll;
-            const int32_t p1 = tr ? fold(1, c.lr, c.t, y, nx - 1) : c.lr;
-            nfold += (tl ? 1 : 0) + (tr ? 1 : 0);
-            if (tl) same_until = std::min(same_until, memo[0].yhi);
-            if (tr) same_until = std::min(same_until, memo[1].yhi);
-            if (p0 == p1) { y = same_until + 1; continue; }                // nothing happens on these rows
-            const bool p0_hi = orig[p0] > orig[p1];                        // the larger FRESH label becomes the smaller (:759/763)
-            const int32_t hi = p0_hi ? p0 : p1, lo = p0_hi ? p1 : p0;
-            if (last[(size_t)hi] >= 0 && inflow[(size_t)hi] < last[(size_t)hi]) { y = same_until + 1; continue; }   // nothing to move, and
-                                                                           // nothing changes until an op is recorded
-            const int32_t *b = box + 6 * (int64_t)hi;
-            const int32_t idx = (int32_t)ops.size();
-            ops.push_back(CtkOp{orig[hi], orig[lo], b[0], b[1], b[2], b[3], b[4], b[5]});
-            lo_d.push_back(lo);
-            next.push_back(-1);
-            if (last[(size_t)hi] >= 0) next[(size_t)last[(size_t)hi]] = idx; else first[(size_t)hi] = idx;
-            last[(size_t)hi] = idx;
-            inflow[(size_t)lo] = idx;
-            y++;                                                           // the next row sees the new op
-        }
-    }
-    h->stats[9] = (int64_t)((now_ms() - t_loop) * 1e6);       // ns spent in the candidate loop
-    h->stats[10] = nfold;
-}
-
-}  // namespace
-
 // Tables the device resolver works on: the shard's own (single GPU) or the concatenation of all shards'.
 struct ResolveIn {
     int64_t T;                                   // timesteps covered by the tables
@@ -1051,12 +1000,18 @@ struct ResolveIn {
     const uint32_t *seam_cnt, *seam_off;         // record i of timestep t: seams[seam_off[t] + i]
     int64_t seam_cap;                            // upper bound of the surviving seam rows
     int32_t *comp_label;                         // out: [components]
+    size_t extra_dense = 0;                      // dense label ids beyond those of candidate records (time shards)
 };
 
 // returns CTK_OK, a negative error, or +1 = "take the host path" (pair table overflow / filter not converged)
-static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, int twosided, bool final_in_extent = false, bool local = false)
+// work space + kernel argument block of the resolver kernels for the tables `in`
+struct ResolvePlan {
+    ResolveDev r;
+    CandMail mail;
+    int nsb = 1, gc = 1, gp = 1;
+};
+static int rs_prepare(ctk_handle *h, const ResolveIn &in, double overlap, int twosided, ResolvePlan &pl)
 {
-    hipStream_t s = h->stream;
     const size_t R = in.R ? in.R : 1;
     const size_t PC = in.pair_cap ? in.pair_cap : 1;
     const int64_t T = in.T;
@@ -1074,10 +1029,10 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     CTKCHK(ensure(h, h->rv_cand_scratch, (size_t)std::max<int64_t>(T * h->ny, 1) * sizeof(CtkCand)));
     CTKCHK(ensure(h, h->rv_seam_res, (size_t)std::max<int64_t>(T * h->ny, 1) * 8));
     CTKCHK(ensure(h, h->rv_scalars, 64));
-    CTKCHK(ensure(h, h->rv_tdirty, (size_t)2 * (T > 0 ? T : 1)));
+    CTKCHK(ensure(h, h->rv_tdirty, (size_t)2 * (size_t)(T + 1)));        // two passes x (halo timestep + T)
     CTKCHK(ensure(h, h->rv_mark, R + 1));
     CTKCHK(ensure(h, h->rv_inv, R * 8)); CTKCHK(ensure(h, h->rv_ff, R * 8));
-    const size_t DC = std::min<size_t>(R + 1, (size_t)2 * std::max<int64_t>(in.seam_cap, 1));       // labels in candidate records
+    const size_t DC = std::min<size_t>(R + 1, (size_t)2 * std::max<int64_t>(in.seam_cap, 1) + in.extra_dense);       // labels in candidate records
     CTKCHK(ensure(h, h->rv_dmap, (R + 1) * 4)); CTKCHK(ensure(h, h->rv_dorig, DC * 4)); CTKCHK(ensure(h, h->rv_dbox, DC * 24));
     CTKCHK(ensure(h, h->op_first, (R + 1) * 4));
     CTKCHK(ensure(h, h->rv_inex, R));
@@ -1095,6 +1050,8 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     r.dmap = P<uint32_t>(h->rv_dmap); r.dorig = P<int32_t>(h->rv_dorig); r.dbox = P<int32_t>(h->rv_dbox); r.dcount = P<uint32_t>(h->rv_scalars); r.op_first = P<int32_t>(h->op_first);
     r.inex = P<uint8_t>(h->rv_inex); r.ambig = P<uint32_t>(h->rv_scalars) + 1; r.minlsb = h->w_minlsb;
     r.next_tiny = (const int32_t *)(P<int64_t>(h->wlo) + 2 * (size_t)h->ny); r.touch = P<uint32_t>(h->rv_touch);
+    r.nh_ptr = nullptr; r.t_lo = 1; r.t_hi = (int)T - 2;                // one slab: timesteps 1 .. T-2 are filtered, no halo
+    r.ovr_slot = nullptr; r.ovr_val = nullptr; r.amb_cnt = P<uint32_t>(h->rv_scalars) + 2; r.amb_list = nullptr; r.amb_cap = 0;
 
     const int gc = (int)std::min<size_t>((R + 255) / 256, 2048), gp = (int)std::min<size_t>((PC + 255) / 256, 2048);
     // mailbox in pinned host memory: the last resolver kernel writes scalars, candidate records and dense label tables
@@ -1115,6 +1072,19 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
     mail.cap_c = (uint32_t)h->mail_cap_c; mail.cap_d = (uint32_t)h->mail_cap_d;
     if (h->debug_mail_c) mail.cap_c = std::min(mail.cap_c, h->debug_mail_c);
     if (h->debug_mail_d) mail.cap_d = std::min(mail.cap_d, h->debug_mail_d);
+    pl.r = r; pl.mail = mail; pl.nsb = nsb; pl.gc = gc; pl.gp = gp;
+    return CTK_OK;
+}
+
+static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, int twosided, bool final_in_extent = false, bool local = false)
+{
+    hipStream_t s = h->stream;
+    const int64_t T = in.T;
+    ResolvePlan pl;
+    CTKCHK(rs_prepare(h, in, overlap, twosided, pl));
+    ResolveDev &r = pl.r;
+    CandMail &mail = pl.mail;
+    const int nsb = pl.nsb, gc = pl.gc, gp = pl.gp;
     uint32_t hs[CTK_MAIL_SCALARS];
     const double t0 = now_ms();
     int it_done = 0;
@@ -1129,7 +1099,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         // overlap filter: a round of passes (passes after the fixed point return at once)
         if (T > 2)
             for (int it = it_done; it < it_done + ROUND; it++)
-                k_rs_pass<<<(int)(T - 2), 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
+                k_rs_pass<<<(int)(T - 2), 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));        // t_lo = 1 .. t_hi = T-2
         it_done += ROUND;
         if (it_done > ROUND) k_rs_parent_init<<<gc, 256, 0, s>>>(r);          // the first round's parents were set by k_rs_init
         k_rs_unite<<<gp, 256, 0, s>>>(r);
@@ -1198,7 +1168,9 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         const double t1 = now_ms();
         const CtkCand *hc = (const CtkCand *)dst;
         const int32_t *ho = (const int32_t *)(dst + cb), *hb = ho + nd;
-        seam_driver(h, hc, ncand, ho, hb, (int64_t)nd, h->nx, ops);
+        h->sd.run(hc, ncand, ho, hb, (int64_t)nd, h->nx, ops);
+        h->stats[9] = h->sd.loop_ns;                              // ns spent in the candidate loop
+        h->stats[10] = h->sd.nfold;
         h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t1;
         HT("driver done");
         const double t2 = now_ms();
@@ -1247,7 +1219,7 @@ struct ExactFromDevice : CtkExactAreas {
         if (run_base.empty()) {
             run_base.resize((size_t)h->T + 1); cprefix.resize((size_t)h->T + 1);
             if (hipMemcpy(run_base.data(), h->run_base.p, run_base.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
-            if (hipMemcpy(cprefix.data(), h->cprefix.p, cprefix.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+            if (hipMemcpy(cprefix.data(), CPX(h), cprefix.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
         }
         const uint32_t nr = run_base[(size_t)t + 1] - run_base[(size_t)t], nc = cprefix[(size_t)t + 1] - cprefix[(size_t)t];
         s.mask.resize(nw); s.wstart.resize(nw); s.rowstart.resize((size_t)h->ny); s.run_comp.resize(nr); s.mrep.resize(nc);
@@ -1317,7 +1289,7 @@ static int device_resolve_local(ctk_handle *h, double overlap, int twosided)
     }
     ResolveIn in;
     in.T = h->T; in.R = R;
-    in.ncomp = P<uint32_t>(h->ncomp); in.cprefix = P<uint32_t>(h->cprefix); in.mrep = P<uint32_t>(h->d_mrep); in.comp_t = P<uint32_t>(h->d_comp_t);
+    in.ncomp = P<uint32_t>(h->ncomp); in.cprefix = CPX(h); in.mrep = P<uint32_t>(h->d_mrep); in.comp_t = P<uint32_t>(h->d_comp_t);
     in.box = P<uint16_t>(h->d_box); in.area = P<int64_t>(h->d_area);
     in.pairs = P<CtkPair>(h->pairs); in.pair_cap = h->pair_cap; in.counters = P<uint32_t>(h->counters);
     in.pair_base = P<uint32_t>(h->pair_base); in.pair_cnt = P<uint32_t>(h->pair_cnt);
@@ -1473,7 +1445,7 @@ extern "C" int ctk_shard_write(ctk_handle *h, int persistence, int32_t *flag_dev
     if (h->T > 0) {
         {
             Timer tm(h, CTK_K_RUNLABEL);
-            k_run_values<<<(int)h->T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), P<uint32_t>(h->cprefix), P<int32_t>(h->comp_label),
+            k_run_values<<<(int)h->T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), CPX(h), P<int32_t>(h->comp_label),
                                                    P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->d_mrep), 0, 0, P<int32_t>(h->run_val));
             HIPCHK(hipGetLastError());
         }
@@ -1683,7 +1655,7 @@ extern "C" int ctk_debug_label2d(ctk_handle *h, int before_seam, int32_t *lab)
     const int64_t n = h->T * h->ny * (int64_t)h->nx;
     if (n == 0) return CTK_OK;
     CTKCHK(ensure(h, h->dbg, (size_t)n * 4));
-    k_run_values<<<(int)h->T, 256, 0, h->stream>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), P<uint32_t>(h->cprefix), nullptr, nullptr, 0, 0,
+    k_run_values<<<(int)h->T, 256, 0, h->stream>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), CPX(h), nullptr, nullptr, 0, 0,
                                                    P<uint32_t>(h->d_mrep), 0, before_seam ? 1 : 2, P<int32_t>(h->run_val));
     HIPCHK(hipGetLastError());
     const int64_t tb = h->t_begin;
@@ -1826,6 +1798,9 @@ extern "C" int ctk_lifecycle_rows(ctk_handle *h, ctk_life_row *rows, int64_t cap
     return CTK_OK;
 }
 
+#include "ctk_comm.h"
+#include "ctk_sharded.hip"
+
 // device-memory helpers for a ctypes host
 // ------------------------------------------------------------------------------------------------
 extern "C" int ctk_dev_malloc(ctk_handle *h, void **p, size_t nbytes)
@@ -1866,6 +1841,7 @@ extern "C" int ctk_sync(ctk_handle *h)
     return CTK_OK;
 }
 extern "C" void *ctk_stream(ctk_handle *h) { return h ? (void *)h->stream : nullptr; }
+extern "C" int ctk_device_of(ctk_handle *h) { return h ? h->device : -1; }
 
 extern "C" int ctk_synth_fill(ctk_handle *h, float *anom_dev, int64_t T, int ny, int nx, uint64_t seed)
 {

@@ -297,8 +297,10 @@ __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v)
     return v;
 }
 
+// base_ptr (time shards): the scan starts at *base_ptr (the number of halo components) and out[-1] = 0
 __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ in, int64_t n,
-                                                   uint32_t *__restrict__ out, uint32_t *ovf, uint32_t *mail = nullptr)
+                                                   uint32_t *__restrict__ out, uint32_t *ovf, uint32_t *mail = nullptr,
+                                                   const uint32_t *base_ptr = nullptr)
 {
     __shared__ uint64_t wsum[16];
     __shared__ uint32_t wmax[16];
@@ -315,7 +317,8 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ 
         if (lane == 0) wmax[wv] = mx;
     }
     __syncthreads();
-    uint64_t base = 0;
+    uint64_t base = base_ptr ? (uint64_t)*base_ptr : 0ull;
+    if (base_ptr && tid == 0) out[-1] = 0u;
     for (int i = 0; i < wv; i++) base += wsum[i];
     uint64_t run = base + inc - s;
     for (int64_t i = b; i < e; i++) { out[i] = (uint32_t)run; run += in[i]; }

@@ -54,6 +54,19 @@ struct ResolveDev {
                                           // rows can be inexact (pole rows); ny if none.  Components that touch no such row sum exactly in
                                           // ANY order: only the others are subject to the minlsb rule.
     uint32_t *touch;                      // [NC] at representatives: some member's box holds such a row
+    // time shards (ctk_sharded.hip): components [0, *nh_ptr) are the HALO -- the previous shard's last timestep, "timestep -1"
+    // (cprefix[-1] = 0, cprefix[0] = *nh_ptr); their keep bits are imported, they are nodes of the 3-D union-find but never
+    // roots that take a number.  nh_ptr == nullptr: no halo.  The filter visits the local timesteps t_lo .. t_hi.
+    const uint32_t *nh_ptr;
+    int t_lo, t_hi;
+    // Decisions on rounded area sums that land within rounding distance of the threshold (exact ties on components with
+    // pole-row pixels) are re-evaluated with numpy-order sums (ctk_sharded.hip, "exact fix-up"): the pass records such
+    // components once (ovr_slot[g] = 0x40000000 | list index) and, once the host has supplied {areacon, forward, backward}
+    // as np.sum returns them (ovr_slot[g] = 0x80000000 | index), decides with those.  ovr_slot == nullptr: only *ambig is set.
+    uint32_t *ovr_slot;                   // [NC]
+    const double *ovr_val;                // [amb_cap][3]
+    uint32_t *amb_cnt, *amb_list;
+    uint32_t amb_cap;
 };
 
 #define CTK_CHG_SLOTS 64            // 'changed' words per filter pass (= wave width: one ballot reads them)
@@ -123,6 +136,7 @@ __global__ void k_rs_init(ResolveDev r)
         r.B[2 * (int64_t)g] = 0; r.B[2 * (int64_t)g + 1] = 0;
         r.keep0[g] = 1; r.keep1[g] = 1;
         r.touch[g] = 0;
+        if (r.ovr_slot) r.ovr_slot[g] = 0;
         r.parent[g] = g;                                   // (k_rs_parent_init, for the first round)
     }
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < (CTK_MAX_JACOBI + 1) * CTK_CHG_SLOTS; i += blockDim.x) r.changed[i] = 0;
@@ -140,7 +154,7 @@ __global__ void k_rs_pairs(ResolveDev r)
     const uint32_t np = dev_npairs(r), ng = dev_ngrouped(r);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
         const CtkPair p = pair_at(r, i, ng);
-        const uint32_t cb = r.cprefix[p.t], db = r.cprefix[p.t - 1];
+        const uint32_t cb = r.cprefix[p.t], db = r.cprefix[(int32_t)p.t - 1];       // (timestep -1: the halo of a time shard)
         const uint32_t gc = cb + p.c, gd = db + p.d;
         const uint32_t rc = cb + r.mrep[gc], rd = db + r.mrep[gd];
         r.p_gc[i] = gc; r.p_gd[i] = gd; r.p_rc[i] = rc; r.p_rd[i] = rd;
@@ -153,7 +167,7 @@ __global__ void k_rs_pairs(ResolveDev r)
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
         const uint16_t *q = r.box + 4 * (int64_t)g;
         if (r.next_tiny[q[0]] <= (int32_t)q[1]) {
-            const uint32_t rep = r.cprefix[r.comp_t[g]] + r.mrep[g];
+            const uint32_t rep = r.cprefix[(int32_t)r.comp_t[g]] + r.mrep[g];
             if (r.touch[rep] == 0u) atomicOr(&r.touch[rep], 1u);
         }
     }
@@ -198,9 +212,10 @@ __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint
                                                 uint8_t *__restrict__ tdirty)
 {
     if (dev_tables_bad(r)) return;
-    const int t = (int)blockIdx.x + 1;                         // timesteps 1 .. T-2 are filtered
+    const int t = (int)blockIdx.x + r.t_lo;                    // one slab: timesteps 1 .. T-2 are filtered
     const int64_t T = r.T;
-    uint8_t *dcur = tdirty + (size_t)(it & 1) * (size_t)T, *dprev = tdirty + (size_t)((it & 1) ^ 1) * (size_t)T;
+    // entry [t + 1] of two buffers of T + 1 flags ([0] = the halo timestep of a time shard)
+    uint8_t *dcur = tdirty + (size_t)(it & 1) * (size_t)(T + 1) + 1, *dprev = tdirty + (size_t)((it & 1) ^ 1) * (size_t)(T + 1) + 1;
     const int lane = (int)threadIdx.x;
     // round trip 1
     const uint32_t ch_prev = it > 0 ? (__ballot(r.changed[(it - 1) * CTK_CHG_SLOTS + lane] != 0u) != 0ull ? 1u : 0u) : 1u;
@@ -268,12 +283,24 @@ __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint
         if ((first ? mrep0 : r.mrep[g]) != c) continue;         // representatives only
         bool inexact = r.inex[g] != 0;
         const double bwd = dev_limbs_to_double(blo, bhi, r.wshift, r.limb_bits, &inexact);
-        const double fb = (first ? inv0 : r.inv[g]) * bwd, ff = first ? ff0 : r.ff[g];
-        if (inexact) {
+        double fb = (first ? inv0 : r.inv[g]) * bwd, ff = first ? ff0 : r.ff[g];
+        const uint32_t os = r.ovr_slot ? r.ovr_slot[g] : 0u;
+        if (os & 0x80000000u) {
+            // numpy's own sums (contrack.py:717-719) for this component, for the current keep bits of its predecessors
+            const double *v = r.ovr_val + 3 * (size_t)(os & 0x3fffffffu);
+            const double inv = 1.0 / v[0];
+            fb = inv * v[2]; ff = inv * v[1];
+        } else if (inexact) {
             // numpy sums these float64 values pairwise; a rounded sum can differ from this exact-then-rounded one by a few
             // ulp: flag decisions that sit that close to the threshold (same rule as ctk_resolve.cpp, DESIGN.md "exact areas")
             const double tol = CTK_AMBIG_ULPS * 2.220446049250313e-16 * fabs(r.overlap);
-            if ((ff != 0 && fabs(ff - r.overlap) <= tol) || (r.twosided && fb != 0 && fabs(fb - r.overlap) <= tol)) *r.ambig = 1u;    // (a zero sum is exact)
+            if ((ff != 0 && fabs(ff - r.overlap) <= tol) || (r.twosided && fb != 0 && fabs(fb - r.overlap) <= tol)) {    // (a zero sum is exact)
+                *r.ambig = 1u;
+                if (r.ovr_slot && os == 0u) {
+                    const uint32_t idx = atomicAdd(r.amb_cnt, 1u);
+                    if (idx < r.amb_cap) { r.amb_list[idx] = g; r.ovr_slot[g] = 0x40000000u | idx; }
+                }
+            }
         }
         bool kill = false;
         if (r.twosided) {
@@ -327,11 +354,11 @@ __global__ void k_rs_roots(ResolveDev r)
 {
     const uint32_t nc = dev_ncomps(r);
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
-        const uint32_t t = r.comp_t[g];
+        const int32_t t = (int32_t)r.comp_t[g];            // -1: halo component
         const bool kept = r.keep0[r.cprefix[t] + r.mrep[g]] != 0;
         const uint32_t root = gfind(r.parent, g);
         r.lab[g] = kept ? (int32_t)root : -1;               // temporarily: root index, -1 = filtered out
-        r.isroot[g] = (kept && root == g) ? 1u : 0u;
+        r.isroot[g] = (kept && root == g && g >= (r.nh_ptr ? *r.nh_ptr : 0u)) ? 1u : 0u;       // (a halo root is numbered by an earlier shard)
         // labels <= components: candidate mark / dense-id slot g+1 are initialised here
         r.mark[g + 1] = 0;
         r.dmap[g + 1] = 0;
@@ -381,9 +408,6 @@ __global__ void k_rs_labels(ResolveDev r)
     }
 }
 
-struct CtkCand {
-    int32_t t, yy, ll, lr;
-};
 // Dense ids for the labels on surviving seam rows (claim order).  A label sits on many consecutive rows and
 // timesteps: only the first row of a stretch tries (compare with the previous lane), the CAS on dmap[l] elects one
 // winner per label, and the winners of a wave take their ids with ONE atomicAdd (same-address atomics serialise).

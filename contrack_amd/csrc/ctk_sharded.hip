@@ -1,0 +1,904 @@
+// ctk_sharded.hip -- the whole path on a TIME SHARD, one rank per GPU (included by ctk_api.hip).
+//
+// Rank r owns the timesteps [t_begin, t_begin + T) of a slab of T_total steps.  Everything that touches pixels is
+// local.  What couples neighbouring shards is one timestep wide, and what couples all of them is a few hundred records:
+//
+//   X1  neighbour exchange (one RCCL group): my labelled LAST timestep -> rank r+1 (the "halo": bit mask, run prefixes,
+//       run -> component ids: the compressed one-timestep label map), my FIRST timestep's bit mask -> rank r-1 (its
+//       last timestep's forward overlap, contrack.py:718, needs nothing else)
+//       overlap histogram and resolver tables are local; the halo's components are "timestep -1" of the local tables
+//   X3  overlap filter (contrack.py:706-742): every rank iterates keep[t] = f(keep[t-1]) on its shard with the halo's
+//       keep bits as boundary condition (first guess: all kept); all-gather of {converged?, keep bits of my last
+//       timestep}; repeat while any rank changed or received changed bits.  The fixed point is the sequential result.
+//   X4  3-D labelling (contrack.py:748-751): local union-find (halo components are nodes), own roots ranked locally;
+//       all-gather of the sets that touch a shard boundary; boundary_resolve (ctk_seam.h) turns them into scipy's ids.
+//   X5  seam merges (contrack.py:753-763): candidate groups whose labels never leave the shard are driven locally;
+//       only the groups connected to a boundary-crossing label are all-gathered and driven identically on every rank.
+//   X6  time extents (persistence, contrack.py:765-772): all-gather + min/max of the boundary-crossing ids only.
+//   X7  counts.
+// Bulk pixel data never crosses the fabric; the replicated work is the (small) boundary and shared-seam part.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+struct HaloHeader {
+    uint32_t nruns, ncomp, pad0, pad1;
+};
+
+// halo blob of the shard's last timestep: [HaloHeader][mask ny*W u64][wstart ny*W u16, padded][rowstart ny u32, padded][run_comp]
+__global__ void k_halo_pack(const uint64_t *__restrict__ mask, const uint16_t *__restrict__ wstart, const uint32_t *__restrict__ rowstart,
+                            const uint32_t *__restrict__ run_base, const uint32_t *__restrict__ run_comp, const uint32_t *__restrict__ ncomp,
+                            int64_t T, int ny, int W, size_t off_w, size_t off_r, size_t off_c, size_t cap_runs, unsigned char *__restrict__ out)
+{
+    const int64_t t = T - 1;
+    const size_t nw = (size_t)ny * W;
+    const uint32_t rb = run_base[t], n = run_base[t + 1] - rb;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    if (i0 == 0) { HaloHeader hd; hd.nruns = n; hd.ncomp = ncomp[t]; hd.pad0 = 0; hd.pad1 = 0; *(HaloHeader *)out = hd; }
+    uint64_t *om = (uint64_t *)(out + sizeof(HaloHeader));
+    uint16_t *ow = (uint16_t *)(out + off_w);
+    uint32_t *orow = (uint32_t *)(out + off_r), *oc = (uint32_t *)(out + off_c);
+    for (size_t i = i0; i < nw; i += st) { om[i] = mask[(size_t)t * nw + i]; ow[i] = wstart[(size_t)t * nw + i]; }
+    for (size_t i = i0; i < (size_t)ny; i += st) orow[i] = rowstart[(size_t)t * ny + i];
+    for (size_t i = i0; i < (size_t)n && i < cap_runs; i += st) oc[i] = run_comp[rb + i];
+}
+
+// table rows of the halo components: each is its own (already seam-resolved) representative at "timestep -1"
+__global__ void k_halo_comps_init(const uint32_t *__restrict__ nh_ptr, uint32_t *__restrict__ mrep, uint32_t *__restrict__ comp_t,
+                                  uint16_t *__restrict__ box, int64_t *__restrict__ area)
+{
+    const uint32_t nh = *nh_ptr;
+    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x) {
+        mrep[h] = h; comp_t[h] = 0xffffffffu;
+        box[4 * (size_t)h] = 0; box[4 * (size_t)h + 1] = 0; box[4 * (size_t)h + 2] = 0; box[4 * (size_t)h + 3] = 0;
+        area[2 * (size_t)h] = 0; area[2 * (size_t)h + 1] = 0;
+    }
+}
+
+// forward overlap of the shard's LAST timestep (contrack.py:718) from the next shard's first bit mask
+__global__ __launch_bounds__(256) void k_sh_fwd_last(ResolveDev r, const uint64_t *__restrict__ mask, const uint16_t *__restrict__ wstart,
+                                                     const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ run_base,
+                                                     const uint32_t *__restrict__ run_comp, const uint64_t *__restrict__ mask_next,
+                                                     const int64_t *__restrict__ wlo, const int64_t *__restrict__ whi, int ny, int W)
+{
+    const int64_t t = r.T - 1;
+    const size_t nw = (size_t)ny * W;
+    const uint64_t *mc = mask + (size_t)t * nw;
+    const uint16_t *ws = wstart + (size_t)t * nw;
+    const uint32_t *rs = rowstart + (size_t)t * ny;
+    const uint32_t *rc = run_comp + run_base[t];
+    const uint32_t cb = r.cprefix[t];
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nw; idx += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t c = mc[idx];
+        uint64_t o = c & mask_next[idx];
+        if (o == 0ull) continue;
+        const int y = (int)(idx / W), w = (int)(idx - (size_t)y * W);
+        const uint64_t cin = (w > 0) ? (mc[idx - 1] >> 63) : 0ull;
+        const uint64_t sc = c & ~((c << 1) | cin);
+        const uint32_t ec = rs[y] + ws[idx];
+        while (o) {
+            const int b = __builtin_ctzll(o);
+            // all set bits of o inside ONE run of c: walk run by run
+            const uint64_t below = (b + 1 >= 64) ? FULL64 : ((1ull << (b + 1)) - 1ull);
+            const uint32_t run = ec + (uint32_t)__popcll(sc & below) - 1u;
+            // the run's bits in this word: from its start (or bit 0) to the first clear bit of c at or after b
+            const uint64_t cs = c >> b;
+            const int len = (~cs == 0ull) ? 64 - b : __builtin_ctzll(~cs);
+            const uint64_t seg = (len >= 64) ? FULL64 : (((1ull << len) - 1ull) << b);
+            const int n = __popcll(o & seg);
+            const uint32_t rep = cb + r.mrep[cb + rc[run]];
+            atomicAdd((unsigned long long *)&r.F[2 * (int64_t)rep], (unsigned long long)((int64_t)n * wlo[y]));
+            atomicAdd((unsigned long long *)&r.F[2 * (int64_t)rep + 1], (unsigned long long)((int64_t)n * whi[y]));
+            o &= ~seg;
+        }
+    }
+}
+
+// X3 payload of one rank: [KeepHeader][keep bit (one byte) of every component of my last timestep, capB bytes]
+struct KeepHeader {
+    uint32_t not_conv, nlast, ambig /* components recorded for the exact fix-up */, tables_bad;
+    uint32_t nc_own, passes, hint_c, hint_d;      // hint_*: capacities this rank would like for the shared seam records (X5)
+};
+__global__ void k_sh_pack_keep(ResolveDev r, int it_first, int it_count, uint32_t capB, uint32_t hint_c, uint32_t hint_d, uint32_t fix_changed,
+                               unsigned char *__restrict__ out)
+{
+    const int64_t T = r.T;
+    const uint32_t cb = r.cprefix[T - 1], nlast = r.cprefix[T] - cb;
+    unsigned char *bits = out + sizeof(KeepHeader);
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < capB; c += gridDim.x * blockDim.x)
+        bits[c] = (c < nlast) ? r.keep0[cb + r.mrep[cb + c]] : (unsigned char)0;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        // converged = the last pass launched changed nothing (passes after a fixed point return at once and record nothing)
+        const bool any = it_count > 0 && __ballot(r.changed[(it_first + it_count - 1) * CTK_CHG_SLOTS + threadIdx.x] != 0u) != 0ull;
+        if (threadIdx.x == 0) {
+            KeepHeader hd;
+            hd.not_conv = (any || fix_changed) ? 1u : 0u; hd.nlast = nlast; hd.ambig = *r.amb_cnt; hd.tables_bad = dev_tables_bad(r) ? 1u : 0u;
+            hd.nc_own = r.cprefix[T] - (r.nh_ptr ? *r.nh_ptr : 0u); hd.passes = (uint32_t)(it_first + it_count); hd.hint_c = hint_c; hd.hint_d = hint_d;
+            *(KeepHeader *)out = hd;
+        }
+    }
+}
+
+// After the all-gather: import the predecessor's bits into the halo components; decide -- identically on every rank --
+// whether another round is needed: some rank has not converged, or some rank's bits differ from the previous round's
+// (then its successor must re-evaluate).  prev = last round's gathered payloads (first round: "all kept").
+#define CTK_SHM_CONTINUE 0
+#define CTK_SHM_MAXNLAST 1
+#define CTK_SHM_NCSUM_LO 2
+#define CTK_SHM_NCSUM_HI 3
+#define CTK_SHM_AMBIG    4
+#define CTK_SHM_BAD      5
+#define CTK_SHM_MYDIFF   6
+#define CTK_SHM_HINT_C   7
+#define CTK_SHM_HINT_D   8
+#define CTK_SHM_MYFLAGGED 9
+__global__ __launch_bounds__(256) void k_sh_unpack_keep(ResolveDev r, const unsigned char *__restrict__ gathered, unsigned char *__restrict__ prev,
+                                                        int first_round, int redo, size_t slot, uint32_t capB, int rank, int world, int it_next,
+                                                        uint8_t *__restrict__ tdirty, uint32_t *__restrict__ mail)
+{
+    __shared__ uint32_t s_diff_any, s_my_diff;
+    if (threadIdx.x == 0) { s_diff_any = 0; s_my_diff = 0; }
+    __syncthreads();
+    const uint32_t nh = r.nh_ptr ? *r.nh_ptr : 0u;
+    // my halo
+    if (rank > 0) {
+        const unsigned char *pb = gathered + (size_t)(rank - 1) * slot + sizeof(KeepHeader);
+        bool d = false;
+        for (uint32_t hh = threadIdx.x; hh < nh && hh < capB; hh += blockDim.x) {
+            const unsigned char nb = pb[hh];
+            if (r.keep0[hh] != nb) { r.keep0[hh] = nb; d = true; }
+        }
+        if (d) s_my_diff = 1;
+    }
+    // every boundary: bits of rank q this round vs last round
+    bool d = false;
+    for (int q = 0; q + 1 < world; q++) {
+        const unsigned char *nb = gathered + (size_t)q * slot + sizeof(KeepHeader), *ob = prev + (size_t)q * slot + sizeof(KeepHeader);
+        const uint32_t n = min(((const KeepHeader *)(gathered + (size_t)q * slot))->nlast, capB);
+        for (uint32_t c = threadIdx.x; c < n; c += blockDim.x) {
+            const unsigned char o = first_round ? (unsigned char)1 : ob[c];
+            if (nb[c] != o) d = true;
+        }
+    }
+    if (d) s_diff_any = 1;
+    __syncthreads();
+    for (size_t i = threadIdx.x; i < (size_t)world * slot; i += blockDim.x) prev[i] = gathered[i];
+    if (threadIdx.x == 0) {
+        uint32_t nc_any = 0, mx = 0, amb = 0, bad = 0, hc = 0, hd_ = 0;
+        uint64_t ncs = 0;
+        for (int q = 0; q < world; q++) {
+            const KeepHeader *hd = (const KeepHeader *)(gathered + (size_t)q * slot);
+            nc_any |= hd->not_conv; mx = max(mx, hd->nlast); ncs += hd->nc_own; amb |= hd->ambig; bad |= hd->tables_bad;
+            hc = max(hc, hd->hint_c); hd_ = max(hd_, hd->hint_d);
+        }
+        mail[CTK_SHM_HINT_C] = hc; mail[CTK_SHM_HINT_D] = hd_;
+        mail[CTK_SHM_MYFLAGGED] = ((const KeepHeader *)(gathered + (size_t)rank * slot))->ambig;
+        mail[CTK_SHM_CONTINUE] = (nc_any || s_diff_any) ? 1u : 0u;
+        mail[CTK_SHM_MAXNLAST] = mx;
+        mail[CTK_SHM_NCSUM_LO] = (uint32_t)ncs; mail[CTK_SHM_NCSUM_HI] = (uint32_t)(ncs >> 32);
+        mail[CTK_SHM_AMBIG] = amb; mail[CTK_SHM_BAD] = bad; mail[CTK_SHM_MYDIFF] = s_my_diff;
+        // the next pass (it_next) must look at timestep 0 again iff the halo's bits changed
+        const int64_t T = r.T;
+        uint8_t *dprev = tdirty + (size_t)(((it_next - 1) & 1)) * (size_t)(T + 1), *dother = tdirty + (size_t)((it_next & 1)) * (size_t)(T + 1);
+        // (redo: the exchange is repeated with a larger capacity; what the first attempt imported stays pending)
+        dprev[0] = (s_my_diff || (redo && dprev[0])) ? 1 : 0;
+        dother[0] = 0;
+        if (s_my_diff && it_next > 0) r.changed[(it_next - 1) * CTK_CHG_SLOTS] = 1u;
+    }
+}
+
+// X4 payload of one rank: [BoundHeader][int32 last[capB]][int32 halo[capB]]  (see boundary_resolve in ctk_seam.h)
+struct BoundHeader {
+    int32_t nlast, nh, nroots, pad;
+};
+__global__ void k_sh_pack_boundary(ResolveDev r, uint32_t capB, unsigned char *__restrict__ out)
+{
+    const int64_t T = r.T;
+    const uint32_t nh = r.nh_ptr ? *r.nh_ptr : 0u;
+    const uint32_t cb = r.cprefix[T - 1], nlast = r.cprefix[T] - cb;
+    int32_t *last = (int32_t *)(out + sizeof(BoundHeader)), *halo = last + capB;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < capB; c += gridDim.x * blockDim.x) {
+        int32_t v = -1;
+        if (c < nlast) {
+            const int32_t root = r.lab[cb + c];                     // k_rs_roots: root index, -1 = filtered out
+            if (root >= 0) v = ((uint32_t)root < nh) ? 2 * root + 1 : 2 * (int32_t)r.rank[root];
+        }
+        last[c] = v;
+        halo[c] = (c < nh) ? r.lab[c] : -1;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        BoundHeader hd;
+        hd.nlast = (int32_t)nlast; hd.nh = (int32_t)nh; hd.nroots = (int32_t)r.rank[r.cprefix[T]]; hd.pad = 0;
+        *(BoundHeader *)out = hd;
+    }
+}
+
+// scipy's ids from the local root ranks and the boundary resolution (pinned staging written by the host):
+//   st[0..1] = off (int64), st[2] = nA, st[3] = nmark, then A[nA], Alab[nA], halo_label[nh], mark_labels[nmark]
+__global__ void k_rs_labels_sh(ResolveDev r, const int32_t *__restrict__ st, uint8_t *__restrict__ mark)
+{
+    const uint32_t nc = dev_ncomps(r);
+    const uint32_t nh = r.nh_ptr ? *r.nh_ptr : 0u;
+    const int64_t off = *(const int64_t *)st;
+    const int32_t nA = st[2], nmark = st[3];
+    const int32_t *A = st + 4, *Alab = A + nA, *hlab = Alab + nA, *ml = hlab + nh;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
+        const int32_t root = r.lab[g];
+        int32_t l = 0;
+        if (root >= 0) {
+            if ((uint32_t)root < nh) l = hlab[root];
+            else {
+                const int32_t k = (int32_t)r.rank[root];
+                int lo = 0, hi = nA;                                  // first absorbed root >= k
+                while (lo < hi) { const int m = (lo + hi) >> 1; if (A[m] < k) lo = m + 1; else hi = m; }
+                l = (lo < nA && A[lo] == k) ? Alab[lo] : (int32_t)(off + k - lo + 1);
+            }
+        }
+        r.lab[g] = l;
+    }
+    // labels that reach a shard boundary always count as "can take part in a relabel operation": another shard may hold
+    // the seam row that says so
+    // ... and always get a dense id: their boxes (find_objects over ALL timesteps, contrack.py:753) are the union of what
+    // every shard holding them contributes, whether or not this shard has a seam row with them
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nmark; i += gridDim.x * blockDim.x) {
+        const int32_t l = ml[i];
+        mark[l] = 1;
+        if (cand_try_claim(r, l)) cand_publish(r, l, atomicAdd(r.dcount, 1u));
+    }
+}
+
+// X6: time extents of the ids shared between shards
+__global__ void k_sh_pack_ext(const int32_t *__restrict__ elist, int32_t ne, const int32_t *__restrict__ ext, int64_t n_labels, int32_t *__restrict__ out)
+{
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += gridDim.x * blockDim.x) {
+        const int32_t l = elist[i];
+        out[2 * i] = ext[l]; out[2 * i + 1] = ext[n_labels + 1 + l];
+    }
+}
+__global__ void k_sh_reduce_ext(const int32_t *__restrict__ elist, int32_t ne, const int32_t *__restrict__ gathered, int world, int32_t *__restrict__ ext,
+                                int64_t n_labels)
+{
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += gridDim.x * blockDim.x) {
+        int32_t lo = INT32_MAX, hi = INT32_MIN;
+        for (int q = 0; q < world; q++) {
+            lo = min(lo, gathered[(size_t)q * 2 * ne + 2 * i]);
+            hi = max(hi, gathered[(size_t)q * 2 * ne + 2 * i + 1]);
+        }
+        const int32_t l = elist[i];
+        ext[l] = lo; ext[n_labels + 1 + l] = hi;
+    }
+}
+// ids numbered by THIS shard (l0 < id <= l1) that are present and survive persistence; + "a zero was written"
+__global__ __launch_bounds__(1024) void k_sh_count(const int32_t *__restrict__ ext, int64_t n_labels, int64_t l0, int64_t l1, int persistence,
+                                                   const uint32_t *__restrict__ counters, uint32_t *__restrict__ out)
+{
+    uint32_t v = 0;
+    for (int64_t l = l0 + 1 + threadIdx.x; l <= l1; l += 1024) {
+        const int64_t lo = ext[l], hi = ext[n_labels + 1 + l];
+        v += (hi >= lo && hi - lo + 1 >= persistence) ? 1u : 0u;
+    }
+    __shared__ uint32_t sm[16];
+    const uint32_t s = wave_sum_u32(v);
+    if (lane_id() == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int i = 0; i < 16; i++) tot += sm[i];
+        out[0] = tot;
+        out[1] = __hip_atomic_load(&counters[CTK_CNT_WROTE_ZERO], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact fix-up: per-row pixel counts of the components whose decision sits on a rounding boundary.  np.sum over
+// weight_grid[slice][mask] (contrack.py:717-719) adds the row weights of the selected pixels in raster order: the array is
+// fully described by how many pixels every row contributes.  counts[k][0|1|2][y] = pixels of flagged component k in row y:
+// all / also set at t+1 / whose pixel at t-1 belongs to a component that is currently kept.
+// ------------------------------------------------------------------------------------------------
+struct PlaneRef {
+    const uint64_t *mask;            // [ny][W]
+    const uint16_t *wstart;
+    const uint32_t *rowstart;
+    const uint32_t *run_comp;        // runs of this timestep
+};
+__device__ __forceinline__ int32_t plane_comp_at(const PlaneRef &p, int W, int y, int w, int b)
+{
+    const uint64_t m = p.mask[(size_t)y * W + w];
+    if (!((m >> b) & 1ull)) return -1;
+    const uint64_t carry = w > 0 ? p.mask[(size_t)y * W + w - 1] >> 63 : 0ull;
+    const uint64_t starts = m & ~((m << 1) | carry);
+    const uint64_t below = b == 63 ? FULL64 : ((1ull << (b + 1)) - 1ull);
+    return (int32_t)p.run_comp[p.rowstart[y] + p.wstart[(size_t)y * W + w] + (uint32_t)__popcll(starts & below) - 1u];
+}
+
+__global__ __launch_bounds__(256) void k_exact_counts(ResolveDev r, const uint32_t *__restrict__ list, const uint64_t *__restrict__ mask,
+                                                      const uint16_t *__restrict__ wstart, const uint32_t *__restrict__ rowstart,
+                                                      const uint32_t *__restrict__ run_base, const uint32_t *__restrict__ run_comp, PlaneRef halo,
+                                                      const uint64_t *__restrict__ mask_next, int has_prev, int has_next, int ny, int W,
+                                                      uint32_t *__restrict__ counts /* [n][3][ny], zeroed */)
+{
+    const uint32_t k = blockIdx.x, g = list[k];
+    const int64_t T = r.T;
+    const int t = (int)r.comp_t[g];
+    const uint32_t cb = r.cprefix[t], c = g - cb;
+    const size_t nw = (size_t)ny * W;
+    PlaneRef cur = {mask + (size_t)t * nw, wstart + (size_t)t * nw, rowstart + (size_t)t * ny, run_comp + run_base[t]};
+    const bool prev_local = t > 0, prev_halo = t == 0 && has_prev;
+    PlaneRef prv = halo;
+    if (prev_local) prv = {mask + (size_t)(t - 1) * nw, wstart + (size_t)(t - 1) * nw, rowstart + (size_t)(t - 1) * ny, run_comp + run_base[t - 1]};
+    const uint32_t pb = r.cprefix[t - 1];                           // (t = 0: the halo components start at cprefix[-1] = 0)
+    const uint64_t *nxt = (t + 1 < T) ? mask + (size_t)(t + 1) * nw : (has_next ? mask_next : nullptr);
+    uint32_t *ca = counts + (size_t)k * 3 * ny, *cf = ca + ny, *cbk = cf + ny;
+    for (size_t idx = threadIdx.x; idx < nw; idx += blockDim.x) {
+        uint64_t m = cur.mask[idx];
+        if (!m) continue;
+        const int y = (int)(idx / W), w = (int)(idx - (size_t)y * W);
+        uint32_t na = 0, nf = 0, nb = 0;
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const int32_t cc = plane_comp_at(cur, W, y, w, b);
+            if (cc < 0 || r.mrep[cb + cc] != c) continue;
+            na++;
+            if (nxt && ((nxt[idx] >> b) & 1ull)) nf++;
+            if (prev_local || prev_halo) {
+                const int32_t d = plane_comp_at(prv, W, y, w, b);
+                if (d >= 0 && r.keep0[pb + r.mrep[pb + d]]) nb++;
+            }
+        }
+        if (na) atomicAdd(&ca[y], na);
+        if (nf) atomicAdd(&cf[y], nf);
+        if (nb) atomicAdd(&cbk[y], nb);
+    }
+}
+
+// the host's numpy-order sums are in place (r.ovr_val): switch the listed components over and make the next pass look at them
+__global__ void k_exact_apply(ResolveDev r, uint32_t n, int it_next, uint8_t *__restrict__ tdirty)
+{
+    const int64_t T = r.T;
+    uint8_t *dprev = tdirty + (size_t)((it_next - 1) & 1) * (size_t)(T + 1) + 1;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t g = r.amb_list[k];
+        r.ovr_slot[g] = 0x80000000u | k;
+        const int t = (int)r.comp_t[g];
+        dprev[t - 1] = 1;                                            // "the predecessor changed": timestep t is evaluated again
+        if (it_next > 0) r.changed[(it_next - 1) * CTK_CHG_SLOTS + (t & (CTK_CHG_SLOTS - 1))] = 1u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------
+static size_t halo2_off_wstart(const ctk_handle *h) { return sizeof(HaloHeader) + (size_t)h->ny * h->W * 8; }
+static size_t halo2_off_rowstart(const ctk_handle *h) { return halo2_off_wstart(h) + ctk_align8((size_t)h->ny * h->W * 2); }
+static size_t halo2_off_runcomp(const ctk_handle *h) { return halo2_off_rowstart(h) + ctk_align8((size_t)h->ny * 4); }
+static size_t halo2_max_runs(const ctk_handle *h) { return (size_t)h->ny * ((size_t)h->nx / 2 + 1); }
+static size_t halo2_bytes(const ctk_handle *h) { return halo2_off_runcomp(h) + halo2_max_runs(h) * 4; }
+
+// (halo_off_* in ctk_api.hip are the offsets behind the header)
+static int shard_overlap_v2(ctk_handle *h) { return ctk_shard_overlap(h); }
+
+struct ShardScratch {
+    // host vectors kept between calls
+    std::vector<unsigned char> hbuf;
+    std::vector<BoundaryIn> bin;
+    BoundaryOut bout;
+    std::vector<int32_t> uf, elist, glabel, gbox, gfirst_lab, marks;
+    std::vector<CtkCand> gcand, lcand;
+    std::vector<CtkOp> ops_g, ops_l;
+    std::vector<uint8_t> isglob;
+    std::vector<int32_t> lmap, lorig, lbox;
+    std::vector<double> ovr, ovr_prev, wsum;
+    std::vector<uint32_t> cnt;
+};
+
+static void shard_scratch_free(ShardScratch *s) { delete s; }
+
+// CTK_SHDEBUG=1: synchronise and report after every stage (finds the stage a fault belongs to)
+static int g_shdbg = -1;
+#define SHDBG(name) do { if (g_shdbg < 0) g_shdbg = getenv("CTK_SHDEBUG") ? 1 : 0; if (g_shdbg) { hipError_t e_ = hipStreamSynchronize(s); \
+    fprintf(stderr, "[shard %d/%d] %-24s %s\n", rank, world, name, hipGetErrorString(e_)); } } while (0)
+
+static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, bool f64, int64_t T, int64_t t_begin, int64_t T_total, int ny, int nx,
+                              const double *thr, int cmp_op, const float *wrow, double overlap, int persistence, int twosided, int32_t *flag_dev,
+                              int64_t *n_tracked)
+{
+    if (!h || !c) return ctk_set_error(CTK_E_INVALID, "ctk_track_sharded: null handle or communicator");
+    const int rank = c->rank, world = c->world;
+    if (T < 1) return ctk_set_error(CTK_E_INVALID, "ctk_track_sharded: rank %d owns no timestep (every rank needs at least one: use at most T ranks)", rank);
+    if (t_begin < 0 || t_begin + T > T_total || (rank == 0) != (t_begin == 0) || (rank == world - 1) != (t_begin + T == T_total))
+        return ctk_set_error(CTK_E_INVALID, "ctk_track_sharded: shard [%lld, %lld) of %lld steps does not fit rank %d of %d", (long long)t_begin,
+                             (long long)(t_begin + T), (long long)T_total, rank, world);
+    if (c->stream != h->stream) return ctk_set_error(CTK_E_INVALID, "ctk_track_sharded: the communicator belongs to another handle");
+    const double t_call = now_ms();
+    hipStream_t s = h->stream;
+    const bool has_prev = rank > 0, has_next = rank + 1 < world;
+    if (!h->shard) h->shard = new (std::nothrow) ShardScratch();
+    if (!h->shard) return ctk_set_error(CTK_E_NOMEM, "out of memory");
+    ShardScratch &S = *h->shard;
+    S.ovr_prev.clear();
+
+    // ---- stage 1: threshold, runs, 2-D labelling (compaction of the component tables waits for the halo) ----------------
+    CTKCHK(shard_label2d_impl(h, anom_dev, f64, T, ny, nx, thr, cmp_op, wrow, has_prev ? 1 : 0, /*defer_compact=*/true));
+    const int W = h->W;
+    const size_t nw = (size_t)ny * W;
+    SHDBG("label2d");
+
+    // ---- X1: halo forward, first mask plane backward ------------------------------------------------------------------
+    const size_t hb = halo2_bytes(h);
+    CTKCHK(ensure(h, h->halo_out, hb));
+    CTKCHK(ensure(h, h->halo_in, hb));
+    CTKCHK(ensure(h, h->sh_mask_next, nw * 8));
+    if (has_next) {
+        k_halo_pack<<<64, 256, 0, s>>>(P<uint64_t>(h->mask), P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart), P<uint32_t>(h->run_base),
+                                       P<uint32_t>(h->run_comp), P<uint32_t>(h->ncomp), T, ny, W, halo2_off_wstart(h), halo2_off_rowstart(h),
+                                       halo2_off_runcomp(h), halo2_max_runs(h), (unsigned char *)h->halo_out.p);
+        HIPCHK(hipGetLastError());
+    }
+    if (!has_prev) HIPCHK(hipMemsetAsync(h->halo_in.p, 0, sizeof(HaloHeader), s));          // no halo: zero components
+    CTKCHK(ctk_comm_shift(c, +1, h->halo_out.p, hb, h->halo_in.p, hb));
+    CTKCHK(ctk_comm_shift(c, -1, h->mask.p, nw * 8, h->sh_mask_next.p, nw * 8));
+    const uint32_t *nh_ptr = &((const HaloHeader *)h->halo_in.p)->ncomp;
+    h->halo_valid = has_prev;
+    SHDBG("X1");
+
+    // ---- component tables: halo components first ("timestep -1"), then the shard's own in (t, c) order ------------------
+    {
+        Timer tm(h, CTK_K_SCAN);
+        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->ncomp), T, CPX(h), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, nullptr, nh_ptr);
+        k_compact_comps<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
+                                               P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box), P<int64_t>(h->d_area),
+                                               P<uint32_t>(h->d_comp_t));
+        k_halo_comps_init<<<16, 256, 0, s>>>(nh_ptr, P<uint32_t>(h->d_mrep), P<uint32_t>(h->d_comp_t), P<uint16_t>(h->d_box), P<int64_t>(h->d_area));
+        HIPCHK(hipGetLastError());
+    }
+    h->state = ST_LABELLED;
+    SHDBG("compact");
+
+    // ---- stage 2: co-occurrence histogram (the first local timestep against the halo) ------------------------------------
+    CTKCHK(shard_overlap_v2(h));
+    SHDBG("overlap");
+
+    // ---- resolver tables ---------------------------------------------------------------------------------------------
+    const size_t HB = halo2_max_runs(h);
+    const size_t R = (size_t)(h->total_runs ? h->total_runs : 1) + HB;
+    CTKCHK(ensure(h, h->comp_label, R * 4));
+    CTKCHK(ensure(h, h->seam_rowoff, (size_t)(T + 1) * 4));
+    if (h->rowoff_T != T || h->rowoff_ny != ny || h->rowoff_p != h->seam_rowoff.p) {
+        k_iota_mul<<<(int)((T + 255) / 256), 256, 0, s>>>(P<uint32_t>(h->seam_rowoff), (uint32_t)T, (uint32_t)ny);
+        h->rowoff_T = T; h->rowoff_ny = ny; h->rowoff_p = h->seam_rowoff.p;
+    }
+    ResolveIn in;
+    in.T = T; in.R = R;
+    in.ncomp = P<uint32_t>(h->ncomp); in.cprefix = CPX(h); in.mrep = P<uint32_t>(h->d_mrep); in.comp_t = P<uint32_t>(h->d_comp_t);
+    in.box = P<uint16_t>(h->d_box); in.area = P<int64_t>(h->d_area);
+    in.pairs = P<CtkPair>(h->pairs); in.pair_cap = h->pair_cap; in.counters = P<uint32_t>(h->counters);
+    in.pair_base = P<uint32_t>(h->pair_base); in.pair_cnt = P<uint32_t>(h->pair_cnt);
+    in.seams = P<CtkSeam>(h->seams); in.seam_cnt = P<uint32_t>(h->seam_cnt); in.seam_off = P<uint32_t>(h->seam_rowoff);
+    in.seam_cap = T * ny;
+    in.comp_label = P<int32_t>(h->comp_label);
+    in.extra_dense = 2 * HB;                          // boundary labels always get a dense id
+    ResolvePlan pl;
+    CTKCHK(rs_prepare(h, in, overlap, twosided, pl));
+    ResolveDev &r = pl.r;
+    r.nh_ptr = nh_ptr;
+    r.t_lo = has_prev ? 0 : 1;                       // global timesteps 1 .. T_total-2 are filtered
+    r.t_hi = has_next ? (int)T - 1 : (int)T - 2;
+    const uint32_t AMB_CAP = 1u << 16;
+    CTKCHK(ensure(h, h->sh_ovr_slot, R * 4));
+    CTKCHK(ensure(h, h->sh_ovr_val, (size_t)AMB_CAP * 24));
+    CTKCHK(ensure(h, h->sh_amb_list, (size_t)AMB_CAP * 4));
+    r.ovr_slot = P<uint32_t>(h->sh_ovr_slot); r.ovr_val = P<double>(h->sh_ovr_val); r.amb_list = P<uint32_t>(h->sh_amb_list); r.amb_cap = AMB_CAP;
+    const int npass_grid = r.t_hi - r.t_lo + 1;
+    const int gc = pl.gc, gp = pl.gp, nsb = pl.nsb;
+
+    // pinned scalars the device writes for the host
+    if (!h->h_mail2) { HIPCHK(hipHostMalloc((void **)&h->h_mail2, 4096, hipHostMallocDefault)); memset(h->h_mail2, 0, 4096); }
+    uint32_t *mail2 = h->h_mail2;
+
+    // ---- X3: overlap filter with boundary exchange --------------------------------------------------------------------
+    // Capacities of the exchanged records must be the SAME on every rank, whatever each handle has seen before: the boundary
+    // component capacity starts at a fixed value and grows by consensus inside the call; for the shared seam records every
+    // rank sends what it remembers and all take the maximum.
+    uint32_t capB = 256;
+    int it_done = 0, rounds = 0;
+    uint64_t nc_sum = 0;
+    bool first_round = true;
+    {
+        Timer tm(h, CTK_K_RESOLVE);
+        HIPCHK(hipMemsetAsync(h->rv_scalars.p, 0, 64, s));
+        k_rs_init<<<gc, 256, 0, s>>>(r);
+        k_rs_pairs<<<gp, 256, 0, s>>>(r);
+        if (has_next)
+            k_sh_fwd_last<<<(int)std::min<size_t>((nw + 255) / 256, 1024), 256, 0, s>>>(r, P<uint64_t>(h->mask), P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart),
+                                                                                        P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp),
+                                                                                        P<uint64_t>(h->sh_mask_next), P<int64_t>(h->wlo),
+                                                                                        P<int64_t>(h->wlo) + ny, ny, W);
+        k_rs_prep<<<gc, 256, 0, s>>>(r);
+        HIPCHK(hipGetLastError());
+    }
+    SHDBG("rs P1");
+    bool fix_changed = false, last_was_fixup = false;
+    int n_fixups = 0;
+    for (;;) {
+        const int npass = first_round ? h->filter_round : std::max(2, h->filter_round / 2);
+        if (it_done + npass > CTK_MAX_JACOBI) return ctk_set_error(CTK_E_RANGE, "ctk_track_sharded: overlap filter did not converge within %d passes", CTK_MAX_JACOBI);
+        {
+            Timer tm(h, CTK_K_RESOLVE);
+            if (npass_grid > 0)
+                for (int it = it_done; it < it_done + npass; it++)
+                    k_rs_pass<<<npass_grid, 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
+            HIPCHK(hipGetLastError());
+        }
+        for (int redo = 0;; redo = 1) {                                  // (repeated only when capB has to grow)
+            const size_t slot = sizeof(KeepHeader) + ctk_align8(capB);
+            CTKCHK(ensure(h, h->sh_send, slot));
+            CTKCHK(ensure(h, h->sh_recv, slot * (size_t)world));
+            if (h->sh_prev.cap < slot * (size_t)world) { CTKCHK(ensure(h, h->sh_prev, slot * (size_t)world)); if (!first_round) return ctk_set_error(CTK_E_INTERNAL, "boundary buffer grew between rounds"); }
+            k_sh_pack_keep<<<8, 256, 0, s>>>(r, it_done, npass_grid > 0 ? npass : 0, capB, h->sh_capC, h->sh_capD, fix_changed ? 1u : 0u, (unsigned char *)h->sh_send.p);
+            HIPCHK(hipGetLastError());
+            CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, slot));
+            k_sh_unpack_keep<<<1, 256, 0, s>>>(r, (const unsigned char *)h->sh_recv.p, (unsigned char *)h->sh_prev.p, first_round ? 1 : 0, redo, slot, capB, rank, world,
+                                               it_done + npass, P<uint8_t>(h->rv_tdirty), mail2);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(s));
+            if (mail2[CTK_SHM_MAXNLAST] <= capB) break;
+            if (!first_round) return ctk_set_error(CTK_E_INTERNAL, "boundary component count changed between rounds");
+            capB = mail2[CTK_SHM_MAXNLAST] + mail2[CTK_SHM_MAXNLAST] / 2 + 64;      // same decision on every rank; nothing was imported
+                                                                                   // beyond capB, the bits are simply exchanged again
+        }
+        it_done += npass;
+        rounds++;
+        first_round = false;
+        if (mail2[CTK_SHM_BAD]) return ctk_set_error(CTK_E_RANGE, "ctk_track_sharded: the co-occurrence table of some rank overflowed");
+        nc_sum = (uint64_t)mail2[CTK_SHM_NCSUM_LO] | ((uint64_t)mail2[CTK_SHM_NCSUM_HI] << 32);
+        fix_changed = false;
+        if (mail2[CTK_SHM_CONTINUE]) { last_was_fixup = false; continue; }
+        if (!mail2[CTK_SHM_AMBIG]) break;                               // converged, no decision on a rounding boundary anywhere
+        if (last_was_fixup) break;                                      // ... or the numpy-order sums were just confirmed: nothing changed
+        // ---- exact fix-up: some rank holds decisions on rounded area sums within rounding distance of the threshold --------
+        const uint32_t nflag = mail2[CTK_SHM_MYFLAGGED];
+        if (nflag > AMB_CAP) return ctk_set_error(CTK_E_RANGE, "ctk_track_sharded: more than %u overlap decisions on rounding boundaries", AMB_CAP);
+        if (nflag) {
+            const size_t cw = (size_t)nflag * 3 * (size_t)ny;
+            CTKCHK(ensure(h, h->sh_counts, cw * 4));
+            HIPCHK(hipMemsetAsync(h->sh_counts.p, 0, cw * 4, s));
+            const char *hl = (const char *)h->halo_in.p + sizeof(HaloHeader);
+            PlaneRef halo = {(const uint64_t *)hl, (const uint16_t *)(hl + halo_off_wstart(h)), (const uint32_t *)(hl + halo_off_rowstart(h)),
+                             (const uint32_t *)(hl + halo_off_runcomp(h))};
+            k_exact_counts<<<nflag, 256, 0, s>>>(r, r.amb_list, P<uint64_t>(h->mask), P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart), P<uint32_t>(h->run_base),
+                                                P<uint32_t>(h->run_comp), halo, P<uint64_t>(h->sh_mask_next), has_prev ? 1 : 0, has_next ? 1 : 0, ny, W,
+                                                P<uint32_t>(h->sh_counts));
+            HIPCHK(hipGetLastError());
+            S.cnt.resize(cw);
+            HIPCHK(hipMemcpyAsync(S.cnt.data(), h->sh_counts.p, cw * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            S.ovr.assign((size_t)nflag * 3, 0.0);
+            for (uint32_t k = 0; k < nflag; k++)
+                for (int q = 0; q < 3; q++) {
+                    const uint32_t *cy = &S.cnt[((size_t)k * 3 + q) * ny];
+                    S.wsum.clear();
+                    for (int y = 0; y < ny; y++) S.wsum.insert(S.wsum.end(), cy[y], (double)h->c_w[(size_t)y]);       // raster order
+                    S.ovr[(size_t)k * 3 + q] = ctk_np_sum(S.wsum.data(), S.wsum.size());
+                }
+            fix_changed = S.ovr_prev.size() != S.ovr.size() || memcmp(S.ovr_prev.data(), S.ovr.data(), S.ovr.size() * 8) != 0;
+            if (fix_changed) {
+                CTKCHK(ensure_host(&h->h_lab, &h->h_lab_cap, S.ovr.size() * 8 + 64));
+                memcpy(h->h_lab, S.ovr.data(), S.ovr.size() * 8);
+                HIPCHK(hipMemcpyAsync(h->sh_ovr_val.p, h->h_lab, S.ovr.size() * 8, hipMemcpyHostToDevice, s));
+                k_exact_apply<<<(int)((nflag + 255) / 256), 256, 0, s>>>(r, nflag, it_done, P<uint8_t>(h->rv_tdirty));
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(s));                          // (h_lab is reused below)
+                S.ovr_prev = S.ovr;
+            }
+            n_fixups = (int)nflag;
+        }
+        last_was_fixup = true;
+    }
+    h->stats[CTK_S_EXACT_FIXUPS] = n_fixups;
+    h->sh_capB = capB;
+    const uint32_t hint_c = mail2[CTK_SHM_HINT_C], hint_d = mail2[CTK_SHM_HINT_D];
+    SHDBG("X3");
+    h->stats[CTK_S_FILTER_PASSES] = it_done; h->stats[CTK_S_FILTER_ROUNDS] = rounds;
+    h->stats[CTK_S_AMBIGUOUS] = mail2[CTK_SHM_AMBIG];
+    if (nc_sum > 0x7ffffff0ull) return ctk_set_error(CTK_E_RANGE, "ctk_track_sharded: more than 2^31 components over all shards");
+
+    // ---- X4: 3-D labelling -------------------------------------------------------------------------------------------
+    const size_t bslot = sizeof(BoundHeader) + (size_t)capB * 8;
+    CTKCHK(ensure(h, h->sh_send, bslot));
+    CTKCHK(ensure(h, h->sh_recv, bslot * (size_t)world));
+    CTKCHK(ensure_host(&h->h_shard, &h->h_shard_cap, bslot * (size_t)world + 4096, true));
+    {
+        Timer tm(h, CTK_K_RESOLVE);
+        k_rs_unite<<<gp, 256, 0, s>>>(r);
+        k_rs_roots<<<gc, 256, 0, s>>>(r);
+        const uint32_t *ncp = in.cprefix + T;
+        k_scan_blocksum<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_bsum));
+        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_bsum), nsb, P<uint32_t>(h->rv_boff), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+        k_scan_apply<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_boff), r.rank);
+        k_sh_pack_boundary<<<8, 256, 0, s>>>(r, capB, (unsigned char *)h->sh_send.p);
+        HIPCHK(hipGetLastError());
+    }
+    SHDBG("pack boundary");
+    CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, bslot));
+    HIPCHK(hipMemcpyAsync(h->h_shard, h->sh_recv.p, bslot * (size_t)world, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    S.bin.assign((size_t)world, BoundaryIn());
+    for (int q = 0; q < world; q++) {
+        const unsigned char *p = (const unsigned char *)h->h_shard + (size_t)q * bslot;
+        const BoundHeader *hd = (const BoundHeader *)p;
+        BoundaryIn &b = S.bin[(size_t)q];
+        b.nlast = hd->nlast; b.nh = hd->nh; b.nroots = hd->nroots;
+        b.last = (const int32_t *)(p + sizeof(BoundHeader)); b.halo = b.last + capB;
+        if (b.nlast < 0 || b.nh < 0 || (uint32_t)b.nlast > capB || (uint32_t)b.nh > capB) return ctk_set_error(CTK_E_INTERNAL, "boundary record of rank %d is malformed", q);
+    }
+    if (!boundary_resolve(S.bin, S.bout)) return ctk_set_error(CTK_E_INTERNAL, "ctk_track_sharded: the shards' boundary records contradict each other");
+    const int64_t NL = S.bout.off[(size_t)world];
+    if (NL > 0x7ffffff0ll) return ctk_set_error(CTK_E_RANGE, "ctk_track_sharded: more than 2^31 - 16 ids");
+    h->n_labels = NL; h->t_begin = t_begin;
+    const int64_t lab0 = S.bout.off[(size_t)rank], lab1 = S.bout.off[(size_t)rank + 1];
+    // labels to mark on this rank: those of my halo components and of my last timestep's components (if a shard follows)
+    S.marks.clear();
+    for (int32_t l : S.bout.halo_label[(size_t)rank]) if (l > 0) S.marks.push_back(l);
+    if (has_next) for (int32_t l : S.bout.last_label[(size_t)rank]) if (l > 0) S.marks.push_back(l);
+    std::sort(S.marks.begin(), S.marks.end());
+    S.marks.erase(std::unique(S.marks.begin(), S.marks.end()), S.marks.end());
+    // staging block read by k_rs_labels_sh straight from pinned memory
+    {
+        const std::vector<int32_t> &A = S.bout.absorbed[(size_t)rank], &AL = S.bout.absorbed_label[(size_t)rank], &HL = S.bout.halo_label[(size_t)rank];
+        const size_t words = 4 + 2 * A.size() + HL.size() + S.marks.size();
+        CTKCHK(ensure_host(&h->h_lab, &h->h_lab_cap, words * 4 + 64));
+        int32_t *st = (int32_t *)h->h_lab;
+        *(int64_t *)st = lab0; st[2] = (int32_t)A.size(); st[3] = (int32_t)S.marks.size();
+        int32_t *p = st + 4;
+        if (!A.empty()) { memcpy(p, A.data(), A.size() * 4); p += A.size(); memcpy(p, AL.data(), A.size() * 4); p += A.size(); }
+        if (!HL.empty()) { memcpy(p, HL.data(), HL.size() * 4); p += HL.size(); }
+        if (!S.marks.empty()) memcpy(p, S.marks.data(), S.marks.size() * 4);
+    }
+    // label-indexed tables are indexed by GLOBAL ids here
+    CTKCHK(ensure(h, h->rv_mark, (size_t)NL + 2));
+    CTKCHK(ensure(h, h->rv_dmap, ((size_t)NL + 2) * 4));
+    CTKCHK(ensure(h, h->op_first, ((size_t)NL + 2) * 4));
+    CTKCHK(ensure(h, h->ext, ((size_t)NL + 1) * 8));
+    r.mark = P<uint8_t>(h->rv_mark); r.dmap = P<uint32_t>(h->rv_dmap); r.op_first = P<int32_t>(h->op_first);
+    // mailbox of the candidate records (same scheme as the single-GPU path)
+    CandMail &mail = pl.mail;
+    {
+        Timer tm(h, CTK_K_RESOLVE);
+        HIPCHK(hipMemsetAsync(h->rv_mark.p, 0, (size_t)NL + 2, s));
+        HIPCHK(hipMemsetAsync(h->rv_dmap.p, 0, ((size_t)NL + 2) * 4, s));
+        HIPCHK(hipMemsetAsync(h->op_first.p, 0xff, ((size_t)NL + 2) * 4, s));
+        k_rs_labels_sh<<<gc, 256, 0, s>>>(r, (const int32_t *)h->h_lab, P<uint8_t>(h->rv_mark));
+        k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, ny, P<uint8_t>(h->rv_mark), P<int2>(h->rv_seam_res));
+        k_rs_cand_groups<<<(int)T, 64, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), P<uint8_t>(h->rv_mark), ny, t_begin,
+                                               P<uint32_t>(h->rv_cand_cnt), P<CtkCand>(h->rv_cand_scratch));
+        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_cand_cnt), T, P<uint32_t>(h->rv_cand_off), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+        k_compact_cands<<<(int)T, 64, 0, s>>>(r, P<CtkCand>(h->rv_cand_scratch), P<uint32_t>(h->rv_cand_cnt), P<uint32_t>(h->rv_cand_off), ny,
+                                              P<CtkCand>(h->rv_cand), P<uint32_t>(h->rv_boff) + nsb, 0, 0, mail);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    uint32_t hs[CTK_MAIL_SCALARS];
+    memcpy(hs, mail.scal, sizeof(hs));
+    SHDBG("labels+cands");
+    const int64_t ncand = hs[CTK_MAIL_NCAND];
+    const size_t nd = hs[CTK_MAIL_ND];
+    h->stats[CTK_S_COMPONENTS] = (int64_t)hs[CTK_MAIL_NC]; h->stats[CTK_S_PAIRS] = (int64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS];
+    h->stats[CTK_S_SEAM_ROWS] = ncand; h->stats[CTK_S_LABELS] = NL; h->stats[CTK_S_UPAIRS] = hs[CTK_CNT_UPAIRS];
+    h->mail_want_c = std::max<size_t>(h->mail_want_c, (size_t)ncand + (size_t)ncand / 2);
+    h->mail_want_d = std::max<size_t>(h->mail_want_d, nd + nd / 2);
+    // candidate records + dense label tables -> pageable copies
+    const size_t cb = (size_t)ncand * sizeof(CtkCand);
+    h->sd_cand.resize(cb + nd * 28 + 64);
+    char *dst = (char *)h->sd_cand.data();
+    if (ncand || nd) {                     // (boundary labels have dense ids even without a candidate record)
+        if ((size_t)ncand <= mail.cap_c && nd <= mail.cap_d) {
+            memcpy(dst, mail.cand, cb); memcpy(dst + cb, mail.dorig, nd * 4); memcpy(dst + cb + nd * 4, mail.dbox, nd * 24);
+        } else {
+            if (cb) HIPCHK(hipMemcpyAsync(dst, h->rv_cand.p, cb, hipMemcpyDeviceToHost, s));
+            if (nd) {
+                HIPCHK(hipMemcpyAsync(dst + cb, h->rv_dorig.p, nd * 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipMemcpyAsync(dst + cb + nd * 4, h->rv_dbox.p, nd * 24, hipMemcpyDeviceToHost, s));
+            }
+            HIPCHK(hipStreamSynchronize(s));
+        }
+    }
+    const CtkCand *hc = (const CtkCand *)dst;
+    const int32_t *ho = (const int32_t *)(dst + cb), *hbx = ho + nd;
+
+    // ---- X5: seam merges.  Candidate groups connected (through shared rows) to a label that reaches a shard boundary are
+    // shared: all-gathered and driven identically everywhere; the others are this shard's own. ------------------------------
+    const double t_host = now_ms();
+    S.uf.resize(nd);
+    for (size_t i = 0; i < nd; i++) S.uf[i] = (int32_t)i;
+    auto find = [&](int32_t i) { while (S.uf[(size_t)i] != i) { S.uf[(size_t)i] = S.uf[(size_t)S.uf[(size_t)i]]; i = S.uf[(size_t)i]; } return i; };
+    for (int64_t k = 0; k < ncand; k++) {
+        const int32_t a = find(hc[k].ll), b = find(hc[k].lr);
+        if (a != b) S.uf[(size_t)std::max(a, b)] = std::min(a, b);
+    }
+    S.isglob.assign(nd, 0);
+    for (size_t i = 0; i < nd; i++)
+        if (std::binary_search(S.marks.begin(), S.marks.end(), ho[i])) S.isglob[(size_t)find((int32_t)i)] = 1;
+    size_t nGd = 0;
+    int64_t nGc = 0;
+    for (size_t i = 0; i < nd; i++) if (S.isglob[(size_t)find((int32_t)i)]) nGd++;
+    for (int64_t k = 0; k < ncand; k++) if (S.isglob[(size_t)find(hc[k].ll)]) nGc++;
+    uint32_t capC = std::max<uint32_t>(hint_c, 256), capD = std::max<uint32_t>(hint_d, 256);
+    struct SeamHeader { uint32_t ncand, nlab, pad0, pad1; };
+    size_t sslot = 0;
+    for (;;) {
+        sslot = sizeof(SeamHeader) + (size_t)capC * sizeof(CtkCand) + (size_t)capD * 28;
+        CTKCHK(ensure_host(&h->h_seam, &h->h_seam_cap, sslot * (size_t)(world + 1), true));
+        CTKCHK(ensure(h, h->sh_send, sslot));
+        CTKCHK(ensure(h, h->sh_recv, sslot * (size_t)world));
+        unsigned char *sb = (unsigned char *)h->h_seam;
+        SeamHeader sh; sh.ncand = (uint32_t)nGc; sh.nlab = (uint32_t)nGd; sh.pad0 = 0; sh.pad1 = 0;
+        memcpy(sb, &sh, sizeof(sh));
+        if ((uint32_t)nGc <= capC && nGd <= capD) {
+            CtkCand *oc = (CtkCand *)(sb + sizeof(SeamHeader));
+            int32_t *ol = (int32_t *)(sb + sizeof(SeamHeader) + (size_t)capC * sizeof(CtkCand));
+            size_t j = 0;
+            for (int64_t k = 0; k < ncand; k++)
+                if (S.isglob[(size_t)find(hc[k].ll)]) { CtkCand q = hc[k]; q.ll = ho[q.ll]; q.lr = ho[q.lr]; oc[j++] = q; }      // GLOBAL labels
+            j = 0;
+            for (size_t i = 0; i < nd; i++)
+                if (S.isglob[(size_t)find((int32_t)i)]) { ol[7 * j] = ho[i]; memcpy(ol + 7 * j + 1, hbx + 6 * i, 24); j++; }
+        }
+        HIPCHK(hipMemcpyAsync(h->sh_send.p, sb, sslot, hipMemcpyHostToDevice, s));
+        CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, sslot));
+        HIPCHK(hipMemcpyAsync(sb + sslot, h->sh_recv.p, sslot * (size_t)world, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        uint32_t mc = 0, md = 0;
+        for (int q = 0; q < world; q++) {
+            const SeamHeader *qh = (const SeamHeader *)(sb + sslot * (size_t)(q + 1));
+            mc = std::max(mc, qh->ncand); md = std::max(md, qh->nlab);
+        }
+        if (mc <= capC && md <= capD) break;
+        capC = std::max(capC, mc + mc / 2 + 64); capD = std::max(capD, md + md / 2 + 64);       // same on every rank
+    }
+    h->sh_capC = capC; h->sh_capD = capD;
+    // merged table of the shared labels (boxes: union over the shards) and the shared candidate groups in (t, y) order
+    S.glabel.clear(); S.gbox.clear(); S.gcand.clear();
+    {
+        const unsigned char *gb = (const unsigned char *)h->h_seam + sslot;
+        std::vector<std::pair<int32_t, int32_t>> &tmp = h->sh_pairs;      // (label, position) for the merge
+        tmp.clear();
+        for (int q = 0; q < world; q++) {
+            const unsigned char *p = gb + sslot * (size_t)q;
+            const SeamHeader *qh = (const SeamHeader *)p;
+            const int32_t *ql = (const int32_t *)(p + sizeof(SeamHeader) + (size_t)capC * sizeof(CtkCand));
+            for (uint32_t i = 0; i < qh->nlab; i++) tmp.emplace_back(ql[7 * i], (int32_t)(q * (int64_t)capD + i));
+        }
+        std::sort(tmp.begin(), tmp.end());
+        for (size_t i = 0; i < tmp.size(); i++) {
+            const int q = tmp[i].second / (int32_t)capD, k = tmp[i].second % (int32_t)capD;
+            const int32_t *ql = (const int32_t *)(gb + sslot * (size_t)q + sizeof(SeamHeader) + (size_t)capC * sizeof(CtkCand)) + 7 * (size_t)k;
+            if (S.glabel.empty() || S.glabel.back() != tmp[i].first) {
+                S.glabel.push_back(tmp[i].first);
+                S.gbox.insert(S.gbox.end(), ql + 1, ql + 7);
+            } else {
+                int32_t *b = &S.gbox[S.gbox.size() - 6];
+                b[0] = std::min(b[0], ql[1]); b[1] = std::max(b[1], ql[2]); b[2] = std::min(b[2], ql[3]);
+                b[3] = std::max(b[3], ql[4]); b[4] = std::min(b[4], ql[5]); b[5] = std::max(b[5], ql[6]);
+            }
+        }
+        auto gid = [&](int32_t l) { return (int32_t)(std::lower_bound(S.glabel.begin(), S.glabel.end(), l) - S.glabel.begin()); };
+        for (int q = 0; q < world; q++) {                                 // rank order = time order
+            const unsigned char *p = gb + sslot * (size_t)q;
+            const SeamHeader *qh = (const SeamHeader *)p;
+            const CtkCand *qc = (const CtkCand *)(p + sizeof(SeamHeader));
+            for (uint32_t i = 0; i < qh->ncand; i++) { CtkCand v = qc[i]; v.ll = gid(v.ll); v.lr = gid(v.lr); S.gcand.push_back(v); }
+        }
+    }
+    h->sd_glob.run(S.gcand.data(), (int64_t)S.gcand.size(), S.glabel.data(), S.gbox.data(), (int64_t)S.glabel.size(), nx, S.ops_g);
+    // this shard's own groups: dense ids renumbered without the shared labels
+    S.lmap.assign(nd, -1); S.lorig.clear(); S.lbox.clear(); S.lcand.clear();
+    for (size_t i = 0; i < nd; i++)
+        if (!S.isglob[(size_t)find((int32_t)i)]) { S.lmap[i] = (int32_t)S.lorig.size(); S.lorig.push_back(ho[i]); S.lbox.insert(S.lbox.end(), hbx + 6 * i, hbx + 6 * i + 6); }
+    for (int64_t k = 0; k < ncand; k++)
+        if (!S.isglob[(size_t)find(hc[k].ll)]) { CtkCand v = hc[k]; v.ll = S.lmap[(size_t)v.ll]; v.lr = S.lmap[(size_t)v.lr]; S.lcand.push_back(v); }
+    h->sd.run(S.lcand.data(), (int64_t)S.lcand.size(), S.lorig.data(), S.lbox.data(), (int64_t)S.lorig.size(), nx, S.ops_l);
+    h->stats[9] = h->sd.loop_ns + h->sd_glob.loop_ns; h->stats[10] = h->sd.nfold + h->sd_glob.nfold;
+    h->stats[CTK_S_OPS] = (int64_t)(S.ops_g.size() + S.ops_l.size());
+    h->stats[CTK_S_SHARED_ROWS] = (int64_t)S.gcand.size();
+    // ids whose time extent is shared between shards: everything that reaches a boundary + the shared seam labels
+    S.elist = S.bout.crossing;
+    S.elist.insert(S.elist.end(), S.glabel.begin(), S.glabel.end());
+    std::sort(S.elist.begin(), S.elist.end());
+    S.elist.erase(std::unique(S.elist.begin(), S.elist.end()), S.elist.end());
+    const int32_t ne = (int32_t)S.elist.size();
+    h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t_host;
+
+    // ---- ops -> device (one pinned staging block read by k_ops_ingest), then extents ---------------------------------------
+    {
+        const int64_t ng = (int64_t)S.ops_g.size(), nl = (int64_t)S.ops_l.size(), nops = ng + nl;
+        h->nops = (int32_t)nops;
+        const size_t bytes = (size_t)std::max<int64_t>(nops, 1) * (sizeof(CtkOp) + 4 + 8) + (size_t)ne * 4 + 64;
+        CTKCHK(ensure_host(&h->h_ops, &h->h_ops_cap, bytes));
+        CTKCHK(ensure(h, h->ops, bytes));
+        CtkOp *s_ops = (CtkOp *)h->h_ops;
+        int32_t *s_next = (int32_t *)(s_ops + nops), *s_label = s_next + nops, *s_first = s_label + nops, *s_el = s_first + nops;
+        int32_t nf = 0;
+        if (ng) memcpy(s_ops, S.ops_g.data(), (size_t)ng * sizeof(CtkOp));
+        if (nl) memcpy(s_ops + ng, S.ops_l.data(), (size_t)nl * sizeof(CtkOp));
+        for (int64_t i = 0; i < ng; i++) s_next[i] = h->sd_glob.next[(size_t)i];
+        for (int64_t i = 0; i < nl; i++) s_next[ng + i] = h->sd.next[(size_t)i] < 0 ? -1 : (int32_t)(h->sd.next[(size_t)i] + ng);
+        for (size_t d = 0; d < S.glabel.size(); d++)
+            if (h->sd_glob.first[d] >= 0) { s_label[nf] = S.glabel[d]; s_first[nf] = h->sd_glob.first[d]; nf++; }
+        for (size_t d = 0; d < S.lorig.size(); d++)
+            if (h->sd.first[d] >= 0) { s_label[nf] = S.lorig[d]; s_first[nf] = (int32_t)(h->sd.first[d] + ng); nf++; }
+        if (ne) memcpy(s_el, S.elist.data(), (size_t)ne * 4);
+        int32_t *d_next = (int32_t *)(P<CtkOp>(h->ops) + nops);
+        h->d_op_next = d_next;
+        const int64_t work = std::max<int64_t>(nops * 9, NL + 1);
+        k_ops_ingest<<<(int)std::min<int64_t>((work + 255) / 256, 1024), 256, 0, s>>>((const int32_t *)h->h_ops, nops, nf, P<int32_t>(h->ops), P<int32_t>(h->op_first),
+                                                                                      P<int32_t>(h->ext), NL, P<uint32_t>(h->counters));
+        HIPCHK(hipGetLastError());
+        h->state = ST_TABLES;
+        h->total_comps = (uint32_t)hs[CTK_MAIL_NC];
+        CTKCHK(launch_extents(h, true, true));                           // + the final id of every own component
+    SHDBG("extents");
+        // ---- X6 -----------------------------------------------------------------------------------------------------
+        if (world > 1 && ne > 0) {
+            CTKCHK(ensure(h, h->sh_send, (size_t)ne * 8));
+            CTKCHK(ensure(h, h->sh_recv, (size_t)ne * 8 * (size_t)world));
+            CTKCHK(ensure(h, h->sh_elist, (size_t)ne * 4));
+            HIPCHK(hipMemcpyAsync(h->sh_elist.p, s_el, (size_t)ne * 4, hipMemcpyHostToDevice, s));
+            const int ge = std::min((ne + 255) / 256, 256);
+            k_sh_pack_ext<<<ge, 256, 0, s>>>(P<int32_t>(h->sh_elist), ne, P<int32_t>(h->ext), NL, P<int32_t>(h->sh_send));
+            HIPCHK(hipGetLastError());
+            CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, (size_t)ne * 8));
+            k_sh_reduce_ext<<<ge, 256, 0, s>>>(P<int32_t>(h->sh_elist), ne, P<int32_t>(h->sh_recv), world, P<int32_t>(h->ext), NL);
+            HIPCHK(hipGetLastError());
+        }
+        h->state = ST_EXTENTS;
+    }
+
+    // ---- persistence + write ----------------------------------------------------------------------------------------
+    {
+        Timer tm(h, CTK_K_RUNLABEL);
+        k_run_values<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), CPX(h), P<int32_t>(h->comp_label), P<int32_t>(h->ext), NL,
+                                            persistence, P<uint32_t>(h->d_mrep), 0, 0, P<int32_t>(h->run_val));
+        HIPCHK(hipGetLastError());
+    }
+    {
+        Timer tm(h, CTK_K_RELABEL);
+        CTKCHK(launch_relabel(h, persistence, flag_dev, true));
+    }
+    SHDBG("relabel");
+    // ---- X7: counts ---------------------------------------------------------------------------------------------------
+    CTKCHK(ensure(h, h->sh_send, 64));
+    CTKCHK(ensure(h, h->sh_recv, 64 * (size_t)world));
+    k_sh_count<<<1, 1024, 0, s>>>(P<int32_t>(h->ext), NL, lab0, lab1, persistence, P<uint32_t>(h->counters), P<uint32_t>(h->sh_send));
+    HIPCHK(hipGetLastError());
+    CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, 8));
+    HIPCHK(hipMemcpyAsync(mail2 + 64, h->sh_recv.p, 8 * (size_t)world, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    int64_t alive = 0;
+    bool zero = false;
+    for (int q = 0; q < world; q++) { alive += mail2[64 + 2 * q]; zero = zero || mail2[64 + 2 * q + 1] != 0; }
+    h->last_alive = alive;
+    if (n_tracked) *n_tracked = alive + (zero ? 1 : 0) - 1;              // len(np.unique(flag)) - 1, contrack.py:793
+    collect_event_times(h);
+    h->state = ST_TABLES;
+    h->ms[CTK_T_TOTAL] += now_ms() - t_call;
+    return CTK_OK;
+}
+
+extern "C" int ctk_track_sharded_f32_dev(ctk_handle *h, ctk_comm *c, const float *anom_dev, int64_t T_local, int64_t t_begin, int64_t T_total, int ny, int nx,
+                                         const double *thr, int cmp_op, const float *wrow, double overlap, int persistence, int twosided,
+                                         int32_t *flag_dev, int64_t *n_tracked)
+{
+    const int rc = track_sharded_impl(h, c, anom_dev, false, T_local, t_begin, T_total, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev, n_tracked);
+    if (rc != CTK_OK) ctk_comm_abort(c);
+    return rc;
+}
+extern "C" int ctk_track_sharded_f64_dev(ctk_handle *h, ctk_comm *c, const double *anom_dev, int64_t T_local, int64_t t_begin, int64_t T_total, int ny, int nx,
+                                         const double *thr, int cmp_op, const float *wrow, double overlap, int persistence, int twosided,
+                                         int32_t *flag_dev, int64_t *n_tracked)
+{
+    const int rc = track_sharded_impl(h, c, anom_dev, true, T_local, t_begin, T_total, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev, n_tracked);
+    if (rc != CTK_OK) ctk_comm_abort(c);
+    return rc;
+}

@@ -34,6 +34,12 @@ struct CtkOp {
     int32_t y0, y1, x0, x1;
 };
 
+// Candidate record of the seam driver: rows y0..y1 (yy = y0 | y1 << 16) of timestep t whose seam pixels carry the pair of
+// fresh labels (ll at x = 0, lr at x = nx-1) -- as dense ids of the labels that occur in such records.
+struct CtkCand {
+    int32_t t, yy, ll, lr;
+};
+
 struct CtkBlobHeader {
     uint64_t magic;
     int64_t T;

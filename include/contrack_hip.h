@@ -135,6 +135,37 @@ int ctk_shard_write(ctk_handle *h, int persistence, int32_t *flag_dev, int64_t *
 /* number of labels that survive persistence (identical on all ranks after the all-reduce)        */
 int ctk_shard_count_tracked(ctk_handle *h, int64_t *n_alive);
 
+/* ---- time-sharded path, one rank per GPU --------------------------------------------------------------------
+ * Rank r owns the timesteps [t_begin, t_begin + T_local) of a slab of T_total steps (time order = rank order; every rank
+ * owns at least one step).  ctk_track_sharded_* is ctk_track_*_dev on that shard: bulk data stays local, the ranks
+ * exchange a one-timestep label-map halo with their neighbours and a few hundred boundary records through the
+ * communicator (contrack_amd/csrc/ctk_sharded.hip).  flag / n_tracked are identical to what one call on the whole slab
+ * returns; n_tracked is the same on every rank.  All ranks must make the call (it contains collectives).
+ *
+ * Communicator: RCCL over xGMI (one process per GPU; librccl.so is loaded on first use), an in-process group (several
+ * handles driven by one host thread each), or a shared-memory transport for several processes on one node without RCCL. */
+typedef struct ctk_comm ctk_comm;
+typedef struct ctk_comm_group ctk_comm_group;
+#define CTK_COMM_ID_BYTES 128
+int  ctk_comm_unique_id(void *id /* CTK_COMM_ID_BYTES, made on rank 0 (ncclGetUniqueId), handed to the other ranks by the launcher */);
+int  ctk_comm_init_rccl(ctk_handle *h, const void *id, int rank, int world, ctk_comm **out);
+int  ctk_comm_group_create(int world, ctk_comm_group **out);
+void ctk_comm_group_destroy(ctk_comm_group *g);
+int  ctk_comm_init_local(ctk_handle *h, ctk_comm_group *g, int rank, ctk_comm **out);
+int  ctk_comm_init_shm(ctk_handle *h, const char *segment_name, int rank, int world, ctk_comm **out);
+void ctk_comm_destroy(ctk_comm *c);
+int  ctk_comm_rank(const ctk_comm *c);
+int  ctk_comm_world(const ctk_comm *c);
+int  ctk_comm_barrier(ctk_comm *c);
+int  ctk_comm_allgather_host(ctk_comm *c, const void *send, void *recv /* world * nbytes */, size_t nbytes /* <= 4096 */);
+int  ctk_comm_ops(const ctk_comm *c, int64_t *shifts, int64_t *allgathers);      /* operations issued so far */
+int  ctk_track_sharded_f32_dev(ctk_handle *h, ctk_comm *c, const float *anom_dev, int64_t T_local, int64_t t_begin, int64_t T_total,
+                               int ny, int nx, const double *thr /* T_local */, int cmp_op, const float *wrow, double overlap,
+                               int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked);
+int  ctk_track_sharded_f64_dev(ctk_handle *h, ctk_comm *c, const double *anom_dev, int64_t T_local, int64_t t_begin, int64_t T_total,
+                               int ny, int nx, const double *thr, int cmp_op, const float *wrow, double overlap,
+                               int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked);
+
 /* ---- staged-parity / debug accessors (host copies) ------------------------------------------- */
 int ctk_debug_mask(ctk_handle *h, uint8_t *mask /* (T,ny,nx) 0/1 */);
 /* 2-D labels exactly as scipy numbers them at contrack.py:684 (before_seam=1) or after the seam merge
@@ -186,6 +217,7 @@ int ctk_set_timing(ctk_handle *h, int level);
                                    whose weight is ~2^-20 of the others) and came out within 8 ulp of the threshold; numpy's pairwise
                                    float64 summation may land on the other side there (only with exact ties: blocky test fields,
                                    overlap = 1.0).  Device path: 0/1 flag; host resolver: the number of such decisions. */
+#define CTK_S_SHARED_ROWS   17  /* time-sharded path: seam candidate groups shared between shards (driven on every rank)        */
 #define CTK_NSTATS          24
 int ctk_get_stats(ctk_handle *h, int64_t *out /* [CTK_NSTATS] */);
 /* filter passes launched per round before convergence is checked on the host (default 10, 1..32)   */

@@ -54,3 +54,44 @@ def sharded(trks, a, thrv, op, w, ov, pers, two, cuts, device_resolve):
         out.append(f); alive = na; bg = bg or z
         trks[r].free(bufs[r][0]); trks[r].free(bufs[r][1])
     return np.concatenate(out, axis=0), alive + (1 if bg else 0) - 1
+
+
+def sharded_threads(trks, a, thrv, op, w, ov, pers, two, cuts, f64=False):
+    """ctk_track_sharded_*: N handles on one GPU, one host thread per rank, in-process communicator group.  Returns the
+    concatenated flag, n_tracked (identical on all ranks, checked) and the per-rank stats."""
+    import threading
+    T, ny, nx = a.shape
+    n = len(cuts) - 1
+    group = _native.CommGroup(n)
+    comms = [_native.Comm.local(trks[r], group, r) for r in range(n)]
+    out, res, err, stats = [None] * n, [None] * n, [None] * n, [None] * n
+
+    def work(r):
+        t0, t1 = cuts[r], cuts[r + 1]
+        nb = max((t1 - t0) * ny * nx * (8 if f64 else 4), 8)
+        d_in, d_out = trks[r].malloc(nb), trks[r].malloc(max((t1 - t0) * ny * nx * 4, 8))
+        try:
+            trks[r].h2d(d_in, np.ascontiguousarray(a[t0:t1], dtype=np.float64 if f64 else np.float32))
+            res[r] = trks[r].track_sharded_dev(comms[r], d_in, t1 - t0, t0, T, ny, nx, thrv[t0:t1], op, w, ov, pers, two, d_out, f64=f64)
+            f = np.empty((t1 - t0, ny, nx), np.int32)
+            trks[r].d2h(f, d_out)
+            out[r] = f
+            stats[r] = trks[r].stats()
+        except Exception as e:                     # noqa: BLE001 -- reported by the caller
+            err[r] = e
+        finally:
+            trks[r].free(d_in); trks[r].free(d_out)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for c in comms:
+        c.close()
+    group.close()
+    for e in err:
+        if e is not None:
+            raise e
+    assert len(set(res)) == 1, res
+    return np.concatenate(out, axis=0), res[0], stats
