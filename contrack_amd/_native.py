@@ -21,9 +21,9 @@ TIMER_NAMES = ["k_threshold", "k_scan", "k_label2d", "k_overlap", "k_extent", "k
 EXPORTS = [
     "ctk_version", "ctk_last_error", "ctk_device_count", "ctk_create", "ctk_destroy", "ctk_track_f32",
     "ctk_track_f32_dev", "ctk_track_f64", "ctk_track_f64_dev", "ctk_shard_label2d", "ctk_shard_label2d_f64", "ctk_shard_halo_size", "ctk_shard_halo_export",
-    "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_shard_tables_dev", "ctk_shard_resolve_dev", "ctk_resolve", "ctk_result_free",
+    "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_resolve", "ctk_result_free",
     "ctk_result_info", "ctk_result_arrays", "ctk_result_nshards", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
-    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_np_sum", "ctk_set_timing", "ctk_get_timings", "ctk_set_device_resolve", "ctk_set_filter_round", "ctk_get_stats",
+    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_np_sum", "ctk_debug_boundary_resolve", "ctk_set_timing", "ctk_get_timings", "ctk_set_device_resolve", "ctk_set_filter_round", "ctk_get_stats",
     "ctk_dev_malloc", "ctk_dev_free", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
     "ctk_synth_fill",
     "ctk_comm_unique_id", "ctk_comm_init_rccl", "ctk_comm_group_create", "ctk_comm_group_destroy", "ctk_comm_init_local", "ctk_comm_init_shm",
@@ -68,8 +68,6 @@ def lib():
     L.ctk_shard_halo_import.argtypes = [p, p, sz]
     L.ctk_shard_overlap.argtypes = [p]
     L.ctk_shard_tables.argtypes = [p, pp, C.POINTER(sz)]
-    L.ctk_shard_tables_dev.argtypes = [p, pp, C.POINTER(sz)]
-    L.ctk_shard_resolve_dev.argtypes = [p, pp, C.POINTER(sz), i32, i32, i64, dbl, i32, pp, C.POINTER(i64)]
     L.ctk_resolve.argtypes = [pp, C.POINTER(sz), i32, dbl, i32, pp]
     L.ctk_result_free.argtypes = [p]
     L.ctk_result_free.restype = None
@@ -86,6 +84,7 @@ def lib():
     L.ctk_debug_set_mailbox.argtypes = [p, C.c_uint32, C.c_uint32]
     L.ctk_debug_np_sum.argtypes = [p, sz]
     L.ctk_debug_np_sum.restype = dbl
+    L.ctk_debug_boundary_resolve.argtypes = [i32, p, p, p, p, p, p, p, p, p]
     L.ctk_set_timing.argtypes = [p, i32]
     L.ctk_get_timings.argtypes = [p, p]
     L.ctk_set_device_resolve.argtypes = [p, i32]
@@ -466,22 +465,6 @@ class Tracker:
         p, s = C.c_void_p(), C.c_size_t(0)
         check(lib().ctk_shard_tables(self._h, C.byref(p), C.byref(s)))
         return C.string_at(p, s.value)
-
-    def shard_tables_dev(self):
-        """(device pointer, nbytes) of the shard's table blob in device memory"""
-        p, s = C.c_void_p(), C.c_size_t(0)
-        check(lib().ctk_shard_tables_dev(self._h, C.byref(p), C.byref(s)))
-        return p, int(s.value)
-
-    def shard_resolve_dev(self, blob_ptrs, blob_sizes, my_shard, t_begin, overlap, twosided):
-        """device resolver on the device blobs of all shards; returns (ext device pointer, n_labels)"""
-        n = len(blob_ptrs)
-        ptrs = (C.c_void_p * n)(*[C.c_void_p(int(x)) for x in blob_ptrs])
-        sizes = (C.c_size_t * n)(*[int(x) for x in blob_sizes])
-        ext, nl = C.c_void_p(), C.c_int64(0)
-        check(lib().ctk_shard_resolve_dev(self._h, ptrs, sizes, n, int(my_shard), int(t_begin), float(overlap), int(bool(twosided)),
-                                          C.byref(ext), C.byref(nl)))
-        return ext, int(nl.value)
 
     def shard_extents(self, result, shard, t_begin):
         p, n = C.c_void_p(), C.c_int64(0)

@@ -111,7 +111,6 @@ struct ctk_handle {
     DevBuf g_x0, g_x1, g_y, g_parent, g_root, g_idmap, g_rs;
     DevBuf pairs, seams, ext, ops, op_first, op_next, op_stage, halo_in, halo_out, dbg;
     DevBuf seam_cnt, seam_off, d_seams, d_comp_t, pair_base, pair_cnt, rv_tdirty, d_blob, seam_rowoff;
-    DevBuf g_ncomp, g_cprefix, g_mrep, g_box, g_area, g_comp_t, g_pairs, g_pair_base, g_pair_cnt, g_seams, g_seam_cnt, g_seam_off, g_counters, g_label;
     // device resolver work space
     DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lbox,
         rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff, rv_dmap, rv_dorig, rv_dbox, rv_inex, rv_touch;
@@ -311,9 +310,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->counters, &h->run_comp, &h->run_val, &h->cs_mrep, &h->cs_box, &h->cs_area, &h->d_mrep, &h->d_box, &h->d_area,
                       &h->comp_label, &h->g_x0, &h->g_x1, &h->g_y, &h->g_parent, &h->g_root, &h->g_idmap, &h->g_rs, &h->pairs, &h->seams,
                       &h->ext, &h->ops, &h->op_first, &h->op_next, &h->op_stage, &h->halo_in, &h->halo_out, &h->dbg, &h->seam_cnt, &h->seam_off, &h->d_seams,
-                      &h->d_comp_t, &h->pair_base, &h->pair_cnt, &h->rv_tdirty, &h->d_blob, &h->seam_rowoff, &h->g_ncomp, &h->g_cprefix, &h->g_mrep, &h->g_box,
-                      &h->g_area, &h->g_comp_t, &h->g_pairs, &h->g_pair_base, &h->g_pair_cnt, &h->g_seams, &h->g_seam_cnt, &h->g_seam_off, &h->g_counters,
-                      &h->g_label, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
+                      &h->d_comp_t, &h->pair_base, &h->pair_cnt, &h->rv_tdirty, &h->d_blob, &h->seam_rowoff, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
                       &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
                       &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
@@ -857,7 +854,6 @@ static int build_tables_blob(ctk_handle *h, bool to_device, const void **blob, s
 }
 
 extern "C" int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes) { return build_tables_blob(h, false, blob, nbytes); }
-extern "C" int ctk_shard_tables_dev(ctk_handle *h, const void **blob_dev, size_t *nbytes) { return build_tables_blob(h, true, blob_dev, nbytes); }
 
 // ------------------------------------------------------------------------------------------------
 // stage 3
@@ -1183,11 +1179,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         h->stats[CTK_S_OPS] = 0;
         CTKCHK(upload_ops_dense(h, ops, nullptr, 0));                         // no ops: the launch still prepares ext / counters
     }
-    if (!final_in_extent) {                                                   // (single GPU: k_extent does it, see launch_extents)
-        Timer tm(h, CTK_K_RESOLVE2);
-        k_rs_final<<<gc, 256, 0, s>>>(r, fold_args(h), 0, in.comp_label);
-        HIPCHK(hipGetLastError());
-    }
+    (void)final_in_extent;                                                    // (k_extent computes the final id of every component)
     return CTK_OK;
 }
 
@@ -1299,109 +1291,6 @@ static int device_resolve_local(ctk_handle *h, double overlap, int twosided)
     int rv = device_resolve(h, in, overlap, twosided, true, true);
     if (rv == 0) { h->total_comps = (uint32_t)h->stats[CTK_S_COMPONENTS]; h->t_begin = 0; }
     return rv;
-}
-
-// ------------------------------------------------------------------------------------------------
-// multi-GPU: device resolver on the table blobs of ALL shards (all-gathered into this GPU's memory)
-// ------------------------------------------------------------------------------------------------
-extern "C" int ctk_shard_resolve_dev(ctk_handle *h, const void *const *blobs_dev, const size_t *nbytes, int nshards, int my_shard, int64_t t_begin,
-                                     double overlap, int twosided, int32_t **ext_dev, int64_t *n_labels)
-{
-    if (!h || !blobs_dev || !nbytes || nshards < 1 || my_shard < 0 || my_shard >= nshards) return ctk_set_error(CTK_E_INVALID, "ctk_shard_resolve_dev: bad arguments");
-    if (h->state != ST_TABLES) return ctk_set_error(CTK_E_STATE, "ctk_shard_resolve_dev needs ctk_shard_tables[_dev] first");
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
-    std::vector<CtkBlobHeader> hd((size_t)nshards);
-    int64_t T = 0, NC = 0, NPG = 0, NPU = 0, NS = 0;
-    for (int k = 0; k < nshards; k++) {
-        if (nbytes[k] < sizeof(CtkBlobHeader)) return ctk_set_error(CTK_E_INVALID, "blob %d too small", k);
-        HIPCHK(hipMemcpy(&hd[(size_t)k], blobs_dev[k], sizeof(CtkBlobHeader), hipMemcpyDeviceToHost));
-        const CtkBlobHeader &q = hd[(size_t)k];
-        if (q.magic != CTK_BLOB_MAGIC || q.T < 0 || q.ncomps < 0 || q.npairs < 0 || q.nseams < 0 || q.npairs_grouped < 0 || q.npairs_grouped > q.npairs ||
-            ctk_blob_bytes(q.T, q.ncomps, q.npairs, q.nseams) > nbytes[k] || q.ny != h->ny || q.nx != h->nx || q.wshift != h->wshift || q.limb_bits != h->limb_bits)
-            return ctk_set_error(CTK_E_INVALID, "blob %d is malformed or belongs to another grid", k);
-        T += q.T; NC += q.ncomps; NPG += q.npairs_grouped; NPU += q.npairs - q.npairs_grouped; NS += q.nseams;
-    }
-    if (hd[(size_t)my_shard].T != h->T || hd[(size_t)my_shard].ncomps != (int64_t)h->total_comps) return ctk_set_error(CTK_E_INVALID, "blob %d is not this shard's", my_shard);
-    const int64_t NP = NPG + NPU;
-    if (NC > 0xfffffff0ll || NP > 0xfffffff0ll || T > 0x7ffffff0ll) return ctk_set_error(CTK_E_RANGE, "gathered tables exceed 32-bit indices");
-    CTKCHK(ensure(h, h->g_ncomp, (size_t)T * 4)); CTKCHK(ensure(h, h->g_cprefix, (size_t)(T + 1) * 4));
-    CTKCHK(ensure(h, h->g_mrep, (size_t)NC * 4)); CTKCHK(ensure(h, h->g_box, (size_t)NC * 8)); CTKCHK(ensure(h, h->g_area, (size_t)NC * 16));
-    CTKCHK(ensure(h, h->g_comp_t, (size_t)NC * 4)); CTKCHK(ensure(h, h->g_pairs, (size_t)std::max<int64_t>(NP, 1) * sizeof(CtkPair)));
-    CTKCHK(ensure(h, h->g_pair_base, (size_t)T * 4)); CTKCHK(ensure(h, h->g_pair_cnt, (size_t)T * 4));
-    CTKCHK(ensure(h, h->g_seams, (size_t)std::max<int64_t>(NS, 1) * sizeof(CtkSeam)));
-    CTKCHK(ensure(h, h->g_seam_cnt, (size_t)T * 4)); CTKCHK(ensure(h, h->g_seam_off, (size_t)(T + 1) * 4));
-    CTKCHK(ensure(h, h->g_counters, CTK_CNT_N * 4)); CTKCHK(ensure(h, h->g_label, (size_t)std::max<int64_t>(NC, 1) * 4));
-    if (T) HIPCHK(hipMemsetAsync(h->g_seam_cnt.p, 0, (size_t)T * 4, s));
-    int64_t t_off = 0, c_off = 0, pg_off = 0, pu_off = 0, s_off = 0, my_c_off = 0;
-    for (int k = 0; k < nshards; k++) {
-        const CtkBlobHeader &q = hd[(size_t)k];
-        const char *p = (const char *)blobs_dev[k] + sizeof(CtkBlobHeader);
-        const int64_t npg = q.npairs_grouped, npu = q.npairs - q.npairs_grouped;
-        if (k == my_shard) my_c_off = c_off;
-        if (q.T) HIPCHK(hipMemcpyAsync(P<uint32_t>(h->g_ncomp) + t_off, p, (size_t)q.T * 4, hipMemcpyDeviceToDevice, s));
-        p += ctk_align8((size_t)q.T * 4);
-        if (q.ncomps) HIPCHK(hipMemcpyAsync(P<uint32_t>(h->g_mrep) + c_off, p, (size_t)q.ncomps * 4, hipMemcpyDeviceToDevice, s));
-        p += ctk_align8((size_t)q.ncomps * 4);
-        if (q.ncomps) HIPCHK(hipMemcpyAsync(P<uint16_t>(h->g_box) + 4 * c_off, p, (size_t)q.ncomps * 8, hipMemcpyDeviceToDevice, s));
-        p += ctk_align8((size_t)q.ncomps * 8);
-        if (q.ncomps) HIPCHK(hipMemcpyAsync(P<int64_t>(h->g_area) + 2 * c_off, p, (size_t)q.ncomps * 16, hipMemcpyDeviceToDevice, s));
-        p += (size_t)q.ncomps * 16;
-        CtkPair *gp = P<CtkPair>(h->g_pairs);
-        if (npg) {
-            HIPCHK(hipMemcpyAsync(gp + pg_off, p, (size_t)npg * sizeof(CtkPair), hipMemcpyDeviceToDevice, s));
-            k_add_t_pairs<<<(int)((npg + 255) / 256), 256, 0, s>>>(gp + pg_off, (uint32_t)npg, (uint32_t)t_off);
-        }
-        if (npu) {                                                   // ungrouped records live at the END of the table
-            CtkPair *dst = gp + (NP - pu_off - npu);
-            HIPCHK(hipMemcpyAsync(dst, p + (size_t)npg * sizeof(CtkPair), (size_t)npu * sizeof(CtkPair), hipMemcpyDeviceToDevice, s));
-            k_add_t_pairs<<<(int)((npu + 255) / 256), 256, 0, s>>>(dst, (uint32_t)npu, (uint32_t)t_off);
-        }
-        p += (size_t)q.npairs * sizeof(CtkPair);
-        if (q.nseams) {
-            HIPCHK(hipMemcpyAsync(P<CtkSeam>(h->g_seams) + s_off, p, (size_t)q.nseams * sizeof(CtkSeam), hipMemcpyDeviceToDevice, s));
-            k_add_t_seams<<<(int)((q.nseams + 255) / 256), 256, 0, s>>>(P<CtkSeam>(h->g_seams) + s_off, (uint32_t)q.nseams, (uint32_t)t_off, P<uint32_t>(h->g_seam_cnt));
-        }
-        p += (size_t)q.nseams * sizeof(CtkSeam);
-        if (q.T) {
-            HIPCHK(hipMemcpyAsync(P<uint32_t>(h->g_pair_base) + t_off, p, (size_t)q.T * 4, hipMemcpyDeviceToDevice, s));
-            k_add_u32<<<(int)((q.T + 255) / 256), 256, 0, s>>>(P<uint32_t>(h->g_pair_base) + t_off, (uint32_t)q.T, (uint32_t)pg_off);
-            p += ctk_align8((size_t)q.T * 4);
-            HIPCHK(hipMemcpyAsync(P<uint32_t>(h->g_pair_cnt) + t_off, p, (size_t)q.T * 4, hipMemcpyDeviceToDevice, s));
-        }
-        t_off += q.T; c_off += q.ncomps; pg_off += npg; pu_off += npu; s_off += q.nseams;
-    }
-    uint32_t cnt[CTK_CNT_N];
-    memset(cnt, 0, sizeof(cnt));
-    cnt[CTK_CNT_PAIRS] = (uint32_t)NPG; cnt[CTK_CNT_UPAIRS] = (uint32_t)NPU;
-    HIPCHK(hipMemcpyAsync(h->g_counters.p, cnt, sizeof(cnt), hipMemcpyHostToDevice, s));
-    k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->g_ncomp), T, P<uint32_t>(h->g_cprefix), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
-    k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->g_seam_cnt), T, P<uint32_t>(h->g_seam_off), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
-    if (T) k_fill_comp_t<<<(int)T, 128, 0, s>>>(P<uint32_t>(h->g_ncomp), P<uint32_t>(h->g_cprefix), P<uint32_t>(h->g_comp_t));
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));                                          // `cnt` leaves scope
-    ResolveIn in;
-    in.T = T; in.R = (size_t)std::max<int64_t>(NC, 1);
-    in.ncomp = P<uint32_t>(h->g_ncomp); in.cprefix = P<uint32_t>(h->g_cprefix); in.mrep = P<uint32_t>(h->g_mrep); in.comp_t = P<uint32_t>(h->g_comp_t);
-    in.box = P<uint16_t>(h->g_box); in.area = P<int64_t>(h->g_area);
-    in.pairs = P<CtkPair>(h->g_pairs); in.pair_cap = (uint32_t)NP; in.counters = P<uint32_t>(h->g_counters);
-    in.pair_base = P<uint32_t>(h->g_pair_base); in.pair_cnt = P<uint32_t>(h->g_pair_cnt);
-    in.seams = P<CtkSeam>(h->g_seams); in.seam_cnt = P<uint32_t>(h->g_seam_cnt); in.seam_off = P<uint32_t>(h->g_seam_off);
-    in.seam_cap = NS;
-    in.comp_label = P<int32_t>(h->g_label);
-    const int64_t my_nc = h->total_comps;
-    int rv = device_resolve(h, in, overlap, twosided);
-    if (rv < 0) return rv;
-    if (rv > 0) return ctk_set_error(CTK_E_RANGE, "ctk_shard_resolve_dev: overlap filter did not converge within %d passes; use ctk_resolve on the host tables", CTK_MAX_JACOBI);
-    CTKCHK(ensure(h, h->comp_label, (size_t)std::max<int64_t>(my_nc, 1) * 4));
-    if (my_nc) HIPCHK(hipMemcpyAsync(h->comp_label.p, P<int32_t>(h->g_label) + my_c_off, (size_t)my_nc * 4, hipMemcpyDeviceToDevice, s));
-    h->total_comps = (uint32_t)my_nc;
-    h->t_begin = t_begin;
-    CTKCHK(launch_extents(h, true));
-    if (ext_dev) *ext_dev = P<int32_t>(h->ext);
-    if (n_labels) *n_labels = h->n_labels;
-    h->state = ST_EXTENTS;
-    return CTK_OK;
 }
 
 static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, bool with_fold)

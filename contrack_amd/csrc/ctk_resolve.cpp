@@ -12,6 +12,7 @@
 // belongs to (contrack.py:691-698), exact integer area sums, the (component@t, component@t-1) pixel
 // co-occurrence areas, and the rows whose two seam pixels are both set.
 #include "ctk_tables.h"
+#include "ctk_seam.h"
 #include "../../include/contrack_hip.h"
 
 #include <algorithm>
@@ -536,5 +537,34 @@ extern "C" int ctk_weights_to_limbs(const float *wrow, int ny, int64_t npix, int
     }
     *wshift = -emin;
     *limb_bits = lb;
+    return CTK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// test hook (GPU-free): the label numbering across time-shard boundaries (boundary_resolve, ctk_seam.h) on flat arrays.
+// last_flat / halo_flat: the per-rank records one after the other (nlast[q] / nh[q] entries each).
+// ---------------------------------------------------------------------------------------------
+extern "C" int ctk_debug_boundary_resolve(int world, const int32_t *nlast, const int32_t *nh, const int32_t *nroots, const int32_t *last_flat,
+                                          const int32_t *halo_flat, int64_t *off, int32_t *last_label_flat, int32_t *halo_label_flat,
+                                          int32_t *n_absorbed)
+{
+    if (world < 1 || !nlast || !nh || !nroots || !off) return ctk_set_error(CTK_E_INVALID, "ctk_debug_boundary_resolve: bad arguments");
+    std::vector<BoundaryIn> in((size_t)world);
+    size_t lo = 0, ho = 0;
+    for (int q = 0; q < world; q++) {
+        in[(size_t)q].nlast = nlast[q]; in[(size_t)q].nh = nh[q]; in[(size_t)q].nroots = nroots[q];
+        in[(size_t)q].last = last_flat + lo; in[(size_t)q].halo = halo_flat + ho;
+        lo += (size_t)nlast[q]; ho += (size_t)nh[q];
+    }
+    BoundaryOut out;
+    if (!boundary_resolve(in, out)) return ctk_set_error(CTK_E_INVALID, "ctk_debug_boundary_resolve: contradictory records");
+    memcpy(off, out.off.data(), sizeof(int64_t) * ((size_t)world + 1));
+    lo = ho = 0;
+    for (int q = 0; q < world; q++) {
+        if (last_label_flat && nlast[q]) memcpy(last_label_flat + lo, out.last_label[(size_t)q].data(), (size_t)nlast[q] * 4);
+        if (halo_label_flat && nh[q]) memcpy(halo_label_flat + ho, out.halo_label[(size_t)q].data(), (size_t)nh[q] * 4);
+        if (n_absorbed) n_absorbed[q] = (int32_t)out.absorbed[(size_t)q].size();
+        lo += (size_t)nlast[q]; ho += (size_t)nh[q];
+    }
     return CTK_OK;
 }

@@ -596,40 +596,6 @@ __global__ __launch_bounds__(64) void k_compact_cands(ResolveDev r, const CtkCan
     }
 }
 
-// R5: final id of every component.  All of a component's pixels move together through an op whose box
-// contains the component's box, none moves when the boxes are disjoint; anything else is resolved per
-// pixel in k_extent / k_relabel (comp_label = -fresh label).
-__global__ void k_rs_final(ResolveDev r, FoldArgs f, int64_t t_begin, int32_t *__restrict__ comp_label)
-{
-    const uint32_t nc = dev_ncomps(r);
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
-        const int32_t l = r.lab[g];
-        comp_label[g] = l <= 0 ? l : comp_final_label(f, l, (int32_t)(t_begin + r.comp_t[g]), r.box + 4 * (int64_t)g);
-    }
-}
-
-
-// ---- helpers for tables gathered from several shards -------------------------------------------------------
-__global__ void k_add_t_pairs(CtkPair *p, uint32_t n, uint32_t dt)
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i].t += dt;
-}
-__global__ void k_add_t_seams(CtkSeam *p, uint32_t n, uint32_t dt, uint32_t *seam_cnt /* global, zeroed */)
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { p[i].t += dt; atomicAdd(&seam_cnt[p[i].t], 1u); }
-}
-__global__ void k_add_u32(uint32_t *p, uint32_t n, uint32_t d)
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] += d;
-}
-__global__ void k_fill_comp_t(const uint32_t *__restrict__ ncomp, const uint32_t *__restrict__ cprefix, uint32_t *__restrict__ comp_t)
-{
-    const uint32_t t = blockIdx.x, n = ncomp[t], cb = cprefix[t];
-    for (uint32_t c = threadIdx.x; c < n; c += blockDim.x) comp_t[cb + c] = t;
-}
 __global__ void k_iota_mul(uint32_t *p, uint32_t n, uint32_t mul)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

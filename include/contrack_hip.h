@@ -70,7 +70,9 @@ int ctk_track_f64_dev(ctk_handle *h, const double *anom_dev, int64_t T, int ny, 
                       const double *thr, int cmp_op, const float *wrow, double overlap,
                       int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked);
 
-/* ---- staged path (time-sharded multi-GPU; each rank owns timesteps [t_begin, t_begin+T)) ------ */
+/* ---- staged path: the stages of the path one by one, with the component tables resolved on the HOST (ctk_resolve).
+ *      Kept for stage-level parity tests and as the table-level specification of the resolver; the multi-GPU product path
+ *      is ctk_track_sharded_* above.  Each shard owns timesteps [t_begin, t_begin+T). ------ */
 /* stage 1: threshold -> bit mask -> 2-D labelling with longitude wrap (contrack.py:646-698) + per
  *          component areas (contrack.py:717).  has_prev != 0 means a previous shard exists and
  *          its last timestep will be imported before stage 2.                                    */
@@ -89,15 +91,6 @@ int ctk_shard_overlap(ctk_handle *h);
 /* tables: serialised component / pair / seam tables of this shard (host memory owned by the
  *         handle, valid until the next staged call on it).                                       */
 int ctk_shard_tables(ctk_handle *h, const void **blob, size_t *nbytes);
-
-/* the same tables as one blob in DEVICE memory (for an all-gather over RCCL), owned by the handle       */
-int ctk_shard_tables_dev(ctk_handle *h, const void **blob_dev, size_t *nbytes);
-/* device resolver on the device blobs of ALL shards (time order), replicated on every rank; replaces
- * ctk_shard_tables + ctk_resolve + ctk_shard_extents: on return the per-id extents are computed (all-reduce
- * them MIN/MAX as described at ctk_shard_extents) and ctk_shard_write may follow.                          */
-int ctk_shard_resolve_dev(ctk_handle *h, const void *const *blobs_dev, const size_t *nbytes, int nshards,
-                          int my_shard, int64_t t_begin, double overlap, int twosided, int32_t **ext_dev,
-                          int64_t *n_labels);
 
 /* resolve: host-side, GPU-free.  Takes the table blobs of ALL shards in time order and evaluates the
  *          sequential parts of the reference on component tables: overlap filter recurrence
@@ -177,6 +170,11 @@ int ctk_debug_set_pair_capacity(ctk_handle *h, uint32_t records);
 /* test hook, GPU-free: numpy's float64 add.reduce order (what np.sum(weight_grid[...]) computes, contrack.py:717-719), used to
  * re-evaluate overlap decisions whose exactly accumulated area sums had to be rounded */
 double ctk_debug_np_sum(const double *a, size_t n);
+/* test hook, GPU-free: scipy's 3-D ids across time-shard boundaries from the per-rank boundary records of ctk_track_sharded_*
+ * (contrack_amd/csrc/ctk_seam.h explains the records); flat arrays, rank after rank */
+int ctk_debug_boundary_resolve(int world, const int32_t *nlast, const int32_t *nh, const int32_t *nroots, const int32_t *last_flat,
+                               const int32_t *halo_flat, int64_t *off /* [world+1] */, int32_t *last_label_flat, int32_t *halo_label_flat,
+                               int32_t *n_absorbed /* [world] */);
 /* test hook: cap the device-written mailbox of the resolver hand-off (0 = no cap), so that the explicit-copy path runs */
 int ctk_debug_set_mailbox(ctk_handle *h, uint32_t cand_records, uint32_t labels);
 

@@ -1,12 +1,14 @@
-"""The staged (time-sharded) C API driven in ONE process: N handles on one GPU play N ranks; the exchanges are plain
-device pointers and numpy reductions (no torch, no processes).  Used by tests/test_gpu_sharded_inprocess.py and
-tools/fuzz_sharded.py."""
+"""Time shards driven in ONE process, N handles on one GPU playing N ranks:
+  sharded          the staged C API (table-level protocol, host resolver); exchanges are plain device pointers / numpy
+  sharded_threads  the product path ctk_track_sharded_*: one host thread per rank, in-process communicator group
+Used by tests/test_gpu_sharded*.py and tools/fuzz_sharded.py."""
 import numpy as np
 
 from contrack_amd import _native
 
 
-def sharded(trks, a, thrv, op, w, ov, pers, two, cuts, device_resolve):
+def sharded(trks, a, thrv, op, w, ov, pers, two, cuts):
+    """the staged C API with the host resolver; returns (flag, n_tracked, resolver info)"""
     T, ny, nx = a.shape
     n = len(cuts) - 1
     bufs = []
@@ -22,21 +24,13 @@ def sharded(trks, a, thrv, op, w, ov, pers, two, cuts, device_resolve):
         trks[r + 1].halo_import(p, sz)
     for r in range(n):
         trks[r].shard_overlap()
+    host = [trks[r].shard_tables() for r in range(n)]
+    res = _native.resolve(host, ov, two)
+    info = res.info()
     exts = []
-    if device_resolve:
-        blobs = [trks[r].shard_tables_dev() for r in range(n)]
-        for r in range(n):
-            trks[r].sync()
-        for r in range(n):
-            ext, nl = trks[r].shard_resolve_dev([b[0].value for b in blobs], [b[1] for b in blobs], r, cuts[r], ov, two)
-            trks[r].sync()
-            exts.append((ext, nl))
-    else:
-        host = [trks[r].shard_tables() for r in range(n)]
-        res = _native.resolve(host, ov, two)
-        for r in range(n):
-            exts.append(trks[r].shard_extents(res, r, cuts[r]))
-            trks[r].sync()
+    for r in range(n):
+        exts.append(trks[r].shard_extents(res, r, cuts[r]))
+        trks[r].sync()
     nl = exts[0][1]
     arrs = []
     for r in range(n):
@@ -53,7 +47,7 @@ def sharded(trks, a, thrv, op, w, ov, pers, two, cuts, device_resolve):
         trks[r].d2h(f, bufs[r][1])
         out.append(f); alive = na; bg = bg or z
         trks[r].free(bufs[r][0]); trks[r].free(bufs[r][1])
-    return np.concatenate(out, axis=0), alive + (1 if bg else 0) - 1
+    return np.concatenate(out, axis=0), alive + (1 if bg else 0) - 1, info
 
 
 def sharded_threads(trks, a, thrv, op, w, ov, pers, two, cuts, f64=False):

@@ -1,6 +1,7 @@
-"""The time-sharded driver (contrack_amd/dist.py) under torch.distributed/gloo, world_size 2 and 3, on CPU:
-halo exchange, table all-gather, replicated resolve, extent all-reduce -- with the numpy shard engine
-standing in for the HIP stages.  Every rank's slice must equal the reference golden."""
+"""The table-level sharded protocol (tests/gloo_driver.py) under torch.distributed/gloo, world_size 2 and 3, on CPU:
+halo exchange, table all-gather, host resolve (ctk_resolve), extent all-reduce -- with the numpy shard engine standing in
+for the HIP stages.  Every rank's slice must equal the reference golden.  (The product's N > 1 path lives in the library:
+tests/test_gpu_sharded.py; its GPU-free parts -- boundary label resolution, rendezvous -- are tested in tests/test_shard_host.py.)"""
 import os
 import socket
 
@@ -26,13 +27,14 @@ def _worker(rank, world, port, name, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from contrack_amd import dist as cdist
+        import gloo_driver
         from cpu_engine import CpuShardEngine
         g = golden_util.load(name)
         T = g["anom"].shape[0]
         t0, t1 = cdist.shard_bounds(T, world)[rank]
         eng = CpuShardEngine(g["anom"][t0:t1], g["thr"][t0:t1], g["gorl"], g["wrow"])
-        comm = cdist.TorchComm(device=None)
-        n, info = cdist.run_sharded(eng, comm, t0, g["overlap"], g["persistence"], g["twosided"])
+        comm = gloo_driver.TorchComm(device=None)
+        n, info = gloo_driver.run_sharded(eng, comm, t0, g["overlap"], g["persistence"], g["twosided"])
         ok = bool(np.array_equal(eng.flag, g["flag"][t0:t1])) and n == len(np.unique(g["flag"])) - 1
         q.put((rank, ok, n))
     finally:

@@ -1,6 +1,7 @@
-"""bench.py's N > 1 leg end to end on ONE GPU: two ranks under torch.distributed.run, gloo instead of RCCL
-(CTK_DIST_BACKEND=gloo: RCCL refuses two ranks on one device), weak scaling = two members concatenated on the time
-axis.  The tracked count must equal the one-call result on the concatenated slab."""
+"""bench.py's N > 1 leg end to end on ONE GPU: two ranks launched by torch.distributed.run exactly as the bench contract says
+(the launcher is all that is used of torch), the shared-memory transport instead of RCCL (CTK_DIST_BACKEND=shm: RCCL refuses
+two ranks on one device), weak scaling = two members concatenated on the time axis.  The tracked count must equal the
+one-call result on the concatenated slab."""
 import json
 import os
 import subprocess
@@ -14,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_bench_two_ranks_weak_scaling():
-    env = dict(os.environ, CTK_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, CTK_DIST_BACKEND="shm", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "era5_1deg_90"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -25,6 +26,7 @@ def test_bench_two_ranks_weak_scaling():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "timesteps/s"
     assert out["config"]["total_timesteps"] == 180 and out["value"] > 0
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
+    assert out["config"]["transport"] == "shm" and out["config"]["collectives_per_step"]["allgathers"] >= 5
 
     from contrack_amd import _native, synth
     from contrack_amd.contrack import row_weights

@@ -327,51 +327,34 @@ def test_size_independent_properties(trk):
 
 
 # ------------------------------------------------------------------------------------------------
-# time-sharded HIP stages: several processes share GPU 0, exchange through gloo (RCCL refuses two ranks
-# on one device; on the 8-GPU node the same driver runs with backend nccl and device-resident buffers)
+# the product's time-sharded path with one PROCESS per rank: several processes share GPU 0 and talk through the shared-memory
+# transport (RCCL refuses two ranks on one device; on a multi-GPU node the same entry runs over RCCL -- contrack_amd/dist.py)
 # ------------------------------------------------------------------------------------------------
-def _shard_worker(rank, world, port, name, q, device_resolve=True):
+def _shard_worker(rank, world, key, name, q):
     import os
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_PORT=str(key), CTK_LAUNCH_PID=str(key),
+                      CTK_DIST_BACKEND="shm")
+    from contrack_amd import dist as cdist
+    g = golden_util.load(name)
+    T = g["anom"].shape[0]
+    t0, t1 = cdist.shard_bounds(T, world)[rank]
+    st = cdist.ShardedTracker()
     try:
-        from contrack_amd import dist as cdist
-        g = golden_util.load(name)
-        T, ny, nx = g["anom"].shape
-        t0, t1 = cdist.shard_bounds(T, world)[rank]
-        trk = _native.Tracker(0)
-        a = np.ascontiguousarray(g["anom"][t0:t1])
-        d_in, d_out = trk.malloc(max(a.nbytes, 8)), trk.malloc(max(a.nbytes, 8))
-        trk.h2d(d_in, a)
-        comm = cdist.TorchComm(device=None)
-        eng = cdist.HipShardEngine(trk, comm, d_in, t1 - t0, ny, nx, g["thr"][t0:t1], _native.CMP_OPS[g["gorl"]], g["wrow"], d_out)
-        n, info = cdist.run_sharded(eng, comm, t0, g["overlap"], g["persistence"], g["twosided"], device_resolve=device_resolve)
-        flag = np.empty((t1 - t0, ny, nx), dtype=np.int32)
-        if flag.size:
-            trk.d2h(flag, d_out)
+        flag, n = st.track(g["anom"][t0:t1], t0, T, g["thr"][t0:t1], _native.CMP_OPS[g["gorl"]], g["wrow"], g["overlap"], g["persistence"], g["twosided"])
         ok = bool(np.array_equal(flag, g["flag"][t0:t1])) and n == len(np.unique(g["flag"])) - 1
         q.put((rank, ok, n))
-        trk.free(d_in)
-        trk.free(d_out)
-        trk.close()
     finally:
-        dist.destroy_process_group()
+        st.close()
 
 
-@pytest.mark.parametrize("device_resolve", [True, False], ids=["devres", "hostres"])
-@pytest.mark.parametrize("name,world", [("syn2deg_s0", 2), ("chain_a", 3), ("busy_s1", 4), ("noise", 2), ("T3", 4), ("syn1deg", 3)])
-def test_time_sharded_hip_stages(name, world, device_resolve):
-    import socket
-    import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+@pytest.mark.parametrize("name,world", [("syn2deg_s0", 2), ("chain_a", 3), ("busy_s1", 4), ("noise", 2), ("T3", 3), ("syn1deg", 3), ("f64pole_blocky", 2)])
+def test_time_sharded_processes_shm_transport(name, world):
+    import multiprocessing as mp
+    import os
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, name, q, device_resolve)) for r in range(world)]
+    key = 40000 + os.getpid() % 20000
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, key, name, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]

@@ -1,0 +1,155 @@
+"""The product's time-sharded path -- ctk_track_sharded_* (contrack_amd/csrc/ctk_sharded.hip) -- on ONE GPU: N handles play N
+ranks, one host thread each, joined by an in-process communicator group (ctk_comm_init_local).  Everything but the transport
+is what runs with RCCL on N GPUs: halo exchange, boundary-coupled overlap filter, scipy ids across shard boundaries, shared /
+local seam merges, extent exchange, exact ties on rounded area sums.  Bit-exact against the reference goldens, the oracle and
+the one-call result -- no case is skipped."""
+import numpy as np
+import pytest
+
+import golden_util
+from contrack_amd import _native, synth
+from shard_inproc import sharded_threads
+from test_gpu_parity import _edge_case, _random_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def handles():
+    hs = [_native.Tracker(0) for _ in range(7)]
+    yield hs
+    for h in hs:
+        h.close()
+
+
+def _cuts(T, n):
+    c = sorted(set(int(round(T * k / n)) for k in range(n + 1)))
+    return c if len(c) == n + 1 else None
+
+
+@pytest.mark.parametrize("name", golden_util.case_names())
+def test_sharded_matches_reference_golden(handles, name):
+    """every golden (the reference's own outputs), split into 2, 3 and 5 time shards -- incl. f64pole_blocky*: exact ties on
+    components with pole-row pixels of a float64-latitude grid, resolved with numpy-order sums inside the sharded path"""
+    g = golden_util.load(name)
+    T = g["anom"].shape[0]
+    op = _native.CMP_OPS[g["gorl"]]
+    want_n = len(np.unique(g["flag"])) - 1
+    for n in (2, 3, 5):
+        cuts = _cuts(T, n)
+        if cuts is None:
+            continue
+        f, nt, st = sharded_threads(handles[:n], g["anom"], g["thr"], op, g["wrow"], g["overlap"], g["persistence"], g["twosided"], cuts)
+        assert np.array_equal(f, g["flag"]) and nt == want_n, (name, cuts)
+        if name == "f64pole_blocky":
+            assert sum(s["exact_fixups"] for s in st) > 0
+
+
+@pytest.mark.parametrize("i", range(48))
+def test_random_shard_boundaries(handles, oracle_lib, i):
+    """random fields / parameters, random cuts (one-step shards included) against the one-call result and the oracle"""
+    a, thr, gorl, ov, pers, two = _random_case(i) if i % 3 else _edge_case(i)
+    T, ny, nx = a.shape
+    if T < 2:
+        pytest.skip("single step: nothing to shard")
+    rng = np.random.default_rng(7000 + i)
+    n = int(rng.integers(2, min(6, T) + 1))
+    cuts = [0] + [int(v) for v in np.sort(rng.choice(np.arange(1, T), size=n - 1, replace=False))] + [T]
+    lat = np.linspace(90, -90, ny).astype(np.float32)
+    w = oracle_lib.row_weights(lat, np.float32(180.0 / max(ny - 1, 1)), np.float32(360.0 / nx))
+    thrv = oracle_lib.prepare_thresholds(thr, T)
+    op = _native.CMP_OPS[gorl]
+    want, nw = handles[6].track(a, thrv, op, w, ov, pers, two)
+    got, ng, _ = sharded_threads(handles[:n], a, thrv, op, w, ov, pers, two, cuts)
+    assert np.array_equal(got, want) and ng == nw, cuts
+    if i % 4 == 0:
+        ow, on = oracle_lib.run_contrack(a, thrv, gorl, w, ov, pers, two)
+        assert np.array_equal(got, ow) and ng == on
+
+
+def test_sharded_025deg_grid(handles, oracle_lib):
+    """BASELINE configs[3] grid (721 x 1440), three shards, one of a single step, persistence 3 -- against the oracle"""
+    T, ny, nx = 14, 721, 1440
+    a = synth.smooth_field(T, ny, nx, seed=31)
+    lat = np.linspace(90, -90, ny).astype(np.float32)
+    w = oracle_lib.row_weights(lat, np.float32(0.25), np.float32(0.25))
+    thr = oracle_lib.prepare_thresholds(160.0, T)
+    want, nw = oracle_lib.run_contrack(a, thr, ">=", w, 0.5, 3, True)
+    got, ng, _ = sharded_threads(handles[:3], a, thr, 0, w, 0.5, 3, True, [0, 6, 7, T])
+    assert np.array_equal(got, want) and ng == nw and nw > 3
+
+
+def test_sharded_cesm_grid_irregular_f64_latitudes(handles, oracle_lib):
+    """BASELINE configs[4] grid (192 x 288): float64 Gaussian-like latitudes (the reference needs set_up(force=True); dlat =
+    round(mean spacing, 2), contrack.py:357-370), four shards incl. a one-step shard, concatenated 'members'"""
+    T, ny, nx = 36, 192, 288
+    a = np.concatenate([synth.smooth_field(T // 2, ny, nx, seed=s) for s in (41, 42)], axis=0)      # two members on the time axis
+    k = np.arange(ny)
+    lat = (90.0 - 180.0 * (k + 0.5) / ny + 0.3 * np.sin(np.pi * k / (ny - 1))).astype(np.float64)
+    dlat = np.float64(round(float(np.abs(np.diff(lat)).mean()), 2))
+    w = oracle_lib.row_weights(lat, dlat, np.float64(360.0 / nx))
+    thr = oracle_lib.prepare_thresholds(150.0, T)
+    want, nw = oracle_lib.run_contrack(a, thr, ">=", w, 0.5, 3, True)
+    got, ng, _ = sharded_threads(handles[:4], a, thr, 0, w, 0.5, 3, True, [0, 11, 18, 19, T])
+    assert np.array_equal(got, want) and ng == nw and nw > 3
+
+
+def test_sharded_float64_slab(handles):
+    g = golden_util.load("thr_vector")
+    a64 = g["anom"].astype(np.float64)
+    op = _native.CMP_OPS[g["gorl"]]
+    want, nw = handles[6].track(a64, g["thr"], op, g["wrow"], g["overlap"], g["persistence"], g["twosided"], f64=True)
+    got, ng, _ = sharded_threads(handles[:3], a64, g["thr"], op, g["wrow"], g["overlap"], g["persistence"], g["twosided"], [0, 13, 27, 40], f64=True)
+    assert np.array_equal(got, want) and ng == nw
+
+
+def test_long_slab_many_seam_operations(handles):
+    """thousands of seam operations, op chains across shard boundaries: eight shards of a 2707-step slab (2 deg grid)"""
+    from contrack_amd.contrack import row_weights
+    T, ny, nx = 2707, 91, 180
+    anom = synth.smooth_field(T, ny, nx, seed=11)
+    lat, _ = synth.grid(ny, nx)
+    wrow = row_weights(lat, np.float32(2.0), np.float32(2.0))
+    thr = np.full(T, 120.0)
+    want, nw = handles[6].track(anom, thr, 0, wrow, 0.5, 3, True)
+    assert handles[6].stats()["seam_ops"] > 300
+    cuts = [0, 300, 301, 900, 1500, 2000, 2706, T]
+    got, ng, st = sharded_threads(handles[:7], anom, thr, 0, wrow, 0.5, 3, True, cuts)
+    assert np.array_equal(got, want) and ng == nw
+    assert st[0]["shared_seam_rows"] < st[0]["seam_rows_to_driver"] + sum(s["seam_rows_to_driver"] for s in st)      # most groups stay local
+
+
+def test_rccl_world_of_one(oracle_lib):
+    """the RCCL transport itself (librccl.so dlopen'ed, ncclCommInitRank, ncclAllGather) with one rank: what a one-GPU box can run"""
+    g = golden_util.load("busy_s0")
+    T, ny, nx = g["anom"].shape
+    with _native.Tracker(0) as t:
+        comm = _native.Comm.rccl(t, _native.comm_unique_id(), 0, 1)
+        try:
+            d_in, d_out = t.malloc(g["anom"].nbytes), t.malloc(g["anom"].nbytes)
+            t.h2d(d_in, g["anom"])
+            n = t.track_sharded_dev(comm, d_in, T, 0, T, ny, nx, g["thr"], _native.CMP_OPS[g["gorl"]], g["wrow"], g["overlap"], g["persistence"], g["twosided"], d_out)
+            f = np.empty((T, ny, nx), np.int32)
+            t.d2h(f, d_out)
+            comm.barrier()
+            assert comm.allgather(np.array([3.5])).tolist() == [[3.5]]
+            assert np.array_equal(f, g["flag"]) and n == len(np.unique(g["flag"])) - 1
+            t.free(d_in); t.free(d_out)
+        finally:
+            comm.close()
+
+
+def test_bad_shard_arguments(handles):
+    g = golden_util.load("T3")
+    group = _native.CommGroup(1)
+    comm = _native.Comm.local(handles[0], group, 0)
+    d = handles[0].malloc(g["anom"].nbytes)
+    try:
+        with pytest.raises(ValueError):          # the only rank must own the whole time axis
+            handles[0].track_sharded_dev(comm, d, 2, 0, 3, 31, 60, g["thr"][:2], 0, g["wrow"], 0.5, 2, True, d)
+        with pytest.raises(ValueError):          # a rank without a timestep
+            handles[0].track_sharded_dev(comm, d, 0, 0, 0, 31, 60, g["thr"][:0], 0, g["wrow"], 0.5, 2, True, d)
+    finally:
+        handles[0].free(d)
+        comm.close()
+        group.close()

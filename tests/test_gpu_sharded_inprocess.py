@@ -1,5 +1,8 @@
-"""Time-sharded stages of the C API with random shard boundaries (shards of a single step included), device and host
-resolver, against the one-call result -- all in one process (tests/shard_inproc.py)."""
+"""The STAGED C API (ctk_shard_label2d -> halo -> ctk_shard_overlap -> ctk_shard_tables -> ctk_resolve on the host ->
+ctk_shard_extents -> ctk_shard_write) with random shard boundaries, driven in one process (tests/shard_inproc.py): the
+table-level protocol that ctk_resolve specifies.  The product's multi-GPU path is ctk_track_sharded_* (tests/test_gpu_sharded.py);
+the table-only host resolver cannot see pixels, so decisions on rounded area sums within rounding distance of the threshold
+are REPORTED by it (n_ambiguous) -- the sharded product path resolves them."""
 import numpy as np
 import pytest
 
@@ -19,7 +22,7 @@ def handles():
 
 
 @pytest.mark.parametrize("i", range(48))
-def test_random_shard_boundaries(handles, oracle_lib, i):
+def test_random_shard_boundaries_staged_api(handles, oracle_lib, i):
     a, thr, gorl, ov, pers, two = _random_case(i) if i % 3 else _edge_case(i)
     T, ny, nx = a.shape
     if T < 2:
@@ -33,8 +36,11 @@ def test_random_shard_boundaries(handles, oracle_lib, i):
     op = _native.CMP_OPS[gorl]
     ref = handles[6]
     want, nw = ref.track(a, thrv, op, w, ov, pers, two)
-    if ref.stats()["exact_fixups"]:
-        pytest.skip("exact ties on pole-touching components: re-evaluated on one GPU only (DESIGN.md, exact areas)")
-    for dev in (True, False):
-        got, ng = sharded(handles[:n], a, thrv, op, w, ov, pers, two, cuts, dev)
-        assert np.array_equal(got, want) and ng == nw, (cuts, dev)
+    ties = ref.stats()["exact_fixups"] > 0
+    got, ng, info = sharded(handles[:n], a, thrv, op, w, ov, pers, two, cuts)
+    if ties:
+        # decisions on rounded sums near the threshold: the table-level resolver reports the ones whose sums it had to round
+        # (the product paths re-evaluate them); it may still come out equal
+        assert info["n_ambiguous"] > 0 or (np.array_equal(got, want) and ng == nw)
+    else:
+        assert np.array_equal(got, want) and ng == nw, cuts

@@ -1,5 +1,5 @@
-"""The staged (time-sharded) C API driven in ONE process: N handles on one GPU play N ranks, the exchanges are plain
-device pointers / numpy reductions.  Random cases, random shard boundaries (shards of one step included), device and
+"""Time shards driven in ONE process: N handles on one GPU play N ranks.  Random cases, random shard boundaries (shards of
+one step included): the product path ctk_track_sharded_* (threads + in-process communicator) and the staged API with the
 host resolver, compared with the single-call result.  python tools/fuzz_sharded.py [first] [count]"""
 import ctypes as C
 import importlib.util
@@ -18,7 +18,7 @@ m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
 first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 100)
 
 
-from shard_inproc import sharded  # noqa: E402
+from shard_inproc import sharded, sharded_threads  # noqa: E402
 
 bad = []
 trks = [_native.Tracker(0) for _ in range(6)]
@@ -38,11 +38,13 @@ for i in range(first, first + count):
     op = _native.CMP_OPS[gorl]
     want, nw = ref.track(a, thrv, op, w, ov, pers, two)
     fixups = ref.stats()["exact_fixups"]
-    for dev in (True, False):
-        try:
-            got, ng = sharded(trks, a, thrv, op, w, ov, pers, two, cuts, dev)
-        except Exception as e:                                    # noqa: BLE001
-            bad.append((i, cuts, dev, "EXC " + str(e)[:80])); continue
+    try:
+        got, ng, _ = sharded_threads(trks[:n], a, thrv, op, w, ov, pers, two, cuts)
+        if not (np.array_equal(got, want) and ng == nw):
+            bad.append((i, a.shape, cuts, "product", ov))
+        got, ng, info = sharded(trks[:n], a, thrv, op, w, ov, pers, two, cuts)
         if not (np.array_equal(got, want) and ng == nw) and not fixups:
-            bad.append((i, a.shape, cuts, "dev" if dev else "host", ov))
+            bad.append((i, a.shape, cuts, "staged", ov))
+    except Exception as e:                                    # noqa: BLE001
+        bad.append((i, cuts, "EXC " + str(e)[:80]))
 print("sharded fuzz %d..%d: problems %d %s" % (first, first + count - 1, len(bad), bad[:6]))
