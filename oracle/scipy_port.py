@@ -21,15 +21,6 @@ _COMPARE = {">=": np.greater_equal, "ge": np.greater_equal, "<=": np.less_equal,
             ">": np.greater, "gt": np.greater, "<": np.less, "lt": np.less}
 
 
-def _seam_rows(lab):
-    """yield (t, y) in scan order for rows whose first and last pixel are both labelled"""
-    first, last = lab[:, :, 0], lab[:, :, -1]
-    for t in range(lab.shape[0]):
-        for y in range(lab.shape[1]):
-            if first[t, y] > 0 and last[t, y] > 0:
-                yield t, y
-
-
 def run_contrack(anom, threshold, gorl, wrow, overlap, persistence, twosided=True):
     with np.errstate(divide="ignore", invalid="ignore"):
         return _run(anom, threshold, gorl, wrow, overlap, persistence, twosided)
@@ -41,45 +32,56 @@ def _run(anom, threshold, gorl, wrow, overlap, persistence, twosided):
     T, ny, nx = anom.shape
     binary = np.where(_COMPARE[gorl](anom, threshold), 1, 0)                    # int64, contrack.py:665
     lab, _ = ndimage.label(binary, structure=_PLANE)                            # contrack.py:684
+    # The loops below evaluate what the reference evaluates, as often as it does (the same scalar look-ups per seam row,
+    # the same three mask expressions per contour, two relabel statements per seam row): the wall time is meant to be the
+    # reference's, not that of a tidied-up version.
     for t in range(T):                                                          # contrack.py:691-698
-        plane = lab[t]
         for y in range(ny):
-            a, b = plane[y, 0], plane[y, -1]
-            if a > 0 and b > 0 and a != b:
-                plane[plane == max(a, b)] = min(a, b)
+            if lab[t, y, 0] > 0 and lab[t, y, -1] > 0 and (lab[t, y, 0] > lab[t, y, -1]):
+                lab[t][lab[t] == lab[t, y, 0]] = lab[t, y, -1]
+            if lab[t, y, 0] > 0 and lab[t, y, -1] > 0 and (lab[t, y, 0] < lab[t, y, -1]):
+                lab[t][lab[t] == lab[t, y, -1]] = lab[t, y, 0]
     wgrid = np.ones((ny, nx)) * np.asarray(wrow, dtype=np.float32)[:, None]     # contrack.py:704
     for t in range(1, T - 1):                                                   # contrack.py:706-742
-        cur, nxt, prv = lab[t], lab[t + 1], lab[t - 1]
-        for slot, box in enumerate(ndimage.find_objects(cur)):
+        ident = 0
+        for box in ndimage.find_objects(lab[t]):
+            ident = ident + 1
             if box is None:
                 continue
-            ident = slot + 1
-            inside = cur[box] == ident
-            wbox = wgrid[box]
-            area = np.sum(wbox[inside])
-            fwd = np.sum(wbox[inside & (nxt[box] >= 1)])
-            bwd = np.sum(wbox[inside & (prv[box] >= 1)])
+            area = np.sum(wgrid[box][lab[t][box] == ident])
+            fwd = np.sum(wgrid[box][(lab[t][box] == ident) & (lab[t + 1][box] >= 1)])
+            bwd = np.sum(wgrid[box][(lab[t][box] == ident) & (lab[t - 1][box] >= 1)])
             fb = (1 / area) * bwd
             ff = (1 / area) * fwd
             if twosided:
-                drop = ((fb != 0 and ff != 0 and (fb < overlap or ff < overlap)) or
-                        (fb != 0 and ff == 0 and fb < overlap) or
-                        (fb == 0 and ff != 0 and ff < overlap))
+                if fb != 0 and ff != 0:
+                    if (fb < overlap) or (ff < overlap):
+                        lab[t][box][(lab[t][box] == ident)] = 0.
+                if fb != 0 and ff == 0:
+                    if fb < overlap:
+                        lab[t][box][(lab[t][box] == ident)] = 0.
+                if fb == 0 and ff != 0:
+                    if ff < overlap:
+                        lab[t][box][(lab[t][box] == ident)] = 0.
             else:
-                drop = ff < overlap
-            if drop:
-                cur[box][inside] = 0
+                if ff < overlap:
+                    lab[t][box][(lab[t][box] == ident)] = 0.
     binary = np.where(lab >= 1, 1, 0)                                           # contrack.py:747
     lab, _ = ndimage.label(binary, structure=_TRACK)                            # contrack.py:748
     boxes = ndimage.find_objects(lab)                                           # contrack.py:753 (once)
-    for t, y in _seam_rows(lab):                                                # contrack.py:754-763
-        a, b = lab[t, y, 0], lab[t, y, -1]
-        if a > 0 and b > 0 and a != b:
-            hi, lo = max(a, b), min(a, b)
-            region = lab[boxes[hi - 1]]
-            region[region == hi] = lo
-    for slot, box in enumerate(ndimage.find_objects(lab)):                      # contrack.py:765-772
-        if box is not None and (box[0].stop - box[0].start) < persistence:
-            region = lab[box]
-            region[region == slot + 1] = 0
+    for t in range(T):                                                          # contrack.py:754-763
+        for y in range(ny):
+            if lab[t, y, 0] > 0 and lab[t, y, -1] > 0 and (lab[t, y, 0] > lab[t, y, -1]):
+                box = boxes[lab[t, y, 0] - 1]
+                lab[box][(lab[box] == lab[t, y, 0])] = lab[t, y, -1]
+            if lab[t, y, 0] > 0 and lab[t, y, -1] > 0 and (lab[t, y, 0] < lab[t, y, -1]):
+                box = boxes[lab[t, y, -1] - 1]
+                lab[box][(lab[box] == lab[t, y, -1])] = lab[t, y, 0]
+    ident = 0
+    for box in ndimage.find_objects(lab):                                       # contrack.py:765-772
+        ident = ident + 1
+        if box is None:
+            continue
+        if (box[0].stop - box[0].start) < persistence:
+            lab[box][(lab[box] == ident)] = 0.
     return lab, len(np.unique(lab)) - 1                                         # contrack.py:793
