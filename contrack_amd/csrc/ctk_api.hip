@@ -116,6 +116,7 @@ struct ctk_handle {
         rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff, rv_dmap, rv_dorig, rv_dbox, rv_inex, rv_touch;
     // run_lifecycle reductions
     DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w;
+    DevBuf chunk_vals;                             // run values in the chunk order of k_relabel_v4
     DevBuf io_in, io_out;                          // device copies of host-array calls (ctk_track_f32 / _f64)
     // time-sharded path (ctk_sharded.hip)
     DevBuf sh_mask_next, sh_send, sh_recv, sh_prev, sh_elist, sh_ovr_slot, sh_ovr_val, sh_amb_list, sh_counts;
@@ -315,7 +316,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
                       &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
                       &h->sh_mask_next, &h->sh_send, &h->sh_recv, &h->sh_prev, &h->sh_elist, &h->sh_ovr_slot, &h->sh_ovr_val,
-                      &h->sh_amb_list, &h->sh_counts};
+                      &h->sh_amb_list, &h->sh_counts, &h->chunk_vals};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -1293,7 +1294,38 @@ static int device_resolve_local(ctk_handle *h, double overlap, int twosided)
     return rv;
 }
 
-static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, bool with_fold)
+// rows per workgroup of k_relabel_v4, measured on MI355X (ms):
+//   2707 x 181 x 360:    990 int4 stores per workgroup (11 rows) 0.147 | 720: 0.159 | 1440: 0.168 | 540: 0.182
+//   480 x 721 x 1440:    720 (2 rows) 0.337 | 2880 (8 rows) 0.343 | 2160: 0.359 | 1440: 0.366
+//   14600 x 721 x 1440:  2880 (8 rows, 1.3 M workgroups) 10.9 | 5760: 11.6 | 1440 (2.6 M): 14.0 | 720 (5.3 M): 17.1
+// -> at most 1024 stores (four per thread) while that keeps the grid below a million workgroups, else at most 3072.
+static int relabel_rows(const ctk_handle *h)
+{
+    const int n4r = std::max(1, h->nx / 4);
+    int rb = std::min(h->ny, std::max(1, std::min(64, 1024 / n4r)));
+    if (h->T * ((h->ny + rb - 1) / rb) > 1000000) rb = std::min(h->ny, std::max(rb, std::min(64, 3072 / n4r)));
+    while (rb < h->ny && h->T * ((h->ny + rb - 1) / rb) >= (1 << 24)) rb++;
+    if (getenv("CTK_RELABEL_ROWS")) rb = std::min(h->ny, std::max(1, atoi(getenv("CTK_RELABEL_ROWS"))));
+    return rb;
+}
+static bool relabel_fast_ok(const ctk_handle *h, const int32_t *flag_dev, int rb)
+{
+    const int64_t npl = (int64_t)h->ny * h->nx, nblk4 = h->T * ((h->ny + rb - 1) / rb);
+    const size_t lds = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) + (size_t)2048 * 4;
+    return (h->nx % 4 == 0) && (((uintptr_t)flag_dev & 15) == 0) && npl < 0x7fffffff && nblk4 < (1 << 24) && h->T > 0 && lds <= 60 * 1024;
+}
+// the chunk-ordered copy of the run values (k_run_values -> k_relabel_v4) is built when the fast relabel path will run
+static int32_t *chunk_vals_for(ctk_handle *h, const int32_t *flag_dev, int *rows)
+{
+    const int rb = relabel_rows(h);
+    *rows = rb;
+    const int64_t nchunk = (h->ny + rb - 1) / rb;
+    if (!relabel_fast_ok(h, flag_dev, rb) || nchunk > CTK_CV_MAXCHUNK) return nullptr;
+    if (ensure(h, h->chunk_vals, (size_t)h->T * (size_t)nchunk * CTK_CV * 4) != CTK_OK) return nullptr;
+    return P<int32_t>(h->chunk_vals);
+}
+
+static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, bool with_fold, const int32_t *chunk_vals = nullptr)
 {
     RelabelArgs a;
     a.mask = P<uint64_t>(h->mask); a.wstart = P<uint16_t>(h->wstart); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
@@ -1302,16 +1334,9 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
     if (with_fold) a.fold = fold_args(h); else { a.fold.ops = nullptr; a.fold.first = nullptr; a.fold.next = nullptr; a.fold.nops = 0; }
     a.flag = flag_dev; a.counters = P<uint32_t>(h->counters);
     a.nrows = h->T * h->ny; a.ny = h->ny; a.nx = h->nx; a.W = h->W;
+    a.chunk_vals = chunk_vals;
     const int64_t npl = (int64_t)h->ny * h->nx;
-    // rows per workgroup, measured on MI355X (k_relabel_v4, ms):
-    //   2707 x 181 x 360:    990 int4 stores per workgroup (11 rows) 0.147 | 720: 0.159 | 1440: 0.168 | 540: 0.182
-    //   480 x 721 x 1440:    720 (2 rows) 0.337 | 2880 (8 rows) 0.343 | 2160: 0.359 | 1440: 0.366
-    //   14600 x 721 x 1440:  2880 (8 rows, 1.3 M workgroups) 10.9 | 5760: 11.6 | 1440 (2.6 M): 14.0 | 720 (5.3 M): 17.1
-    // -> at most 1024 stores (four per thread) while that keeps the grid below a million workgroups, else at most 3072.
-    const int n4r = std::max(1, h->nx / 4);
-    int rb = std::min(h->ny, std::max(1, std::min(64, 1024 / n4r)));
-    if (h->T * ((h->ny + rb - 1) / rb) > 1000000) rb = std::min(h->ny, std::max(rb, std::min(64, 3072 / n4r)));
-    while (rb < h->ny && h->T * ((h->ny + rb - 1) / rb) >= (1 << 24)) rb++;
+    const int rb = relabel_rows(h);
     const int rvcap = 2048;
     const size_t lds = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) + (size_t)rvcap * 4;
     const int64_t nblk4 = h->T * ((h->ny + rb - 1) / rb);
@@ -1319,6 +1344,7 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
         const unsigned grid = (unsigned)nblk4;
         k_relabel_v4<<<grid, 256, lds, h->stream>>>(a, rb, rvcap);
     } else {
+        a.chunk_vals = nullptr;
         k_relabel<<<grid_for_rows(a.nrows), 256, 0, h->stream>>>(a);
     }
     HIPCHK(hipGetLastError());
@@ -1332,15 +1358,18 @@ extern "C" int ctk_shard_write(ctk_handle *h, int persistence, int32_t *flag_dev
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     if (h->T > 0) {
+        int cv_rows = 0;
+        int32_t *cv = chunk_vals_for(h, flag_dev, &cv_rows);
         {
             Timer tm(h, CTK_K_RUNLABEL);
             k_run_values<<<(int)h->T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), CPX(h), P<int32_t>(h->comp_label),
-                                                   P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->d_mrep), 0, 0, P<int32_t>(h->run_val));
+                                                   P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->d_mrep), 0, 0, P<int32_t>(h->run_val),
+                                                   P<uint32_t>(h->rowstart), h->ny, cv_rows, cv);
             HIPCHK(hipGetLastError());
         }
         {
             Timer tm(h, CTK_K_RELABEL);
-            CTKCHK(launch_relabel(h, persistence, flag_dev, true));
+            CTKCHK(launch_relabel(h, persistence, flag_dev, true, cv));
         }
     }
     {

@@ -162,16 +162,21 @@ __global__ __launch_bounds__(256) void k_threshold_v4(const float *__restrict__ 
     const int64_t row0 = (int64_t)t * ny + y0;
     const float *base = anom + row0 * (int64_t)nx;
     const int sub = tid & 15;
+    // (row, slot) of the lane's next load, advanced by 256 slots at a time without dividing
+    int nr = tid / n4p, nc = tid - nr * n4p;
+    const int dr = 256 / n4p, dc = 256 - dr * n4p;
     for (int i0 = 0; i0 < total; i0 += 256 * U) {
         f32x4 v[U];
         int rr[U], cc[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int i = i0 + u * 256 + tid;
-            const int r = i / n4p, c = i - r * n4p;
+            const int r = nr, c = nc;
             rr[u] = r; cc[u] = c;
             if (i < total && c < n4) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (int64_t)r * nx) + c);
             else v[u] = (f32x4)(__builtin_nanf(""));
+            nr += dr; nc += dc;
+            if (nc >= n4p) { nc -= n4p; nr++; }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -791,6 +796,8 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
 // ctk_resolve.cpp): only used for the rare "complex" components.
 //   first / next : per label, the chain of ops that have it as `hi`, in execution order
 // ------------------------------------------------------------------------------------------------
+#define CTK_CV 64                       // run values per chunk in the chunk-ordered copy (more runs in a chunk: staged from run_val)
+#define CTK_CV_MAXCHUNK 1024            // chunks per timestep the copy is built for
 struct FoldArgs {
     const CtkOp *ops;          // execution order
     const int32_t *first;      // [n_labels + 1] first op that has the label as `hi` (-1: none)
@@ -944,10 +951,20 @@ __global__ __launch_bounds__(256) void k_run_values(const uint32_t *__restrict__
                                                     const uint32_t *__restrict__ cprefix, const int32_t *__restrict__ comp_label,
                                                     const int32_t *__restrict__ ext, int64_t n_labels, int persistence,
                                                     const uint32_t *__restrict__ d_mrep, int64_t comp_id_base, int mode,
-                                                    int32_t *__restrict__ run_val)
+                                                    int32_t *__restrict__ run_val,
+                                                    // optional: the values again, grouped the way k_relabel_v4 consumes them -- CTK_CV slots per chunk of
+                                                    // `rows` rows, so that its workgroups can load them together with their tables (no dependent load)
+                                                    const uint32_t *__restrict__ rowstart = nullptr, int ny = 0, int rows = 0,
+                                                    int32_t *__restrict__ chunk_vals = nullptr)
 {
     const int t = (int)blockIdx.x;
     const uint32_t rb = run_base[t], n = run_base[t + 1] - rb, cb = cprefix[t];
+    __shared__ uint32_t qb[CTK_CV_MAXCHUNK + 1];                        // first run of every chunk
+    const int nchunk = chunk_vals ? (ny + rows - 1) / rows : 0;
+    if (chunk_vals) {
+        for (int q = threadIdx.x; q <= nchunk; q += blockDim.x) qb[q] = q < nchunk ? rowstart[(int64_t)t * ny + (int64_t)q * rows] : n;
+        __syncthreads();
+    }
     for (uint32_t r = threadIdx.x; r < n; r += blockDim.x) {
         uint32_t c = run_comp[rb + r];
         int32_t v;
@@ -958,6 +975,12 @@ __global__ __launch_bounds__(256) void k_run_values(const uint32_t *__restrict__
         } else if (mode == 1) v = (int32_t)(comp_id_base + cb + c + 1);
         else v = (int32_t)(comp_id_base + cb + d_mrep[cb + c] + 1);
         run_val[rb + r] = v;
+        if (chunk_vals) {
+            int lo = 0, hi = nchunk - 1;                                // last chunk whose first run is <= r
+            while (lo < hi) { const int m = (lo + hi + 1) >> 1; if (qb[m] <= r) lo = m; else hi = m - 1; }
+            const uint32_t pos = r - qb[lo];
+            if (pos < CTK_CV) chunk_vals[((int64_t)t * nchunk + lo) * CTK_CV + pos] = v;
+        }
     }
 }
 
@@ -981,6 +1004,7 @@ struct RelabelArgs {
     uint32_t *counters;
     int64_t nrows;
     int ny, nx, W;
+    const int32_t *chunk_vals;     // [T][nchunk][CTK_CV] (k_run_values) or nullptr
 };
 
 // fast path (nx % 4 == 0, 16-byte aligned flag): one workgroup per (timestep, 16 rows).  The rows' mask
@@ -1003,17 +1027,25 @@ __global__ __launch_bounds__(256) void k_relabel_v4(RelabelArgs a, int rb, int r
     const uint32_t trun = a.run_base[t + 1] - a.run_base[t];
     for (int i = tid; i < rows * W; i += 256) { mrow[i] = a.mask[row0 * W + i]; wst[i] = a.wstart[row0 * W + i]; }
     for (int i = tid; i <= rows; i += 256) rst[i] = (y0 + i < ny) ? a.rowstart[row0 + i] : trun;
+    // the chunk's run values in chunk order (k_run_values): loaded together with the tables -- one round trip, one barrier
+    if (a.chunk_vals && tid >= 256 - CTK_CV) rvs[tid - (256 - CTK_CV)] = a.chunk_vals[(int64_t)blockIdx.x * CTK_CV + (tid - (256 - CTK_CV))];
     __syncthreads();
     const uint32_t r0 = rst[0], nr = rst[rows] - r0;
     const int32_t *rvg = a.run_val + a.run_base[t] + r0;
     const bool staged = nr <= (uint32_t)rvcap;
-    if (staged) for (uint32_t i = tid; i < nr; i += 256) rvs[i] = rvg[i];
-    __syncthreads();
+    if (!(a.chunk_vals && nr <= (uint32_t)CTK_CV)) {                    // more runs than the chunk-ordered copy holds (or no copy)
+        if (staged) for (uint32_t i = tid; i < nr; i += 256) rvs[i] = rvg[i];
+        __syncthreads();
+    }
     const int n4 = nx >> 2, total = rows * n4;
     i32x4 *dst = reinterpret_cast<i32x4 *>(a.flag + row0 * (int64_t)nx);
     bool z = false;
-    for (int i = tid; i < total; i += 256) {
-        const int r = i / n4, c = i - r * n4;
+    // (row, column) of this lane's slot, advanced by 256 slots per step without dividing (integer division costs more than
+    // the rest of the loop body)
+    int r = tid / n4, c = tid - r * n4;
+    const int dr = 256 / n4, dc = 256 - dr * n4;
+    for (int i = tid; i < total; i += 256, r += dr, c += dc) {
+        if (c >= n4) { c -= n4; r++; }
         const int x = c << 2, w = x >> 6, xb = x & 63;
         const uint64_t m = mrow[r * W + w];
         const uint32_t nib = (uint32_t)(m >> xb) & 0xfu;
@@ -1040,7 +1072,7 @@ __global__ __launch_bounds__(256) void k_relabel_v4(RelabelArgs a, int rb, int r
             }
             out.x = v[0]; out.y = v[1]; out.z = v[2]; out.w = v[3];
         }
-        __builtin_nontemporal_store(out, dst + (int64_t)r * n4 + c);
+        __builtin_nontemporal_store(out, dst + i);                               // (the chunk's rows are contiguous: slot i)
         z |= (out.x == 0) | (out.y == 0) | (out.z == 0) | (out.w == 0);
     }
     if (__ballot(z) && lane_id() == 0 && a.counters[CTK_CNT_WROTE_ZERO] == 0) atomicOr(&a.counters[CTK_CNT_WROTE_ZERO], 1u);

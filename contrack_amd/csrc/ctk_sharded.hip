@@ -856,15 +856,17 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     }
 
     // ---- persistence + write ----------------------------------------------------------------------------------------
+    int cv_rows = 0;
+    int32_t *cv = chunk_vals_for(h, flag_dev, &cv_rows);
     {
         Timer tm(h, CTK_K_RUNLABEL);
         k_run_values<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), CPX(h), P<int32_t>(h->comp_label), P<int32_t>(h->ext), NL,
-                                            persistence, P<uint32_t>(h->d_mrep), 0, 0, P<int32_t>(h->run_val));
+                                            persistence, P<uint32_t>(h->d_mrep), 0, 0, P<int32_t>(h->run_val), P<uint32_t>(h->rowstart), ny, cv_rows, cv);
         HIPCHK(hipGetLastError());
     }
     {
         Timer tm(h, CTK_K_RELABEL);
-        CTKCHK(launch_relabel(h, persistence, flag_dev, true));
+        CTKCHK(launch_relabel(h, persistence, flag_dev, true, cv));
     }
     SHDBG("relabel");
     // ---- X7: counts ---------------------------------------------------------------------------------------------------
