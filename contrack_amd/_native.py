@@ -20,7 +20,7 @@ TIMER_NAMES = ["k_threshold", "k_scan", "k_label2d", "k_overlap", "k_extent", "k
 
 EXPORTS = [
     "ctk_version", "ctk_last_error", "ctk_device_count", "ctk_create", "ctk_destroy", "ctk_track_f32",
-    "ctk_track_f32_dev", "ctk_track_f64", "ctk_track_f64_dev", "ctk_shard_label2d", "ctk_shard_label2d_f64", "ctk_shard_halo_size", "ctk_shard_halo_export",
+    "ctk_track_f32_dev", "ctk_track_f64", "ctk_track_f64_dev", "ctk_release_io", "ctk_shard_label2d", "ctk_shard_label2d_f64", "ctk_shard_halo_size", "ctk_shard_halo_export",
     "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_resolve", "ctk_result_free",
     "ctk_result_info", "ctk_result_arrays", "ctk_result_nshards", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
     "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_np_sum", "ctk_debug_boundary_resolve", "ctk_set_timing", "ctk_get_timings", "ctk_set_device_resolve", "ctk_set_filter_round", "ctk_get_stats",
@@ -61,6 +61,7 @@ def lib():
     L.ctk_track_f32_dev.argtypes = track_args
     L.ctk_track_f64.argtypes = track_args
     L.ctk_track_f64_dev.argtypes = track_args
+    L.ctk_release_io.argtypes = [p]
     L.ctk_shard_label2d.argtypes = [p, p, i64, i32, i32, p, i32, p, i32]
     L.ctk_shard_label2d_f64.argtypes = [p, p, i64, i32, i32, p, i32, p, i32]
     L.ctk_shard_halo_size.argtypes = [p, C.POINTER(sz)]
@@ -336,6 +337,10 @@ class Tracker:
         check(fn(self._h, anom.ctypes.data, T, ny, nx, thr.ctypes.data, int(cmp_op), wrow.ctypes.data,
                                   float(overlap), int(persistence), int(bool(twosided)), flag.ctypes.data, C.byref(n)))
         return flag, int(n.value)
+
+    def release_io(self):
+        """free the device copies of slab / result that the host-array calls keep in the handle"""
+        check(lib().ctk_release_io(self._h))
 
     # ---- device-resident --------------------------------------------------------------------------
     def malloc(self, nbytes):

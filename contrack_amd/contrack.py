@@ -477,6 +477,8 @@ class contrack(object):
         else:
             flag, n_tracked = trk.track(np.ascontiguousarray(slab, dtype=np.float64), thr, _native.CMP_OPS[gorl], wrow, overlap,
                                         persistence, twosided, f64=True)
+        if slab.nbytes > (4 << 30):
+            trk.release_io()               # a big one-off slab: do not keep 2 x its size allocated on the GPU
         logger.info("Create new variable 'flag'...")
         inverse = np.argsort(sort)
         attrs = {'units': 'flag', 'long_name': 'contrack flag', 'standard_name': 'contrack flag',

@@ -58,13 +58,13 @@ enum State { ST_IDLE = 0, ST_LABELLED, ST_OVERLAPPED, ST_TABLES, ST_EXTENTS };
 
 #define CTK_KI_ROWCOUNT (CTK_K_COUNT + 1)
 
-// pinned bounce buffers of the host-array entries (bounce_copy)
+// pinned (CPU-cacheable) bounce buffers of the host-array entries' device -> host copy (bounce_copy)
 struct BounceLane {
     void *pin[2] = {nullptr, nullptr};
     hipStream_t st = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
-constexpr int kLanes = 4;
+constexpr int kLanes = 8;
 constexpr size_t kBounce = (size_t)8 << 20;
 
 struct BouncePool {
@@ -74,9 +74,11 @@ struct BouncePool {
     {
         if (ready) return true;
         for (int i = 0; i < kLanes; i++) {
-            for (int b = 0; b < 2; b++)
-                if (hipHostMalloc(&lane[i].pin[b], kBounce, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&lane[i].ev[b], hipEventDisableTiming) != hipSuccess) return false;
-            if (hipStreamCreateWithFlags(&lane[i].st, hipStreamNonBlocking) != hipSuccess) return false;
+            bool ok = true;
+            for (int b = 0; b < 2 && ok; b++)
+                ok = hipHostMalloc(&lane[i].pin[b], kBounce, hipHostMallocNonCoherent) == hipSuccess && hipEventCreateWithFlags(&lane[i].ev[b], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipStreamCreateWithFlags(&lane[i].st, hipStreamNonBlocking) == hipSuccess;
+            if (!ok) { destroy(); return false; }                // nothing half-built is left behind
         }
         ready = true;
         return true;
@@ -84,8 +86,13 @@ struct BouncePool {
     void destroy()
     {
         for (int i = 0; i < kLanes; i++) {
-            for (int b = 0; b < 2; b++) { if (lane[i].pin[b]) (void)hipHostFree(lane[i].pin[b]); if (lane[i].ev[b]) (void)hipEventDestroy(lane[i].ev[b]); }
+            for (int b = 0; b < 2; b++) {
+                if (lane[i].pin[b]) (void)hipHostFree(lane[i].pin[b]);
+                if (lane[i].ev[b]) (void)hipEventDestroy(lane[i].ev[b]);
+                lane[i].pin[b] = nullptr; lane[i].ev[b] = nullptr;
+            }
             if (lane[i].st) (void)hipStreamDestroy(lane[i].st);
+            lane[i].st = nullptr;
         }
         ready = false;
     }
@@ -118,6 +125,7 @@ struct ctk_handle {
     DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w;
     DevBuf chunk_vals;                             // run values in the chunk order of k_relabel_v4
     DevBuf io_in, io_out;                          // device copies of host-array calls (ctk_track_f32 / _f64)
+    BouncePool *bounce = nullptr;                  // created on first use
     // time-sharded path (ctk_sharded.hip)
     DevBuf sh_mask_next, sh_send, sh_recv, sh_prev, sh_elist, sh_ovr_slot, sh_ovr_val, sh_amb_list, sh_counts;
     struct ShardScratch *shard = nullptr;
@@ -127,7 +135,6 @@ struct ctk_handle {
     uint32_t sh_capB = 0, sh_capC = 0, sh_capD = 0;     // agreed capacities of the exchanged records (grow-only)
     std::vector<std::pair<int32_t, int32_t>> sh_pairs;
     bool halo_valid = false, halo_v2 = false;
-    BouncePool *bounce = nullptr;                  // created on first use
     std::vector<ctk_life_row> lc_host, lc_tmp;
     std::vector<std::pair<uint64_t, uint32_t>> lc_keys;
     std::vector<uint32_t> lc_cnt_host;
@@ -1445,9 +1452,16 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
 
 
 // ------------------------------------------------------------------------------------------------
-// host <-> device copies of pageable caller memory.  hipMemcpy stages such memory through one pinned buffer with one
-// CPU thread (~20 GB/s here); several threads, each with its own pinned bounce buffers and stream, keep more of the
-// link busy.  Used by the host-array entries only (ctk_track_f32 / _f64).
+// host-array entries (what the drop-in class calls): H2D, the device path, D2H.
+// Measured on the MI355X box (2 x EPYC 9575F, PCIe Gen5; tools/e2e_probe.py, 705.6 MB each way):
+//   * H2D: a plain hipMemcpy of the caller's pageable slab runs at 56 GB/s (12.6 ms) -- nothing to add.
+//   * D2H: the result usually lands in an array fresh from np.empty, i.e. in pages that do not exist yet; a plain hipMemcpy
+//     then crawls at 25 GB/s behind first-touch page faults taken by one thread (28 ms).  Eight threads, each draining its
+//     own double-buffered pinned bounce buffer with memcpy, take those faults in parallel: 14.9 ms.  The bounce buffers are
+//     hipHostMallocNonCoherent: the CPU reads the default, fine-grained pinned memory uncached (that kept the first version
+//     of this scheme at 22 GB/s in both directions whatever the number of threads).
+//   Populating the pages from helper threads while the input travels (MADV_POPULATE_WRITE) was tried and is worse: the
+//   faults contend with the page pinning of the concurrent H2D copy (H2D 12.6 -> 25-37 ms).
 // ------------------------------------------------------------------------------------------------
 namespace {
 // to_device: host -> device, else device -> host.  Lane i moves the chunks i, i + kLanes, ...
@@ -1505,25 +1519,39 @@ static int track_host_impl(ctk_handle *h, const void *anom, bool f64, int64_t T,
         CTKCHK(ensure(h, h->io_in, n * esz));
         CTKCHK(ensure(h, h->io_out, n * 4));
         a_dev = h->io_in.p; f_dev = P<int32_t>(h->io_out);
-        if (!h->bounce) h->bounce = new (std::nothrow) BouncePool();
-        if (!h->bounce || !bounce_copy(*h->bounce, h->device, a_dev, const_cast<void *>(anom), n * esz, true)) {
-            hipError_t e = hipMemcpy(a_dev, anom, n * esz, hipMemcpyHostToDevice);
-            if (e != hipSuccess) return ctk_set_error(CTK_E_NODEVICE, "H2D copy failed: %s", hipGetErrorString(e));
-        }
     }
+    const double e0 = now_ms();
+    if (n) {
+        hipError_t e = hipMemcpy(a_dev, anom, n * esz, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return ctk_set_error(CTK_E_NODEVICE, "H2D copy failed: %s", hipGetErrorString(e));
+    }
+    const double e1 = now_ms();
     int rc = track_dev_impl(h, a_dev, f64, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, f_dev, n_tracked);
+    const double e2 = now_ms();
     if (rc == CTK_OK && n) {
-        // the result usually lands in freshly allocated, never touched memory: ask for huge pages (fewer first-touch faults)
-        {
-            const uintptr_t a0 = ((uintptr_t)flag + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1), a1 = ((uintptr_t)flag + n * 4) & ~(((uintptr_t)2 << 20) - 1);
-            if (a1 > a0) (void)madvise((void *)a0, a1 - a0, MADV_HUGEPAGE);
-        }
+        // huge pages where the allocation allows, then the parallel copy; plain hipMemcpy for small results / if the lanes fail
+        const uintptr_t a0 = ((uintptr_t)flag + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1), a1 = ((uintptr_t)flag + n * 4) & ~(((uintptr_t)2 << 20) - 1);
+        if (a1 > a0) (void)madvise((void *)a0, a1 - a0, MADV_HUGEPAGE);
+        if (!h->bounce) h->bounce = new (std::nothrow) BouncePool();
         if (!h->bounce || !bounce_copy(*h->bounce, h->device, f_dev, flag, n * 4, false)) {
             hipError_t e = hipMemcpy(flag, f_dev, n * 4, hipMemcpyDeviceToHost);
             if (e != hipSuccess) rc = ctk_set_error(CTK_E_NODEVICE, "D2H copy failed: %s", hipGetErrorString(e));
         }
     }
+    const double e3 = now_ms();
+    if (getenv("CTK_HOSTTRACE")) fprintf(stderr, "e2e: H2D %.1f ms | device path %.2f ms | D2H %.1f ms\n", e1 - e0, e2 - e1, e3 - e2);
+    h->ms[CTK_T_H2D] = e1 - e0; h->ms[CTK_T_D2H] = e3 - e2; h->ms[CTK_T_TOTAL] = e3 - e0;      // (whole-call figures of the host entry)
     return rc;
+}
+
+// frees the device copies the host-array entries keep between calls (slab + result: twice the slab size) and the bounce lanes
+extern "C" int ctk_release_io(ctk_handle *h)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    for (DevBuf *b : {&h->io_in, &h->io_out}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    if (h->bounce) { h->bounce->destroy(); delete h->bounce; h->bounce = nullptr; }
+    return CTK_OK;
 }
 
 extern "C" int ctk_track_f32_dev(ctk_handle *h, const float *anom_dev, int64_t T, int ny, int nx, const double *thr, int cmp_op,
@@ -1683,11 +1711,8 @@ static int lifecycle_host_impl(ctk_handle *h, const int32_t *flag, const void *f
         CTKCHK(ensure(h, h->io_out, n * 4));                     // the flag slab (the tracker's own result buffer, if it ran here)
         CTKCHK(ensure(h, h->io_in, n * esz));
         f_dev = h->io_out.p; v_dev = h->io_in.p;
-        if (!h->bounce) h->bounce = new (std::nothrow) BouncePool();
-        if (!h->bounce || !bounce_copy(*h->bounce, h->device, f_dev, const_cast<int32_t *>(flag), n * 4, true))
-            HIPCHK(hipMemcpy(f_dev, flag, n * 4, hipMemcpyHostToDevice));
-        if (!h->bounce || !bounce_copy(*h->bounce, h->device, v_dev, const_cast<void *>(field), n * esz, true))
-            HIPCHK(hipMemcpy(v_dev, field, n * esz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(f_dev, flag, n * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(v_dev, field, n * esz, hipMemcpyHostToDevice));
     }
     return lifecycle_dev_impl(h, (const int32_t *)f_dev, v_dev, f64, T, ny, nx, wrow, nrows);
 }

@@ -61,6 +61,10 @@ int ctk_track_f32_dev(ctk_handle *h, const float *anom_dev, int64_t T, int ny, i
                       const double *thr, int cmp_op, const float *wrow, double overlap,
                       int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked);
 
+/* The host-array entries keep device copies of the slab and of the result in the handle between calls (grow-only, so that
+ * repeated calls do not reallocate).  ctk_release_io frees them (and the copy lanes): call it after a one-off large slab. */
+int ctk_release_io(ctk_handle *h);
+
 /* float64 slabs (xarray often hands float64 anomalies): the compare is evaluated in float64, exactly as
  * numpy does for a float64 array at contrack.py:665; everything downstream is identical.            */
 int ctk_track_f64(ctk_handle *h, const double *anom, int64_t T, int ny, int nx, const double *thr,
