@@ -29,6 +29,7 @@ EXPORTS = [
     "ctk_comm_unique_id", "ctk_comm_init_rccl", "ctk_comm_group_create", "ctk_comm_group_destroy", "ctk_comm_init_local", "ctk_comm_init_shm",
     "ctk_comm_destroy", "ctk_comm_rank", "ctk_comm_world", "ctk_comm_barrier", "ctk_comm_allgather_host", "ctk_comm_ops",
     "ctk_track_sharded_f32_dev", "ctk_track_sharded_f64_dev",
+    "ctk_anom_f32", "ctk_anom_f64", "ctk_resident_anom", "ctk_track_resident", "ctk_percentile_f32", "ctk_percentile_f64",
     "ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev", "ctk_lifecycle_rows",
 ]
 
@@ -102,6 +103,12 @@ def lib():
     for name in ("ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev"):
         getattr(L, name).argtypes = [p, p, p, i64, i32, i32, p, C.POINTER(i64)]
     L.ctk_lifecycle_rows.argtypes = [p, p, i64]
+    for name in ("ctk_anom_f32", "ctk_anom_f64"):
+        getattr(L, name).argtypes = [p, p, i64, i32, i32, p, i32, i32, i32, p, p, p, i32]
+    L.ctk_resident_anom.argtypes = [p, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.ctk_track_resident.argtypes = [p, p, i32, p, dbl, i32, i32, p, C.POINTER(i64)]
+    for name in ("ctk_percentile_f32", "ctk_percentile_f64"):
+        getattr(L, name).argtypes = [p, p, i64, i32, i32, i32, i32, dbl, C.POINTER(dbl)]
     L.ctk_comm_unique_id.argtypes = [p]
     L.ctk_comm_init_rccl.argtypes = [p, p, i32, i32, pp]
     L.ctk_comm_group_create.argtypes = [i32, pp]
@@ -337,6 +344,66 @@ class Tracker:
         check(fn(self._h, anom.ctypes.data, T, ny, nx, thr.ctypes.data, int(cmp_op), wrow.ctypes.data,
                                   float(overlap), int(persistence), int(bool(twosided)), flag.ctypes.data, C.byref(n)))
         return flag, int(n.value)
+
+    # ---- calc_anom / percentile threshold on the device ---------------------------------------------------------
+    def anomalies(self, x, group, ngroups, window=1, smooth=1, clim=None, want_anom=True, want_clim=False, keep_resident=False):
+        """x (T, ny, nx) float32 / float64; group: T ids in [0, ngroups).  Returns (anom or None, clim or None)."""
+        x = np.ascontiguousarray(x)
+        f64 = x.dtype != np.float32
+        if f64:
+            x = np.ascontiguousarray(x, dtype=np.float64)
+        T, ny, nx = x.shape
+        group = np.ascontiguousarray(group, dtype=np.int32)
+        if group.shape != (T,):
+            raise ValueError("group must hold one id per timestep")
+        cin = None if clim is None else np.ascontiguousarray(clim, dtype=x.dtype)
+        if cin is not None and cin.shape != (ngroups, ny, nx):
+            raise ValueError("clim must have shape (ngroups, ny, nx)")
+        anom = np.empty_like(x) if want_anom else None
+        cout = np.empty((ngroups, ny, nx), dtype=x.dtype) if want_clim else None
+        fn = lib().ctk_anom_f64 if f64 else lib().ctk_anom_f32
+        check(fn(self._h, x.ctypes.data, T, ny, nx, group.ctypes.data, int(ngroups), int(window), int(smooth),
+                 None if cin is None else cin.ctypes.data, None if anom is None else anom.ctypes.data,
+                 None if cout is None else cout.ctypes.data, int(bool(keep_resident))))
+        return anom, cout
+
+    def resident_anom(self):
+        T, ny, nx, f = C.c_int64(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().ctk_resident_anom(self._h, C.byref(T), C.byref(ny), C.byref(nx), C.byref(f)))
+        return None if T.value < 0 else (int(T.value), int(ny.value), int(nx.value), bool(f.value))
+
+    def track_resident(self, thr, cmp_op, wrow, overlap, persistence, twosided=True):
+        shape = self.resident_anom()
+        if shape is None:
+            raise ContrackHipError("no anomaly slab is resident on the device")
+        T, ny, nx, _ = shape
+        thr = np.ascontiguousarray(thr, dtype=np.float64)
+        wrow = np.ascontiguousarray(wrow, dtype=np.float32)
+        flag = np.empty((T, ny, nx), dtype=np.int32)
+        n = C.c_int64(0)
+        check(lib().ctk_track_resident(self._h, thr.ctypes.data, int(cmp_op), wrow.ctypes.data, float(overlap), int(persistence),
+                                       int(bool(twosided)), flag.ctypes.data, C.byref(n)))
+        return flag, int(n.value)
+
+    def percentile(self, x, y0, y1, q):
+        """mean over rows [y0, y1) of the per-grid-point q-quantile over time; x = None: the resident anomaly slab"""
+        out = C.c_double(0.0)
+        if x is None:
+            shape = self.resident_anom()
+            if shape is None:
+                raise ContrackHipError("no anomaly slab is resident on the device")
+            T, ny, nx, f64 = shape
+            ptr = None
+        else:
+            x = np.ascontiguousarray(x)
+            f64 = x.dtype != np.float32
+            if f64:
+                x = np.ascontiguousarray(x, dtype=np.float64)
+            T, ny, nx = x.shape
+            ptr = x.ctypes.data
+        fn = lib().ctk_percentile_f64 if f64 else lib().ctk_percentile_f32
+        check(fn(self._h, ptr, T, ny, nx, int(y0), int(y1), float(q), C.byref(out)))
+        return float(out.value)
 
     def release_io(self):
         """free the device copies of slab / result that the host-array calls keep in the handle"""

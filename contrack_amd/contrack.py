@@ -3,8 +3,9 @@
 
 Same constructor, `read`, `read_xarray`, `set_up`, `calc_clim`, `calc_anom`, `run_contrack` signatures, the
 same `ValueError` / `IOError` texts, the same INFO log lines and the same `flag` variable (dims of the input
-variable, int32 ids identical to the reference's, same attrs).  Only `run_contrack` is accelerated; the
-pre-processing methods stay thin xarray calls (they are upstream glue).
+variable, int32 ids identical to the reference's, same attrs).  `run_contrack`, `run_lifecycle`, `calc_clim` / `calc_anom`
+and the percentile threshold of the reference's README run on the GPU; `calc_anom` leaves its slab resident in HBM so that
+the following `run_contrack` does not cross PCIe on the way in.
 
 xarray is imported lazily: the class itself only needs the small part of the Dataset/DataArray API listed in
 tests/minixr.py, so it also works on any duck-typed dataset.  `track_numpy` is the array-level entry.
@@ -173,6 +174,15 @@ def lifecycle_frame(rows, lat, lon, dates, flags=None, field=None, wrow=None):
 def _xr():
     import xarray as xr
     return xr
+
+
+def _fingerprint(a):
+    """cheap identity of a host array (address, shape, dtype and a strided sample of its bytes): is the copy that calc_anom left
+    on the GPU still the array the dataset holds?  An in-place edit of a sampled element, a new array or another shape miss."""
+    a = np.asarray(a)
+    flat = a.reshape(-1) if a.flags.c_contiguous else None
+    sample = b"" if flat is None or flat.size == 0 else np.ascontiguousarray(flat[::max(1, flat.size // 2048)][:2048]).tobytes()
+    return (a.__array_interface__["data"][0], a.shape, str(a.dtype), hash(sample))
 
 
 class contrack(object):
@@ -394,32 +404,95 @@ class contrack(object):
             return None
         return self[variable].mean(dim="time")
 
+    # ---- climatology / anomaly (contrack.py:458-581) on the device: SURVEY.md section 8(f) row N2 ------------------------
+    def _group_ids(self, groupby):
+        """(ids per timestep in 0..G-1, the G group values in ascending order) for time.<groupby> (dayofyear, month, ...)"""
+        t = self.ds[self._time_name]
+        try:
+            vals = np.asarray(getattr(t.dt, groupby))
+        except (AttributeError, TypeError):
+            import pandas as pd
+            vals = np.asarray(getattr(pd.DatetimeIndex(np.asarray(t.data)), groupby))
+        uniq, ids = np.unique(vals, return_inverse=True)
+        return ids.astype(np.int32), uniq
+
+    def _slab_tll(self, variable):
+        da = self.ds[variable]
+        dims = tuple(da.dims)
+        sort = [dims.index(d) for d in (self._time_name, self._latitude_name, self._longitude_name)]
+        return np.asarray(da.data).transpose(sort), dims, sort
+
+    def _wrap(self, like, data, dims, coords=None, attrs=None):
+        """a labelled array of the same class as `like` (xarray.DataArray, or whatever duck-typed dataset is wrapped)"""
+        return type(like)(data, dims=dims, coords=coords, attrs=attrs or {})
+
     def calc_clim(self, variable, window=1, groupby='dayofyear'):
-        clim = self[variable].groupby(self._time_name + '.' + groupby).mean(self._time_name)
-        return clim.rolling(**{groupby: window}, center=True).mean().fillna(clim[-window:].mean(dim=groupby))
+        """climatological mean per `groupby` value, smoothed with a centred running mean over `window` groups; NaNs of the
+        running mean (both ends of the axis) are replaced by the mean of the last `window` groups, as the reference does"""
+        slab, dims, sort = self._slab_tll(variable)
+        ids, uniq = self._group_ids(groupby)
+        if slab.dtype.kind != "f":
+            slab = slab.astype(np.float64)
+        _, clim = _tracker().anomalies(slab, ids, len(uniq), window=window, smooth=1, want_anom=False, want_clim=True)
+        da = self.ds[variable]
+        coords = {groupby: uniq}
+        for name in (self._latitude_name, self._longitude_name):
+            coords[name] = np.asarray(self.ds[name].data)
+        return self._wrap(da, clim, (groupby, self._latitude_name, self._longitude_name), coords)
 
     def calc_anom(self, variable, window=1, smooth=1, groupby='dayofyear', clim=None):
+        """adds the variable 'anom': departure of `variable` from its climatology (calc_clim, or the one given as `clim`:
+        a labelled array over `groupby` on this grid, or the path of one), smoothed with a centred running mean over `smooth`
+        timesteps.  The slab also stays resident on the GPU: a following run_contrack(variable='anom') starts from HBM."""
         self._ensure_set_up()
+        slab, dims, sort = self._slab_tll(variable)
+        if slab.dtype.kind != "f":
+            slab = slab.astype(np.float64)
+        ids, uniq = self._group_ids(groupby)
+        clim_arr = None
         if clim is None:
             logger.info('Calculating climatological mean from {}...'.format(variable))
-            clim_mean = self.calc_clim(variable=variable, window=window, groupby=groupby)
-            clim = 'from {} with running window time steps {}'.format(variable, window)
+            clim_txt = 'from {} with running window time steps {}'.format(variable, window)
         else:
             logger.info('Reading climatological mean from {}...'.format(clim))
+            clim_txt = clim
             clim_mean = _xr().open_dataarray(clim) if isinstance(clim, str) else clim
             if groupby not in clim_mean.dims:
-                clim_mean = clim_mean.groupby(self._time_name + '.' + groupby)
-            clim_mean = clim_mean.reindex(**{self._latitude_name: self.ds[self._latitude_name],
-                                             self._longitude_name: self.ds[self._longitude_name]}, method='nearest')
-        anom = (self.ds[variable].groupby(self._time_name + '.' + groupby) - clim_mean).rolling(time=smooth, center=True).mean()
-        self.ds['anom'] = _xr().Variable(
-            self.ds[variable].dims, anom,
-            attrs={'units': self.ds[variable].attrs['units'],
-                   'long_name': self.ds[variable].attrs['long_name'] + ' Anomaly',
-                   'standard_name': self.ds[variable].attrs['long_name'] + ' anomaly',
-                   'history': ' '.join(['Calculated from {} with input attributes:', 'smoothing time steps = {},',
-                                        'climatology = {}.']).format(variable, smooth, clim)})
+                raise ValueError("the climatology must have the dimension {!r}".format(groupby))
+            if hasattr(clim_mean, "reindex"):       # regrid to this grid (nearest neighbour), as the reference does
+                clim_mean = clim_mean.reindex(**{self._latitude_name: self.ds[self._latitude_name],
+                                                 self._longitude_name: self.ds[self._longitude_name]}, method='nearest')
+            cd = tuple(clim_mean.dims)
+            carr = np.asarray(clim_mean.data).transpose([cd.index(d) for d in (groupby, self._latitude_name, self._longitude_name)])
+            cvals = np.asarray(clim_mean[groupby].data if hasattr(clim_mean[groupby], "data") else clim_mean[groupby])
+            pos = {v: i for i, v in enumerate(cvals.tolist())}
+            clim_arr = np.stack([carr[pos[v]] for v in uniq.tolist()])       # one plane per group value present in the data
+        anom, _ = _tracker().anomalies(slab, ids, len(uniq), window=window, smooth=smooth, clim=clim_arr, keep_resident=True)
+        da = self.ds[variable]
+        attrs = {'units': da.attrs['units'], 'long_name': da.attrs['long_name'] + ' Anomaly',
+                 'standard_name': da.attrs['long_name'] + ' anomaly',
+                 'history': ' '.join(['Calculated from {} with input attributes:', 'smoothing time steps = {},',
+                                      'climatology = {}.']).format(variable, smooth, clim_txt)}
+        out = anom.transpose(np.argsort(sort))
+        self.ds['anom'] = (dims, out, attrs)
+        self._anom_resident = _fingerprint(np.asarray(self.ds['anom'].data))
         logger.info('Calculating Anomaly... DONE')
+
+    def percentile_threshold(self, variable='anom', q=0.90, lat_bounds=(50, 80)):
+        """the more objective threshold of the reference's README (README.rst:150-151):
+        block[variable].sel(latitude=band).quantile([q], dim='time').mean() -- the mean over the latitude band of the
+        per-grid-point q-quantile over time.  Evaluated on the GPU (exact order statistics, numpy's linear interpolation)."""
+        self._ensure_set_up()
+        slab, dims, sort = self._slab_tll(variable)
+        lat = np.asarray(self.ds[self._latitude_name].data, dtype=np.float64)
+        rows = np.nonzero((lat >= min(lat_bounds)) & (lat <= max(lat_bounds)))[0]
+        if len(rows) == 0 or not np.array_equal(rows, np.arange(rows[0], rows[-1] + 1)):
+            raise ValueError("latitude band {} selects no contiguous rows".format(lat_bounds))
+        if slab.dtype.kind != "f":
+            slab = slab.astype(np.float64)
+        resident = variable == 'anom' and getattr(self, "_anom_resident", None) == _fingerprint(np.asarray(self.ds['anom'].data)) \
+            and _tracker().resident_anom() == (slab.shape[0], slab.shape[1], slab.shape[2], slab.dtype != np.float32)
+        return _tracker().percentile(None if resident else slab, int(rows[0]), int(rows[-1]) + 1, q)
 
     # ---- the hot path (contrack.py:583-796) -----------------------------------------------------------------
     def _dayofyear(self):
@@ -472,7 +545,13 @@ class contrack(object):
         logger.info("Apply overlap...")
         logger.info("Apply persistence...")
         trk = _tracker()
-        if slab.dtype == np.float32:
+        resident = variable == 'anom' and getattr(self, "_anom_resident", None) is not None and \
+            self._anom_resident == _fingerprint(np.asarray(da.data)) and \
+            trk.resident_anom() == (slab.shape[0], slab.shape[1], slab.shape[2], slab.dtype != np.float32)
+        if resident:
+            # calc_anom left this very slab in HBM: no host-to-device copy
+            flag, n_tracked = trk.track_resident(thr, _native.CMP_OPS[gorl], wrow, overlap, persistence, twosided)
+        elif slab.dtype == np.float32:
             flag, n_tracked = trk.track(np.ascontiguousarray(slab), thr, _native.CMP_OPS[gorl], wrow, overlap, persistence, twosided)
         else:
             flag, n_tracked = trk.track(np.ascontiguousarray(slab, dtype=np.float64), thr, _native.CMP_OPS[gorl], wrow, overlap,

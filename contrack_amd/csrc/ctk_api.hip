@@ -124,6 +124,9 @@ struct ctk_handle {
     // run_lifecycle reductions
     DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w;
     DevBuf chunk_vals;                             // run values in the chunk order of k_relabel_v4
+    // calc_anom / percentile (ctk_anom.hip): resident anomaly slab, climatology, scratch
+    DevBuf an_out, an_clim, an_raw, an_idx;
+    int64_t an_T = -1; int an_ny = 0, an_nx = 0; bool an_f64 = false;
     DevBuf io_in, io_out;                          // device copies of host-array calls (ctk_track_f32 / _f64)
     BouncePool *bounce = nullptr;                  // created on first use
     // time-sharded path (ctk_sharded.hip)
@@ -323,7 +326,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
                       &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
                       &h->sh_mask_next, &h->sh_send, &h->sh_recv, &h->sh_prev, &h->sh_elist, &h->sh_ovr_slot, &h->sh_ovr_val,
-                      &h->sh_amb_list, &h->sh_counts, &h->chunk_vals};
+                      &h->sh_amb_list, &h->sh_counts, &h->chunk_vals, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -1549,7 +1552,8 @@ extern "C" int ctk_release_io(ctk_handle *h)
 {
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->device));
-    for (DevBuf *b : {&h->io_in, &h->io_out}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    for (DevBuf *b : {&h->io_in, &h->io_out, &h->an_out, &h->an_raw}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    h->an_T = -1;
     if (h->bounce) { h->bounce->destroy(); delete h->bounce; h->bounce = nullptr; }
     return CTK_OK;
 }
@@ -1743,6 +1747,7 @@ extern "C" int ctk_lifecycle_rows(ctk_handle *h, ctk_life_row *rows, int64_t cap
 
 #include "ctk_comm.h"
 #include "ctk_sharded.hip"
+#include "ctk_anom.hip"
 
 // device-memory helpers for a ctypes host
 // ------------------------------------------------------------------------------------------------

@@ -260,6 +260,32 @@ int ctk_lifecycle_f32(ctk_handle *h, const int32_t *flag, const float *field, in
 int ctk_lifecycle_f64(ctk_handle *h, const int32_t *flag, const double *field, int64_t T, int ny, int nx, const float *wrow, int64_t *nrows);
 int ctk_lifecycle_rows(ctk_handle *h, ctk_life_row *rows, int64_t cap);
 
+/* ---- next rows N2 / N3: the producer of the slab on the device ----------------------------------------------------------
+ * ctk_anom_*: contrack.calc_clim / calc_anom (contrack/contrack.py:458-581) on a host slab x (T, ny, nx):
+ *   clim_raw[g] = mean over the timesteps t with group[t] == g, NaNs skipped           (groupby(...).mean, :483)
+ *   clim[g]     = mean of clim_raw over the centred window of `window` groups; NaN (window beyond the axis, or NaN data) ->
+ *                 mean of the last `window` groups of clim_raw                         (rolling(center=True).mean().fillna, :487-489)
+ *   anom[t]     = mean over the centred window of `smooth` timesteps of x[j] - clim[group[j]]; NaN where the window leaves the
+ *                 axis or holds a NaN                                                  (:568-570)
+ *   centred window of w around i: [i - w / 2, i + (w - 1) / 2].
+ * group: T ids in [0, ngroups) (the class maps the time coordinate's dayofyear / month ... to them).  clim_in (optional,
+ * [ngroups][ny][nx]): use this climatology instead of computing one (the `clim=` argument).  anom_out / clim_out: optional host
+ * outputs.  keep_resident != 0: the anomaly slab stays in HBM and ctk_track_resident / ctk_percentile_* (x = NULL) run on it
+ * without another host-to-device copy.  Sums in float64, results in the slab's dtype (xarray's dtype rules).  The xarray calls
+ * themselves cannot be run in the build container: checked against the numpy restatement oracle/anom_port.py (parity unpinned). */
+int ctk_anom_f32(ctk_handle *h, const float *x, int64_t T, int ny, int nx, const int32_t *group, int ngroups, int window, int smooth,
+                 const float *clim_in, float *anom_out, float *clim_out, int keep_resident);
+int ctk_anom_f64(ctk_handle *h, const double *x, int64_t T, int ny, int nx, const int32_t *group, int ngroups, int window, int smooth,
+                 const double *clim_in, double *anom_out, double *clim_out, int keep_resident);
+int ctk_resident_anom(ctk_handle *h, int64_t *T, int *ny, int *nx, int *is_f64);       /* T = -1: nothing resident */
+/* ctk_track_f32 / _f64 on the resident anomaly slab (flag: host int32 (T, ny, nx)) */
+int ctk_track_resident(ctk_handle *h, const double *thr, int cmp_op, const float *wrow, double overlap, int persistence, int twosided,
+                       int32_t *flag, int64_t *n_tracked);
+/* README.rst:150-151: anom.sel(latitude=rows y0..y1-1).quantile(q, dim='time').mean() -- per grid point the exact q-quantile over
+ * time (numpy's linear interpolation, NaNs skipped), then the mean over the band.  x = NULL: the resident anomaly slab. */
+int ctk_percentile_f32(ctk_handle *h, const float *x, int64_t T, int ny, int nx, int y0, int y1, double q, double *out);
+int ctk_percentile_f64(ctk_handle *h, const double *x, int64_t T, int ny, int nx, int y0, int y1, double q, double *out);
+
 #ifdef __cplusplus
 }
 #endif
