@@ -30,12 +30,16 @@ EXPORTS = [
     "ctk_comm_destroy", "ctk_comm_rank", "ctk_comm_world", "ctk_comm_barrier", "ctk_comm_allgather_host", "ctk_comm_ops",
     "ctk_track_sharded_f32_dev", "ctk_track_sharded_f64_dev",
     "ctk_anom_f32", "ctk_anom_f64", "ctk_resident_anom", "ctk_track_resident", "ctk_percentile_f32", "ctk_percentile_f64",
-    "ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev", "ctk_lifecycle_rows",
+    "ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev", "ctk_lifecycle_rows", "ctk_lifecycle_exact",
 ]
 
 # ctk_life_row (include/contrack_hip.h)
 LIFE_ROW = np.dtype([("t", "<i4"), ("label", "<i4"), ("shift", "<i4"), ("pad", "<i4"),
                      ("area", "<f8"), ("swv", "<f8"), ("swvy", "<f8"), ("swvx", "<f8")])
+
+
+# ctk_life_exact
+LIFE_EXACT = np.dtype([("area", "<f8"), ("swv", "<f8"), ("s", "<f8"), ("sy", "<f8"), ("sx", "<f8")])
 
 
 class ContrackHipError(RuntimeError):
@@ -103,6 +107,7 @@ def lib():
     for name in ("ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev"):
         getattr(L, name).argtypes = [p, p, p, i64, i32, i32, p, C.POINTER(i64)]
     L.ctk_lifecycle_rows.argtypes = [p, p, i64]
+    L.ctk_lifecycle_exact.argtypes = [p, p, i64, p]
     for name in ("ctk_anom_f32", "ctk_anom_f64"):
         getattr(L, name).argtypes = [p, p, i64, i32, i32, p, i32, i32, i32, p, p, p, i32]
     L.ctk_resident_anom.argtypes = [p, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
@@ -474,6 +479,13 @@ class Tracker:
         fn = lib().ctk_lifecycle_f64 if f64 else lib().ctk_lifecycle_f32
         check(fn(self._h, flag.ctypes.data, field.ctypes.data, T, ny, nx, wrow.ctypes.data, C.byref(n)))
         return self._life_rows(int(n.value))
+
+    def lifecycle_exact(self, row_idx):
+        """rows of the LAST lifecycle call (indices into its sorted rows) in the reference's own summation orders: LIFE_EXACT"""
+        idx = np.ascontiguousarray(row_idx, dtype=np.int64)
+        out = np.empty(len(idx), dtype=LIFE_EXACT)
+        check(lib().ctk_lifecycle_exact(self._h, idx.ctypes.data, len(idx), out.ctypes.data))
+        return out
 
     def lifecycle_dev(self, flag_dev, field_dev, T, ny, nx, wrow, f64=False):
         wrow = np.ascontiguousarray(wrow, dtype=np.float32)

@@ -90,32 +90,15 @@ def track_numpy(anom, wrow, threshold, gorl, overlap, persistence, twosided=True
 # the class
 # ------------------------------------------------------------------------------------------------
 
-def _lifecycle_row_on_host(plane, values, wgrid, ident):
-    """one (time step, id) evaluated exactly like contrack.py:874-892 (same numpy / scipy calls, hence the same
-    summation order): (area, intensity, com_y, com_x, shift)"""
-    from scipy import ndimage
-    member = plane == ident
-    area = np.sum(wgrid[member])                                                                        # :874
-    intensity = np.sum(wgrid[member] * values[member]) / area                                          # :875-876
-    shift = -1
-    if ident in plane[:, 0] and ident in plane[:, -1]:                                                  # :880
-        cols = np.unique(np.nonzero(member)[1])
-        shift = int(cols[np.argmax(np.diff(cols)) + 1])                                                 # :883
-        com = ndimage.center_of_mass(np.roll(values, -shift, axis=1) * wgrid, np.roll(plane, -shift, axis=1), [ident])
-    else:
-        com = ndimage.center_of_mass(values * wgrid, plane, [ident])                                    # :892
-    return area, intensity, com[0][0], com[0][1], shift
-
-
-def lifecycle_columns(rows, lat, lon, dates, flags=None, field=None, wrow=None):
+def lifecycle_columns(rows, lat, lon, dates, tracker=None):
     """ctk_life_row records -> the columns of the reference's frame (contrack.py:876-906), rows sorted by (Flag, Date):
     dict of arrays Flag, Date, Longitude, Latitude, Intensity, Size.
 
-    The device sums are float64 but in another order than scipy's (sequential, raster order).  That shows only where a
-    result sits on a rounding boundary: a centre of mass that is an integer up to rounding (contours one pixel wide or
-    high: int() then gives the cell or its neighbour) or a value at the edge of two decimals.  With the host arrays at
-    hand (flags, field (time, lat, lon) and wrow) those rows -- about 1 % in practice -- are re-evaluated with the
-    reference's own numpy / scipy calls."""
+    The device sums are float64 but in another order than the reference's (np.sum pairwise, np.bincount sequential).  That shows
+    only where a result sits on a rounding boundary: a centre of mass that is an integer up to rounding (contours one pixel wide
+    or high: int() then gives the cell or its neighbour) or a value at the edge of two decimals.  With the Tracker that produced
+    `rows` at hand those rows -- about 1 % in practice -- are re-evaluated ON THE DEVICE in the reference's own summation orders
+    (ctk_lifecycle_exact)."""
     nx, ny = len(lon), len(lat)
     if (rows["shift"] == -2).any():
         raise ValueError("attempt to get argmax of an empty sequence")                                  # np.argmax(np.diff(.)), :883
@@ -123,8 +106,7 @@ def lifecycle_columns(rows, lat, lon, dates, flags=None, field=None, wrow=None):
         intensity = rows["swv"] / rows["area"]                                                          # :876
         com_y, com_x = rows["swvy"] / rows["swv"], rows["swvx"] / rows["swv"]                           # ndimage.center_of_mass
     area = rows["area"].copy()
-    shift_in = rows["shift"].copy()
-    if flags is not None and field is not None and wrow is not None and len(rows):
+    if tracker is not None and len(rows):
         def near_int(v):
             return np.abs(v - np.rint(v)) <= 1e-9 * np.maximum(1.0, np.abs(v))
 
@@ -135,21 +117,18 @@ def lifecycle_columns(rows, lat, lon, dates, flags=None, field=None, wrow=None):
             fragile = near_int(com_y) | near_int(com_x) | near_half(intensity) | near_half(area) | ~np.isfinite(com_y) | ~np.isfinite(com_x)
         idx = np.nonzero(fragile)[0]
         if len(idx):
-            try:
-                wgrid = np.ones((ny, nx)) * np.asarray(wrow, dtype=np.float32)[:, None]                 # :848
-                intensity, com_y, com_x = intensity.copy(), com_y.copy(), com_x.copy()
-                for i in idx:
-                    t = int(rows["t"][i])
-                    a_, i_, cy_, cx_, sh_ = _lifecycle_row_on_host(np.asarray(flags[t]), np.asarray(field[t]), wgrid, rows["label"][i])
-                    area[i], intensity[i], com_y[i], com_x[i], shift_in[i] = a_, i_, cy_, cx_, sh_
-            except ImportError:                             # no scipy: keep the device values
-                pass
+            ex = tracker.lifecycle_exact(idx)
+            intensity, com_y, com_x = intensity.copy(), com_y.copy(), com_x.copy()
+            with np.errstate(divide="ignore", invalid="ignore"):
+                area[idx] = ex["area"]
+                intensity[idx] = ex["swv"] / ex["area"]
+                com_y[idx], com_x[idx] = ex["sy"] / ex["s"], ex["sx"] / ex["s"]
     if not (np.isfinite(com_y).all() and np.isfinite(com_x).all()):
         raise ValueError("cannot convert float NaN to integer")                                         # int(center_of_mass[..]), :886
     iy, ix = np.trunc(com_y).astype(np.int64), np.trunc(com_x).astype(np.int64)
     if ((iy < -ny) | (iy >= ny) | (ix < -nx) | (ix >= nx)).any():
         raise IndexError("centre of mass outside the grid")
-    shift = np.where(shift_in > 0, shift_in, 0)
+    shift = np.where(rows["shift"] > 0, rows["shift"], 0)
     ix = np.where(ix < 0, ix + nx, ix)                                                                  # Python indexing of the rolled axis
     lon_of = np.asarray(lon)[(ix + shift) % nx]                                                         # np.roll(lon, -shift)[ix], :884-887
     lat_of = np.asarray(lat)[iy]
@@ -164,9 +143,9 @@ def lifecycle_columns(rows, lat, lon, dates, flags=None, field=None, wrow=None):
     return cols if order is None else {k: v[order] for k, v in cols.items()}
 
 
-def lifecycle_frame(rows, lat, lon, dates, flags=None, field=None, wrow=None):
+def lifecycle_frame(rows, lat, lon, dates, tracker=None):
     """the same as a list of (Flag, Date, Longitude, Latitude, Intensity, Size) tuples"""
-    c = lifecycle_columns(rows, lat, lon, dates, flags, field, wrow)
+    c = lifecycle_columns(rows, lat, lon, dates, tracker)
     return [(int(f), d, int(lo), int(la), float(it), float(sz)) for f, d, lo, la, it, sz in
             zip(c["Flag"], c["Date"], c["Longitude"], c["Latitude"], c["Intensity"], c["Size"])]
 
@@ -615,7 +594,7 @@ class contrack(object):
         lon = np.asarray(self.ds[self._longitude_name].data)
         wrow = row_weights(lat, self._dlat, self._dlon)                                                 # contrack.py:847-848
         rows = _tracker().lifecycle(flags, field, wrow)
-        return pd.DataFrame(lifecycle_columns(rows, lat, lon, self._time_labels(), flags, field, wrow),
+        return pd.DataFrame(lifecycle_columns(rows, lat, lon, self._time_labels(), _tracker()),
                             columns=['Flag', 'Date', 'Longitude', 'Latitude', 'Intensity', 'Size'])
 
     # ---- utility (contrack.py:912-949) ---------------------------------------------------------------------------

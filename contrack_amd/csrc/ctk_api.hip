@@ -122,7 +122,9 @@ struct ctk_handle {
     DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lbox,
         rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff, rv_dmap, rv_dorig, rv_dbox, rv_inex, rv_touch;
     // run_lifecycle reductions
-    DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w;
+    DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w, lc_work, lc_ovf, lc_ekeys, lc_offs, lc_sw, lc_sp, lc_out;
+    const int32_t *lc_flag = nullptr; const void *lc_field = nullptr;       // slabs of the last ctk_lifecycle_* call (for the exact rows)
+    bool lc_f64 = false; int64_t lc_T = 0; int lc_ny = 0, lc_nx = 0;
     DevBuf chunk_vals;                             // run values in the chunk order of k_relabel_v4
     // calc_anom / percentile (ctk_anom.hip): resident anomaly slab, climatology, scratch
     DevBuf an_out, an_clim, an_raw, an_idx;
@@ -326,7 +328,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
                       &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
                       &h->sh_mask_next, &h->sh_send, &h->sh_recv, &h->sh_prev, &h->sh_elist, &h->sh_ovr_slot, &h->sh_ovr_val,
-                      &h->sh_amb_list, &h->sh_counts, &h->chunk_vals, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx};
+                      &h->sh_amb_list, &h->sh_counts, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -1137,6 +1139,9 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         if (it_done + ROUND > CTK_MAX_JACOBI) return 1;                       // very long removal cascade: host resolver
     }
     const int64_t NC = hs[CTK_MAIL_NC], ncand = hs[CTK_MAIL_NCAND], nlab = hs[CTK_MAIL_NLAB];
+    // ids are int32 here; scipy (and with it the reference) switches to int64 labels for slabs of 2^31 - 2 pixels and more
+    // (contrack.py:687, :751).  More ids than int32 holds must be an error, never a wrap-around.
+    if (nlab > 0x7ffffffell) return ctk_set_error(CTK_E_RANGE, "%lld ids do not fit the int32 flag variable", (long long)nlab);
     const size_t nd = hs[CTK_MAIL_ND];                                        // labels on surviving seam rows (dense ids)
     h->n_labels = nlab;
     CTKCHK(ensure(h, h->ext, (size_t)(nlab + 1) * 8));
@@ -1650,23 +1655,59 @@ static int lifecycle_dev_impl(ctk_handle *h, const int32_t *flag_dev, const void
     const int ks = std::max(1, std::min(32, 32768 / (nxw * 4)));
     size_t cap = std::max<size_t>(h->lc_rows.cap / sizeof(CtkLifeRowDev), (size_t)T * 16 + 1024);
     unsigned long long cnt[2] = {0, 0};
+    h->lc_flag = flag_dev; h->lc_field = field_dev; h->lc_f64 = f64; h->lc_T = T; h->lc_ny = ny; h->lc_nx = nx;
+    auto launch = [&](const int32_t *work, unsigned items) -> int {
+        if (f64)
+            k_lifecycle<double><<<items, LC_THREADS, (size_t)ks * nxw * 4, h->stream>>>(flag_dev, (const double *)field_dev, ny, nx, nxw, ks, P<int64_t>(h->lc_wlo),
+                                                                                        P<int64_t>(h->lc_whi), P<float>(h->lc_w), wshift, limb_bits,
+                                                                                        P<CtkLifeRowDev>(h->lc_rows), cap, P<unsigned long long>(h->lc_cnt), work,
+                                                                                        P<unsigned char>(h->lc_ovf));
+        else
+            k_lifecycle<float><<<items, LC_THREADS, (size_t)ks * nxw * 4, h->stream>>>(flag_dev, (const float *)field_dev, ny, nx, nxw, ks, P<int64_t>(h->lc_wlo),
+                                                                                       P<int64_t>(h->lc_whi), P<float>(h->lc_w), wshift, limb_bits,
+                                                                                       P<CtkLifeRowDev>(h->lc_rows), cap, P<unsigned long long>(h->lc_cnt), work,
+                                                                                       P<unsigned char>(h->lc_ovf));
+        HIPCHK(hipGetLastError());
+        return CTK_OK;
+    };
     for (int attempt = 0; attempt < 2; ++attempt) {
         CTKCHK(ensure(h, h->lc_rows, cap * sizeof(CtkLifeRowDev)));
         cap = h->lc_rows.cap / sizeof(CtkLifeRowDev);
+        CTKCHK(ensure(h, h->lc_ovf, (size_t)T));
         HIPCHK(hipMemsetAsync(h->lc_cnt.p, 0, 16, h->stream));
-        if (f64)
-            k_lifecycle<double><<<(unsigned)T, LC_THREADS, (size_t)ks * nxw * 4, h->stream>>>(flag_dev, (const double *)field_dev, ny, nx, nxw, ks, P<int64_t>(h->lc_wlo),
-                                                                                           P<int64_t>(h->lc_whi), P<float>(h->lc_w), wshift, limb_bits,
-                                                                                           P<CtkLifeRowDev>(h->lc_rows), cap, P<unsigned long long>(h->lc_cnt));
-        else
-            k_lifecycle<float><<<(unsigned)T, LC_THREADS, (size_t)ks * nxw * 4, h->stream>>>(flag_dev, (const float *)field_dev, ny, nx, nxw, ks, P<int64_t>(h->lc_wlo),
-                                                                                          P<int64_t>(h->lc_whi), P<float>(h->lc_w), wshift, limb_bits,
-                                                                                          P<CtkLifeRowDev>(h->lc_rows), cap, P<unsigned long long>(h->lc_cnt));
-        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemsetAsync(h->lc_ovf.p, 0, (size_t)T, h->stream));
+        CTKCHK(launch(nullptr, (unsigned)T));
         HIPCHK(hipMemcpyAsync(cnt, h->lc_cnt.p, 16, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        if (cnt[1] & LC_ERR_LABELS) return ctk_set_error(CTK_E_RANGE, "ctk_lifecycle: a time step holds more than %d distinct flag ids", LC_NL);
-        if (cnt[1] & LC_ERR_SEAM) return ctk_set_error(CTK_E_RANGE, "ctk_lifecycle: a time step holds more than %d flag ids that cross the longitude seam", ks);
+        // Time steps with more ids (or more seam-crossing ids) than the LDS tables hold: redone in passes that each take one
+        // residue class of the ids; classes that still do not fit are split again.
+        std::vector<int32_t> work;
+        if (cnt[1]) {
+            std::vector<unsigned char> ov((size_t)T);
+            HIPCHK(hipMemcpy(ov.data(), h->lc_ovf.p, (size_t)T, hipMemcpyDeviceToHost));
+            for (int64_t t = 0; t < T; ++t) if (ov[(size_t)t]) for (int j = 0; j < 2; ++j) { work.push_back((int32_t)t); work.push_back(2); work.push_back(j); }
+        }
+        while (!work.empty()) {
+            const size_t items = work.size() / 3;
+            if (work[1] > (1 << 24)) return ctk_set_error(CTK_E_RANGE, "ctk_lifecycle: a time step's flag ids cannot be split into passes that fit");
+            CTKCHK(ensure(h, h->lc_work, work.size() * 4));
+            CTKCHK(ensure(h, h->lc_ovf, std::max<size_t>(items, (size_t)T)));
+            HIPCHK(hipMemcpy(h->lc_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemsetAsync(h->lc_ovf.p, 0, items, h->stream));
+            unsigned long long zero = 0;
+            HIPCHK(hipMemcpyAsync(P<unsigned long long>(h->lc_cnt) + 1, &zero, 8, hipMemcpyHostToDevice, h->stream));
+            CTKCHK(launch(P<int32_t>(h->lc_work), (unsigned)items));
+            HIPCHK(hipMemcpyAsync(cnt, h->lc_cnt.p, 16, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            std::vector<int32_t> next;
+            if (cnt[1]) {
+                std::vector<unsigned char> ov(items);
+                HIPCHK(hipMemcpy(ov.data(), h->lc_ovf.p, items, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < items; ++i)
+                    if (ov[i]) for (int j = 0; j < 2; ++j) { next.push_back(work[3 * i]); next.push_back(work[3 * i + 1] * 2); next.push_back(work[3 * i + 2] + j * work[3 * i + 1]); }
+            }
+            work.swap(next);
+        }
         if (cnt[0] <= cap) break;
         if (attempt == 1) return ctk_set_error(CTK_E_INTERNAL, "ctk_lifecycle: row count changed between passes");
         cap = (size_t)cnt[0];
@@ -1737,6 +1778,49 @@ extern "C" int ctk_lifecycle_f64(ctk_handle *h, const int32_t *flag, const doubl
 {
     return lifecycle_host_impl(h, flag, field, true, T, ny, nx, wrow, nrows);
 }
+// the listed rows (indices into the sorted rows of the last ctk_lifecycle_* call) re-evaluated in the reference's own summation orders
+extern "C" int ctk_lifecycle_exact(ctk_handle *h, const int64_t *row_idx, int64_t n, ctk_life_exact *out)
+{
+    static_assert(sizeof(ctk_life_exact) == sizeof(CtkLifeExact), "row layouts must agree");
+    if (!h || n < 0 || (n > 0 && (!row_idx || !out))) return ctk_set_error(CTK_E_INVALID, "ctk_lifecycle_exact: bad arguments");
+    if (n == 0) return CTK_OK;
+    if (!h->lc_flag || !h->lc_field) return ctk_set_error(CTK_E_STATE, "ctk_lifecycle_exact needs a ctk_lifecycle_* call first");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    std::vector<CtkLifeKey> keys((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (row_idx[i] < 0 || (size_t)row_idx[i] >= h->lc_host.size()) return ctk_set_error(CTK_E_INVALID, "ctk_lifecycle_exact: row %lld out of range", (long long)row_idx[i]);
+        const ctk_life_row &r = h->lc_host[(size_t)row_idx[i]];
+        keys[(size_t)i] = CtkLifeKey{r.t, r.label, r.shift, 0};
+    }
+    CTKCHK(ensure(h, h->lc_ekeys, (size_t)n * sizeof(CtkLifeKey)));
+    CTKCHK(ensure(h, h->lc_offs, (size_t)n * 8));
+    CTKCHK(ensure(h, h->lc_out, (size_t)n * sizeof(CtkLifeExact)));
+    HIPCHK(hipMemcpy(h->lc_ekeys.p, keys.data(), (size_t)n * sizeof(CtkLifeKey), hipMemcpyHostToDevice));
+    uint32_t *d_counts = (uint32_t *)h->lc_out.p;                            // (reused below for the results)
+    k_life_count<<<(unsigned)n, 64, 0, s>>>(h->lc_flag, P<CtkLifeKey>(h->lc_ekeys), h->lc_ny, h->lc_nx, d_counts);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> counts((size_t)n);
+    HIPCHK(hipMemcpyAsync(counts.data(), d_counts, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<uint64_t> offs((size_t)n);
+    uint64_t total = 0;
+    for (int64_t i = 0; i < n; ++i) { offs[(size_t)i] = total; total += counts[(size_t)i]; }
+    CTKCHK(ensure(h, h->lc_sw, (size_t)std::max<uint64_t>(total, 1) * 8));
+    CTKCHK(ensure(h, h->lc_sp, (size_t)std::max<uint64_t>(total, 1) * 8));
+    HIPCHK(hipMemcpy(h->lc_offs.p, offs.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    if (h->lc_f64)
+        k_life_exact<double><<<(unsigned)n, 64, 0, s>>>(h->lc_flag, (const double *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),
+                                                        h->lc_ny, h->lc_nx, P<double>(h->lc_sw), P<double>(h->lc_sp), P<CtkLifeExact>(h->lc_out));
+    else
+        k_life_exact<float><<<(unsigned)n, 64, 0, s>>>(h->lc_flag, (const float *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),
+                                                       h->lc_ny, h->lc_nx, P<double>(h->lc_sw), P<double>(h->lc_sp), P<CtkLifeExact>(h->lc_out));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, h->lc_out.p, (size_t)n * sizeof(CtkLifeExact), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return CTK_OK;
+}
+
 extern "C" int ctk_lifecycle_rows(ctk_handle *h, ctk_life_row *rows, int64_t cap)
 {
     if (!h || (cap > 0 && !rows)) return ctk_set_error(CTK_E_INVALID, "null argument");

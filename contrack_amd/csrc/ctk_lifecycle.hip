@@ -50,7 +50,11 @@ template <typename VT>
 __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restrict__ flag, const VT *__restrict__ field, int ny, int nx, int nxw,
                                                           int ks, const int64_t *__restrict__ wlo, const int64_t *__restrict__ whi,
                                                           const float *__restrict__ wrow, int wshift, int limb_bits, CtkLifeRowDev *rows,
-                                                          unsigned long long cap_rows, unsigned long long *counters)
+                                                          unsigned long long cap_rows, unsigned long long *counters,
+                                                          // A time step with more ids than the LDS tables hold is redone in several passes, each
+                                                          // taking the ids of one residue class: work item i = {t, P, j} -> ids with id mod P == j.
+                                                          // work == nullptr: item = time step, all ids.  ovf[item] = 1: the item did not fit.
+                                                          const int32_t *__restrict__ work, unsigned char *__restrict__ ovf)
 {
     __shared__ int32_t hkey[LC_HASH];
     __shared__ unsigned hedge[LC_HASH / 4];      // per slot one byte: bit 0: id seen at x = 0, bit 1: at x = nx-1
@@ -65,7 +69,8 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
     extern __shared__ unsigned colbits[];        // [ks][nxw] occupied columns of the seam-crossing ids
 
     const int tid = threadIdx.x;
-    const int64_t t = blockIdx.x;
+    const int64_t t = work ? work[3 * blockIdx.x] : (int64_t)blockIdx.x;
+    const uint32_t cP = work ? (uint32_t)work[3 * blockIdx.x + 1] : 1u, cj = work ? (uint32_t)work[3 * blockIdx.x + 2] : 0u;
     const uint32_t npx = (uint32_t)ny * (uint32_t)nx;            // ny, nx <= 65535 (checked by the host)
     const int32_t *fp = flag + t * (int64_t)npx;
     const VT *vp = field + t * (int64_t)npx;
@@ -83,6 +88,10 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) l[k] = (p0 + k < npx) ? fp[p0 + k] : 0;
+        }
+        if (cP > 1u) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if ((uint32_t)l[k] % cP != cj) l[k] = 0;
         }
     };
 
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
     for (int w = tid; w < ks * nxw; w += LC_THREADS) colbits[w] = 0;
     __syncthreads();
     if (nlab > LC_NL || nseam > ks || err) {
-        if (tid == 0) atomicOr((unsigned *)&counters[1], err | (nlab > LC_NL ? LC_ERR_LABELS : 0u) | (nseam > ks ? LC_ERR_SEAM : 0u));
+        if (tid == 0) { ovf[blockIdx.x] = 1; counters[1] = 1ull; }        // (plain stores: any writer says the same)
         return;
     }
     const int n = nlab;
@@ -258,5 +267,144 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
         r.area = dev_limbs_to_double(alo[i], ahi[i], wshift, limb_bits);
         r.swv = swv[i]; r.swvy = swvy[i]; r.swvx = swvx[i];
         rows[base + i] = r;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Exact rows.  The sums above are float64 but taken in another order than the reference's: np.sum (pairwise) for the area and
+// the intensity numerator (contrack.py:874-875), and np.bincount -- strictly sequential, raster order of the ROLLED plane --
+// inside ndimage.center_of_mass (:886 / :892).  That matters only for rows on a rounding boundary (a centre of mass that is an
+// integer up to rounding, a value at the edge of two decimals): the host picks those (about 1 %) and this kernel re-evaluates
+// them in the reference's own orders.  One wave per row; every lane executes the same scalar recurrence on values broadcast from
+// the lane that holds the pixel.
+//   out[i] = {np.sum(w), np.sum(w * v), sequential sum of p, of p * y, of p * x'}   with p = v * w,  x' = (x - shift) mod nx
+// ------------------------------------------------------------------------------------------------
+struct CtkLifeExact {
+    double area, swv, s, sy, sx;
+};
+
+// numpy's pairwise float64 add.reduce over a contiguous array (ctk_np_sum / np_pairwise in ctk_resolve.cpp), without recursion
+__device__ inline double dev_np_leaf(const double *a, uint32_t n)
+{
+    if (n < 8u) {
+        double r = 0.0;
+        for (uint32_t i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    uint32_t i = 8;
+    for (; i + 8 <= n; i += 8) { r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3]; r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7]; }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+__device__ inline double dev_np_sum(const double *a, size_t n)
+{
+    double acc = 0.0;
+    for (size_t c0 = 0; c0 < n; c0 += 8192) {
+        const uint32_t cn = (uint32_t)(n - c0 < 8192 ? n - c0 : 8192);
+        // post-order walk of the halving tree: frames {offset, n, state, value of the left child}
+        uint32_t f_off[16], f_n[16], f_st[16];
+        double f_l[16];
+        int sp = 1;
+        f_off[0] = 0; f_n[0] = cn; f_st[0] = 0;
+        double val = 0.0;
+        bool have = false;
+        while (sp > 0) {
+            const int k = sp - 1;
+            if (!have) {
+                if (f_n[k] <= 128u) { val = dev_np_leaf(a + c0 + f_off[k], f_n[k]); have = true; sp--; continue; }
+                uint32_t n2 = f_n[k] / 2; n2 -= n2 % 8u;
+                f_st[k] = 1;
+                f_off[sp] = f_off[k]; f_n[sp] = n2; f_st[sp] = 0; sp++;
+                continue;
+            }
+            // a child of frame k has just finished with `val`
+            if (f_st[k] == 1) {
+                uint32_t n2 = f_n[k] / 2; n2 -= n2 % 8u;
+                f_l[k] = val; f_st[k] = 2; have = false;
+                f_off[sp] = f_off[k] + n2; f_n[sp] = f_n[k] - n2; f_st[sp] = 0; sp++;
+            } else { val = f_l[k] + val; sp--; }
+        }
+        acc += val;
+    }
+    return acc;
+}
+
+struct CtkLifeKey {
+    int32_t t, label, shift, pad;
+};
+
+// members of every listed (time step, id)
+__global__ __launch_bounds__(64) void k_life_count(const int32_t *__restrict__ flag, const CtkLifeKey *__restrict__ keys, int ny, int nx, uint32_t *__restrict__ counts)
+{
+    const CtkLifeKey k = keys[blockIdx.x];
+    const uint32_t npx = (uint32_t)ny * (uint32_t)nx;
+    const int32_t *fp = flag + (int64_t)k.t * npx;
+    uint32_t c = 0;
+    for (uint32_t p = threadIdx.x; p < npx; p += 64) c += fp[p] == k.label ? 1u : 0u;
+    c = wave_sum_u32(c);
+    if (threadIdx.x == 0) counts[blockIdx.x] = c;
+}
+
+template <typename VT>
+__global__ __launch_bounds__(64) void k_life_exact(const int32_t *__restrict__ flag, const VT *__restrict__ field, const float *__restrict__ wrow,
+                                                   const CtkLifeKey *__restrict__ keys, const uint64_t *__restrict__ offs, int ny, int nx,
+                                                   double *__restrict__ sw, double *__restrict__ sp_, CtkLifeExact *__restrict__ out)
+{
+    const CtkLifeKey k = keys[blockIdx.x];
+    const uint32_t npx = (uint32_t)ny * (uint32_t)nx;
+    const int32_t *fp = flag + (int64_t)k.t * npx;
+    const VT *vp = field + (int64_t)k.t * npx;
+    const int lane = (int)threadIdx.x;
+    double *gw = sw + offs[blockIdx.x], *gp = sp_ + offs[blockIdx.x];
+    // A: the row weights and the products of the id's pixels, raster order -> scratch (what weight_grid[mask] and
+    //    weight_grid[mask] * variable[mask] hand to np.sum, contrack.py:874-875)
+    uint32_t pos = 0;
+    for (uint32_t p0 = 0; p0 < npx; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        const bool m = p < npx && fp[p] == k.label;
+        const uint64_t bal = __ballot(m);
+        if (!bal) continue;
+        if (m) {
+            const int y = (int)(p / (uint32_t)nx);
+            const double w = (double)wrow[y];
+            const uint32_t at = pos + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            gw[at] = w;
+            gp[at] = w * (double)vp[p];
+        }
+        pos += (uint32_t)__popcll(bal);
+    }
+    // B: ndimage.center_of_mass = np.bincount: strictly sequential over the (rolled) plane in raster order
+    const int shift = k.shift > 0 ? k.shift : 0;
+    double s = 0.0, sy = 0.0, sx = 0.0;
+    for (int y = 0; y < ny; y++) {
+        const double w = (double)wrow[y];
+        for (int x0 = 0; x0 < nx; x0 += 64) {
+            const int xr = x0 + lane;                                  // column in the rolled frame
+            int x = xr + shift;
+            if (x >= nx) x -= nx;
+            const bool m = xr < nx && fp[(uint32_t)y * (uint32_t)nx + (uint32_t)x] == k.label;
+            uint64_t bal = __ballot(m);
+            if (!bal) continue;
+            const double pv = m ? (double)vp[(uint32_t)y * (uint32_t)nx + (uint32_t)x] * w : 0.0;      // variable * weight_grid (:886 / :892)
+            while (bal) {
+                const int b = __builtin_ctzll(bal);
+                bal &= bal - 1;
+                const double q = __shfl(pv, b);
+                s += q;
+                sy += q * (double)y;
+                sx += q * (double)(x0 + b);
+            }
+        }
+    }
+    __threadfence();
+    if (lane == 0) {
+        CtkLifeExact r;
+        r.area = dev_np_sum(gw, pos);
+        r.swv = dev_np_sum(gp, pos);
+        r.s = s; r.sy = sy; r.sx = sx;
+        out[blockIdx.x] = r;
     }
 }

@@ -249,7 +249,8 @@ int ctk_synth_fill(ctk_handle *h, float *anom_dev, int64_t T, int ny, int nx, ui
  * The host finishes with  intensity = swv / area,  com = (swvy / swv, swvx / swv),  int() and the coordinate
  * look-ups (contrack.py:886-895).  ctk_lifecycle_* computes and keeps the rows in the handle (sorted by
  * (label, t) like the reference's frame, contrack.py:906) and returns their number; ctk_lifecycle_rows copies
- * them out.  wrow: float32 row weights, contrack.py:847-848.  Limits: 512 ids per time step. */
+ * them out.  wrow: float32 row weights, contrack.py:847-848.  A time step with more ids than the kernel's LDS tables hold
+ * (512, or 32 that cross the seam) is processed in several passes over residue classes of the ids: no limit. */
 typedef struct ctk_life_row {
     int32_t t, label, shift, pad;
     double area, swv, swvy, swvx;
@@ -259,6 +260,16 @@ int ctk_lifecycle_f64_dev(ctk_handle *h, const int32_t *flag_dev, const double *
 int ctk_lifecycle_f32(ctk_handle *h, const int32_t *flag, const float *field, int64_t T, int ny, int nx, const float *wrow, int64_t *nrows);
 int ctk_lifecycle_f64(ctk_handle *h, const int32_t *flag, const double *field, int64_t T, int ny, int nx, const float *wrow, int64_t *nrows);
 int ctk_lifecycle_rows(ctk_handle *h, ctk_life_row *rows, int64_t cap);
+/* The sums above are float64 but not in the reference's summation order; that shows only where a result sits on a rounding
+ * boundary (a centre of mass that is an integer up to rounding, a value at the edge of two decimals).  The caller picks those rows
+ * (indices into the sorted rows) and gets them in the reference's own orders: np.sum (pairwise) for weight_grid[mask] and
+ * weight_grid[mask] * variable[mask] (contrack.py:874-875), np.bincount (sequential, raster order of the rolled plane) inside
+ * ndimage.center_of_mass (:886 / :892).  Valid until the next ctk_lifecycle_* call on the handle; for the *_dev entries the
+ * caller's device slabs must still be alive. */
+typedef struct ctk_life_exact {
+    double area, swv, s, sy, sx;       /* np.sum(w), np.sum(w * v), sum p, sum p * y, sum p * x'   (p = v * w) */
+} ctk_life_exact;
+int ctk_lifecycle_exact(ctk_handle *h, const int64_t *row_idx, int64_t n, ctk_life_exact *out);
 
 /* ---- next rows N2 / N3: the producer of the slab on the device ----------------------------------------------------------
  * ctk_anom_*: contrack.calc_clim / calc_anom (contrack/contrack.py:458-581) on a host slab x (T, ny, nx):

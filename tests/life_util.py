@@ -81,3 +81,23 @@ def random_life_case(i):
     wrow = row_weights(lat, 180.0 / (ny - 1), 360.0 / nx)
     dates = ["%02d" % t for t in range(T)]
     return flag, field, lat, lon, wrow, dates
+
+
+def numpy_exact_rows(flags, field, wrow, rows):
+    """what ctk_lifecycle_exact returns for `rows`, evaluated with the reference's own calls: np.sum for the area and the
+    intensity numerator (contrack.py:874-875), np.bincount (what ndimage.center_of_mass sums with, :886 / :892) on the rolled plane"""
+    from contrack_amd._native import LIFE_EXACT
+    T, ny, nx = flags.shape
+    wgrid = np.ones((ny, nx)) * np.asarray(wrow, dtype=np.float32)[:, None]
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    out = np.zeros(len(rows), dtype=LIFE_EXACT)
+    for i, r in enumerate(rows):
+        plane, values = flags[r["t"]], field[r["t"]]
+        m = plane == r["label"]
+        sh = int(r["shift"]) if r["shift"] > 0 else 0
+        pr, vr = np.roll(plane, -sh, axis=1), np.roll(values, -sh, axis=1)
+        inp = vr * wgrid
+        sel = (pr == r["label"]).ravel().astype(np.intp)
+        out[i] = (np.sum(wgrid[m]), np.sum(wgrid[m] * values[m]), np.bincount(sel, weights=inp.ravel())[1],
+                  np.bincount(sel, weights=(inp * yy.astype(float)).ravel())[1], np.bincount(sel, weights=(inp * xx.astype(float)).ravel())[1])
+    return out

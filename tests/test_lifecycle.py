@@ -161,8 +161,14 @@ def test_hip_lifecycle_random_frames(tracker, i):
     the scipy port's in every column, digit for digit"""
     flag, field, lat, lon, wrow, dates = life_util.random_life_case(i)
     rows = tracker.lifecycle(flag, field, wrow)
-    got = lifecycle_frame(rows, lat, lon, dates, flag, field, wrow)
+    got = lifecycle_frame(rows, lat, lon, dates, tracker)
     assert got == lifecycle_port.run_lifecycle(flag, field, lat, lon, wrow, dates)
+    # ... and with EVERY row re-evaluated in the reference's summation orders on the device: the sums themselves are the
+    # reference's, bit for bit (np.sum pairwise for area / intensity, np.bincount sequential for the centre of mass)
+    ex = tracker.lifecycle_exact(np.arange(len(rows)))
+    want = life_util.numpy_exact_rows(flag, field, wrow, rows)
+    for k in ("area", "swv", "s", "sy", "sx"):
+        assert np.array_equal(ex[k], want[k]), k
 
 
 @pytest.mark.gpu
@@ -170,10 +176,18 @@ def test_hip_lifecycle_limits(tracker):
     ny, nx = 40, 64
     wrow = row_weights(np.linspace(60, 21, ny, dtype=np.float32), 1.0, 1.0)
     flag = np.zeros((1, ny, nx), dtype=np.int32)
-    flag[0, ::2, ::2] = np.arange(1, 20 * 32 + 1).reshape(20, 32)          # 640 ids in one time step
-    with pytest.raises(ValueError, match="distinct flag ids"):
-        tracker.lifecycle(flag, np.ones(flag.shape, np.float32), wrow)
-    flag[0, ::2, ::2] = np.arange(1, 20 * 32 + 1).reshape(20, 32) % 500 + 1 # 500 ids: fits
+    flag[0, ::2, ::2] = np.arange(1, 20 * 32 + 1).reshape(20, 32)          # 640 ids in one time step: more than the LDS tables hold,
+    rows = tracker.lifecycle(flag, np.ones(flag.shape, np.float32), wrow)   # processed in passes over residue classes of the ids
+    want = life_util.numpy_rows(flag, np.ones(flag.shape, np.float32), wrow)
+    assert len(rows) == 640 and np.array_equal(rows["label"], want["label"]) and np.array_equal(rows["area"], want["area"])
+    big = np.zeros((2, ny, nx), dtype=np.int32)
+    big[1] = np.arange(1, ny * nx + 1).reshape(ny, nx)                      # 2560 ids, every one its own pixel; 40 of them touch both seam columns? no: one column each
+    big[1, :, -1] = big[1, :, 0]                                            # ... now 40 ids cross the seam (more than the 32 column bit sets)
+    rows = tracker.lifecycle(big, np.ones(big.shape, np.float32), wrow)
+    want = life_util.numpy_rows(big, np.ones(big.shape, np.float32), wrow)
+    assert len(rows) == len(want) and np.array_equal(rows["label"], want["label"]) and np.array_equal(rows["shift"], want["shift"])
+    assert np.array_equal(rows["area"], want["area"]) and np.allclose(rows["swvx"], want["swvx"], rtol=1e-12)
+    flag[0, ::2, ::2] = np.arange(1, 20 * 32 + 1).reshape(20, 32) % 500 + 1 # 500 ids: fits in one pass
     rows = tracker.lifecycle(flag, np.ones(flag.shape, np.float32), wrow)
     assert len(rows) == 500
     want = life_util.numpy_rows(flag, np.ones(flag.shape, np.float32), wrow)

@@ -16,7 +16,7 @@ with _native.Tracker(0) as trk:
         T, ny, nx = flag.shape
         want = lifecycle_port.run_lifecycle(flag, field, lat, lon, wrow, dates)
         rows = trk.lifecycle(flag, field, wrow)
-        got = lifecycle_frame(rows, lat, lon, dates, flag, field, wrow)
+        got = lifecycle_frame(rows, lat, lon, dates, trk)
         ok = len(got) == len(want) and all(a == b
                                           for a, b in zip(got, want))
         if not ok:
