@@ -545,10 +545,13 @@ class contrack(object):
                      variable, gorl, threshold, overlap, persistence, twosided),
                  'reference': 'https://github.com/steidani/ConTrack'}
         self.ds['flag'] = (dims, flag.transpose(inverse), attrs)
-        if _tracker().stats().get("ambiguous_decisions", 0):
-            # components touching a pole row have area sums that must be rounded; numpy rounds them in another order
-            logger.warning("an overlap decision lies within rounding distance of overlap = {}: ids may differ from the "
-                           "scipy path's for components that touch a pole row (see DESIGN.md, exact areas)".format(overlap))
+        st = _tracker().stats()
+        if st.get("off_fused_path_reason", 0):
+            # not an error: the result is the same, the call was slower (exact areas / host resolver)
+            why = {1: "the co-occurrence table had to be regrown (host resolver)", 2: "a removal cascade longer than 240 steps (host resolver)",
+                   3: "table regrowth and a long removal cascade (host resolver)",
+                   4: "{} overlap decisions on rounding boundaries were re-evaluated with numpy-order sums".format(st.get("exact_fixups", 0))}
+            logger.info("run_contrack left the fused device path: " + why.get(st["off_fused_path_reason"], "host resolver"))
         logger.info("Running contrack... DONE\n{} contours tracked".format(n_tracked))
 
     # ---- life cycle (contrack.py:798-906), consumer of `flag` ----------------------------

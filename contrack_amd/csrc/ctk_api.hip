@@ -5,6 +5,7 @@
 #include "ctk_resolve_dev.hip"
 #include "ctk_lifecycle.hip"
 #include "ctk_seam.h"
+#include "ctk_comm.h"
 #include "../../include/contrack_hip.h"
 
 #include <chrono>
@@ -1131,12 +1132,14 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         HIPCHK(hipStreamSynchronize(s));
         HT("sync2 done");
         memcpy(hs, mail.scal, sizeof(hs));
-        if ((hs[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) || (uint64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS] > in.pair_cap)
+        if ((hs[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) || (uint64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS] > in.pair_cap) {
+            h->stats[CTK_S_HOST_REASON] |= 1;
             return 1;                                                         // the host path regrows the pair table
+        }
         int conv = -1;
         for (int k = 0; k < ROUND; k++) if (hs[CTK_MAIL_CHANGED + k] == 0) { conv = it_done - ROUND + k; break; }
         if (conv >= 0) { h->stats[CTK_S_FILTER_PASSES] = conv + 1; h->stats[CTK_S_FILTER_ROUNDS] = it_done / ROUND; break; }
-        if (it_done + ROUND > CTK_MAX_JACOBI) return 1;                       // very long removal cascade: host resolver
+        if (it_done + ROUND > CTK_MAX_JACOBI) { h->stats[CTK_S_HOST_REASON] |= 2; return 1; }      // very long removal cascade: host resolver
     }
     const int64_t NC = hs[CTK_MAIL_NC], ncand = hs[CTK_MAIL_NCAND], nlab = hs[CTK_MAIL_NLAB];
     // ids are int32 here; scipy (and with it the reference) switches to int64 labels for slabs of 2^31 - 2 pixels and more
@@ -1418,6 +1421,11 @@ extern "C" int ctk_shard_count_tracked(ctk_handle *h, int64_t *n_alive)
 // ------------------------------------------------------------------------------------------------
 // whole path, one GPU
 // ------------------------------------------------------------------------------------------------
+struct ctk_comm;
+static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, bool f64, int64_t T, int64_t t_begin, int64_t T_total, int ny, int nx,
+                              const double *thr, int cmp_op, const float *wrow, double overlap, int persistence, int twosided, int32_t *flag_dev,
+                              int64_t *n_tracked);                                                      // ctk_sharded.hip
+
 static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t T, int ny, int nx, const double *thr, int cmp_op,
                           const float *wrow, double overlap, int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked)
 {
@@ -1430,6 +1438,18 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
     HT("overlap launched");
     int rv = h->use_device_resolve ? device_resolve_local(h, overlap, twosided) : 1;
     if (rv < 0) return rv;
+    if (rv == 1 && h->use_device_resolve && h->stats[CTK_S_AMBIGUOUS] && !(h->stats[CTK_S_HOST_REASON] & 3)) {
+        // Decisions on rounded area sums within rounding distance of the threshold (exact ties on components with pole-row
+        // pixels): the time-shard path re-evaluates exactly those on the device with numpy-order sums (its "exact fix-up").
+        // A shard that is the whole slab, a communicator of one rank: no exchange happens, the result is the one-call result.
+        h->stats[CTK_S_HOST_REASON] = 4;
+        ctk_comm self;
+        self.rank = 0; self.world = 1; self.kind = 0; self.device = h->device; self.stream = h->stream;
+        const int rc = track_sharded_impl(h, &self, anom_dev, f64, T, 0, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev, n_tracked);
+        h->stats[CTK_S_HOST_REASON] = 4;
+        h->ms[CTK_T_TOTAL] = now_ms() - t0;
+        return rc;
+    }
     if (rv == 0) {
         CTKCHK(launch_extents(h, true, true));                  // + the final id of every component (k_rs_final's work)
         h->state = ST_EXTENTS;
@@ -1829,7 +1849,6 @@ extern "C" int ctk_lifecycle_rows(ctk_handle *h, ctk_life_row *rows, int64_t cap
     return CTK_OK;
 }
 
-#include "ctk_comm.h"
 #include "ctk_sharded.hip"
 #include "ctk_anom.hip"
 

@@ -601,7 +601,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     const uint32_t hint_c = mail2[CTK_SHM_HINT_C], hint_d = mail2[CTK_SHM_HINT_D];
     SHDBG("X3");
     h->stats[CTK_S_FILTER_PASSES] = it_done; h->stats[CTK_S_FILTER_ROUNDS] = rounds;
-    h->stats[CTK_S_AMBIGUOUS] = mail2[CTK_SHM_AMBIG];
+    h->stats[CTK_S_AMBIGUOUS] = 0;                    // (decisions on rounding boundaries are resolved here: CTK_S_EXACT_FIXUPS)
     if (nc_sum > 0x7ffffff0ull) return ctk_set_error(CTK_E_RANGE, "ctk_track_sharded: more than 2^31 components over all shards");
 
     // ---- X4: 3-D labelling -------------------------------------------------------------------------------------------

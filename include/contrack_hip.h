@@ -219,6 +219,9 @@ int ctk_set_timing(ctk_handle *h, int level);
                                    whose weight is ~2^-20 of the others) and came out within 8 ulp of the threshold; numpy's pairwise
                                    float64 summation may land on the other side there (only with exact ties: blocky test fields,
                                    overlap = 1.0).  Device path: 0/1 flag; host resolver: the number of such decisions. */
+#define CTK_S_HOST_REASON   18  /* why a one-call track left the fused device path: bit 0 the co-occurrence table had to be regrown, bit 1
+                                   the overlap filter needed more than 240 passes (both: host resolver, CTK_S_HOST_PATH = 1); 4 = decisions
+                                   on rounding boundaries, re-evaluated on the device through the time-shard path with one rank */
 #define CTK_S_SHARED_ROWS   17  /* time-sharded path: seam candidate groups shared between shards (driven on every rank)        */
 #define CTK_NSTATS          24
 int ctk_get_stats(ctk_handle *h, int64_t *out /* [CTK_NSTATS] */);
