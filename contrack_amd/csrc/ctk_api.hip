@@ -123,7 +123,7 @@ struct ctk_handle {
     DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lbox,
         rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff, rv_dmap, rv_dorig, rv_dbox, rv_inex, rv_touch;
     // run_lifecycle reductions
-    DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w, lc_work, lc_ovf, lc_ekeys, lc_offs, lc_sw, lc_sp, lc_out;
+    DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w, lc_work, lc_ovf, lc_ekeys, lc_offs, lc_sw, lc_sp, lc_out, lc_cross, lc_gtab, lc_occ, lc_cp;
     const int32_t *lc_flag = nullptr; const void *lc_field = nullptr;       // slabs of the last ctk_lifecycle_* call (for the exact rows)
     bool lc_f64 = false; int64_t lc_T = 0; int lc_ny = 0, lc_nx = 0;
     DevBuf chunk_vals;                             // run values in the chunk order of k_relabel_v4
@@ -329,7 +329,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
                       &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
                       &h->sh_mask_next, &h->sh_send, &h->sh_recv, &h->sh_prev, &h->sh_elist, &h->sh_ovr_slot, &h->sh_ovr_val,
-                      &h->sh_amb_list, &h->sh_counts, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx};
+                      &h->sh_amb_list, &h->sh_counts, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -1690,22 +1690,47 @@ static int lifecycle_dev_impl(ctk_handle *h, const int32_t *flag_dev, const void
         HIPCHK(hipGetLastError());
         return CTK_OK;
     };
+    // Banded form first (every byte read once, T x chunks workgroups); the time steps it gives up (more ids than its tables
+    // hold) are redone by k_lifecycle, which splits further by residue classes of the ids.
+    const int nsx = (nx + LB_SW - 1) / LB_SW, nby = (ny + LB_R * (LB_THREADS / 64) - 1) / (LB_R * (LB_THREADS / 64)), nb = nsx * nby;
+    const size_t gkey_bytes = (size_t)T * LB_GH * 4, gacc_bytes = (size_t)T * LB_GH * sizeof(CtkLifeAcc);
+    const size_t occ_bytes = (size_t)T * LB_KS * nxw * 4, cp_bytes = (size_t)T * LB_KS * nx * 8;
+    if ((uint64_t)T * (uint64_t)nb > 0x7fffffffull) return ctk_set_error(CTK_E_RANGE, "ctk_lifecycle: %lld time steps x %d chunks beyond one launch", (long long)T, nb);
+    CTKCHK(ensure(h, h->lc_cross, (size_t)T * (LB_KS + 1) * 4));
+    CTKCHK(ensure(h, h->lc_gtab, gkey_bytes + gacc_bytes));
+    CTKCHK(ensure(h, h->lc_occ, occ_bytes));
+    CTKCHK(ensure(h, h->lc_cp, cp_bytes));
+    int32_t *gkey = P<int32_t>(h->lc_gtab);
+    CtkLifeAcc *gacc = (CtkLifeAcc *)((char *)h->lc_gtab.p + gkey_bytes);
     for (int attempt = 0; attempt < 2; ++attempt) {
         CTKCHK(ensure(h, h->lc_rows, cap * sizeof(CtkLifeRowDev)));
         cap = h->lc_rows.cap / sizeof(CtkLifeRowDev);
         CTKCHK(ensure(h, h->lc_ovf, (size_t)T));
         HIPCHK(hipMemsetAsync(h->lc_cnt.p, 0, 16, h->stream));
         HIPCHK(hipMemsetAsync(h->lc_ovf.p, 0, (size_t)T, h->stream));
-        CTKCHK(launch(nullptr, (unsigned)T));
+        HIPCHK(hipMemsetAsync(h->lc_gtab.p, 0, gkey_bytes + gacc_bytes, h->stream));
+        HIPCHK(hipMemsetAsync(h->lc_occ.p, 0, occ_bytes, h->stream));
+        HIPCHK(hipMemsetAsync(h->lc_cp.p, 0, cp_bytes, h->stream));
+        k_life_seam<<<(unsigned)T, 64, 0, h->stream>>>(flag_dev, ny, nx, P<int32_t>(h->lc_cross), P<unsigned char>(h->lc_ovf));
+        if (f64)
+            k_life_strips<double><<<(unsigned)(T * nb), LB_THREADS, 0, h->stream>>>(flag_dev, (const double *)field_dev, ny, nx, nxw, nsx, nby, P<int64_t>(h->lc_wlo),
+                                                                                   P<int64_t>(h->lc_whi), P<float>(h->lc_w), P<int32_t>(h->lc_cross), gkey, gacc,
+                                                                                   P<unsigned>(h->lc_occ), P<double>(h->lc_cp), P<unsigned char>(h->lc_ovf));
+        else
+            k_life_strips<float><<<(unsigned)(T * nb), LB_THREADS, 0, h->stream>>>(flag_dev, (const float *)field_dev, ny, nx, nxw, nsx, nby, P<int64_t>(h->lc_wlo),
+                                                                                  P<int64_t>(h->lc_whi), P<float>(h->lc_w), P<int32_t>(h->lc_cross), gkey, gacc,
+                                                                                  P<unsigned>(h->lc_occ), P<double>(h->lc_cp), P<unsigned char>(h->lc_ovf));
+        k_life_finish<<<(unsigned)T, LB_GH, 0, h->stream>>>(nx, nxw, P<int32_t>(h->lc_cross), gkey, gacc, P<unsigned>(h->lc_occ), P<double>(h->lc_cp), wshift,
+                                                            limb_bits, P<CtkLifeRowDev>(h->lc_rows), cap, P<unsigned long long>(h->lc_cnt),
+                                                            P<unsigned char>(h->lc_ovf));
+        HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(cnt, h->lc_cnt.p, 16, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        // Time steps with more ids (or more seam-crossing ids) than the LDS tables hold: redone in passes that each take one
-        // residue class of the ids; classes that still do not fit are split again.
         std::vector<int32_t> work;
         if (cnt[1]) {
             std::vector<unsigned char> ov((size_t)T);
             HIPCHK(hipMemcpy(ov.data(), h->lc_ovf.p, (size_t)T, hipMemcpyDeviceToHost));
-            for (int64_t t = 0; t < T; ++t) if (ov[(size_t)t]) for (int j = 0; j < 2; ++j) { work.push_back((int32_t)t); work.push_back(2); work.push_back(j); }
+            for (int64_t t = 0; t < T; ++t) if (ov[(size_t)t]) { work.push_back((int32_t)t); work.push_back(1); work.push_back(0); }
         }
         while (!work.empty()) {
             const size_t items = work.size() / 3;
@@ -1811,7 +1836,7 @@ extern "C" int ctk_lifecycle_exact(ctk_handle *h, const int64_t *row_idx, int64_
     for (int64_t i = 0; i < n; ++i) {
         if (row_idx[i] < 0 || (size_t)row_idx[i] >= h->lc_host.size()) return ctk_set_error(CTK_E_INVALID, "ctk_lifecycle_exact: row %lld out of range", (long long)row_idx[i]);
         const ctk_life_row &r = h->lc_host[(size_t)row_idx[i]];
-        keys[(size_t)i] = CtkLifeKey{r.t, r.label, r.shift, 0};
+        keys[(size_t)i] = CtkLifeKey{r.t, r.label, r.shift, r.pad};
     }
     CTKCHK(ensure(h, h->lc_ekeys, (size_t)n * sizeof(CtkLifeKey)));
     CTKCHK(ensure(h, h->lc_offs, (size_t)n * 8));

@@ -24,6 +24,7 @@
 
 struct CtkLifeRowDev {
     int32_t t, label, shift, pad;    // shift: roll applied before the centre of mass (-1: none, -2: undefined, single column)
+                                     // pad: rows that may hold the id, first | last << 16 (bounds the scans of the exact kernels)
     double area, swv, swvy, swvx;
 };
 
@@ -263,11 +264,406 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
     if (base + (unsigned long long)n > cap_rows) return;
     for (int i = tid; i < n; i += LC_THREADS) {
         CtkLifeRowDev r;
-        r.t = (int32_t)t; r.label = dlabel[i]; r.shift = dshift[i]; r.pad = 0;
+        r.t = (int32_t)t; r.label = dlabel[i]; r.shift = dshift[i]; r.pad = (int32_t)((uint32_t)(ny - 1) << 16);      // (rows 0 .. ny-1)
         r.area = dev_limbs_to_double(alo[i], ahi[i], wshift, limb_bits);
         r.swv = swv[i]; r.swvy = swvy[i]; r.swvx = swvx[i];
         rows[base + i] = r;
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Strip form: the plane of one time step is cut into strips of LB_SW columns x 4 * LB_R rows, one workgroup each (one wave per
+// LB_R rows), so that a few hundred time steps of a 0.25-degree grid (10^6 pixels per plane) fill the chip, and every byte of
+// flag / field is read once.
+//   k_life_seam   per time step: the ids present in BOTH seam columns (x = 0, x = nx-1)               -> cross[t][LB_KS]
+//   k_life_strips a lane owns four columns and walks down the rows: inside a contour it adds to registers (no table look-up, no
+//                 cross-lane traffic); the sums go to the workgroup's LDS table when another id enters the lane's columns and
+//                 at the end, and from there into the time step's global table (LB_GH slots; integer / float64 atomics).  The
+//                 x-sum is taken on the UNROLLED axis; for the crossing ids the lanes also hand in the occupancy of their
+//                 columns and the per-column sums of p = w*v
+//   k_life_finish per time step: western edge of the crossing ids from the occupancy (as phase C above), then
+//                   sum p*x' = sum p*x - shift * sum p + nx * sum_{x < shift} p          x' = (x - shift) mod nx
+//                 and one row per id.
+// A time step with more ids than the tables hold raises ovf[t]; the host redoes those with k_lifecycle (which splits further).
+// ------------------------------------------------------------------------------------------------
+#define LB_THREADS 256
+#define LB_SW 256         // columns per strip: one wave, four per lane
+#define LB_R 16           // rows per wave; a workgroup = 4 waves = 64 rows of one strip
+#define LB_LH 128         // LDS hash slots per chunk (<= LB_LN ids)
+#define LB_LN 64
+#define LB_GH 256         // global hash slots per time step (<= LB_GN ids)
+#define LB_GN 128
+#define LB_KS 4           // seam-crossing ids per time step
+#define LB_BATCH 4        // flag loads in flight per lane
+
+struct CtkLifeAcc {
+    unsigned long long lo, hi;      // area limbs
+    double swv, swvy, swvx;         // sum p, sum p*y, sum p*x (x unrolled)
+    unsigned ytop, ybot;            // 65536 - first row, last row + 1 (0 = none yet: the table starts zeroed, both grow by atomicMax)
+};
+
+template <int SLOTS>
+__device__ inline int lb_slot_insert(int32_t *hkey, int32_t label)
+{
+    uint32_t s = (((uint32_t)label * 2654435761u) >> 16) & (SLOTS - 1);
+    for (int probe = 0; probe < SLOTS; ++probe) {
+        const int32_t k = hkey[s];
+        if (k == label) return (int)s;
+        if (k == 0) {
+            const int32_t old = atomicCAS(&hkey[s], 0, label);
+            if (old == 0 || old == label) return (int)s;
+        }
+        s = (s + 1) & (SLOTS - 1);
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(64) void k_life_seam(const int32_t *__restrict__ flag, int ny, int nx, int32_t *__restrict__ cross,
+                                                  unsigned char *__restrict__ ovf)
+{
+    __shared__ int32_t hkey[LC_HASH];
+    __shared__ unsigned hedge[LC_HASH / 4];
+    __shared__ int ncr, bad;
+    const int tid = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    const int32_t *fp = flag + t * (int64_t)ny * nx;
+    for (int s = tid; s < LC_HASH; s += 64) { hkey[s] = 0; if (s < LC_HASH / 4) hedge[s] = 0; }
+    if (tid == 0) { ncr = 0; bad = 0; }
+    __syncthreads();
+    for (int y = tid; y < ny; y += 64) {
+        const int32_t a = fp[(int64_t)y * nx], b = fp[(int64_t)y * nx + nx - 1];
+        if (a) { const int s = lc_slot<true>(hkey, a); if (s < 0) bad = 1; else atomicOr(&hedge[s >> 2], 1u << (8 * (s & 3))); }
+        if (b) { const int s = lc_slot<true>(hkey, b); if (s < 0) bad = 1; else atomicOr(&hedge[s >> 2], 2u << (8 * (s & 3))); }
+    }
+    __syncthreads();
+    for (int s = tid; s < LC_HASH; s += 64) {
+        if (hkey[s] == 0 || ((hedge[s >> 2] >> (8 * (s & 3))) & 3u) != 3u) continue;
+        const int q = atomicAdd(&ncr, 1);
+        if (q < LB_KS) cross[t * (LB_KS + 1) + 1 + q] = hkey[s];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        cross[t * (LB_KS + 1)] = ncr <= LB_KS ? ncr : 0;
+        if (ncr > LB_KS || bad) ovf[t] = 1;
+    }
+}
+
+// inclusive sum along each row of 16 lanes (DPP row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0): lane 15 of a
+// row ends up with the row's total
+template <int CTRL>
+__device__ inline long long dpp_mov_i64(long long v)
+{
+    int lo = (int)(unsigned)(unsigned long long)v, hi = (int)(unsigned)((unsigned long long)v >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ inline long long row16_sum(long long v)
+{
+    v += dpp_mov_i64<0x111>(v); v += dpp_mov_i64<0x112>(v); v += dpp_mov_i64<0x114>(v); v += dpp_mov_i64<0x118>(v);
+    return v;
+}
+__device__ inline double row16_sum(double v)
+{
+    v += __longlong_as_double(dpp_mov_i64<0x111>(__double_as_longlong(v)));
+    v += __longlong_as_double(dpp_mov_i64<0x112>(__double_as_longlong(v)));
+    v += __longlong_as_double(dpp_mov_i64<0x114>(__double_as_longlong(v)));
+    v += __longlong_as_double(dpp_mov_i64<0x118>(__double_as_longlong(v)));
+    return v;
+}
+
+template <typename VT>
+__global__ __launch_bounds__(LB_THREADS) void k_life_strips(const int32_t *__restrict__ flag, const VT *__restrict__ field, int ny, int nx, int nxw, int nsx, int nby,
+                                                            const int64_t *__restrict__ wlo, const int64_t *__restrict__ whi, const float *__restrict__ wrow,
+                                                            const int32_t *__restrict__ cross, int32_t *__restrict__ gkey, CtkLifeAcc *__restrict__ gacc,
+                                                            unsigned *__restrict__ occ, double *__restrict__ cp, unsigned char *__restrict__ ovf)
+{
+    __shared__ int32_t hkey[LB_LH];
+    __shared__ long long alo[LB_LH], ahi[LB_LH];
+    __shared__ double swv[LB_LH], swvy[LB_LH], swvx[LB_LH];
+    __shared__ unsigned ytop[LB_LH], ybot[LB_LH];
+    __shared__ int bad, skip;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned per_t = (unsigned)nsx * (unsigned)nby;
+    const int64_t t = blockIdx.x / per_t;
+    const unsigned rem = blockIdx.x % per_t;
+    const int x0 = (int)(rem % (unsigned)nsx) * LB_SW + lane * 4;          // this lane's four columns, the same in every row
+    const int ya = ((int)(rem / (unsigned)nsx) * (LB_THREADS / 64) + wave) * LB_R, yb = min(ny, ya + LB_R);
+    for (int s = tid; s < LB_LH; s += LB_THREADS) { hkey[s] = 0; alo[s] = 0; ahi[s] = 0; swv[s] = 0.0; swvy[s] = 0.0; swvx[s] = 0.0; ytop[s] = 0u; ybot[s] = 0u; }
+    if (tid == 0) { bad = 0; skip = ovf[t]; }                              // the seam kernel (or a sibling) already gave the time step up
+    __syncthreads();
+    if (skip) return;
+    const uint32_t npx = (uint32_t)ny * (uint32_t)nx;
+    const int32_t *fp = flag + t * (int64_t)npx;
+    const VT *vp = field + t * (int64_t)npx;
+    const bool vec = (nx & 3) == 0 && (((uintptr_t)flag) & 15u) == 0;
+    const bool vecv = vec && (((uintptr_t)field) & (4 * sizeof(VT) - 1)) == 0;
+    const int32_t *cr = cross + t * (LB_KS + 1);
+    const int ncr = cr[0];
+    int32_t cid[LB_KS];
+#pragma unroll
+    for (int q = 0; q < LB_KS; ++q) cid[q] = q < ncr ? cr[1 + q] : 0;
+    auto cross_of = [&](int32_t lab) { int cq = -1;
+#pragma unroll
+        for (int q = 0; q < LB_KS; ++q) if (cid[q] == lab) cq = q;
+        return cq; };
+
+    // The id this lane currently collects (in registers): its columns stay the same from row to row, so inside a contour a lane
+    // keeps adding to registers; only when another id enters its columns the collected sums go to the LDS tables.
+    int32_t h = 0;
+    int hs = -1, hq = -1;
+    long long h_lo = 0, h_hi = 0;
+    double h_wv = 0.0, h_wvy = 0.0, h_wvx = 0.0, hc[4] = {0.0, 0.0, 0.0, 0.0};
+    unsigned hoc = 0;                                                      // which of the four columns hold a pixel of h
+    int h_y0 = 0, h_y1 = 0;                                                // first / last row with a pixel of h in this lane
+    auto flush_columns = [&]() {                                            // seam-crossing id: occupied columns, column sums of p
+        if (hq < 0 || !hoc) return;
+        const size_t row = (size_t)t * LB_KS + (size_t)hq;
+        unsigned *wp = &occ[row * nxw + (x0 >> 5)];
+        const unsigned bits = hoc << (x0 & 31);                             // (x0 is a multiple of 4: one word)
+        if ((*wp & bits) != bits) atomicOr(wp, bits);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if ((hoc >> k) & 1u) unsafeAtomicAdd(&cp[row * nx + x0 + k], hc[k]);
+    };
+    auto flush_rows = [&](int slot, int ya_, int yb_) {                    // (look before the atomic: most lanes of a contour say the same)
+        if (ytop[slot] < 65536u - (unsigned)ya_) atomicMax(&ytop[slot], 65536u - (unsigned)ya_);
+        if (ybot[slot] < (unsigned)yb_ + 1u) atomicMax(&ybot[slot], (unsigned)yb_ + 1u);
+    };
+    auto flush_held = [&]() {
+        if (!h) return;
+        flush_rows(hs, h_y0, h_y1);
+        atomicAdd((unsigned long long *)&alo[hs], (unsigned long long)h_lo);
+        atomicAdd((unsigned long long *)&ahi[hs], (unsigned long long)h_hi);
+        atomicAdd(&swv[hs], h_wv);
+        atomicAdd(&swvy[hs], h_wvy);
+        atomicAdd(&swvx[hs], h_wvx);
+        flush_columns();
+        h = 0; hs = -1; hq = -1; h_lo = 0; h_hi = 0; h_wv = h_wvy = h_wvx = 0.0; hoc = 0;
+        hc[0] = hc[1] = hc[2] = hc[3] = 0.0;
+    };
+
+    // uniform loops: whole waves take part in the ballots.  The flags of LB_BATCH rows are requested before the first is looked
+    // at, then the field values of the rows that hold foreground (one load in flight per lane = bound by latency, not bandwidth).
+    for (int yq = ya; yq < yb; yq += LB_BATCH) {
+        int4 qb[LB_BATCH];
+        VT vb[LB_BATCH][4];
+#pragma unroll
+        for (int u = 0; u < LB_BATCH; ++u) {
+            qb[u] = make_int4(0, 0, 0, 0);
+            if (yq + u < yb && x0 < nx) {
+                const int32_t *rp = fp + (size_t)(yq + u) * nx + x0;
+                if (vec) {
+                    typedef int i32x4 __attribute__((ext_vector_type(4)));
+                    const i32x4 q = __builtin_nontemporal_load((const i32x4 *)rp);
+                    qb[u] = make_int4(q.x, q.y, q.z, q.w);
+                } else {
+                    qb[u].x = rp[0];
+                    qb[u].y = (x0 + 1 < nx) ? rp[1] : 0;
+                    qb[u].z = (x0 + 2 < nx) ? rp[2] : 0;
+                    qb[u].w = (x0 + 3 < nx) ? rp[3] : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LB_BATCH; ++u) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vb[u][k] = (VT)0;
+            if ((qb[u].x | qb[u].y | qb[u].z | qb[u].w) != 0) {
+                const VT *rp = vp + (size_t)(yq + u) * nx + x0;
+                if (vecv) __builtin_memcpy(vb[u], (const void *)rp, sizeof(vb[u]));        // one 16- / 32-byte request
+                else {
+                    if (qb[u].x) vb[u][0] = rp[0];
+                    if (qb[u].y) vb[u][1] = rp[1];
+                    if (qb[u].z) vb[u][2] = rp[2];
+                    if (qb[u].w) vb[u][3] = rp[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LB_BATCH; ++u) {
+            const int y = yq + u;                                          // (wave-uniform)
+            const int32_t l[4] = {qb[u].x, qb[u].y, qb[u].z, qb[u].w};
+            const bool anyfg = (l[0] | l[1] | l[2] | l[3]) != 0;
+            if (__ballot(anyfg) == 0ull) continue;
+            if (!anyfg) continue;
+            const double wy = (double)wrow[y];
+            const long long lo_y = wlo[y], hi_y = whi[y];
+            bool own = h != 0 && (l[0] == h || l[1] == h || l[2] == h || l[3] == h);
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (l[k] == 0) continue;
+                const double wv = (double)vb[u][k] * wy;                   // variable * weight_grid (contrack.py:892), float64
+                if (l[k] != h) {
+                    if (!own) {                                            // the held id is not in this row's columns: hand it in, take this one
+                        flush_held();
+                        h = l[k];
+                        hs = lb_slot_insert<LB_LH>(hkey, h);
+                        if (hs < 0) { bad = 1; hs = 0; }
+                        hq = cross_of(h);
+                        h_y0 = y;
+                        own = true;
+                    } else {                                               // a second id in the lane's columns (rare): straight to the tables
+                        int s2 = lb_slot_insert<LB_LH>(hkey, l[k]);
+                        if (s2 < 0) { bad = 1; s2 = 0; }
+                        atomicAdd((unsigned long long *)&alo[s2], (unsigned long long)lo_y);
+                        atomicAdd((unsigned long long *)&ahi[s2], (unsigned long long)hi_y);
+                        atomicAdd(&swv[s2], wv);
+                        atomicAdd(&swvy[s2], wv * (double)y);
+                        atomicAdd(&swvx[s2], wv * (double)(x0 + k));
+                        flush_rows(s2, y, y);
+                        const int q2 = cross_of(l[k]);
+                        if (q2 >= 0) {
+                            const size_t row = (size_t)t * LB_KS + (size_t)q2;
+                            unsigned *wp = &occ[row * nxw + ((x0 + k) >> 5)];
+                            const unsigned bit = 1u << ((x0 + k) & 31);
+                            if (!(*wp & bit)) atomicOr(wp, bit);
+                            unsafeAtomicAdd(&cp[row * nx + x0 + k], wv);
+                        }
+                        continue;
+                    }
+                }
+                cnt += 1;
+                h_wv += wv;
+                h_wvy += wv * (double)y;
+                h_wvx += wv * (double)(x0 + k);
+                hc[k] += wv;
+                hoc |= 1u << k;
+            }
+            h_lo += (long long)cnt * lo_y;
+            h_hi += (long long)cnt * hi_y;
+            if (cnt) h_y1 = y;
+        }
+    }
+    // what the lanes still hold: column data lane by lane, the five sums combined per row of 16 lanes first (same-address LDS
+    // atomics serialise; DPP moves run at VALU speed)
+    flush_columns();
+    if (h) flush_rows(hs, h_y0, h_y1);
+    uint64_t todo = __ballot(h != 0);
+    while (todo) {
+        const int L = __builtin_amdgcn_readlane(hs, __builtin_ctzll(todo));
+        const bool mine = h != 0 && hs == L;
+        double r_wv = mine ? h_wv : 0.0, r_wvy = mine ? h_wvy : 0.0, r_wvx = mine ? h_wvx : 0.0;
+        long long r_lo = mine ? h_lo : 0ll, r_hi = mine ? h_hi : 0ll;
+        r_wv = row16_sum(r_wv); r_wvy = row16_sum(r_wvy); r_wvx = row16_sum(r_wvx);
+        r_lo = row16_sum(r_lo); r_hi = row16_sum(r_hi);
+        if ((lane & 15) == 15) {
+            if ((r_lo | r_hi) != 0) {
+                atomicAdd((unsigned long long *)&alo[L], (unsigned long long)r_lo);
+                atomicAdd((unsigned long long *)&ahi[L], (unsigned long long)r_hi);
+            }
+            if (r_wv != 0.0 || r_wvy != 0.0 || r_wvx != 0.0) {
+                atomicAdd(&swv[L], r_wv);
+                atomicAdd(&swvy[L], r_wvy);
+                atomicAdd(&swvx[L], r_wvx);
+            }
+        }
+        todo &= ~__ballot(mine);
+    }
+    __syncthreads();
+    if (bad) { if (tid == 0) ovf[t] = 1; return; }
+    // merge the workgroup's ids into the time step's table
+    for (int s = tid; s < LB_LH; s += LB_THREADS) {
+        const int32_t lab = hkey[s];
+        if (lab == 0) continue;
+        int32_t *gk = gkey + t * LB_GH;
+        const int g = lb_slot_insert<LB_GH>(gk, lab);
+        if (g < 0) { ovf[t] = 1; continue; }
+        CtkLifeAcc *a = gacc + t * LB_GH + g;
+        atomicAdd(&a->lo, (unsigned long long)alo[s]);
+        atomicAdd(&a->hi, (unsigned long long)ahi[s]);
+        unsafeAtomicAdd(&a->swv, swv[s]);
+        unsafeAtomicAdd(&a->swvy, swvy[s]);
+        unsafeAtomicAdd(&a->swvx, swvx[s]);
+        if (a->ytop < ytop[s]) atomicMax(&a->ytop, ytop[s]);
+        if (a->ybot < ybot[s]) atomicMax(&a->ybot, ybot[s]);
+    }
+}
+
+__global__ __launch_bounds__(LB_GH) void k_life_finish(int nx, int nxw, const int32_t *__restrict__ cross, const int32_t *__restrict__ gkey,
+                                                        const CtkLifeAcc *__restrict__ gacc, const unsigned *__restrict__ occ, const double *__restrict__ cp,
+                                                        int wshift, int limb_bits, CtkLifeRowDev *rows, unsigned long long cap_rows,
+                                                        unsigned long long *counters, unsigned char *__restrict__ ovf)
+{
+    __shared__ int cshift[LB_KS];
+    __shared__ double cleft[LB_KS];
+    __shared__ int nlab;
+    __shared__ unsigned long long base;
+    const int tid = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    if (tid == 0) nlab = 0;
+    __syncthreads();
+    const int32_t lab = gkey[t * LB_GH + tid];
+    int mine = -1;
+    if (lab != 0) mine = atomicAdd(&nlab, 1);
+    const int32_t *cr = cross + t * (LB_KS + 1);
+    const int ncr = cr[0];
+    {   // wave q: western edge of crossing id q, np.argmax(np.diff(cols)) + 1 = column right of the FIRST largest gap (contrack.py:883)
+        const int q = tid >> 6, lane = tid & 63;
+        if (q < ncr) {                                       // (uniform per wave)
+            const unsigned *cb = occ + ((size_t)t * LB_KS + q) * nxw;
+            int prev = -1, best = 0, sh = -2;
+            for (int w0 = 0; w0 < nxw; w0 += 64) {
+                const unsigned mine_w = (w0 + lane < nxw) ? cb[w0 + lane] : 0u;
+                // inside the lane's word: first largest gap between neighbouring occupied columns (all lanes at once) ...
+                int in_best = 0, in_at = 0;
+                {
+                    int p = -1;
+                    for (unsigned bb = mine_w; bb; bb &= bb - 1) {
+                        const int x = __builtin_ctz(bb);
+                        if (p >= 0 && x - p > in_best) { in_best = x - p; in_at = x; }
+                        p = x;
+                    }
+                }
+                // ... then the words in order (wave-uniform scalars): gap to the previous word's last column, the word's own gap
+                uint64_t nz = __ballot(mine_w != 0u);
+                while (nz) {
+                    const int wl = __builtin_ctzll(nz);
+                    nz &= nz - 1;
+                    const unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)mine_w, wl);
+                    const int wb = __builtin_amdgcn_readlane(in_best, wl), wa = __builtin_amdgcn_readlane(in_at, wl);
+                    const int xbase = (w0 + wl) * 32, first = xbase + __builtin_ctz(bits), last = xbase + 31 - __builtin_clz(bits);
+                    if (prev >= 0 && first - prev > best) { best = first - prev; sh = first; }
+                    if (wb > best) { best = wb; sh = xbase + wa; }
+                    prev = last;
+                }
+            }
+            if (lane == 0) { cshift[q] = sh; cleft[q] = 0.0; }
+        }
+    }
+    __syncthreads();
+    for (int q = 0; q < ncr; ++q) {                          // sum of the columns left of the edge: all lanes, independent loads
+        const double *cc = cp + ((size_t)t * LB_KS + q) * nx;
+        const int sh = cshift[q];
+        double left = 0.0;
+        for (int x = tid; x < sh; x += LB_GH) left += cc[x];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) left += __shfl_xor(left, o);
+        if ((tid & 63) == 0 && left != 0.0) atomicAdd(&cleft[q], left);
+    }
+    __syncthreads();
+    if (ovf[t] != 0 || nlab > LB_GN) {                          // uniform: ovf[t] was written by earlier launches only
+        if (tid == 0) { ovf[t] = 1; counters[1] = 1ull; }
+        return;
+    }
+    if (nlab == 0) return;
+    if (tid == 0) base = atomicAdd(&counters[0], (unsigned long long)nlab);
+    __syncthreads();
+    if (base + (unsigned long long)nlab > cap_rows || mine < 0) return;
+    const CtkLifeAcc a = gacc[t * LB_GH + tid];
+    CtkLifeRowDev r;
+    r.t = (int32_t)t; r.label = lab; r.shift = -1;
+    r.pad = (int32_t)((65536u - a.ytop) | ((a.ybot - 1u) << 16));
+    r.area = dev_limbs_to_double((long long)a.lo, (long long)a.hi, wshift, limb_bits);
+    r.swv = a.swv; r.swvy = a.swvy; r.swvx = a.swvx;
+    for (int q = 0; q < ncr; ++q) {
+        if (cr[1 + q] != lab) continue;
+        r.shift = cshift[q];
+        if (r.shift > 0) r.swvx = (a.swvx - (double)r.shift * a.swv) + (double)nx * cleft[q];
+    }
+    rows[base + mine] = r;
 }
 
 
@@ -343,7 +739,8 @@ __global__ __launch_bounds__(64) void k_life_count(const int32_t *__restrict__ f
     const uint32_t npx = (uint32_t)ny * (uint32_t)nx;
     const int32_t *fp = flag + (int64_t)k.t * npx;
     uint32_t c = 0;
-    for (uint32_t p = threadIdx.x; p < npx; p += 64) c += fp[p] == k.label ? 1u : 0u;
+    const uint32_t pa = ((uint32_t)k.pad & 0xffffu) * (uint32_t)nx, pb = min(npx, (((uint32_t)k.pad >> 16) + 1u) * (uint32_t)nx);
+    for (uint32_t p = pa + threadIdx.x; p < pb; p += 64) c += fp[p] == k.label ? 1u : 0u;
     c = wave_sum_u32(c);
     if (threadIdx.x == 0) counts[blockIdx.x] = c;
 }
@@ -362,9 +759,10 @@ __global__ __launch_bounds__(64) void k_life_exact(const int32_t *__restrict__ f
     // A: the row weights and the products of the id's pixels, raster order -> scratch (what weight_grid[mask] and
     //    weight_grid[mask] * variable[mask] hand to np.sum, contrack.py:874-875)
     uint32_t pos = 0;
-    for (uint32_t p0 = 0; p0 < npx; p0 += 64) {
+    const int ya = (int)((uint32_t)k.pad & 0xffffu), yb = min(ny - 1, (int)((uint32_t)k.pad >> 16));       // rows that can hold the id
+    for (uint32_t p0 = (uint32_t)ya * (uint32_t)nx; p0 < ((uint32_t)yb + 1u) * (uint32_t)nx; p0 += 64) {
         const uint32_t p = p0 + lane;
-        const bool m = p < npx && fp[p] == k.label;
+        const bool m = p < ((uint32_t)yb + 1u) * (uint32_t)nx && fp[p] == k.label;
         const uint64_t bal = __ballot(m);
         if (!bal) continue;
         if (m) {
@@ -379,7 +777,7 @@ __global__ __launch_bounds__(64) void k_life_exact(const int32_t *__restrict__ f
     // B: ndimage.center_of_mass = np.bincount: strictly sequential over the (rolled) plane in raster order
     const int shift = k.shift > 0 ? k.shift : 0;
     double s = 0.0, sy = 0.0, sx = 0.0;
-    for (int y = 0; y < ny; y++) {
+    for (int y = ya; y <= yb; y++) {
         const double w = (double)wrow[y];
         for (int x0 = 0; x0 < nx; x0 += 64) {
             const int xr = x0 + lane;                                  // column in the rolled frame

@@ -252,8 +252,10 @@ int ctk_synth_fill(ctk_handle *h, float *anom_dev, int64_t T, int ny, int nx, ui
  * The host finishes with  intensity = swv / area,  com = (swvy / swv, swvx / swv),  int() and the coordinate
  * look-ups (contrack.py:886-895).  ctk_lifecycle_* computes and keeps the rows in the handle (sorted by
  * (label, t) like the reference's frame, contrack.py:906) and returns their number; ctk_lifecycle_rows copies
- * them out.  wrow: float32 row weights, contrack.py:847-848.  A time step with more ids than the kernel's LDS tables hold
- * (512, or 32 that cross the seam) is processed in several passes over residue classes of the ids: no limit. */
+ * them out.  wrow: float32 row weights, contrack.py:847-848.  Every byte of flag / field is read once (strips of 256 columns x
+ * 64 rows per workgroup); a time step with more ids than the tables of that form hold (128, or 4 that cross the seam) is redone
+ * by a one-workgroup-per-time-step kernel in passes over residue classes of the ids: no limit.
+ * pad: the rows that hold the id, first | last << 16 (internal: bounds the scans of ctk_lifecycle_exact). */
 typedef struct ctk_life_row {
     int32_t t, label, shift, pad;
     double area, swv, swvy, swvx;

@@ -27,9 +27,9 @@ with _native.Tracker(0) as trk:
     dt = (time.perf_counter() - t0) / reps
     dates = ["%06d" % t for t in range(T)]
     t1 = time.perf_counter()
-    cols = lifecycle_columns(rows, lat, lon, dates)
+    cols = lifecycle_columns(rows, lat, lon, dates, trk)          # incl. the rows re-evaluated in the reference's summation order
     dt_frame = time.perf_counter() - t1
-    frame = lifecycle_frame(rows, lat, lon, dates)
+    frame = lifecycle_frame(rows, lat, lon, dates, trk)
     print("tracked %d contours; lifecycle rows %d (%d rolled); device reductions + download + sort %.3f ms (%.0f timesteps/s); host finish %.1f ms"
           % (tracked, len(rows), int((rows["shift"] > 0).sum()), dt * 1e3, T / dt, dt_frame * 1e3))
     Ts = min(T, 40)
