@@ -31,7 +31,11 @@ EXPORTS = [
     "ctk_track_sharded_f32_dev", "ctk_track_sharded_f64_dev",
     "ctk_anom_f32", "ctk_anom_f64", "ctk_resident_anom", "ctk_track_resident", "ctk_percentile_f32", "ctk_percentile_f64",
     "ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev", "ctk_lifecycle_rows", "ctk_lifecycle_exact",
+    "ctk_track_stream_f32", "ctk_track_stream_f64", "ctk_track_stream_cb", "ctk_stream_times",
 ]
+
+READ_CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p)       # ctk_read_chunk_fn
+WRITE_CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p)      # ctk_write_chunk_fn
 
 # ctk_life_row (include/contrack_hip.h)
 LIFE_ROW = np.dtype([("t", "<i4"), ("label", "<i4"), ("shift", "<i4"), ("pad", "<i4"),
@@ -67,6 +71,10 @@ def lib():
     L.ctk_track_f64.argtypes = track_args
     L.ctk_track_f64_dev.argtypes = track_args
     L.ctk_release_io.argtypes = [p]
+    L.ctk_track_stream_f32.argtypes = track_args + [i64]
+    L.ctk_track_stream_f64.argtypes = track_args + [i64]
+    L.ctk_track_stream_cb.argtypes = [p, i32, i64, i32, i32, READ_CHUNK_FN, p, p, i32, p, dbl, i32, i32, WRITE_CHUNK_FN, p, C.POINTER(i64), i64]
+    L.ctk_stream_times.argtypes = [p, C.POINTER(dbl)]
     L.ctk_shard_label2d.argtypes = [p, p, i64, i32, i32, p, i32, p, i32]
     L.ctk_shard_label2d_f64.argtypes = [p, p, i64, i32, i32, p, i32, p, i32]
     L.ctk_shard_halo_size.argtypes = [p, C.POINTER(sz)]
@@ -349,6 +357,85 @@ class Tracker:
         check(fn(self._h, anom.ctypes.data, T, ny, nx, thr.ctypes.data, int(cmp_op), wrow.ctypes.data,
                                   float(overlap), int(persistence), int(bool(twosided)), flag.ctypes.data, C.byref(n)))
         return flag, int(n.value)
+
+    # ---- streaming entries (next row N4) ------------------------------------------------------------------------
+    def track_stream(self, source, thr, cmp_op, wrow, overlap, persistence, twosided=True, sink=None, shape=None, dtype=None, chunk_steps=0):
+        """ctk_track_* with the slab passing through chunk-sized device buffers (device footprint: 4 chunks + slab / 32).
+
+        source: a (T, ny, nx) float32 / float64 array (np.memmap included), or a callable reader(t0, nt, out) that fills
+                `out` (a (nt, ny, nx) view of pinned memory) with the timesteps [t0, t0 + nt) -- then `shape` = (T, ny, nx)
+                and `dtype` are required;
+        sink:   None (a new int32 array is returned), an int32 array (T, ny, nx), or a callable writer(t0, nt, flags) that
+                receives each flag chunk as a (nt, ny, nx) int32 view valid during the call.
+        Returns (flag array or None, n_tracked)."""
+        L = lib()
+        if callable(source):
+            if shape is None or dtype is None:
+                raise ValueError("a reader callback needs shape=(T, ny, nx) and dtype")
+            T, ny, nx = (int(v) for v in shape)
+            dt = np.dtype(dtype)
+        else:
+            source = np.ascontiguousarray(source) if not isinstance(source, np.memmap) else source
+            if source.dtype not in (np.float32, np.float64):
+                source = np.ascontiguousarray(source, dtype=np.float64)
+            T, ny, nx = source.shape
+            dt = source.dtype
+        if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("the slab must be float32 or float64")
+        thr = np.ascontiguousarray(thr, dtype=np.float64)
+        wrow = np.ascontiguousarray(wrow, dtype=np.float32)
+        if thr.shape != (T,) or wrow.shape != (ny,):
+            raise ValueError("thr must have shape (T,) and wrow (ny,)")
+        out = None
+        if sink is None:
+            out = sink = np.empty((T, ny, nx), dtype=np.int32)
+        elif not callable(sink):
+            if sink.dtype != np.int32 or sink.shape != (T, ny, nx) or not sink.flags.c_contiguous:
+                raise ValueError("the sink array must be C-contiguous int32 (T, ny, nx)")
+            out = sink
+        n = C.c_int64(0)
+        tail = (thr.ctypes.data, int(cmp_op), wrow.ctypes.data, float(overlap), int(persistence), int(bool(twosided)))
+        if not callable(source) and not callable(sink):
+            fn = L.ctk_track_stream_f64 if dt == np.float64 else L.ctk_track_stream_f32
+            check(fn(self._h, source.ctypes.data, T, ny, nx, *tail, sink.ctypes.data, C.byref(n), int(chunk_steps)))
+            return out, int(n.value)
+        errors = []
+
+        def rd(_user, t0, nt, dst):
+            try:
+                view = np.ctypeslib.as_array(C.cast(dst, C.POINTER(C.c_float if dt == np.float32 else C.c_double)), shape=(nt, ny, nx))
+                if callable(source):
+                    source(int(t0), int(nt), view)
+                else:
+                    view[...] = source[t0:t0 + nt]
+                return 0
+            except BaseException as e:                    # an exception must not cross the C frames
+                errors.append(e)
+                return 1
+
+        def wr(_user, t0, nt, src):
+            try:
+                view = np.ctypeslib.as_array(C.cast(src, C.POINTER(C.c_int32)), shape=(nt, ny, nx))
+                if callable(sink):
+                    sink(int(t0), int(nt), view)
+                else:
+                    sink[t0:t0 + nt] = view
+                return 0
+            except BaseException as e:
+                errors.append(e)
+                return 1
+        rcb, wcb = READ_CHUNK_FN(rd), WRITE_CHUNK_FN(wr)
+        rc = L.ctk_track_stream_cb(self._h, dt.itemsize, T, ny, nx, rcb, None, *tail, wcb, None, C.byref(n), int(chunk_steps))
+        if errors:
+            raise errors[0]
+        check(rc)
+        return out, int(n.value)
+
+    def stream_times(self):
+        """ms of the last streaming call: reader callbacks, writer callbacks, input phase, output phase"""
+        ms = (C.c_double * 4)()
+        check(lib().ctk_stream_times(self._h, ms))
+        return dict(zip(("reader", "writer", "input_phase", "output_phase"), (float(v) for v in ms)))
 
     # ---- calc_anom / percentile threshold on the device ---------------------------------------------------------
     def anomalies(self, x, group, ngroups, window=1, smooth=1, clim=None, want_anom=True, want_clim=False, keep_resident=False):

@@ -500,13 +500,17 @@ class contrack(object):
             return prepare_thresholds(values, T, dtype)
         return prepare_thresholds(threshold, T, dtype)
 
-    def run_contrack(self, variable, threshold, gorl, overlap, persistence, twosided=True):
+    def run_contrack(self, variable, threshold, gorl, overlap, persistence, twosided=True, chunk_steps=None):
         """Spatial and temporal tracking of closed contours; adds the integer variable 'flag' to the dataset.
 
         variable: name of the input field; threshold: number or 1-D DataArray over 'dayofyear'; gorl: one of
         [>, >=, <, <=, ge, le, gt, lt]; overlap: fraction [0-1] of area overlap between consecutive steps;
         persistence: minimum life time in time steps; twosided: forward+backward overlap test (True) or forward
-        only."""
+        only.
+        chunk_steps (extension, not in the reference): stream the variable through the GPU in slices of that many time steps
+        (0: about 256 MB each) instead of materialising it on the host and in HBM -- for a lazily loaded netCDF variable
+        (xr.open_dataset) each slice is read from the file when its turn comes (`isel(time=slice)`), and the device holds four
+        slices and the bit mask instead of twice the slab.  Same result."""
         logger.info("\nRun ConTrack \n########### \n    threshold:    {} {} \n    overlap:      {} \n"
                     "    persistence:  {} time steps".format(gorl, threshold, overlap, persistence))
         self._ensure_set_up()
@@ -516,18 +520,24 @@ class contrack(object):
         da = self.ds[variable]
         dims = tuple(da.dims)
         sort = [dims.index(d) for d in (self._time_name, self._latitude_name, self._longitude_name)]
-        slab = np.asarray(da.data).transpose(sort)
-        T = slab.shape[0]
-        thr = self._thresholds_per_step(threshold, T, slab.dtype)
         lat = self.ds[self._latitude_name].data
         wrow = row_weights(lat, self._dlat, self._dlon)
+        trk = _tracker()
+        if chunk_steps is not None:
+            flag, n_tracked = self._run_streaming(trk, da, dims, sort, threshold, gorl, wrow, overlap, persistence, twosided, int(chunk_steps))
+            resident, slab = False, None
+        else:
+            slab = np.asarray(da.data).transpose(sort)
+            T = slab.shape[0]
+            thr = self._thresholds_per_step(threshold, T, slab.dtype)
         logger.info("Apply overlap...")
         logger.info("Apply persistence...")
-        trk = _tracker()
-        resident = variable == 'anom' and getattr(self, "_anom_resident", None) is not None and \
+        resident = chunk_steps is None and variable == 'anom' and getattr(self, "_anom_resident", None) is not None and \
             self._anom_resident == _fingerprint(np.asarray(da.data)) and \
             trk.resident_anom() == (slab.shape[0], slab.shape[1], slab.shape[2], slab.dtype != np.float32)
-        if resident:
+        if chunk_steps is not None:
+            pass
+        elif resident:
             # calc_anom left this very slab in HBM: no host-to-device copy
             flag, n_tracked = trk.track_resident(thr, _native.CMP_OPS[gorl], wrow, overlap, persistence, twosided)
         elif slab.dtype == np.float32:
@@ -535,7 +545,7 @@ class contrack(object):
         else:
             flag, n_tracked = trk.track(np.ascontiguousarray(slab, dtype=np.float64), thr, _native.CMP_OPS[gorl], wrow, overlap,
                                         persistence, twosided, f64=True)
-        if slab.nbytes > (4 << 30):
+        if slab is not None and slab.nbytes > (4 << 30):
             trk.release_io()               # a big one-off slab: do not keep 2 x its size allocated on the GPU
         logger.info("Create new variable 'flag'...")
         inverse = np.argsort(sort)
@@ -553,6 +563,20 @@ class contrack(object):
                    4: "{} overlap decisions on rounding boundaries were re-evaluated with numpy-order sums".format(st.get("exact_fixups", 0))}
             logger.info("run_contrack left the fused device path: " + why.get(st["off_fused_path_reason"], "host resolver"))
         logger.info("Running contrack... DONE\n{} contours tracked".format(n_tracked))
+
+    def _run_streaming(self, trk, da, dims, sort, threshold, gorl, wrow, overlap, persistence, twosided, chunk_steps):
+        """run_contrack with the variable read slice by slice"""
+        shape = tuple(da.shape[i] for i in sort)                                  # (time, lat, lon)
+        dtype = np.dtype(np.float32) if np.dtype(da.dtype) == np.float32 else np.dtype(np.float64)
+        thr = self._thresholds_per_step(threshold, shape[0], dtype)
+        tname = self._time_name
+
+        def reader(t0, nt, out):
+            part = da.isel(**{tname: slice(t0, t0 + nt)}) if hasattr(da, "isel") else None
+            arr = np.asarray(part.data if part is not None else np.asarray(da.data).take(range(t0, t0 + nt), axis=dims.index(tname)))
+            out[...] = arr.transpose(sort)
+        return trk.track_stream(reader, thr, _native.CMP_OPS[gorl], wrow, overlap, persistence, twosided, shape=shape, dtype=dtype,
+                                chunk_steps=chunk_steps)
 
     # ---- life cycle (contrack.py:798-906), consumer of `flag` (SURVEY.md section 8(f) N1) ----------------------------
     def _time_labels(self):

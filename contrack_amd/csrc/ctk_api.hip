@@ -18,6 +18,7 @@
 #include <sys/mman.h>
 #include <atomic>
 #include <thread>
+#include <functional>
 
 int ctk_set_error(int code, const char *fmt, ...);            // ctk_resolve.cpp
 extern "C" int ctk_weights_to_limbs(const float *wrow, int ny, int64_t npix, int64_t *wlo, int64_t *whi, int32_t *wshift, int32_t *limb_bits);
@@ -99,6 +100,20 @@ struct BouncePool {
     }
 };
 
+// Source and sink of a streaming call.  Arrays (host_in / host_out) or callbacks that fill / drain pinned chunk buffers.
+struct StreamIO {
+    const void *host_in = nullptr;                 // (T, ny, nx) slab in host memory, or
+    ctk_read_chunk_fn read = nullptr;              // reader of [t0, t0 + nt) into a pinned buffer
+    void *read_user = nullptr;
+    int32_t *host_out = nullptr;
+    ctk_write_chunk_fn write = nullptr;
+    void *write_user = nullptr;
+    int64_t chunk = 0;                             // timesteps per chunk
+    size_t esz = 4;
+    double ms_read = 0, ms_write = 0, ms_in = 0, ms_out = 0;
+    int64_t passes_in = 0;                         // how often the input was streamed (2: the call had to re-read it)
+};
+
 struct ctk_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -131,6 +146,13 @@ struct ctk_handle {
     DevBuf an_out, an_clim, an_raw, an_idx;
     int64_t an_T = -1; int an_ny = 0, an_nx = 0; bool an_f64 = false;
     DevBuf io_in, io_out;                          // device copies of host-array calls (ctk_track_f32 / _f64)
+    // streaming entries (ctk_track_stream_*): the slab passes through two chunk-sized device buffers per direction
+    struct StreamIO *sio = nullptr;                // set for the duration of a streaming call: where the slab comes from
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_thr[2] = {nullptr, nullptr}, ev_rel[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
+    void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
+    size_t pin_in_cap = 0, pin_out_cap = 0;
+    double stream_ms[4] = {0, 0, 0, 0};
     BouncePool *bounce = nullptr;                  // created on first use
     // time-sharded path (ctk_sharded.hip)
     DevBuf sh_mask_next, sh_send, sh_recv, sh_prev, sh_elist, sh_ovr_slot, sh_ovr_val, sh_amb_list, sh_counts;
@@ -277,6 +299,19 @@ int grid_for_rows(int64_t nrows)
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+static void stream_teardown(ctk_handle *h)
+{
+    for (int b = 0; b < 2; b++) {
+        if (h->pin_in[b]) (void)hipHostFree(h->pin_in[b]);
+        if (h->pin_out[b]) (void)hipHostFree(h->pin_out[b]);
+        h->pin_in[b] = nullptr; h->pin_out[b] = nullptr;
+        for (hipEvent_t *e : {&h->ev_h2d[b], &h->ev_thr[b], &h->ev_rel[b], &h->ev_d2h[b]}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+    }
+    h->pin_in_cap = h->pin_out_cap = 0;
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    h->copy_stream = nullptr;
+}
+
 extern "C" int ctk_version(void) { return 100; }
 
 extern "C" int ctk_device_count(void)
@@ -337,6 +372,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
     if (h->h_ops) (void)hipHostFree(h->h_ops);
     if (h->h_mail) (void)hipHostFree(h->h_mail);
     if (h->bounce) { h->bounce->destroy(); delete h->bounce; }
+    stream_teardown(h);
     if (h->h_mail1) (void)hipHostFree(h->h_mail1);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_mail2) (void)hipHostFree(h->h_mail2);
@@ -430,6 +466,9 @@ extern "C" int ctk_get_timings(ctk_handle *h, double *ms)
 // ------------------------------------------------------------------------------------------------
 // rows per workgroup of k_threshold_v4.  Swept on MI355X: 2707 x 181 x 360: 8..64 rows 0.128-0.137 ms (4 rows 0.195);
 // 480 x 721 x 1440: 2..32 rows 0.345-0.366 ms -- flat, 16 it is.
+static int stream_in(ctk_handle *h, bool f64, int64_t T, int ny, int nx, const std::function<int(const void *, int64_t, int64_t)> &consume);
+static int stream_out(ctk_handle *h, int persistence, const int32_t *chunk_vals);
+
 static int threshold_rows(int ny, int nx, int64_t T)
 {
     (void)nx; (void)T;
@@ -442,7 +481,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                               int cmp_op, const float *wrow, int has_prev, bool defer_compact = false)
 {
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
-    if (T < 0 || ny < 1 || nx < 1 || (T > 0 && (!anom_dev || !thr)) || !wrow)
+    if (T < 0 || ny < 1 || nx < 1 || (T > 0 && ((!anom_dev && !h->sio) || !thr)) || !wrow)
         return ctk_set_error(CTK_E_INVALID, "ctk_shard_label2d: bad shape (T=%lld ny=%d nx=%d) or null pointer", (long long)T, ny, nx);
     if (cmp_op < 0 || cmp_op > 3) return ctk_set_error(CTK_E_INVALID, "ctk_shard_label2d: cmp_op %d not in 0..3", cmp_op);
     if (nx > 65535 || ny > 65535) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: grid %dx%d exceeds 65535 per axis", ny, nx);
@@ -530,25 +569,33 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
 
     if (T > 0) {
         Timer tm(h, CTK_K_THRESHOLD);
-        const int g = grid_for_rows(nrows);
         const int rbt = threshold_rows(ny, nx, T);
-        const int64_t nblk4 = T * ((ny + rbt - 1) / rbt);                             // one workgroup per (timestep, rbt rows)
-        const bool v4 = !f64 && (nx % 4 == 0) && (((uintptr_t)anom_dev & 15) == 0) && nblk4 < (1 << 24);     // < 2^32 work-items
-        const unsigned g4 = (unsigned)nblk4;
+        // timesteps [t0, t0 + nt) of the slab, at `src` on the device
+        auto launch_threshold = [&](const void *src, int64_t t0, int64_t nt) -> int {
+            const int64_t rows = nt * ny;
+            const int g = grid_for_rows(rows);
+            const int64_t nblk4 = nt * ((ny + rbt - 1) / rbt);                            // one workgroup per (timestep, rbt rows)
+            const bool v4 = !f64 && (nx % 4 == 0) && (((uintptr_t)src & 15) == 0) && nblk4 < (1 << 24);     // < 2^32 work-items
+            const unsigned g4 = (unsigned)nblk4;
+            uint64_t *mk = P<uint64_t>(h->mask) + t0 * ny * W;
 #define LAUNCH_THR(OP)                                                                                                                      \
     do {                                                                                                                                \
-        if (f64) k_threshold<OP, double><<<g, 256, 0, s>>>((const double *)anom_dev, P<double>(h->thr32), nrows, ny, nx, W, P<uint64_t>(h->mask)); \
-        else if (v4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)anom_dev, P<float>(h->thr32), ny, nx, W, P<uint64_t>(h->mask), rbt); \
-        else k_threshold<OP, float><<<g, 256, 0, s>>>((const float *)anom_dev, P<float>(h->thr32), nrows, ny, nx, W, P<uint64_t>(h->mask)); \
+        if (f64) k_threshold<OP, double><<<g, 256, 0, s>>>((const double *)src, P<double>(h->thr32) + t0, rows, ny, nx, W, mk); \
+        else if (v4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt); \
+        else k_threshold<OP, float><<<g, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, rows, ny, nx, W, mk); \
     } while (0)
-        switch (cmp_op) {
-        case 0: LAUNCH_THR(0); break;
-        case 1: LAUNCH_THR(1); break;
-        case 2: LAUNCH_THR(2); break;
-        default: LAUNCH_THR(3); break;
-        }
+            switch (cmp_op) {
+            case 0: LAUNCH_THR(0); break;
+            case 1: LAUNCH_THR(1); break;
+            case 2: LAUNCH_THR(2); break;
+            default: LAUNCH_THR(3); break;
+            }
 #undef LAUNCH_THR
-        HIPCHK(hipGetLastError());
+            HIPCHK(hipGetLastError());
+            return CTK_OK;
+        };
+        if (anom_dev) CTKCHK(launch_threshold(anom_dev, 0, T));
+        else CTKCHK(stream_in(h, f64, T, ny, nx, launch_threshold));                     // the slab arrives in chunks (ctk_track_stream_*)
     }
     {
         Timer tm(h, CTK_KI_ROWCOUNT);
@@ -1343,25 +1390,29 @@ static int32_t *chunk_vals_for(ctk_handle *h, const int32_t *flag_dev, int *rows
     return P<int32_t>(h->chunk_vals);
 }
 
-static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, bool with_fold, const int32_t *chunk_vals = nullptr)
+// timesteps [t0, t0 + nt) of the shard into flag_dev (which starts at t0); nt < 0: the whole shard
+static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, bool with_fold, const int32_t *chunk_vals = nullptr, int64_t t0 = 0, int64_t nt = -1)
 {
+    if (nt < 0) nt = h->T;
     RelabelArgs a;
-    a.mask = P<uint64_t>(h->mask); a.wstart = P<uint16_t>(h->wstart); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
+    const int rb = relabel_rows(h);                                   // (of the whole shard: the chunk values were built for it)
+    const int64_t nchunk = (h->ny + rb - 1) / rb;
+    a.mask = P<uint64_t>(h->mask) + t0 * h->ny * h->W; a.wstart = P<uint16_t>(h->wstart) + t0 * h->ny * h->W;
+    a.rowstart = P<uint32_t>(h->rowstart) + t0 * h->ny; a.run_base = P<uint32_t>(h->run_base) + t0;
     a.run_val = P<int32_t>(h->run_val); a.ext = P<int32_t>(h->ext); a.n_labels = h->n_labels; a.persistence = persistence;
-    a.t_begin = h->t_begin;
+    a.t_begin = h->t_begin + t0;
     if (with_fold) a.fold = fold_args(h); else { a.fold.ops = nullptr; a.fold.first = nullptr; a.fold.next = nullptr; a.fold.nops = 0; }
     a.flag = flag_dev; a.counters = P<uint32_t>(h->counters);
-    a.nrows = h->T * h->ny; a.ny = h->ny; a.nx = h->nx; a.W = h->W;
-    a.chunk_vals = chunk_vals;
+    a.nrows = nt * h->ny; a.ny = h->ny; a.nx = h->nx; a.W = h->W;
+    a.chunk_vals = chunk_vals ? chunk_vals + t0 * nchunk * CTK_CV : nullptr;
     const int64_t npl = (int64_t)h->ny * h->nx;
-    const int rb = relabel_rows(h);
     const int rvcap = 2048;
     const size_t lds = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) + (size_t)rvcap * 4;
-    const int64_t nblk4 = h->T * ((h->ny + rb - 1) / rb);
-    if ((h->nx % 4 == 0) && (((uintptr_t)flag_dev & 15) == 0) && npl < 0x7fffffff && nblk4 < (1 << 24) && h->T > 0 && lds <= 60 * 1024) {
+    const int64_t nblk4 = nt * nchunk;
+    if ((h->nx % 4 == 0) && (((uintptr_t)flag_dev & 15) == 0) && npl < 0x7fffffff && nblk4 < (1 << 24) && nt > 0 && lds <= 60 * 1024) {
         const unsigned grid = (unsigned)nblk4;
         k_relabel_v4<<<grid, 256, lds, h->stream>>>(a, rb, rvcap);
-    } else {
+    } else if (nt > 0) {
         a.chunk_vals = nullptr;
         k_relabel<<<grid_for_rows(a.nrows), 256, 0, h->stream>>>(a);
     }
@@ -1371,7 +1422,7 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
 
 extern "C" int ctk_shard_write(ctk_handle *h, int persistence, int32_t *flag_dev, int64_t *n_alive_local, int *wrote_background)
 {
-    if (!h || (h->T > 0 && !flag_dev)) return ctk_set_error(CTK_E_INVALID, "null argument");
+    if (!h || (h->T > 0 && !flag_dev && !h->sio)) return ctk_set_error(CTK_E_INVALID, "null argument");
     if (h->state != ST_EXTENTS) return ctk_set_error(CTK_E_STATE, "ctk_shard_write needs ctk_shard_extents first");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -1387,7 +1438,7 @@ extern "C" int ctk_shard_write(ctk_handle *h, int persistence, int32_t *flag_dev
         }
         {
             Timer tm(h, CTK_K_RELABEL);
-            CTKCHK(launch_relabel(h, persistence, flag_dev, true, cv));
+            CTKCHK((flag_dev || !h->sio) ? launch_relabel(h, persistence, flag_dev, true, cv) : stream_out(h, persistence, cv));
         }
     }
     {
@@ -1572,6 +1623,171 @@ static int track_host_impl(ctk_handle *h, const void *anom, bool f64, int64_t T,
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// streaming entries (next row N4): see include/contrack_hip.h.  The two pixel passes of the path (k_threshold, k_relabel) are
+// independent per timestep; everything between them works on the bit mask and the tables.
+// ------------------------------------------------------------------------------------------------
+static int stream_setup(ctk_handle *h, size_t in_bytes, size_t out_bytes, bool pinned)
+{
+    if (!h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++)
+        for (hipEvent_t *e : {&h->ev_h2d[b], &h->ev_thr[b], &h->ev_rel[b], &h->ev_d2h[b]})
+            if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    if (in_bytes) CTKCHK(ensure(h, h->io_in, 2 * in_bytes));
+    if (out_bytes) CTKCHK(ensure(h, h->io_out, 2 * out_bytes));
+    if (pinned) {
+        if (in_bytes > h->pin_in_cap) {
+            for (int b = 0; b < 2; b++) { if (h->pin_in[b]) (void)hipHostFree(h->pin_in[b]); h->pin_in[b] = nullptr; }
+            h->pin_in_cap = 0;
+            for (int b = 0; b < 2; b++)
+                if (hipHostMalloc(&h->pin_in[b], in_bytes, hipHostMallocNonCoherent) != hipSuccess) return ctk_set_error(CTK_E_NOMEM, "pinned chunk buffer (%zu bytes)", in_bytes);
+            h->pin_in_cap = in_bytes;
+        }
+        if (out_bytes > h->pin_out_cap) {
+            for (int b = 0; b < 2; b++) { if (h->pin_out[b]) (void)hipHostFree(h->pin_out[b]); h->pin_out[b] = nullptr; }
+            h->pin_out_cap = 0;
+            for (int b = 0; b < 2; b++)
+                if (hipHostMalloc(&h->pin_out[b], out_bytes, hipHostMallocNonCoherent) != hipSuccess) return ctk_set_error(CTK_E_NOMEM, "pinned chunk buffer (%zu bytes)", out_bytes);
+            h->pin_out_cap = out_bytes;
+        }
+    }
+    return CTK_OK;
+}
+
+// input phase: chunk k+1 travels (reader + H2D on the copy stream) while `consume` (k_threshold) works on chunk k
+static int stream_in(ctk_handle *h, bool f64, int64_t T, int ny, int nx, const std::function<int(const void *, int64_t, int64_t)> &consume)
+{
+    StreamIO &io = *h->sio;
+    const size_t plane = (size_t)ny * nx * io.esz, cbytes = (size_t)io.chunk * plane;
+    (void)f64;
+    CTKCHK(stream_setup(h, cbytes, 0, io.read != nullptr));
+    const double t_in = now_ms();
+    io.passes_in++;
+    int k = 0;
+    for (int64_t t0 = 0; t0 < T; t0 += io.chunk, k++) {
+        const int b = k & 1;
+        const int64_t nt = std::min<int64_t>(io.chunk, T - t0);
+        char *dev = (char *)h->io_in.p + (size_t)b * cbytes;
+        if (k >= 2) HIPCHK(hipEventSynchronize(h->ev_thr[b]));                 // the device buffer (and its pinned twin) is free again
+        if (io.read) {
+            const double r0 = now_ms();
+            const int rc = io.read(io.read_user, t0, nt, h->pin_in[b]);
+            io.ms_read += now_ms() - r0;
+            if (rc) return ctk_set_error(CTK_E_INVALID, "ctk_track_stream: the reader returned %d for timesteps [%lld, %lld)", rc, (long long)t0, (long long)(t0 + nt));
+            HIPCHK(hipMemcpyAsync(dev, h->pin_in[b], (size_t)nt * plane, hipMemcpyHostToDevice, h->copy_stream));
+        } else {
+            // pageable source: the runtime stages it; the call returns when the data has left the caller's array
+            HIPCHK(hipMemcpyAsync(dev, (const char *)io.host_in + (size_t)t0 * plane, (size_t)nt * plane, hipMemcpyHostToDevice, h->copy_stream));
+        }
+        HIPCHK(hipEventRecord(h->ev_h2d[b], h->copy_stream));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_h2d[b], 0));
+        CTKCHK(consume(dev, t0, nt));
+        HIPCHK(hipEventRecord(h->ev_thr[b], h->stream));
+    }
+    io.ms_in += now_ms() - t_in;
+    return CTK_OK;
+}
+
+// output phase: k_relabel writes chunk k+1 into one device buffer while chunk k leaves the other
+static int stream_out(ctk_handle *h, int persistence, const int32_t *chunk_vals)
+{
+    StreamIO &io = *h->sio;
+    const int64_t T = h->T;
+    const size_t plane = (size_t)h->ny * h->nx * 4, cbytes = (size_t)io.chunk * plane;
+    CTKCHK(stream_setup(h, 0, cbytes, io.write != nullptr));
+    const double t_out = now_ms();
+    if (io.host_out) {                                                           // huge pages where the allocation allows (first-touch faults)
+        const uintptr_t a0 = ((uintptr_t)io.host_out + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1);
+        const uintptr_t a1 = ((uintptr_t)io.host_out + (size_t)T * plane) & ~(((uintptr_t)2 << 20) - 1);
+        if (a1 > a0) (void)madvise((void *)a0, a1 - a0, MADV_HUGEPAGE);
+        if (!h->bounce) h->bounce = new (std::nothrow) BouncePool();
+    }
+    struct Pending { int64_t t0 = -1, nt = 0; int b = 0; } pend;
+    auto drain = [&](const Pending &p) -> int {                                 // chunk p leaves the device
+        if (p.t0 < 0) return CTK_OK;
+        int32_t *dev = (int32_t *)((char *)h->io_out.p + (size_t)p.b * cbytes);
+        HIPCHK(hipEventSynchronize(h->ev_rel[p.b]));
+        if (io.write) {
+            HIPCHK(hipMemcpyAsync(h->pin_out[p.b], dev, (size_t)p.nt * plane, hipMemcpyDeviceToHost, h->copy_stream));
+            HIPCHK(hipEventRecord(h->ev_d2h[p.b], h->copy_stream));
+            HIPCHK(hipEventSynchronize(h->ev_d2h[p.b]));
+            const double w0 = now_ms();
+            const int rc = io.write(io.write_user, p.t0, p.nt, (const int32_t *)h->pin_out[p.b]);
+            io.ms_write += now_ms() - w0;
+            if (rc) return ctk_set_error(CTK_E_INVALID, "ctk_track_stream: the writer returned %d for timesteps [%lld, %lld)", rc, (long long)p.t0, (long long)(p.t0 + p.nt));
+        } else {
+            char *dst = (char *)io.host_out + (size_t)p.t0 * plane;
+            if (!h->bounce || !bounce_copy(*h->bounce, h->device, dev, dst, (size_t)p.nt * plane, false))
+                HIPCHK(hipMemcpy(dst, dev, (size_t)p.nt * plane, hipMemcpyDeviceToHost));
+        }
+        return CTK_OK;
+    };
+    int k = 0;
+    for (int64_t t0 = 0; t0 < T; t0 += io.chunk, k++) {
+        const int b = k & 1;
+        const int64_t nt = std::min<int64_t>(io.chunk, T - t0);
+        int32_t *dev = (int32_t *)((char *)h->io_out.p + (size_t)b * cbytes);
+        // buffer b was drained two chunks ago (drain is synchronous): relabel chunk k into it, then drain chunk k-1 meanwhile
+        CTKCHK(launch_relabel(h, persistence, dev, true, chunk_vals, t0, nt));
+        HIPCHK(hipEventRecord(h->ev_rel[b], h->stream));
+        CTKCHK(drain(pend));
+        pend.t0 = t0; pend.nt = nt; pend.b = b;
+    }
+    CTKCHK(drain(pend));
+    io.ms_out += now_ms() - t_out;
+    return CTK_OK;
+}
+
+static int track_stream_impl(ctk_handle *h, StreamIO &io, bool f64, int64_t T, int ny, int nx, const double *thr, int cmp_op, const float *wrow,
+                             double overlap, int persistence, int twosided, int64_t *n_tracked, int64_t chunk_steps)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    if (T < 0 || ny < 1 || nx < 1 || chunk_steps < 0) return ctk_set_error(CTK_E_INVALID, "ctk_track_stream: bad shape");
+    if (T > 0 && ((!io.host_in && !io.read) || (!io.host_out && !io.write))) return ctk_set_error(CTK_E_INVALID, "ctk_track_stream: no source or no sink");
+    HIPCHK(hipSetDevice(h->device));
+    io.esz = f64 ? 8 : 4;
+    const size_t plane = (size_t)ny * nx * io.esz;
+    io.chunk = chunk_steps > 0 ? chunk_steps : std::max<int64_t>(1, (int64_t)(((size_t)256 << 20) / plane));
+    io.chunk = std::max<int64_t>(1, std::min<int64_t>(io.chunk, std::max<int64_t>(T, 1)));
+    const double t0 = now_ms();
+    h->sio = &io;
+    const int rc = track_dev_impl(h, nullptr, f64, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, nullptr, n_tracked);
+    h->sio = nullptr;
+    h->stream_ms[0] = io.ms_read; h->stream_ms[1] = io.ms_write; h->stream_ms[2] = io.ms_in; h->stream_ms[3] = io.ms_out;
+    h->ms[CTK_T_H2D] = io.ms_in; h->ms[CTK_T_D2H] = io.ms_out; h->ms[CTK_T_TOTAL] = now_ms() - t0;
+    return rc;
+}
+
+extern "C" int ctk_track_stream_f32(ctk_handle *h, const float *anom, int64_t T, int ny, int nx, const double *thr, int cmp_op, const float *wrow,
+                                    double overlap, int persistence, int twosided, int32_t *flag, int64_t *n_tracked, int64_t chunk_steps)
+{
+    StreamIO io;
+    io.host_in = anom; io.host_out = flag;
+    return track_stream_impl(h, io, false, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, n_tracked, chunk_steps);
+}
+extern "C" int ctk_track_stream_f64(ctk_handle *h, const double *anom, int64_t T, int ny, int nx, const double *thr, int cmp_op, const float *wrow,
+                                    double overlap, int persistence, int twosided, int32_t *flag, int64_t *n_tracked, int64_t chunk_steps)
+{
+    StreamIO io;
+    io.host_in = anom; io.host_out = flag;
+    return track_stream_impl(h, io, true, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, n_tracked, chunk_steps);
+}
+extern "C" int ctk_track_stream_cb(ctk_handle *h, int elem_bytes, int64_t T, int ny, int nx, ctk_read_chunk_fn reader, void *reader_user, const double *thr,
+                                   int cmp_op, const float *wrow, double overlap, int persistence, int twosided, ctk_write_chunk_fn writer,
+                                   void *writer_user, int64_t *n_tracked, int64_t chunk_steps)
+{
+    if (elem_bytes != 4 && elem_bytes != 8) return ctk_set_error(CTK_E_INVALID, "ctk_track_stream_cb: elem_bytes must be 4 (float32) or 8 (float64)");
+    StreamIO io;
+    io.read = reader; io.read_user = reader_user; io.write = writer; io.write_user = writer_user;
+    return track_stream_impl(h, io, elem_bytes == 8, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, n_tracked, chunk_steps);
+}
+extern "C" int ctk_stream_times(ctk_handle *h, double *ms4)
+{
+    if (!h || !ms4) return ctk_set_error(CTK_E_INVALID, "null argument");
+    for (int i = 0; i < 4; i++) ms4[i] = h->stream_ms[i];
+    return CTK_OK;
+}
+
 // frees the device copies the host-array entries keep between calls (slab + result: twice the slab size) and the bounce lanes
 extern "C" int ctk_release_io(ctk_handle *h)
 {
@@ -1580,6 +1796,7 @@ extern "C" int ctk_release_io(ctk_handle *h)
     for (DevBuf *b : {&h->io_in, &h->io_out, &h->an_out, &h->an_raw}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     h->an_T = -1;
     if (h->bounce) { h->bounce->destroy(); delete h->bounce; h->bounce = nullptr; }
+    stream_teardown(h);
     return CTK_OK;
 }
 

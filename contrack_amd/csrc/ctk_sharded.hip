@@ -866,7 +866,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     }
     {
         Timer tm(h, CTK_K_RELABEL);
-        CTKCHK(launch_relabel(h, persistence, flag_dev, true, cv));
+        CTKCHK((flag_dev || !h->sio) ? launch_relabel(h, persistence, flag_dev, true, cv) : stream_out(h, persistence, cv));
     }
     SHDBG("relabel");
     // ---- X7: counts ---------------------------------------------------------------------------------------------------

@@ -163,6 +163,32 @@ int  ctk_track_sharded_f64_dev(ctk_handle *h, ctk_comm *c, const double *anom_de
                                int ny, int nx, const double *thr, int cmp_op, const float *wrow, double overlap,
                                int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked);
 
+/* ---- next row N4: streaming entries (xr.open_dataset contrack.py:176 -> run_contrack -> to_netcdf README.rst:154) ------------
+ * ctk_track_f32 / _f64 for slabs that should not (or cannot) sit in HBM twice: the slab passes through two chunk-sized device
+ * buffers per direction; only the bit mask (1/32 of the slab) and the run / component tables stay resident between the
+ * two pixel passes.
+ *     chunk k+1 arrives (reader callback / host array -> H2D)   ||   k_threshold(chunk k) -> mask
+ *     labelling, overlap filter, 3-D ids, seam merges, persistence on mask and tables          (nothing of the slab needed)
+ *     k_relabel(chunk k+1)                                      ||   D2H(chunk k) -> writer callback / host array
+ * ctk_track_stream_f32 / _f64: source and sink are host arrays (any size the host holds; device footprint 4 chunks + slab/32).
+ * ctk_track_stream_cb: source and sink are callbacks, e.g. a netCDF variable read / written slice by slice.  The reader fills
+ * `dst` (pinned host memory owned by the library, nt * ny * nx elements of elem_bytes) with timesteps [t0, t0 + nt) and returns 0;
+ * the writer receives the int32 flag values of [t0, t0 + nt) in pinned memory valid during the call and returns 0; a nonzero
+ * return aborts the call with CTK_E_INVALID.  Readers are called in increasing t0, once per chunk -- unless the call meets a
+ * decision on a rounding boundary (CTK_S_EXACT_FIXUPS), in which case the input is streamed a second time.  Writers are called
+ * in increasing t0, once.  chunk_steps = 0: about 256 MB of input per chunk.  Results: identical to ctk_track_*. */
+typedef int (*ctk_read_chunk_fn)(void *user, int64_t t0, int64_t nt, void *dst);
+typedef int (*ctk_write_chunk_fn)(void *user, int64_t t0, int64_t nt, const int32_t *src);
+int ctk_track_stream_f32(ctk_handle *h, const float *anom, int64_t T, int ny, int nx, const double *thr, int cmp_op, const float *wrow,
+                         double overlap, int persistence, int twosided, int32_t *flag, int64_t *n_tracked, int64_t chunk_steps);
+int ctk_track_stream_f64(ctk_handle *h, const double *anom, int64_t T, int ny, int nx, const double *thr, int cmp_op, const float *wrow,
+                         double overlap, int persistence, int twosided, int32_t *flag, int64_t *n_tracked, int64_t chunk_steps);
+int ctk_track_stream_cb(ctk_handle *h, int elem_bytes /* 4: float32, 8: float64 */, int64_t T, int ny, int nx, ctk_read_chunk_fn reader,
+                        void *reader_user, const double *thr, int cmp_op, const float *wrow, double overlap, int persistence, int twosided,
+                        ctk_write_chunk_fn writer, void *writer_user, int64_t *n_tracked, int64_t chunk_steps);
+/* times of the last streaming call: {reader callbacks, writer callbacks, input phase, output phase} in ms */
+int ctk_stream_times(ctk_handle *h, double *ms4);
+
 /* ---- staged-parity / debug accessors (host copies) ------------------------------------------- */
 int ctk_debug_mask(ctk_handle *h, uint8_t *mask /* (T,ny,nx) 0/1 */);
 /* 2-D labels exactly as scipy numbers them at contrack.py:684 (before_seam=1) or after the seam merge

@@ -86,6 +86,11 @@ class DataArray:
         data, dims, coords = self.data, list(self.dims), dict(self.coords)
         for name, i in indexers.items():
             ax = dims.index(name)
+            if isinstance(i, slice):                      # keeps the dimension
+                data = data[(slice(None),) * ax + (i,)]
+                if name in coords:
+                    coords[name] = DataArray(np.asarray(coords[name].data)[i], (name,))
+                continue
             data = np.take(data, i, axis=ax)
             dims.pop(ax)
             if name in coords:

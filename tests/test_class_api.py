@@ -121,6 +121,19 @@ def test_run_contrack_class(name, dims):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dims,chunk", [(("time", "latitude", "longitude"), 4), (("latitude", "longitude", "time"), 3), (("time", "latitude", "longitude"), 0)])
+def test_run_contrack_class_streaming(dims, chunk):
+    """chunk_steps: the variable is read slice by slice (isel) and streamed through the GPU; same flag variable"""
+    ds, g = _dataset("refslab_two", dims)
+    c = contrack(ds=ds)
+    c.run_contrack(variable='anom', threshold=float(g["thr"][0]), gorl=g["gorl"], overlap=g["overlap"], persistence=g["persistence"],
+                   twosided=g["twosided"], chunk_steps=chunk)
+    assert c['flag'].dims == dims
+    order = [dims.index(d) for d in ("time", "latitude", "longitude")]
+    assert np.array_equal(np.asarray(c.flag).transpose(order), g["flag"])
+
+
+@pytest.mark.gpu
 def test_run_contrack_float64_and_dayofyear_threshold():
     g = golden_util.load("thr_vector")
     T = g["anom"].shape[0]

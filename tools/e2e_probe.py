@@ -25,3 +25,34 @@ with _native.Tracker(0) as trk:
     print("host arrays in/out: %.1f ms per call (%.0f timesteps/s; inside the library: H2D %.1f ms = %.1f GB/s, device pass %.2f ms, "
           "D2H %.1f ms = %.1f GB/s; %d tracked)" % (dt * 1e3, T / dt, lib["h2d"], a.nbytes / lib["h2d"] / 1e6, lib["total"] - lib["h2d"] - lib["d2h"],
                                                     lib["d2h"], a.nbytes / lib["d2h"] / 1e6, n))
+    # the streaming entry (next row N4): same arrays, chunked through 4 chunk-sized device buffers
+    want = keep[-1]
+    del keep[:-1]
+    for chunk in (0, max(1, T // 16), max(1, T // 4)):
+        for _ in range(2):
+            f, n2 = trk.track_stream(a, thr, 0, w, 0.5, 5, True, chunk_steps=chunk)
+        res, dt = [], 0.0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            f, n2 = trk.track_stream(a, thr, 0, w, 0.5, 5, True, chunk_steps=chunk)
+            dt += time.perf_counter() - t0
+            res.append(f)
+        dt /= 3
+        ms = trk.stream_times()
+        print("streaming, chunk %5d steps: %.1f ms per call (%.0f timesteps/s; input phase %.1f ms, output phase %.1f ms); equal: %s"
+              % (chunk, dt * 1e3, T / dt, ms["input_phase"], ms["output_phase"], bool(np.array_equal(f, want) and n2 == n)))
+        del res
+    # reader / writer callbacks copying from / into numpy arrays (the cost floor of a Python-side netCDF reader)
+    out = np.empty_like(want)
+
+    def reader(t0, nt, dst):
+        dst[...] = a[t0:t0 + nt]
+
+    def writer(t0, nt, flags):
+        out[t0:t0 + nt] = flags
+    for _ in range(2):
+        t0 = time.perf_counter()
+        trk.track_stream(reader, thr, 0, w, 0.5, 5, True, sink=writer, shape=a.shape, dtype=a.dtype)
+        dt = time.perf_counter() - t0
+    ms = trk.stream_times()
+    print("streaming through Python callbacks: %.1f ms (reader %.1f ms, writer %.1f ms); equal: %s" % (dt * 1e3, ms["reader"], ms["writer"], bool(np.array_equal(out, want))))
