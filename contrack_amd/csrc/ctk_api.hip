@@ -2056,27 +2056,38 @@ extern "C" int ctk_lifecycle_exact(ctk_handle *h, const int64_t *row_idx, int64_
         keys[(size_t)i] = CtkLifeKey{r.t, r.label, r.shift, r.pad};
     }
     CTKCHK(ensure(h, h->lc_ekeys, (size_t)n * sizeof(CtkLifeKey)));
-    CTKCHK(ensure(h, h->lc_offs, (size_t)n * 8));
+    CTKCHK(ensure(h, h->lc_offs, (size_t)n * 16));                           // pixel offsets, row-table offsets
     CTKCHK(ensure(h, h->lc_out, (size_t)n * sizeof(CtkLifeExact)));
     HIPCHK(hipMemcpy(h->lc_ekeys.p, keys.data(), (size_t)n * sizeof(CtkLifeKey), hipMemcpyHostToDevice));
     uint32_t *d_counts = (uint32_t *)h->lc_out.p;                            // (reused below for the results)
-    k_life_count<<<(unsigned)n, 64, 0, s>>>(h->lc_flag, P<CtkLifeKey>(h->lc_ekeys), h->lc_ny, h->lc_nx, d_counts);
+    k_life_count<<<(unsigned)n, 256, 0, s>>>(h->lc_flag, P<CtkLifeKey>(h->lc_ekeys), h->lc_ny, h->lc_nx, d_counts);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> counts((size_t)n);
     HIPCHK(hipMemcpyAsync(counts.data(), d_counts, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    std::vector<uint64_t> offs((size_t)n);
-    uint64_t total = 0;
-    for (int64_t i = 0; i < n; ++i) { offs[(size_t)i] = total; total += counts[(size_t)i]; }
-    CTKCHK(ensure(h, h->lc_sw, (size_t)std::max<uint64_t>(total, 1) * 8));
-    CTKCHK(ensure(h, h->lc_sp, (size_t)std::max<uint64_t>(total, 1) * 8));
-    HIPCHK(hipMemcpy(h->lc_offs.p, offs.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    std::vector<uint64_t> offs((size_t)2 * n);
+    uint64_t total = 0, rtotal = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        offs[(size_t)i] = total; total += counts[(size_t)i];
+        const uint32_t pad = (uint32_t)keys[(size_t)i].pad;
+        const int ya = (int)(pad & 0xffffu), yb = std::min(h->lc_ny - 1, (int)(pad >> 16));
+        if (yb < ya) return ctk_set_error(CTK_E_INTERNAL, "ctk_lifecycle_exact: row %lld has no row extent", (long long)row_idx[i]);
+        offs[(size_t)(n + i)] = rtotal; rtotal += 3 * (uint64_t)(yb - ya + 1);
+    }
+    const size_t px = (size_t)std::max<uint64_t>(total, 1) * 8;
+    CTKCHK(ensure(h, h->lc_sw, 5 * px));                                      // sw | sp | sq | sqy | sqx
+    CTKCHK(ensure(h, h->lc_sp, (size_t)std::max<uint64_t>(rtotal, 1) * 4));   // the row tables
+    HIPCHK(hipMemcpy(h->lc_offs.p, offs.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    double *d_sw = P<double>(h->lc_sw);
+    const size_t st = px / 8;
     if (h->lc_f64)
-        k_life_exact<double><<<(unsigned)n, 64, 0, s>>>(h->lc_flag, (const double *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),
-                                                        h->lc_ny, h->lc_nx, P<double>(h->lc_sw), P<double>(h->lc_sp), P<CtkLifeExact>(h->lc_out));
+        k_life_exact<double><<<(unsigned)n, 256, 0, s>>>(h->lc_flag, (const double *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),
+                                                         P<uint64_t>(h->lc_offs) + n, h->lc_ny, h->lc_nx, d_sw, d_sw + st, d_sw + 2 * st, d_sw + 3 * st, d_sw + 4 * st,
+                                                         P<uint32_t>(h->lc_sp), P<CtkLifeExact>(h->lc_out));
     else
-        k_life_exact<float><<<(unsigned)n, 64, 0, s>>>(h->lc_flag, (const float *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),
-                                                       h->lc_ny, h->lc_nx, P<double>(h->lc_sw), P<double>(h->lc_sp), P<CtkLifeExact>(h->lc_out));
+        k_life_exact<float><<<(unsigned)n, 256, 0, s>>>(h->lc_flag, (const float *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),
+                                                        P<uint64_t>(h->lc_offs) + n, h->lc_ny, h->lc_nx, d_sw, d_sw + st, d_sw + 2 * st, d_sw + 3 * st, d_sw + 4 * st,
+                                                        P<uint32_t>(h->lc_sp), P<CtkLifeExact>(h->lc_out));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, h->lc_out.p, (size_t)n * sizeof(CtkLifeExact), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

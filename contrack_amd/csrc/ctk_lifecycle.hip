@@ -695,35 +695,55 @@ __device__ inline double dev_np_leaf(const double *a, uint32_t n)
     for (; i < n; i++) res += a[i];
     return res;
 }
-__device__ inline double dev_np_sum(const double *a, size_t n)
+// post-order walk of numpy's halving tree over a block of cn <= 8192 elements; leaf(offset, n) is called for the leaves
+// (n <= 128) in order and returns their sums.  The frame stack lives where the caller puts it (LDS: a dynamically indexed
+// private array would sit in scratch memory, i.e. one HBM round trip per access)
+struct NpFrame { uint32_t off, n, st, pad; double l; };       // {offset, n, state, value of the left child}
+template <typename Leaf>
+__device__ inline double np_walk(uint32_t cn, Leaf leaf, NpFrame *f)
+{
+    int sp = 1;
+    f[0].off = 0; f[0].n = cn; f[0].st = 0;
+    double val = 0.0;
+    bool have = false;
+    while (sp > 0) {
+        const int k = sp - 1;
+        if (!have) {
+            if (f[k].n <= 128u) { val = leaf(f[k].off, f[k].n); have = true; sp--; continue; }
+            uint32_t n2 = f[k].n / 2; n2 -= n2 % 8u;
+            f[k].st = 1;
+            f[sp].off = f[k].off; f[sp].n = n2; f[sp].st = 0; sp++;
+            continue;
+        }
+        // a child of frame k has just finished with `val`
+        if (f[k].st == 1) {
+            uint32_t n2 = f[k].n / 2; n2 -= n2 % 8u;
+            f[k].l = val; f[k].st = 2; have = false;
+            f[sp].off = f[k].off + n2; f[sp].n = f[k].n - n2; f[sp].st = 0; sp++;
+        } else { val = f[k].l + val; sp--; }
+    }
+    return val;
+}
+// the same sum by a workgroup of 256: thread 0 lists the leaves of a block, the threads sum one leaf each, thread 0 combines them
+// in the tree's order.  Result valid in thread 0.  lo / ln / lv: LDS scratch for 128 leaves.
+__device__ inline double wg_np_sum(const double *a, size_t n, uint32_t *lo, uint32_t *ln, double *lv, int *nleaf, NpFrame *frames)
 {
     double acc = 0.0;
     for (size_t c0 = 0; c0 < n; c0 += 8192) {
         const uint32_t cn = (uint32_t)(n - c0 < 8192 ? n - c0 : 8192);
-        // post-order walk of the halving tree: frames {offset, n, state, value of the left child}
-        uint32_t f_off[16], f_n[16], f_st[16];
-        double f_l[16];
-        int sp = 1;
-        f_off[0] = 0; f_n[0] = cn; f_st[0] = 0;
-        double val = 0.0;
-        bool have = false;
-        while (sp > 0) {
-            const int k = sp - 1;
-            if (!have) {
-                if (f_n[k] <= 128u) { val = dev_np_leaf(a + c0 + f_off[k], f_n[k]); have = true; sp--; continue; }
-                uint32_t n2 = f_n[k] / 2; n2 -= n2 % 8u;
-                f_st[k] = 1;
-                f_off[sp] = f_off[k]; f_n[sp] = n2; f_st[sp] = 0; sp++;
-                continue;
-            }
-            // a child of frame k has just finished with `val`
-            if (f_st[k] == 1) {
-                uint32_t n2 = f_n[k] / 2; n2 -= n2 % 8u;
-                f_l[k] = val; f_st[k] = 2; have = false;
-                f_off[sp] = f_off[k] + n2; f_n[sp] = f_n[k] - n2; f_st[sp] = 0; sp++;
-            } else { val = f_l[k] + val; sp--; }
+        if (threadIdx.x == 0) {
+            int k = 0;
+            (void)np_walk(cn, [&](uint32_t off, uint32_t m) { lo[k] = off; ln[k] = m; k++; return 0.0; }, frames);
+            *nleaf = k;
         }
-        acc += val;
+        __syncthreads();
+        if ((int)threadIdx.x < *nleaf) lv[threadIdx.x] = dev_np_leaf(a + c0 + lo[threadIdx.x], ln[threadIdx.x]);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int k = 0;
+            acc += np_walk(cn, [&](uint32_t, uint32_t) { return lv[k++]; }, frames);
+        }
+        __syncthreads();
     }
     return acc;
 }
@@ -733,76 +753,143 @@ struct CtkLifeKey {
 };
 
 // members of every listed (time step, id)
-__global__ __launch_bounds__(64) void k_life_count(const int32_t *__restrict__ flag, const CtkLifeKey *__restrict__ keys, int ny, int nx, uint32_t *__restrict__ counts)
+__global__ __launch_bounds__(256) void k_life_count(const int32_t *__restrict__ flag, const CtkLifeKey *__restrict__ keys, int ny, int nx, uint32_t *__restrict__ counts)
 {
+    __shared__ uint32_t part[4];
     const CtkLifeKey k = keys[blockIdx.x];
     const uint32_t npx = (uint32_t)ny * (uint32_t)nx;
     const int32_t *fp = flag + (int64_t)k.t * npx;
     uint32_t c = 0;
     const uint32_t pa = ((uint32_t)k.pad & 0xffffu) * (uint32_t)nx, pb = min(npx, (((uint32_t)k.pad >> 16) + 1u) * (uint32_t)nx);
-    for (uint32_t p = pa + threadIdx.x; p < pb; p += 64) c += fp[p] == k.label ? 1u : 0u;
+    for (uint32_t p = pa + threadIdx.x; p < pb; p += 4 * 256) {               // four loads in flight per lane (latency-bound scan)
+        int32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (p + u * 256 < pb) ? fp[p + u * 256] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c += (p + u * 256 < pb && v[u] == k.label) ? 1u : 0u;
+    }
     c = wave_sum_u32(c);
-    if (threadIdx.x == 0) counts[blockIdx.x] = c;
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
+// One workgroup per listed row.  rowtab (per key, 2 * nrows words): pixels of the id per row -> their offset in the compact
+// lists, and how many of them lie left of the roll edge.  sw / sp: the weights and products in raster order of the plane (what
+// np.sum sees, contrack.py:874-875); sq / sqy / sqx: p, p*y, p*x' in raster order of the ROLLED plane (np.bincount's order inside
+// ndimage.center_of_mass, :886 / :892).
+#define LX_STAGE 1024
 template <typename VT>
-__global__ __launch_bounds__(64) void k_life_exact(const int32_t *__restrict__ flag, const VT *__restrict__ field, const float *__restrict__ wrow,
-                                                   const CtkLifeKey *__restrict__ keys, const uint64_t *__restrict__ offs, int ny, int nx,
-                                                   double *__restrict__ sw, double *__restrict__ sp_, CtkLifeExact *__restrict__ out)
+__global__ __launch_bounds__(256) void k_life_exact(const int32_t *__restrict__ flag, const VT *__restrict__ field, const float *__restrict__ wrow,
+                                                    const CtkLifeKey *__restrict__ keys, const uint64_t *__restrict__ offs, const uint64_t *__restrict__ roffs,
+                                                    int ny, int nx, double *__restrict__ sw, double *__restrict__ sp_, double *__restrict__ sq,
+                                                    double *__restrict__ sqy, double *__restrict__ sqx, uint32_t *__restrict__ rowtab,
+                                                    CtkLifeExact *__restrict__ out)
 {
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t lo[128], ln[128];
+    __shared__ double lv[128];
+    __shared__ int nleaf;
+    __shared__ NpFrame frames[16];
+    __shared__ double stage[3][LX_STAGE];
+    __shared__ double res[5];
     const CtkLifeKey k = keys[blockIdx.x];
     const uint32_t npx = (uint32_t)ny * (uint32_t)nx;
     const int32_t *fp = flag + (int64_t)k.t * npx;
     const VT *vp = field + (int64_t)k.t * npx;
-    const int lane = (int)threadIdx.x;
-    double *gw = sw + offs[blockIdx.x], *gp = sp_ + offs[blockIdx.x];
-    // A: the row weights and the products of the id's pixels, raster order -> scratch (what weight_grid[mask] and
-    //    weight_grid[mask] * variable[mask] hand to np.sum, contrack.py:874-875)
-    uint32_t pos = 0;
-    const int ya = (int)((uint32_t)k.pad & 0xffffu), yb = min(ny - 1, (int)((uint32_t)k.pad >> 16));       // rows that can hold the id
-    for (uint32_t p0 = (uint32_t)ya * (uint32_t)nx; p0 < ((uint32_t)yb + 1u) * (uint32_t)nx; p0 += 64) {
-        const uint32_t p = p0 + lane;
-        const bool m = p < ((uint32_t)yb + 1u) * (uint32_t)nx && fp[p] == k.label;
-        const uint64_t bal = __ballot(m);
-        if (!bal) continue;
-        if (m) {
-            const int y = (int)(p / (uint32_t)nx);
-            const double w = (double)wrow[y];
-            const uint32_t at = pos + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            gw[at] = w;
-            gp[at] = w * (double)vp[p];
-        }
-        pos += (uint32_t)__popcll(bal);
-    }
-    // B: ndimage.center_of_mass = np.bincount: strictly sequential over the (rolled) plane in raster order
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ya = (int)((uint32_t)k.pad & 0xffffu), yb = min(ny - 1, (int)((uint32_t)k.pad >> 16)), nrows = yb - ya + 1;
     const int shift = k.shift > 0 ? k.shift : 0;
-    double s = 0.0, sy = 0.0, sx = 0.0;
-    for (int y = ya; y <= yb; y++) {
-        const double w = (double)wrow[y];
-        for (int x0 = 0; x0 < nx; x0 += 64) {
-            const int xr = x0 + lane;                                  // column in the rolled frame
-            int x = xr + shift;
-            if (x >= nx) x -= nx;
-            const bool m = xr < nx && fp[(uint32_t)y * (uint32_t)nx + (uint32_t)x] == k.label;
-            uint64_t bal = __ballot(m);
-            if (!bal) continue;
-            const double pv = m ? (double)vp[(uint32_t)y * (uint32_t)nx + (uint32_t)x] * w : 0.0;      // variable * weight_grid (:886 / :892)
-            while (bal) {
-                const int b = __builtin_ctzll(bal);
-                bal &= bal - 1;
-                const double q = __shfl(pv, b);
-                s += q;
-                sy += q * (double)y;
-                sx += q * (double)(x0 + b);
+    double *gw = sw + offs[blockIdx.x], *gp = sp_ + offs[blockIdx.x], *gq = sq + offs[blockIdx.x], *gqy = sqy + offs[blockIdx.x], *gqx = sqx + offs[blockIdx.x];
+    uint32_t *rcnt = rowtab + roffs[blockIdx.x], *rleft = rcnt + nrows, *roff = rleft + nrows;
+
+    // A: per row the id's pixels, and those left of the roll edge (one wave per row, round robin)
+    for (int r = wave; r < nrows; r += 4) {
+        const int32_t *rp = fp + (size_t)(ya + r) * nx;
+        uint32_t c = 0, cl = 0;
+        for (int x0 = 0; x0 < nx; x0 += 4 * 64) {                            // four loads in flight per lane
+            int32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int x = x0 + u * 64 + lane; v[u] = x < nx ? rp[x] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int x = x0 + u * 64 + lane;
+                const bool m = x < nx && v[u] == k.label;
+                c += (uint32_t)__popcll(__ballot(m));
+                cl += (uint32_t)__popcll(__ballot(m && x < shift));
             }
         }
+        if (lane == 0) { rcnt[r] = c; rleft[r] = cl; }
     }
-    __threadfence();
-    if (lane == 0) {
+    __syncthreads();
+    // B: exclusive scan of the row counts
+    {
+        const int per = (nrows + 255) / 256, r0 = tid * per, r1 = min(nrows, r0 + per);
+        uint32_t sum = 0;
+        for (int r = r0; r < r1; ++r) sum += rcnt[r];
+        part[tid] = sum;
+        __syncthreads();
+        if (tid == 0) { uint32_t run = 0; for (int i = 0; i < 256; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; } }
+        __syncthreads();
+        uint32_t run = part[tid];
+        for (int r = r0; r < r1; ++r) { roff[r] = run; run += rcnt[r]; }
+    }
+    __syncthreads();
+    const size_t total = (size_t)roff[nrows - 1] + rcnt[nrows - 1];
+    // C: the compact lists.  Rolled row = the pixels right of the edge (x >= shift) first, then those left of it.
+    for (int r = wave; r < nrows; r += 4) {
+        const int y = ya + r;
+        const int32_t *rp = fp + (size_t)y * nx;
+        const VT *rv = vp + (size_t)y * nx;
+        const double w = (double)wrow[y];
+        const uint32_t base = roff[r], nleft = rleft[r], nright = rcnt[r] - nleft;
+        if (rcnt[r] == 0) continue;                                        // (wave-uniform)
+        uint32_t seen = 0;
+        for (int xq = 0; xq < nx; xq += 4 * 64) {
+          int32_t v4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int x = xq + u * 64 + lane; v4[u] = x < nx ? rp[x] : 0; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int x = xq + u * 64 + lane;
+            const bool m = x < nx && v4[u] == k.label;
+            const uint64_t bal = __ballot(m);
+            if (!bal) continue;
+            if (m) {
+                const uint32_t idx = seen + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                const double p = (double)rv[x] * w;                       // variable * weight_grid (:886 / :892) = weight_grid * variable (:875)
+                gw[base + idx] = w;
+                gp[base + idx] = p;
+                int xr = x - shift;
+                uint32_t pos;
+                if (xr < 0) { xr += nx; pos = nright + idx; } else pos = idx - nleft;
+                gq[base + pos] = p;
+                gqy[base + pos] = p * (double)y;
+                gqx[base + pos] = p * (double)xr;
+            }
+            seen += (uint32_t)__popcll(bal);
+          }
+        }
+    }
+    __syncthreads();
+    // D: np.sum over the raster-order lists
+    const double area = wg_np_sum(gw, total, lo, ln, lv, &nleaf, frames);
+    const double swv = wg_np_sum(gp, total, lo, ln, lv, &nleaf, frames);
+    if (tid == 0) { res[0] = area; res[1] = swv; }
+    // E: np.bincount's strictly sequential sums over the rolled lists: blocks staged in LDS, one lane per sum
+    double acc = 0.0;
+    for (size_t c0 = 0; c0 < total; c0 += LX_STAGE) {
+        const int cn = (int)min((size_t)LX_STAGE, total - c0);
+        for (int i = tid; i < cn; i += 256) { stage[0][i] = gq[c0 + i]; stage[1][i] = gqy[c0 + i]; stage[2][i] = gqx[c0 + i]; }
+        __syncthreads();
+        if (lane == 0 && wave < 3) { const double *sv = stage[wave]; for (int i = 0; i < cn; ++i) acc += sv[i]; }
+        __syncthreads();
+    }
+    if (lane == 0 && wave < 3) res[2 + wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
         CtkLifeExact r;
-        r.area = dev_np_sum(gw, pos);
-        r.swv = dev_np_sum(gp, pos);
-        r.s = s; r.sy = sy; r.sx = sx;
+        r.area = res[0]; r.swv = res[1]; r.s = res[2]; r.sy = res[3]; r.sx = res[4];
         out[blockIdx.x] = r;
     }
 }

@@ -17,6 +17,7 @@ import atexit
 import ctypes as C
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -92,10 +93,22 @@ def init_comm(tracker, rank, world, backend=None):
     """the communicator of this rank: RCCL (default) or the shared-memory transport"""
     backend = backend or os.environ.get("CTK_DIST_BACKEND", "rccl")
     if backend == "rccl":
-        uid = broadcast_bytes(rank, _native.comm_unique_id, _native.COMM_ID_BYTES)
-        return _native.Comm.rccl(tracker, uid, rank, world)
+        def make_id():
+            try:
+                return _native.comm_unique_id()
+            except _native.ContrackHipError as e:          # librccl.so cannot be loaded / refuses to start on this node
+                sys.stderr.write("contrack_amd.dist: RCCL is not usable here (%s); all ranks use the shared-memory transport\n" % e)
+                return bytes(_native.COMM_ID_BYTES)         # the all-zero id tells every rank the same thing
+        uid = broadcast_bytes(rank, make_id, _native.COMM_ID_BYTES)
+        if uid != bytes(_native.COMM_ID_BYTES):
+            c = _native.Comm.rccl(tracker, uid, rank, world)
+            c.transport = "rccl"
+            return c
+        backend = "shm"
     if backend == "shm":
-        return _native.Comm.shm(tracker, "ctk_%s" % launch_key(), rank, world)
+        c = _native.Comm.shm(tracker, "ctk_%s" % launch_key(), rank, world)
+        c.transport = "shm"
+        return c
     raise ValueError("CTK_DIST_BACKEND must be 'rccl' or 'shm', not %r" % backend)
 
 
@@ -108,7 +121,9 @@ class ShardedTracker:
         self.rank = r if rank is None else int(rank)
         self.world = w if world is None else int(world)
         backend = backend or os.environ.get("CTK_DIST_BACKEND", "rccl")
-        self.device = (local if backend == "rccl" else 0) if device is None else int(device)
+        ndev = max(1, _native.device_count())
+        # RCCL wants one device per rank; the shared-memory transport also runs several ranks on one device (tests on a 1-GPU box)
+        self.device = (local if backend == "rccl" else local % ndev) if device is None else int(device)
         self.trk = _native.Tracker(self.device)
         self.comm = init_comm(self.trk, self.rank, self.world, backend)
 
@@ -150,6 +165,7 @@ def bench_main(args, wl, workloads, hbm_peak):
     backend = os.environ.get("CTK_DIST_BACKEND", "rccl")
     st = ShardedTracker(rank=rank, world=world, backend=backend)
     trk, comm = st.trk, st.comm
+    backend = getattr(comm, "transport", backend)              # (shm if RCCL could not be loaded)
     T, ny, nx = wl["T"], wl["ny"], wl["nx"]
     weak = getattr(args, "scaling", "weak") == "weak"
     if weak:
@@ -211,7 +227,7 @@ def bench_main(args, wl, workloads, hbm_peak):
                        wl["threshold"], wl["overlap"], wl["persistence"], wl["twosided"]),
                        total_timesteps=T_total,
                        parallelism="time-sharded x%d: one-timestep halo + boundary records, shard-local resolver (%s)" % (
-                           world, "RCCL ncclSend/Recv + ncclAllGather" if backend == "rccl" else "shared-memory transport, ONE GPU shared: timings not meaningful"),
+                           world, "RCCL ncclSend/Recv + ncclAllGather" if backend == "rccl" else "shared-memory transport (host staging; several ranks may share a GPU)"),
                        transport=backend, rccl_ranks=world if backend == "rccl" else 0, n_tracked=n_tracked,
                        collectives_per_step=dict(neighbour_exchanges=(ops1["neighbour_exchanges"] - ops0["neighbour_exchanges"]) / nsteps,
                                                  allgathers=(ops1["allgathers"] - ops0["allgathers"]) / nsteps)),
