@@ -43,6 +43,27 @@ __global__ __launch_bounds__(256) void k_write(i4 *__restrict__ out, int64_t n4)
     }
 }
 
+// relabel-shaped write: a one-shot grid, every workgroup writes S consecutive int4 per thread (its own contiguous block), optionally
+// after a "table" phase like k_relabel_v4's (1 KB per workgroup from a table in HBM -> LDS -> barrier; the stored value depends on it)
+template <int S, bool TABLES>
+__global__ __launch_bounds__(256) void k_write_blocks(i4 *__restrict__ out, int64_t n4, const int *__restrict__ table)
+{
+    __shared__ int lds[256];
+    int add = 0;
+    if (TABLES) {
+        lds[threadIdx.x] = table[((int64_t)blockIdx.x * 256 + threadIdx.x) & ((16 << 20) - 1)];
+        __syncthreads();
+        add = lds[(threadIdx.x * 7) & 255];
+    }
+    const int64_t base = (int64_t)blockIdx.x * 256 * S;
+    const i4 z = (i4)(add);
+#pragma unroll
+    for (int u = 0; u < S; u++) {
+        const int64_t j = base + (int64_t)u * 256 + threadIdx.x;
+        if (j < n4) __builtin_nontemporal_store(z, &out[j]);
+    }
+}
+
 template <typename F>
 double time_ms(F f, int reps)
 {
@@ -86,6 +107,18 @@ int main()
         double r = time_ms([&] { k_read<1, false><<<g, 256>>>((f4 *)buf, n4, sink); }, 20);
         double w = time_ms([&] { k_write<1, false><<<g, 256>>>((i4 *)buf, n4); }, 20);
         printf("one-shot grid %d: read %.0f GB/s write %.0f GB/s\n", g, gb / r * 1e3, gb / w * 1e3);
+    }
+    // how many stores per thread a short-lived workgroup should issue, and what a table phase in front costs
+    {
+        int *table = nullptr;
+        hipMalloc((void **)&table, (size_t)(16 << 20) * 4);
+        hipMemset(table, 0, (size_t)(16 << 20) * 4);
+#define WB(S) do { const int g = (int)((n4 + 256 * S - 1) / (256 * S)); \
+        double a = time_ms([&] { k_write_blocks<S, false><<<g, 256>>>((i4 *)buf, n4, table); }, 20); \
+        double b = time_ms([&] { k_write_blocks<S, true><<<g, 256>>>((i4 *)buf, n4, table); }, 20); \
+        printf("write blocks, %2d stores/thread (%6d workgroups): %.0f GB/s; with a table phase in front: %.0f GB/s\n", S, g, gb / a * 1e3, gb / b * 1e3); } while (0)
+        WB(1); WB(2); WB(3); WB(4); WB(6); WB(8); WB(16); WB(32);
+        hipFree(table);
     }
     hipFree(buf);
     return 0;
