@@ -727,6 +727,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     uint32_t capC = std::max<uint32_t>(hint_c, 256), capD = std::max<uint32_t>(hint_d, 256);
     struct SeamHeader { uint32_t ncand, nlab, pad0, pad1; };
     size_t sslot = 0;
+    bool local_done = false;
     for (;;) {
         sslot = sizeof(SeamHeader) + (size_t)capC * sizeof(CtkCand) + (size_t)capD * 28;
         CTKCHK(ensure_host(&h->h_seam, &h->h_seam_cap, sslot * (size_t)(world + 1), true));
@@ -748,6 +749,16 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         HIPCHK(hipMemcpyAsync(h->sh_send.p, sb, sslot, hipMemcpyHostToDevice, s));
         CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, sslot));
         HIPCHK(hipMemcpyAsync(sb + sslot, h->sh_recv.p, sslot * (size_t)world, hipMemcpyDeviceToHost, s));
+        if (!local_done) {
+            // while the shared groups travel: this shard's own groups (dense ids renumbered without the shared labels), driven here
+            local_done = true;
+            S.lmap.assign(nd, -1); S.lorig.clear(); S.lbox.clear(); S.lcand.clear();
+            for (size_t i = 0; i < nd; i++)
+                if (!S.isglob[(size_t)find((int32_t)i)]) { S.lmap[i] = (int32_t)S.lorig.size(); S.lorig.push_back(ho[i]); S.lbox.insert(S.lbox.end(), hbx + 6 * i, hbx + 6 * i + 6); }
+            for (int64_t k = 0; k < ncand; k++)
+                if (!S.isglob[(size_t)find(hc[k].ll)]) { CtkCand v = hc[k]; v.ll = S.lmap[(size_t)v.ll]; v.lr = S.lmap[(size_t)v.lr]; S.lcand.push_back(v); }
+            h->sd.run(S.lcand.data(), (int64_t)S.lcand.size(), S.lorig.data(), S.lbox.data(), (int64_t)S.lorig.size(), nx, S.ops_l);
+        }
         HIPCHK(hipStreamSynchronize(s));
         uint32_t mc = 0, md = 0;
         for (int q = 0; q < world; q++) {
@@ -792,13 +803,6 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         }
     }
     h->sd_glob.run(S.gcand.data(), (int64_t)S.gcand.size(), S.glabel.data(), S.gbox.data(), (int64_t)S.glabel.size(), nx, S.ops_g);
-    // this shard's own groups: dense ids renumbered without the shared labels
-    S.lmap.assign(nd, -1); S.lorig.clear(); S.lbox.clear(); S.lcand.clear();
-    for (size_t i = 0; i < nd; i++)
-        if (!S.isglob[(size_t)find((int32_t)i)]) { S.lmap[i] = (int32_t)S.lorig.size(); S.lorig.push_back(ho[i]); S.lbox.insert(S.lbox.end(), hbx + 6 * i, hbx + 6 * i + 6); }
-    for (int64_t k = 0; k < ncand; k++)
-        if (!S.isglob[(size_t)find(hc[k].ll)]) { CtkCand v = hc[k]; v.ll = S.lmap[(size_t)v.ll]; v.lr = S.lmap[(size_t)v.lr]; S.lcand.push_back(v); }
-    h->sd.run(S.lcand.data(), (int64_t)S.lcand.size(), S.lorig.data(), S.lbox.data(), (int64_t)S.lorig.size(), nx, S.ops_l);
     h->stats[9] = h->sd.loop_ns + h->sd_glob.loop_ns; h->stats[10] = h->sd.nfold + h->sd_glob.nfold;
     h->stats[CTK_S_OPS] = (int64_t)(S.ops_g.size() + S.ops_l.size());
     h->stats[CTK_S_SHARED_ROWS] = (int64_t)S.gcand.size();
