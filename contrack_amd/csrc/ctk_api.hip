@@ -1079,7 +1079,7 @@ static int rs_prepare(ctk_handle *h, const ResolveIn &in, double overlap, int tw
     CTKCHK(ensure(h, h->rv_changed, (size_t)(CTK_MAX_JACOBI + 8) * CTK_CHG_SLOTS * 4));
     CTKCHK(ensure(h, h->rv_parent, R * 4)); CTKCHK(ensure(h, h->rv_isroot, R * 4)); CTKCHK(ensure(h, h->rv_rank, (R + 1) * 4));
     CTKCHK(ensure(h, h->rv_lab, R * 4));
-    const int nsb = (int)((R + CTK_SCAN_ITEMS - 1) / CTK_SCAN_ITEMS);
+    const int nsb = (int)((R + 255) / 256);                                   // blocks of the rank scan (k_rs_roots / k_rs_rank)
     CTKCHK(ensure(h, h->rv_bsum, (size_t)nsb * 4)); CTKCHK(ensure(h, h->rv_boff, (size_t)(nsb + 1) * 4));
     CTKCHK(ensure(h, h->rv_cand_cnt, (size_t)T * 4)); CTKCHK(ensure(h, h->rv_cand_off, (size_t)(T + 1) * 4));
     CTKCHK(ensure(h, h->rv_cand, (size_t)std::max<int64_t>(in.seam_cap, 1) * sizeof(CtkCand)));
@@ -1160,11 +1160,9 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         it_done += ROUND;
         if (it_done > ROUND) k_rs_parent_init<<<gc, 256, 0, s>>>(r);          // the first round's parents were set by k_rs_init
         k_rs_unite<<<gp, 256, 0, s>>>(r);
-        k_rs_roots<<<gc, 256, 0, s>>>(r);
         const uint32_t *ncp = in.cprefix + T;
-        k_scan_blocksum<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_bsum));
-        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_bsum), nsb, P<uint32_t>(h->rv_boff), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
-        k_scan_apply<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_boff), r.rank);
+        k_rs_roots<<<nsb, 256, 0, s>>>(r, P<uint32_t>(h->rv_bsum));                       // (nsb blocks of 256 components)
+        k_rs_rank<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_bsum), r.rank, P<uint32_t>(h->rv_boff) + nsb);
         k_rs_labels<<<gc, 256, 0, s>>>(r);
         if (T > 0) {
             k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, h->ny, P<uint8_t>(h->rv_mark), P<int2>(h->rv_seam_res));

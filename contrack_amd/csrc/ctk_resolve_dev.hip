@@ -350,52 +350,53 @@ __global__ void k_rs_unite(ResolveDev r)
     }
 }
 
-__global__ void k_rs_roots(ResolveDev r)
+// one component per thread; bsum[block] = surviving roots among the block's components (first half of the rank scan)
+__global__ __launch_bounds__(256) void k_rs_roots(ResolveDev r, uint32_t *__restrict__ bsum)
 {
     const uint32_t nc = dev_ncomps(r);
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    uint32_t isr = 0;
+    if (g < nc) {
         const int32_t t = (int32_t)r.comp_t[g];            // -1: halo component
         const bool kept = r.keep0[r.cprefix[t] + r.mrep[g]] != 0;
         const uint32_t root = gfind(r.parent, g);
         r.lab[g] = kept ? (int32_t)root : -1;               // temporarily: root index, -1 = filtered out
-        r.isroot[g] = (kept && root == g && g >= (r.nh_ptr ? *r.nh_ptr : 0u)) ? 1u : 0u;       // (a halo root is numbered by an earlier shard)
+        isr = (kept && root == g && g >= (r.nh_ptr ? *r.nh_ptr : 0u)) ? 1u : 0u;       // (a halo root is numbered by an earlier shard)
+        r.isroot[g] = isr;
         // labels <= components: candidate mark / dense-id slot g+1 are initialised here
         r.mark[g + 1] = 0;
         r.dmap[g + 1] = 0;
         r.op_first[g + 1] = -1;
         if (g == 0) { *r.dcount = 0; r.op_first[0] = -1; }
     }
+    const int tot = __syncthreads_count((int)isr);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = (uint32_t)tot;
 }
 
-// generic multi-block exclusive scan of a uint32 vector whose length lives on the device:
-//   pass 1: per-block sums (2048 items per block)   pass 2: k_scan_u32 over the block sums   pass 3: apply
-#define CTK_SCAN_ITEMS 2048
-__global__ __launch_bounds__(256) void k_scan_blocksum(const uint32_t *__restrict__ in, const uint32_t *n_ptr, uint32_t *__restrict__ bsum)
+// rank[g] = surviving roots before g (second half: every block sums the block counts in front of it itself -- a few hundred
+// values -- instead of waiting for a separate scan launch); rank[n] and *total = their number.  Same partition as k_rs_roots.
+__global__ __launch_bounds__(256) void k_rs_rank(const uint32_t *__restrict__ isroot, const uint32_t *n_ptr, const uint32_t *__restrict__ bsum,
+                                                 uint32_t *__restrict__ rank, uint32_t *__restrict__ total)
 {
-    const uint32_t n = *n_ptr;
-    const uint32_t b0 = blockIdx.x * CTK_SCAN_ITEMS;
+    __shared__ uint32_t sm[8];
+    const uint32_t n = *n_ptr, b = blockIdx.x;
+    const uint32_t nblk = (n + 255u) / 256u;
+    if (b >= nblk && b != 0) return;
+    const uint32_t upto = (b == 0) ? nblk : b;               // block 0 also delivers the grand total
     uint32_t s = 0;
-    for (uint32_t i = b0 + threadIdx.x; i < b0 + CTK_SCAN_ITEMS && i < n; i += 256) s += in[i];
-    __shared__ uint32_t sm[8];
-    uint32_t tot;
-    block_excl_scan(s, sm, &tot);
-    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
-}
-__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__ in, const uint32_t *n_ptr, const uint32_t *__restrict__ boff,
-                                                    uint32_t *__restrict__ out)
-{
-    const uint32_t n = *n_ptr;
-    const uint32_t b0 = blockIdx.x * CTK_SCAN_ITEMS;
-    __shared__ uint32_t sm[8];
-    uint32_t carry = boff[blockIdx.x];
-    for (uint32_t i0 = b0; i0 < b0 + CTK_SCAN_ITEMS; i0 += 256) {
-        const uint32_t i = i0 + threadIdx.x;
-        uint32_t v = (i < n) ? in[i] : 0u, tot;
-        uint32_t ex = block_excl_scan(v, sm, &tot);
-        if (i < n) out[i] = carry + ex;
-        carry += tot;
+    for (uint32_t j = threadIdx.x; j < upto; j += 256) s += bsum[j];
+    uint32_t front;
+    (void)block_excl_scan(s, sm, &front);
+    __syncthreads();
+    if (b == 0) {
+        if (threadIdx.x == 0) { rank[n] = front; *total = front; }
+        front = 0;
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = boff[gridDim.x];     // grand total
+    const uint32_t i = b * 256u + threadIdx.x;
+    const uint32_t v = (i < n) ? isroot[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(v, sm, &tot);
+    if (i < n) rank[i] = front + ex;
 }
 
 // fresh labels: 1 + rank of the root among surviving roots (raster order)

@@ -612,11 +612,9 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     {
         Timer tm(h, CTK_K_RESOLVE);
         k_rs_unite<<<gp, 256, 0, s>>>(r);
-        k_rs_roots<<<gc, 256, 0, s>>>(r);
         const uint32_t *ncp = in.cprefix + T;
-        k_scan_blocksum<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_bsum));
-        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_bsum), nsb, P<uint32_t>(h->rv_boff), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
-        k_scan_apply<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_boff), r.rank);
+        k_rs_roots<<<nsb, 256, 0, s>>>(r, P<uint32_t>(h->rv_bsum));                       // (nsb blocks of 256 components)
+        k_rs_rank<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_bsum), r.rank, P<uint32_t>(h->rv_boff) + nsb);
         k_sh_pack_boundary<<<8, 256, 0, s>>>(r, capB, (unsigned char *)h->sh_send.p);
         HIPCHK(hipGetLastError());
     }
