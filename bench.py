@@ -90,6 +90,50 @@ def cpu_baseline(wl, a, w, budget_s=20.0):
                                   "720x181x360 slab, one core: unmodified reference 9.6 s, port 8.7 s (ratio 1.1, run-to-run noise +-30 %)")
 
 
+def concurrent_members(wl, a, thr, op, w, nh, steps):
+    """nh handles, each tracking its own copy of the slab `steps` times, all at once"""
+    import threading
+    T, ny, nx = wl["T"], wl["ny"], wl["nx"]
+    nbytes = T * ny * nx * 4
+    dev = int(os.environ.get("LOCAL_RANK", "0"))
+    trks = [_native.Tracker(dev) for _ in range(nh)]
+    bufs = []
+    for t in trks:
+        di, do = t.malloc(nbytes), t.malloc(nbytes)
+        if a is not None:
+            t.h2d(di, a)
+        else:
+            t.synth_fill(di, T, ny, nx, seed=0)
+        t.set_timing(0)
+        t.track_dev(di, T, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], do)      # warm-up: work spaces
+        bufs.append((di, do))
+    for t in trks:
+        t.sync()
+    start = threading.Barrier(nh + 1)
+    res = [None] * nh
+
+    def run(i):
+        t, (di, do) = trks[i], bufs[i]
+        start.wait()
+        for _ in range(steps):
+            res[i] = t.track_dev(di, T, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], do)
+        t.sync()
+    th = [threading.Thread(target=run, args=(i,)) for i in range(nh)]
+    for x in th:
+        x.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    for t, (di, do) in zip(trks, bufs):
+        t.free(di)
+        t.free(do)
+        t.close()
+    return dict(handles=nh, passes_each=steps, ms_per_slab=dt * 1e3 / (nh * steps), timesteps_per_s=T * nh * steps / dt, n_tracked=res[0],
+                note="independent slabs on %d handles / streams / host threads of ONE GPU; not the headline value" % nh)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,6 +241,11 @@ def main():
                           d2h_ms=lib["d2h"], d2h_gb_per_s=4.0 * px / lib["d2h"] / 1e6,
                           note="pageable numpy slab in (plain hipMemcpy), fresh numpy flag out (8 threads draining pinned bounce buffers: the "
                                "copy is bound by first-touch page faults of the result array) over PCIe; includes the %.2f ms device pass" % ms_per_step)
+    # ensemble members side by side: four handles (own streams and work spaces) driven by four host threads on this one GPU.
+    # Not `value` (that is one pass after the other on one handle): what a job with many independent slabs -- BASELINE.json
+    # configs[4], 35 members -- gets from the latency-bound middle of one pass running underneath the streaming of another.
+    if not args.no_extra and nbytes * 8 < (64 << 30):
+        out["concurrent_members"] = concurrent_members(wl, a, thr, op, w, 4, max(args.steps // 2, 4))
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, a, w)
     print(json.dumps(out))
