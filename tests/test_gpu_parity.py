@@ -81,6 +81,10 @@ CASES_VS_ORACLE = [
     (1, 91, 180, 8, "smooth", 150.0, ">=", 0.5, 1, True),            # T = 1 (the reference cannot even set up)
     (40, 91, 4200, 9, "smooth", 150.0, ">=", 0.5, 3, True),          # more than 64 words per row
     (12, 2100, 64, 10, "smooth", 150.0, ">=", 0.5, 2, True),         # more rows than the LDS row table
+    # the BASELINE.json configurations at their own sizes / parameters (the C oracle needs a few seconds for each):
+    (2707, 181, 360, 0, "smooth", 160.0, ">=", 0.5, 5, True),        # configs[1] complete: the bench slab itself, 3305 tracks
+    (64, 721, 1440, 5, "smooth", 160.0, ">=", 0.5, 20, True),        # configs[2]'s grid with its persistence of 20 steps
+    (240, 192, 288, 7, "smooth", 160.0, ">=", 0.5, 5, True),         # configs[4]'s grid (CESM 0.9 x 1.25 deg), eight months daily
 ]
 
 

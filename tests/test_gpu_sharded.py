@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def handles():
-    hs = [_native.Tracker(0) for _ in range(7)]
+    hs = [_native.Tracker(0) for _ in range(9)]
     yield hs
     for h in hs:
         h.close()
@@ -117,6 +117,36 @@ def test_long_slab_many_seam_operations(handles):
     got, ng, st = sharded_threads(handles[:7], anom, thr, 0, wrow, 0.5, 3, True, cuts)
     assert np.array_equal(got, want) and ng == nw
     assert st[0]["shared_seam_rows"] < st[0]["seam_rows_to_driver"] + sum(s["seam_rows_to_driver"] for s in st)      # most groups stay local
+
+
+def test_bench_slab_in_eight_shards(handles):
+    """BASELINE configs[1] complete (2707 x 181 x 360, the bench slab, compared with the oracle in test_gpu_parity.py) cut into the
+    eight time shards an 8-GPU node would hold: the strong-scaling layout of `bench.py --gpus 8 --scaling strong`"""
+    from contrack_amd.contrack import row_weights
+    from contrack_amd.dist import shard_bounds
+    T, ny, nx = 2707, 181, 360
+    anom = synth.smooth_field(T, ny, nx, seed=0)
+    lat, _ = synth.grid(ny, nx)
+    wrow = row_weights(lat, np.float32(1.0), np.float32(1.0))
+    thr = np.full(T, 160.0)
+    want, nw = handles[8].track(anom, thr, 0, wrow, 0.5, 5, True)
+    assert nw == 3305
+    b = shard_bounds(T, 8)
+    got, ng, _ = sharded_threads(handles[:8], anom, thr, 0, wrow, 0.5, 5, True, [x[0] for x in b] + [T])
+    assert np.array_equal(got, want) and ng == nw
+
+
+def test_025deg_persistence_20_in_four_shards(handles):
+    """BASELINE configs[2] / [3] parameters (721 x 1440, persistence 20): tracks that live across three shard boundaries"""
+    from contrack_amd.contrack import row_weights
+    T, ny, nx = 64, 721, 1440
+    anom = synth.smooth_field(T, ny, nx, seed=5)
+    lat, _ = synth.grid(ny, nx)
+    wrow = row_weights(lat, np.float32(0.25), np.float32(0.25))
+    thr = np.full(T, 160.0)
+    want, nw = handles[8].track(anom, thr, 0, wrow, 0.5, 20, True)
+    got, ng, _ = sharded_threads(handles[:4], anom, thr, 0, wrow, 0.5, 20, True, [0, 16, 32, 48, T])
+    assert np.array_equal(got, want) and ng == nw and nw > 0
 
 
 def test_rccl_world_of_one(oracle_lib):
