@@ -334,10 +334,10 @@ def test_size_independent_properties(trk):
 # the product's time-sharded path with one PROCESS per rank: several processes share GPU 0 and talk through the shared-memory
 # transport (RCCL refuses two ranks on one device; on a multi-GPU node the same entry runs over RCCL -- contrack_amd/dist.py)
 # ------------------------------------------------------------------------------------------------
-def _shard_worker(rank, world, key, name, q):
+def _shard_worker(rank, world, key, name, q, backend="shm"):
     import os
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_PORT=str(key), CTK_LAUNCH_PID=str(key),
-                      CTK_DIST_BACKEND="shm")
+                      CTK_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     from contrack_amd import dist as cdist
     g = golden_util.load(name)
     T = g["anom"].shape[0]
@@ -364,5 +364,31 @@ def test_time_sharded_processes_shm_transport(name, world):
     res = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert len({n for _, _, n in res}) == 1
+
+
+@pytest.mark.parametrize("name,world", [("syn2deg_s0", 2), ("chain_a", 3), ("busy_s1", 4), ("f64pole_blocky", 2), ("syn1deg", 8)])
+def test_time_sharded_processes_rccl(name, world):
+    """the same over RCCL, one process per GPU: runs where the node has at least `world` GPUs (the one-GPU box of the build
+    skips it: RCCL refuses two ranks on one device) -- the first place ncclSend / ncclRecv / ncclAllGather of csrc/ctk_comm.hip
+    meet more than one rank"""
+    import multiprocessing as mp
+    import os
+    if _native.device_count() < world:
+        pytest.skip("needs %d GPUs" % world)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = 20000 + os.getpid() % 20000
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, key, name, q, "rccl")) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=600) for _ in range(world)]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
     assert all(ok for _, ok, _ in res), res
     assert len({n for _, _, n in res}) == 1
