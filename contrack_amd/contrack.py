@@ -157,8 +157,13 @@ def _xr():
 
 def _fingerprint(a):
     """cheap identity of a host array (address, shape, dtype and a strided sample of its bytes): is the copy that calc_anom left
-    on the GPU still the array the dataset holds?  An in-place edit of a sampled element, a new array or another shape miss."""
+    on the GPU still the array the dataset holds?  A new array, another shape or an in-place edit of a sampled element miss.
+    Edits the sample cannot see are excluded differently: calc_anom hands the host copy out READ-ONLY (an in-place edit raises
+    instead of silently diverging from its twin in HBM; assign a new array to the variable to change it), and an array that has
+    been made writeable again never counts as resident."""
     a = np.asarray(a)
+    if a.flags.writeable:
+        return None
     flat = a.reshape(-1) if a.flags.c_contiguous else None
     sample = b"" if flat is None or flat.size == 0 else np.ascontiguousarray(flat[::max(1, flat.size // 2048)][:2048]).tobytes()
     return (a.__array_interface__["data"][0], a.shape, str(a.dtype), hash(sample))
@@ -452,6 +457,7 @@ class contrack(object):
                  'standard_name': da.attrs['long_name'] + ' anomaly',
                  'history': ' '.join(['Calculated from {} with input attributes:', 'smoothing time steps = {},',
                                       'climatology = {}.']).format(variable, smooth, clim_txt)}
+        anom.flags.writeable = False                         # (its twin stays in HBM for run_contrack: see _fingerprint)
         out = anom.transpose(np.argsort(sort))
         self.ds['anom'] = (dims, out, attrs)
         self._anom_resident = _fingerprint(np.asarray(self.ds['anom'].data))
@@ -469,7 +475,8 @@ class contrack(object):
             raise ValueError("latitude band {} selects no contiguous rows".format(lat_bounds))
         if slab.dtype.kind != "f":
             slab = slab.astype(np.float64)
-        resident = variable == 'anom' and getattr(self, "_anom_resident", None) == _fingerprint(np.asarray(self.ds['anom'].data)) \
+        resident = variable == 'anom' and getattr(self, "_anom_resident", None) is not None and \
+            self._anom_resident == _fingerprint(np.asarray(self.ds['anom'].data)) \
             and _tracker().resident_anom() == (slab.shape[0], slab.shape[1], slab.shape[2], slab.dtype != np.float32)
         return _tracker().percentile(None if resident else slab, int(rows[0]), int(rows[-1]) + 1, q)
 
@@ -613,7 +620,8 @@ class contrack(object):
         flags, field = slab(flag), slab(variable)
         if flags.dtype.kind not in "iub":
             raise ValueError("flag variable {!r} is not an integer field".format(flag))
-        if flags.size and (flags.max() > np.iinfo(np.int32).max or flags.min() < np.iinfo(np.int32).min):
+        if flags.size and (flags.dtype.itemsize > 4 or flags.dtype == np.uint32) and \
+                (flags.max() > np.iinfo(np.int32).max or flags.min() < np.iinfo(np.int32).min):      # (nothing to check for int32 and narrower)
             raise ValueError("flag ids beyond int32")
         if field.dtype != np.float64:
             field = field.astype(np.float32, copy=False)

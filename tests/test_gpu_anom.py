@@ -102,8 +102,22 @@ def test_class_calc_anom_then_run_contrack_from_hbm(trk):
     c._anom_resident = None                                          # force the host-array path
     c.run_contrack('anom', threshold=40.0, gorl='>=', overlap=0.5, persistence=3)
     assert np.array_equal(from_hbm, np.asarray(c['flag'].data)) and from_hbm.max() > 0
-    # an edited slab must not be served from the stale device copy
+    # an edited slab must not be served from the stale device copy: the host copy is read-only while its twin lives in HBM ...
     c.calc_anom('z', window=5, smooth=2)
-    c.ds['anom'].data[...] = 0.0
+    with pytest.raises(ValueError, match="read-only"):
+        c.ds['anom'].data[3, 4, 5] = 0.0
+    # ... a single pixel edited after making it writeable again (invisible to any sampled check) is seen ...
+    arr = c.ds['anom'].data
+    if arr.base is not None:
+        arr.base.flags.writeable = True                              # (the variable holds a transposed view of the library's array)
+    arr.flags.writeable = True
+    hot = np.unravel_index(np.argmax(arr[1:-1]), arr[1:-1].shape)
+    arr[:, hot[1], hot[2]] = 0.0
+    c.run_contrack('anom', threshold=40.0, gorl='>=', overlap=0.5, persistence=3)
+    edited = np.asarray(c['flag'].data).copy()
+    assert not np.array_equal(edited, from_hbm) and (edited[:, hot[1], hot[2]] == 0).all()
+    # ... and so is a replaced variable
+    c.calc_anom('z', window=5, smooth=2)
+    c.ds['anom'] = (c['anom'].dims, np.zeros_like(np.asarray(c['anom'].data)), dict(c['anom'].attrs))
     c.run_contrack('anom', threshold=40.0, gorl='>=', overlap=0.5, persistence=3)
     assert np.asarray(c['flag'].data).max() == 0
