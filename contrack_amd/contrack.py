@@ -14,7 +14,11 @@ Stated deviations from the reference:
   * `flag` is written back with the INVERSE of the (time, lat, lon) permutation; the reference applies the
     forward permutation twice (contrack.py:778), which is only correct when the permutation is its own
     inverse -- for every such input (including the tested (time, lat, lon) order) both agree.
-  * ids are int32 (the reference switches to int64 beyond 2^31-2 pixels, sizes it cannot realistically run).
+  * ids are int32 (the reference switches to int64 beyond 2^31-2 pixels, sizes it cannot realistically run); more than
+    2^31-2 ids raise instead of wrapping.
+  * the numpy array behind `ds['anom']` after `calc_anom` is read-only (its twin stays in HBM for `run_contrack`); assign a
+    new array to the variable to change it.
+  * `run_contrack(..., chunk_steps=n)` (extension): stream the variable through the GPU in slices of n time steps.
 """
 import logging
 import os
