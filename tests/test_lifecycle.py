@@ -129,6 +129,25 @@ def test_hip_lifecycle_on_tracked_slab(tracker, f64):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,thr,pers", [((6, 721, 1440), 160.0, 2), ((24, 181, 360), 160.0, 3), ((8, 192, 288), 150.0, 2)])
+def test_hip_lifecycle_on_baseline_grids(tracker, shape, thr, pers):
+    """the grids of BASELINE.json (0.25 deg: six 256-column strips x twelve 64-row bands per plane; 1 deg; CESM): frame identical to
+    the scipy port's in every column, with the rows on rounding boundaries re-evaluated on the device"""
+    from contrack_amd import synth
+    T, ny, nx = shape
+    anom = synth.smooth_field(T, ny, nx, seed=9)
+    lat, lon = synth.grid(ny, nx)
+    wrow = row_weights(lat, 180.0 / (ny - 1), 360.0 / nx)
+    flag, n = tracker.track(anom, np.full(T, thr), 0, wrow, 0.5, pers, True)
+    assert n > 2
+    rows = tracker.lifecycle(flag, anom, wrow)
+    dates = ["%03d" % t for t in range(T)]
+    got = lifecycle_frame(rows, lat, lon, dates, tracker)
+    assert (rows["shift"] > 0).any()                                   # contours across the seam
+    assert got == lifecycle_port.run_lifecycle(flag, anom, lat, lon, wrow, dates)
+
+
+@pytest.mark.gpu
 def test_hip_lifecycle_device_resident_and_empty(tracker):
     from contrack_amd import synth
     T, ny, nx = 6, 46, 72
