@@ -31,7 +31,8 @@ def _field(rng, T, ny, nx, dtype, nans):
 
 
 @pytest.mark.parametrize("case", [(400, 13, 20, np.float32, 1, 1, 0), (800, 9, 16, np.float32, 31, 2, 0), (800, 9, 16, np.float32, 4, 5, 1),
-                                  (500, 7, 12, np.float64, 7, 3, 1), (366, 5, 8, np.float64, 1, 4, 0), (90, 6, 8, np.float32, 5, 1, 1)],
+                                  (500, 7, 12, np.float64, 7, 3, 1), (366, 5, 8, np.float64, 1, 4, 0), (90, 6, 8, np.float32, 5, 1, 1),
+                                  (1100, 181, 360, np.float32, 31, 2, 0), (380, 192, 288, np.float64, 5, 3, 1)],           # the 1 deg and CESM grids, three years
                          ids=str)
 def test_anomalies_match_numpy_port(trk, case):
     T, ny, nx, dtype, window, smooth, nans = case
