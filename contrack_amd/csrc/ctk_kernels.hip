@@ -727,40 +727,74 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
         mp = a.mask + (int64_t)(t - 1) * nwords; wsp = a.wstart + (int64_t)(t - 1) * nwords;
         rsp = a.rowstart + (int64_t)(t - 1) * ny; rcp = a.run_comp + a.run_base[t - 1];
     }
-    // one thread per mask word; all loads are independent of each other
-    for (int idx = tid; idx < nwords; idx += 256) {
-        const uint64_t c = mc[idx], p = mp[idx];
-        uint64_t o = c & p;
-        if (o == 0ull) continue;
-        const int y = idx / W, w = idx - y * W;
-        const uint64_t cinc = (w > 0) ? (mc[idx - 1] >> 63) : 0ull, cinp = (w > 0) ? (mp[idx - 1] >> 63) : 0ull;
-        const uint64_t sc = c & ~((c << 1) | cinc), sp = p & ~((p << 1) | cinp);
-        const uint32_t ec = rsc[y] + wsc[idx], ep = rsp[y] + wsp[idx];            // runs started left of this word
-        const int64_t wl = a.wlo[y], wh = a.whi[y];
-        while (o) {
-            const int b = __builtin_ctzll(o);
-            const uint64_t sh = o >> b;
-            const int n = (~sh == 0ull) ? 64 : __builtin_ctzll(~sh);
-            const uint64_t below = (b + 1 >= 64) ? FULL64 : ((1ull << (b + 1)) - 1ull);   // bits 0..b
-            const uint32_t rcur = ec + (uint32_t)__popcll(sc & below) - 1u;
-            const uint32_t rprv = ep + (uint32_t)__popcll(sp & below) - 1u;
-            const uint32_t cc = rcc[rcur], cd = rcp[rprv];
-            const int64_t lo = (int64_t)n * wl, hi = (int64_t)n * wh;
-            const unsigned long long key = ((unsigned long long)cc << 32) | cd;
-            uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (CTK_HASH_SLOTS - 1);
-            bool placed = false;
-            for (int q = 0; q < CTK_HASH_PROBES; q++) {
-                const unsigned long long old = atomicCAS(&hkey[h], FULL64, key);
-                if (old == FULL64 || old == key) {
-                    atomicAdd((unsigned long long *)&hlo[h], (unsigned long long)lo);
-                    atomicAdd((unsigned long long *)&hhi[h], (unsigned long long)hi);
-                    placed = true;
-                    break;
-                }
-                h = (h + 1) & (CTK_HASH_SLOTS - 1);
+    // One thread per mask word, OVB words per thread and step.  The work on a word is a chain of dependent loads (the two mask
+    // words -> neighbours, run prefixes, row starts, weights -> the two runs' components); written word by word that is three
+    // round trips to L2 per word, most of this kernel's time.  Here every load of a level is issued for all OVB words before the
+    // first is used: three round trips per OVB words.  (Words without common pixels -- nine of ten -- load their tables in vain:
+    // L2 hits next to data that is read anyway.)
+    constexpr int OVB = 4;
+    auto insert = [&](uint32_t cc, uint32_t cd, int64_t lo, int64_t hi) {
+        const unsigned long long key = ((unsigned long long)cc << 32) | cd;
+        uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (CTK_HASH_SLOTS - 1);
+        for (int q = 0; q < CTK_HASH_PROBES; q++) {
+            const unsigned long long old = atomicCAS(&hkey[h], FULL64, key);
+            if (old == FULL64 || old == key) {
+                atomicAdd((unsigned long long *)&hlo[h], (unsigned long long)lo);
+                atomicAdd((unsigned long long *)&hhi[h], (unsigned long long)hi);
+                return;
             }
-            if (!placed) emit_pair(a, (uint32_t)t, cc, cd, lo, hi);
-            o = (n >= 64 - b) ? 0ull : (o & ~(((1ull << n) - 1ull) << b));
+            h = (h + 1) & (CTK_HASH_SLOTS - 1);
+        }
+        emit_pair(a, (uint32_t)t, cc, cd, lo, hi);
+    };
+    for (int i0 = tid; i0 < nwords; i0 += 256 * OVB) {
+        uint64_t c[OVB], p[OVB], cl[OVB], pl[OVB];
+        uint32_t ec[OVB], ep[OVB];
+        int64_t wl[OVB], wh[OVB];
+        int ww[OVB];
+#pragma unroll
+        for (int u = 0; u < OVB; u++) {                                  // level 1 (and everything whose address is known already)
+            const int idx = i0 + u * 256, ii = min(idx, nwords - 1), im = max(ii - 1, 0);
+            const int y = ii / W;
+            ww[u] = idx < nwords ? ii - y * W : -1;
+            c[u] = mc[ii]; p[u] = mp[ii];
+            cl[u] = mc[im]; pl[u] = mp[im];
+            ec[u] = rsc[y] + wsc[ii]; ep[u] = rsp[y] + wsp[ii];          // runs started left of this word
+            wl[u] = a.wlo[y]; wh[u] = a.whi[y];
+        }
+        uint64_t o[OVB], sc[OVB], sp[OVB];
+        uint32_t cc0[OVB], cd0[OVB];
+        int n0[OVB];
+#pragma unroll
+        for (int u = 0; u < OVB; u++) {                                  // level 2: the components of the first common piece
+            o[u] = ww[u] >= 0 ? (c[u] & p[u]) : 0ull;
+            cc0[u] = 0; cd0[u] = 0; n0[u] = 0; sc[u] = 0; sp[u] = 0;
+            if (o[u] == 0ull) continue;
+            const uint64_t cinc = (ww[u] > 0) ? (cl[u] >> 63) : 0ull, cinp = (ww[u] > 0) ? (pl[u] >> 63) : 0ull;
+            sc[u] = c[u] & ~((c[u] << 1) | cinc); sp[u] = p[u] & ~((p[u] << 1) | cinp);
+            const int b = __builtin_ctzll(o[u]);
+            const uint64_t sh = o[u] >> b;
+            n0[u] = (~sh == 0ull) ? 64 : __builtin_ctzll(~sh);
+            const uint64_t below = (b + 1 >= 64) ? FULL64 : ((1ull << (b + 1)) - 1ull);   // bits 0..b
+            cc0[u] = rcc[ec[u] + (uint32_t)__popcll(sc[u] & below) - 1u];
+            cd0[u] = rcp[ep[u] + (uint32_t)__popcll(sp[u] & below) - 1u];
+        }
+#pragma unroll
+        for (int u = 0; u < OVB; u++) {                                  // the table; further pieces of a word (rare) one by one
+            uint64_t ou = o[u];
+            if (ou == 0ull) continue;
+            int b = __builtin_ctzll(ou), n = n0[u];
+            insert(cc0[u], cd0[u], (int64_t)n * wl[u], (int64_t)n * wh[u]);
+            ou = (n >= 64 - b) ? 0ull : (ou & ~(((1ull << n) - 1ull) << b));
+            while (ou) {
+                b = __builtin_ctzll(ou);
+                const uint64_t sh = ou >> b;
+                n = (~sh == 0ull) ? 64 : __builtin_ctzll(~sh);
+                const uint64_t below = (b + 1 >= 64) ? FULL64 : ((1ull << (b + 1)) - 1ull);
+                const uint32_t cc = rcc[ec[u] + (uint32_t)__popcll(sc[u] & below) - 1u], cd = rcp[ep[u] + (uint32_t)__popcll(sp[u] & below) - 1u];
+                insert(cc, cd, (int64_t)n * wl[u], (int64_t)n * wh[u]);
+                ou = (n >= 64 - b) ? 0ull : (ou & ~(((1ull << n) - 1ull) << b));
+            }
         }
     }
     __syncthreads();
