@@ -412,48 +412,57 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
     {
         const uint16_t *wglob = a.wstart + (int64_t)t * ny * W;
         const uint64_t *mglob = a.mask + (int64_t)t * ny * W;
-        // band buffer in the table area: rows x W mask words followed by rows x W 16-bit prefixes
-        uint64_t *band = (uint64_t *)lds_tab;
-        const bool banded = !mrow_staged && lds_tab != nullptr && W * 10 <= LDS_COMPS * 32;
-        const int band_rows = banded ? max(1, (LDS_COMPS * 32) / (W * 10)) : ny;
-        uint16_t *wband = banded ? (uint16_t *)(band + (size_t)band_rows * W) : nullptr;
-        for (int yb = 0; yb < ny; yb += band_rows) {
-            const int rows = min(band_rows, ny - yb);
-            const uint64_t *src = mrow_staged ? mrow + (int64_t)yb * W : mglob + (int64_t)yb * W;    // word (y, w) at src[(y - yb) * W + w]
-            const uint16_t *ws = wglob + (int64_t)yb * W;
-            if (banded) {
-                __syncthreads();                                      // previous band fully consumed
-                for (int i = tid; i < rows * W; i += THREADS) { band[i] = mglob[(int64_t)yb * W + i]; wband[i] = wglob[(int64_t)yb * W + i]; }
-                __syncthreads();
-                src = band;
-                ws = wband;
+        const int nwords = ny * W;
+        // one word: the i-th start bit and the i-th end bit of a row delimit its i-th run
+        auto extract = [&](int k, uint64_t m, uint64_t left, uint64_t right, uint32_t wpre) {
+            const int y = k / W, w = k - y * W;
+            const uint64_t cin = (w > 0) ? (left >> 63) : 0ull;
+            const uint64_t nin = (w + 1 < W) ? (right & 1ull) : 0ull;
+            uint64_t starts = m & ~((m << 1) | cin);
+            uint64_t ends = m & ~((m >> 1) | (nin << 63));
+            const uint32_t nbefore = rs[y] + wpre;
+            uint32_t si = nbefore, ei = nbefore - (uint32_t)(cin & m & 1ull);      // open run: started, not yet ended
+            const int xb = w * 64;
+            while (starts) {
+                int b = __builtin_ctzll(starts);
+                starts &= starts - 1;
+                x0[si] = (uint16_t)(xb + b);
+                yrow[si] = (uint16_t)y;
+                parent[si] = si;
+                si++;
             }
-            const int nwords = rows * W;
+            while (ends) {
+                int b = __builtin_ctzll(ends);
+                ends &= ends - 1;
+                x1[ei] = (uint16_t)(xb + b);
+                ei++;
+            }
+        };
+        if (mrow_staged) {                                           // the timestep's words (and prefixes) are in LDS
+            const uint16_t *ws = wglob;
             for (int k = tid; k < nwords; k += THREADS) {
-                const uint64_t m = src[k];
+                const uint64_t m = mrow[k];
                 if (m == 0ull) continue;
-                const int yl = k / W, w = k - yl * W, y = yb + yl;
-                const uint64_t cin = (w > 0) ? (src[k - 1] >> 63) : 0ull;
-                const uint64_t nin = (w + 1 < W) ? (src[k + 1] & 1ull) : 0ull;
-                uint64_t starts = m & ~((m << 1) | cin);
-                uint64_t ends = m & ~((m >> 1) | (nin << 63));
-                const uint32_t nbefore = rs[y] + ws[k];
-                uint32_t si = nbefore, ei = nbefore - (uint32_t)(cin & m & 1ull);      // open run: started, not yet ended
-                const int xb = w * 64;
-                while (starts) {
-                    int b = __builtin_ctzll(starts);
-                    starts &= starts - 1;
-                    x0[si] = (uint16_t)(xb + b);
-                    yrow[si] = (uint16_t)y;
-                    parent[si] = si;
-                    si++;
+                extract(k, m, k > 0 ? mrow[k - 1] : 0ull, k + 1 < nwords ? mrow[k + 1] : 0ull, ws[k]);
+            }
+        } else {
+            // Straight from global memory (L2), P2B words per thread at a time: every load is issued before the first word is
+            // looked at.  (Staging bands of rows through LDS first cost a dependent round trip and two barriers per band: eleven
+            // bands = 29 of the 54 us a 721 x 1440 timestep took.)
+            constexpr int P2B = 8;
+            for (int k0 = tid; k0 < nwords; k0 += THREADS * P2B) {
+                uint64_t m[P2B], ml[P2B], mr[P2B];
+                uint32_t wp[P2B];
+#pragma unroll
+                for (int u = 0; u < P2B; u++) {
+                    const int k = k0 + u * THREADS, kc = min(k, nwords - 1);
+                    m[u] = k < nwords ? mglob[kc] : 0ull;
+                    ml[u] = mglob[max(kc - 1, 0)];
+                    mr[u] = mglob[min(kc + 1, nwords - 1)];
+                    wp[u] = wglob[kc];
                 }
-                while (ends) {
-                    int b = __builtin_ctzll(ends);
-                    ends &= ends - 1;
-                    x1[ei] = (uint16_t)(xb + b);
-                    ei++;
-                }
+#pragma unroll
+                for (int u = 0; u < P2B; u++) if (m[u] != 0ull) extract(k0 + u * THREADS, m[u], ml[u], mr[u], wp[u]);
             }
         }
     }
