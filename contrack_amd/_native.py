@@ -551,12 +551,16 @@ class Tracker:
         check(lib().ctk_lifecycle_rows(self._h, rows.ctypes.data, n))
         return rows
 
-    def lifecycle(self, flag, field, wrow):
-        """flag (T, ny, nx) int32, field float32/float64 of the same shape -> LIFE_ROW records sorted by (label, t)"""
+    def lifecycle(self, flag, field, wrow, resident_f64=None):
+        """flag (T, ny, nx) int32, field float32/float64 of the same shape -> LIFE_ROW records sorted by (label, t).
+        field = None: the anomaly slab left resident by `anomalies(..., keep_resident=True)` (resident_f64: its type)"""
         flag = np.ascontiguousarray(flag, dtype=np.int32)
-        f64 = np.asarray(field).dtype == np.float64
-        field = np.ascontiguousarray(field, dtype=np.float64 if f64 else np.float32)
-        if flag.ndim != 3 or field.shape != flag.shape:
+        if field is None:
+            f64 = bool(resident_f64)
+        else:
+            f64 = np.asarray(field).dtype == np.float64
+            field = np.ascontiguousarray(field, dtype=np.float64 if f64 else np.float32)
+        if flag.ndim != 3 or (field is not None and field.shape != flag.shape):
             raise ValueError("flag and field must share one (time, lat, lon) shape")
         T, ny, nx = flag.shape
         wrow = np.ascontiguousarray(wrow, dtype=np.float32)
@@ -564,7 +568,7 @@ class Tracker:
             raise ValueError("wrow must have shape (ny,)")
         n = C.c_int64(0)
         fn = lib().ctk_lifecycle_f64 if f64 else lib().ctk_lifecycle_f32
-        check(fn(self._h, flag.ctypes.data, field.ctypes.data, T, ny, nx, wrow.ctypes.data, C.byref(n)))
+        check(fn(self._h, flag.ctypes.data, None if field is None else field.ctypes.data, T, ny, nx, wrow.ctypes.data, C.byref(n)))
         return self._life_rows(int(n.value))
 
     def lifecycle_exact(self, row_idx):

@@ -632,7 +632,12 @@ class contrack(object):
         lat = np.asarray(self.ds[self._latitude_name].data)
         lon = np.asarray(self.ds[self._longitude_name].data)
         wrow = row_weights(lat, self._dlat, self._dlon)                                                 # contrack.py:847-848
-        rows = _tracker().lifecycle(flags, field, wrow)
+        trk = _tracker()
+        resident = variable == 'anom' and getattr(self, "_anom_resident", None) is not None and \
+            self._anom_resident == _fingerprint(np.asarray(self.ds['anom'].data)) and \
+            trk.resident_anom() == (field.shape[0], field.shape[1], field.shape[2], field.dtype == np.float64)
+        # (the anomaly slab calc_anom left in HBM: only the flags cross PCIe)
+        rows = trk.lifecycle(flags, None, wrow, resident_f64=field.dtype == np.float64) if resident else trk.lifecycle(flags, field, wrow)
         return pd.DataFrame(lifecycle_columns(rows, lat, lon, self._time_labels(), _tracker()),
                             columns=['Flag', 'Date', 'Longitude', 'Latitude', 'Intensity', 'Size'])
 

@@ -2008,16 +2008,22 @@ static int lifecycle_dev_impl(ctk_handle *h, const int32_t *flag_dev, const void
 static int lifecycle_host_impl(ctk_handle *h, const int32_t *flag, const void *field, bool f64, int64_t T, int ny, int nx, const float *wrow, int64_t *nrows)
 {
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
-    if (T < 0 || ny < 1 || nx < 1 || (T > 0 && (!flag || !field))) return ctk_set_error(CTK_E_INVALID, "ctk_lifecycle: bad shape or null pointer");
+    if (T < 0 || ny < 1 || nx < 1 || (T > 0 && !flag)) return ctk_set_error(CTK_E_INVALID, "ctk_lifecycle: bad shape or null pointer");
+    // field == NULL: the anomaly slab that ctk_anom_* left resident (no second trip over PCIe for it)
+    if (T > 0 && !field && !(h->an_T == T && h->an_ny == ny && h->an_nx == nx && h->an_f64 == f64 && h->an_out.p))
+        return ctk_set_error(CTK_E_STATE, "ctk_lifecycle: field = NULL needs a resident anomaly slab of this shape and type (ctk_anom_* with keep_resident)");
     HIPCHK(hipSetDevice(h->device));
     const size_t n = (size_t)T * ny * nx, esz = f64 ? 8 : 4;
     void *f_dev = nullptr, *v_dev = nullptr;
     if (n) {
         CTKCHK(ensure(h, h->io_out, n * 4));                     // the flag slab (the tracker's own result buffer, if it ran here)
-        CTKCHK(ensure(h, h->io_in, n * esz));
-        f_dev = h->io_out.p; v_dev = h->io_in.p;
+        f_dev = h->io_out.p;
         HIPCHK(hipMemcpy(f_dev, flag, n * 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(v_dev, field, n * esz, hipMemcpyHostToDevice));
+        if (field) {
+            CTKCHK(ensure(h, h->io_in, n * esz));
+            v_dev = h->io_in.p;
+            HIPCHK(hipMemcpy(v_dev, field, n * esz, hipMemcpyHostToDevice));
+        } else v_dev = h->an_out.p;
     }
     return lifecycle_dev_impl(h, (const int32_t *)f_dev, v_dev, f64, T, ny, nx, wrow, nrows);
 }

@@ -281,7 +281,8 @@ int ctk_synth_fill(ctk_handle *h, float *anom_dev, int64_t T, int ny, int nx, ui
  * them out.  wrow: float32 row weights, contrack.py:847-848.  Every byte of flag / field is read once (strips of 256 columns x
  * 64 rows per workgroup); a time step with more ids than the tables of that form hold (128, or 4 that cross the seam) is redone
  * by a one-workgroup-per-time-step kernel in passes over residue classes of the ids: no limit.
- * pad: the rows that hold the id, first | last << 16 (internal: bounds the scans of ctk_lifecycle_exact). */
+ * pad: the rows that hold the id, first | last << 16 (internal: bounds the scans of ctk_lifecycle_exact).
+ * Host entries with field = NULL take the anomaly slab that ctk_anom_* left resident in HBM (same shape and type). */
 typedef struct ctk_life_row {
     int32_t t, label, shift, pad;
     double area, swv, swvy, swvx;

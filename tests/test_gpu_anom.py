@@ -100,9 +100,14 @@ def test_class_calc_anom_then_run_contrack_from_hbm(trk):
     assert _tracker().resident_anom() == (T, ny, nx, False)
     c.run_contrack('anom', threshold=40.0, gorl='>=', overlap=0.5, persistence=3)
     from_hbm = np.asarray(c['flag'].data).copy()
+    life_hbm = c.run_lifecycle(flag='flag', variable='anom')         # field = the resident slab: only the flags cross PCIe
+    keep = c._anom_resident
     c._anom_resident = None                                          # force the host-array path
     c.run_contrack('anom', threshold=40.0, gorl='>=', overlap=0.5, persistence=3)
     assert np.array_equal(from_hbm, np.asarray(c['flag'].data)) and from_hbm.max() > 0
+    life_host = c.run_lifecycle(flag='flag', variable='anom')
+    assert len(life_hbm) > 10 and life_hbm.equals(life_host)
+    c._anom_resident = keep
     # an edited slab must not be served from the stale device copy: the host copy is read-only while its twin lives in HBM ...
     c.calc_anom('z', window=5, smooth=2)
     with pytest.raises(ValueError, match="read-only"):
