@@ -22,7 +22,11 @@ import time
 
 import numpy as np
 
-from . import _native
+# the host driver of the target nodes only supports dmabuf IPC: without this RCCL's intra-node set-up fails with
+# `hipIpcGetMemHandle: invalid argument` (read by the HIP runtime when it initialises, i.e. before the first library call)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+from . import _native  # noqa: E402
 
 
 def shard_bounds(T, world):
