@@ -205,7 +205,8 @@ def main():
     alg_bytes = {"k_threshold": 4.0 * px, "k_relabel": 4.0 * px}          # float32 read once / int32 written once
     kern = max(alg_bytes, key=lambda k: per.get(k, 0.0))
     achieved = alg_bytes[kern] / (per[kern] * 1e-3) / 1e9 if per.get(kern, 0) > 0 else 0.0
-    kname = {"k_threshold": "k_threshold_v4", "k_relabel": "k_relabel_v4"}[kern]
+    rk = {5: "k_relabel_v5", 4: "k_relabel_v4"}.get(trk.stats().get("relabel_kernel", 4), "k_relabel")
+    kname = {"k_threshold": "k_threshold_v4", "k_relabel": rk}[kern]
     out = dict(metric="timesteps/sec labeled+tracked", value=value, unit="timesteps/s", n_gpus=1, steps=args.steps,
                warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f32 compare / int32 labels / int64 exact areas", data="synthetic",

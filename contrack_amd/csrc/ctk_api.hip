@@ -1409,10 +1409,16 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
     const int64_t nblk4 = nt * nchunk;
     if ((h->nx % 4 == 0) && (((uintptr_t)flag_dev & 15) == 0) && npl < 0x7fffffff && nblk4 < (1 << 24) && nt > 0 && lds <= 60 * 1024) {
         const unsigned grid = (unsigned)nblk4;
-        k_relabel_v4<<<grid, 256, lds, h->stream>>>(a, rb, rvcap);
+        // word-centric form while the LDS image of the chunk's values (rows x nx x 4 bytes) leaves eight workgroups per CU
+        const int rv5 = 512;
+        const size_t lds5 = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) +
+                            (((size_t)rv5 * 4 + 15) & ~(size_t)15) + (size_t)rb * h->nx * 4 + 16;
+        if (lds5 <= 20 * 1024 && !getenv("CTK_RELABEL_V4")) { k_relabel_v5<<<grid, 256, lds5, h->stream>>>(a, rb, rv5); h->stats[CTK_S_RELABEL_KERNEL] = 5; }
+        else { k_relabel_v4<<<grid, 256, lds, h->stream>>>(a, rb, rvcap); h->stats[CTK_S_RELABEL_KERNEL] = 4; }
     } else if (nt > 0) {
         a.chunk_vals = nullptr;
         k_relabel<<<grid_for_rows(a.nrows), 256, 0, h->stream>>>(a);
+        h->stats[CTK_S_RELABEL_KERNEL] = 0;
     }
     HIPCHK(hipGetLastError());
     return CTK_OK;

@@ -1170,6 +1170,95 @@ __global__ __launch_bounds__(256) void k_relabel_v4(RelabelArgs a, int rb, int r
     if (__ballot(z) && lane_id() == 0 && a.counters[CTK_CNT_WROTE_ZERO] == 0) atomicOr(&a.counters[CTK_CNT_WROTE_ZERO], 1u);
 }
 
+// Word-centric form of the fast path: the same tables and launch geometry as k_relabel_v4 above, but the chunk's flag values are
+// assembled in LDS (dynamic LDS: the tables + rvcap * 4 + rows * nx * 4 bytes) and stored from there.  Used while that image
+// leaves room for eight workgroups per CU (1 degree: 11 rows = 15.8 KB; 0.25 degree: 2 rows = 11.5 KB); the 8-row chunks of
+// slabs with millions of chunks stay with k_relabel_v4.
+__global__ __launch_bounds__(256) void k_relabel_v5(RelabelArgs a, int rb, int rvcap)
+{
+    const int ny = a.ny, nx = a.nx, W = a.W;
+    const int nchunk = (ny + rb - 1) / rb;
+    const int t = (int)(blockIdx.x / (unsigned)nchunk), y0 = (int)(blockIdx.x - (unsigned)t * nchunk) * rb, tid = (int)threadIdx.x;
+    const int rows = min(rb, ny - y0);
+    const int64_t row0 = (int64_t)t * ny + y0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *mrow = reinterpret_cast<uint64_t *>(smem);
+    uint16_t *wst = reinterpret_cast<uint16_t *>(smem + (size_t)rb * W * 8);
+    uint32_t *rst = reinterpret_cast<uint32_t *>(smem + (size_t)rb * W * 8 + (((size_t)rb * W * 2 + 7) & ~(size_t)7));
+    int32_t *rvs = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(rst) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7));
+    const uint32_t trun = a.run_base[t + 1] - a.run_base[t];
+    for (int i = tid; i < rows * W; i += 256) { mrow[i] = a.mask[row0 * W + i]; wst[i] = a.wstart[row0 * W + i]; }
+    for (int i = tid; i <= rows; i += 256) rst[i] = (y0 + i < ny) ? a.rowstart[row0 + i] : trun;
+    // the chunk's run values in chunk order (k_run_values): loaded together with the tables -- one round trip, one barrier
+    if (a.chunk_vals && tid >= 256 - CTK_CV) rvs[tid - (256 - CTK_CV)] = a.chunk_vals[(int64_t)blockIdx.x * CTK_CV + (tid - (256 - CTK_CV))];
+    __syncthreads();
+    const uint32_t r0 = rst[0], nr = rst[rows] - r0;
+    const int32_t *rvg = a.run_val + a.run_base[t] + r0;
+    const bool staged = nr <= (uint32_t)rvcap;
+    if (!(a.chunk_vals && nr <= (uint32_t)CTK_CV)) {                    // more runs than the chunk-ordered copy holds (or no copy)
+        if (staged) for (uint32_t i = tid; i < nr; i += 256) rvs[i] = rvg[i];
+        __syncthreads();
+    }
+    // Word-centric: the chunk's flag values are assembled in LDS and stored from there.
+    //   A  zero the LDS image (four 16-byte LDS stores per thread, no mask decoding)
+    //   B  one thread per mask word that holds foreground (a tenth of the words): every maximal piece of set bits belongs to one
+    //      run, whose value is written over the piece's pixels
+    //   C  the store stream: LDS -> 16 bytes per lane, 1 KB contiguous per wave instruction, non-temporal
+    // Decoding the mask per four-pixel slot instead (the first form of this kernel) cost some 500 VALU instructions per wave, the
+    // foreground branch being taken by a whole wave whenever one of its 64 slots needed it: the kernel was bound by that, not by
+    // HBM.  The barriers wait for LDS traffic only (no global store precedes them).
+    const int n4 = nx >> 2, total = rows * n4;
+    i32x4 *dst = reinterpret_cast<i32x4 *>(a.flag + row0 * (int64_t)nx);
+    int32_t *outv = reinterpret_cast<int32_t *>(smem + ((((size_t)(reinterpret_cast<unsigned char *>(rvs) - smem) + (size_t)rvcap * 4) + 15) & ~(size_t)15));
+    i32x4 *outv4 = reinterpret_cast<i32x4 *>(outv);
+    bool z = false;
+    for (int i = tid; i < total; i += 256) outv4[i] = (i32x4)(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int nw = rows * W;
+    const int tail = nx - (W - 1) * 64;                                       // valid bits of a row's last word
+    for (int idx = tid; idx < nw; idx += 256) {
+        const uint64_t m = mrow[idx];
+        const int r = idx / W, w = idx - r * W;
+        const uint64_t valid = (w == W - 1 && tail < 64) ? ((1ull << tail) - 1ull) : FULL64;
+        if (m != valid) z = true;                                               // a background pixel in this word
+        if (m == 0ull) continue;
+        const uint64_t cin = (w > 0) ? (mrow[idx - 1] >> 63) : 0ull;
+        const uint64_t st = m & ~((m << 1) | cin);
+        const uint32_t base = rst[r] - r0 + wst[idx];
+        int32_t *orow = outv + r * nx + w * 64;
+        uint64_t mm = m;
+        while (mm) {
+            const int b = __builtin_ctzll(mm);
+            const uint64_t sh = mm >> b;
+            const int n = (~sh == 0ull) ? 64 : __builtin_ctzll(~sh);
+            const uint64_t below = (b + 1 >= 64) ? FULL64 : ((1ull << (b + 1)) - 1ull);     // bits 0..b
+            const uint32_t k = base + (uint32_t)__popcll(st & below) - 1u;
+            const int32_t val = staged ? rvs[k] : rvg[k];
+            if (val > 0) {                                                      // head up to a multiple of four, 16-byte LDS stores, tail
+                int q = b;
+                const int e = b + n;
+                for (; q < e && (q & 3); q++) orow[q] = val;
+                const i32x4 v4 = (i32x4)(val);
+                for (; q + 4 <= e; q += 4) *reinterpret_cast<i32x4 *>(orow + q) = v4;
+                for (; q < e; q++) orow[q] = val;
+            } else if (val == 0) {
+                z = true;                                                       // filtered out: the zeros are there already
+            } else {                                                            // complex component: fold pixel by pixel
+                for (int q = 0; q < n; q++) {
+                    const int32_t fl = fold_pixel(a.fold, -val, (int32_t)(a.t_begin + t), y0 + r, w * 64 + b + q);
+                    const int32_t v = ((int64_t)a.ext[a.n_labels + 1 + fl] - (int64_t)a.ext[fl] + 1 < a.persistence) ? 0 : fl;
+                    z |= v == 0;
+                    orow[b + q] = v;
+                }
+            }
+            mm = (n >= 64 - b) ? 0ull : (mm & ~(((1ull << n) - 1ull) << b));
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int i = tid; i < total; i += 256) __builtin_nontemporal_store(outv4[i], dst + i);    // (the chunk's rows are contiguous: slot i)
+    if (__ballot(z) && lane_id() == 0 && a.counters[CTK_CNT_WROTE_ZERO] == 0) atomicOr(&a.counters[CTK_CNT_WROTE_ZERO], 1u);
+}
+
 __global__ __launch_bounds__(256) void k_relabel(RelabelArgs a)
 {
     const int lane = lane_id();
