@@ -145,6 +145,10 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = one member of the workload per GPU, concatenated on the time axis (default); "
                          "strong = the single-GPU slab split over the GPUs")
+    ap.add_argument("--no-parity-check", action="store_true",
+                    help="N > 1: skip the in-run parity check (rank 0 tracks the concatenated slab with one call and compares checksums)")
+    ap.add_argument("--strong-steps", type=int, default=2000,
+                    help="N > 1: timesteps of the device-generated 0.25 deg slab of the strong-scaling block (0 = skip)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     rank = int(os.environ.get("RANK", "0"))

@@ -28,6 +28,7 @@ EXPORTS = [
     "ctk_synth_fill",
     "ctk_comm_unique_id", "ctk_comm_init_rccl", "ctk_comm_group_create", "ctk_comm_group_destroy", "ctk_comm_init_local", "ctk_comm_init_shm",
     "ctk_comm_destroy", "ctk_comm_rank", "ctk_comm_world", "ctk_comm_barrier", "ctk_comm_allgather_host", "ctk_comm_ops",
+    "ctk_comm_set_timeout", "ctk_comm_failed", "ctk_comm_abort_rank", "ctk_debug_fail_at", "ctk_synth_fill_window", "ctk_checksum_i32_dev",
     "ctk_track_sharded_f32_dev", "ctk_track_sharded_f64_dev",
     "ctk_anom_f32", "ctk_anom_f64", "ctk_resident_anom", "ctk_track_resident", "ctk_percentile_f32", "ctk_percentile_f64",
     "ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev", "ctk_lifecycle_rows", "ctk_lifecycle_exact",
@@ -48,6 +49,10 @@ LIFE_EXACT = np.dtype([("area", "<f8"), ("swv", "<f8"), ("s", "<f8"), ("sy", "<f
 
 class ContrackHipError(RuntimeError):
     pass
+
+
+class CommError(ContrackHipError):
+    """CTK_E_COMM: another rank of the time-shard path gave up, died or did not arrive in time; the communicator is retired"""
 
 
 def lib():
@@ -112,6 +117,12 @@ def lib():
     L.ctk_stream.argtypes = [p]
     L.ctk_stream.restype = p
     L.ctk_synth_fill.argtypes = [p, p, i64, i32, i32, C.c_uint64]
+    L.ctk_synth_fill_window.argtypes = [p, p, i64, i64, i32, i32, C.c_uint64]
+    L.ctk_checksum_i32_dev.argtypes = [p, p, i64, i64, p]
+    L.ctk_comm_set_timeout.argtypes = [p, dbl]
+    L.ctk_comm_failed.argtypes = [p, C.POINTER(i32), C.POINTER(i32)]
+    L.ctk_comm_abort_rank.argtypes = [p, i32]
+    L.ctk_debug_fail_at.argtypes = [p, i32]
     for name in ("ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev"):
         getattr(L, name).argtypes = [p, p, p, i64, i32, i32, p, C.POINTER(i64)]
     L.ctk_lifecycle_rows.argtypes = [p, p, i64]
@@ -150,6 +161,8 @@ def check(rc):
             raise MemoryError(msg)
         if rc in (-1, -4):
             raise ValueError(msg)
+        if rc == -7:
+            raise CommError("libcontrack_hip rc=-7: %s" % msg)
         raise ContrackHipError("libcontrack_hip rc=%d: %s" % (rc, msg))
 
 
@@ -303,6 +316,20 @@ class Comm:
         out = np.empty((self.world,) + arr.shape, dtype=arr.dtype)
         check(lib().ctk_comm_allgather_host(self._c, arr.ctypes.data, out.ctypes.data, arr.nbytes))
         return out
+
+    def set_timeout(self, seconds):
+        """deadline of every wait of the time-shard path on this communicator (default 120 s / CTK_COMM_TIMEOUT_S)"""
+        check(lib().ctk_comm_set_timeout(self._c, float(seconds)))
+
+    def failed(self):
+        """None, or (code, rank) of the failure published by the rank that gave up first"""
+        a, b = C.c_int(0), C.c_int(-1)
+        check(lib().ctk_comm_failed(self._c, C.byref(a), C.byref(b)))
+        return None if a.value == 0 else (int(a.value), int(b.value))
+
+    def abort(self, code=-5):
+        """this rank gives up: the other ranks' calls return CommError instead of waiting for it"""
+        check(lib().ctk_comm_abort_rank(self._c, int(code)))
 
     def ops(self):
         a, b = C.c_int64(0), C.c_int64(0)
@@ -521,8 +548,18 @@ class Tracker:
     def sync(self):
         check(lib().ctk_sync(self._h))
 
-    def synth_fill(self, dst, T, ny, nx, seed=0):
-        check(lib().ctk_synth_fill(self._h, dst, T, ny, nx, int(seed)))
+    def synth_fill(self, dst, T, ny, nx, seed=0, t0=0):
+        """deterministic synthetic slab (bench only); t0 > 0: the window [t0, t0 + T) of the same slab"""
+        check(lib().ctk_synth_fill_window(self._h, dst, int(t0), T, ny, nx, int(seed)))
+
+    def checksum_i32(self, ptr, n, index0=0):
+        """(position-weighted 64-bit checksum, number of nonzero elements) of an int32 device array"""
+        out = np.zeros(2, dtype=np.uint64)
+        check(lib().ctk_checksum_i32_dev(self._h, ptr, int(n), int(index0), out.ctypes.data))
+        return int(out[0]), int(out[1])
+
+    def debug_fail_at(self, stage):
+        check(lib().ctk_debug_fail_at(self._h, int(stage)))
 
     def track_dev(self, anom_dev, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev):
         thr = np.ascontiguousarray(thr, dtype=np.float64)

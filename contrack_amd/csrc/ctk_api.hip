@@ -19,6 +19,7 @@
 #include <atomic>
 #include <thread>
 #include <functional>
+#include <string>
 
 int ctk_set_error(int code, const char *fmt, ...);            // ctk_resolve.cpp
 extern "C" int ctk_weights_to_limbs(const float *wrow, int ny, int64_t npix, int64_t *wlo, int64_t *whi, int32_t *wshift, int32_t *limb_bits);
@@ -191,6 +192,9 @@ struct ctk_handle {
     int filter_round = CTK_JACOBI_ROUND;          // filter passes launched before convergence is checked
     uint32_t debug_pair_cap = 0;                  // test hook: pretend the pair table holds only this many records
     uint32_t debug_mail_c = 0, debug_mail_d = 0;  // test hook: pretend the resolver mailbox holds only this many records / labels
+    int debug_fail_stage = 0;                     // test hook (ctk_debug_fail_at): the time-shard path fails at this stage, once
+    bool sh_collective_err = false;               // the time-shard path's error was decided identically on every rank
+    ctk_comm *active_comm = nullptr;              // set while the time-shard path runs with more than one rank
     // host scratch of the seam driver, kept between calls (fresh 100+ KB vectors would page-fault every call)
     SeamDriver sd, sd_glob;                       // sd_glob: candidate groups shared between time shards (ctk_sharded.hip)
     std::vector<int32_t> sd_last;
@@ -219,6 +223,8 @@ int ensure(ctk_handle *h, DevBuf &b, size_t need)
 {
     if (need == 0) need = 8;
     if (b.cap >= need) return CTK_OK;
+    // hipFree waits for the device: with a collective in flight that wait must be the communicator's guarded one
+    if (b.p && h && h->active_comm) { if (int rc = ctk_comm_wait(h->active_comm)) return rc; }
     if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
     size_t cap = need + need / 8 + 256;                   // a little head room: sizes vary between calls
     hipError_t e = hipMalloc(&b.p, cap);
@@ -247,6 +253,12 @@ int ensure_host(void **p, size_t *cap, size_t need, bool non_coherent = false)
     *cap = c;
     return CTK_OK;
 }
+
+struct ActiveComm {                        // scope of ctk_handle::active_comm
+    ctk_handle *h;
+    ActiveComm(ctk_handle *h_, ctk_comm *c) : h(h_) { h->active_comm = (c && c->world > 1) ? c : nullptr; }
+    ~ActiveComm() { h->active_comm = nullptr; }
+};
 
 template <typename T>
 T *P(const DevBuf &b) { return (T *)b.p; }
@@ -1118,6 +1130,7 @@ static int rs_prepare(ctk_handle *h, const ResolveIn &in, double overlap, int tw
         h->mail_cap_c = std::max<size_t>(std::max<size_t>(h->mail_want_c, h->mail_cap_c), 4096);
         h->mail_cap_d = std::max<size_t>(std::max<size_t>(h->mail_want_d, h->mail_cap_d), 8192);
         size_t cap = 0;
+        if (h->h_mail && h->active_comm) CTKCHK(ctk_comm_wait(h->active_comm));       // (hipHostFree waits for the device)
         if (h->h_mail) { (void)hipHostFree(h->h_mail); h->h_mail = nullptr; }
         CTKCHK(ensure_host(&h->h_mail, &cap, CTK_MAIL_SCALARS * 4 + h->mail_cap_c * sizeof(CtkCand) + h->mail_cap_d * 28, true));
     }
@@ -2157,14 +2170,35 @@ extern "C" int ctk_sync(ctk_handle *h)
 extern "C" void *ctk_stream(ctk_handle *h) { return h ? (void *)h->stream : nullptr; }
 extern "C" int ctk_device_of(ctk_handle *h) { return h ? h->device : -1; }
 
+extern "C" int ctk_synth_fill_window(ctk_handle *h, float *anom_dev, int64_t t0, int64_t T, int ny, int nx, uint64_t seed);
 extern "C" int ctk_synth_fill(ctk_handle *h, float *anom_dev, int64_t T, int ny, int nx, uint64_t seed)
 {
-    if (!h || !anom_dev) return ctk_set_error(CTK_E_INVALID, "null argument");
+    return ctk_synth_fill_window(h, anom_dev, 0, T, ny, nx, seed);
+}
+
+extern "C" int ctk_checksum_i32_dev(ctk_handle *h, const int32_t *p_dev, int64_t n, int64_t index0, uint64_t *out2)
+{
+    if (!h || !out2 || n < 0 || (n > 0 && !p_dev)) return ctk_set_error(CTK_E_INVALID, "ctk_checksum_i32_dev: null argument or negative size");
+    HIPCHK(hipSetDevice(h->device));
+    CTKCHK(ensure(h, h->dbg, 16));
+    HIPCHK(hipMemsetAsync(h->dbg.p, 0, 16, h->stream));
+    if (n > 0) {
+        k_checksum_i32<<<(int)std::min<int64_t>((n + 255) / 256, 8192), 256, 0, h->stream>>>(p_dev, n, index0, (unsigned long long *)h->dbg.p);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(out2, h->dbg.p, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CTK_OK;
+}
+
+extern "C" int ctk_synth_fill_window(ctk_handle *h, float *anom_dev, int64_t t0, int64_t T, int ny, int nx, uint64_t seed)
+{
+    if (!h || !anom_dev || t0 < 0) return ctk_set_error(CTK_E_INVALID, "null argument");
     HIPCHK(hipSetDevice(h->device));
     const int64_t n = T * (int64_t)ny * nx;
     if (n > 0) {
         const int64_t blocks = std::min<int64_t>((n + 255) / 256, 1 << 20);      // grid-stride beyond 2^28 pixels
-        k_synth<<<(int)blocks, 256, 0, h->stream>>>(anom_dev, T, ny, nx, seed);
+        k_synth<<<(int)blocks, 256, 0, h->stream>>>(anom_dev, T, ny, nx, seed, t0);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -1409,14 +1409,14 @@ __global__ void k_copy_u32(const uint32_t *__restrict__ src, uint32_t *__restric
 // deterministic synthetic slab for throughput runs (bench only): a sum of 24 drifting smooth waves, tuned
 // (numpy emulation) to std ~ 94, ~9 % of the pixels above 160 and ~40 components per 1 deg timestep.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_synth(float *__restrict__ out, int64_t T, int ny, int nx, uint64_t seed)
+__global__ void k_synth(float *__restrict__ out, int64_t T, int ny, int nx, uint64_t seed, int64_t t_first)
 {
     // grid-stride: a HIP grid carries at most 2^32-1 work-items per dimension
     const int64_t n = T * (int64_t)ny * nx;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int x = (int)(i % nx);
     int y = (int)((i / nx) % ny);
-    int64_t t = i / ((int64_t)nx * ny);
+    int64_t t = i / ((int64_t)nx * ny) + t_first;
     float lon = 6.2831853f * (float)x / (float)nx, lat = 3.1415927f * ((float)y / (float)(ny - 1) - 0.5f);
     float tt = (float)t;
     float s = 0.f;
@@ -1437,3 +1437,23 @@ __global__ void k_synth(float *__restrict__ out, int64_t T, int ny, int nx, uint
     }
 }
 
+
+// position-weighted checksum of an int32 array (ctk_checksum_i32_dev): out[0] += sum (uint32)p[i] * (((index0 + i) * golden) | 1),
+// out[1] += nonzero elements.  One 64-bit atomic pair per workgroup (integer: the result does not depend on the order).
+__global__ __launch_bounds__(256) void k_checksum_i32(const int32_t *__restrict__ p, int64_t n, int64_t index0, unsigned long long *__restrict__ out)
+{
+    unsigned long long s = 0, nz = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = (uint32_t)p[i];
+        if (v) { s += (unsigned long long)v * ((((unsigned long long)(index0 + i)) * 0x9E3779B97F4A7C15ull) | 1ull); nz++; }
+    }
+    __shared__ unsigned long long sm[2][4];
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); nz += __shfl_down(nz, o); }
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = s; sm[1][threadIdx.x >> 6] = nz; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long a = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3], b = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
+        if (a) atomicAdd(&out[0], a);
+        if (b) atomicAdd(&out[1], b);
+    }
+}

@@ -133,6 +133,7 @@ __global__ void k_sh_pack_keep(ResolveDev r, int it_first, int it_count, uint32_
 #define CTK_SHM_HINT_C   7
 #define CTK_SHM_HINT_D   8
 #define CTK_SHM_MYFLAGGED 9
+#define CTK_SHM_MAXFLAGGED 10
 __global__ __launch_bounds__(256) void k_sh_unpack_keep(ResolveDev r, const unsigned char *__restrict__ gathered, unsigned char *__restrict__ prev,
                                                         int first_round, int redo, size_t slot, uint32_t capB, int rank, int world, int it_next,
                                                         uint8_t *__restrict__ tdirty, uint32_t *__restrict__ mail)
@@ -165,14 +166,14 @@ __global__ __launch_bounds__(256) void k_sh_unpack_keep(ResolveDev r, const unsi
     __syncthreads();
     for (size_t i = threadIdx.x; i < (size_t)world * slot; i += blockDim.x) prev[i] = gathered[i];
     if (threadIdx.x == 0) {
-        uint32_t nc_any = 0, mx = 0, amb = 0, bad = 0, hc = 0, hd_ = 0;
+        uint32_t nc_any = 0, mx = 0, amb = 0, bad = 0, hc = 0, hd_ = 0, mxf = 0;
         uint64_t ncs = 0;
         for (int q = 0; q < world; q++) {
             const KeepHeader *hd = (const KeepHeader *)(gathered + (size_t)q * slot);
-            nc_any |= hd->not_conv; mx = max(mx, hd->nlast); ncs += hd->nc_own; amb |= hd->ambig; bad |= hd->tables_bad;
+            nc_any |= hd->not_conv; mx = max(mx, hd->nlast); ncs += hd->nc_own; amb |= hd->ambig; bad |= hd->tables_bad; mxf = max(mxf, hd->ambig);
             hc = max(hc, hd->hint_c); hd_ = max(hd_, hd->hint_d);
         }
-        mail[CTK_SHM_HINT_C] = hc; mail[CTK_SHM_HINT_D] = hd_;
+        mail[CTK_SHM_HINT_C] = hc; mail[CTK_SHM_HINT_D] = hd_; mail[CTK_SHM_MAXFLAGGED] = mxf;
         mail[CTK_SHM_MYFLAGGED] = ((const KeepHeader *)(gathered + (size_t)rank * slot))->ambig;
         mail[CTK_SHM_CONTINUE] = (nc_any || s_diff_any) ? 1u : 0u;
         mail[CTK_SHM_MAXNLAST] = mx;
@@ -411,6 +412,15 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         return ctk_set_error(CTK_E_INVALID, "ctk_track_sharded: shard [%lld, %lld) of %lld steps does not fit rank %d of %d", (long long)t_begin,
                              (long long)(t_begin + T), (long long)T_total, rank, world);
     if (c->stream != h->stream) return ctk_set_error(CTK_E_INVALID, "ctk_track_sharded: the communicator belongs to another handle");
+    if (world > 448) return ctk_set_error(CTK_E_RANGE, "ctk_track_sharded: at most 448 ranks");         // (pinned scalar block of the counts)
+    if (c->dead) return ctk_set_error(CTK_E_COMM, "ctk_track_sharded: the communicator was aborted by an earlier failure; create a new one");
+    // from here on every buffer growth (hipFree waits for the device) and every wait goes through the communicator's guarded
+    // wait, and every error return that the other ranks cannot see by themselves is published to them (ctk_comm_abort in the
+    // C entry): no rank is left inside a collective
+    ActiveComm active(h, c);
+    // a failure decided on the SAME gathered data by every rank (all return the same code; the communicator stays usable)
+#define COLLECTIVE_FAIL(...) do { h->sh_collective_err = true; return ctk_set_error(__VA_ARGS__); } while (0)
+#define INJECT(k) do { if (h->debug_fail_stage == (k)) { h->debug_fail_stage = 0; return ctk_set_error(CTK_E_INTERNAL, "injected failure at stage %d (test hook)", (k)); } } while (0)
     const double t_call = now_ms();
     hipStream_t s = h->stream;
     const bool has_prev = rank > 0, has_next = rank + 1 < world;
@@ -424,6 +434,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     const int W = h->W;
     const size_t nw = (size_t)ny * W;
     SHDBG("label2d");
+    INJECT(1);
 
     // ---- X1: halo forward, first mask plane backward ------------------------------------------------------------------
     const size_t hb = halo2_bytes(h);
@@ -442,6 +453,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     const uint32_t *nh_ptr = &((const HaloHeader *)h->halo_in.p)->ncomp;
     h->halo_valid = has_prev;
     SHDBG("X1");
+    INJECT(2);
 
     // ---- component tables: halo components first ("timestep -1"), then the shard's own in (t, c) order ------------------
     {
@@ -523,7 +535,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     int n_fixups = 0;
     for (;;) {
         const int npass = first_round ? h->filter_round : std::max(2, h->filter_round / 2);
-        if (it_done + npass > CTK_MAX_JACOBI) return ctk_set_error(CTK_E_RANGE, "ctk_track_sharded: overlap filter did not converge within %d passes", CTK_MAX_JACOBI);
+        if (it_done + npass > CTK_MAX_JACOBI) COLLECTIVE_FAIL(CTK_E_RANGE, "ctk_track_sharded: overlap filter did not converge within %d passes", CTK_MAX_JACOBI);      // (the rounds are in lockstep)
         {
             Timer tm(h, CTK_K_RESOLVE);
             if (npass_grid > 0)
@@ -542,7 +554,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
             k_sh_unpack_keep<<<1, 256, 0, s>>>(r, (const unsigned char *)h->sh_recv.p, (unsigned char *)h->sh_prev.p, first_round ? 1 : 0, redo, slot, capB, rank, world,
                                                it_done + npass, P<uint8_t>(h->rv_tdirty), mail2);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(s));
+            CTKCHK(ctk_comm_wait(c));
             if (mail2[CTK_SHM_MAXNLAST] <= capB) break;
             if (!first_round) return ctk_set_error(CTK_E_INTERNAL, "boundary component count changed between rounds");
             capB = mail2[CTK_SHM_MAXNLAST] + mail2[CTK_SHM_MAXNLAST] / 2 + 64;      // same decision on every rank; nothing was imported
@@ -551,7 +563,8 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         it_done += npass;
         rounds++;
         first_round = false;
-        if (mail2[CTK_SHM_BAD]) return ctk_set_error(CTK_E_RANGE, "ctk_track_sharded: the co-occurrence table of some rank overflowed");
+        INJECT(3);
+        if (mail2[CTK_SHM_BAD]) COLLECTIVE_FAIL(CTK_E_RANGE, "ctk_track_sharded: the co-occurrence table of some rank overflowed");
         nc_sum = (uint64_t)mail2[CTK_SHM_NCSUM_LO] | ((uint64_t)mail2[CTK_SHM_NCSUM_HI] << 32);
         fix_changed = false;
         if (mail2[CTK_SHM_CONTINUE]) { last_was_fixup = false; continue; }
@@ -559,7 +572,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         if (last_was_fixup) break;                                      // ... or the numpy-order sums were just confirmed: nothing changed
         // ---- exact fix-up: some rank holds decisions on rounded area sums within rounding distance of the threshold --------
         const uint32_t nflag = mail2[CTK_SHM_MYFLAGGED];
-        if (nflag > AMB_CAP) return ctk_set_error(CTK_E_RANGE, "ctk_track_sharded: more than %u overlap decisions on rounding boundaries", AMB_CAP);
+        if (mail2[CTK_SHM_MAXFLAGGED] > AMB_CAP) COLLECTIVE_FAIL(CTK_E_RANGE, "ctk_track_sharded: more than %u overlap decisions on rounding boundaries on one rank", AMB_CAP);
         if (nflag) {
             const size_t cw = (size_t)nflag * 3 * (size_t)ny;
             CTKCHK(ensure(h, h->sh_counts, cw * 4));
@@ -573,7 +586,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
             HIPCHK(hipGetLastError());
             S.cnt.resize(cw);
             HIPCHK(hipMemcpyAsync(S.cnt.data(), h->sh_counts.p, cw * 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
+            CTKCHK(ctk_comm_wait(c));
             S.ovr.assign((size_t)nflag * 3, 0.0);
             for (uint32_t k = 0; k < nflag; k++)
                 for (int q = 0; q < 3; q++) {
@@ -589,7 +602,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
                 HIPCHK(hipMemcpyAsync(h->sh_ovr_val.p, h->h_lab, S.ovr.size() * 8, hipMemcpyHostToDevice, s));
                 k_exact_apply<<<(int)((nflag + 255) / 256), 256, 0, s>>>(r, nflag, it_done, P<uint8_t>(h->rv_tdirty));
                 HIPCHK(hipGetLastError());
-                HIPCHK(hipStreamSynchronize(s));                          // (h_lab is reused below)
+                CTKCHK(ctk_comm_wait(c));                                 // (h_lab is reused below)
                 S.ovr_prev = S.ovr;
             }
             n_fixups = (int)nflag;
@@ -602,7 +615,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     SHDBG("X3");
     h->stats[CTK_S_FILTER_PASSES] = it_done; h->stats[CTK_S_FILTER_ROUNDS] = rounds;
     h->stats[CTK_S_AMBIGUOUS] = 0;                    // (decisions on rounding boundaries are resolved here: CTK_S_EXACT_FIXUPS)
-    if (nc_sum > 0x7ffffff0ull) return ctk_set_error(CTK_E_RANGE, "ctk_track_sharded: more than 2^31 components over all shards");
+    if (nc_sum > 0x7ffffff0ull) COLLECTIVE_FAIL(CTK_E_RANGE, "ctk_track_sharded: more than 2^31 components over all shards");
 
     // ---- X4: 3-D labelling -------------------------------------------------------------------------------------------
     const size_t bslot = sizeof(BoundHeader) + (size_t)capB * 8;
@@ -621,7 +634,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     SHDBG("pack boundary");
     CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, bslot));
     HIPCHK(hipMemcpyAsync(h->h_shard, h->sh_recv.p, bslot * (size_t)world, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    CTKCHK(ctk_comm_wait(c));
     S.bin.assign((size_t)world, BoundaryIn());
     for (int q = 0; q < world; q++) {
         const unsigned char *p = (const unsigned char *)h->h_shard + (size_t)q * bslot;
@@ -629,11 +642,12 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         BoundaryIn &b = S.bin[(size_t)q];
         b.nlast = hd->nlast; b.nh = hd->nh; b.nroots = hd->nroots;
         b.last = (const int32_t *)(p + sizeof(BoundHeader)); b.halo = b.last + capB;
-        if (b.nlast < 0 || b.nh < 0 || (uint32_t)b.nlast > capB || (uint32_t)b.nh > capB) return ctk_set_error(CTK_E_INTERNAL, "boundary record of rank %d is malformed", q);
+        if (b.nlast < 0 || b.nh < 0 || (uint32_t)b.nlast > capB || (uint32_t)b.nh > capB) COLLECTIVE_FAIL(CTK_E_INTERNAL, "boundary record of rank %d is malformed", q);
     }
-    if (!boundary_resolve(S.bin, S.bout)) return ctk_set_error(CTK_E_INTERNAL, "ctk_track_sharded: the shards' boundary records contradict each other");
+    INJECT(4);
+    if (!boundary_resolve(S.bin, S.bout)) COLLECTIVE_FAIL(CTK_E_INTERNAL, "ctk_track_sharded: the shards' boundary records contradict each other");
     const int64_t NL = S.bout.off[(size_t)world];
-    if (NL > 0x7ffffff0ll) return ctk_set_error(CTK_E_RANGE, "ctk_track_sharded: more than 2^31 - 16 ids");
+    if (NL > 0x7ffffff0ll) COLLECTIVE_FAIL(CTK_E_RANGE, "ctk_track_sharded: more than 2^31 - 16 ids");
     h->n_labels = NL; h->t_begin = t_begin;
     const int64_t lab0 = S.bout.off[(size_t)rank], lab1 = S.bout.off[(size_t)rank + 1];
     // labels to mark on this rank: those of my halo components and of my last timestep's components (if a shard follows)
@@ -675,7 +689,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         k_compact_cands<<<(int)T, 64, 0, s>>>(r, P<CtkCand>(h->rv_cand_scratch), P<uint32_t>(h->rv_cand_cnt), P<uint32_t>(h->rv_cand_off), ny,
                                               P<CtkCand>(h->rv_cand), P<uint32_t>(h->rv_boff) + nsb, 0, 0, mail);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s));
+        CTKCHK(ctk_comm_wait(c));
     }
     uint32_t hs[CTK_MAIL_SCALARS];
     memcpy(hs, mail.scal, sizeof(hs));
@@ -699,7 +713,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
                 HIPCHK(hipMemcpyAsync(dst + cb, h->rv_dorig.p, nd * 4, hipMemcpyDeviceToHost, s));
                 HIPCHK(hipMemcpyAsync(dst + cb + nd * 4, h->rv_dbox.p, nd * 24, hipMemcpyDeviceToHost, s));
             }
-            HIPCHK(hipStreamSynchronize(s));
+            CTKCHK(ctk_comm_wait(c));
         }
     }
     const CtkCand *hc = (const CtkCand *)dst;
@@ -757,7 +771,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
                 if (!S.isglob[(size_t)find(hc[k].ll)]) { CtkCand v = hc[k]; v.ll = S.lmap[(size_t)v.ll]; v.lr = S.lmap[(size_t)v.lr]; S.lcand.push_back(v); }
             h->sd.run(S.lcand.data(), (int64_t)S.lcand.size(), S.lorig.data(), S.lbox.data(), (int64_t)S.lorig.size(), nx, S.ops_l);
         }
-        HIPCHK(hipStreamSynchronize(s));
+        CTKCHK(ctk_comm_wait(c));
         uint32_t mc = 0, md = 0;
         for (int q = 0; q < world; q++) {
             const SeamHeader *qh = (const SeamHeader *)(sb + sslot * (size_t)(q + 1));
@@ -767,6 +781,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         capC = std::max(capC, mc + mc / 2 + 64); capD = std::max(capD, md + md / 2 + 64);       // same on every rank
     }
     h->sh_capC = capC; h->sh_capD = capD;
+    INJECT(5);
     // merged table of the shared labels (boxes: union over the shards) and the shared candidate groups in (t, y) order
     S.glabel.clear(); S.gbox.clear(); S.gcand.clear();
     {
@@ -871,6 +886,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         CTKCHK((flag_dev || !h->sio) ? launch_relabel(h, persistence, flag_dev, true, cv) : stream_out(h, persistence, cv));
     }
     SHDBG("relabel");
+    INJECT(6);
     // ---- X7: counts ---------------------------------------------------------------------------------------------------
     CTKCHK(ensure(h, h->sh_send, 64));
     CTKCHK(ensure(h, h->sh_recv, 64 * (size_t)world));
@@ -878,7 +894,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     HIPCHK(hipGetLastError());
     CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, 8));
     HIPCHK(hipMemcpyAsync(mail2 + 64, h->sh_recv.p, 8 * (size_t)world, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    CTKCHK(ctk_comm_wait(c));
     int64_t alive = 0;
     bool zero = false;
     for (int q = 0; q < world; q++) { alive += mail2[64 + 2 * q]; zero = zero || mail2[64 + 2 * q + 1] != 0; }
@@ -890,19 +906,38 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     return CTK_OK;
 }
 
+// C entries: an error the other ranks cannot see by themselves (anything but a COLLECTIVE_FAIL) is published to them and retires
+// the communicator -- they return CTK_E_COMM from their next wait instead of sitting in a collective for ever
+static int track_sharded_entry(ctk_handle *h, ctk_comm *c, const void *anom_dev, bool f64, int64_t T_local, int64_t t_begin, int64_t T_total, int ny, int nx,
+                               const double *thr, int cmp_op, const float *wrow, double overlap, int persistence, int twosided, int32_t *flag_dev,
+                               int64_t *n_tracked)
+{
+    if (h) h->sh_collective_err = false;
+    const int rc = track_sharded_impl(h, c, anom_dev, f64, T_local, t_begin, T_total, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev, n_tracked);
+    if (rc != CTK_OK && c && h && !h->sh_collective_err) {
+        std::string msg = ctk_last_error();                          // (the abort drains the stream: keep the message of the cause)
+        ctk_comm_abort(c, rc);
+        ctk_set_error(rc, "%s", msg.c_str());
+    }
+    return rc;
+}
+
+extern "C" int ctk_debug_fail_at(ctk_handle *h, int stage)
+{
+    if (!h || stage < 0) return ctk_set_error(CTK_E_INVALID, "ctk_debug_fail_at: null handle or negative stage");
+    h->debug_fail_stage = stage;
+    return CTK_OK;
+}
+
 extern "C" int ctk_track_sharded_f32_dev(ctk_handle *h, ctk_comm *c, const float *anom_dev, int64_t T_local, int64_t t_begin, int64_t T_total, int ny, int nx,
                                          const double *thr, int cmp_op, const float *wrow, double overlap, int persistence, int twosided,
                                          int32_t *flag_dev, int64_t *n_tracked)
 {
-    const int rc = track_sharded_impl(h, c, anom_dev, false, T_local, t_begin, T_total, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev, n_tracked);
-    if (rc != CTK_OK) ctk_comm_abort(c);
-    return rc;
+    return track_sharded_entry(h, c, anom_dev, false, T_local, t_begin, T_total, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev, n_tracked);
 }
 extern "C" int ctk_track_sharded_f64_dev(ctk_handle *h, ctk_comm *c, const double *anom_dev, int64_t T_local, int64_t t_begin, int64_t T_total, int ny, int nx,
                                          const double *thr, int cmp_op, const float *wrow, double overlap, int persistence, int twosided,
                                          int32_t *flag_dev, int64_t *n_tracked)
 {
-    const int rc = track_sharded_impl(h, c, anom_dev, true, T_local, t_begin, T_total, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev, n_tracked);
-    if (rc != CTK_OK) ctk_comm_abort(c);
-    return rc;
+    return track_sharded_entry(h, c, anom_dev, true, T_local, t_begin, T_total, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev, n_tracked);
 }

@@ -11,12 +11,17 @@ What Python does here: split the time axis, bring the ranks together (the 128-by
 in /tmp keyed by the launcher -- single node, no sockets, no torch), and call ctk_track_sharded_*.
 
 Transports (CTK_DIST_BACKEND): "rccl" (default, one GPU per rank), "shm" (several processes sharing ONE GPU, host
-staging through POSIX shared memory: RCCL refuses two ranks on one device; plumbing tests on a one-GPU box).
+staging through POSIX shared memory: RCCL refuses two ranks on one device; plumbing tests on a one-GPU box).  There is no
+silent fallback: if RCCL cannot start, every rank raises.
+
+Failure behaviour: a rank that fails tells the others through the communicator's control segment (csrc/ctk_comm.h); their calls
+raise _native.CommError within milliseconds.  Dead ranks are noticed by pid; everything else by a deadline
+(CTK_COMM_TIMEOUT_S, default 120 s).
 """
-import atexit
 import ctypes as C
 import json
 import os
+import struct
 import sys
 import time
 
@@ -49,41 +54,85 @@ def launch_key():
                          int(os.environ.get("CTK_LAUNCH_PID", os.getppid())))
 
 
-def rendezvous_file(tag="id"):
-    return os.environ.get("CTK_RDZV_FILE") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "ctk_rdzv_%s_%s" % (launch_key(), tag))
+# communicators created by this process so far: every rank of a launch creates them in the same order, so the number names
+# the rendezvous of ONE communicator (a second ShardedTracker of the same launch never reads the first one's file)
+_comm_seq = [0]
 
 
-def broadcast_bytes(rank, make, nbytes, path=None, timeout_s=180.0):
+def rendezvous_file(tag="id", seq=None):
+    if os.environ.get("CTK_RDZV_FILE"):
+        return os.environ["CTK_RDZV_FILE"]
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "ctk_rdzv_%s_%d_%s" % (launch_key(), _comm_seq[0] if seq is None else seq, tag))
+
+
+_RDZV_MAGIC = b"CTKRDZV2"
+
+
+def _pid_alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return True
+    try:
+        with open("/proc/%d/stat" % pid) as f:
+            st = f.read()
+        return st[st.rindex(")") + 2] not in "ZX"          # killed but not reaped yet
+    except (OSError, ValueError, IndexError):
+        return True
+
+
+def broadcast_bytes(rank, make, nbytes, path=None, timeout_s=None):
     """rank 0 calls make() -> bytes of length nbytes and publishes them through a file; the other ranks wait for it.
-    Single node (the ranks share a file system); the file is removed by rank 0 at exit."""
+    Single node (the ranks share a file system).  The record carries rank 0's pid: a file left behind by a rank 0 that no
+    longer exists (a killed earlier launch with the same key) is ignored; a make() that raises is published as such, so that
+    the other ranks fail at once with rank 0's message instead of waiting for the deadline.  Remove the file with
+    rendezvous_done() once every rank is known to have read it (i.e. after the communicator exists)."""
     path = path or rendezvous_file()
+    timeout_s = float(os.environ.get("CTK_COMM_TIMEOUT_S", "120")) if timeout_s is None else timeout_s
     if rank == 0:
-        data = make()
-        assert len(data) == nbytes
+        err = None
+        try:
+            data = make()
+            assert len(data) == nbytes
+            rec = _RDZV_MAGIC + struct.pack("<iiq", 0, os.getpid(), nbytes) + data
+        except BaseException as e:      # noqa: BLE001 -- told to the other ranks, then re-raised
+            err = e
+            msg = ("%s: %s" % (type(e).__name__, e)).encode("utf-8", "replace")[:2000]
+            rec = _RDZV_MAGIC + struct.pack("<iiq", 1, os.getpid(), len(msg)) + msg
         tmp = "%s.tmp.%d" % (path, os.getpid())
         with open(tmp, "wb") as f:
-            f.write(data)
+            f.write(rec)
         os.replace(tmp, path)                       # atomic: readers see nothing or everything
-
-        def _cleanup(p=path):
-            try:
-                os.remove(p)
-            except OSError:
-                pass
-        atexit.register(_cleanup)
+        if err is not None:
+            raise err
         return data
     t0 = time.time()
     while True:
         try:
             with open(path, "rb") as f:
-                data = f.read()
-            if len(data) == nbytes:
-                return data
+                rec = f.read()
+            if len(rec) >= 24 and rec[:8] == _RDZV_MAGIC:
+                status, pid, n = struct.unpack("<iiq", rec[8:24])
+                if len(rec) == 24 + n and _pid_alive(pid):
+                    if status != 0:
+                        raise _native.CommError("rank %d: rank 0 could not start the communicator: %s" % (rank, rec[24:].decode("utf-8", "replace")))
+                    if n == nbytes:
+                        return rec[24:]
         except OSError:
             pass
         if time.time() - t0 > timeout_s:
-            raise TimeoutError("rank %d: rendezvous file %s did not appear within %.0f s" % (rank, path, timeout_s))
-        time.sleep(0.01)
+            raise _native.CommError("rank %d: rendezvous file %s did not appear within %.0f s" % (rank, path, timeout_s))
+        time.sleep(0.005)
+
+
+def rendezvous_done(rank, path):
+    if rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
 
 
 def env_rank_world():
@@ -94,23 +143,27 @@ def env_rank_world():
 
 
 def init_comm(tracker, rank, world, backend=None):
-    """the communicator of this rank: RCCL (default) or the shared-memory transport"""
+    """the communicator of this rank: RCCL (default) or the shared-memory transport (CTK_DIST_BACKEND=shm).  No fallback from
+    one to the other: a node where RCCL does not start is a node where the multi-GPU path does not run, and says so."""
     backend = backend or os.environ.get("CTK_DIST_BACKEND", "rccl")
+    seq = _comm_seq[0]
+    _comm_seq[0] += 1
     if backend == "rccl":
-        def make_id():
-            try:
-                return _native.comm_unique_id()
-            except _native.ContrackHipError as e:          # librccl.so cannot be loaded / refuses to start on this node
-                sys.stderr.write("contrack_amd.dist: RCCL is not usable here (%s); all ranks use the shared-memory transport\n" % e)
-                return bytes(_native.COMM_ID_BYTES)         # the all-zero id tells every rank the same thing
-        uid = broadcast_bytes(rank, make_id, _native.COMM_ID_BYTES)
-        if uid != bytes(_native.COMM_ID_BYTES):
-            c = _native.Comm.rccl(tracker, uid, rank, world)
-            c.transport = "rccl"
-            return c
-        backend = "shm"
+        path = rendezvous_file("id", seq)
+        uid = broadcast_bytes(rank, _native.comm_unique_id, _native.COMM_ID_BYTES, path)
+        try:
+            c = _native.Comm.rccl(tracker, uid, rank, world)         # (returns once every rank has arrived)
+        finally:
+            rendezvous_done(rank, path)
+        c.transport = "rccl"
+        return c
     if backend == "shm":
-        c = _native.Comm.shm(tracker, "ctk_%s" % launch_key(), rank, world)
+        path = rendezvous_file("shm", seq)
+        nonce = broadcast_bytes(rank, lambda: os.urandom(8), 8, path)      # a segment name nobody has used before
+        try:
+            c = _native.Comm.shm(tracker, "ctk_%s" % nonce.hex(), rank, world)
+        finally:
+            rendezvous_done(rank, path)
         c.transport = "shm"
         return c
     raise ValueError("CTK_DIST_BACKEND must be 'rccl' or 'shm', not %r" % backend)
@@ -129,7 +182,12 @@ class ShardedTracker:
         # RCCL wants one device per rank; the shared-memory transport also runs several ranks on one device (tests on a 1-GPU box)
         self.device = (local if backend == "rccl" else local % ndev) if device is None else int(device)
         self.trk = _native.Tracker(self.device)
-        self.comm = init_comm(self.trk, self.rank, self.world, backend)
+        self.comm = None
+        try:
+            self.comm = init_comm(self.trk, self.rank, self.world, backend)
+        except BaseException:
+            self.trk.close()
+            raise
 
     def close(self):
         if self.comm is not None:
@@ -143,7 +201,11 @@ class ShardedTracker:
         if f64:
             a = a.astype(np.float64)
         T, ny, nx = a.shape
-        d_in, d_out = self.trk.malloc(max(a.nbytes, 8)), self.trk.malloc(max(T * ny * nx * 4, 8))
+        try:
+            d_in, d_out = self.trk.malloc(max(a.nbytes, 8)), self.trk.malloc(max(T * ny * nx * 4, 8))
+        except BaseException:
+            self.comm.abort(-3)                      # the other ranks must not wait for this one
+            raise
         try:
             self.trk.h2d(d_in, a)
             n = self.trk.track_sharded_dev(self.comm, d_in, T, t_begin, T_total, ny, nx, thr_local, cmp_op, wrow, overlap, persistence,
@@ -159,6 +221,146 @@ class ShardedTracker:
 # ------------------------------------------------------------------------------------------------
 # bench.py leg for N > 1 (one rank per GPU, launched as the bench contract says)
 # ------------------------------------------------------------------------------------------------
+def _ptr(p, off):
+    return C.c_void_p((p.value if hasattr(p, "value") else int(p)) + int(off))
+
+
+def _scratch_dir():
+    d = os.environ.get("CTK_BENCH_TMP") or ("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else os.environ.get("TMPDIR", "/tmp"))
+    return d
+
+
+def _weights(ny, nx):
+    from . import synth
+    lat, _ = synth.grid(ny, nx)
+    return np.array((111 * np.float32(180.0 / (ny - 1)) * 111 * np.float32(360.0 / nx) * np.cos(lat * np.pi / 180))).astype(np.float32)
+
+
+def _timed_sharded(trk, comm, step, steps, warmup):
+    """barrier + sync | `steps` calls | sync + barrier; max over ranks (the bench contract's timing)"""
+    n = None
+    for _ in range(max(warmup, 0)):
+        n = step()
+    comm.barrier()
+    trk.sync()
+    ops0 = comm.ops()
+    tb = time.perf_counter()
+    for _ in range(steps):
+        n = step()
+    trk.sync()
+    comm.barrier()
+    dt_local = time.perf_counter() - tb
+    dt = float(comm.allgather(np.array([dt_local], dtype=np.float64)).max())
+    ops1 = comm.ops()
+    k = max(steps, 1)
+    return n, dt, dict(neighbour_exchanges=(ops1["neighbour_exchanges"] - ops0["neighbour_exchanges"]) / k,
+                       allgathers=(ops1["allgathers"] - ops0["allgathers"] - 2) / k)       # (- the two barriers / the time gather)
+
+
+def parity_check(trk, comm, rank, world, members, d_out_local, nloc, t0, T_total, ny, nx, thr_value, op, w, wl, n_tracked):
+    """In-run proof that the sharded result is the one-call result: every rank checksums its shard of `flag` on its GPU; rank 0
+    tracks the concatenated slab with ONE call on its own GPU and checksums the same windows.  `members`: how rank 0 obtains
+    member q's input -- ("file", path) written by rank q, or ("fill", seed, t_first, T_q) for the device generator.
+    Returns (checked, detail) on rank 0, (None, None) elsewhere.  Collective: every rank must call."""
+    plane = ny * nx
+    mine = np.array(trk.checksum_i32(d_out_local, nloc * plane, t0 * plane), dtype=np.uint64)
+    allsum = comm.allgather(mine)                                     # (world, 2)
+    bounds = comm.allgather(np.array([t0, nloc], dtype=np.int64))
+    detail = None
+    if rank == 0:
+        d_in = d_out = None
+        try:
+            d_in = trk.malloc(T_total * plane * 4)
+            d_out = trk.malloc(T_total * plane * 4)
+            for q in range(world):
+                tq, nq = int(bounds[q][0]), int(bounds[q][1])
+                m = members[q]
+                if m[0] == "file":
+                    trk.h2d(_ptr(d_in, tq * plane * 4), np.load(m[1], mmap_mode="r"))
+                else:
+                    trk.synth_fill(_ptr(d_in, tq * plane * 4), nq, ny, nx, seed=m[1], t0=m[2])
+            thr = np.full(T_total, thr_value)
+            trk.set_timing(0)
+            n_one = trk.track_dev(d_in, T_total, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], d_out)
+            equal = []
+            for q in range(world):
+                tq, nq = int(bounds[q][0]), int(bounds[q][1])
+                ref = trk.checksum_i32(_ptr(d_out, tq * plane * 4), nq * plane, tq * plane)
+                equal.append(bool(ref[0] == int(allsum[q][0]) and ref[1] == int(allsum[q][1])))
+            detail = dict(shards_equal=equal, n_tracked_one_call=int(n_one), n_tracked_sharded=int(n_tracked),
+                          flag_pixels=int(allsum[:, 1].sum()),
+                          method="64-bit position-weighted checksum of every rank's flag shard vs the same window of ONE ctk_track_f32_dev "
+                                 "call on the concatenated %dx%dx%d slab on rank 0's GPU" % (T_total, ny, nx))
+        except (MemoryError, _native.ContrackHipError, ValueError) as e:
+            detail = dict(error="%s: %s" % (type(e).__name__, e))
+        finally:
+            for p in (d_in, d_out):
+                if p is not None:
+                    trk.free(p)
+    comm.barrier()
+    if rank != 0:
+        return None, None
+    ok = bool(detail.get("shards_equal")) and all(detail["shards_equal"]) and detail["n_tracked_one_call"] == detail["n_tracked_sharded"]
+    return ok, detail
+
+
+def strong_block(trk, comm, rank, world, wl, T, steps, warmup):
+    """Strong scaling of ONE device-generated slab of T steps (the north_star's >= 6x target is stated on 0.25 deg): rank 0 times
+    the one-call path on the whole slab on its GPU, then all ranks track their windows of the same slab; speed-up = the ratio."""
+    ny, nx = wl["ny"], wl["nx"]
+    plane = ny * nx
+    w = _weights(ny, nx)
+    op = _native.CMP_OPS[wl["gorl"]]
+    thr_value = np.float64(np.float32(wl["threshold"]))
+    one = np.zeros(2, dtype=np.float64)                                # ms per pass on one GPU, tracked count
+    err = None
+    if rank == 0:
+        d_in = d_out = None
+        try:
+            d_in, d_out = trk.malloc(T * plane * 4), trk.malloc(T * plane * 4)
+            trk.synth_fill(d_in, T, ny, nx, seed=0)
+            thr = np.full(T, thr_value)
+            trk.set_timing(0)
+            for _ in range(max(warmup, 1)):
+                n1 = trk.track_dev(d_in, T, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], d_out)
+            trk.sync()
+            tb = time.perf_counter()
+            for _ in range(steps):
+                n1 = trk.track_dev(d_in, T, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], d_out)
+            trk.sync()
+            one[:] = ((time.perf_counter() - tb) * 1e3 / steps, n1)
+        except (MemoryError, _native.ContrackHipError, ValueError) as e:
+            err = "%s: %s" % (type(e).__name__, e)
+        finally:
+            for p in (d_in, d_out):
+                if p is not None:
+                    trk.free(p)
+    one = comm.allgather(one)[0]
+    if one[0] <= 0:
+        return dict(error=err or "the one-GPU pass did not run") if rank == 0 else None
+    t0, t1 = shard_bounds(T, world)[rank]
+    nloc = t1 - t0
+    d_in, d_out = trk.malloc(nloc * plane * 4), trk.malloc(nloc * plane * 4)
+    trk.synth_fill(d_in, nloc, ny, nx, seed=0, t0=t0)
+    thr = np.full(nloc, thr_value)
+
+    def step():
+        return trk.track_sharded_dev(comm, d_in, nloc, t0, T, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], d_out)
+    nN, dt, coll = _timed_sharded(trk, comm, step, steps, warmup)
+    trk.free(d_in)
+    trk.free(d_out)
+    if rank != 0:
+        return None
+    ms = dt * 1e3 / steps
+    return dict(workload="%dx%dx%d float32 (device-generated), threshold %s %g, overlap %g, persistence %d" % (
+                    T, ny, nx, wl["gorl"], wl["threshold"], wl["overlap"], wl["persistence"]),
+                n_gpus=world, ms_per_step_1gpu=float(one[0]), ms_per_step=ms, speedup_vs_1gpu=float(one[0]) / ms,
+                timesteps_per_s=T / (ms * 1e-3), n_tracked=int(nN), n_tracked_one_call=int(one[1]), n_tracked_equal=bool(int(one[1]) == int(nN)),
+                collectives_per_step=coll, steps=steps,
+                note="same launch: the one-call time is measured on rank 0's GPU (the whole slab resident), then the slab is split into "
+                     "%d time shards; barrier + sync around the timed calls, max over ranks" % world)
+
+
 def bench_main(args, wl, workloads, hbm_peak):
     from . import synth
     # Keep stdout clean for the ONE JSON line: RCCL may print through C stdio at communicator creation.  Everything
@@ -169,8 +371,9 @@ def bench_main(args, wl, workloads, hbm_peak):
     backend = os.environ.get("CTK_DIST_BACKEND", "rccl")
     st = ShardedTracker(rank=rank, world=world, backend=backend)
     trk, comm = st.trk, st.comm
-    backend = getattr(comm, "transport", backend)              # (shm if RCCL could not be loaded)
+    backend = getattr(comm, "transport", backend)
     T, ny, nx = wl["T"], wl["ny"], wl["nx"]
+    plane = ny * nx
     weak = getattr(args, "scaling", "weak") == "weak"
     if weak:
         # weak scaling: one member of wl["T"] steps per GPU, members concatenated on the time axis (the layout of
@@ -181,17 +384,25 @@ def bench_main(args, wl, workloads, hbm_peak):
         t0, t1 = shard_bounds(T, world)[rank]
         T_total = T
     nloc = t1 - t0
-    d_in = trk.malloc(max(nloc * ny * nx * 4, 8))
-    d_out = trk.malloc(max(nloc * ny * nx * 4, 8))
+    d_in = trk.malloc(max(nloc * plane * 4, 8))
+    d_out = trk.malloc(max(nloc * plane * 4, 8))
+    check_parity = not getattr(args, "no_parity_check", False) and 2 * T_total * plane * 4 <= (96 << 30)
+    member = None
     if wl.get("device_fill"):
-        trk.synth_fill(d_in, nloc, ny, nx, seed=rank if weak else 0)       # (strong + device_fill: every rank its own window)
-    elif weak:
-        trk.h2d(d_in, synth.smooth_field(T, ny, nx, seed=rank))
+        seed, tf = (rank, 0) if weak else (0, t0)
+        trk.synth_fill(d_in, nloc, ny, nx, seed=seed, t0=tf)
+        member = ("fill", seed, tf)
     else:
-        trk.h2d(d_in, synth.smooth_field(T, ny, nx, seed=0)[t0:t1])
-    lat, _ = synth.grid(ny, nx)
-    w = np.array((111 * np.float32(180.0 / (ny - 1)) * 111 * np.float32(360.0 / nx) * np.cos(lat * np.pi / 180))).astype(np.float32)
-    thr = np.full(nloc, np.float64(np.float32(wl["threshold"])))
+        a = synth.smooth_field(T, ny, nx, seed=rank) if weak else synth.smooth_field(T, ny, nx, seed=0)[t0:t1]
+        trk.h2d(d_in, a)
+        if check_parity:
+            path = os.path.join(_scratch_dir(), "ctk_bench_%s_member%d.npy" % (launch_key(), rank))
+            np.save(path, a)
+            member = ("file", path)
+        del a
+    w = _weights(ny, nx)
+    thr_value = np.float64(np.float32(wl["threshold"]))
+    thr = np.full(nloc, thr_value)
     op = _native.CMP_OPS[wl["gorl"]]
     trk.set_timing(1)            # HIP events around the two streaming kernels only (see bench.py)
 
@@ -217,7 +428,29 @@ def bench_main(args, wl, workloads, hbm_peak):
     ops1 = comm.ops()
     per = {k: v / max(args.steps, 1) for k, v in acc.items()}
     stats = trk.stats()
-    px = nloc * ny * nx
+    px = nloc * plane
+
+    # ---- untimed: the result proves itself (in-run parity against the one-call path), then the strong-scaling leg -----------
+    parity_ok, parity = None, None
+    if check_parity:
+        kinds = comm.allgather(np.array([1 if member[0] == "file" else 0, member[1] if member[0] == "fill" else 0,
+                                         member[2] if member[0] == "fill" else 0], dtype=np.int64))
+        members = [("file", os.path.join(_scratch_dir(), "ctk_bench_%s_member%d.npy" % (launch_key(), q))) if int(kinds[q][0]) else
+                   ("fill", int(kinds[q][1]), int(kinds[q][2])) for q in range(world)]
+        parity_ok, parity = parity_check(trk, comm, rank, world, members, d_out, nloc, t0, T_total, ny, nx, thr_value, op, w, wl, n_tracked)
+        if member[0] == "file":
+            try:
+                os.remove(member[1])
+            except OSError:
+                pass
+    trk.free(d_in)
+    trk.free(d_out)
+    strong = None
+    sT = int(getattr(args, "strong_steps", 0) or 0)
+    if sT >= world and world > 1:
+        swl = workloads["era5_025deg_2k"]
+        strong = strong_block(trk, comm, rank, world, swl, sT, max(2, min(args.steps, 5)), 1)
+
     alg = {"k_threshold": 4.0 * px, "k_relabel": 4.0 * px}
     kern = max(alg, key=lambda k: per.get(k, 0.0))
     achieved = alg[kern] / (per[kern] * 1e-3) / 1e9 if per.get(kern, 0) > 0 else 0.0
@@ -233,18 +466,19 @@ def bench_main(args, wl, workloads, hbm_peak):
                        parallelism="time-sharded x%d: one-timestep halo + boundary records, shard-local resolver (%s)" % (
                            world, "RCCL ncclSend/Recv + ncclAllGather" if backend == "rccl" else "shared-memory transport (host staging; several ranks may share a GPU)"),
                        transport=backend, rccl_ranks=world if backend == "rccl" else 0, n_tracked=n_tracked,
+                       parity_checked=bool(parity_ok) if parity_ok is not None else False, parity=parity,
                        collectives_per_step=dict(neighbour_exchanges=(ops1["neighbour_exchanges"] - ops0["neighbour_exchanges"]) / nsteps,
-                                                 allgathers=(ops1["allgathers"] - ops0["allgathers"]) / nsteps)),
+                                                 allgathers=(ops1["allgathers"] - ops0["allgathers"] - 2) / nsteps)),      # (- the closing barrier and the time gather)
                    roofline=dict(bound="hbm", kernel={"k_threshold": "k_threshold_v4", "k_relabel": {5: "k_relabel_v5", 4: "k_relabel_v4"}.get(stats.get("relabel_kernel", 4), "k_relabel")}[kern], achieved=achieved, peak=hbm_peak,
                                  unit="GB/s", frac=achieved / hbm_peak, traffic=None, algorithmic_bytes_per_launch=alg[kern],
                                  avg_kernel_ms=per.get(kern), note="rank 0's shard"),
                    kernels_ms=per, workload_stats_rank0=stats)
+        if strong is not None:
+            out["strong_025deg"] = strong
         try:
             C.CDLL(None).fflush(None)            # drain C stdio into stderr before stdout is restored
         except Exception:
             pass
         os.dup2(sys_stdout_fd, 1)
         print(json.dumps(out), flush=True)
-    trk.free(d_in)
-    trk.free(d_out)
     st.close()

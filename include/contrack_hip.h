@@ -41,6 +41,8 @@ extern "C" {
 #define CTK_E_RANGE      -4   /* weight dynamic range or problem size beyond what the kernels carry */
 #define CTK_E_INTERNAL   -5
 #define CTK_E_STATE      -6   /* staged calls out of order                                       */
+#define CTK_E_COMM       -7   /* time-shard path: another rank gave up, died or did not arrive in time (the message names it);
+                                 the communicator is retired -- create a new one                      */
 
 typedef struct ctk_handle ctk_handle;
 
@@ -156,6 +158,18 @@ int  ctk_comm_world(const ctk_comm *c);
 int  ctk_comm_barrier(ctk_comm *c);
 int  ctk_comm_allgather_host(ctk_comm *c, const void *send, void *recv /* world * nbytes */, size_t nbytes /* <= 4096 */);
 int  ctk_comm_ops(const ctk_comm *c, int64_t *shifts, int64_t *allgathers);      /* operations issued so far */
+/* Failure behaviour.  No rank is left waiting for one that gave up or died: the ranks of an rccl / shm communicator share a small
+ * control segment in POSIX shared memory (single node) with a failure word and every rank's pid; every wait of the path polls it,
+ * checks that the peers' processes still exist, and carries a deadline (seconds; default 120 or CTK_COMM_TIMEOUT_S).  A call that
+ * fails on one rank makes every other rank's call return CTK_E_COMM (the message names the rank and its code) -- within
+ * milliseconds, not at the deadline; the RCCL communicator is aborted (ncclCommAbort) so that kernels in flight return.  Errors
+ * that every rank derives from the same gathered data (table overflow, id range) are returned by all ranks with their own code
+ * and leave the communicator usable. */
+int  ctk_comm_set_timeout(ctk_comm *c, double seconds);
+int  ctk_comm_failed(const ctk_comm *c, int *code /* 0: fine */, int *rank);
+int  ctk_comm_abort_rank(ctk_comm *c, int code /* < 0 */);                      /* this rank gives up (e.g. its caller failed elsewhere) */
+/* test hook: the next ctk_track_sharded_* call on this handle fails at stage 1..6 (between two collectives), once */
+int  ctk_debug_fail_at(ctk_handle *h, int stage);
 int  ctk_track_sharded_f32_dev(ctk_handle *h, ctk_comm *c, const float *anom_dev, int64_t T_local, int64_t t_begin, int64_t T_total,
                                int ny, int nx, const double *thr /* T_local */, int cmp_op, const float *wrow, double overlap,
                                int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked);
@@ -267,6 +281,12 @@ int ctk_sync(ctk_handle *h);
 void *ctk_stream(ctk_handle *h);                          /* hipStream_t */
 /* deterministic on-device synthetic slab for throughput runs (bench only; not part of the path) */
 int ctk_synth_fill(ctk_handle *h, float *anom_dev, int64_t T, int ny, int nx, uint64_t seed);
+/* the window [t0, t0 + T) of the slab that ctk_synth_fill(seed) generates for any T >= t0 + T: time shards of one synthetic slab */
+int ctk_synth_fill_window(ctk_handle *h, float *anom_dev, int64_t t0, int64_t T, int ny, int nx, uint64_t seed);
+/* position-weighted checksum of an int32 device array (bench.py's in-run parity check of the time-shard path: the shards'
+ * checksums against those of the one-call result).  out[0] = sum over i of (uint32)p[i] * (((index0 + i) * 0x9E3779B97F4A7C15) | 1)
+ * mod 2^64, out[1] = number of nonzero elements.  Equal for two arrays iff (up to 2^-64 collisions) the arrays are equal. */
+int ctk_checksum_i32_dev(ctk_handle *h, const int32_t *p_dev, int64_t n, int64_t index0, uint64_t *out2);
 
 /* ---- next row N1: contrack.run_lifecycle reductions (contrack/contrack.py:798-906) --------------------------
  * One row per (time step, flag id != 0) of an int32 flag slab (time, lat, lon) and a field of the same shape:

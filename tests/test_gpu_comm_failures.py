@@ -1,0 +1,167 @@
+"""Failure behaviour of the time-shard path (csrc/ctk_comm.h): no rank is ever left inside a collective.
+
+* a rank that fails between two collectives (test hook ctk_debug_fail_at, stages 1..6) -> every rank's call returns an error within
+  seconds: the failing one with its own error, the others with CTK_E_COMM naming it -- in-process group (threads) and one
+  process per rank over the shared-memory transport (same control segment as the RCCL transport);
+* a rank whose process is gone, a rank that never makes the call (deadline);
+* an error every rank derives from the same gathered data (co-occurrence table overflow) leaves the communicator usable.
+The couplings the exchanges keep exact: contrack/contrack.py:719, :729-737, :753-763.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import golden_util
+from contrack_amd import _native
+
+pytestmark = pytest.mark.gpu
+
+
+def _case():
+    g = golden_util.load("busy_s1")
+    return g, g["anom"].shape
+
+
+@pytest.mark.parametrize("stage", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("bad_rank", [0, 2])
+def test_injected_failure_in_process_group(stage, bad_rank):
+    import threading
+    g, (T, ny, nx) = _case()
+    n = 3
+    cuts = [0, T // 3, 2 * T // 3, T]
+    trks = [_native.Tracker(0) for _ in range(n)]
+    group = _native.CommGroup(n)
+    comms = [_native.Comm.local(trks[r], group, r) for r in range(n)]
+    for c in comms:
+        c.set_timeout(20.0)
+    err = [None] * n
+
+    def work(r):
+        t0, t1 = cuts[r], cuts[r + 1]
+        d_in, d_out = trks[r].malloc((t1 - t0) * ny * nx * 4), trks[r].malloc((t1 - t0) * ny * nx * 4)
+        try:
+            trks[r].h2d(d_in, np.ascontiguousarray(g["anom"][t0:t1]))
+            if r == bad_rank:
+                trks[r].debug_fail_at(stage)
+            trks[r].track_sharded_dev(comms[r], d_in, t1 - t0, t0, T, ny, nx, g["thr"][t0:t1], _native.CMP_OPS[g["gorl"]], g["wrow"], g["overlap"],
+                                      g["persistence"], g["twosided"], d_out)
+        except Exception as e:      # noqa: BLE001
+            err[r] = e
+        finally:
+            trks[r].free(d_in); trks[r].free(d_out)
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    t_start = time.time()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=60)
+    took = time.time() - t_start
+    assert not any(t.is_alive() for t in th), "a rank is still waiting"
+    assert took < 15, took
+    assert "injected failure" in str(err[bad_rank])
+    for r in range(n):
+        if r != bad_rank:
+            assert isinstance(err[r], _native.CommError), (r, err[r])
+            assert "rank %d" % bad_rank in str(err[r])
+    assert comms[0].failed() is not None
+    for c in comms:
+        c.close()
+    group.close()
+    for t in trks:
+        t.close()
+
+
+def _proc_worker(rank, world, key, mode, stage, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_PORT=str(key), CTK_LAUNCH_PID=str(key),
+                      CTK_DIST_BACKEND="shm", HSA_ENABLE_IPC_MODE_LEGACY="0", CTK_COMM_TIMEOUT_S="60")
+    from contrack_amd import dist as cdist
+    g = golden_util.load("busy_s1")
+    T = g["anom"].shape[0]
+    t0, t1 = cdist.shard_bounds(T, world)[rank]
+    st = cdist.ShardedTracker()
+    args = (g["anom"][t0:t1], t0, T, g["thr"][t0:t1], _native.CMP_OPS[g["gorl"]], g["wrow"], g["overlap"], g["persistence"], g["twosided"])
+    t_start = time.time()
+    try:
+        if mode == "inject" and rank == 1:
+            st.trk.debug_fail_at(stage)
+        if mode == "exit" and rank == 1:
+            q.put((rank, "gone", "", 0.0))
+            os._exit(0)                                   # the process disappears without a word
+        if mode == "absent" and rank == 1:
+            time.sleep(8)                                 # alive, but never makes the call in time
+        if mode == "absent" and rank == 0:
+            st.comm.set_timeout(3.0)
+        if mode == "collective":
+            # the pair table of rank 1 overflows: every rank learns it from the gathered headers and returns the same error ...
+            if rank == 1:
+                _native.lib().ctk_debug_set_pair_capacity(st.trk.handle, 4)
+            try:
+                st.track(*args)
+                q.put((rank, "no error", "", time.time() - t_start))
+                return
+            except ValueError as e:
+                first = str(e)
+            # ... and the communicator is still usable: the next call gives the right result
+            flag, n = st.track(*args)
+            ok = bool(np.array_equal(flag, g["flag"][t0:t1])) and n == len(np.unique(g["flag"])) - 1
+            q.put((rank, "ok" if ok else "mismatch", first, time.time() - t_start))
+            return
+        st.track(*args)
+        q.put((rank, "no error", "", time.time() - t_start))
+    except Exception as e:      # noqa: BLE001
+        q.put((rank, type(e).__name__, str(e), time.time() - t_start))
+    finally:
+        st.close()
+
+
+def _run(mode, stage=0, world=2, deadline=120):
+    import multiprocessing as mp
+    import uuid
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = 30000 + uuid.uuid4().int % 30000
+    procs = [ctx.Process(target=_proc_worker, args=(r, world, key, mode, stage, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = dict()
+        for _ in range(world):
+            r = q.get(timeout=deadline)
+            res[r[0]] = r[1:]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    return res
+
+
+@pytest.mark.parametrize("stage", [1, 3, 5])
+def test_injected_failure_processes_shm(stage):
+    res = _run("inject", stage)
+    assert "injected failure" in res[1][1], res
+    assert res[0][0] == "CommError" and "rank 1" in res[0][1], res
+    assert res[0][2] < 20 and res[1][2] < 20, res          # seconds, not the deadline
+
+
+def test_vanished_rank_is_noticed():
+    res = _run("exit")
+    assert res[0][0] == "CommError", res
+    assert "gone" in res[0][1] or "rank 1" in res[0][1], res
+    assert res[0][2] < 30, res
+
+
+def test_absent_rank_meets_the_deadline():
+    res = _run("absent")
+    assert res[0][0] == "CommError" and "did not complete within" in res[0][1], res
+    assert 2.0 < res[0][2] < 30, res
+    assert res[1][0] == "CommError", res                   # the late rank finds the published failure at once
+
+
+def test_collective_error_leaves_the_communicator_usable():
+    res = _run("collective")
+    for r in (0, 1):
+        assert res[r][0] == "ok", res
+        assert "co-occurrence table" in res[r][1], res

@@ -135,12 +135,13 @@ def _rdzv_worker(rank, path, q):
     payload = bytes(range(128))
     got = cdist.broadcast_bytes(rank, lambda: payload, 128, timeout_s=60.0)
     q.put((rank, got == payload))
-    # rank 0 removes the file when it exits; in a real job that is after the last collective.  Here: after rank 1 has read it.
+    # rank 0 removes the file once every rank is known to have read it (in a real job: when the communicator exists)
     import time
     if rank == 0:
         t0 = time.time()
         while not os.path.exists(path + ".ack") and time.time() - t0 < 60:
             time.sleep(0.01)
+        cdist.rendezvous_done(0, path)
     else:
         open(path + ".ack", "w").close()
 
@@ -156,6 +157,43 @@ def test_rendezvous_two_processes(tmp_path):
     for p in procs:
         p.join(timeout=30)
     assert res == [(0, True), (1, True)]
+    assert not os.path.exists(path)
+
+
+def test_rendezvous_ignores_a_dead_writers_file(tmp_path):
+    """a record left behind by a rank 0 that no longer exists (killed earlier launch, same key) must not be taken for the new one"""
+    import struct
+    import subprocess
+    import sys
+    from contrack_amd import _native
+    path = str(tmp_path / "rdzv")
+    p = subprocess.Popen([sys.executable, "-c", "pass"])
+    p.wait()                                                   # a pid that existed and is gone
+    with open(path, "wb") as f:
+        f.write(b"CTKRDZV2" + struct.pack("<iiq", 0, p.pid, 8) + b"stale!!!")
+    with pytest.raises(_native.CommError):
+        cdist.broadcast_bytes(1, None, 8, path=path, timeout_s=0.5)
+    # the live writer's record replaces it and is accepted
+    assert cdist.broadcast_bytes(0, lambda: b"fresh..!", 8, path=path) == b"fresh..!"
+    assert cdist.broadcast_bytes(1, None, 8, path=path, timeout_s=5.0) == b"fresh..!"
+
+
+def test_rendezvous_publishes_rank0_failure(tmp_path):
+    """rank 0 cannot make the id (RCCL does not start): the others hear about it at once instead of waiting for the deadline"""
+    from contrack_amd import _native
+    path = str(tmp_path / "rdzv")
+
+    def boom():
+        raise RuntimeError("librccl.so not found")
+    with pytest.raises(RuntimeError):
+        cdist.broadcast_bytes(0, boom, 128, path=path)
+    with pytest.raises(_native.CommError, match="librccl.so not found"):
+        cdist.broadcast_bytes(1, None, 128, path=path, timeout_s=30.0)
+
+
+def test_rendezvous_names_are_per_communicator(monkeypatch):
+    monkeypatch.delenv("CTK_RDZV_FILE", raising=False)
+    assert cdist.rendezvous_file("id", 0) != cdist.rendezvous_file("id", 1)
 
 
 def test_shard_bounds():
