@@ -3,6 +3,7 @@
 // sequential resolver in ctk_resolve.cpp.
 #include "ctk_kernels.hip"
 #include "ctk_resolve_dev.hip"
+#include "ctk_seam_dev.hip"
 #include "ctk_lifecycle.hip"
 #include "ctk_seam.h"
 #include "ctk_comm.h"
@@ -143,6 +144,16 @@ struct ctk_handle {
     const int32_t *lc_flag = nullptr; const void *lc_field = nullptr;       // slabs of the last ctk_lifecycle_* call (for the exact rows)
     bool lc_f64 = false; int64_t lc_T = 0; int lc_ny = 0, lc_nx = 0;
     DevBuf chunk_vals;                             // run values in the chunk order of k_relabel_v4
+    // fused one-call path (ctk_seam_dev.hip): clusters of candidate labels, cluster root per group record; the pass runs without a
+    // host hand-off and is validated from a device-written block of scalars after its only synchronisation
+    DevBuf sd_parent, sd_tmin, sd_tmax, sd_root, sd_nops;
+    uint32_t *h_amail = nullptr;                   // pinned: AsyncMail scalars
+    uint32_t op_cap_hint = 4096;                   // operation slots of the next fused pass (grows with what the passes needed)
+    uint32_t nd_hint = 4096;                       // dense candidate labels of the last pass: grid of k_seam_driver
+    int async_passes = CTK_JACOBI_ROUND;           // filter passes the next fused pass launches
+    int use_async = -1;                            // -1: not decided (env CTK_ASYNC), 0 / 1
+    int async_off_ny = -1, async_off_nx = -1;      // grid whose clusters did not fit the device seam driver: synchronous path from then on
+    bool guard_on = false;                         // kernels behind the resolver check the device counters before touching the tables
     // calc_anom / percentile (ctk_anom.hip): resident anomaly slab, climatology, scratch
     DevBuf an_out, an_clim, an_raw, an_idx;
     int64_t an_T = -1; int an_ny = 0, an_nx = 0; bool an_f64 = false;
@@ -179,7 +190,7 @@ struct ctk_handle {
     std::vector<double> c_thr; std::vector<float> c_w;
     int64_t c_T = -1; bool c_f64 = false, c_thr_valid = false, c_w_valid = false; int c_cmp = -1, c_w_nx = -1;
     int w_minlsb = 0;                            // lowest set bit over the integer row weights
-    int64_t last_alive = 0;
+    int64_t last_alive = 0, last_nlab = 0;
     int64_t rowoff_T = -1; int rowoff_ny = -1; void *rowoff_p = nullptr;     // what seam_rowoff currently holds
     // speculative launch of the 2-D labelling: capacity (in runs) of the run-indexed buffers, the previous call's variants
     uint32_t runs_cap = 0;
@@ -376,7 +387,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
                       &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
                       &h->sh_mask_next, &h->sh_send, &h->sh_recv, &h->sh_prev, &h->sh_elist, &h->sh_ovr_slot, &h->sh_ovr_val,
-                      &h->sh_amb_list, &h->sh_counts, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx};
+                      &h->sh_amb_list, &h->sh_counts, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_root, &h->sd_nops};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -388,6 +399,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
     if (h->h_mail1) (void)hipHostFree(h->h_mail1);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_mail2) (void)hipHostFree(h->h_mail2);
+    if (h->h_amail) (void)hipHostFree(h->h_amail);
     if (h->h_shard) (void)hipHostFree(h->h_shard);
     if (h->h_lab) (void)hipHostFree(h->h_lab);
     if (h->h_seam) (void)hipHostFree(h->h_seam);
@@ -1015,6 +1027,7 @@ static int launch_extents(ctk_handle *h, bool ext_filled = false, bool with_fina
     }
     if (h->T > 0) {
         ExtentArgs a;
+        a.guard = h->guard_on ? P<uint32_t>(h->counters) : nullptr;
         a.mask = P<uint64_t>(h->mask); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
         a.run_comp = P<uint32_t>(h->run_comp); a.ncomp = P<uint32_t>(h->ncomp); a.cprefix = CPX(h);
         a.comp_label = P<int32_t>(h->comp_label); a.lab = with_final ? P<int32_t>(h->rv_lab) : nullptr; a.comp_label_w = P<int32_t>(h->comp_label);
@@ -1121,6 +1134,7 @@ static int rs_prepare(ctk_handle *h, const ResolveIn &in, double overlap, int tw
     r.next_tiny = (const int32_t *)(P<int64_t>(h->wlo) + 2 * (size_t)h->ny); r.touch = P<uint32_t>(h->rv_touch);
     r.nh_ptr = nullptr; r.t_lo = 1; r.t_hi = (int)T - 2;                // one slab: timesteps 1 .. T-2 are filtered, no halo
     r.ovr_slot = nullptr; r.ovr_val = nullptr; r.amb_cnt = P<uint32_t>(h->rv_scalars) + 2; r.amb_list = nullptr; r.amb_cap = 0;
+    r.cl_parent = nullptr; r.cl_tmin = nullptr; r.cl_tmax = nullptr; r.cl_nops = nullptr; r.ext = nullptr; r.ext_off = 0; r.counters_w = nullptr;      // (fused one-call path only)
 
     const int gc = (int)std::min<size_t>((R + 255) / 256, 2048), gp = (int)std::min<size_t>((PC + 255) / 256, 2048);
     // mailbox in pinned host memory: the last resolver kernel writes scalars, candidate records and dense label tables
@@ -1242,6 +1256,28 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         const CtkCand *hc = (const CtkCand *)dst;
         const int32_t *ho = (const int32_t *)(dst + cb), *hb = ho + nd;
         h->sd.run(hc, ncand, ho, hb, (int64_t)nd, h->nx, ops);
+        if (getenv("CTK_SEAMSTATS")) {
+            // clusters of candidate labels (connected through shared seam rows): what a parallel device-side driver would see
+            std::vector<int32_t> uf(nd);
+            for (size_t i = 0; i < nd; i++) uf[i] = (int32_t)i;
+            auto find = [&](int32_t i) { while (uf[(size_t)i] != i) { uf[(size_t)i] = uf[(size_t)uf[(size_t)i]]; i = uf[(size_t)i]; } return i; };
+            for (int64_t k = 0; k < ncand; k++) { const int32_t a = find(hc[k].ll), b = find(hc[k].lr); if (a != b) uf[(size_t)std::max(a, b)] = std::min(a, b); }
+            std::vector<int32_t> nrec(nd, 0), nops(nd, 0), nrows(nd, 0), tmin(nd, INT32_MAX), tmax(nd, -1), ndiff(nd, 0);
+            for (int64_t k = 0; k < ncand; k++) { const int32_t r = find(hc[k].ll); nrec[r]++; nrows[r] += (int32_t)(((uint32_t)hc[k].yy >> 16) - (hc[k].yy & 0xffff) + 1); tmin[r] = std::min(tmin[r], hc[k].t); tmax[r] = std::max(tmax[r], hc[k].t); if (hc[k].ll != hc[k].lr) ndiff[r]++; }
+            std::vector<int32_t> dense_of(1);
+            for (size_t i = 0; i < ops.size(); i++) { for (size_t d = 0; d < nd; d++) if (ho[d] == ops[i].hi) { nops[find((int32_t)d)]++; break; } }
+            int ncl = 0, mrec = 0, mops = 0, mspan = 0, ntriv = 0; int64_t sumspan = 0;
+            std::vector<int> hist(12, 0);
+            for (size_t d = 0; d < nd; d++) if (nrec[d]) { ncl++; mrec = std::max(mrec, nrec[d]); mops = std::max(mops, nops[d]); mspan = std::max(mspan, tmax[d] - tmin[d] + 1); sumspan += tmax[d] - tmin[d] + 1; if (!ndiff[d]) ntriv++; int b = 0; while ((1 << b) < nrec[d]) b++; hist[std::min(b, 11)]++; }
+            fprintf(stderr, "SEAMSTATS ncand %lld nd %zu ops %zu clusters %d (trivial %d) max_records %d max_ops %d max_span %d sum_span %lld hist(log2 records):", (long long)ncand, nd, ops.size(), ncl, ntriv, mrec, mops, mspan, (long long)sumspan);
+            for (int b = 0; b < 12; b++) fprintf(stderr, " %d", hist[b]);
+            fprintf(stderr, "\n");
+            // the heaviest clusters
+            std::vector<std::pair<int, int>> top;
+            for (size_t d = 0; d < nd; d++) if (nrec[d]) top.emplace_back(nrec[d], (int)d);
+            std::sort(top.rbegin(), top.rend());
+            for (size_t i = 0; i < std::min<size_t>(top.size(), 8); i++) fprintf(stderr, "  cluster records %d rows %d ops %d span %d\n", top[i].first, nrows[top[i].second], nops[top[i].second], tmax[top[i].second] - tmin[top[i].second] + 1);
+        }
         h->stats[9] = h->sd.loop_ns;                              // ns spent in the candidate loop
         h->stats[10] = h->sd.nfold;
         h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t1;
@@ -1416,6 +1452,7 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
     a.flag = flag_dev; a.counters = P<uint32_t>(h->counters);
     a.nrows = nt * h->ny; a.ny = h->ny; a.nx = h->nx; a.W = h->W;
     a.chunk_vals = chunk_vals ? chunk_vals + t0 * nchunk * CTK_CV : nullptr;
+    a.guard = h->guard_on ? P<uint32_t>(h->counters) : nullptr;
     const int64_t npl = (int64_t)h->ny * h->nx;
     const int rvcap = 2048;
     const size_t lds = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) + (size_t)rvcap * 4;
@@ -1462,10 +1499,10 @@ extern "C" int ctk_shard_write(ctk_handle *h, int persistence, int32_t *flag_dev
         Timer tm(h, CTK_K_COUNT);
         // (the counters were zeroed by k_fill_ext / k_ops_ingest; the last workgroup writes the results to pinned memory)
         if (h->n_labels <= 262144)
-            k_count_alive_1<<<1, 1024, 0, s>>>(P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->counters), h->h_mail1 + 8);
+            k_count_alive_1<<<1, 1024, 0, s>>>(P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->counters), h->h_mail1 + 8, AsyncMail{});
         else
-            k_count_alive<<<(int)((h->n_labels + 255) / 256 + 1), 256, 0, s>>>(P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->counters),
-                                                                               h->h_mail1 + 8);
+            k_count_alive<<<(int)std::min<int64_t>((h->n_labels + 255) / 256 + 1, 4096), 256, 0, s>>>(P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->counters),
+                                                                                                    h->h_mail1 + 8, AsyncMail{});
         HIPCHK(hipGetLastError());
     }
     HT("tail launched");
@@ -1487,6 +1524,149 @@ extern "C" int ctk_shard_count_tracked(ctk_handle *h, int64_t *n_alive)
 }
 
 // ------------------------------------------------------------------------------------------------
+// fused one-call path: everything behind k_overlap without a host hand-off.  The resolver kernels, the device seam driver
+// (ctk_seam_dev.hip), extents, run values, the write pass and the count are enqueued in one go; the counting kernel leaves a
+// block of scalars in pinned memory; the host synchronises ONCE and validates: co-occurrence table intact, filter converged
+// within the passes launched, no decision on a rounding boundary, seam clusters within the driver's tables.  Anything else:
+// returns 1 and the caller repeats the resolution on the synchronous path (which handles all of those).
+// ------------------------------------------------------------------------------------------------
+static bool async_wanted(ctk_handle *h)
+{
+    if (h->use_async < 0) { const char *e = getenv("CTK_ASYNC"); h->use_async = (e && atoi(e) == 0) ? 0 : 1; }
+    return h->use_async == 1 && !h->sio && h->T >= 1 && !(h->async_off_ny == h->ny && h->async_off_nx == h->nx);
+}
+
+static int resolve_async(ctk_handle *h, double overlap, int twosided, int persistence, int32_t *flag_dev, int64_t *n_tracked)
+{
+    hipStream_t s = h->stream;
+    const int64_t T = h->T;
+    const size_t R = h->total_runs ? h->total_runs : 1;
+    CTKCHK(ensure(h, h->comp_label, R * 4));
+    CTKCHK(ensure(h, h->seam_rowoff, (size_t)(T + 1) * 4));
+    if (h->rowoff_T != T || h->rowoff_ny != h->ny || h->rowoff_p != h->seam_rowoff.p) {
+        k_iota_mul<<<(int)((T + 255) / 256), 256, 0, s>>>(P<uint32_t>(h->seam_rowoff), (uint32_t)T, (uint32_t)h->ny);
+        h->rowoff_T = T; h->rowoff_ny = h->ny; h->rowoff_p = h->seam_rowoff.p;
+    }
+    ResolveIn in;
+    in.T = T; in.R = R;
+    in.ncomp = P<uint32_t>(h->ncomp); in.cprefix = CPX(h); in.mrep = P<uint32_t>(h->d_mrep); in.comp_t = P<uint32_t>(h->d_comp_t);
+    in.box = P<uint16_t>(h->d_box); in.area = P<int64_t>(h->d_area);
+    in.pairs = P<CtkPair>(h->pairs); in.pair_cap = h->pair_cap; in.counters = P<uint32_t>(h->counters);
+    in.pair_base = P<uint32_t>(h->pair_base); in.pair_cnt = P<uint32_t>(h->pair_cnt);
+    in.seams = P<CtkSeam>(h->seams); in.seam_cnt = P<uint32_t>(h->seam_cnt); in.seam_off = P<uint32_t>(h->seam_rowoff);
+    in.seam_cap = T * h->ny;
+    in.comp_label = P<int32_t>(h->comp_label);
+    ResolvePlan pl;
+    CTKCHK(rs_prepare(h, in, overlap, twosided, pl));
+    ResolveDev &r = pl.r;
+    const int nsb = pl.nsb, gc = pl.gc, gp = pl.gp;
+    const size_t DC = std::min<size_t>(R + 1, (size_t)2 * std::max<int64_t>(in.seam_cap, 1));       // (rs_prepare's capacity of the dense tables)
+    CTKCHK(ensure(h, h->sd_parent, DC * 4)); CTKCHK(ensure(h, h->sd_tmin, DC * 4)); CTKCHK(ensure(h, h->sd_tmax, DC * 4)); CTKCHK(ensure(h, h->sd_nops, DC * 4));
+    CTKCHK(ensure(h, h->sd_root, (size_t)std::max<int64_t>(T * h->ny, 1) * 4));
+    // op slots: SD_OPS_OWN per candidate label id (sized after the previous pass) + a shared tail for the clusters with more
+    const uint32_t own_ids = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)h->nd_hint * 2, 4096), DC);
+    const uint32_t op_cap = own_ids * SD_OPS_OWN + h->op_cap_hint;
+    CTKCHK(ensure(h, h->ops, (size_t)op_cap * (sizeof(CtkOp) + 4)));
+    // ids <= components <= runs: R + 1 is the offset of the second half of ext (only the entries of real ids are ever touched)
+    CTKCHK(ensure(h, h->ext, (R + 1) * 8));
+    if (!h->h_amail) { HIPCHK(hipHostMalloc((void **)&h->h_amail, CTK_AM_WORDS * 4, hipHostMallocDefault)); }
+    memset(h->h_amail, 0, CTK_AM_WORDS * 4);
+    h->n_labels = (int64_t)R; h->t_begin = 0;
+    r.cl_parent = P<uint32_t>(h->sd_parent); r.cl_tmin = P<int32_t>(h->sd_tmin); r.cl_tmax = P<int32_t>(h->sd_tmax); r.cl_nops = P<uint32_t>(h->sd_nops);
+    r.ext = P<int32_t>(h->ext); r.ext_off = (int64_t)R + 1; r.counters_w = P<uint32_t>(h->counters);
+    SeamDev sd;
+    sd.cl_parent = r.cl_parent; sd.cl_tmin = r.cl_tmin; sd.cl_tmax = r.cl_tmax; sd.rec_root = P<uint32_t>(h->sd_root);
+    sd.recs = P<CtkCand>(h->rv_cand_scratch); sd.rec_cnt = P<uint32_t>(h->rv_cand_cnt); sd.dcount = r.dcount; sd.dorig = r.dorig; sd.dbox = r.dbox;
+    sd.dmap = r.dmap; sd.ops = P<CtkOp>(h->ops); sd.op_next = (int32_t *)(P<CtkOp>(h->ops) + op_cap); sd.op_first = r.op_first;
+    sd.op_count = P<uint32_t>(h->counters) + CTK_CNT_NOPS; sd.op_cap = op_cap; sd.own_ids = own_ids; sd.cl_nops = r.cl_nops; sd.dense_cap = (uint32_t)std::min<size_t>(DC, 0xffffffffu);
+    sd.poison = P<uint32_t>(h->counters) + CTK_CNT_POISON; sd.ny = h->ny; sd.nx = h->nx; sd.T = T;
+    sd.dbg = getenv("CTK_SD_DBG") ? atoi(getenv("CTK_SD_DBG")) : 0;
+    h->d_op_next = sd.op_next;
+    h->nops = 1;                                                  // (unknown here; nonzero = the folds look at the chains)
+    const int NP = T > 2 ? std::min(std::max(h->async_passes, 2), CTK_MAX_JACOBI) : 0;
+    h->guard_on = true;
+    struct GuardOff { ctk_handle *h; ~GuardOff() { h->guard_on = false; } } guard_off{h};
+    {
+        Timer tm(h, CTK_K_RESOLVE);
+        k_rs_init<<<gc, 256, 0, s>>>(r);
+        k_rs_pairs<<<gp, 256, 0, s>>>(r);
+        k_rs_prep<<<gc, 256, 0, s>>>(r);
+        for (int it = 0; it < NP; it++)
+            k_rs_pass<<<(int)(T - 2), 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
+        k_rs_unite<<<gp, 256, 0, s>>>(r);
+        k_rs_roots<<<nsb, 256, 0, s>>>(r, P<uint32_t>(h->rv_bsum));
+        k_rs_rank<<<nsb, 256, 0, s>>>(r.isroot, in.cprefix + T, P<uint32_t>(h->rv_bsum), r.rank, P<uint32_t>(h->rv_boff) + nsb);
+        k_rs_labels<<<gc, 256, 0, s>>>(r);
+        k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, h->ny, P<uint8_t>(h->rv_mark), P<int2>(h->rv_seam_res));
+        k_rs_cand_groups<<<(int)T, 64, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), P<uint8_t>(h->rv_mark),
+                                               h->ny, 0, P<uint32_t>(h->rv_cand_cnt), P<CtkCand>(h->rv_cand_scratch));
+        k_seam_clusters<<<(int)T, 64, 0, s>>>(sd);
+        k_seam_driver<<<(int)std::min<size_t>(std::max<size_t>((size_t)h->nd_hint + h->nd_hint / 2, 1024), 65536), 64, 0, s>>>(sd, 0);
+        HIPCHK(hipGetLastError());
+    }
+    CTKCHK(launch_extents(h, true, true));
+    h->state = ST_EXTENTS;
+    int cv_rows = 0;
+    int32_t *cv = chunk_vals_for(h, flag_dev, &cv_rows);
+    {
+        Timer tm(h, CTK_K_RUNLABEL);
+        k_run_values<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), CPX(h), P<int32_t>(h->comp_label),
+                                            P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->d_mrep), 0, 0, P<int32_t>(h->run_val),
+                                            P<uint32_t>(h->rowstart), h->ny, cv_rows, cv, P<uint32_t>(h->counters));
+        HIPCHK(hipGetLastError());
+    }
+    {
+        Timer tm(h, CTK_K_RELABEL);
+        CTKCHK(launch_relabel(h, persistence, flag_dev, true, cv));
+    }
+    AsyncMail am;
+    am.scal = h->h_amail; am.nlab_ptr = P<uint32_t>(h->rv_boff) + nsb; am.nc_ptr = in.cprefix + T; am.dcount = r.dcount;
+    am.changed = r.changed; am.ambig = r.ambig; am.rec_cnt = P<uint32_t>(h->rv_cand_cnt); am.cl_nops = r.cl_nops; am.T = T; am.passes = NP;
+    {
+        Timer tm(h, CTK_K_COUNT);
+        if (h->last_nlab <= 1000000)                  // (the previous pass' id count: a slab of the same kind)
+            k_count_alive_1<<<1, 1024, 0, s>>>(P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->counters), h->h_mail1 + 8, am);
+        else
+            k_count_alive<<<1024, 256, 0, s>>>(P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->counters), h->h_mail1 + 8, am);
+        HIPCHK(hipGetLastError());
+    }
+    HT("fused pass launched");
+    HIPCHK(hipStreamSynchronize(s));
+    HT("fused pass done");
+    const uint32_t *m = h->h_amail;
+    if (!m[CTK_AM_DONE]) return ctk_set_error(CTK_E_INTERNAL, "fused pass: the device did not report");
+    h->state = ST_TABLES;
+    const uint32_t *cnt = m + CTK_AM_COUNTERS;
+    // ---- validation: anything the host would have seen at one of its (removed) hand-offs -----------------------------------
+    if ((cnt[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) || (uint64_t)cnt[CTK_CNT_PAIRS] + cnt[CTK_CNT_UPAIRS] > in.pair_cap) return 1;      // (the synchronous path regrows the table)
+    if (NP > 0 && m[CTK_AM_CONV] == 0) { h->async_passes = std::min(CTK_MAX_JACOBI, NP * 2); return 1; }          // longer removal cascade than launched for
+    if (m[CTK_AM_AMBIG]) return 1;                                                                               // decisions on rounding boundaries
+    if (getenv("CTK_SD_DBG")) fprintf(stderr, "SDDBG max row steps %u, max fold iterations %u, max process time %.2f us, max cluster time %.2f us\n", cnt[10], cnt[11], cnt[12] * 0.01, cnt[13] * 0.01);
+    const uint32_t poison = cnt[CTK_CNT_POISON];
+    if (poison) {
+        if (poison & CTK_POISON_OPCAP) h->op_cap_hint = std::max(h->op_cap_hint * 2, cnt[CTK_CNT_NOPS] + cnt[CTK_CNT_NOPS] / 2 + 1024);
+        if (poison & CTK_POISON_CLUSTER) { h->async_off_ny = h->ny; h->async_off_nx = h->nx; }                 // this kind of slab: host driver from now on
+        return 1;
+    }
+    const int64_t nlab = m[CTK_AM_NLAB];
+    if (nlab > 0x7ffffffell) return ctk_set_error(CTK_E_RANGE, "%lld ids do not fit the int32 flag variable", (long long)nlab);
+    if (NP > 0) h->async_passes = std::max<int>(CTK_JACOBI_ROUND, (int)m[CTK_AM_CONV] + 2);
+    h->nd_hint = std::max<uint32_t>(m[CTK_AM_ND], 1024);
+    h->op_cap_hint = std::max<uint32_t>(h->op_cap_hint, cnt[CTK_CNT_NOPS] * 2 + 1024);
+    h->nops = (int32_t)cnt[CTK_CNT_NOPS];
+    h->last_nlab = nlab;
+    h->total_comps = m[CTK_AM_NC];
+    h->stats[CTK_S_COMPONENTS] = m[CTK_AM_NC]; h->stats[CTK_S_PAIRS] = (int64_t)cnt[CTK_CNT_PAIRS] + cnt[CTK_CNT_UPAIRS];
+    h->stats[CTK_S_UPAIRS] = cnt[CTK_CNT_UPAIRS]; h->stats[CTK_S_SEAM_ROWS] = m[CTK_AM_NCAND]; h->stats[CTK_S_LABELS] = nlab;
+    h->stats[CTK_S_OPS] = cnt[CTK_CNT_NOPS]; h->stats[CTK_S_FILTER_PASSES] = NP > 0 ? m[CTK_AM_CONV] : 0; h->stats[CTK_S_FILTER_ROUNDS] = NP > 0 ? 1 : 0;
+    h->stats[CTK_S_AMBIGUOUS] = 0; h->stats[CTK_S_FUSED] = 1;
+    h->last_alive = h->h_mail1[8];
+    if (n_tracked) *n_tracked = (int64_t)h->h_mail1[8] + (h->h_mail1[9] ? 1 : 0) - 1;       // len(np.unique(flag)) - 1, contrack.py:793
+    collect_event_times(h);
+    return CTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // whole path, one GPU
 // ------------------------------------------------------------------------------------------------
 struct ctk_comm;
@@ -1504,6 +1684,11 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
     HT("label2d stage done");
     CTKCHK(ctk_shard_overlap(h));
     HT("overlap launched");
+    if (h->use_device_resolve && async_wanted(h) && T > 0) {
+        const int ra = resolve_async(h, overlap, twosided, persistence, flag_dev, n_tracked);
+        if (ra <= 0) { h->ms[CTK_T_TOTAL] += now_ms() - t0; return ra; }
+        h->stats[CTK_S_FUSED] = 0;                           // fell off the fused path: the synchronous one resolves the same tables
+    }
     int rv = h->use_device_resolve ? device_resolve_local(h, overlap, twosided) : 1;
     if (rv < 0) return rv;
     if (rv == 1 && h->use_device_resolve && h->stats[CTK_S_AMBIGUOUS] && !(h->stats[CTK_S_HOST_REASON] & 3)) {

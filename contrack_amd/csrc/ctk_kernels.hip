@@ -971,7 +971,16 @@ __device__ inline int32_t comp_final_label(const FoldArgs &f, int32_t l, int32_t
     }
 }
 
+// fused one-call path: the kernels behind the resolver run without the host having looked at the tables.  `guard` = the device
+// counters: a co-occurrence table that overflowed or a poisoned resolution (CTK_CNT_POISON) means the tables hold nothing
+// usable -- the kernel returns at once and the host repeats the resolution on its synchronous path.
+__device__ __forceinline__ bool ctk_guard_bad(const uint32_t *guard)
+{
+    return guard && ((guard[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) != 0u || guard[CTK_CNT_POISON] != 0u);
+}
+
 struct ExtentArgs {
+    const uint32_t *guard;
     const uint64_t *mask;
     const uint32_t *rowstart;
     const uint32_t *run_base;
@@ -993,18 +1002,20 @@ struct ExtentArgs {
 // same-address atomics serialise)
 __device__ inline void ext_update(int32_t *tmin, int32_t *tmax, int32_t l, int32_t tg)
 {
-    // plain loads: a stale bound is looser than the true one -- at worst a superfluous atomic
-    if (tg < tmin[l]) atomicMin(&tmin[l], tg);
-    if (tg > tmax[l]) atomicMax(&tmax[l], tg);
+    // a stale bound is looser than the true one -- at worst a superfluous atomic.  Device-scope loads: the L2s of the eight XCDs
+    // are not coherent with each other, a plain load would keep returning the bound this XCD saw first.
+    if (tg < __hip_atomic_load(&tmin[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&tmin[l], tg);
+    if (tg > __hip_atomic_load(&tmax[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&tmax[l], tg);
 }
 
 __global__ __launch_bounds__(256) void k_extent(ExtentArgs a)
 {
+    if (ctk_guard_bad(a.guard)) return;
     const int t = (int)blockIdx.x;
     const int tid = (int)threadIdx.x;
     const uint32_t n = a.ncomp[t], cb = a.cprefix[t];
     const int32_t tg = (int32_t)(a.t_begin + t);
-    int32_t *tmin = a.ext, *tmax = a.ext + a.n_labels + 1;
+    int32_t *tmin = a.ext, *tmax = a.ext + a.n_labels + 1;        // (n_labels + 1: the offset of the second half; an upper bound in the fused path)
     __shared__ int ylo, yhi;                               // rows that hold pixels of complex components
     if (tid == 0) { ylo = 0x7fffffff; yhi = -1; }
     __syncthreads();
@@ -1047,8 +1058,9 @@ __global__ __launch_bounds__(256) void k_run_values(const uint32_t *__restrict__
                                                     // optional: the values again, grouped the way k_relabel_v4 consumes them -- CTK_CV slots per chunk of
                                                     // `rows` rows, so that its workgroups can load them together with their tables (no dependent load)
                                                     const uint32_t *__restrict__ rowstart = nullptr, int ny = 0, int rows = 0,
-                                                    int32_t *__restrict__ chunk_vals = nullptr)
+                                                    int32_t *__restrict__ chunk_vals = nullptr, const uint32_t *guard = nullptr)
 {
+    if (ctk_guard_bad(guard)) return;
     const int t = (int)blockIdx.x;
     const uint32_t rb = run_base[t], n = run_base[t + 1] - rb, cb = cprefix[t];
     __shared__ uint32_t qb[CTK_CV_MAXCHUNK + 1];                        // first run of every chunk
@@ -1097,6 +1109,7 @@ struct RelabelArgs {
     int64_t nrows;
     int ny, nx, W;
     const int32_t *chunk_vals;     // [T][nchunk][CTK_CV] (k_run_values) or nullptr
+    const uint32_t *guard;         // see ctk_guard_bad
 };
 
 // fast path (nx % 4 == 0, 16-byte aligned flag): one workgroup per (timestep, 16 rows).  The rows' mask
@@ -1106,6 +1119,7 @@ struct RelabelArgs {
 // rb*W*8 + rb*W*2 (padded to 8) + (rb+1)*4 (padded to 8) + rvcap*4 bytes).
 __global__ __launch_bounds__(256) void k_relabel_v4(RelabelArgs a, int rb, int rvcap)
 {
+    if (ctk_guard_bad(a.guard)) return;
     const int ny = a.ny, nx = a.nx, W = a.W;
     const int nchunk = (ny + rb - 1) / rb;
     const int t = (int)(blockIdx.x / (unsigned)nchunk), y0 = (int)(blockIdx.x - (unsigned)t * nchunk) * rb, tid = (int)threadIdx.x;
@@ -1176,6 +1190,7 @@ __global__ __launch_bounds__(256) void k_relabel_v4(RelabelArgs a, int rb, int r
 // slabs with millions of chunks stay with k_relabel_v4.
 __global__ __launch_bounds__(256) void k_relabel_v5(RelabelArgs a, int rb, int rvcap)
 {
+    if (ctk_guard_bad(a.guard)) return;
     const int ny = a.ny, nx = a.nx, W = a.W;
     const int nchunk = (ny + rb - 1) / rb;
     const int t = (int)(blockIdx.x / (unsigned)nchunk), y0 = (int)(blockIdx.x - (unsigned)t * nchunk) * rb, tid = (int)threadIdx.x;
@@ -1261,6 +1276,7 @@ __global__ __launch_bounds__(256) void k_relabel_v5(RelabelArgs a, int rb, int r
 
 __global__ __launch_bounds__(256) void k_relabel(RelabelArgs a)
 {
+    if (ctk_guard_bad(a.guard)) return;
     const int lane = lane_id();
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -1310,14 +1326,75 @@ __global__ __launch_bounds__(256) void k_relabel(RelabelArgs a)
 // ------------------------------------------------------------------------------------------------
 // K8  number of ids that are present and survive persistence
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__ ext, int64_t n_labels, int persistence,
-                                                     uint32_t *counters, uint32_t *mail)
+// Fused one-call path: what the host wants to know about the pass it did not watch, written by the counting kernel into pinned
+// host memory (scal[CTK_AM_*]); the host validates it after its only synchronisation.
+struct AsyncMail {
+    uint32_t *scal;                 // nullptr: not the fused path
+    const uint32_t *nlab_ptr;       // number of fresh 3-D labels (= ids to count; n_labels is then only the offset of ext's second half)
+    const uint32_t *nc_ptr;         // cprefix[T]
+    const uint32_t *dcount;         // candidate labels
+    const uint32_t *changed;        // [passes][CTK_CHG_SLOTS]
+    const uint32_t *ambig;
+    const uint32_t *rec_cnt;        // [T] candidate group records per timestep
+    const uint32_t *cl_nops;        // [dcount] relabel operations per cluster root
+    int64_t T;
+    int passes;
+};
+#define CTK_AM_COUNTERS 0           // .. + CTK_CNT_N
+#define CTK_AM_NC       16
+#define CTK_AM_NLAB     17
+#define CTK_AM_ND       18
+#define CTK_AM_NCAND    19
+#define CTK_AM_AMBIG    20
+#define CTK_AM_CONV     21          // first filter pass that changed nothing, + 1; 0 = none of the passes launched
+#define CTK_AM_DONE     22          // written last: the block is complete
+#define CTK_AM_WORDS    32
+
+// called by the first 64 threads of a workgroup (one word per lane: the stores to host memory leave together)
+__device__ inline void async_mail_write(const AsyncMail &m, const uint32_t *counters, uint32_t ncand)
 {
-    int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int lane = (int)threadIdx.x;
+    if (lane >= 64) return;
     uint32_t v = 0;
-    if (l <= n_labels) {
+    bool has = false;
+    uint32_t nops = 0;                                            // operations of all clusters
+    if (!ctk_guard_bad(counters)) {
+        const uint32_t nd = *m.dcount;
+        for (uint32_t d = lane; d < nd; d += 64) nops += m.cl_nops[d];
+        nops = wave_sum_u32(nops);
+    }
+    if (lane == CTK_CNT_NOPS) { v = nops; has = true; }
+    else if (lane < CTK_CNT_N) { v = __hip_atomic_load(&counters[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); has = true; }
+    else if (lane == CTK_AM_NC) { v = *m.nc_ptr; has = true; }
+    else if (lane == CTK_AM_NLAB) { v = *m.nlab_ptr; has = true; }
+    else if (lane == CTK_AM_ND) { v = *m.dcount; has = true; }
+    else if (lane == CTK_AM_NCAND) { v = ncand; has = true; }
+    else if (lane == CTK_AM_AMBIG) { v = *m.ambig; has = true; }
+    else if (lane == CTK_AM_DONE) { v = 1u; has = true; }
+    // first filter pass that changed nothing: lane k looks at pass k (and k + 64, ...)
+    uint32_t conv = 0xffffffffu;
+    for (int k = lane; k < m.passes; k += 64) {
+        bool any = false;
+        for (int j = 0; j < 64; j++) any |= m.changed[k * 64 + j] != 0u;
+        if (!any) { conv = (uint32_t)k; break; }
+    }
+    for (int o = 32; o > 0; o >>= 1) conv = min(conv, (uint32_t)__shfl_xor((int)conv, o));
+    if (lane == CTK_AM_CONV) { v = conv == 0xffffffffu ? 0u : conv + 1u; has = true; }
+    if (has) m.scal[lane] = v;
+}
+
+__global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__ ext, int64_t n_labels, int persistence,
+                                                     uint32_t *counters, uint32_t *mail, AsyncMail am)
+{
+    if (ctk_guard_bad(am.scal ? counters : nullptr)) {
+        if (blockIdx.x == 0) async_mail_write(am, counters, 0u);
+        return;
+    }
+    const int64_t nl = am.scal ? (int64_t)*am.nlab_ptr : n_labels;
+    uint32_t v = 0;
+    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; l <= nl; l += (int64_t)gridDim.x * blockDim.x) {
         int64_t lo = ext[l], hi = ext[n_labels + 1 + l];
-        v = (hi >= lo && hi - lo + 1 >= persistence) ? 1u : 0u;
+        v += (hi >= lo && hi - lo + 1 >= persistence) ? 1u : 0u;
     }
     uint32_t s = wave_sum_u32(v);
     if (lane_id() == 0 && s) atomicAdd(&counters[CTK_CNT_ALIVE], s);
@@ -1331,27 +1408,45 @@ __global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__
         mail[0] = __hip_atomic_load(&counters[CTK_CNT_ALIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         mail[1] = __hip_atomic_load(&counters[CTK_CNT_WROTE_ZERO], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (last && am.scal) {
+        uint32_t nc = 0;
+        if (threadIdx.x < 64) {
+            for (int64_t t = threadIdx.x; t < am.T; t += 64) nc += am.rec_cnt[t];
+            nc = wave_sum_u32(nc);
+        }
+        async_mail_write(am, counters, nc);
+    }
 }
 
 // the same in ONE workgroup (up to a few hundred thousand ids): no atomics, no ticket
 __global__ __launch_bounds__(1024) void k_count_alive_1(const int32_t *__restrict__ ext, int64_t n_labels, int persistence,
-                                                        uint32_t *counters, uint32_t *mail)
+                                                        uint32_t *counters, uint32_t *mail, AsyncMail am)
 {
-    uint32_t v = 0;
-    for (int64_t l = threadIdx.x + 1; l <= n_labels; l += 1024) {
+    if (ctk_guard_bad(am.scal ? counters : nullptr)) {
+        async_mail_write(am, counters, 0u);
+        return;
+    }
+    uint32_t v = 0, nc = 0;
+    if (am.scal) for (int64_t t = threadIdx.x; t < am.T; t += 1024) nc += am.rec_cnt[t];
+    const int64_t nl = am.scal ? (int64_t)*am.nlab_ptr : n_labels;
+    for (int64_t l = threadIdx.x + 1; l <= nl; l += 1024) {
         const int64_t lo = ext[l], hi = ext[n_labels + 1 + l];
         v += (hi >= lo && hi - lo + 1 >= persistence) ? 1u : 0u;
     }
-    __shared__ uint32_t sm[16];
-    const uint32_t s = wave_sum_u32(v);
-    if (lane_id() == 0) sm[threadIdx.x >> 6] = s;
+    __shared__ uint32_t sm[16], sn[16];
+    const uint32_t s = wave_sum_u32(v), s2 = wave_sum_u32(nc);
+    if (lane_id() == 0) { sm[threadIdx.x >> 6] = s; sn[threadIdx.x >> 6] = s2; }
     __syncthreads();
+    uint32_t tot = 0, ncand = 0;
+    for (int i = 0; i < 16; i++) { tot += sm[i]; ncand += sn[i]; }
     if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int i = 0; i < 16; i++) tot += sm[i];
         counters[CTK_CNT_ALIVE] = tot;
         mail[0] = tot;
         mail[1] = __hip_atomic_load(&counters[CTK_CNT_WROTE_ZERO], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (am.scal) {
+        __syncthreads();                                   // (counters[CTK_CNT_ALIVE] is one of the words mailed)
+        async_mail_write(am, counters, ncand);
     }
 }
 

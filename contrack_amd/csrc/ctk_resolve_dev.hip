@@ -67,6 +67,13 @@ struct ResolveDev {
     const double *ovr_val;                // [amb_cap][3]
     uint32_t *amb_cnt, *amb_list;
     uint32_t amb_cap;
+    // fused one-call path (no host hand-off, ctk_seam_dev.hip); all nullptr elsewhere
+    uint32_t *cl_parent;                  // [dense] clusters of candidate labels that share seam rows: union-find over dense ids
+    int32_t *cl_tmin, *cl_tmax;           // [dense] at cluster roots: timesteps that hold records of the cluster
+    uint32_t *cl_nops;                    // [dense] operations of the cluster (k_seam_driver)
+    int32_t *ext;                         // time extents of the ids, reset by k_rs_roots: ext[l] = min t, ext[ext_off + l] = max t
+    int64_t ext_off;
+    uint32_t *counters_w;                 // the write-stage counters are reset by k_rs_roots as well
 };
 
 #define CTK_CHG_SLOTS 64            // 'changed' words per filter pass (= wave width: one ballot reads them)
@@ -368,6 +375,13 @@ __global__ __launch_bounds__(256) void k_rs_roots(ResolveDev r, uint32_t *__rest
         r.dmap[g + 1] = 0;
         r.op_first[g + 1] = -1;
         if (g == 0) { *r.dcount = 0; r.op_first[0] = -1; }
+        if (r.ext) {                                        // fused one-call path: what k_ops_ingest / k_fill_ext do elsewhere
+            r.ext[g + 1] = INT32_MAX; r.ext[r.ext_off + g + 1] = INT32_MIN;
+            if (g == 0) {
+                r.ext[0] = INT32_MAX; r.ext[r.ext_off] = INT32_MIN;
+                r.counters_w[CTK_CNT_WROTE_ZERO] = 0; r.counters_w[CTK_CNT_ALIVE] = 0; r.counters_w[CTK_CNT_TICKET] = 0;
+            }
+        }
     }
     const int tot = __syncthreads_count((int)isr);
     if (threadIdx.x == 0) bsum[blockIdx.x] = (uint32_t)tot;
@@ -421,6 +435,7 @@ __device__ inline void cand_publish(const ResolveDev &r, int32_t l, uint32_t id)
     r.dorig[id] = l;
     int32_t *d = r.dbox + 6 * (int64_t)id;                // box of the label (find_objects ONCE, contrack.py:753): filled
     d[0] = INT32_MAX; d[1] = -1; d[2] = INT32_MAX; d[3] = -1; d[4] = INT32_MAX; d[5] = -1;    // by k_rs_cand_groups
+    if (r.cl_parent) { r.cl_parent[id] = id; r.cl_tmin[id] = INT32_MAX; r.cl_tmax[id] = -1; r.cl_nops[id] = 0u; }
     r.dmap[l] = id + 1;                                   // read by later launches
 }
 
@@ -489,14 +504,17 @@ __global__ __launch_bounds__(64) void k_rs_cand_groups(ResolveDev r, const CtkSe
         // look first: a long-lived label receives one update per timestep and bound, and same-address atomics serialise
         // (a contour alive for thousands of steps made this kernel 0.7 ms on the 10-year slab).  Plain loads: a stale
         // bound is only ever looser than the true one, so it can cause a superfluous atomic, never a missing one.
-        const int2 *bv = reinterpret_cast<const int2 *>(b);
-        const int2 b01 = bv[0], b23 = bv[1], b45 = bv[2];
-        if (tt < b01.x) atomicMin(&b[0], tt);
-        if (tt > b01.y) atomicMax(&b[1], tt);
-        if ((int32_t)q[0] < b23.x) atomicMin(&b[2], (int32_t)q[0]);
-        if ((int32_t)q[1] > b23.y) atomicMax(&b[3], (int32_t)q[1]);
-        if ((int32_t)q[2] < b45.x) atomicMin(&b[4], (int32_t)q[2]);
-        if ((int32_t)q[3] > b45.y) atomicMax(&b[5], (int32_t)q[3]);
+        // Device-scope loads: the L2s of the eight XCDs are not coherent with each other -- a plain load keeps returning the bound
+        // this XCD saw first, and every timestep of a long-lived label would issue its six atomics again (0.5 ms on the 10-year slab).
+        const int32_t b0 = __hip_atomic_load(&b[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b1 = __hip_atomic_load(&b[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t b2 = __hip_atomic_load(&b[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b3 = __hip_atomic_load(&b[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t b4 = __hip_atomic_load(&b[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b5 = __hip_atomic_load(&b[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tt < b0) atomicMin(&b[0], tt);
+        if (tt > b1) atomicMax(&b[1], tt);
+        if ((int32_t)q[0] < b2) atomicMin(&b[2], (int32_t)q[0]);
+        if ((int32_t)q[1] > b3) atomicMax(&b[3], (int32_t)q[1]);
+        if ((int32_t)q[2] < b4) atomicMin(&b[4], (int32_t)q[2]);
+        if ((int32_t)q[3] > b5) atomicMax(&b[5], (int32_t)q[3]);
     }
     const uint32_t n = seam_cnt[t];
     const CtkSeam *sc = seams + seam_off[t];
@@ -526,7 +544,21 @@ __global__ __launch_bounds__(64) void k_rs_cand_groups(ResolveDev r, const CtkSe
         const uint64_t S = __ballot(start), V = __ballot(valid);
         const uint64_t upto = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
         const uint32_t idx = ng + (uint32_t)__popcll(S & upto) - 1u;          // record of this row's group
-        if (start) { CtkCand g; g.t = tt; g.yy = y | (y << 16); g.ll = v.x; g.lr = v.y; dst[idx] = g; }
+        if (start) {
+            CtkCand g; g.t = tt; g.yy = y | (y << 16); g.ll = v.x; g.lr = v.y; dst[idx] = g;
+            if (r.cl_parent && v.x != v.y) {                 // the two labels belong to one cluster of the seam driver
+                uint32_t a = r.dmap[v.x] - 1u, b = r.dmap[v.y] - 1u;
+                for (;;) {
+                    a = gfind(r.cl_parent, a);
+                    b = gfind(r.cl_parent, b);
+                    if (a == b) break;
+                    if (a < b) { const uint32_t s = a; a = b; b = s; }
+                    const uint32_t old = atomicMin(&r.cl_parent[a], b);
+                    if (old == a) break;
+                    a = old;
+                }
+            }
+        }
         // the previous step's last row ended its group if this step's first row does not continue it
         if (lane == 0 && c_valid && (!valid || start)) reinterpret_cast<uint16_t *>(&dst[ng - 1u].yy)[1] = (uint16_t)c_y;
         if (valid && lane < 63) {

@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_two_ranks_weak_scaling():
     env = dict(os.environ, CTK_DIST_BACKEND="shm", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "era5_1deg_90"]
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "era5_1deg_90",
+           "--strong-steps", "24"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
@@ -26,7 +27,16 @@ def test_bench_two_ranks_weak_scaling():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "timesteps/s"
     assert out["config"]["total_timesteps"] == 180 and out["value"] > 0
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
-    assert out["config"]["transport"] == "shm" and out["config"]["collectives_per_step"]["allgathers"] >= 5
+    assert out["config"]["transport"] == "shm" and out["config"]["collectives_per_step"]["allgathers"] >= 4
+    # the run proves itself: every rank's flag shard checksummed against the one-call result on the concatenated slab
+    assert out["config"]["parity_checked"] is True, out["config"]["parity"]
+    assert out["config"]["parity"]["shards_equal"] == [True, True]
+    assert out["config"]["parity"]["n_tracked_one_call"] == out["config"]["n_tracked"]
+    # strong scaling of one device-generated 0.25 degree slab, measured in the same launch
+    sb = out["strong_025deg"]
+    assert sb["n_gpus"] == 2 and sb["n_tracked_equal"] is True and sb["ms_per_step"] > 0 and sb["ms_per_step_1gpu"] > 0
+    assert sb["speedup_vs_1gpu"] == pytest.approx(sb["ms_per_step_1gpu"] / sb["ms_per_step"])
+    assert sb["collectives_per_step"]["allgathers"] >= 4
 
     from contrack_amd import _native, synth
     from contrack_amd.contrack import row_weights
