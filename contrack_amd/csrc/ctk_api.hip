@@ -146,7 +146,7 @@ struct ctk_handle {
     DevBuf chunk_vals;                             // run values in the chunk order of k_relabel_v4
     // fused one-call path (ctk_seam_dev.hip): clusters of candidate labels, cluster root per group record; the pass runs without a
     // host hand-off and is validated from a device-written block of scalars after its only synchronisation
-    DevBuf sd_parent, sd_tmin, sd_tmax, sd_root, sd_nops;
+    DevBuf sd_parent, sd_tmin, sd_tmax, sd_root, sd_nops, rv_pstate;
     uint32_t *h_amail = nullptr;                   // pinned: AsyncMail scalars
     uint32_t op_cap_hint = 4096;                   // operation slots of the next fused pass (grows with what the passes needed)
     uint32_t nd_hint = 4096;                       // dense candidate labels of the last pass: grid of k_seam_driver
@@ -203,6 +203,7 @@ struct ctk_handle {
     int filter_round = CTK_JACOBI_ROUND;          // filter passes launched before convergence is checked
     uint32_t debug_pair_cap = 0;                  // test hook: pretend the pair table holds only this many records
     uint32_t debug_mail_c = 0, debug_mail_d = 0;  // test hook: pretend the resolver mailbox holds only this many records / labels
+    int debug_sd_lab = 0, debug_sd_ops = 0;       // test hook: labels / operations per cluster the device seam driver accepts
     int debug_fail_stage = 0;                     // test hook (ctk_debug_fail_at): the time-shard path fails at this stage, once
     bool sh_collective_err = false;               // the time-shard path's error was decided identically on every rank
     ctk_comm *active_comm = nullptr;              // set while the time-shard path runs with more than one rank
@@ -387,7 +388,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
                       &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
                       &h->sh_mask_next, &h->sh_send, &h->sh_recv, &h->sh_prev, &h->sh_elist, &h->sh_ovr_slot, &h->sh_ovr_val,
-                      &h->sh_amb_list, &h->sh_counts, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_root, &h->sd_nops};
+                      &h->sh_amb_list, &h->sh_counts, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_root, &h->sd_nops, &h->rv_pstate};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -452,10 +453,26 @@ extern "C" int ctk_debug_set_mailbox(ctk_handle *h, uint32_t cand_records, uint3
     return CTK_OK;
 }
 
+extern "C" int ctk_debug_set_seam_caps(ctk_handle *h, int labels, int ops)
+{
+    if (!h || labels < 0 || ops < 0) return ctk_set_error(CTK_E_INVALID, "ctk_debug_set_seam_caps: null handle or negative capacity");
+    h->debug_sd_lab = labels; h->debug_sd_ops = ops;
+    h->async_off_ny = -1; h->async_off_nx = -1;          // (a grid that was sent to the host driver gets another try)
+    return CTK_OK;
+}
+
 extern "C" int ctk_set_filter_round(ctk_handle *h, int passes)
 {
     if (!h || passes < 1 || passes > 32) return ctk_set_error(CTK_E_INVALID, "ctk_set_filter_round: 1..32 passes per round");
     h->filter_round = passes;
+    h->async_passes = passes;                            // (the fused pass launches this many; it adapts from there)
+    return CTK_OK;
+}
+
+extern "C" int ctk_set_fused_pass(ctk_handle *h, int enable)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    h->use_async = enable ? 1 : 0;
     return CTK_OK;
 }
 
@@ -583,9 +600,9 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     CTKCHK(ensure(h, h->counters, CTK_CNT_N * 4));
     CTKCHK(ensure_host(&h->h_small, &h->h_small_cap, (size_t)(T + 1) * 4 + 1024));     // run_base copy + scalar downloads
 
-    HIPCHK(hipMemsetAsync(h->counters.p, 0, CTK_CNT_N * 4, s));
+    // (the device counters are zeroed by the first threshold launch of the pass; k_rowcount writes every tcount[t])
+    if (T == 0) HIPCHK(hipMemsetAsync(h->counters.p, 0, CTK_CNT_N * 4, s));
     if (T > 0) {
-        HIPCHK(hipMemsetAsync(h->tcount.p, 0, (size_t)T * 4, s));
         if (!same_thr) { HIPCHK(hipMemcpyAsync(h->thr32.p, thr32, (size_t)T * (f64 ? 8 : 4), hipMemcpyHostToDevice, s)); h->c_thr_valid = true; }
     }
     if (!same_w) { HIPCHK(hipMemcpyAsync(h->wlo.p, wlo, w_bytes, hipMemcpyHostToDevice, s)); h->c_w_valid = true; }    // same layout on both sides
@@ -602,11 +619,12 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
             const bool v4 = !f64 && (nx % 4 == 0) && (((uintptr_t)src & 15) == 0) && nblk4 < (1 << 24);     // < 2^32 work-items
             const unsigned g4 = (unsigned)nblk4;
             uint64_t *mk = P<uint64_t>(h->mask) + t0 * ny * W;
+            uint32_t *zc = t0 == 0 ? P<uint32_t>(h->counters) : nullptr;
 #define LAUNCH_THR(OP)                                                                                                                      \
     do {                                                                                                                                \
-        if (f64) k_threshold<OP, double><<<g, 256, 0, s>>>((const double *)src, P<double>(h->thr32) + t0, rows, ny, nx, W, mk); \
-        else if (v4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt); \
-        else k_threshold<OP, float><<<g, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, rows, ny, nx, W, mk); \
+        if (f64) k_threshold<OP, double><<<g, 256, 0, s>>>((const double *)src, P<double>(h->thr32) + t0, rows, ny, nx, W, mk, zc); \
+        else if (v4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
+        else k_threshold<OP, float><<<g, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, rows, ny, nx, W, mk, zc); \
     } while (0)
             switch (cmp_op) {
             case 0: LAUNCH_THR(0); break;
@@ -1134,7 +1152,7 @@ static int rs_prepare(ctk_handle *h, const ResolveIn &in, double overlap, int tw
     r.next_tiny = (const int32_t *)(P<int64_t>(h->wlo) + 2 * (size_t)h->ny); r.touch = P<uint32_t>(h->rv_touch);
     r.nh_ptr = nullptr; r.t_lo = 1; r.t_hi = (int)T - 2;                // one slab: timesteps 1 .. T-2 are filtered, no halo
     r.ovr_slot = nullptr; r.ovr_val = nullptr; r.amb_cnt = P<uint32_t>(h->rv_scalars) + 2; r.amb_list = nullptr; r.amb_cap = 0;
-    r.cl_parent = nullptr; r.cl_tmin = nullptr; r.cl_tmax = nullptr; r.cl_nops = nullptr; r.ext = nullptr; r.ext_off = 0; r.counters_w = nullptr;      // (fused one-call path only)
+    r.cl_parent = nullptr; r.cl_tmin = nullptr; r.cl_tmax = nullptr; r.cl_nops = nullptr; r.pstate = nullptr; r.ext = nullptr; r.ext_off = 0; r.counters_w = nullptr;      // (fused one-call path only)
 
     const int gc = (int)std::min<size_t>((R + 255) / 256, 2048), gp = (int)std::min<size_t>((PC + 255) / 256, 2048);
     // mailbox in pinned host memory: the last resolver kernel writes scalars, candidate records and dense label tables
@@ -1581,22 +1599,32 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     sd.op_count = P<uint32_t>(h->counters) + CTK_CNT_NOPS; sd.op_cap = op_cap; sd.own_ids = own_ids; sd.cl_nops = r.cl_nops; sd.dense_cap = (uint32_t)std::min<size_t>(DC, 0xffffffffu);
     sd.poison = P<uint32_t>(h->counters) + CTK_CNT_POISON; sd.ny = h->ny; sd.nx = h->nx; sd.T = T;
     sd.dbg = getenv("CTK_SD_DBG") ? atoi(getenv("CTK_SD_DBG")) : 0;
+    sd.lab_cap = h->debug_sd_lab ? std::min(h->debug_sd_lab, SD_LAB) : SD_LAB; sd.ops_cap = h->debug_sd_ops ? std::min(h->debug_sd_ops, 64) : 64;
     h->d_op_next = sd.op_next;
     h->nops = 1;                                                  // (unknown here; nonzero = the folds look at the chains)
-    const int NP = T > 2 ? std::min(std::max(h->async_passes, 2), CTK_MAX_JACOBI) : 0;
+    // filter passes: all of them in one launch (k_rs_pass_sys, at most 24 iterations) when every workgroup of the launch can wait
+    // for its predecessor, else one launch per pass
+    const bool sys = !getenv("CTK_PASS_LAUNCHES") && h->async_passes <= 24 && T - 2 <= 60000;
+    const int NP = T > 2 ? std::min(std::max(h->async_passes, 2), sys ? 24 : CTK_MAX_JACOBI) : 0;
+    if (sys) { CTKCHK(ensure(h, h->rv_pstate, (size_t)(T + 1) * 4 * CTK_PSTATE_STRIDE)); r.pstate = P<uint32_t>(h->rv_pstate); }
     h->guard_on = true;
     struct GuardOff { ctk_handle *h; ~GuardOff() { h->guard_on = false; } } guard_off{h};
     {
         Timer tm(h, CTK_K_RESOLVE);
         k_rs_init<<<gc, 256, 0, s>>>(r);
         k_rs_pairs<<<gp, 256, 0, s>>>(r);
-        k_rs_prep<<<gc, 256, 0, s>>>(r);
-        for (int it = 0; it < NP; it++)
-            k_rs_pass<<<(int)(T - 2), 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
+        if (!(sys && NP > 0)) k_rs_prep<<<gc, 256, 0, s>>>(r);         // (k_rs_pass_sys does it for its own timestep)
+        if (sys && NP > 0) k_rs_pass_sys<<<(int)(T - 2), 64, 0, s>>>(r, 0, NP, in.pair_base, in.pair_cnt, r.pstate, 1);
+        else
+            for (int it = 0; it < NP; it++)
+                k_rs_pass<<<(int)(T - 2), 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
         k_rs_unite<<<gp, 256, 0, s>>>(r);
         k_rs_roots<<<nsb, 256, 0, s>>>(r, P<uint32_t>(h->rv_bsum));
-        k_rs_rank<<<nsb, 256, 0, s>>>(r.isroot, in.cprefix + T, P<uint32_t>(h->rv_bsum), r.rank, P<uint32_t>(h->rv_boff) + nsb);
-        k_rs_labels<<<gc, 256, 0, s>>>(r);
+        if (nsb <= CTK_RL_BLOCKS) k_rs_rank_labels<<<nsb, 256, (size_t)nsb * 4, s>>>(r, P<uint32_t>(h->rv_bsum), (uint32_t)nsb, P<uint32_t>(h->rv_boff) + nsb);
+        else {
+            k_rs_rank<<<nsb, 256, 0, s>>>(r.isroot, in.cprefix + T, P<uint32_t>(h->rv_bsum), r.rank, P<uint32_t>(h->rv_boff) + nsb);
+            k_rs_labels<<<gc, 256, 0, s>>>(r);
+        }
         k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, h->ny, P<uint8_t>(h->rv_mark), P<int2>(h->rv_seam_res));
         k_rs_cand_groups<<<(int)T, 64, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), P<uint8_t>(h->rv_mark),
                                                h->ny, 0, P<uint32_t>(h->rv_cand_cnt), P<CtkCand>(h->rv_cand_scratch));
@@ -1641,7 +1669,7 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     if ((cnt[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) || (uint64_t)cnt[CTK_CNT_PAIRS] + cnt[CTK_CNT_UPAIRS] > in.pair_cap) return 1;      // (the synchronous path regrows the table)
     if (NP > 0 && m[CTK_AM_CONV] == 0) { h->async_passes = std::min(CTK_MAX_JACOBI, NP * 2); return 1; }          // longer removal cascade than launched for
     if (m[CTK_AM_AMBIG]) return 1;                                                                               // decisions on rounding boundaries
-    if (getenv("CTK_SD_DBG")) fprintf(stderr, "SDDBG max row steps %u, max fold iterations %u, max process time %.2f us, max cluster time %.2f us\n", cnt[10], cnt[11], cnt[12] * 0.01, cnt[13] * 0.01);
+    if (getenv("CTK_SD_DBG")) fprintf(stderr, "SDDBG max row steps %u, max fold iterations %u, max process time %.2f us, max cluster time %.2f us, fold cycles (clock64) %u\n", cnt[10], cnt[11], cnt[12] * 0.01, cnt[13] * 0.01, cnt[14]);
     const uint32_t poison = cnt[CTK_CNT_POISON];
     if (poison) {
         if (poison & CTK_POISON_OPCAP) h->op_cap_hint = std::max(h->op_cap_hint * 2, cnt[CTK_CNT_NOPS] + cnt[CTK_CNT_NOPS] / 2 + 1024);

@@ -150,8 +150,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <int OP>
 __global__ __launch_bounds__(256) void k_threshold_v4(const float *__restrict__ anom, const float *__restrict__ thr32,
-                                                      int ny, int nx, int W, uint64_t *__restrict__ mask, int rb)
+                                                      int ny, int nx, int W, uint64_t *__restrict__ mask, int rb,
+                                                      uint32_t *__restrict__ zero_counters /* the pass' device counters start at zero (or nullptr) */)
 {
+    if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_N) zero_counters[threadIdx.x] = 0u;
     constexpr int U = 4;                                   // independent 16-byte loads in flight per lane
     const int nchunk = (ny + rb - 1) / rb;
     const int t = (int)(blockIdx.x / (unsigned)nchunk), y0 = (int)(blockIdx.x - (unsigned)t * nchunk) * rb, tid = (int)threadIdx.x;
@@ -193,8 +195,10 @@ __global__ __launch_bounds__(256) void k_threshold_v4(const float *__restrict__ 
 
 template <int OP, typename TIN>
 __global__ __launch_bounds__(256) void k_threshold(const TIN *__restrict__ anom, const TIN *__restrict__ thr32,
-                                                   int64_t nrows, int ny, int nx, int W, uint64_t *__restrict__ mask)
+                                                   int64_t nrows, int ny, int nx, int W, uint64_t *__restrict__ mask,
+                                                   uint32_t *__restrict__ zero_counters)
 {
+    if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_N) zero_counters[threadIdx.x] = 0u;
     const int lane = lane_id();
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -1351,18 +1355,12 @@ struct AsyncMail {
 #define CTK_AM_WORDS    32
 
 // called by the first 64 threads of a workgroup (one word per lane: the stores to host memory leave together)
-__device__ inline void async_mail_write(const AsyncMail &m, const uint32_t *counters, uint32_t ncand)
+__device__ inline void async_mail_write(const AsyncMail &m, const uint32_t *counters, uint32_t ncand, uint32_t nops)
 {
     const int lane = (int)threadIdx.x;
     if (lane >= 64) return;
     uint32_t v = 0;
     bool has = false;
-    uint32_t nops = 0;                                            // operations of all clusters
-    if (!ctk_guard_bad(counters)) {
-        const uint32_t nd = *m.dcount;
-        for (uint32_t d = lane; d < nd; d += 64) nops += m.cl_nops[d];
-        nops = wave_sum_u32(nops);
-    }
     if (lane == CTK_CNT_NOPS) { v = nops; has = true; }
     else if (lane < CTK_CNT_N) { v = __hip_atomic_load(&counters[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); has = true; }
     else if (lane == CTK_AM_NC) { v = *m.nc_ptr; has = true; }
@@ -1387,7 +1385,7 @@ __global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__
                                                      uint32_t *counters, uint32_t *mail, AsyncMail am)
 {
     if (ctk_guard_bad(am.scal ? counters : nullptr)) {
-        if (blockIdx.x == 0) async_mail_write(am, counters, 0u);
+        if (blockIdx.x == 0) async_mail_write(am, counters, 0u, 0u);
         return;
     }
     const int64_t nl = am.scal ? (int64_t)*am.nlab_ptr : n_labels;
@@ -1409,12 +1407,14 @@ __global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__
         mail[1] = __hip_atomic_load(&counters[CTK_CNT_WROTE_ZERO], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (last && am.scal) {
-        uint32_t nc = 0;
+        uint32_t nc = 0, no = 0;
         if (threadIdx.x < 64) {
             for (int64_t t = threadIdx.x; t < am.T; t += 64) nc += am.rec_cnt[t];
-            nc = wave_sum_u32(nc);
+            const uint32_t nd = *am.dcount;
+            for (uint32_t d = threadIdx.x; d < nd; d += 64) no += am.cl_nops[d];
+            nc = wave_sum_u32(nc); no = wave_sum_u32(no);
         }
-        async_mail_write(am, counters, nc);
+        async_mail_write(am, counters, nc, no);
     }
 }
 
@@ -1423,22 +1423,26 @@ __global__ __launch_bounds__(1024) void k_count_alive_1(const int32_t *__restric
                                                         uint32_t *counters, uint32_t *mail, AsyncMail am)
 {
     if (ctk_guard_bad(am.scal ? counters : nullptr)) {
-        async_mail_write(am, counters, 0u);
+        async_mail_write(am, counters, 0u, 0u);
         return;
     }
-    uint32_t v = 0, nc = 0;
-    if (am.scal) for (int64_t t = threadIdx.x; t < am.T; t += 1024) nc += am.rec_cnt[t];
+    uint32_t v = 0, nc = 0, no = 0;
+    if (am.scal) {
+        for (int64_t t = threadIdx.x; t < am.T; t += 1024) nc += am.rec_cnt[t];
+        const uint32_t nd = *am.dcount;
+        for (uint32_t d = threadIdx.x; d < nd; d += 1024) no += am.cl_nops[d];
+    }
     const int64_t nl = am.scal ? (int64_t)*am.nlab_ptr : n_labels;
     for (int64_t l = threadIdx.x + 1; l <= nl; l += 1024) {
         const int64_t lo = ext[l], hi = ext[n_labels + 1 + l];
         v += (hi >= lo && hi - lo + 1 >= persistence) ? 1u : 0u;
     }
-    __shared__ uint32_t sm[16], sn[16];
-    const uint32_t s = wave_sum_u32(v), s2 = wave_sum_u32(nc);
-    if (lane_id() == 0) { sm[threadIdx.x >> 6] = s; sn[threadIdx.x >> 6] = s2; }
+    __shared__ uint32_t sm[16], sn[16], so[16];
+    const uint32_t s = wave_sum_u32(v), s2 = wave_sum_u32(nc), s3 = wave_sum_u32(no);
+    if (lane_id() == 0) { sm[threadIdx.x >> 6] = s; sn[threadIdx.x >> 6] = s2; so[threadIdx.x >> 6] = s3; }
     __syncthreads();
-    uint32_t tot = 0, ncand = 0;
-    for (int i = 0; i < 16; i++) { tot += sm[i]; ncand += sn[i]; }
+    uint32_t tot = 0, ncand = 0, nops = 0;
+    for (int i = 0; i < 16; i++) { tot += sm[i]; ncand += sn[i]; nops += so[i]; }
     if (threadIdx.x == 0) {
         counters[CTK_CNT_ALIVE] = tot;
         mail[0] = tot;
@@ -1446,7 +1450,7 @@ __global__ __launch_bounds__(1024) void k_count_alive_1(const int32_t *__restric
     }
     if (am.scal) {
         __syncthreads();                                   // (counters[CTK_CNT_ALIVE] is one of the words mailed)
-        async_mail_write(am, counters, ncand);
+        async_mail_write(am, counters, ncand, nops);
     }
 }
 

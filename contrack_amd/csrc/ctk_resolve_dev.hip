@@ -74,8 +74,11 @@ struct ResolveDev {
     int32_t *ext;                         // time extents of the ids, reset by k_rs_roots: ext[l] = min t, ext[ext_off + l] = max t
     int64_t ext_off;
     uint32_t *counters_w;                 // the write-stage counters are reset by k_rs_roots as well
+    uint32_t *pstate;                     // [T + 1] k_rs_pass_sys: per timestep (iterations done) << 24 | changed bits; zeroed by k_rs_init
 };
 
+#define CTK_PSTATE_STRIDE 32        // words between the per-timestep state words of k_rs_pass_sys: one 128-byte line each (the words are
+                                    // polled with device-scope loads: neighbours in one line would all hit the same memory channel)
 #define CTK_CHG_SLOTS 64            // 'changed' words per filter pass (= wave width: one ballot reads them)
 #define CTK_MAX_JACOBI 240          // hard cap of filter passes on the device (then: host resolver)
 #define CTK_JACOBI_ROUND 10         // passes launched per round before convergence is checked
@@ -148,6 +151,7 @@ __global__ void k_rs_init(ResolveDev r)
     }
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < (CTK_MAX_JACOBI + 1) * CTK_CHG_SLOTS; i += blockDim.x) r.changed[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) *r.ambig = 0;
+    if (r.pstate) for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= r.T; t += (int64_t)gridDim.x * blockDim.x) r.pstate[(size_t)t * CTK_PSTATE_STRIDE] = 0u;
 }
 
 __global__ void k_rs_parent_init(ResolveDev r)
@@ -181,10 +185,8 @@ __global__ void k_rs_pairs(ResolveDev r)
 }
 
 // 1/areacon and the forward fraction do not change between passes
-__global__ void k_rs_prep(ResolveDev r)
+__device__ __forceinline__ void dev_prep_comp(const ResolveDev &r, uint32_t g, double *inv_out, double *ff_out)
 {
-    const uint32_t nc = dev_ncomps(r);
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
         bool inexact = false;
         const double areacon = dev_limbs_to_double(r.A[2 * (int64_t)g], r.A[2 * (int64_t)g + 1], r.wshift, r.limb_bits, &inexact);
         const double fwd = dev_limbs_to_double(r.F[2 * (int64_t)g], r.F[2 * (int64_t)g + 1], r.wshift, r.limb_bits, &inexact);
@@ -199,6 +201,14 @@ __global__ void k_rs_prep(ResolveDev r)
         const double inv = 1.0 / areacon;                     // reciprocal, then multiply -- as the reference does
         r.inv[g] = inv;
         r.ff[g] = inv * fwd;
+        *inv_out = inv; *ff_out = inv * fwd;
+}
+__global__ void k_rs_prep(ResolveDev r)
+{
+    const uint32_t nc = dev_ncomps(r);
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
+        double a, b;
+        dev_prep_comp(r, g, &a, &b);
     }
 }
 
@@ -330,6 +340,148 @@ __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same iteration in ONE launch ("systolic"): the workgroup of timestep t runs its iterations 0 .. K-1 itself; iteration k
+// needs the predecessor's bits of iteration k-1 and nothing else, so it waits for ONE word -- pstate[t-1], written by the
+// workgroup of t-1 after each of its iterations: (iterations done) << 24 | bit k = "my bits changed in iteration k" -- instead of
+// a kernel boundary.  Workgroups are dispatched in index order, so the one waited for is always running or done.  The pair
+// records and component constants of the timestep stay in registers across the iterations (a launch per pass reloaded them:
+// three dependent round trips + the launch, 4.7 us a pass, 47-56 us for the ten to twelve passes of the bench slab).  An
+// iteration whose predecessor did not change in the previous one does nothing but publish its word.  K <= 24.
+// changed[] (per pass, read by the host / the mailbox) is kept as k_rs_pass keeps it.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_rs_pass_sys(ResolveDev r, int it0, int K, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_cnt,
+                                                    uint32_t *__restrict__ pstate /* [T + 1], zeroed */, int prep_inline /* k_rs_prep's work for this timestep first */)
+{
+    if (dev_tables_bad(r)) return;
+    const int t = (int)blockIdx.x + r.t_lo;
+    const int lane = (int)threadIdx.x;
+    // round trip 1
+    const uint32_t cb = r.cprefix[t], ce = r.cprefix[t + 1];
+    const uint32_t pb = pair_base[t], pn = pair_cnt[t];
+    const uint32_t nu = dev_nungrouped(r);
+    const uint32_t nct = ce - cb;
+    __shared__ long long Bl[2 * CTK_PASS_COMPS];
+    const bool lds = nct <= CTK_PASS_COMPS;
+    long long *B = lds ? Bl : (long long *)(r.B + 2 * (int64_t)cb);
+    // round trip 2: first pair and first component of this lane (constant over the iterations)
+    uint8_t *keep = r.keep0;
+    const bool has_p = (uint32_t)lane < pn, has_c = (uint32_t)lane < nct;
+    const uint32_t k0 = pb + lane, g0 = cb + lane;
+    const uint32_t rd0 = has_p ? r.p_rd[k0] : 0u, rc0 = has_p ? r.p_rc[k0] : 0u;
+    CtkPair p0;
+    if (has_p) p0 = r.pairs[k0]; else { p0.lo = 0; p0.hi = 0; }
+    const uint32_t mrep0 = has_c ? r.mrep[g0] : 0xffffffffu;
+    double inv0 = 0.0, ff0 = 0.0;
+    if (prep_inline) {
+        for (uint32_t c = lane; c < nct; c += 64) {
+            double a, b;
+            dev_prep_comp(r, cb + c, &a, &b);
+            if (c == (uint32_t)lane) { inv0 = a; ff0 = b; }
+        }
+        if (nct > 64) __syncthreads();                     // (components beyond the first 64 are re-read from memory below)
+    } else if (has_c) { inv0 = r.inv[g0]; ff0 = r.ff[g0]; }
+    uint8_t kold0 = has_c ? __hip_atomic_load(&keep[g0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
+    const bool dyn_pred = t > r.t_lo;                      // the predecessor is filtered by this launch too
+    uint32_t mybits = 0;
+    for (int k = 0; k < K; k++) {
+        const int it = it0 + k;
+        bool evaluate = k == 0;
+        if (k > 0 && dyn_pred) {
+            uint32_t st;
+            // relaxed polls (an acquire load invalidates the caches on EVERY poll: 2705 waves doing that made an iteration cost 95 us);
+            // the bits are read with device-scope loads, which need no invalidation
+            while (((st = __hip_atomic_load(&pstate[(size_t)(t - 1) * CTK_PSTATE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 24) < (uint32_t)k) __builtin_amdgcn_s_sleep(2);
+            evaluate = (st >> (k - 1)) & 1u;
+        }
+        bool wave_any = false;
+        if (evaluate) {
+            if (lds) for (uint32_t c = lane; c < 2 * nct; c += 64) Bl[c] = 0;
+            const uint8_t kd0 = has_p ? __hip_atomic_load(&keep[rd0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
+            __syncthreads();
+            if (has_p && kd0) {
+                const uint32_t c = rc0 - cb;
+                atomicAdd((unsigned long long *)&B[2 * c], (unsigned long long)p0.lo);
+                atomicAdd((unsigned long long *)&B[2 * c + 1], (unsigned long long)p0.hi);
+            }
+            for (uint32_t i = lane + 64; i < pn; i += 64) {            // timesteps with more than 64 pair records
+                const uint32_t kk = pb + i;
+                if (!__hip_atomic_load(&keep[r.p_rd[kk]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+                const CtkPair p = r.pairs[kk];
+                const uint32_t c = r.p_rc[kk] - cb;
+                atomicAdd((unsigned long long *)&B[2 * c], (unsigned long long)p.lo);
+                atomicAdd((unsigned long long *)&B[2 * c + 1], (unsigned long long)p.hi);
+            }
+            if (nu) {                                                   // records that bypassed the hash table (rare)
+                const uint32_t ng = dev_ngrouped(r);
+                for (uint32_t i = lane; i < nu; i += 64) {
+                    const CtkPair p = r.pairs[r.pair_cap - 1u - i];
+                    if ((int)p.t != t) continue;
+                    if (!__hip_atomic_load(&keep[r.p_rd[ng + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+                    const uint32_t c = r.p_rc[ng + i] - cb;
+                    atomicAdd((unsigned long long *)&B[2 * c], (unsigned long long)p.lo);
+                    atomicAdd((unsigned long long *)&B[2 * c + 1], (unsigned long long)p.hi);
+                }
+            }
+            __syncthreads();
+            bool any = false;
+            for (uint32_t c = lane; c < nct; c += 64) {
+                const uint32_t g = cb + c;
+                const bool first = c == (uint32_t)lane;
+                long long blo, bhi;
+                if (lds) { blo = Bl[2 * c]; bhi = Bl[2 * c + 1]; }
+                else {
+                    blo = __hip_atomic_load(&B[2 * c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bhi = __hip_atomic_load(&B[2 * c + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&B[2 * c], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&B[2 * c + 1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if ((first ? mrep0 : r.mrep[g]) != c) continue;         // representatives only
+                bool inexact = r.inex[g] != 0;
+                const double bwd = dev_limbs_to_double(blo, bhi, r.wshift, r.limb_bits, &inexact);
+                double fb = (first ? inv0 : r.inv[g]) * bwd, ff = first ? ff0 : r.ff[g];
+                const uint32_t os = r.ovr_slot ? r.ovr_slot[g] : 0u;
+                if (os & 0x80000000u) {
+                    const double *v = r.ovr_val + 3 * (size_t)(os & 0x3fffffffu);
+                    const double inv = 1.0 / v[0];
+                    fb = inv * v[2]; ff = inv * v[1];
+                } else if (inexact) {
+                    const double tol = CTK_AMBIG_ULPS * 2.220446049250313e-16 * fabs(r.overlap);
+                    if ((ff != 0 && fabs(ff - r.overlap) <= tol) || (r.twosided && fb != 0 && fabs(fb - r.overlap) <= tol)) {
+                        *r.ambig = 1u;
+                        if (r.ovr_slot && os == 0u) {
+                            const uint32_t idx = atomicAdd(r.amb_cnt, 1u);
+                            if (idx < r.amb_cap) { r.amb_list[idx] = g; r.ovr_slot[g] = 0x40000000u | idx; }
+                        }
+                    }
+                }
+                bool kill = false;
+                if (r.twosided) {
+                    if (fb != 0 && ff != 0) { if (fb < r.overlap || ff < r.overlap) kill = true; }
+                    if (fb != 0 && ff == 0) { if (fb < r.overlap) kill = true; }
+                    if (fb == 0 && ff != 0) { if (ff < r.overlap) kill = true; }
+                } else {
+                    if (ff < r.overlap) kill = true;
+                }
+                const uint8_t kn = kill ? 0 : 1;
+                // only this workgroup writes the bits of timestep t (device-scope load: what an earlier iteration of this launch stored)
+                const uint8_t kold = first ? kold0 : __hip_atomic_load(&keep[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (kn != kold) { __hip_atomic_store(&keep[g], kn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); any = true; if (first) kold0 = kn; }
+            }
+            wave_any = __ballot(any) != 0ull;
+            __syncthreads();                                            // (Bl is zeroed again by the next evaluation)
+        }
+        if (wave_any) mybits |= 1u << k;
+        if (lane == 0) {
+            if (wave_any) r.changed[it * CTK_CHG_SLOTS + (t & (CTK_CHG_SLOTS - 1))] = 1u;
+            // the bits (device-scope stores: written through to the coherence point) before the word that announces them: all
+            // stores of this wave acknowledged, then the word.  (A release fence would write back the whole L2 of this XCD.)
+            __builtin_amdgcn_s_waitcnt(0);
+            __hip_atomic_store(&pstate[(size_t)t * CTK_PSTATE_STRIDE], ((uint32_t)(k + 1) << 24) | mybits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 __device__ __forceinline__ uint32_t gfind(uint32_t *p, uint32_t i)
 {
     for (;;) {
@@ -383,8 +535,11 @@ __global__ __launch_bounds__(256) void k_rs_roots(ResolveDev r, uint32_t *__rest
             }
         }
     }
-    const int tot = __syncthreads_count((int)isr);
-    if (threadIdx.x == 0) bsum[blockIdx.x] = (uint32_t)tot;
+    __shared__ uint32_t sm[8];
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(isr, sm, &tot);
+    if (g < nc) r.rank[g] = ex;                             // roots in front of g inside its block (k_rs_rank overwrites it with the global rank)
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
 // rank[g] = surviving roots before g (second half: every block sums the block counts in front of it itself -- a few hundred
@@ -411,6 +566,37 @@ __global__ __launch_bounds__(256) void k_rs_rank(const uint32_t *__restrict__ is
     uint32_t tot;
     const uint32_t ex = block_excl_scan(v, sm, &tot);
     if (i < n) rank[i] = front + ex;
+}
+
+// k_rs_rank + k_rs_labels in one launch (while the block sums fit LDS): every workgroup builds the exclusive prefix of ALL block
+// counts itself (a few hundred values), then label = 1 + prefix[block of the root] + roots in front of it inside that block.
+// rank[] is not written (the time-shard path, which reads it, keeps the two kernels); *total = number of labels.
+#define CTK_RL_BLOCKS 8192
+__global__ __launch_bounds__(256) void k_rs_rank_labels(ResolveDev r, const uint32_t *__restrict__ bsum, uint32_t nsb, uint32_t *__restrict__ total)
+{
+    extern __shared__ uint32_t pre[];                       // [nsb]
+    __shared__ uint32_t sm[8];
+    const uint32_t nc = dev_ncomps(r);
+    const uint32_t nblk = min((nc + 255u) / 256u, nsb);       // blocks that hold components (the grid is sized for the run count)
+    if (blockIdx.x >= nblk && blockIdx.x != 0) return;
+    uint32_t carry = 0;
+    for (uint32_t j0 = 0; j0 < nblk; j0 += 256) {
+        const uint32_t j = j0 + threadIdx.x;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(j < nblk ? bsum[j] : 0u, sm, &tot);
+        if (j < nblk) pre[j] = carry + ex;
+        carry += tot;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *total = carry;
+    __syncthreads();
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
+        const int32_t root = r.lab[g];
+        int32_t l = 0;
+        if (root >= 0) {
+            l = (int32_t)(pre[(uint32_t)root >> 8] + r.rank[root]) + 1;      // (r.rank: roots in front of it inside its block, k_rs_roots)
+        }
+        r.lab[g] = l;
+    }
 }
 
 // fresh labels: 1 + rank of the root among surviving roots (raster order)

@@ -43,6 +43,7 @@ struct SeamDev {
     int ny, nx;
     int64_t T;
     int dbg;                       // experiments (CTK_SD_DBG): stop after a stage
+    int lab_cap, ops_cap;          // labels / operations of one cluster (<= 64; a test hook lowers them)
 };
 
 __global__ __launch_bounds__(64) void k_seam_clusters(SeamDev a)
@@ -80,8 +81,8 @@ __device__ __forceinline__ int32_t sd_wave_max(int32_t v)
     return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 #define SD_RL(v, i) __builtin_amdgcn_readlane((int)(v), (int)(i))
+#define SD_U(x) __builtin_amdgcn_readfirstlane((int)(x))          // wave-uniform by construction: keep it in a scalar register
 
-struct SdMemo { int32_t l, t, ylo, yhi, res; uint32_t epoch; };
 #define SD_BATCH 512         // records of one 64-timestep batch staged in LDS (more: the cluster goes to the host path)
 
 // One wave (= one workgroup) per cluster.  The cluster's state lives in REGISTERS, one item per lane: lane k holds operation k
@@ -105,46 +106,44 @@ __global__ __launch_bounds__(64) void k_seam_driver(SeamDev a, int64_t t_begin)
         int32_t l_id = -1, l_orig = 0, l_b0 = 0, l_b1 = 0, l_b2 = 0, l_b3 = 0, l_b4 = 0, l_b5 = 0;        // label slot `lane`
         int nl = 0, nops = 0;
         bool bad = false;
-        uint32_t dbg_steps = 0, dbg_fold = 0; unsigned long long dbg_tp = 0, dbg_t0 = wall_clock64();
-        SdMemo memo[2];
-        memo[0].l = -1; memo[0].t = -1; memo[0].ylo = 0; memo[0].yhi = -1; memo[0].res = 0; memo[0].epoch = 0xffffffffu;
-        memo[1] = memo[0];
-        // fold of the cluster's operations over the seam pixel (t, y, x) that carried label slot l0 on the fresh labelling, with
-        // the interval of rows over which the answer provably stays the same (ctk_seam.h, SeamDriver::run)
-        auto fold = [&](SdMemo &m, int32_t l0, int32_t t, int32_t y, int32_t x) -> int32_t {
-            if (m.l == l0 && m.t == t && m.epoch == (uint32_t)nops && y >= m.ylo && y <= m.yhi) return m.res;
-            int32_t l = l0, s = 0, ylo = INT32_MIN, yhi = INT32_MAX;
-            const bool tx_in = lane < nops && t >= o_t0 && t <= o_t1 && x >= o_x0 && x <= o_x1;
-            const bool y_in = y >= o_y0 && y <= o_y1;
-            for (;;) {
-                dbg_fold++;
-                const bool cand = tx_in && o_hi == l && lane >= s;
-                const uint64_t cb = __ballot(cand), ib = __ballot(cand && y_in);
-                const int k = ib ? (int)__builtin_ctzll(ib) : 64;
-                const uint64_t visited = k < 64 ? (cb & ((1ull << k) - 1ull)) : cb;      // examined before the hit: outside because of y only
-                if (visited) {
-                    const bool v = (visited >> lane) & 1ull;
-                    yhi = min(yhi, sd_wave_min((v && y < o_y0) ? o_y0 - 1 : INT32_MAX));
-                    ylo = max(ylo, sd_wave_max((v && y > o_y1) ? o_y1 + 1 : INT32_MIN));
-                }
-                if (k == 64) break;
-                ylo = max(ylo, SD_RL(o_y0, k)); yhi = min(yhi, SD_RL(o_y1, k));
-                l = SD_RL(o_lo, k); s = k + 1;
-            }
-            m.l = l0; m.t = t; m.ylo = ylo; m.yhi = yhi; m.res = l; m.epoch = (uint32_t)nops;
-            return l;
-        };
-        // rows ya..yb of (global) timestep tg carry the pair of label slots (sl, sr): SeamDriver::run's inner loop
+        uint32_t dbg_steps = 0, dbg_fold = 0; unsigned long long dbg_tp = 0, dbg_t0 = wall_clock64(), dbg_tf = 0;
+        // Rows ya..yb of (global) timestep tg carry the pair of label slots (sl, sr): SeamDriver::run's inner loop (ctk_seam.h).
+        // The folds of the two seam pixels are independent chains and advance together in one loop (a lone dependent chain issues
+        // an instruction every ~8 cycles on this machine: a row step of ~150 of them was 0.7 us).  Only the upper end of the row
+        // interval over which both answers provably stay the same is needed (the lower end served the host version's memo).
         auto record = [&](int32_t tg, int32_t ya, int32_t yb, int sl, int sr) {
+            nops = SD_U(nops);
+            bool tl = __ballot(lane < nops && o_hi == sl) != 0ull;                         // is `hi` of some op
+            bool tr = (sr == sl) ? tl : (__ballot(lane < nops && o_hi == sr) != 0ull);
+            sl = SD_U(sl); sr = SD_U(sr); ya = SD_U(ya); yb = SD_U(yb); tg = SD_U(tg);
             for (int32_t y = ya; y <= yb;) {
                 dbg_steps++;
-                const bool tl = __ballot(lane < nops && o_hi == sl) != 0ull, tr = __ballot(lane < nops && o_hi == sr) != 0ull;      // is `hi` of some op
+                y = SD_U(y);
                 if (sl == sr && !tl) break;                                  // same label, never relabelled: nothing can differ
-                int32_t same_until = yb;
-                const int32_t p0 = tl ? fold(memo[0], sl, tg, y, 0) : sl;
-                const int32_t p1 = tr ? fold(memo[1], sr, tg, y, a.nx - 1) : sr;
-                if (tl) same_until = min(same_until, memo[0].yhi);
-                if (tr) same_until = min(same_until, memo[1].yhi);
+                int32_t p0 = sl, p1 = sr, yhi = INT32_MAX;
+                const unsigned long long tf0 = a.dbg >= 10 ? clock64() : 0;
+                if (tl || tr) {
+                    const bool live = lane < nops && tg >= o_t0 && tg <= o_t1;
+                    const bool y_in = y >= o_y0 && y <= o_y1, below = y < o_y0;
+                    const bool xa = live && o_x0 <= 0, xb = live && o_x1 >= a.nx - 1;      // the box holds x = 0 / x = nx - 1
+                    int32_t sa = 0, sb = 0;
+                    bool ga = tl, gb = tr;                                   // chain still going
+                    while (ga || gb) {
+                        dbg_fold++;
+                        const bool ca = ga && xa && o_hi == p0 && lane >= sa, cb = gb && xb && o_hi == p1 && lane >= sb;
+                        const uint64_t ia = __ballot(ca && y_in), ib = __ballot(cb && y_in);
+                        const int ka = ia ? (int)__builtin_ctzll(ia) : 64, kb = ib ? (int)__builtin_ctzll(ib) : 64;
+                        // ops examined before the hit (or all, without one) and found outside because of y only: they stay outside
+                        // while y stays on the same side of their rows
+                        const bool va = ca && lane < ka && below, vb = cb && lane < kb && below;
+                        if (__ballot(va || vb)) yhi = min(yhi, sd_wave_min((va || vb) ? o_y0 - 1 : INT32_MAX));
+                        if (ka < 64) { yhi = min(yhi, SD_RL(o_y1, ka)); p0 = SD_RL(o_lo, ka); sa = ka + 1; } else ga = false;
+                        if (kb < 64) { yhi = min(yhi, SD_RL(o_y1, kb)); p1 = SD_RL(o_lo, kb); sb = kb + 1; } else gb = false;
+                        yhi = SD_U(yhi); p0 = SD_U(p0); p1 = SD_U(p1); sa = SD_U(sa); sb = SD_U(sb);
+                    }
+                }
+                if (a.dbg >= 10) dbg_tf += clock64() - tf0;
+                const int32_t same_until = min(yb, yhi);
                 if (p0 == p1) { y = same_until + 1; continue; }              // nothing happens on these rows
                 const bool p0_hi = SD_RL(l_orig, p0) > SD_RL(l_orig, p1);    // the larger FRESH label becomes the smaller (:759/763)
                 const int32_t hi = p0_hi ? p0 : p1, lo = p0_hi ? p1 : p0;
@@ -152,10 +151,11 @@ __global__ __launch_bounds__(64) void k_seam_driver(SeamDev a, int64_t t_begin)
                 const int lh = hb ? 63 - (int)__builtin_clzll(hb) : -1;      // last op with this `hi`; last op that moved pixels INTO it
                 const int inflow = fb ? 63 - (int)__builtin_clzll(fb) : -1;
                 if (lh >= 0 && inflow < lh) { y = same_until + 1; continue; }      // nothing to move until an op is recorded
-                if (nops >= 64) { bad = true; return; }
+                if (nops >= a.ops_cap) { bad = true; return; }
                 const int32_t b0 = SD_RL(l_b0, hi), b1 = SD_RL(l_b1, hi), b2 = SD_RL(l_b2, hi), b3 = SD_RL(l_b3, hi), b4 = SD_RL(l_b4, hi), b5 = SD_RL(l_b5, hi);
                 if (lane == nops) { o_hi = hi; o_lo = lo; o_t0 = b0; o_t1 = b1; o_y0 = b2; o_y1 = b3; o_x0 = b4; o_x1 = b5; }
                 nops++;
+                tl = tl || hi == sl; tr = tr || hi == sr;
                 y++;                                                         // the next row sees the new op
             }
         };
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) void k_seam_driver(SeamDev a, int64_t t_begin)
                 for (;;) {
                     const uint64_t bl = __ballot(need_l), br = __ballot(need_r);
                     if (!(bl | br)) break;
-                    if (nl >= SD_LAB) { bad = true; break; }
+                    if (nl >= a.lab_cap) { bad = true; break; }
                     const int32_t d = bl ? SD_RL(c.ll, __builtin_ctzll(bl)) : SD_RL(c.lr, __builtin_ctzll(br));
                     if (lane == nl) l_id = d;
                     nl++;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64) void k_seam_driver(SeamDev a, int64_t t_begin)
                 dbg_tp += wall_clock64() - tp0;
             }
         }
-        if (a.dbg >= 10 && lane == 0) { atomicMax(&a.poison[2], dbg_steps); atomicMax(&a.poison[3], dbg_fold); atomicMax(&a.poison[4], (uint32_t)dbg_tp); atomicMax(&a.poison[5], (uint32_t)(wall_clock64() - dbg_t0)); }
+        if (a.dbg >= 10 && lane == 0) { atomicMax(&a.poison[2], dbg_steps); atomicMax(&a.poison[3], dbg_fold); atomicMax(&a.poison[4], (uint32_t)dbg_tp); atomicMax(&a.poison[5], (uint32_t)(wall_clock64() - dbg_t0)); atomicMax(&a.poison[6], (uint32_t)dbg_tf); }
         if (bad) { if (lane == 0) atomicOr(a.poison, CTK_POISON_CLUSTER); continue; }
         if (nops == 0) continue;
         // The cluster's operations take a contiguous range of the op arrays (chain order = index order inside the cluster): the

@@ -219,6 +219,9 @@ double ctk_debug_np_sum(const double *a, size_t n);
 int ctk_debug_boundary_resolve(int world, const int32_t *nlast, const int32_t *nh, const int32_t *nroots, const int32_t *last_flat,
                                const int32_t *halo_flat, int64_t *off /* [world+1] */, int32_t *last_label_flat, int32_t *halo_label_flat,
                                int32_t *n_absorbed /* [world] */);
+/* test hook: labels / operations of one seam cluster the device seam driver accepts (0 = its limits, 64 each): clusters beyond
+ * send the pass to the synchronous path with the host driver, and the grid stays there */
+int ctk_debug_set_seam_caps(ctk_handle *h, int labels, int ops);
 /* test hook: cap the device-written mailbox of the resolver hand-off (0 = no cap), so that the explicit-copy path runs */
 int ctk_debug_set_mailbox(ctk_handle *h, uint32_t cand_records, uint32_t labels);
 
@@ -269,6 +272,10 @@ int ctk_set_timing(ctk_handle *h, int level);
 int ctk_get_stats(ctk_handle *h, int64_t *out /* [CTK_NSTATS] */);
 /* filter passes launched per round before convergence is checked on the host (default 10, 1..32)   */
 int ctk_set_filter_round(ctk_handle *h, int passes);
+/* 1 (default; CTK_ASYNC=0 in the environment turns it off): the one-call entries run the whole pass without a host hand-off (device
+ * seam driver, one synchronisation at the end, validated from a device-written block of scalars; CTK_S_FUSED) and repeat the
+ * resolution on the synchronous path below only if the validation says so; 0: always the synchronous path (host seam driver) */
+int ctk_set_fused_pass(ctk_handle *h, int enable);
 /* 1 (default): ctk_track_* resolve the tables on the device; 0: download + ctk_resolve on the host */
 int ctk_set_device_resolve(ctk_handle *h, int enable);
 int ctk_get_timings(ctk_handle *h, double *ms /* [CTK_NTIMERS] */);

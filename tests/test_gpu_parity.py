@@ -248,15 +248,56 @@ def test_rare_paths_are_exercised(oracle_lib):
         got2, _ = t.track(a, thr, 0, w, 0.5, 2, True)                 # table is large enough now: device resolver
         st2 = t.stats()
         assert np.array_equal(got2, want) and st2["host_path"] == 0 and st2["ungrouped_pairs"] > 0
-        # several rounds of filter passes: convergence is only checked every `filter_round` passes
+        # several rounds of filter passes: convergence is only checked every `filter_round` passes.  The fused pass launches that
+        # many, finds at its end that the filter had not converged, and the synchronous path repeats the resolution ...
         g = golden_util.load("syn2deg_s0")
+        args = (g["anom"], g["thr"], _native.CMP_OPS[g["gorl"]], g["wrow"], g["overlap"], g["persistence"], g["twosided"])
         t.set_filter_round(2)
-        f, n = t.track(g["anom"], g["thr"], _native.CMP_OPS[g["gorl"]], g["wrow"], g["overlap"], g["persistence"], g["twosided"])
+        f, n = t.track(*args)
         st = t.stats()
-        assert np.array_equal(f, g["flag"]) and st["host_path"] == 0
+        assert np.array_equal(f, g["flag"]) and st["host_path"] == 0 and st["fused_pass"] == 0
         assert st["filter_passes"] > 2 and st["filter_rounds"] == (st["filter_passes"] + 1) // 2
+        # ... and launches more the next time, until the fused pass carries the whole cascade
+        for _ in range(4):
+            f, n = t.track(*args)
+            assert np.array_equal(f, g["flag"])
+            if t.stats()["fused_pass"]:
+                break
+        assert t.stats()["fused_pass"] == 1 and t.stats()["filter_passes"] > 2
+        # the synchronous path alone, same bookkeeping
+        t.set_fused(False)
+        t.set_filter_round(2)
+        f, n = t.track(*args)
+        st = t.stats()
+        assert np.array_equal(f, g["flag"]) and st["fused_pass"] == 0 and st["filter_rounds"] == (st["filter_passes"] + 1) // 2
     finally:
         t.close()
+
+
+@pytest.mark.parametrize("name", ["chain_a", "chain_b", "chain_c", "busy_s1", "refslab_fwd", "noise"])
+def test_fused_pass_and_its_fallbacks(name):
+    """the one-call pass without a host hand-off (device seam driver: one wave per cluster of candidate labels, contrack.py:753-763)
+    against the goldens; with the driver's per-cluster tables cut down to one label (an operation needs two) the clusters of these cases do not
+    fit, the pass says so at its end and the synchronous path (host driver) repeats the resolution -- same result, and the grid
+    stays on the host driver from then on"""
+    g = golden_util.load(name)
+    args = (g["anom"], g["thr"], _native.CMP_OPS[g["gorl"]], g["wrow"], g["overlap"], g["persistence"], g["twosided"])
+    want_n = len(np.unique(g["flag"])) - 1
+    with _native.Tracker(0) as t:
+        f, n = t.track(*args)
+        st = t.stats()
+        assert np.array_equal(f, g["flag"]) and n == want_n
+        fused_first = st["fused_pass"]
+        t.set_fused(False)
+        f0, n0 = t.track(*args)
+        assert np.array_equal(f0, g["flag"]) and n0 == want_n and t.stats()["fused_pass"] == 0
+        if fused_first and st["seam_ops"] > 0:
+            t.set_fused(True)
+            t.debug_set_seam_caps(1, 1)
+            f1, n1 = t.track(*args)
+            assert np.array_equal(f1, g["flag"]) and n1 == want_n and t.stats()["fused_pass"] == 0
+            f2, n2 = t.track(*args)                          # sticky: no second attempt on this grid
+            assert np.array_equal(f2, g["flag"]) and t.stats()["fused_pass"] == 0
 
 
 @pytest.mark.parametrize("shape", [(5, 1, 7), (5, 7, 1), (3, 2, 2), (4, 3, 64), (4, 3, 65), (2, 5, 128), (6, 4, 4), (9, 33, 3), (1, 1, 1),
