@@ -146,13 +146,14 @@ struct ctk_handle {
     DevBuf chunk_vals;                             // run values in the chunk order of k_relabel_v4
     // fused one-call path (ctk_seam_dev.hip): clusters of candidate labels, cluster root per group record; the pass runs without a
     // host hand-off and is validated from a device-written block of scalars after its only synchronisation
-    DevBuf sd_parent, sd_tmin, sd_tmax, sd_root, sd_nops, rv_pstate;
+    DevBuf sd_parent, sd_tmin, sd_tmax, sd_root, sd_nops, sd_lbox, rv_pstate;
     uint32_t *h_amail = nullptr;                   // pinned: AsyncMail scalars
     uint32_t op_cap_hint = 4096;                   // operation slots of the next fused pass (grows with what the passes needed)
     uint32_t nd_hint = 4096;                       // dense candidate labels of the last pass: grid of k_seam_driver
     int async_passes = CTK_JACOBI_ROUND;           // filter passes the next fused pass launches
     int use_async = -1;                            // -1: not decided (env CTK_ASYNC), 0 / 1
     int async_off_ny = -1, async_off_nx = -1;      // grid whose clusters did not fit the device seam driver: synchronous path from then on
+    bool fz_init = false;                          // k_compact_init ran (the resolver arrays are initialised), k_overlap prepared the pair arrays
     bool guard_on = false;                         // kernels behind the resolver check the device counters before touching the tables
     // calc_anom / percentile (ctk_anom.hip): resident anomaly slab, climatology, scratch
     DevBuf an_out, an_clim, an_raw, an_idx;
@@ -223,6 +224,7 @@ struct ctk_handle {
     int32_t nops = 0;
     // timing
     int timing = 0;
+    uint64_t pass_no = 0;                        // stage-1 launches so far (level-1 timing alternates between the two streaming kernels)
     hipEvent_t ev[CTK_K_COUNT + 2][2];           // + one internal pair: stage-1 row count / run scan, reported inside CTK_K_SCAN
     bool ev_used[CTK_K_COUNT + 2];
     double ms[CTK_NTIMERS];
@@ -283,7 +285,11 @@ struct Timer {
     int k;
     // level 1: only the two pixel-streaming kernels carry events (an event record is a command of its own, ~5 us on
     // the stream: twenty of them would stretch the pass they are supposed to measure); level 2: every group
-    bool on() const { return h->ev_ready && (h->timing >= 2 || (h->timing == 1 && (k == CTK_K_THRESHOLD || k == CTK_K_RELABEL))); }
+    // (level 1 times ONE of the two per pass, alternating: two event records per pass instead of four)
+    bool on() const
+    {
+        return h->ev_ready && (h->timing >= 2 || (h->timing == 1 && ((k == CTK_K_THRESHOLD && (h->pass_no & 1) == 0) || (k == CTK_K_RELABEL && (h->pass_no & 1) == 1))));
+    }
     Timer(ctk_handle *h_, int k_) : h(h_), k(k_)
     {
         if (on()) { (void)hipEventRecord(h->ev[k][0], h->stream); }
@@ -388,7 +394,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
                       &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
                       &h->sh_mask_next, &h->sh_send, &h->sh_recv, &h->sh_prev, &h->sh_elist, &h->sh_ovr_slot, &h->sh_ovr_val,
-                      &h->sh_amb_list, &h->sh_counts, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_root, &h->sd_nops, &h->rv_pstate};
+                      &h->sh_amb_list, &h->sh_counts, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_root, &h->sd_nops, &h->sd_lbox, &h->rv_pstate};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -510,6 +516,7 @@ extern "C" int ctk_get_timings(ctk_handle *h, double *ms)
 static int stream_in(ctk_handle *h, bool f64, int64_t T, int ny, int nx, const std::function<int(const void *, int64_t, int64_t)> &consume);
 static int stream_out(ctk_handle *h, int persistence, const int32_t *chunk_vals);
 
+static bool async_wanted(ctk_handle *h);
 static int threshold_rows(int ny, int nx, int64_t T)
 {
     (void)nx; (void)T;
@@ -530,6 +537,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     if (T > 4000000ll) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: more than 4 000 000 timesteps in one shard");
     HIPCHK(hipSetDevice(h->device));
     memset(h->ms, 0, sizeof(h->ms));
+    h->pass_no++;
     h->state = ST_IDLE;
     h->halo_valid = false; h->halo_v2 = defer_compact;
     h->T = T; h->ny = ny; h->nx = nx; h->W = (nx + 63) / 64; h->has_prev = has_prev ? 1 : 0; h->cmp_op = cmp_op;
@@ -639,13 +647,16 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         if (anom_dev) CTKCHK(launch_threshold(anom_dev, 0, T));
         else CTKCHK(stream_in(h, f64, T, ny, nx, launch_threshold));                     // the slab arrives in chunks (ctk_track_stream_*)
     }
+    // The host learns the run totals from the scan kernel's block of scalars in pinned memory and knows that it is complete by
+    // the stamp the kernel writes last (an event record after the kernel is a command of its own: 5 us of stream time).
+    const uint32_t scan_stamp = (uint32_t)(h->pass_no & 0x7fffffffu) | 0x80000000u;
     {
         Timer tm(h, CTK_KI_ROWCOUNT);
         if (T > 0) k_rowcount<<<(int)T, 256, 0, s>>>(P<uint64_t>(h->mask), ny, W, P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart), P<uint32_t>(h->tcount));
-        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, h->h_mail1);
+        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, h->h_mail1,
+                                      nullptr, scan_stamp);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(h->ev_scan, s));
     // 2-D labelling.  The variants take disjoint sets of timesteps (by run count; nruns == 0 goes to the small one) and
     // run on concurrent streams.  Which variants are needed and how large the run-indexed buffers must be is known only
     // after the run scan -- but a call on the same kind of data as the previous one needs the same: the launch is made
@@ -694,7 +705,17 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     }
     // the scan kernel wrote total / maximum / overflow / last count into the pinned mailbox
     HT("thr+scan launched");
-    HIPCHK(hipEventSynchronize(h->ev_scan));                      // not the stream: the speculative labelling may still be running
+    {   // not the stream: the speculative labelling may still be running
+        volatile uint32_t *vm = h->h_mail1;
+        for (uint64_t spins = 0; vm[4] != scan_stamp; spins++) {
+            if ((spins & 0xfff) == 0xfff) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) { if (vm[4] != scan_stamp) return ctk_set_error(CTK_E_INTERNAL, "stage 1: the run scan did not report"); break; }
+                if (q != hipErrorNotReady) return ctk_set_error(CTK_E_NODEVICE, "stage 1: %s", hipGetErrorString(q));
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
     const uint32_t m_total = h->h_mail1[0], m_max = h->h_mail1[1], m_ovf = h->h_mail1[2], m_last = h->h_mail1[3];
     HT("sync1 done");
     if (m_ovf & CTK_OVF_RUNS) return ctk_set_error(CTK_E_RANGE, "ctk_shard_label2d: more than 2^32-1 runs in one shard");
@@ -747,7 +768,30 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         h->spec_set.v1 = true; h->spec_set.v2 = need.v2; h->spec_set.v3 = need.v3; h->spec_set.glb = need.glb;
         h->spec_ny = ny; h->spec_nx = nx; h->spec_T = T;
     }
-    if (!defer_compact) {
+    h->fz_init = false;
+    if (!defer_compact && T > 0 && T <= 65536 && h->use_device_resolve && async_wanted(h)) {
+        // fused one-call path: prefix of the component counts, compaction and the initialisation of the resolver's per-component
+        // arrays in one launch (k_compact_init)
+        const size_t R = h->total_runs ? h->total_runs : 1;
+        CTKCHK(ensure(h, h->rv_F, R * 16)); CTKCHK(ensure(h, h->rv_B, R * 16));
+        CTKCHK(ensure(h, h->rv_keep0, R)); CTKCHK(ensure(h, h->rv_keep1, R));
+        CTKCHK(ensure(h, h->rv_touch, R * 4)); CTKCHK(ensure(h, h->rv_parent, R * 4));
+        CTKCHK(ensure(h, h->rv_changed, (size_t)(CTK_MAX_JACOBI + 8) * CTK_CHG_SLOTS * 4));
+        CTKCHK(ensure(h, h->rv_scalars, 64));
+        CTKCHK(ensure(h, h->rv_pstate, (size_t)(T + 1) * 4 * CTK_PSTATE_STRIDE));
+        CompInit ci;
+        ci.F = P<int64_t>(h->rv_F); ci.B = P<int64_t>(h->rv_B); ci.keep0 = P<uint8_t>(h->rv_keep0); ci.keep1 = P<uint8_t>(h->rv_keep1);
+        ci.touch = P<uint32_t>(h->rv_touch); ci.parent = P<uint32_t>(h->rv_parent); ci.changed = P<uint32_t>(h->rv_changed);
+        ci.ambig = P<uint32_t>(h->rv_scalars) + 1; ci.pstate = P<uint32_t>(h->rv_pstate);
+        ci.next_tiny = (const int32_t *)(P<int64_t>(h->wlo) + 2 * (size_t)h->ny);
+        ci.nchanged = (CTK_MAX_JACOBI + 1) * CTK_CHG_SLOTS; ci.pstride = CTK_PSTATE_STRIDE; ci.T = T;
+        Timer tm(h, CTK_K_SCAN);
+        k_compact_init<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
+                                              P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box), P<int64_t>(h->d_area),
+                                              P<uint32_t>(h->d_comp_t), ci);
+        HIPCHK(hipGetLastError());
+        h->fz_init = true;
+    } else if (!defer_compact) {
         Timer tm(h, CTK_K_SCAN);
         k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->ncomp), T, CPX(h), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
         HIPCHK(hipGetLastError());
@@ -847,6 +891,13 @@ static int launch_overlap(ctk_handle *h)
     a.pair_base = P<uint32_t>(h->pair_base); a.pair_cnt = P<uint32_t>(h->pair_cnt);
     a.wlo = P<int64_t>(h->wlo); a.whi = P<int64_t>(h->wlo) + h->ny;
     a.ny = h->ny; a.nx = h->nx; a.W = h->W;
+    a.cprefix = nullptr; a.mrep = nullptr; a.p_rc = nullptr; a.p_rd = nullptr; a.p_gc = nullptr; a.p_gd = nullptr; a.F = nullptr;
+    if (h->fz_init) {
+        const size_t PC = h->pair_cap ? h->pair_cap : 1;
+        CTKCHK(ensure(h, h->rv_prc, PC * 4)); CTKCHK(ensure(h, h->rv_prd, PC * 4)); CTKCHK(ensure(h, h->rv_pgc, PC * 4)); CTKCHK(ensure(h, h->rv_pgd, PC * 4));
+        a.cprefix = CPX(h); a.mrep = P<uint32_t>(h->d_mrep); a.F = P<int64_t>(h->rv_F);
+        a.p_rc = P<uint32_t>(h->rv_prc); a.p_rd = P<uint32_t>(h->rv_prd); a.p_gc = P<uint32_t>(h->rv_pgc); a.p_gd = P<uint32_t>(h->rv_pgd);
+    }
     Timer tm(h, CTK_K_OVERLAP);
     k_overlap<<<(int)h->T, 256, 0, h->stream>>>(a);
     HIPCHK(hipGetLastError());
@@ -911,6 +962,7 @@ static int build_tables_blob(ctk_handle *h, bool to_device, const void **blob, s
         uint32_t ovf = cnt[CTK_CNT_OVERFLOW] & ~CTK_OVF_PAIRS;
         HIPCHK(hipMemcpyAsync(P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, &ovf, 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
+        h->fz_init = false;                                    // (the synchronous resolver prepares the pair arrays itself)
         CTKCHK(launch_overlap(h));
     }
     h->total_comps = ctot;
@@ -1152,7 +1204,7 @@ static int rs_prepare(ctk_handle *h, const ResolveIn &in, double overlap, int tw
     r.next_tiny = (const int32_t *)(P<int64_t>(h->wlo) + 2 * (size_t)h->ny); r.touch = P<uint32_t>(h->rv_touch);
     r.nh_ptr = nullptr; r.t_lo = 1; r.t_hi = (int)T - 2;                // one slab: timesteps 1 .. T-2 are filtered, no halo
     r.ovr_slot = nullptr; r.ovr_val = nullptr; r.amb_cnt = P<uint32_t>(h->rv_scalars) + 2; r.amb_list = nullptr; r.amb_cap = 0;
-    r.cl_parent = nullptr; r.cl_tmin = nullptr; r.cl_tmax = nullptr; r.cl_nops = nullptr; r.pstate = nullptr; r.ext = nullptr; r.ext_off = 0; r.counters_w = nullptr;      // (fused one-call path only)
+    r.cl_parent = nullptr; r.cl_tmin = nullptr; r.cl_tmax = nullptr; r.cl_nops = nullptr; r.lbox = nullptr; r.pstate = nullptr; r.ext = nullptr; r.ext_off = 0; r.counters_w = nullptr;      // (fused one-call path only)
 
     const int gc = (int)std::min<size_t>((R + 255) / 256, 2048), gp = (int)std::min<size_t>((PC + 255) / 256, 2048);
     // mailbox in pinned host memory: the last resolver kernel writes scalars, candidate records and dense label tables
@@ -1578,11 +1630,12 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     CTKCHK(rs_prepare(h, in, overlap, twosided, pl));
     ResolveDev &r = pl.r;
     const int nsb = pl.nsb, gc = pl.gc, gp = pl.gp;
-    const size_t DC = std::min<size_t>(R + 1, (size_t)2 * std::max<int64_t>(in.seam_cap, 1));       // (rs_prepare's capacity of the dense tables)
-    CTKCHK(ensure(h, h->sd_parent, DC * 4)); CTKCHK(ensure(h, h->sd_tmin, DC * 4)); CTKCHK(ensure(h, h->sd_tmax, DC * 4)); CTKCHK(ensure(h, h->sd_nops, DC * 4));
+    // label-indexed tables of the device seam driver (ids <= components <= runs: only the entries of real ids are ever touched)
+    CTKCHK(ensure(h, h->sd_parent, (R + 1) * 4)); CTKCHK(ensure(h, h->sd_tmin, (R + 1) * 4)); CTKCHK(ensure(h, h->sd_tmax, (R + 1) * 4));
+    CTKCHK(ensure(h, h->sd_nops, (R + 1) * 4)); CTKCHK(ensure(h, h->sd_lbox, (R + 1) * 24));
     CTKCHK(ensure(h, h->sd_root, (size_t)std::max<int64_t>(T * h->ny, 1) * 4));
-    // op slots: SD_OPS_OWN per candidate label id (sized after the previous pass) + a shared tail for the clusters with more
-    const uint32_t own_ids = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)h->nd_hint * 2, 4096), DC);
+    // op slots: SD_OPS_OWN per label id (sized after the previous pass) + a shared tail for the clusters with more and the ids beyond
+    const uint32_t own_ids = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)h->last_nlab + h->last_nlab / 4, 8192), R + 1);
     const uint32_t op_cap = own_ids * SD_OPS_OWN + h->op_cap_hint;
     CTKCHK(ensure(h, h->ops, (size_t)op_cap * (sizeof(CtkOp) + 4)));
     // ids <= components <= runs: R + 1 is the offset of the second half of ext (only the entries of real ids are ever touched)
@@ -1591,12 +1644,15 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     memset(h->h_amail, 0, CTK_AM_WORDS * 4);
     h->n_labels = (int64_t)R; h->t_begin = 0;
     r.cl_parent = P<uint32_t>(h->sd_parent); r.cl_tmin = P<int32_t>(h->sd_tmin); r.cl_tmax = P<int32_t>(h->sd_tmax); r.cl_nops = P<uint32_t>(h->sd_nops);
+    r.lbox = P<int32_t>(h->sd_lbox);
     r.ext = P<int32_t>(h->ext); r.ext_off = (int64_t)R + 1; r.counters_w = P<uint32_t>(h->counters);
     SeamDev sd;
-    sd.cl_parent = r.cl_parent; sd.cl_tmin = r.cl_tmin; sd.cl_tmax = r.cl_tmax; sd.rec_root = P<uint32_t>(h->sd_root);
-    sd.recs = P<CtkCand>(h->rv_cand_scratch); sd.rec_cnt = P<uint32_t>(h->rv_cand_cnt); sd.dcount = r.dcount; sd.dorig = r.dorig; sd.dbox = r.dbox;
-    sd.dmap = r.dmap; sd.ops = P<CtkOp>(h->ops); sd.op_next = (int32_t *)(P<CtkOp>(h->ops) + op_cap); sd.op_first = r.op_first;
-    sd.op_count = P<uint32_t>(h->counters) + CTK_CNT_NOPS; sd.op_cap = op_cap; sd.own_ids = own_ids; sd.cl_nops = r.cl_nops; sd.dense_cap = (uint32_t)std::min<size_t>(DC, 0xffffffffu);
+    sd.dummy = nullptr;
+    sd.cl_parent = r.cl_parent; sd.cl_tmin = r.cl_tmin; sd.cl_tmax = r.cl_tmax; sd.cl_nops = r.cl_nops; sd.lbox = r.lbox; sd.mark = P<uint8_t>(h->rv_mark);
+    sd.rec_root = P<uint32_t>(h->sd_root); sd.recs = P<CtkCand>(h->rv_cand_scratch); sd.rec_cnt = P<uint32_t>(h->rv_cand_cnt);
+    sd.t_nops = P<uint32_t>(h->rv_cand_off);              // ([T + 1], unused on this path otherwise)
+    sd.ops = P<CtkOp>(h->ops); sd.op_next = (int32_t *)(P<CtkOp>(h->ops) + op_cap); sd.op_first = r.op_first;
+    sd.op_count = P<uint32_t>(h->counters) + CTK_CNT_NOPS; sd.op_cap = op_cap; sd.own_ids = own_ids;
     sd.poison = P<uint32_t>(h->counters) + CTK_CNT_POISON; sd.ny = h->ny; sd.nx = h->nx; sd.T = T;
     sd.dbg = getenv("CTK_SD_DBG") ? atoi(getenv("CTK_SD_DBG")) : 0;
     sd.lab_cap = h->debug_sd_lab ? std::min(h->debug_sd_lab, SD_LAB) : SD_LAB; sd.ops_cap = h->debug_sd_ops ? std::min(h->debug_sd_ops, 64) : 64;
@@ -1611,8 +1667,10 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     struct GuardOff { ctk_handle *h; ~GuardOff() { h->guard_on = false; } } guard_off{h};
     {
         Timer tm(h, CTK_K_RESOLVE);
-        k_rs_init<<<gc, 256, 0, s>>>(r);
-        k_rs_pairs<<<gp, 256, 0, s>>>(r);
+        if (!h->fz_init) {                                             // (else: k_compact_init and k_overlap did both)
+            k_rs_init<<<gc, 256, 0, s>>>(r);
+            k_rs_pairs<<<gp, 256, 0, s>>>(r);
+        }
         if (!(sys && NP > 0)) k_rs_prep<<<gc, 256, 0, s>>>(r);         // (k_rs_pass_sys does it for its own timestep)
         if (sys && NP > 0) k_rs_pass_sys<<<(int)(T - 2), 64, 0, s>>>(r, 0, NP, in.pair_base, in.pair_cnt, r.pstate, 1);
         else
@@ -1625,11 +1683,9 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
             k_rs_rank<<<nsb, 256, 0, s>>>(r.isroot, in.cprefix + T, P<uint32_t>(h->rv_bsum), r.rank, P<uint32_t>(h->rv_boff) + nsb);
             k_rs_labels<<<gc, 256, 0, s>>>(r);
         }
-        k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, h->ny, P<uint8_t>(h->rv_mark), P<int2>(h->rv_seam_res));
-        k_rs_cand_groups<<<(int)T, 64, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), P<uint8_t>(h->rv_mark),
-                                               h->ny, 0, P<uint32_t>(h->rv_cand_cnt), P<CtkCand>(h->rv_cand_scratch));
-        k_seam_clusters<<<(int)T, 64, 0, s>>>(sd);
-        k_seam_driver<<<(int)std::min<size_t>(std::max<size_t>((size_t)h->nd_hint + h->nd_hint / 2, 1024), 65536), 64, 0, s>>>(sd, 0);
+        k_fz_mark<<<(int)T, 64, 0, s>>>(r, sd, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res));
+        k_fz_groups<<<(int)T, 64, 0, s>>>(r, sd, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), 0);
+        k_seam_driver<<<(int)std::min<int64_t>(T, 65536), 64, 0, s>>>(sd, 0);
         HIPCHK(hipGetLastError());
     }
     CTKCHK(launch_extents(h, true, true));
@@ -1648,8 +1704,8 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
         CTKCHK(launch_relabel(h, persistence, flag_dev, true, cv));
     }
     AsyncMail am;
-    am.scal = h->h_amail; am.nlab_ptr = P<uint32_t>(h->rv_boff) + nsb; am.nc_ptr = in.cprefix + T; am.dcount = r.dcount;
-    am.changed = r.changed; am.ambig = r.ambig; am.rec_cnt = P<uint32_t>(h->rv_cand_cnt); am.cl_nops = r.cl_nops; am.T = T; am.passes = NP;
+    am.scal = h->h_amail; am.nlab_ptr = P<uint32_t>(h->rv_boff) + nsb; am.nc_ptr = in.cprefix + T;
+    am.changed = r.changed; am.ambig = r.ambig; am.rec_cnt = P<uint32_t>(h->rv_cand_cnt); am.t_nops = sd.t_nops; am.T = T; am.passes = NP;
     {
         Timer tm(h, CTK_K_COUNT);
         if (h->last_nlab <= 1000000)                  // (the previous pass' id count: a slab of the same kind)
@@ -1679,7 +1735,6 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     const int64_t nlab = m[CTK_AM_NLAB];
     if (nlab > 0x7ffffffell) return ctk_set_error(CTK_E_RANGE, "%lld ids do not fit the int32 flag variable", (long long)nlab);
     if (NP > 0) h->async_passes = std::max<int>(CTK_JACOBI_ROUND, (int)m[CTK_AM_CONV] + 2);
-    h->nd_hint = std::max<uint32_t>(m[CTK_AM_ND], 1024);
     h->op_cap_hint = std::max<uint32_t>(h->op_cap_hint, cnt[CTK_CNT_NOPS] * 2 + 1024);
     h->nops = (int32_t)cnt[CTK_CNT_NOPS];
     h->last_nlab = nlab;

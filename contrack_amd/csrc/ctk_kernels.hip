@@ -358,7 +358,7 @@ __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v)
 // base_ptr (time shards): the scan starts at *base_ptr (the number of halo components) and out[-1] = 0
 __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ in, int64_t n,
                                                    uint32_t *__restrict__ out, uint32_t *ovf, uint32_t *mail = nullptr,
-                                                   const uint32_t *base_ptr = nullptr)
+                                                   const uint32_t *base_ptr = nullptr, uint32_t stamp = 0 /* written to mail[4] after the rest: the host polls for it */)
 {
     __shared__ uint64_t wsum[16];
     __shared__ uint32_t wmax[16];
@@ -389,6 +389,7 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ 
             uint32_t m = 0;
             for (int i = 0; i < 16; i++) m = max(m, wmax[i]);
             mail[0] = (uint32_t)run; mail[1] = m; mail[2] = run > 0xffffffffull ? CTK_OVF_RUNS : 0u; mail[3] = n > 0 ? in[n - 1] : 0u;
+            if (stamp) { __threadfence_system(); __hip_atomic_store(&mail[4], stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
         }
     }
 }
@@ -708,6 +709,60 @@ __global__ __launch_bounds__(256) void k_compact_comps(const uint32_t *__restric
     }
 }
 
+// Fused one-call path: the same compaction with (a) the component prefix computed by the workgroup itself -- the sum of the
+// component counts of the timesteps in front of it, T^2 / 2 cached loads in all instead of a scan launch -- and (b) the resolver's
+// per-component work arrays initialised on the way (k_rs_init and the second half of k_rs_pairs): one launch instead of four.
+struct CompInit {
+    int64_t *F, *B;                 // [NC][2]
+    uint8_t *keep0, *keep1;
+    uint32_t *touch, *parent;
+    uint32_t *changed;              // [(passes + 1) * 64]
+    uint32_t *ambig;
+    uint32_t *pstate;               // [(T + 1) * stride] or nullptr
+    const int32_t *next_tiny;       // [ny + 1]
+    int nchanged, pstride;
+    int64_t T;
+};
+__global__ __launch_bounds__(256) void k_compact_init(const uint32_t *__restrict__ run_base, const uint32_t *__restrict__ ncomp,
+                                                      uint32_t *__restrict__ cprefix, const uint32_t *__restrict__ cs_mrep,
+                                                      const uint32_t *__restrict__ cs_box, const int64_t *__restrict__ cs_area,
+                                                      uint32_t *__restrict__ d_mrep, uint16_t *__restrict__ d_box,
+                                                      int64_t *__restrict__ d_area, uint32_t *__restrict__ d_comp_t, CompInit ci)
+{
+    const int t = (int)blockIdx.x, tid = (int)threadIdx.x;
+    __shared__ uint32_t sm[8];
+    uint32_t s = 0;
+    for (int u = tid; u < t; u += 256) s += ncomp[u];
+    uint32_t cb;
+    (void)block_excl_scan(s, sm, &cb);
+    const uint32_t n = ncomp[t], rb = run_base[t];
+    if (tid == 0) { cprefix[t] = cb; if (t == ci.T - 1) cprefix[ci.T] = cb + n; }
+    for (uint32_t c = tid; c < n; c += 256) {
+        const uint32_t g = cb + c;
+        d_mrep[g] = cs_mrep[rb + c];
+        for (int k = 0; k < 4; k++) d_box[(int64_t)g * 4 + k] = (uint16_t)cs_box[(int64_t)(rb + c) * 4 + k];
+        d_area[(int64_t)g * 2] = cs_area[(int64_t)(rb + c) * 2];
+        d_area[(int64_t)g * 2 + 1] = cs_area[(int64_t)(rb + c) * 2 + 1];
+        d_comp_t[g] = (uint32_t)t;
+        ci.F[2 * (int64_t)g] = 0; ci.F[2 * (int64_t)g + 1] = 0;
+        ci.B[2 * (int64_t)g] = 0; ci.B[2 * (int64_t)g + 1] = 0;
+        ci.keep0[g] = 1; ci.keep1[g] = 1;
+        ci.touch[g] = 0;
+        ci.parent[g] = g;
+    }
+    __syncthreads();
+    // seam-merged components that hold a row with very low weight bits (ResolveDev::next_tiny): flag at the representative
+    for (uint32_t c = tid; c < n; c += 256) {
+        const uint32_t y0 = cs_box[(int64_t)(rb + c) * 4], y1 = cs_box[(int64_t)(rb + c) * 4 + 1];
+        if (ci.next_tiny[y0] <= (int32_t)y1) ci.touch[cb + cs_mrep[rb + c]] = 1u;
+    }
+    if (t == 0) {
+        for (int i = tid; i < ci.nchanged; i += 256) ci.changed[i] = 0u;
+        if (tid == 0) *ci.ambig = 0u;
+    }
+    if (ci.pstate && tid == 0) { ci.pstate[(size_t)t * ci.pstride] = 0u; if (t == ci.T - 1) ci.pstate[(size_t)ci.T * ci.pstride] = 0u; }
+}
+
 // dense (t, y)-ordered seam records from the row-indexed scratch
 __global__ __launch_bounds__(256) void k_compact_seams(const CtkSeam *__restrict__ scratch, const uint32_t *__restrict__ seam_cnt,
                                                        const uint32_t *__restrict__ seam_off, int ny, CtkSeam *__restrict__ out)
@@ -748,15 +803,31 @@ struct OverlapArgs {
                                    // (pairs[pair_cap-1-i]), counted by CTK_CNT_UPAIRS
     const int64_t *wlo, *whi;
     int ny, nx, W;
+    // fused one-call path: what k_rs_pairs derives from every record is written with the record -- dense ids of both components
+    // and of their seam-merged representatives, and the forward overlap of the EARLIER component (contrack.py:718) added to F
+    // (zeroed by k_compact_init).  nullptr: k_rs_pairs does it.
+    const uint32_t *cprefix, *mrep;
+    uint32_t *p_rc, *p_rd, *p_gc, *p_gd;
+    int64_t *F;
 };
 
-__device__ __forceinline__ void emit_pair(const OverlapArgs &a, uint32_t t, uint32_t c, uint32_t d, int64_t lo, int64_t hi)
+__device__ __forceinline__ void pair_prepare(const OverlapArgs &a, uint32_t slot, uint32_t cb, uint32_t db, uint32_t c, uint32_t d, int64_t lo, int64_t hi)
+{
+    const uint32_t gc = cb + c, gd = db + d;
+    const uint32_t rd = db + a.mrep[gd];
+    a.p_gc[slot] = gc; a.p_gd[slot] = gd; a.p_rc[slot] = cb + a.mrep[gc]; a.p_rd[slot] = rd;
+    atomicAdd((unsigned long long *)&a.F[2 * (int64_t)rd], (unsigned long long)lo);
+    atomicAdd((unsigned long long *)&a.F[2 * (int64_t)rd + 1], (unsigned long long)hi);
+}
+
+__device__ __forceinline__ void emit_pair(const OverlapArgs &a, uint32_t t, uint32_t c, uint32_t d, int64_t lo, int64_t hi, uint32_t cb = 0, uint32_t db = 0)
 {
     uint32_t i = atomicAdd(&a.counters[CTK_CNT_UPAIRS], 1u);
     if (i < a.pair_cap) {
         CtkPair p;
         p.t = t; p.c = c; p.d = d; p.pad = 0; p.lo = lo; p.hi = hi;
         a.pairs[a.pair_cap - 1u - i] = p;
+        if (a.p_rc) pair_prepare(a, a.pair_cap - 1u - i, cb, db, c, d, lo, hi);
     } else atomicOr(&a.counters[CTK_CNT_OVERFLOW], CTK_OVF_PAIRS);
 }
 
@@ -769,6 +840,8 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
     }
     const int tid = (int)threadIdx.x;
     const int ny = a.ny, W = a.W;
+    // (fused path: the component prefixes of t and t-1, needed when the table is flushed -- requested now, used then)
+    const uint32_t cbc = a.p_rc ? a.cprefix[t] : 0u, cbd = a.p_rc ? a.cprefix[t - 1] : 0u;
     __shared__ unsigned long long hkey[CTK_HASH_SLOTS];
     __shared__ long long hlo[CTK_HASH_SLOTS], hhi[CTK_HASH_SLOTS];
     __shared__ uint32_t sm_scan[8];
@@ -807,7 +880,7 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
             }
             h = (h + 1) & (CTK_HASH_SLOTS - 1);
         }
-        emit_pair(a, (uint32_t)t, cc, cd, lo, hi);
+        emit_pair(a, (uint32_t)t, cc, cd, lo, hi, cbc, cbd);
     };
     for (int i0 = tid; i0 < nwords; i0 += 256 * OVB) {
         uint64_t c[OVB], p[OVB], cl[OVB], pl[OVB];
@@ -881,6 +954,7 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
                 p.t = (uint32_t)t; p.c = (uint32_t)(hkey[i] >> 32); p.d = (uint32_t)hkey[i]; p.pad = 0;
                 p.lo = hlo[i]; p.hi = hhi[i];
                 a.pairs[j] = p;
+                if (a.p_rc) pair_prepare(a, j, cbc, cbd, p.c, p.d, p.lo, p.hi);
             }
             j++;
         }
@@ -1336,11 +1410,10 @@ struct AsyncMail {
     uint32_t *scal;                 // nullptr: not the fused path
     const uint32_t *nlab_ptr;       // number of fresh 3-D labels (= ids to count; n_labels is then only the offset of ext's second half)
     const uint32_t *nc_ptr;         // cprefix[T]
-    const uint32_t *dcount;         // candidate labels
     const uint32_t *changed;        // [passes][CTK_CHG_SLOTS]
     const uint32_t *ambig;
     const uint32_t *rec_cnt;        // [T] candidate group records per timestep
-    const uint32_t *cl_nops;        // [dcount] relabel operations per cluster root
+    const uint32_t *t_nops;         // [T] relabel operations of the clusters that start in timestep t
     int64_t T;
     int passes;
 };
@@ -1365,7 +1438,6 @@ __device__ inline void async_mail_write(const AsyncMail &m, const uint32_t *coun
     else if (lane < CTK_CNT_N) { v = __hip_atomic_load(&counters[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); has = true; }
     else if (lane == CTK_AM_NC) { v = *m.nc_ptr; has = true; }
     else if (lane == CTK_AM_NLAB) { v = *m.nlab_ptr; has = true; }
-    else if (lane == CTK_AM_ND) { v = *m.dcount; has = true; }
     else if (lane == CTK_AM_NCAND) { v = ncand; has = true; }
     else if (lane == CTK_AM_AMBIG) { v = *m.ambig; has = true; }
     else if (lane == CTK_AM_DONE) { v = 1u; has = true; }
@@ -1410,8 +1482,7 @@ __global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__
         uint32_t nc = 0, no = 0;
         if (threadIdx.x < 64) {
             for (int64_t t = threadIdx.x; t < am.T; t += 64) nc += am.rec_cnt[t];
-            const uint32_t nd = *am.dcount;
-            for (uint32_t d = threadIdx.x; d < nd; d += 64) no += am.cl_nops[d];
+            for (int64_t t = threadIdx.x; t < am.T; t += 64) no += am.t_nops[t];
             nc = wave_sum_u32(nc); no = wave_sum_u32(no);
         }
         async_mail_write(am, counters, nc, no);
@@ -1429,8 +1500,7 @@ __global__ __launch_bounds__(1024) void k_count_alive_1(const int32_t *__restric
     uint32_t v = 0, nc = 0, no = 0;
     if (am.scal) {
         for (int64_t t = threadIdx.x; t < am.T; t += 1024) nc += am.rec_cnt[t];
-        const uint32_t nd = *am.dcount;
-        for (uint32_t d = threadIdx.x; d < nd; d += 1024) no += am.cl_nops[d];
+        for (int64_t t = threadIdx.x; t < am.T; t += 1024) no += am.t_nops[t];
     }
     const int64_t nl = am.scal ? (int64_t)*am.nlab_ptr : n_labels;
     for (int64_t l = threadIdx.x + 1; l <= nl; l += 1024) {

@@ -68,9 +68,10 @@ struct ResolveDev {
     uint32_t *amb_cnt, *amb_list;
     uint32_t amb_cap;
     // fused one-call path (no host hand-off, ctk_seam_dev.hip); all nullptr elsewhere
-    uint32_t *cl_parent;                  // [dense] clusters of candidate labels that share seam rows: union-find over dense ids
-    int32_t *cl_tmin, *cl_tmax;           // [dense] at cluster roots: timesteps that hold records of the cluster
-    uint32_t *cl_nops;                    // [dense] operations of the cluster (k_seam_driver)
+    uint32_t *cl_parent;                  // [labels + 1] clusters of labels that share seam rows: union-find (reset here, k_rs_roots)
+    int32_t *cl_tmin, *cl_tmax;           // [labels + 1] at cluster roots: timesteps that hold records of the cluster
+    uint32_t *cl_nops;                    // [labels + 1] operations of the cluster (k_seam_driver)
+    int32_t *lbox;                        // [labels + 1][6] boxes of the marked labels (k_fz_groups)
     int32_t *ext;                         // time extents of the ids, reset by k_rs_roots: ext[l] = min t, ext[ext_off + l] = max t
     int64_t ext_off;
     uint32_t *counters_w;                 // the write-stage counters are reset by k_rs_roots as well
@@ -111,6 +112,8 @@ __device__ __forceinline__ const CtkPair &pair_at(const ResolveDev &r, uint32_t 
 {
     return k < ng ? r.pairs[k] : r.pairs[r.pair_cap - 1u - (k - ng)];
 }
+// index of pair record k (0 <= k < ng + nu) in the pair arrays p_rc / p_rd / p_gc / p_gd: where the record itself sits
+__device__ __forceinline__ uint32_t pair_slot(const ResolveDev &r, uint32_t k, uint32_t ng) { return k < ng ? k : r.pair_cap - 1u - (k - ng); }
 __device__ __forceinline__ uint32_t dev_ncomps(const ResolveDev &r) { return r.cprefix[r.T]; }
 
 // exact limb sums -> float64, rounded once to nearest-even (identical to limbs_to_double in ctk_resolve.cpp)
@@ -162,13 +165,14 @@ __global__ void k_rs_parent_init(ResolveDev r)
 
 __global__ void k_rs_pairs(ResolveDev r)
 {
-    const uint32_t np = dev_npairs(r), ng = dev_ngrouped(r);
+    const uint32_t np = dev_npairs(r), ng = dev_ngrouped(r);     // (the fused path does all of this in k_overlap / k_compact_init)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
         const CtkPair p = pair_at(r, i, ng);
         const uint32_t cb = r.cprefix[p.t], db = r.cprefix[(int32_t)p.t - 1];       // (timestep -1: the halo of a time shard)
         const uint32_t gc = cb + p.c, gd = db + p.d;
         const uint32_t rc = cb + r.mrep[gc], rd = db + r.mrep[gd];
-        r.p_gc[i] = gc; r.p_gd[i] = gd; r.p_rc[i] = rc; r.p_rd[i] = rd;
+        const uint32_t q = pair_slot(r, i, ng);
+        r.p_gc[q] = gc; r.p_gd[q] = gd; r.p_rc[q] = rc; r.p_rd[q] = rd;
         // forward overlap of the EARLIER component: plane t is unfiltered when t-1 is visited (contrack.py:718)
         atomicAdd((unsigned long long *)&r.F[2 * (int64_t)rd], (unsigned long long)p.lo);
         atomicAdd((unsigned long long *)&r.F[2 * (int64_t)rd + 1], (unsigned long long)p.hi);
@@ -274,12 +278,11 @@ __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint
         atomicAdd((unsigned long long *)&B[2 * c + 1], (unsigned long long)p.hi);
     }
     if (nu) {                                                   // records that bypassed the hash table (rare)
-        const uint32_t ng = dev_ngrouped(r);
         for (uint32_t i = lane; i < nu; i += 64) {
             const CtkPair p = r.pairs[r.pair_cap - 1u - i];
             if ((int)p.t != t) continue;
-            if (!__hip_atomic_load(&keep[r.p_rd[ng + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
-            const uint32_t c = r.p_rc[ng + i] - cb;
+            if (!__hip_atomic_load(&keep[r.p_rd[r.pair_cap - 1u - i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+            const uint32_t c = r.p_rc[r.pair_cap - 1u - i] - cb;
             atomicAdd((unsigned long long *)&B[2 * c], (unsigned long long)p.lo);
             atomicAdd((unsigned long long *)&B[2 * c + 1], (unsigned long long)p.hi);
         }
@@ -413,12 +416,11 @@ __global__ __launch_bounds__(64) void k_rs_pass_sys(ResolveDev r, int it0, int K
                 atomicAdd((unsigned long long *)&B[2 * c + 1], (unsigned long long)p.hi);
             }
             if (nu) {                                                   // records that bypassed the hash table (rare)
-                const uint32_t ng = dev_ngrouped(r);
                 for (uint32_t i = lane; i < nu; i += 64) {
                     const CtkPair p = r.pairs[r.pair_cap - 1u - i];
                     if ((int)p.t != t) continue;
-                    if (!__hip_atomic_load(&keep[r.p_rd[ng + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
-                    const uint32_t c = r.p_rc[ng + i] - cb;
+                    if (!__hip_atomic_load(&keep[r.p_rd[r.pair_cap - 1u - i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+                    const uint32_t c = r.p_rc[r.pair_cap - 1u - i] - cb;
                     atomicAdd((unsigned long long *)&B[2 * c], (unsigned long long)p.lo);
                     atomicAdd((unsigned long long *)&B[2 * c + 1], (unsigned long long)p.hi);
                 }
@@ -493,8 +495,9 @@ __device__ __forceinline__ uint32_t gfind(uint32_t *p, uint32_t i)
 
 __global__ void k_rs_unite(ResolveDev r)
 {
-    const uint32_t np = dev_npairs(r);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
+    const uint32_t np = dev_npairs(r), ng = dev_ngrouped(r);
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < np; k += gridDim.x * blockDim.x) {
+        const uint32_t i = pair_slot(r, k, ng);
         if (!r.keep0[r.p_rc[i]] || !r.keep0[r.p_rd[i]]) continue;
         uint32_t a = r.p_gc[i], b = r.p_gd[i];
         for (;;) {
@@ -527,6 +530,12 @@ __global__ __launch_bounds__(256) void k_rs_roots(ResolveDev r, uint32_t *__rest
         r.dmap[g + 1] = 0;
         r.op_first[g + 1] = -1;
         if (g == 0) { *r.dcount = 0; r.op_first[0] = -1; }
+        if (r.cl_parent) {                                  // fused one-call path: label-indexed tables of the device seam driver
+            const uint32_t l = g + 1u;
+            r.cl_parent[l] = l; r.cl_tmin[l] = INT32_MAX; r.cl_tmax[l] = -1; r.cl_nops[l] = 0xffffffffu;
+            int32_t *b = r.lbox + 6 * (int64_t)l;
+            b[0] = INT32_MAX; b[1] = -1; b[2] = INT32_MAX; b[3] = -1; b[4] = INT32_MAX; b[5] = -1;
+        }
         if (r.ext) {                                        // fused one-call path: what k_ops_ingest / k_fill_ext do elsewhere
             r.ext[g + 1] = INT32_MAX; r.ext[r.ext_off + g + 1] = INT32_MIN;
             if (g == 0) {
@@ -621,7 +630,6 @@ __device__ inline void cand_publish(const ResolveDev &r, int32_t l, uint32_t id)
     r.dorig[id] = l;
     int32_t *d = r.dbox + 6 * (int64_t)id;                // box of the label (find_objects ONCE, contrack.py:753): filled
     d[0] = INT32_MAX; d[1] = -1; d[2] = INT32_MAX; d[3] = -1; d[4] = INT32_MAX; d[5] = -1;    // by k_rs_cand_groups
-    if (r.cl_parent) { r.cl_parent[id] = id; r.cl_tmin[id] = INT32_MAX; r.cl_tmax[id] = -1; r.cl_nops[id] = 0u; }
     r.dmap[l] = id + 1;                                   // read by later launches
 }
 
@@ -730,21 +738,7 @@ __global__ __launch_bounds__(64) void k_rs_cand_groups(ResolveDev r, const CtkSe
         const uint64_t S = __ballot(start), V = __ballot(valid);
         const uint64_t upto = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
         const uint32_t idx = ng + (uint32_t)__popcll(S & upto) - 1u;          // record of this row's group
-        if (start) {
-            CtkCand g; g.t = tt; g.yy = y | (y << 16); g.ll = v.x; g.lr = v.y; dst[idx] = g;
-            if (r.cl_parent && v.x != v.y) {                 // the two labels belong to one cluster of the seam driver
-                uint32_t a = r.dmap[v.x] - 1u, b = r.dmap[v.y] - 1u;
-                for (;;) {
-                    a = gfind(r.cl_parent, a);
-                    b = gfind(r.cl_parent, b);
-                    if (a == b) break;
-                    if (a < b) { const uint32_t s = a; a = b; b = s; }
-                    const uint32_t old = atomicMin(&r.cl_parent[a], b);
-                    if (old == a) break;
-                    a = old;
-                }
-            }
-        }
+        if (start) { CtkCand g; g.t = tt; g.yy = y | (y << 16); g.ll = v.x; g.lr = v.y; dst[idx] = g; }
         // the previous step's last row ended its group if this step's first row does not continue it
         if (lane == 0 && c_valid && (!valid || start)) reinterpret_cast<uint16_t *>(&dst[ng - 1u].yy)[1] = (uint16_t)c_y;
         if (valid && lane < 63) {

@@ -16,29 +16,29 @@
 #pragma once
 
 #define SD_LAB 64            // labels of one cluster (one per lane: the slot search is a ballot)
-#define SD_OPS_OWN 8         // op slots every candidate label id owns (clusters with more: shared tail)
+#define SD_OPS_OWN 8         // op slots every label id owns (clusters with more: shared tail)
 #define CTK_POISON_OPCAP   1u    // more operations than the op arrays hold
-#define CTK_POISON_CLUSTER 2u    // a cluster with more labels / operations than the LDS tables hold
-#define CTK_POISON_TABLES  4u    // the co-occurrence table overflowed (k_overlap)
-#define CTK_POISON_DENSE   8u    // more candidate labels than the dense tables hold
+#define CTK_POISON_CLUSTER 2u    // a cluster with more labels / operations than the driver's per-cluster tables hold
 
+// Everything is indexed by the FRESH 3-D label itself (ids <= components): no dense renumbering of the candidate labels, hence
+// no claim counter -- a counter that every claiming wave of eight XCDs adds to costs ~80 ns per add.
 struct SeamDev {
-    uint32_t *cl_parent;           // [dense] union-find over dense label ids (init: cand_publish)
-    int32_t *cl_tmin, *cl_tmax;    // [dense] at cluster roots: local timesteps that hold records of the cluster
+    const ResolveDev *dummy;       // (unused; keeps the layout explicit)
+    uint32_t *cl_parent;           // [labels + 1] union-find over labels that share seam rows (init: k_rs_roots; unions: k_fz_mark)
+    int32_t *cl_tmin, *cl_tmax;    // [labels + 1] at cluster roots: local timesteps that hold records of the cluster
+    uint32_t *cl_nops;             // [labels + 1] claim word of a cluster root (0xffffffff: nobody drives the cluster yet)
+    uint32_t *t_nops;              // [T] operations of the clusters whose first record sits in timestep t (the count kernel adds them up)
+    int32_t *lbox;                 // [labels + 1][6] box of every marked label on the fresh labelling (find_objects ONCE, contrack.py:753)
+    uint8_t *mark;                 // [labels + 1] label occurs in a seam row with two different labels
     uint32_t *rec_root;            // [T][ny] cluster root of every group record
-    CtkCand *recs;                 // [T][ny] group records (k_rs_cand_groups' scratch); labels become dense ids in k_seam_clusters
-    const uint32_t *rec_cnt;       // [T]
-    const uint32_t *dcount;        // number of dense ids
-    const int32_t *dorig, *dbox;   // [dense], [dense][6]
-    const uint32_t *dmap;          // [labels + 1]
+    CtkCand *recs;                 // [T][ny] group records, row-indexed scratch (labels = fresh labels)
+    uint32_t *rec_cnt;             // [T]
     CtkOp *ops;                    // [op_cap] out
     int32_t *op_next;              // [op_cap]
     int32_t *op_first;             // [labels + 1] (reset to -1 by k_rs_roots)
     uint32_t *op_count;            // operations placed in the shared tail of the op arrays
-    uint32_t *cl_nops;             // [dense] at cluster roots: operations of the cluster (the count kernel adds them up)
     uint32_t op_cap;               // slots of ops / op_next: own_ids * SD_OPS_OWN + shared tail
-    uint32_t own_ids;              // cluster roots below this id own SD_OPS_OWN slots each
-    uint32_t dense_cap;
+    uint32_t own_ids;              // cluster roots below this label own SD_OPS_OWN slots each
     uint32_t *poison;
     int ny, nx;
     int64_t T;
@@ -46,22 +46,111 @@ struct SeamDev {
     int lab_cap, ops_cap;          // labels / operations of one cluster (<= 64; a test hook lowers them)
 };
 
-__global__ __launch_bounds__(64) void k_seam_clusters(SeamDev a)
+// fresh labels of the two seam pixels of every seam row; labels that meet a different label on a row are marked (only they can
+// ever take part in an operation) and united into one cluster
+__global__ __launch_bounds__(64) void k_fz_mark(ResolveDev r, SeamDev a, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
+                                                const uint32_t *__restrict__ seam_off, int2 *__restrict__ res)
 {
-    if (*a.poison) return;
+    if (dev_tables_bad(r)) return;
     const int t = (int)blockIdx.x, lane = (int)threadIdx.x;
-    const uint32_t n = a.rec_cnt[t];
-    for (uint32_t i = lane; i < n; i += 64) {
-        CtkCand c = a.recs[(int64_t)t * a.ny + i];
-        const uint32_t dl = a.dmap[c.ll] - 1u, dr = a.dmap[c.lr] - 1u;
-        const uint32_t root = gfind(a.cl_parent, dl);
-        c.ll = (int32_t)dl; c.lr = (int32_t)dr;
-        a.recs[(int64_t)t * a.ny + i] = c;
-        a.rec_root[(int64_t)t * a.ny + i] = root;
-        // look first: same-address atomics serialise.  Device-scope loads: the L2s of the eight XCDs are not coherent with each
-        // other, a plain load would keep returning the bound this XCD saw first.
-        if (t < __hip_atomic_load(&a.cl_tmin[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&a.cl_tmin[root], t);
-        if (t > __hip_atomic_load(&a.cl_tmax[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.cl_tmax[root], t);
+    const uint32_t n = seam_cnt[t], cb = r.cprefix[t];
+    const CtkSeam *scratch = seams + seam_off[t];
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        int2 v = make_int2(-1, -1);
+        if (i < n) {
+            const CtkSeam q = scratch[i];
+            if (r.keep0[cb + r.mrep[cb + q.cl]]) { v.x = r.lab[cb + q.cl]; v.y = r.lab[cb + q.cr]; }
+            res[(int64_t)t * a.ny + i] = v;
+        }
+        const int px = __shfl_up(v.x, 1), py = __shfl_up(v.y, 1);
+        if (v.x >= 0 && v.x != v.y && !(lane > 0 && px == v.x && py == v.y)) {      // first row of a stretch with this pair
+            a.mark[v.x] = 1; a.mark[v.y] = 1;
+            uint32_t p = (uint32_t)v.x, q = (uint32_t)v.y;
+            for (;;) {
+                p = gfind(a.cl_parent, p);
+                q = gfind(a.cl_parent, q);
+                if (p == q) break;
+                if (p < q) { const uint32_t s = p; p = q; q = s; }
+                const uint32_t old = atomicMin(&a.cl_parent[p], q);
+                if (old == p) break;
+                p = old;
+            }
+        }
+    }
+}
+
+// k_rs_cand_groups for the fused path: boxes of the marked labels, surviving seam rows run-length grouped, and for every group
+// record the root of its cluster and the cluster's range of timesteps (the unions are complete: k_fz_mark is a launch of its own)
+__global__ __launch_bounds__(64) void k_fz_groups(ResolveDev r, SeamDev a, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
+                                                  const uint32_t *__restrict__ seam_off, const int2 *__restrict__ res, int64_t t_begin)
+{
+    if (dev_tables_bad(r)) return;
+    const int64_t t = blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    const int ny = a.ny;
+    const uint32_t cb = r.cprefix[t], nct = r.cprefix[t + 1] - cb;
+    const int32_t tt = (int32_t)(t_begin + t);
+    for (uint32_t c = lane; c < nct; c += 64) {
+        const uint32_t g = cb + c;
+        const int32_t l = r.lab[g];
+        if (l <= 0 || !a.mark[l]) continue;
+        int32_t *b = a.lbox + 6 * (int64_t)l;
+        const uint16_t *q = r.box + 4 * (int64_t)g;
+        // look first (device-scope loads: the L2s of the XCDs are not coherent with each other); a stale bound is only looser
+        const int32_t b0 = __hip_atomic_load(&b[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b1 = __hip_atomic_load(&b[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t b2 = __hip_atomic_load(&b[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b3 = __hip_atomic_load(&b[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t b4 = __hip_atomic_load(&b[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b5 = __hip_atomic_load(&b[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tt < b0) atomicMin(&b[0], tt);
+        if (tt > b1) atomicMax(&b[1], tt);
+        if ((int32_t)q[0] < b2) atomicMin(&b[2], (int32_t)q[0]);
+        if ((int32_t)q[1] > b3) atomicMax(&b[3], (int32_t)q[1]);
+        if ((int32_t)q[2] < b4) atomicMin(&b[4], (int32_t)q[2]);
+        if ((int32_t)q[3] > b5) atomicMax(&b[5], (int32_t)q[3]);
+    }
+    const uint32_t n = seam_cnt[t];
+    const CtkSeam *sc = seams + seam_off[t];
+    const int2 *rs = res + t * ny;
+    CtkCand *dst = a.recs + t * ny;                        // at most one group per seam row
+    uint32_t ng = 0;
+    bool c_valid = false;
+    int32_t c_ll = 0, c_lr = 0, c_y = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        int2 v = make_int2(-1, -1);
+        int32_t y = 0;
+        if (i < n) {
+            v = rs[i];
+            if (v.x >= 0 && v.x == v.y && !a.mark[v.x]) v.x = -1;      // can never take part in an op
+            y = (int32_t)sc[i].y;
+        }
+        const bool valid = v.x >= 0;
+        int32_t pll = __shfl_up(v.x, 1), plr = __shfl_up(v.y, 1), py = __shfl_up(y, 1);
+        bool pvalid = pll >= 0;
+        if (lane == 0) { pll = c_ll; plr = c_lr; py = c_y; pvalid = c_valid; }
+        const bool start = valid && !(pvalid && pll == v.x && plr == v.y && y == py + 1);
+        const uint64_t S = __ballot(start), V = __ballot(valid);
+        const uint64_t upto = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+        const uint32_t idx = ng + (uint32_t)__popcll(S & upto) - 1u;          // record of this row's group
+        if (start) {
+            CtkCand g; g.t = tt; g.yy = y | (y << 16); g.ll = v.x; g.lr = v.y; dst[idx] = g;
+            const uint32_t root = gfind(a.cl_parent, (uint32_t)v.x);
+            a.rec_root[t * ny + idx] = root;
+            if ((int32_t)t < __hip_atomic_load(&a.cl_tmin[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&a.cl_tmin[root], (int32_t)t);
+            if ((int32_t)t > __hip_atomic_load(&a.cl_tmax[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.cl_tmax[root], (int32_t)t);
+        }
+        if (lane == 0 && c_valid && (!valid || start)) reinterpret_cast<uint16_t *>(&dst[ng - 1u].yy)[1] = (uint16_t)c_y;
+        if (valid && lane < 63) {
+            const bool next_valid = (V >> (lane + 1)) & 1ull, next_start = (S >> (lane + 1)) & 1ull;
+            if ((!next_valid || next_start) && !start) reinterpret_cast<uint16_t *>(&dst[idx].yy)[1] = (uint16_t)y;
+        }
+        ng += (uint32_t)__popcll(S);
+        c_valid = (V >> 63) & 1ull;
+        c_ll = __shfl(v.x, 63); c_lr = __shfl(v.y, 63); c_y = __shfl(y, 63);
+    }
+    if (lane == 0) {
+        if (c_valid) reinterpret_cast<uint16_t *>(&dst[ng - 1u].yy)[1] = (uint16_t)c_y;
+        a.rec_cnt[t] = ng;
     }
 }
 
@@ -96,13 +185,37 @@ __global__ __launch_bounds__(64) void k_seam_driver(SeamDev a, int64_t t_begin)
     if (*a.poison) return;
     __shared__ CtkCand brec[SD_BATCH];
     const int lane = (int)threadIdx.x;
-    const uint32_t nd = min(*a.dcount, a.dense_cap);
-    for (uint32_t R = blockIdx.x; R < nd; R += gridDim.x) {
-        const uint32_t par = a.cl_parent[R];
-        const int32_t tmin = a.cl_tmin[R], tmax = a.cl_tmax[R];            // (one round trip for the three)
-        if (par != R || tmax < tmin) continue;                             // not a cluster root / a boundary label without records
+    // A cluster is driven by the workgroup of the FIRST timestep that holds one of its records (its "home"): the records of a
+    // timestep are few, the clusters spread evenly over the timesteps, and nothing has to be scanned for roots.  The lane whose
+    // record wins the claim word of the root (cl_nops: 0xffffffff = unclaimed) brings the cluster in.
+    for (int32_t th = (int32_t)blockIdx.x; th < (int32_t)a.T; th += (int32_t)gridDim.x) {
+      const uint32_t nrec = a.rec_cnt[th];
+      uint32_t home_ops = 0;
+      for (uint32_t i0 = 0; i0 < nrec; i0 += 64) {
+      const uint32_t irec = i0 + lane;
+      bool isr = false;
+      uint32_t my_root = 0;
+      int32_t my_tmax = -1;
+      if (irec < nrec) {
+          my_root = a.rec_root[(int64_t)th * a.ny + irec];
+          const int32_t rt_min = a.cl_tmin[my_root];
+          my_tmax = a.cl_tmax[my_root];                                    // (requested together)
+          isr = rt_min == th;
+      }
+      if (nrec <= 64) {                                                    // the first record of its root in this timestep brings the cluster in
+          bool dup = false;
+          for (uint32_t j = 0; j + 1 < nrec; j++) { const uint32_t rj = (uint32_t)__shfl((int)my_root, (int)j); dup = dup || ((uint32_t)lane > j && rj == my_root); }
+          isr = isr && !dup;
+      } else if (isr) isr = atomicCAS(&a.cl_nops[my_root], 0xffffffffu, 0u) == 0xffffffffu;       // many records: a claim word per root
+      uint64_t roots = __ballot(isr);
+      while (roots) {
+        const int src = (int)__builtin_ctzll(roots);
+        roots &= roots - 1;
+        const uint32_t R = (uint32_t)SD_RL(my_root, src);
+        const int32_t tmin = th, tmax = SD_RL(my_tmax, src);
         if (a.dbg == 1) continue;
         int32_t o_hi = -1, o_lo = -1, o_t0 = 0, o_t1 = -1, o_y0 = 0, o_y1 = -1, o_x0 = 0, o_x1 = -1;      // operation `lane`
+        bool o_succ = false;                                               // a LATER operation has this one's `lo` as `hi`: a pixel it moved may move again
         int32_t l_id = -1, l_orig = 0, l_b0 = 0, l_b1 = 0, l_b2 = 0, l_b3 = 0, l_b4 = 0, l_b5 = 0;        // label slot `lane`
         int nl = 0, nops = 0;
         bool bad = false;
@@ -137,8 +250,9 @@ __global__ __launch_bounds__(64) void k_seam_driver(SeamDev a, int64_t t_begin)
                         // while y stays on the same side of their rows
                         const bool va = ca && lane < ka && below, vb = cb && lane < kb && below;
                         if (__ballot(va || vb)) yhi = min(yhi, sd_wave_min((va || vb) ? o_y0 - 1 : INT32_MAX));
-                        if (ka < 64) { yhi = min(yhi, SD_RL(o_y1, ka)); p0 = SD_RL(o_lo, ka); sa = ka + 1; } else ga = false;
-                        if (kb < 64) { yhi = min(yhi, SD_RL(o_y1, kb)); p1 = SD_RL(o_lo, kb); sb = kb + 1; } else gb = false;
+                        const uint64_t sm = __ballot(o_succ);
+                        if (ka < 64) { yhi = min(yhi, SD_RL(o_y1, ka)); p0 = SD_RL(o_lo, ka); sa = ka + 1; ga = (sm >> ka) & 1ull; } else ga = false;
+                        if (kb < 64) { yhi = min(yhi, SD_RL(o_y1, kb)); p1 = SD_RL(o_lo, kb); sb = kb + 1; gb = (sm >> kb) & 1ull; } else gb = false;
                         yhi = SD_U(yhi); p0 = SD_U(p0); p1 = SD_U(p1); sa = SD_U(sa); sb = SD_U(sb);
                     }
                 }
@@ -154,6 +268,7 @@ __global__ __launch_bounds__(64) void k_seam_driver(SeamDev a, int64_t t_begin)
                 if (nops >= a.ops_cap) { bad = true; return; }
                 const int32_t b0 = SD_RL(l_b0, hi), b1 = SD_RL(l_b1, hi), b2 = SD_RL(l_b2, hi), b3 = SD_RL(l_b3, hi), b4 = SD_RL(l_b4, hi), b5 = SD_RL(l_b5, hi);
                 if (lane == nops) { o_hi = hi; o_lo = lo; o_t0 = b0; o_t1 = b1; o_y0 = b2; o_y1 = b3; o_x0 = b4; o_x1 = b5; }
+                if (lane < nops && o_lo == hi) o_succ = true;
                 nops++;
                 tl = tl || hi == sl; tr = tr || hi == sr;
                 y++;                                                         // the next row sees the new op
@@ -211,8 +326,8 @@ __global__ __launch_bounds__(64) void k_seam_driver(SeamDev a, int64_t t_begin)
                 }
                 if (bad) break;
                 if (lane >= nl0 && lane < nl) {
-                    l_orig = a.dorig[l_id];
-                    const int32_t *bx = a.dbox + 6 * (int64_t)l_id;
+                    l_orig = l_id;                                          // (slots are keyed by the fresh label itself)
+                    const int32_t *bx = a.lbox + 6 * (int64_t)l_id;
                     l_b0 = bx[0]; l_b1 = bx[1]; l_b2 = bx[2]; l_b3 = bx[3]; l_b4 = bx[4]; l_b5 = bx[5];
                 }
                 if (a.dbg == 3) continue;
@@ -232,7 +347,7 @@ __global__ __launch_bounds__(64) void k_seam_driver(SeamDev a, int64_t t_begin)
         // The cluster's operations take a contiguous range of the op arrays (chain order = index order inside the cluster): the
         // first SD_OPS_OWN in the slots that belong to its root id, larger clusters a range of the shared tail.  (One counter for
         // all clusters: a thousand same-address atomics from eight XCDs, ~80 ns each -- 47 of this kernel's 54 us.)
-        a.cl_nops[R] = (uint32_t)nops;
+        home_ops += (uint32_t)nops;
         uint32_t base = R * SD_OPS_OWN;
         if (nops > SD_OPS_OWN || R >= a.own_ids) {
             if (lane == 0) base = a.own_ids * SD_OPS_OWN + atomicAdd(a.op_count, (uint32_t)nops);
@@ -254,5 +369,8 @@ __global__ __launch_bounds__(64) void k_seam_driver(SeamDev a, int64_t t_begin)
             a.op_next[base + lane] = nxt < 0 ? -1 : (int32_t)(base + (uint32_t)nxt);
         }
         if (lane < nl && fst >= 0) a.op_first[l_orig] = (int32_t)(base + (uint32_t)fst);
+      }
+      }
+      if (lane == 0) a.t_nops[th] = home_ops;
     }
 }
