@@ -35,6 +35,7 @@ WORKLOADS = {
 }
 WORKLOADS["era5_025deg_10yr"] = dict(T=14600, ny=721, nx=1440, threshold=160.0, gorl=">=", overlap=0.5, persistence=20, twosided=True,
                                      device_fill=True)      # BASELINE.json configs[2]: 60.6 GB in + 60.6 GB out, generated on the device
+WORKLOADS["era5_025deg_1k"] = dict(T=1000, ny=721, nx=1440, threshold=160.0, gorl=">=", overlap=0.5, persistence=20, twosided=True, device_fill=True)
 WORKLOADS["era5_025deg_2k"] = dict(T=2000, ny=721, nx=1440, threshold=160.0, gorl=">=", overlap=0.5, persistence=20, twosided=True, device_fill=True)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 

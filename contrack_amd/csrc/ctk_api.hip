@@ -61,6 +61,7 @@ enum State { ST_IDLE = 0, ST_LABELLED, ST_OVERLAPPED, ST_TABLES, ST_EXTENTS };
 }  // namespace
 
 #define CTK_KI_ROWCOUNT (CTK_K_COUNT + 1)
+#define CTK_PSLOT 128            // fused path: pair-record slots per timestep (k_overlap); a timestep with more spills to the ungrouped records
 
 // pinned (CPU-cacheable) bounce buffers of the host-array entries' device -> host copy (bounce_copy)
 struct BounceLane {
@@ -153,7 +154,9 @@ struct ctk_handle {
     int async_passes = CTK_JACOBI_ROUND;           // filter passes the next fused pass launches
     int use_async = -1;                            // -1: not decided (env CTK_ASYNC), 0 / 1
     int async_off_ny = -1, async_off_nx = -1;      // grid whose clusters did not fit the device seam driver: synchronous path from then on
+    uint32_t fz_pslot = 0;                         // k_overlap wrote the pair records into fixed per-timestep slots of this size
     bool fz_init = false;                          // k_compact_init ran (the resolver arrays are initialised), k_overlap prepared the pair arrays
+    bool in_one_call = false;                      // inside ctk_track_*_dev (the staged entries never take the fused path)
     bool guard_on = false;                         // kernels behind the resolver check the device counters before touching the tables
     // calc_anom / percentile (ctk_anom.hip): resident anomaly slab, climatology, scratch
     DevBuf an_out, an_clim, an_raw, an_idx;
@@ -605,7 +608,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     CTKCHK(ensure(h, h->cprefix, (size_t)(T + 2) * 4));                  // [-1] = 0: the halo components of a time shard come first
     CTKCHK(ensure(h, h->thr32, (size_t)T * 8));
     CTKCHK(ensure(h, h->wlo, w_bytes));                               // wlo[ny] whi[ny] next_tiny[ny+1] in one allocation
-    CTKCHK(ensure(h, h->counters, CTK_CNT_N * 4));
+    CTKCHK(ensure(h, h->counters, CTK_CNT_WORDS * 4));
     CTKCHK(ensure_host(&h->h_small, &h->h_small_cap, (size_t)(T + 1) * 4 + 1024));     // run_base copy + scalar downloads
 
     // (the device counters are zeroed by the first threshold launch of the pass; k_rowcount writes every tcount[t])
@@ -892,6 +895,12 @@ static int launch_overlap(ctk_handle *h)
     a.wlo = P<int64_t>(h->wlo); a.whi = P<int64_t>(h->wlo) + h->ny;
     a.ny = h->ny; a.nx = h->nx; a.W = h->W;
     a.cprefix = nullptr; a.mrep = nullptr; a.p_rc = nullptr; a.p_rd = nullptr; a.p_gc = nullptr; a.p_gd = nullptr; a.F = nullptr;
+    a.pslot = 0; a.upair_cap = h->pair_cap;
+    h->fz_pslot = 0;
+    if (h->fz_init && (uint64_t)h->T * CTK_PSLOT + 4096 <= (uint64_t)h->pair_cap) {
+        a.pslot = CTK_PSLOT; a.upair_cap = h->pair_cap - (uint32_t)(h->T * CTK_PSLOT);
+        h->fz_pslot = CTK_PSLOT;
+    }
     if (h->fz_init) {
         const size_t PC = h->pair_cap ? h->pair_cap : 1;
         CTKCHK(ensure(h, h->rv_prc, PC * 4)); CTKCHK(ensure(h, h->rv_prd, PC * 4)); CTKCHK(ensure(h, h->rv_pgc, PC * 4)); CTKCHK(ensure(h, h->rv_pgd, PC * 4));
@@ -899,7 +908,13 @@ static int launch_overlap(ctk_handle *h)
         a.p_rc = P<uint32_t>(h->rv_prc); a.p_rd = P<uint32_t>(h->rv_prd); a.p_gc = P<uint32_t>(h->rv_pgc); a.p_gd = P<uint32_t>(h->rv_pgd);
     }
     Timer tm(h, CTK_K_OVERLAP);
-    k_overlap<<<(int)h->T, 256, 0, h->stream>>>(a);
+    {
+        const int nwords = h->ny * h->W, per = (nwords + 255) / 256;                       // words per thread if one step is to cover all
+        if (per <= 4 || per > 8) k_overlap<4><<<(int)h->T, 256, 0, h->stream>>>(a);
+        else if (per == 5) k_overlap<5><<<(int)h->T, 256, 0, h->stream>>>(a);
+        else if (per == 6) k_overlap<6><<<(int)h->T, 256, 0, h->stream>>>(a);
+        else k_overlap<8><<<(int)h->T, 256, 0, h->stream>>>(a);
+    }
     HIPCHK(hipGetLastError());
     return CTK_OK;
 }
@@ -912,6 +927,7 @@ extern "C" int ctk_shard_overlap(ctk_handle *h)
     if (h->has_prev && (!h->halo_in.p || !h->halo_valid))
         return ctk_set_error(CTK_E_STATE, "ctk_shard_overlap: has_prev set but no halo imported since ctk_shard_label2d");
     size_t want = (size_t)h->total_runs / 2 + (size_t)h->T * 8 + 4096;
+    if (h->fz_init) want = std::max<size_t>(want, (size_t)h->T * CTK_PSLOT + (size_t)h->T * 8 + 8192);       // fixed slots per timestep + ungrouped
     if (want > 0x7fffffffull) want = 0x7fffffffull;
     if (h->pair_cap < want || !h->pairs.p) {
         CTKCHK(ensure(h, h->pairs, want * sizeof(CtkPair)));
@@ -1485,7 +1501,11 @@ static int relabel_rows(const ctk_handle *h)
 {
     const int n4r = std::max(1, h->nx / 4);
     int rb = std::min(h->ny, std::max(1, std::min(64, 1024 / n4r)));
-    if (h->T * ((h->ny + rb - 1) / rb) > 1000000) rb = std::min(h->ny, std::max(rb, std::min(64, 3072 / n4r)));
+    // Small chunks stop paying once there are more than ~200 000 of them: at 721 x 1440 a 2-row chunk costs 1.9 ns of kernel time
+    // at 480 timesteps (173 k chunks, 6.1 TB/s), 2.8 ns at 1000 and 3.2 ns at 2000 (722 k chunks, 3.6 TB/s), while 8-row chunks
+    // cost 8.4 ns apiece at every size measured (5.4 TB/s; round 3, `tools/gpu_r03h.sh`).  Up to 3072 stores per workgroup.
+    const int rb_max = std::min(h->ny, std::max(rb, std::min(64, 3072 / n4r)));
+    while (rb < rb_max && h->T * ((h->ny + rb - 1) / rb) > 200000) rb++;
     while (rb < h->ny && h->T * ((h->ny + rb - 1) / rb) >= (1 << 24)) rb++;
     if (getenv("CTK_RELABEL_ROWS")) rb = std::min(h->ny, std::max(1, atoi(getenv("CTK_RELABEL_ROWS"))));
     return rb;
@@ -1603,7 +1623,7 @@ extern "C" int ctk_shard_count_tracked(ctk_handle *h, int64_t *n_alive)
 static bool async_wanted(ctk_handle *h)
 {
     if (h->use_async < 0) { const char *e = getenv("CTK_ASYNC"); h->use_async = (e && atoi(e) == 0) ? 0 : 1; }
-    return h->use_async == 1 && !h->sio && h->T >= 1 && !(h->async_off_ny == h->ny && h->async_off_nx == h->nx);
+    return h->use_async == 1 && h->in_one_call && !h->sio && h->T >= 1 && !(h->async_off_ny == h->ny && h->async_off_nx == h->nx);
 }
 
 static int resolve_async(ctk_handle *h, double overlap, int twosided, int persistence, int32_t *flag_dev, int64_t *n_tracked)
@@ -1676,7 +1696,8 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
         else
             for (int it = 0; it < NP; it++)
                 k_rs_pass<<<(int)(T - 2), 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
-        k_rs_unite<<<gp, 256, 0, s>>>(r);
+        if (h->fz_pslot) k_rs_unite_slots<<<(int)std::min<int64_t>((T * h->fz_pslot + 255) / 256 + 1, 4096), 256, 0, s>>>(r, in.pair_cnt, h->fz_pslot);
+        else k_rs_unite<<<gp, 256, 0, s>>>(r);
         k_rs_roots<<<nsb, 256, 0, s>>>(r, P<uint32_t>(h->rv_bsum));
         if (nsb <= CTK_RL_BLOCKS) k_rs_rank_labels<<<nsb, 256, (size_t)nsb * 4, s>>>(r, P<uint32_t>(h->rv_bsum), (uint32_t)nsb, P<uint32_t>(h->rv_boff) + nsb);
         else {
@@ -1705,7 +1726,7 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     }
     AsyncMail am;
     am.scal = h->h_amail; am.nlab_ptr = P<uint32_t>(h->rv_boff) + nsb; am.nc_ptr = in.cprefix + T;
-    am.changed = r.changed; am.ambig = r.ambig; am.rec_cnt = P<uint32_t>(h->rv_cand_cnt); am.t_nops = sd.t_nops; am.T = T; am.passes = NP;
+    am.changed = r.changed; am.ambig = r.ambig; am.rec_cnt = P<uint32_t>(h->rv_cand_cnt); am.t_nops = sd.t_nops; am.pair_cnt = in.pair_cnt; am.T = T; am.passes = NP;
     {
         Timer tm(h, CTK_K_COUNT);
         if (h->last_nlab <= 1000000)                  // (the previous pass' id count: a slab of the same kind)
@@ -1723,6 +1744,7 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     const uint32_t *cnt = m + CTK_AM_COUNTERS;
     // ---- validation: anything the host would have seen at one of its (removed) hand-offs -----------------------------------
     if ((cnt[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) || (uint64_t)cnt[CTK_CNT_PAIRS] + cnt[CTK_CNT_UPAIRS] > in.pair_cap) return 1;      // (the synchronous path regrows the table)
+    const int64_t npairs_grouped = h->fz_pslot ? (int64_t)m[CTK_AM_NPAIRS] : (int64_t)cnt[CTK_CNT_PAIRS];
     if (NP > 0 && m[CTK_AM_CONV] == 0) { h->async_passes = std::min(CTK_MAX_JACOBI, NP * 2); return 1; }          // longer removal cascade than launched for
     if (m[CTK_AM_AMBIG]) return 1;                                                                               // decisions on rounding boundaries
     if (getenv("CTK_SD_DBG")) fprintf(stderr, "SDDBG max row steps %u, max fold iterations %u, max process time %.2f us, max cluster time %.2f us, fold cycles (clock64) %u\n", cnt[10], cnt[11], cnt[12] * 0.01, cnt[13] * 0.01, cnt[14]);
@@ -1739,7 +1761,7 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     h->nops = (int32_t)cnt[CTK_CNT_NOPS];
     h->last_nlab = nlab;
     h->total_comps = m[CTK_AM_NC];
-    h->stats[CTK_S_COMPONENTS] = m[CTK_AM_NC]; h->stats[CTK_S_PAIRS] = (int64_t)cnt[CTK_CNT_PAIRS] + cnt[CTK_CNT_UPAIRS];
+    h->stats[CTK_S_COMPONENTS] = m[CTK_AM_NC]; h->stats[CTK_S_PAIRS] = npairs_grouped + cnt[CTK_CNT_UPAIRS];
     h->stats[CTK_S_UPAIRS] = cnt[CTK_CNT_UPAIRS]; h->stats[CTK_S_SEAM_ROWS] = m[CTK_AM_NCAND]; h->stats[CTK_S_LABELS] = nlab;
     h->stats[CTK_S_OPS] = cnt[CTK_CNT_NOPS]; h->stats[CTK_S_FILTER_PASSES] = NP > 0 ? m[CTK_AM_CONV] : 0; h->stats[CTK_S_FILTER_ROUNDS] = NP > 0 ? 1 : 0;
     h->stats[CTK_S_AMBIGUOUS] = 0; h->stats[CTK_S_FUSED] = 1;
@@ -1763,6 +1785,8 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
     const double t0 = now_ms();
     HT0();
+    h->in_one_call = true;
+    struct OneCall { ctk_handle *h; ~OneCall() { h->in_one_call = false; } } one_call{h};
     CTKCHK(shard_label2d_impl(h, anom_dev, f64, T, ny, nx, thr, cmp_op, wrow, 0));
     HT("label2d stage done");
     CTKCHK(ctk_shard_overlap(h));
@@ -1771,6 +1795,16 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
         const int ra = resolve_async(h, overlap, twosided, persistence, flag_dev, n_tracked);
         if (ra <= 0) { h->ms[CTK_T_TOTAL] += now_ms() - t0; return ra; }
         h->stats[CTK_S_FUSED] = 0;                           // fell off the fused path: the synchronous one resolves the same tables
+        if (h->fz_pslot) {
+            // ... which wants the co-occurrence records in one contiguous range: the histogram again, ranges from the counter
+            const uint32_t ovf_keep = h->h_amail[CTK_AM_COUNTERS + CTK_CNT_OVERFLOW] & ~CTK_OVF_PAIRS;
+            HIPCHK(hipMemsetAsync(P<uint32_t>(h->counters) + CTK_CNT_PAIRS, 0, 4, h->stream));
+            HIPCHK(hipMemsetAsync(P<uint32_t>(h->counters) + CTK_CNT_UPAIRS, 0, 4, h->stream));
+            HIPCHK(hipMemcpyAsync(P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, &ovf_keep, 4, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            h->fz_init = false;
+            CTKCHK(launch_overlap(h));
+        }
     }
     int rv = h->use_device_resolve ? device_resolve_local(h, overlap, twosided) : 1;
     if (rv < 0) return rv;

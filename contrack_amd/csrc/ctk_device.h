@@ -14,6 +14,15 @@
                                   host-driven path (CTK_POISON_* bits, ctk_seam_dev.hip) */
 #define CTK_CNT_NOPS       9   /* fused one-call path: relabel operations recorded by k_seam_driver */
 #define CTK_CNT_N          16
+/* "a background value was written" (the + 1 of len(np.unique(flag)), contrack.py:793) is recorded by the write kernels in one of
+ * CTK_ZF_SLOTS words, 64 bytes apart, picked by the workgroup index -- behind the counters, in the same buffer.  One word for all
+ * workgroups was an atomicOr on ONE address from every workgroup of eight XCDs (each XCD's L2 keeps showing its stale zero, so the
+ * look-before never helped): ~2.7 ns per workgroup, serialised -- it bounded k_relabel_v5 (123 us for 46 k workgroups at 1 degree,
+ * 2.3 ms for 722 k at 2000 x 721 x 1440). */
+#define CTK_ZF_OFF    64
+#define CTK_ZF_SLOTS  1024
+#define CTK_ZF_STRIDE 16
+#define CTK_CNT_WORDS (CTK_ZF_OFF + CTK_ZF_SLOTS * CTK_ZF_STRIDE)
 
 // overflow bits
 #define CTK_OVF_PAIRS 1u

@@ -26,6 +26,17 @@
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
 
+// "a background value was written": one of CTK_ZF_SLOTS words per workgroup (ctk_device.h), plain stores
+__device__ __forceinline__ void ctk_zf_set(uint32_t *counters, uint32_t key) { counters[CTK_ZF_OFF + (key & (CTK_ZF_SLOTS - 1)) * CTK_ZF_STRIDE] = 1u; }
+__device__ __forceinline__ void ctk_zf_reset(uint32_t *counters, int64_t i) { if (i < CTK_ZF_SLOTS) counters[CTK_ZF_OFF + i * CTK_ZF_STRIDE] = 0u; }
+// any slot set?  called by all threads of a workgroup of `nthreads`; the result is valid for thread 0 .. 63 after a wave OR
+__device__ __forceinline__ uint32_t ctk_zf_mine(const uint32_t *counters, int tid, int nthreads)
+{
+    uint32_t v = 0;
+    for (int i = tid; i < CTK_ZF_SLOTS; i += nthreads) v |= __hip_atomic_load(&counters[CTK_ZF_OFF + i * CTK_ZF_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 {
     int lane = lane_id();
@@ -781,7 +792,7 @@ __global__ __launch_bounds__(256) void k_compact_seams(const CtkSeam *__restrict
 // LDS-resident hash table with LDS atomics; entries that do not find a slot are emitted directly
 // (records are additive, duplicates are fine).
 // ------------------------------------------------------------------------------------------------
-#define CTK_HASH_SLOTS 1024
+#define CTK_HASH_SLOTS 512              // (12 KB: twelve workgroups per CU; a 1 degree timestep has ~40 pairs, a 0.25 degree one ~100)
 #define CTK_HASH_PROBES 12
 
 struct OverlapArgs {
@@ -809,6 +820,11 @@ struct OverlapArgs {
     const uint32_t *cprefix, *mrep;
     uint32_t *p_rc, *p_rd, *p_gc, *p_gd;
     int64_t *F;
+    // ... and the grouped records of timestep t go to the FIXED slots pairs[t * pslot .. + pslot) (entries beyond: the ungrouped
+    // path) instead of a range taken from one counter: 2707 workgroups adding to one address was most of this kernel's time
+    // (~20 ns per add, serialised: 54 us).  0: ranges from the counter (the synchronous resolver wants them contiguous).
+    uint32_t pslot;
+    uint32_t upair_cap;            // ungrouped records the end of the buffer may hold
 };
 
 __device__ __forceinline__ void pair_prepare(const OverlapArgs &a, uint32_t slot, uint32_t cb, uint32_t db, uint32_t c, uint32_t d, int64_t lo, int64_t hi)
@@ -823,7 +839,7 @@ __device__ __forceinline__ void pair_prepare(const OverlapArgs &a, uint32_t slot
 __device__ __forceinline__ void emit_pair(const OverlapArgs &a, uint32_t t, uint32_t c, uint32_t d, int64_t lo, int64_t hi, uint32_t cb = 0, uint32_t db = 0)
 {
     uint32_t i = atomicAdd(&a.counters[CTK_CNT_UPAIRS], 1u);
-    if (i < a.pair_cap) {
+    if (i < a.upair_cap) {
         CtkPair p;
         p.t = t; p.c = c; p.d = d; p.pad = 0; p.lo = lo; p.hi = hi;
         a.pairs[a.pair_cap - 1u - i] = p;
@@ -831,6 +847,9 @@ __device__ __forceinline__ void emit_pair(const OverlapArgs &a, uint32_t t, uint
     } else atomicOr(&a.counters[CTK_CNT_OVERFLOW], CTK_OVF_PAIRS);
 }
 
+// OVB: mask words per thread and step -- chosen by the host so that ONE step covers the timestep where it can (1086 words at
+// 181 x 360: five per thread; with four a second step ran for the last 62 words)
+template <int OVB>
 __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
 {
     const int t = (int)blockIdx.x;
@@ -867,7 +886,6 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
     // round trips to L2 per word, most of this kernel's time.  Here every load of a level is issued for all OVB words before the
     // first is used: three round trips per OVB words.  (Words without common pixels -- nine of ten -- load their tables in vain:
     // L2 hits next to data that is read anyway.)
-    constexpr int OVB = 4;
     auto insert = [&](uint32_t cc, uint32_t cd, int64_t lo, int64_t hi) {
         const unsigned long long key = ((unsigned long long)cc << 32) | cd;
         uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (CTK_HASH_SLOTS - 1);
@@ -940,16 +958,28 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
         uint32_t tot;
         const uint32_t ex = block_excl_scan(mine, sm_scan, &tot);
         if (tid == 0) {
-            out_base = tot ? atomicAdd(&a.counters[CTK_CNT_PAIRS], tot) : 0u;
-            a.pair_base[t] = out_base;
-            a.pair_cnt[t] = (tot && out_base + tot <= a.pair_cap) ? tot : 0u;
-            if (tot && out_base + tot > a.pair_cap) atomicOr(&a.counters[CTK_CNT_OVERFLOW], CTK_OVF_PAIRS);
+            if (a.pslot) {
+                out_base = (uint32_t)t * a.pslot;
+                a.pair_base[t] = out_base;
+                a.pair_cnt[t] = min(tot, a.pslot);
+            } else {
+                out_base = tot ? atomicAdd(&a.counters[CTK_CNT_PAIRS], tot) : 0u;
+                a.pair_base[t] = out_base;
+                a.pair_cnt[t] = (tot && out_base + tot <= a.pair_cap) ? tot : 0u;
+                if (tot && out_base + tot > a.pair_cap) atomicOr(&a.counters[CTK_CNT_OVERFLOW], CTK_OVF_PAIRS);
+            }
         }
         __syncthreads();
         uint32_t j = out_base + ex;
+        const uint32_t jend = a.pslot ? out_base + a.pslot : a.pair_cap;
         for (int i = tid; i < CTK_HASH_SLOTS; i += 256) {
             if (hkey[i] == FULL64) continue;
-            if (j < a.pair_cap) {
+            if (a.pslot && j >= jend) {                                         // more entries than the timestep's slots: ungrouped
+                emit_pair(a, (uint32_t)t, (uint32_t)(hkey[i] >> 32), (uint32_t)hkey[i], hlo[i], hhi[i], cbc, cbd);
+                j++;
+                continue;
+            }
+            if (j < jend) {
                 CtkPair p;
                 p.t = (uint32_t)t; p.c = (uint32_t)(hkey[i] >> 32); p.d = (uint32_t)hkey[i]; p.pad = 0;
                 p.lo = hlo[i]; p.hi = hhi[i];
@@ -1259,7 +1289,7 @@ __global__ __launch_bounds__(256) void k_relabel_v4(RelabelArgs a, int rb, int r
         __builtin_nontemporal_store(out, dst + i);                               // (the chunk's rows are contiguous: slot i)
         z |= (out.x == 0) | (out.y == 0) | (out.z == 0) | (out.w == 0);
     }
-    if (__ballot(z) && lane_id() == 0 && a.counters[CTK_CNT_WROTE_ZERO] == 0) atomicOr(&a.counters[CTK_CNT_WROTE_ZERO], 1u);
+    if (__ballot(z) && lane_id() == 0) ctk_zf_set(a.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
 }
 
 // Word-centric form of the fast path: the same tables and launch geometry as k_relabel_v4 above, but the chunk's flag values are
@@ -1349,7 +1379,7 @@ __global__ __launch_bounds__(256) void k_relabel_v5(RelabelArgs a, int rb, int r
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int i = tid; i < total; i += 256) __builtin_nontemporal_store(outv4[i], dst + i);    // (the chunk's rows are contiguous: slot i)
-    if (__ballot(z) && lane_id() == 0 && a.counters[CTK_CNT_WROTE_ZERO] == 0) atomicOr(&a.counters[CTK_CNT_WROTE_ZERO], 1u);
+    if (__ballot(z) && lane_id() == 0) ctk_zf_set(a.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
 }
 
 __global__ __launch_bounds__(256) void k_relabel(RelabelArgs a)
@@ -1398,7 +1428,7 @@ __global__ __launch_bounds__(256) void k_relabel(RelabelArgs a)
             carry = shfl_u64(m, wn - 1) >> 63;
         }
     }
-    if (__ballot(wrote_zero != 0) && lane == 0) atomicOr(&a.counters[CTK_CNT_WROTE_ZERO], 1u);
+    if (__ballot(wrote_zero != 0) && lane == 0) ctk_zf_set(a.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1414,13 +1444,14 @@ struct AsyncMail {
     const uint32_t *ambig;
     const uint32_t *rec_cnt;        // [T] candidate group records per timestep
     const uint32_t *t_nops;         // [T] relabel operations of the clusters that start in timestep t
+    const uint32_t *pair_cnt;       // [T] grouped co-occurrence records per timestep
     int64_t T;
     int passes;
 };
 #define CTK_AM_COUNTERS 0           // .. + CTK_CNT_N
 #define CTK_AM_NC       16
 #define CTK_AM_NLAB     17
-#define CTK_AM_ND       18
+#define CTK_AM_NPAIRS   18          // grouped co-occurrence records (sum of pair_cnt)
 #define CTK_AM_NCAND    19
 #define CTK_AM_AMBIG    20
 #define CTK_AM_CONV     21          // first filter pass that changed nothing, + 1; 0 = none of the passes launched
@@ -1428,7 +1459,7 @@ struct AsyncMail {
 #define CTK_AM_WORDS    32
 
 // called by the first 64 threads of a workgroup (one word per lane: the stores to host memory leave together)
-__device__ inline void async_mail_write(const AsyncMail &m, const uint32_t *counters, uint32_t ncand, uint32_t nops)
+__device__ inline void async_mail_write(const AsyncMail &m, const uint32_t *counters, uint32_t ncand, uint32_t nops, uint32_t npairs = 0)
 {
     const int lane = (int)threadIdx.x;
     if (lane >= 64) return;
@@ -1439,6 +1470,7 @@ __device__ inline void async_mail_write(const AsyncMail &m, const uint32_t *coun
     else if (lane == CTK_AM_NC) { v = *m.nc_ptr; has = true; }
     else if (lane == CTK_AM_NLAB) { v = *m.nlab_ptr; has = true; }
     else if (lane == CTK_AM_NCAND) { v = ncand; has = true; }
+    else if (lane == CTK_AM_NPAIRS) { v = npairs; has = true; }
     else if (lane == CTK_AM_AMBIG) { v = *m.ambig; has = true; }
     else if (lane == CTK_AM_DONE) { v = 1u; has = true; }
     // first filter pass that changed nothing: lane k looks at pass k (and k + 64, ...)
@@ -1474,18 +1506,27 @@ __global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) last = atomicAdd(&counters[CTK_CNT_TICKET], 1u) == gridDim.x - 1;
     __syncthreads();
-    if (last && threadIdx.x == 0) {
-        mail[0] = __hip_atomic_load(&counters[CTK_CNT_ALIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        mail[1] = __hip_atomic_load(&counters[CTK_CNT_WROTE_ZERO], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (last) {
+        __shared__ uint32_t zw[4];
+        const uint32_t zv = ctk_zf_mine(counters, (int)threadIdx.x, 256);
+        const bool zany = __ballot(zv != 0u) != 0ull;
+        if (lane_id() == 0) zw[threadIdx.x >> 6] = zany ? 1u : 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t z = zw[0] | zw[1] | zw[2] | zw[3];
+            counters[CTK_CNT_WROTE_ZERO] = z;
+            mail[0] = __hip_atomic_load(&counters[CTK_CNT_ALIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mail[1] = z;
+        }
+        __syncthreads();
     }
     if (last && am.scal) {
-        uint32_t nc = 0, no = 0;
+        uint32_t nc = 0, no = 0, np = 0;
         if (threadIdx.x < 64) {
-            for (int64_t t = threadIdx.x; t < am.T; t += 64) nc += am.rec_cnt[t];
-            for (int64_t t = threadIdx.x; t < am.T; t += 64) no += am.t_nops[t];
-            nc = wave_sum_u32(nc); no = wave_sum_u32(no);
+            for (int64_t t = threadIdx.x; t < am.T; t += 64) { nc += am.rec_cnt[t]; no += am.t_nops[t]; np += am.pair_cnt[t]; }
+            nc = wave_sum_u32(nc); no = wave_sum_u32(no); np = wave_sum_u32(np);
         }
-        async_mail_write(am, counters, nc, no);
+        async_mail_write(am, counters, nc, no, np);
     }
 }
 
@@ -1497,30 +1538,39 @@ __global__ __launch_bounds__(1024) void k_count_alive_1(const int32_t *__restric
         async_mail_write(am, counters, 0u, 0u);
         return;
     }
-    uint32_t v = 0, nc = 0, no = 0;
+    uint32_t v = 0, nc = 0, no = 0, np = 0;
     if (am.scal) {
-        for (int64_t t = threadIdx.x; t < am.T; t += 1024) nc += am.rec_cnt[t];
-        for (int64_t t = threadIdx.x; t < am.T; t += 1024) no += am.t_nops[t];
+        for (int64_t t = threadIdx.x; t < am.T; t += 1024) { nc += am.rec_cnt[t]; no += am.t_nops[t]; np += am.pair_cnt[t]; }
     }
     const int64_t nl = am.scal ? (int64_t)*am.nlab_ptr : n_labels;
     for (int64_t l = threadIdx.x + 1; l <= nl; l += 1024) {
         const int64_t lo = ext[l], hi = ext[n_labels + 1 + l];
         v += (hi >= lo && hi - lo + 1 >= persistence) ? 1u : 0u;
     }
-    __shared__ uint32_t sm[16], sn[16], so[16];
-    const uint32_t s = wave_sum_u32(v), s2 = wave_sum_u32(nc), s3 = wave_sum_u32(no);
-    if (lane_id() == 0) { sm[threadIdx.x >> 6] = s; sn[threadIdx.x >> 6] = s2; so[threadIdx.x >> 6] = s3; }
+    __shared__ uint32_t sm[16], sn[16], so[16], sp[16];
+    const uint32_t s = wave_sum_u32(v), s2 = wave_sum_u32(nc), s3 = wave_sum_u32(no), s4 = wave_sum_u32(np);
+    if (lane_id() == 0) { sm[threadIdx.x >> 6] = s; sn[threadIdx.x >> 6] = s2; so[threadIdx.x >> 6] = s3; sp[threadIdx.x >> 6] = s4; }
     __syncthreads();
-    uint32_t tot = 0, ncand = 0, nops = 0;
-    for (int i = 0; i < 16; i++) { tot += sm[i]; ncand += sn[i]; nops += so[i]; }
+    uint32_t tot = 0, ncand = 0, nops = 0, npairs = 0;
+    for (int i = 0; i < 16; i++) { tot += sm[i]; ncand += sn[i]; nops += so[i]; npairs += sp[i]; }
+    __shared__ uint32_t zw[16];
+    {
+        const uint32_t zv = ctk_zf_mine(counters, (int)threadIdx.x, 1024);
+        const bool zany = __ballot(zv != 0u) != 0ull;
+        if (lane_id() == 0) zw[threadIdx.x >> 6] = zany ? 1u : 0u;
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
+        uint32_t z = 0;
+        for (int i = 0; i < 16; i++) z |= zw[i];
         counters[CTK_CNT_ALIVE] = tot;
+        counters[CTK_CNT_WROTE_ZERO] = z;
         mail[0] = tot;
-        mail[1] = __hip_atomic_load(&counters[CTK_CNT_WROTE_ZERO], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mail[1] = z;
     }
     if (am.scal) {
         __syncthreads();                                   // (counters[CTK_CNT_ALIVE] is one of the words mailed)
-        async_mail_write(am, counters, ncand, nops);
+        async_mail_write(am, counters, ncand, nops, npairs);
     }
 }
 
@@ -1530,6 +1580,7 @@ __global__ void k_fill_ext(int32_t *ext, int64_t n_labels, uint32_t *counters)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_labels; i += (int64_t)gridDim.x * blockDim.x) {
         ext[i] = INT32_MAX; ext[n_labels + 1 + i] = INT32_MIN;
     }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < CTK_ZF_SLOTS; i += (int64_t)gridDim.x * blockDim.x) ctk_zf_reset(counters, i);
     if (blockIdx.x == 0 && threadIdx.x == 0) { counters[CTK_CNT_WROTE_ZERO] = 0; counters[CTK_CNT_ALIVE] = 0; counters[CTK_CNT_TICKET] = 0; }
 }
 
@@ -1548,6 +1599,7 @@ __global__ void k_ops_ingest(const int32_t *__restrict__ staging, int64_t nops, 
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_labels; i += (int64_t)gridDim.x * blockDim.x) {
         ext[i] = INT32_MAX; ext[n_labels + 1 + i] = INT32_MIN;
     }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < CTK_ZF_SLOTS; i += (int64_t)gridDim.x * blockDim.x) ctk_zf_reset(counters, i);
     if (blockIdx.x == 0 && threadIdx.x == 0) { counters[CTK_CNT_WROTE_ZERO] = 0; counters[CTK_CNT_ALIVE] = 0; counters[CTK_CNT_TICKET] = 0; }
 }
 

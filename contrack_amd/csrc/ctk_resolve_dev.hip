@@ -512,6 +512,33 @@ __global__ void k_rs_unite(ResolveDev r)
     }
 }
 
+// the same on pair records in fixed per-timestep slots (k_overlap with pslot): thread = slot, + the ungrouped records
+__global__ void k_rs_unite_slots(ResolveDev r, const uint32_t *__restrict__ pair_cnt, uint32_t pslot)
+{
+    if (dev_tables_bad(r)) return;
+    const uint64_t nslots = (uint64_t)r.T * pslot;
+    const uint32_t nu = dev_nungrouped(r);
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nslots + nu; k += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t i;
+        if (k < nslots) {
+            const uint32_t t = (uint32_t)(k / pslot), j = (uint32_t)(k - (uint64_t)t * pslot);
+            if (j >= pair_cnt[t]) continue;
+            i = (uint32_t)k;
+        } else i = r.pair_cap - 1u - (uint32_t)(k - nslots);
+        if (!r.keep0[r.p_rc[i]] || !r.keep0[r.p_rd[i]]) continue;
+        uint32_t a = r.p_gc[i], b = r.p_gd[i];
+        for (;;) {
+            a = gfind(r.parent, a);
+            b = gfind(r.parent, b);
+            if (a == b) break;
+            if (a < b) { uint32_t s = a; a = b; b = s; }
+            uint32_t old = atomicMin(&r.parent[a], b);
+            if (old == a) break;
+            a = old;
+        }
+    }
+}
+
 // one component per thread; bsum[block] = surviving roots among the block's components (first half of the rank scan)
 __global__ __launch_bounds__(256) void k_rs_roots(ResolveDev r, uint32_t *__restrict__ bsum)
 {
@@ -544,6 +571,7 @@ __global__ __launch_bounds__(256) void k_rs_roots(ResolveDev r, uint32_t *__rest
             }
         }
     }
+    if (r.ext) for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < CTK_ZF_SLOTS; i += (int64_t)gridDim.x * 256) ctk_zf_reset(r.counters_w, i);
     __shared__ uint32_t sm[8];
     uint32_t tot;
     const uint32_t ex = block_excl_scan(isr, sm, &tot);

@@ -182,7 +182,7 @@ __device__ __forceinline__ int32_t sd_wave_max(int32_t v)
 // loads of a batch in flight together) and worked off in (t, y) order.  At most 64 labels and 64 operations per cluster.
 __global__ __launch_bounds__(64) void k_seam_driver(SeamDev a, int64_t t_begin)
 {
-    if (*a.poison) return;
+    if (ctk_guard_bad(a.poison - CTK_CNT_POISON)) return;         // (the kernels in front returned early: nothing here is valid)
     __shared__ CtkCand brec[SD_BATCH];
     const int lane = (int)threadIdx.x;
     // A cluster is driven by the workgroup of the FIRST timestep that holds one of its records (its "home"): the records of a

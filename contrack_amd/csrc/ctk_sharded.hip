@@ -283,11 +283,16 @@ __global__ __launch_bounds__(1024) void k_sh_count(const int32_t *__restrict__ e
     const uint32_t s = wave_sum_u32(v);
     if (lane_id() == 0) sm[threadIdx.x >> 6] = s;
     __syncthreads();
+    __shared__ uint32_t zw[16];
+    const uint32_t zv = ctk_zf_mine(counters, (int)threadIdx.x, 1024);
+    const bool zany = __ballot(zv != 0u) != 0ull;
+    if (lane_id() == 0) zw[threadIdx.x >> 6] = zany ? 1u : 0u;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int i = 0; i < 16; i++) tot += sm[i];
+        uint32_t tot = 0, z = 0;
+        for (int i = 0; i < 16; i++) { tot += sm[i]; z |= zw[i]; }
         out[0] = tot;
-        out[1] = __hip_atomic_load(&counters[CTK_CNT_WROTE_ZERO], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out[1] = z;
     }
 }
 
