@@ -30,7 +30,7 @@ EXPORTS = [
     "ctk_comm_destroy", "ctk_comm_rank", "ctk_comm_world", "ctk_comm_barrier", "ctk_comm_allgather_host", "ctk_comm_ops",
     "ctk_comm_set_timeout", "ctk_comm_failed", "ctk_comm_abort_rank", "ctk_debug_fail_at", "ctk_synth_fill_window", "ctk_checksum_i32_dev",
     "ctk_track_sharded_f32_dev", "ctk_track_sharded_f64_dev",
-    "ctk_anom_f32", "ctk_anom_f64", "ctk_resident_anom", "ctk_track_resident", "ctk_percentile_f32", "ctk_percentile_f64",
+    "ctk_anom_f32", "ctk_anom_f64", "ctk_resident_anom", "ctk_resident_anom_generation", "ctk_track_resident", "ctk_percentile_f32", "ctk_percentile_f64",
     "ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev", "ctk_lifecycle_rows", "ctk_lifecycle_exact",
     "ctk_track_stream_f32", "ctk_track_stream_f64", "ctk_track_stream_cb", "ctk_stream_times",
 ]
@@ -132,6 +132,7 @@ def lib():
     for name in ("ctk_anom_f32", "ctk_anom_f64"):
         getattr(L, name).argtypes = [p, p, i64, i32, i32, p, i32, i32, i32, p, p, p, i32]
     L.ctk_resident_anom.argtypes = [p, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.ctk_resident_anom_generation.argtypes = [p, C.POINTER(C.c_uint64)]
     L.ctk_track_resident.argtypes = [p, p, i32, p, dbl, i32, i32, p, C.POINTER(i64)]
     for name in ("ctk_percentile_f32", "ctk_percentile_f64"):
         getattr(L, name).argtypes = [p, p, i64, i32, i32, i32, i32, dbl, C.POINTER(dbl)]
@@ -492,6 +493,12 @@ class Tracker:
         T, ny, nx, f = C.c_int64(0), C.c_int(0), C.c_int(0), C.c_int(0)
         check(lib().ctk_resident_anom(self._h, C.byref(T), C.byref(ny), C.byref(nx), C.byref(f)))
         return None if T.value < 0 else (int(T.value), int(ny.value), int(nx.value), bool(f.value))
+
+    def resident_generation(self):
+        """identity of the resident anomaly slab (changes whenever one is written or dropped)"""
+        g = C.c_uint64(0)
+        check(lib().ctk_resident_anom_generation(self._h, C.byref(g)))
+        return int(g.value)
 
     def track_resident(self, thr, cmp_op, wrow, overlap, persistence, twosided=True):
         shape = self.resident_anom()

@@ -412,7 +412,10 @@ class contrack(object):
 
     def _wrap(self, like, data, dims, coords=None, attrs=None):
         """a labelled array of the same class as `like` (xarray.DataArray, or whatever duck-typed dataset is wrapped)"""
-        return type(like)(data, dims=dims, coords=coords, attrs=attrs or {})
+        try:                                         # (the climatology keeps the variable's name, as xarray's groupby().mean() does)
+            return type(like)(data, dims=dims, coords=coords, attrs=attrs or {}, name=getattr(like, "name", None))
+        except TypeError:
+            return type(like)(data, dims=dims, coords=coords, attrs=attrs or {})
 
     def calc_clim(self, variable, window=1, groupby='dayofyear'):
         """climatological mean per `groupby` value, smoothed with a centred running mean over `window` groups; NaNs of the
@@ -454,6 +457,10 @@ class contrack(object):
             carr = np.asarray(clim_mean.data).transpose([cd.index(d) for d in (groupby, self._latitude_name, self._longitude_name)])
             cvals = np.asarray(clim_mean[groupby].data if hasattr(clim_mean[groupby], "data") else clim_mean[groupby])
             pos = {v: i for i, v in enumerate(cvals.tolist())}
+            missing = [v for v in uniq.tolist() if v not in pos]
+            if missing:
+                raise ValueError("the climatology has no {} {} (present in {!r}); it covers {}..{}".format(
+                    groupby, missing[:5] + (['...'] if len(missing) > 5 else []), variable, cvals.min(), cvals.max()))
             clim_arr = np.stack([carr[pos[v]] for v in uniq.tolist()])       # one plane per group value present in the data
         anom, _ = _tracker().anomalies(slab, ids, len(uniq), window=window, smooth=smooth, clim=clim_arr, keep_resident=True)
         da = self.ds[variable]
@@ -464,8 +471,19 @@ class contrack(object):
         anom.flags.writeable = False                         # (its twin stays in HBM for run_contrack: see _fingerprint)
         out = anom.transpose(np.argsort(sort))
         self.ds['anom'] = (dims, out, attrs)
-        self._anom_resident = _fingerprint(np.asarray(self.ds['anom'].data))
+        # (fingerprint of the host twin, identity of the slab in HBM: another instance's calc_anom on the shared handle changes
+        # the second and this instance's run_contrack goes back to its own host array)
+        self._anom_resident = (_fingerprint(np.asarray(self.ds['anom'].data)), _tracker().resident_generation())
         logger.info('Calculating Anomaly... DONE')
+
+    def _resident_for(self, variable, arr, shape, is_f64):
+        """True if `variable` is this instance's anomaly and its twin is still the slab resident in HBM"""
+        res = getattr(self, "_anom_resident", None)
+        if variable != 'anom' or res is None or res[0] is None:
+            return False
+        trk = _tracker()
+        return res[0] == _fingerprint(np.asarray(arr)) and res[1] == trk.resident_generation() and \
+            trk.resident_anom() == (shape[0], shape[1], shape[2], bool(is_f64))
 
     def percentile_threshold(self, variable='anom', q=0.90, lat_bounds=(50, 80)):
         """the more objective threshold of the reference's README (README.rst:150-151):
@@ -479,9 +497,7 @@ class contrack(object):
             raise ValueError("latitude band {} selects no contiguous rows".format(lat_bounds))
         if slab.dtype.kind != "f":
             slab = slab.astype(np.float64)
-        resident = variable == 'anom' and getattr(self, "_anom_resident", None) is not None and \
-            self._anom_resident == _fingerprint(np.asarray(self.ds['anom'].data)) \
-            and _tracker().resident_anom() == (slab.shape[0], slab.shape[1], slab.shape[2], slab.dtype != np.float32)
+        resident = self._resident_for(variable, self.ds['anom'].data if variable == 'anom' else None, slab.shape, slab.dtype != np.float32)
         return _tracker().percentile(None if resident else slab, int(rows[0]), int(rows[-1]) + 1, q)
 
     # ---- the hot path (contrack.py:583-796) -----------------------------------------------------------------
@@ -534,28 +550,25 @@ class contrack(object):
         lat = self.ds[self._latitude_name].data
         wrow = row_weights(lat, self._dlat, self._dlon)
         trk = _tracker()
-        if chunk_steps is not None:
-            flag, n_tracked = self._run_streaming(trk, da, dims, sort, threshold, gorl, wrow, overlap, persistence, twosided, int(chunk_steps))
-            resident, slab = False, None
-        else:
-            slab = np.asarray(da.data).transpose(sort)
-            T = slab.shape[0]
-            thr = self._thresholds_per_step(threshold, T, slab.dtype)
+        # threshold, 2-D labelling, overlap filter, 3-D tracking and persistence are ONE call into the library (the reference logs
+        # them as it goes through them, contrack.py:646-772)
         logger.info("Apply overlap...")
         logger.info("Apply persistence...")
-        resident = chunk_steps is None and variable == 'anom' and getattr(self, "_anom_resident", None) is not None and \
-            self._anom_resident == _fingerprint(np.asarray(da.data)) and \
-            trk.resident_anom() == (slab.shape[0], slab.shape[1], slab.shape[2], slab.dtype != np.float32)
         if chunk_steps is not None:
-            pass
-        elif resident:
-            # calc_anom left this very slab in HBM: no host-to-device copy
-            flag, n_tracked = trk.track_resident(thr, _native.CMP_OPS[gorl], wrow, overlap, persistence, twosided)
-        elif slab.dtype == np.float32:
-            flag, n_tracked = trk.track(np.ascontiguousarray(slab), thr, _native.CMP_OPS[gorl], wrow, overlap, persistence, twosided)
+            # the variable is read slice by slice and passes through chunk-sized device buffers
+            flag, n_tracked = self._run_streaming(trk, da, dims, sort, threshold, gorl, wrow, overlap, persistence, twosided, int(chunk_steps))
+            slab = None
         else:
-            flag, n_tracked = trk.track(np.ascontiguousarray(slab, dtype=np.float64), thr, _native.CMP_OPS[gorl], wrow, overlap,
-                                        persistence, twosided, f64=True)
+            slab = np.asarray(da.data).transpose(sort)
+            thr = self._thresholds_per_step(threshold, slab.shape[0], slab.dtype)
+            if self._resident_for(variable, da.data, slab.shape, slab.dtype != np.float32):
+                # calc_anom left this very slab in HBM: no host-to-device copy
+                flag, n_tracked = trk.track_resident(thr, _native.CMP_OPS[gorl], wrow, overlap, persistence, twosided)
+            elif slab.dtype == np.float32:
+                flag, n_tracked = trk.track(np.ascontiguousarray(slab), thr, _native.CMP_OPS[gorl], wrow, overlap, persistence, twosided)
+            else:
+                flag, n_tracked = trk.track(np.ascontiguousarray(slab, dtype=np.float64), thr, _native.CMP_OPS[gorl], wrow, overlap,
+                                            persistence, twosided, f64=True)
         if slab is not None and slab.nbytes > (4 << 30):
             trk.release_io()               # a big one-off slab: do not keep 2 x its size allocated on the GPU
         logger.info("Create new variable 'flag'...")
@@ -633,9 +646,7 @@ class contrack(object):
         lon = np.asarray(self.ds[self._longitude_name].data)
         wrow = row_weights(lat, self._dlat, self._dlon)                                                 # contrack.py:847-848
         trk = _tracker()
-        resident = variable == 'anom' and getattr(self, "_anom_resident", None) is not None and \
-            self._anom_resident == _fingerprint(np.asarray(self.ds['anom'].data)) and \
-            trk.resident_anom() == (field.shape[0], field.shape[1], field.shape[2], field.dtype == np.float64)
+        resident = self._resident_for(variable, self.ds['anom'].data if variable == 'anom' else None, field.shape, field.dtype == np.float64)
         # (the anomaly slab calc_anom left in HBM: only the flags cross PCIe)
         rows = trk.lifecycle(flags, None, wrow, resident_f64=field.dtype == np.float64) if resident else trk.lifecycle(flags, field, wrow)
         return pd.DataFrame(lifecycle_columns(rows, lat, lon, self._time_labels(), _tracker()),

@@ -218,7 +218,7 @@ static int anom_impl(ctk_handle *h, const VT *x_host, int64_t T, int ny, int nx,
     }
     if (clim_out) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipMemcpy(clim_out, h->an_clim.p, (size_t)ngroups * npix * esz, hipMemcpyDeviceToHost)); }
     if (anom_out || keep_resident) {
-        h->an_T = -1;                                                  // the resident slab (if any) is being overwritten
+        h->an_T = -1; h->an_gen++;                                     // the resident slab (if any) is being overwritten
         const int tseg = 32;
         k_anom<VT><<<dim3(gx, (unsigned)((T + tseg - 1) / tseg)), 256, 0, s>>>((const VT *)h->io_in.p, (const VT *)h->an_clim.p, d_grp, T, npix, smooth, tseg,
                                                                              (VT *)h->an_out.p);
@@ -244,6 +244,16 @@ extern "C" int ctk_anom_f64(ctk_handle *h, const double *x, int64_t T, int ny, i
                             const double *clim_in, double *anom_out, double *clim_out, int keep_resident)
 {
     return anom_impl<double>(h, x, T, ny, nx, group, ngroups, window, smooth, clim_in, anom_out, clim_out, keep_resident);
+}
+
+// WHICH slab is resident: a number that changes whenever the resident slab is written (any ctk_anom_* call that produces
+// anomalies) or dropped (ctk_release_io).  A caller that left a slab resident remembers the number and runs on the slab only
+// while it is unchanged -- two class instances sharing one handle cannot take each other's anomalies for their own.
+extern "C" int ctk_resident_anom_generation(ctk_handle *h, uint64_t *generation)
+{
+    if (!h || !generation) return ctk_set_error(CTK_E_INVALID, "null argument");
+    *generation = h->an_gen;
+    return CTK_OK;
 }
 
 // shape of the anomaly slab kept in HBM by the last ctk_anom_* call with keep_resident (T = -1: none)

@@ -161,6 +161,7 @@ struct ctk_handle {
     // calc_anom / percentile (ctk_anom.hip): resident anomaly slab, climatology, scratch
     DevBuf an_out, an_clim, an_raw, an_idx;
     int64_t an_T = -1; int an_ny = 0, an_nx = 0; bool an_f64 = false;
+    uint64_t an_gen = 0;                           // bumped whenever the resident slab is written or dropped: WHICH slab is resident
     DevBuf io_in, io_out;                          // device copies of host-array calls (ctk_track_f32 / _f64)
     // streaming entries (ctk_track_stream_*): the slab passes through two chunk-sized device buffers per direction
     struct StreamIO *sio = nullptr;                // set for the duration of a streaming call: where the slab comes from
@@ -2113,7 +2114,7 @@ extern "C" int ctk_release_io(ctk_handle *h)
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->device));
     for (DevBuf *b : {&h->io_in, &h->io_out, &h->an_out, &h->an_raw}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
-    h->an_T = -1;
+    h->an_T = -1; h->an_gen++;
     if (h->bounce) { h->bounce->destroy(); delete h->bounce; h->bounce = nullptr; }
     stream_teardown(h);
     return CTK_OK;

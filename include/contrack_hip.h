@@ -350,6 +350,9 @@ int ctk_anom_f32(ctk_handle *h, const float *x, int64_t T, int ny, int nx, const
 int ctk_anom_f64(ctk_handle *h, const double *x, int64_t T, int ny, int nx, const int32_t *group, int ngroups, int window, int smooth,
                  const double *clim_in, double *anom_out, double *clim_out, int keep_resident);
 int ctk_resident_anom(ctk_handle *h, int64_t *T, int *ny, int *nx, int *is_f64);       /* T = -1: nothing resident */
+/* identity of the resident slab: changes whenever a ctk_anom_* call writes anomalies or ctk_release_io drops them.  Remember it
+ * after the call that left YOUR slab resident and use the slab only while it is unchanged. */
+int ctk_resident_anom_generation(ctk_handle *h, uint64_t *generation);
 /* ctk_track_f32 / _f64 on the resident anomaly slab (flag: host int32 (T, ny, nx)) */
 int ctk_track_resident(ctk_handle *h, const double *thr, int cmp_op, const float *wrow, double overlap, int persistence, int twosided,
                        int32_t *flag, int64_t *n_tracked);

@@ -127,3 +127,39 @@ def test_class_calc_anom_then_run_contrack_from_hbm(trk):
     c.ds['anom'] = (c['anom'].dims, np.zeros_like(np.asarray(c['anom'].data)), dict(c['anom'].attrs))
     c.run_contrack('anom', threshold=40.0, gorl='>=', overlap=0.5, persistence=3)
     assert np.asarray(c['flag'].data).max() == 0
+
+
+def test_two_instances_do_not_share_a_resident_slab(trk):
+    """A.calc_anom, B.calc_anom on a same-shaped dataset, A.run_contrack: the slab resident in HBM is B's by then -- A must run on
+    ITS anomalies (the resident slab is tied to the call that produced it: ctk_resident_anom_generation), B may use the slab"""
+    from contrack_amd.contrack import row_weights
+    T, ny, nx = 400, 31, 60
+    a, b = (contrack(ds=_daily_dataset(T, ny, nx, seed=s)[0]) for s in (3, 4))
+    a.calc_anom("z", window=3, smooth=1)
+    anom_a = np.array(a.ds["anom"].data)
+    b.calc_anom("z", window=3, smooth=1)                       # same shape, same handle: B's slab replaces A's in HBM
+    anom_b = np.array(b.ds["anom"].data)
+    assert anom_a.shape == anom_b.shape and not np.array_equal(anom_a, anom_b)
+    a.run_contrack("anom", threshold=40.0, gorl=">=", overlap=0.5, persistence=2)
+    b.run_contrack("anom", threshold=40.0, gorl=">=", overlap=0.5, persistence=2)
+    for c, anom in ((a, anom_a), (b, anom_b)):                 # references: the same call on plain host copies
+        w = row_weights(np.asarray(c.ds["latitude"].data), c._dlat, c._dlon)
+        want, _ = trk.track(np.ascontiguousarray(anom), np.full(T, np.float64(np.float32(40.0))), 0, w, 0.5, 2, True)
+        assert want.max() > 0 and np.array_equal(np.asarray(c.ds["flag"].data), want)
+    assert not np.array_equal(np.asarray(a.ds["flag"].data), np.asarray(b.ds["flag"].data))
+
+
+def test_calc_anom_with_a_climatology_that_lacks_a_group(trk):
+    """a `clim=` without one of the data's day-of-year values: a ValueError that says so (not a bare KeyError); the climatology
+    keeps the variable's name"""
+    T, ny, nx = 400, 9, 16
+    ds, _ = _daily_dataset(T, ny, nx, seed=1)
+    c = contrack(ds=ds)
+    c.set_up()
+    clim = c.calc_clim("z")
+    assert getattr(clim, "name", None) == "z"
+    n = np.asarray(clim.data).shape[0]
+    short = type(clim)(np.asarray(clim.data)[:n - 5], dims=clim.dims, coords={"dayofyear": np.asarray(clim["dayofyear"].data)[:n - 5],
+                       "latitude": np.asarray(ds["latitude"].data), "longitude": np.asarray(ds["longitude"].data)})
+    with pytest.raises(ValueError, match="dayofyear"):
+        c.calc_anom("z", clim=short)
