@@ -83,12 +83,19 @@ def cpu_baseline(wl, a, w, budget_s=20.0):
     t0 = time.perf_counter()
     scipy_port.run_contrack(a[:n], thr, wl["gorl"], w, wl["overlap"], wl["persistence"], wl["twosided"])
     dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="timesteps/s", cores=1, kind="port",
-                sample="first %d of %d steps of the same slab, scipy.ndimage/numpy port of contrack.py:646-796 "
-                       "(oracle/scipy_port.py), %.2f s" % (n, wl["T"], dt),
-                port_vs_reference="the port evaluates the reference's expressions one for one (same scalar look-ups per seam row, the "
-                                  "three mask expressions per contour, contrack.py:691-698/717-719/754-763); build container, same "
-                                  "720x181x360 slab, one core: unmodified reference 9.6 s, port 8.7 s (ratio 1.1, run-to-run noise +-30 %)")
+    out = dict(value=n / dt, unit="timesteps/s", cores=1, kind="port",
+               sample="first %d of %d steps of the same slab, scipy.ndimage/numpy port of contrack.py:646-796 "
+                      "(oracle/scipy_port.py), %.2f s" % (n, wl["T"], dt))
+    # how the port's wall time relates to the unmodified reference's: MEASURED in the build container by tools/port_vs_reference.py
+    # (alternating repeats on one slab, one core) and committed; quoted here, not typed in
+    try:
+        pv = json.load(open(os.path.join(ROOT, "profiles", "port_vs_reference.json")))
+        out["port_vs_reference"] = dict(port_over_reference_median=pv["port_over_reference"], port_over_reference_best=pv.get("port_over_reference_best"),
+                                        reference_s=pv["reference_s"]["median"], port_s=pv["port_s"]["median"], repeats=pv["repeats"], slab=pv["slab"],
+                                        identical_flags=pv["identical_flags"], source="profiles/port_vs_reference.json (tools/port_vs_reference.py, build container)")
+    except (OSError, KeyError, ValueError):
+        out["port_vs_reference"] = None
+    return out
 
 
 def concurrent_members(wl, a, thr, op, w, nh, steps):
