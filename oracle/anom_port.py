@@ -1,9 +1,13 @@
 """numpy restatement of contrack.calc_clim / calc_anom (contrack/contrack.py:458-581) and of the README's percentile
 threshold (README.rst:150-151), for checking the HIP kernels of contrack_amd/csrc/ctk_anom.hip.
 
-TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED: the reference evaluates these steps with xarray (groupby().mean(), rolling(center=True)
-.mean(), fillna, groupby arithmetic, quantile), and xarray cannot be installed in the build container, so the reference itself
-cannot be run on them here.  What is restated is the documented behaviour of those xarray calls:
+TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED against the reference itself: it evaluates these steps with xarray (groupby().mean(),
+rolling(center=True).mean(), fillna, groupby arithmetic, quantile), and xarray cannot be installed in the build container, so the
+reference cannot be run on them here.  Two things stand in: (1) tests/test_anom_pandas.py -- the same steps a second time with
+pandas' groupby / rolling / fillna (whose semantics xarray documents as its own), equal to this module for odd and even windows,
+NaNs and a supplied climatology; (2) tests/golden/make_anom_golden.py, which writes fixtures from the reference's own calc_clim /
+calc_anom wherever xarray is installed -- tests/test_anom_fixtures.py consumes them when present and pins the row then.
+What is restated is the documented behaviour of the xarray calls:
 
   calc_clim  (:482-489)  clim_raw[g] = mean over the timesteps of group g (NaNs skipped: xarray's mean has skipna=True for floats);
                          clim[g] = mean of clim_raw over the centred window of `window` groups, NaN where the window leaves the
