@@ -14,8 +14,9 @@ Stated deviations from the reference:
   * `flag` is written back with the INVERSE of the (time, lat, lon) permutation; the reference applies the
     forward permutation twice (contrack.py:778), which is only correct when the permutation is its own
     inverse -- for every such input (including the tested (time, lat, lon) order) both agree.
-  * ids are int32 (the reference switches to int64 beyond 2^31-2 pixels, sizes it cannot realistically run); more than
-    2^31-2 ids raise instead of wrapping.
+  * the library computes int32 ids (more than 2^31-2 ids raise instead of wrapping); the class hands `flag` out in the
+    reference's dtype -- int32, int64 from 2^31-2 elements on, as scipy.ndimage.label does (contrack.py:687, :751).  `track_numpy`
+    and the C ABI stay int32.
   * the numpy array behind `ds['anom']` after `calc_anom` is read-only (its twin stays in HBM for `run_contrack`); assign a
     new array to the variable to change it.
   * `run_contrack(..., chunk_steps=n)` (extension): stream the variable through the GPU in slices of n time steps.
@@ -152,6 +153,9 @@ def lifecycle_frame(rows, lat, lon, dates, tracker=None):
     c = lifecycle_columns(rows, lat, lon, dates, tracker)
     return [(int(f), d, int(lo), int(la), float(it), float(sz)) for f, d, lo, la, it, sz in
             zip(c["Flag"], c["Date"], c["Longitude"], c["Latitude"], c["Intensity"], c["Size"])]
+
+
+INT64_FLAG_FROM = 2 ** 31 - 2       # elements from which scipy.ndimage.label (and the reference's 'flag') switch to int64
 
 
 def _xr():
@@ -572,6 +576,11 @@ class contrack(object):
         if slab is not None and slab.nbytes > (4 << 30):
             trk.release_io()               # a big one-off slab: do not keep 2 x its size allocated on the GPU
         logger.info("Create new variable 'flag'...")
+        # scipy.ndimage.label returns int32 labels, int64 from 2^31 - 2 elements on (scipy/_measurements.py:190-199), and with it the
+        # reference's 'flag' (contrack.py:687, :751).  The library writes int32 ids (more than 2^31 - 2 ids are an error, never a
+        # wrap-around); slabs of that size get the reference's dtype here.
+        if flag.size >= INT64_FLAG_FROM:
+            flag = flag.astype(np.int64)
         inverse = np.argsort(sort)
         attrs = {'units': 'flag', 'long_name': 'contrack flag', 'standard_name': 'contrack flag',
                  'history': ' '.join(['Calculated from {} with input attributes:', 'threshold = {} {},', 'overlap fraction = {},',

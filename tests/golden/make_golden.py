@@ -235,16 +235,23 @@ def main():
         a = decode_input(coding)
         T = a.shape[0]
         thr_in = kw["threshold"]
+        time = None
         if isinstance(thr_in, str) and thr_in == "vector":
             thr_in = vector_threshold(T)
-            # The reference's DataArray-threshold branch needs groupby('time.dayofyear'); the compare
-            # it evaluates is the slab against a per-step float64 value (contrack.py:650), reproduced
-            # here by broadcasting the float64 vector against the slab.
-            thr_ref = thr_in[:, None, None]
+            # Through the reference's OWN DataArray-threshold branch (contrack.py:648-661): a daily time axis, the threshold as a
+            # DataArray over 'dayofyear', `self.ds[variable].groupby('time.dayofyear') >= threshold` (tests/minixr.py provides
+            # that groupby comparison and reset_coords, nothing more).  Day of year k+1 gets the k-th value of the vector, i.e.
+            # time step k is compared with thr_in[k] -- in float64 (the threshold is a float64 array, contrack.py:650).
+            time = (np.datetime64("2001-01-01") + np.arange(T).astype("timedelta64[D]")).astype("datetime64[ns]")
+            import minixr
+            thr_ref = minixr.DataArray(thr_in, ("dayofyear",), coords={"dayofyear": minixr.DataArray(np.arange(1, T + 1), ("dayofyear",))})
+            minixr.install_as_xarray()
+            import xarray
+            assert isinstance(thr_ref, xarray.DataArray)                 # the reference's isinstance test takes this branch
         else:
             thr_ref = thr_in
         flag, c = refimport.run_reference(a, lat, lon, thr_ref, kw["gorl"], kw["overlap"], kw["persistence"],
-                                          kw["twosided"], force=force)
+                                          kw["twosided"], force=force, time=time)
         dlat, dlon = np.asarray(c._dlat), np.asarray(c._dlon)
         wrow = cpu_oracle.row_weights(lat, c._dlat, c._dlon)
         thr = cpu_oracle.prepare_thresholds(thr_in, T, a.dtype)

@@ -68,8 +68,7 @@ class DataArray:
     def to_index(self):
         if self.data.dtype.kind != "M":
             raise AttributeError("to_index")          # like dates xarray cannot decode
-        import pandas as pd
-        return pd.DatetimeIndex(self.data)
+        return _Index(np.asarray(self.data))
 
     def transpose(self, *dims):
         if len(dims) == 1 and not isinstance(dims[0], str):
@@ -105,11 +104,90 @@ class DataArray:
                 coords[name] = DataArray(np.roll(coords[name].data, k), (name,), attrs=coords[name].attrs)
         return DataArray(data, self.dims, coords, self.attrs)
 
+    # DataArray.groupby('time.dayofyear') <op> threshold-per-day-of-year: the reference's DataArray-threshold branch of
+    # run_contrack (contrack.py:648-661) and nothing more
+    def groupby(self, spec):
+        name, _, what = spec.partition(".")
+        if what != "dayofyear" or name not in self.dims:
+            raise NotImplementedError("minixr groupby: only '<time dimension>.dayofyear' (%r)" % (spec,))
+        return _GroupByDayOfYear(self, name)
+
+    def reset_coords(self, names=None, drop=False):
+        if not drop:
+            raise NotImplementedError("minixr reset_coords: drop=True only")
+        names = [names] if isinstance(names, str) else list(names or [])
+        return DataArray(self.data, self.dims, {k: v for k, v in self.coords.items() if k not in names}, self.attrs, self.name)
+
     @property
     def dt(self):
         if self.data.dtype.kind != "M":
             raise TypeError("'.dt' accessor only available for DataArray with datetime64 timedelta64 dtype")
         return _DatetimeAccessor(self)
+
+
+class _Index:
+    """what DataArray.to_index() returns here: `.values`, slicing, and a difference that is a plain numpy timedelta64 array --
+    the unmodified reference takes `(idx[1:] - idx[:-1]).astype('timedelta64[h]')` (contrack.py:335-339), which pandas >= 2
+    refuses on its own TimedeltaIndex while numpy (and the pandas the reference was written against) accepts it"""
+
+    def __init__(self, values):
+        self.values = np.asarray(values)
+
+    def __len__(self):
+        return len(self.values)
+
+    def __getitem__(self, key):
+        v = self.values[key]
+        return _Index(v) if isinstance(key, slice) else v
+
+    def __sub__(self, other):
+        return self.values - (other.values if isinstance(other, _Index) else other)
+
+    def __iter__(self):
+        return iter(self.values)
+
+
+class _GroupByDayOfYear:
+    """what `da.groupby('time.dayofyear') >= thr` evaluates in xarray: every time step compared with the threshold of ITS day of
+    year (binary op between a groupby object and a DataArray indexed by the group label); the result carries a 'dayofyear'
+    coordinate along time, which the reference drops again (reset_coords, contrack.py:661)"""
+
+    def __init__(self, da, time_name):
+        self._da, self._time = da, time_name
+        tc = da.coords.get(time_name)
+        if tc is None or np.asarray(tc.data).dtype.kind != "M":
+            raise TypeError("groupby('%s.dayofyear') needs a datetime64 coordinate" % time_name)
+        import pandas as pd
+        self._doy = np.asarray(pd.DatetimeIndex(np.asarray(tc.data)).dayofyear)
+
+    def _cmp(self, thr, op):
+        if not isinstance(thr, DataArray) or thr.dims != ("dayofyear",):
+            raise TypeError("the threshold must be a DataArray over 'dayofyear'")
+        labels = np.asarray(thr.coords["dayofyear"].data if isinstance(thr.coords["dayofyear"], DataArray) else thr.coords["dayofyear"])
+        pos = {int(v): i for i, v in enumerate(labels.tolist())}
+        try:
+            idx = np.array([pos[int(d)] for d in self._doy])
+        except KeyError as e:
+            raise KeyError("dayofyear %s is not in the threshold" % e)
+        ax = self._da.dims.index(self._time)
+        shape = [1] * self._da.data.ndim
+        shape[ax] = -1
+        per_step = np.asarray(thr.data)[idx].reshape(shape)              # (numpy promotes float32 data vs float64 thresholds to float64)
+        coords = dict(self._da.coords)
+        coords["dayofyear"] = DataArray(self._doy, (self._time,))
+        return DataArray(op(self._da.data, per_step), self._da.dims, coords)
+
+    def __ge__(self, o):
+        return self._cmp(o, np.greater_equal)
+
+    def __le__(self, o):
+        return self._cmp(o, np.less_equal)
+
+    def __gt__(self, o):
+        return self._cmp(o, np.greater)
+
+    def __lt__(self, o):
+        return self._cmp(o, np.less)
 
 
 class _DatetimeAccessor:

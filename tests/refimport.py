@@ -34,12 +34,12 @@ def load():
     return refpkg.contrack
 
 
-def run_reference(anom, lat, lon, threshold, gorl, overlap, persistence, twosided=True, force=False):
+def run_reference(anom, lat, lon, threshold, gorl, overlap, persistence, twosided=True, force=False, time=None):
     """Run the reference's run_contrack on a (T,ny,nx) numpy slab; returns the int flag array."""
     import numpy as np
     import minixr
     cls = load()
-    ds = minixr.make_dataset(anom, lat, lon)
+    ds = minixr.make_dataset(anom, lat, lon) if time is None else minixr.make_dataset(anom, lat, lon, time=time)
     c = cls()
     c.read_xarray(ds)
     logging.disable(logging.CRITICAL)

@@ -167,3 +167,20 @@ def test_run_lifecycle_known_answer():
         assert 0 <= r.Longitude < 360 and -90 <= r.Latitude <= 90
         ys, xs = np.nonzero(m)
         assert g["lat"][ys].min() - 1 <= r.Latitude <= g["lat"][ys].max() + 1
+
+
+@pytest.mark.gpu
+def test_flag_dtype_follows_scipy(monkeypatch):
+    """int32 ids below 2^31 - 2 elements, int64 from there on -- scipy.ndimage.label's rule, hence the reference's (contrack.py:687,
+    :751); the switch-over is exercised by lowering it"""
+    import contrack_amd.contrack as mod
+    g = golden_util.load("refslab_fwd")
+    ds = minixr.make_dataset(g["anom"], g["lat"], g["lon"])
+    c = mod.contrack(ds=ds)
+    c.run_contrack("anom", threshold=float(g["thr"][0]), gorl=g["gorl"], overlap=float(g["overlap"]), persistence=int(g["persistence"]), twosided=bool(g["twosided"]))
+    f32 = np.asarray(c["flag"].data)
+    assert f32.dtype == np.int32 and np.array_equal(f32, g["flag"])
+    monkeypatch.setattr(mod, "INT64_FLAG_FROM", f32.size)
+    c.run_contrack("anom", threshold=float(g["thr"][0]), gorl=g["gorl"], overlap=float(g["overlap"]), persistence=int(g["persistence"]), twosided=bool(g["twosided"]))
+    f64 = np.asarray(c["flag"].data)
+    assert f64.dtype == np.int64 and np.array_equal(f64, g["flag"])
