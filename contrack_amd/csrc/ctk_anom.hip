@@ -9,6 +9,13 @@
 // dtype where xarray keeps it.
 #pragma once
 
+// gfx950 only.  k_quantile alone keeps 66 KB of static LDS per workgroup (64 pixels x 257 histogram bins): more than the 64 KB a
+// workgroup gets on gfx90a / gfx942.  The Makefile's ARCH is overridable for gfx950 variants (xnack / sramecc suffixes), not for
+// other parts.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libcontrack_hip.so is written for gfx950 (MI355X): build with ARCH=gfx950"
+#endif
+
 template <typename VT>
 __device__ __forceinline__ bool an_isnan(VT v) { return v != v; }
 

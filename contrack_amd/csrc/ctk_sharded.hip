@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void k_sh_unpack_keep(ResolveDev r, const unsi
                                                         int first_round, int redo, size_t slot, uint32_t capB, int rank, int world, int it_next,
                                                         uint8_t *__restrict__ tdirty, uint32_t *__restrict__ mail)
 {
+    if (r.pstate) for (int64_t t = threadIdx.x; t <= r.T; t += blockDim.x) r.pstate[(size_t)t * CTK_PSTATE_STRIDE] = 0u;      // (the next round of k_rs_pass_sys counts from zero)
     __shared__ uint32_t s_diff_any, s_my_diff;
     if (threadIdx.x == 0) { s_diff_any = 0; s_my_diff = 0; }
     __syncthreads();
@@ -508,6 +509,8 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     CTKCHK(ensure(h, h->sh_amb_list, (size_t)AMB_CAP * 4));
     r.ovr_slot = P<uint32_t>(h->sh_ovr_slot); r.ovr_val = P<double>(h->sh_ovr_val); r.amb_list = P<uint32_t>(h->sh_amb_list); r.amb_cap = AMB_CAP;
     const int npass_grid = r.t_hi - r.t_lo + 1;
+    const bool sys_pass = !getenv("CTK_PASS_LAUNCHES") && T <= 60000;
+    if (sys_pass) { CTKCHK(ensure(h, h->rv_pstate, (size_t)(T + 1) * 4 * CTK_PSTATE_STRIDE)); r.pstate = P<uint32_t>(h->rv_pstate); }
     const int gc = pl.gc, gp = pl.gp, nsb = pl.nsb;
 
     // pinned scalars the device writes for the host
@@ -543,9 +546,15 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         if (it_done + npass > CTK_MAX_JACOBI) COLLECTIVE_FAIL(CTK_E_RANGE, "ctk_track_sharded: overlap filter did not converge within %d passes", CTK_MAX_JACOBI);      // (the rounds are in lockstep)
         {
             Timer tm(h, CTK_K_RESOLVE);
-            if (npass_grid > 0)
-                for (int it = it_done; it < it_done + npass; it++)
-                    k_rs_pass<<<npass_grid, 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
+            if (npass_grid > 0) {
+                if (sys_pass && npass <= 24) {
+                    // all passes of the round in one launch (neighbour hand-shake through pstate, zeroed by k_rs_init / by the
+                    // previous round's k_sh_unpack_keep)
+                    k_rs_pass_sys<<<npass_grid, 64, 0, s>>>(r, it_done, npass, in.pair_base, in.pair_cnt, r.pstate, 0);
+                } else
+                    for (int it = it_done; it < it_done + npass; it++)
+                        k_rs_pass<<<npass_grid, 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
+            }
             HIPCHK(hipGetLastError());
         }
         for (int redo = 0;; redo = 1) {                                  // (repeated only when capB has to grow)
