@@ -678,7 +678,13 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         a.g_x0 = P<uint16_t>(h->g_x0); a.g_x1 = P<uint16_t>(h->g_x1); a.g_y = P<uint16_t>(h->g_y);
         a.g_parent = P<uint32_t>(h->g_parent); a.g_root = P<uint32_t>(h->g_root); a.g_idmap = P<uint32_t>(h->g_idmap);
         if (vs.v2 || vs.v3) HIPCHK(hipEventRecord(h->ev_fork, s));
-        if (vs.v1) k_label2d_lds<1024, 288, -1, 256><<<(int)T, 256, 0, s>>>(a);
+        if (vs.v1) {
+            static const int l2d = getenv("CTK_L2D_VARIANT") ? atoi(getenv("CTK_L2D_VARIANT")) : 0;
+            if (l2d == 1) k_label2d_lds<1024, 96, -1, 256><<<(int)T, 256, 0, s>>>(a);
+            else if (l2d == 2) k_label2d_lds<1024, 96, -1, 128><<<(int)T, 128, 0, s>>>(a);
+            else if (l2d == 3) k_label2d_lds<1024, 288, -1, 128><<<(int)T, 128, 0, s>>>(a);
+            else k_label2d_lds<1024, 288, -1, 256><<<(int)T, 256, 0, s>>>(a);
+        }
         if (vs.v2) {
             HIPCHK(hipStreamWaitEvent(h->side[0], h->ev_fork, 0));
             k_label2d_lds<2048, 512, 1024, 512><<<(int)T, 512, 0, h->side[0]>>>(a);
@@ -1693,11 +1699,13 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
             k_rs_pairs<<<gp, 256, 0, s>>>(r);
         }
         if (!(sys && NP > 0)) k_rs_prep<<<gc, 256, 0, s>>>(r);         // (k_rs_pass_sys does it for its own timestep)
-        if (sys && NP > 0) k_rs_pass_sys<<<(int)(T - 2), 64, 0, s>>>(r, 0, NP, in.pair_base, in.pair_cnt, r.pstate, 1);
+        // (grid: the filtered timesteps 1 .. T-2 and T-1, whose workgroup only unites its pairs)
+        if (sys && NP > 0) k_rs_pass_sys<<<(int)(T - 1), 64, 0, s>>>(r, 0, NP, in.pair_base, in.pair_cnt, r.pstate, 1, 1);
         else
             for (int it = 0; it < NP; it++)
                 k_rs_pass<<<(int)(T - 2), 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
-        if (h->fz_pslot) k_rs_unite_slots<<<(int)std::min<int64_t>((T * h->fz_pslot + 255) / 256 + 1, 4096), 256, 0, s>>>(r, in.pair_cnt, h->fz_pslot);
+        if (sys && NP > 0) { /* united by k_rs_pass_sys */ }
+        else if (h->fz_pslot) k_rs_unite_slots<<<(int)std::min<int64_t>((T * h->fz_pslot + 255) / 256 + 1, 4096), 256, 0, s>>>(r, in.pair_cnt, h->fz_pslot);
         else k_rs_unite<<<gp, 256, 0, s>>>(r);
         k_rs_roots<<<nsb, 256, 0, s>>>(r, P<uint32_t>(h->rv_bsum));
         if (nsb <= CTK_RL_BLOCKS) k_rs_rank_labels<<<nsb, 256, (size_t)nsb * 4, s>>>(r, P<uint32_t>(h->rv_bsum), (uint32_t)nsb, P<uint32_t>(h->rv_boff) + nsb);
@@ -1718,7 +1726,8 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
         Timer tm(h, CTK_K_RUNLABEL);
         k_run_values<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), CPX(h), P<int32_t>(h->comp_label),
                                             P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->d_mrep), 0, 0, P<int32_t>(h->run_val),
-                                            P<uint32_t>(h->rowstart), h->ny, cv_rows, cv, P<uint32_t>(h->counters));
+                                            P<uint32_t>(h->rowstart), h->ny, cv_rows, cv, P<uint32_t>(h->counters),
+                                            P<uint32_t>(h->rv_boff) + nsb, P<uint32_t>(h->seam_off) /* t_alive: [T + 1], unused on this path otherwise */);
         HIPCHK(hipGetLastError());
     }
     {
@@ -1727,7 +1736,7 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     }
     AsyncMail am;
     am.scal = h->h_amail; am.nlab_ptr = P<uint32_t>(h->rv_boff) + nsb; am.nc_ptr = in.cprefix + T;
-    am.changed = r.changed; am.ambig = r.ambig; am.rec_cnt = P<uint32_t>(h->rv_cand_cnt); am.t_nops = sd.t_nops; am.pair_cnt = in.pair_cnt; am.T = T; am.passes = NP;
+    am.changed = r.changed; am.ambig = r.ambig; am.rec_cnt = P<uint32_t>(h->rv_cand_cnt); am.t_nops = sd.t_nops; am.pair_cnt = in.pair_cnt; am.t_alive = P<uint32_t>(h->seam_off); am.T = T; am.passes = NP;
     {
         Timer tm(h, CTK_K_COUNT);
         if (h->last_nlab <= 1000000)                  // (the previous pass' id count: a slab of the same kind)

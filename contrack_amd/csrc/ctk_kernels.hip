@@ -1166,10 +1166,31 @@ __global__ __launch_bounds__(256) void k_run_values(const uint32_t *__restrict__
                                                     // optional: the values again, grouped the way k_relabel_v4 consumes them -- CTK_CV slots per chunk of
                                                     // `rows` rows, so that its workgroups can load them together with their tables (no dependent load)
                                                     const uint32_t *__restrict__ rowstart = nullptr, int ny = 0, int rows = 0,
-                                                    int32_t *__restrict__ chunk_vals = nullptr, const uint32_t *guard = nullptr)
+                                                    int32_t *__restrict__ chunk_vals = nullptr, const uint32_t *guard = nullptr,
+                                                    // fused path: the ids that are present and survive persistence are counted here, a slice of
+                                                    // the ids per workgroup (t_alive[t]); the counting kernel only adds the T numbers up
+                                                    const uint32_t *__restrict__ nlab_ptr = nullptr, uint32_t *__restrict__ t_alive = nullptr)
 {
     if (ctk_guard_bad(guard)) return;
     const int t = (int)blockIdx.x;
+    if (t_alive) {
+        const uint32_t nl = *nlab_ptr, per = (nl + gridDim.x - 1) / gridDim.x;
+        const uint32_t l0 = 1u + (uint32_t)t * per, l1 = min(nl + 1u, l0 + per);
+        uint32_t v = 0;
+        for (uint32_t l = l0 + threadIdx.x; l < l1; l += blockDim.x) {
+            const int64_t lo = ext[l], hi = ext[n_labels + 1 + l];
+            v += (hi >= lo && hi - lo + 1 >= persistence) ? 1u : 0u;
+        }
+        const int tot = __syncthreads_count((int)(v != 0u));             // (per <= 256 in practice: one id per thread; else add up)
+        if (per > blockDim.x) {
+            __shared__ uint32_t sacc;
+            if (threadIdx.x == 0) sacc = 0;
+            __syncthreads();
+            if (v) atomicAdd(&sacc, v);
+            __syncthreads();
+            if (threadIdx.x == 0) t_alive[t] = sacc;
+        } else if (threadIdx.x == 0) t_alive[t] = (uint32_t)tot;
+    }
     const uint32_t rb = run_base[t], n = run_base[t + 1] - rb, cb = cprefix[t];
     __shared__ uint32_t qb[CTK_CV_MAXCHUNK + 1];                        // first run of every chunk
     const int nchunk = chunk_vals ? (ny + rows - 1) / rows : 0;
@@ -1445,6 +1466,7 @@ struct AsyncMail {
     const uint32_t *rec_cnt;        // [T] candidate group records per timestep
     const uint32_t *t_nops;         // [T] relabel operations of the clusters that start in timestep t
     const uint32_t *pair_cnt;       // [T] grouped co-occurrence records per timestep
+    const uint32_t *t_alive;        // [T] surviving ids counted by k_run_values (nullptr: the counting kernel walks the ids itself)
     int64_t T;
     int passes;
 };
@@ -1543,7 +1565,8 @@ __global__ __launch_bounds__(1024) void k_count_alive_1(const int32_t *__restric
         for (int64_t t = threadIdx.x; t < am.T; t += 1024) { nc += am.rec_cnt[t]; no += am.t_nops[t]; np += am.pair_cnt[t]; }
     }
     const int64_t nl = am.scal ? (int64_t)*am.nlab_ptr : n_labels;
-    for (int64_t l = threadIdx.x + 1; l <= nl; l += 1024) {
+    if (am.scal && am.t_alive) { for (int64_t t = threadIdx.x; t < am.T; t += 1024) v += am.t_alive[t]; }
+    else for (int64_t l = threadIdx.x + 1; l <= nl; l += 1024) {
         const int64_t lo = ext[l], hi = ext[n_labels + 1 + l];
         v += (hi >= lo && hi - lo + 1 >= persistence) ? 1u : 0u;
     }

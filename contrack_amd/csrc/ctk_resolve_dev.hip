@@ -141,6 +141,15 @@ __device__ inline double dev_limbs_to_double(int64_t lo, int64_t hi, int wshift,
     return neg ? -d : d;
 }
 
+__device__ __forceinline__ uint32_t gfind(uint32_t *p, uint32_t i)
+{
+    for (;;) {
+        uint32_t q = __hip_atomic_load(&p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (q == i) return i;
+        i = q;
+    }
+}
+
 __global__ void k_rs_init(ResolveDev r)
 {
     const uint32_t nc = dev_ncomps(r);
@@ -354,9 +363,11 @@ __global__ __launch_bounds__(64) void k_rs_pass(ResolveDev r, int it, const uint
 // changed[] (per pass, read by the host / the mailbox) is kept as k_rs_pass keeps it.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_rs_pass_sys(ResolveDev r, int it0, int K, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_cnt,
-                                                    uint32_t *__restrict__ pstate /* [T + 1], zeroed */, int prep_inline /* k_rs_prep's work for this timestep first */)
+                                                    uint32_t *__restrict__ pstate /* [T + 1], zeroed */, int prep_inline /* k_rs_prep's work for this timestep first */,
+                                                    int do_unite /* k_rs_unite's work for the pairs of this timestep last; the grid then also covers t_hi + 1 .. T - 1 */)
 {
     if (dev_tables_bad(r)) return;
+    const int Kfull = K;
     const int t = (int)blockIdx.x + r.t_lo;
     const int lane = (int)threadIdx.x;
     // round trip 1
@@ -364,6 +375,8 @@ __global__ __launch_bounds__(64) void k_rs_pass_sys(ResolveDev r, int it0, int K
     const uint32_t pb = pair_base[t], pn = pair_cnt[t];
     const uint32_t nu = dev_nungrouped(r);
     const uint32_t nct = ce - cb;
+    const bool filtered = t <= r.t_hi;                     // (workgroups behind t_hi only unite their pairs)
+    if (!filtered) K = 0;
     __shared__ long long Bl[2 * CTK_PASS_COMPS];
     const bool lds = nct <= CTK_PASS_COMPS;
     long long *B = lds ? Bl : (long long *)(r.B + 2 * (int64_t)cb);
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(64) void k_rs_pass_sys(ResolveDev r, int it0, int K
     if (has_p) p0 = r.pairs[k0]; else { p0.lo = 0; p0.hi = 0; }
     const uint32_t mrep0 = has_c ? r.mrep[g0] : 0xffffffffu;
     double inv0 = 0.0, ff0 = 0.0;
-    if (prep_inline) {
+    if (prep_inline && filtered) {
         for (uint32_t c = lane; c < nct; c += 64) {
             double a, b;
             dev_prep_comp(r, cb + c, &a, &b);
@@ -482,15 +495,29 @@ __global__ __launch_bounds__(64) void k_rs_pass_sys(ResolveDev r, int it0, int K
             __hip_atomic_store(&pstate[(size_t)t * CTK_PSTATE_STRIDE], ((uint32_t)(k + 1) << 24) | mybits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-}
-
-__device__ __forceinline__ uint32_t gfind(uint32_t *p, uint32_t i)
-{
-    for (;;) {
-        uint32_t q = __hip_atomic_load(&p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (q == i) return i;
-        i = q;
+    if (!do_unite) return;
+    // 3-D links of this timestep (contrack.py:748-750): its kept components with the kept components of t-1 they overlap.  The
+    // predecessor's bits are final once it has published all of its iterations.
+    if (t - 1 >= r.t_lo && t - 1 <= r.t_hi) {
+        const uint32_t need = (uint32_t)Kfull;
+        while ((__hip_atomic_load(&pstate[(size_t)(t - 1) * CTK_PSTATE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 24) < need) __builtin_amdgcn_s_sleep(2);
     }
+    auto link = [&](uint32_t slot) {
+        if (!__hip_atomic_load(&keep[r.p_rc[slot]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+            !__hip_atomic_load(&keep[r.p_rd[slot]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        uint32_t a = r.p_gc[slot], b = r.p_gd[slot];
+        for (;;) {
+            a = gfind(r.parent, a);
+            b = gfind(r.parent, b);
+            if (a == b) break;
+            if (a < b) { const uint32_t q = a; a = b; b = q; }
+            const uint32_t old = atomicMin(&r.parent[a], b);
+            if (old == a) break;
+            a = old;
+        }
+    };
+    for (uint32_t i = lane; i < pn; i += 64) link(pb + i);
+    for (uint32_t i = lane; i < nu; i += 64) { if ((int)r.pairs[r.pair_cap - 1u - i].t == t) link(r.pair_cap - 1u - i); }
 }
 
 __global__ void k_rs_unite(ResolveDev r)

@@ -550,7 +550,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
                 if (sys_pass && npass <= 24) {
                     // all passes of the round in one launch (neighbour hand-shake through pstate, zeroed by k_rs_init / by the
                     // previous round's k_sh_unpack_keep)
-                    k_rs_pass_sys<<<npass_grid, 64, 0, s>>>(r, it_done, npass, in.pair_base, in.pair_cnt, r.pstate, 0);
+                    k_rs_pass_sys<<<npass_grid, 64, 0, s>>>(r, it_done, npass, in.pair_base, in.pair_cnt, r.pstate, 0, 0);
                 } else
                     for (int it = it_done; it < it_done + npass; it++)
                         k_rs_pass<<<npass_grid, 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
