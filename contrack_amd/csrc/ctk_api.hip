@@ -1550,17 +1550,22 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
     a.nrows = nt * h->ny; a.ny = h->ny; a.nx = h->nx; a.W = h->W;
     a.chunk_vals = chunk_vals ? chunk_vals + t0 * nchunk * CTK_CV : nullptr;
     a.guard = h->guard_on ? P<uint32_t>(h->counters) : nullptr;
+    a.plain_stores = getenv("CTK_RELABEL_PLAIN") ? 1 : 0;
     const int64_t npl = (int64_t)h->ny * h->nx;
     const int rvcap = 2048;
     const size_t lds = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) + (size_t)rvcap * 4;
     const int64_t nblk4 = nt * nchunk;
     if ((h->nx % 4 == 0) && (((uintptr_t)flag_dev & 15) == 0) && npl < 0x7fffffff && nblk4 < (1 << 24) && nt > 0 && lds <= 60 * 1024) {
         const unsigned grid = (unsigned)nblk4;
-        // word-centric form while the LDS image of the chunk's values (rows x nx x 4 bytes) leaves eight workgroups per CU
+        // word-centric form: the LDS image of `sub` rows of flag values (sub x nx x 4 bytes) leaves eight workgroups per CU; tall
+        // chunks (the 8-row chunks of slabs with many timesteps) are written in several passes of `sub` rows
         const int rv5 = 512;
-        const size_t lds5 = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) +
-                            (((size_t)rv5 * 4 + 15) & ~(size_t)15) + (size_t)rb * h->nx * 4 + 16;
-        if (lds5 <= 20 * 1024 && !getenv("CTK_RELABEL_V4")) { k_relabel_v5<<<grid, 256, lds5, h->stream>>>(a, rb, rv5); h->stats[CTK_S_RELABEL_KERNEL] = 5; }
+        const size_t tab5 = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) +
+                            (((size_t)rv5 * 4 + 15) & ~(size_t)15) + 16;
+        int sub = rb;
+        while (sub > 1 && tab5 + (size_t)sub * h->nx * 4 > 20 * 1024) sub--;
+        const size_t lds5 = tab5 + (size_t)sub * h->nx * 4;
+        if (lds5 <= 20 * 1024 && !getenv("CTK_RELABEL_V4")) { k_relabel_v5<<<grid, 256, lds5, h->stream>>>(a, rb, rv5, sub); h->stats[CTK_S_RELABEL_KERNEL] = 5; }
         else { k_relabel_v4<<<grid, 256, lds, h->stream>>>(a, rb, rvcap); h->stats[CTK_S_RELABEL_KERNEL] = 4; }
     } else if (nt > 0) {
         a.chunk_vals = nullptr;

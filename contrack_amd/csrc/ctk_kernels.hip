@@ -1239,6 +1239,7 @@ struct RelabelArgs {
     int ny, nx, W;
     const int32_t *chunk_vals;     // [T][nchunk][CTK_CV] (k_run_values) or nullptr
     const uint32_t *guard;         // see ctk_guard_bad
+    int plain_stores;              // experiment: plain instead of non-temporal stores
 };
 
 // fast path (nx % 4 == 0, 16-byte aligned flag): one workgroup per (timestep, 16 rows).  The rows' mask
@@ -1317,7 +1318,7 @@ __global__ __launch_bounds__(256) void k_relabel_v4(RelabelArgs a, int rb, int r
 // assembled in LDS (dynamic LDS: the tables + rvcap * 4 + rows * nx * 4 bytes) and stored from there.  Used while that image
 // leaves room for eight workgroups per CU (1 degree: 11 rows = 15.8 KB; 0.25 degree: 2 rows = 11.5 KB); the 8-row chunks of
 // slabs with millions of chunks stay with k_relabel_v4.
-__global__ __launch_bounds__(256) void k_relabel_v5(RelabelArgs a, int rb, int rvcap)
+__global__ __launch_bounds__(256) void k_relabel_v5(RelabelArgs a, int rb, int rvcap, int sub /* rows per LDS image: rb, or less for tall chunks */)
 {
     if (ctk_guard_bad(a.guard)) return;
     const int ny = a.ny, nx = a.nx, W = a.W;
@@ -1343,63 +1344,69 @@ __global__ __launch_bounds__(256) void k_relabel_v5(RelabelArgs a, int rb, int r
         if (staged) for (uint32_t i = tid; i < nr; i += 256) rvs[i] = rvg[i];
         __syncthreads();
     }
-    // Word-centric: the chunk's flag values are assembled in LDS and stored from there.
-    //   A  zero the LDS image (four 16-byte LDS stores per thread, no mask decoding)
+    // Word-centric: the chunk's flag values are assembled in LDS and stored from there, `sub` rows at a time.
+    //   A  zero the LDS image (16-byte LDS stores, no mask decoding)
     //   B  one thread per mask word that holds foreground (a tenth of the words): every maximal piece of set bits belongs to one
     //      run, whose value is written over the piece's pixels
     //   C  the store stream: LDS -> 16 bytes per lane, 1 KB contiguous per wave instruction, non-temporal
-    // Decoding the mask per four-pixel slot instead (the first form of this kernel) cost some 500 VALU instructions per wave, the
-    // foreground branch being taken by a whole wave whenever one of its 64 slots needed it: the kernel was bound by that, not by
-    // HBM.  The barriers wait for LDS traffic only (no global store precedes them).
-    const int n4 = nx >> 2, total = rows * n4;
-    i32x4 *dst = reinterpret_cast<i32x4 *>(a.flag + row0 * (int64_t)nx);
+    // Decoding the mask per four-pixel slot instead (k_relabel_v4) costs some 500 VALU instructions per wave, the foreground branch
+    // being taken by a whole wave whenever one of its 64 slots needs it: that kernel is bound by those, not by HBM.  The barriers
+    // wait for LDS traffic only (no global store precedes the first two; the third lets the image be zeroed again).
+    const int n4 = nx >> 2;
     int32_t *outv = reinterpret_cast<int32_t *>(smem + ((((size_t)(reinterpret_cast<unsigned char *>(rvs) - smem) + (size_t)rvcap * 4) + 15) & ~(size_t)15));
     i32x4 *outv4 = reinterpret_cast<i32x4 *>(outv);
     bool z = false;
-    for (int i = tid; i < total; i += 256) outv4[i] = (i32x4)(0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const int nw = rows * W;
     const int tail = nx - (W - 1) * 64;                                       // valid bits of a row's last word
-    for (int idx = tid; idx < nw; idx += 256) {
-        const uint64_t m = mrow[idx];
-        const int r = idx / W, w = idx - r * W;
-        const uint64_t valid = (w == W - 1 && tail < 64) ? ((1ull << tail) - 1ull) : FULL64;
-        if (m != valid) z = true;                                               // a background pixel in this word
-        if (m == 0ull) continue;
-        const uint64_t cin = (w > 0) ? (mrow[idx - 1] >> 63) : 0ull;
-        const uint64_t st = m & ~((m << 1) | cin);
-        const uint32_t base = rst[r] - r0 + wst[idx];
-        int32_t *orow = outv + r * nx + w * 64;
-        uint64_t mm = m;
-        while (mm) {
-            const int b = __builtin_ctzll(mm);
-            const uint64_t sh = mm >> b;
-            const int n = (~sh == 0ull) ? 64 : __builtin_ctzll(~sh);
-            const uint64_t below = (b + 1 >= 64) ? FULL64 : ((1ull << (b + 1)) - 1ull);     // bits 0..b
-            const uint32_t k = base + (uint32_t)__popcll(st & below) - 1u;
-            const int32_t val = staged ? rvs[k] : rvg[k];
-            if (val > 0) {                                                      // head up to a multiple of four, 16-byte LDS stores, tail
-                int q = b;
-                const int e = b + n;
-                for (; q < e && (q & 3); q++) orow[q] = val;
-                const i32x4 v4 = (i32x4)(val);
-                for (; q + 4 <= e; q += 4) *reinterpret_cast<i32x4 *>(orow + q) = v4;
-                for (; q < e; q++) orow[q] = val;
-            } else if (val == 0) {
-                z = true;                                                       // filtered out: the zeros are there already
-            } else {                                                            // complex component: fold pixel by pixel
-                for (int q = 0; q < n; q++) {
-                    const int32_t fl = fold_pixel(a.fold, -val, (int32_t)(a.t_begin + t), y0 + r, w * 64 + b + q);
-                    const int32_t v = ((int64_t)a.ext[a.n_labels + 1 + fl] - (int64_t)a.ext[fl] + 1 < a.persistence) ? 0 : fl;
-                    z |= v == 0;
-                    orow[b + q] = v;
+    for (int s0 = 0; s0 < rows; s0 += sub) {
+        const int srows = min(sub, rows - s0), total = srows * n4;
+        i32x4 *dst = reinterpret_cast<i32x4 *>(a.flag + (row0 + s0) * (int64_t)nx);
+        for (int i = tid; i < total; i += 256) outv4[i] = (i32x4)(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int nw = srows * W;
+        for (int k = tid; k < nw; k += 256) {
+            const int idx = s0 * W + k;                                         // word of the chunk
+            const uint64_t m = mrow[idx];
+            const int rr = k / W, w = k - rr * W, r = s0 + rr;
+            const uint64_t valid = (w == W - 1 && tail < 64) ? ((1ull << tail) - 1ull) : FULL64;
+            if (m != valid) z = true;                                           // a background pixel in this word
+            if (m == 0ull) continue;
+            const uint64_t cin = (w > 0) ? (mrow[idx - 1] >> 63) : 0ull;
+            const uint64_t st = m & ~((m << 1) | cin);
+            const uint32_t base = rst[r] - r0 + wst[idx];
+            int32_t *orow = outv + rr * nx + w * 64;
+            uint64_t mm = m;
+            while (mm) {
+                const int b = __builtin_ctzll(mm);
+                const uint64_t sh = mm >> b;
+                const int n = (~sh == 0ull) ? 64 : __builtin_ctzll(~sh);
+                const uint64_t below = (b + 1 >= 64) ? FULL64 : ((1ull << (b + 1)) - 1ull);     // bits 0..b
+                const uint32_t kk = base + (uint32_t)__popcll(st & below) - 1u;
+                const int32_t val = staged ? rvs[kk] : rvg[kk];
+                if (val > 0) {                                                      // head up to a multiple of four, 16-byte LDS stores, tail
+                    int q = b;
+                    const int e = b + n;
+                    for (; q < e && (q & 3); q++) orow[q] = val;
+                    const i32x4 v4 = (i32x4)(val);
+                    for (; q + 4 <= e; q += 4) *reinterpret_cast<i32x4 *>(orow + q) = v4;
+                    for (; q < e; q++) orow[q] = val;
+                } else if (val == 0) {
+                    z = true;                                                       // filtered out: the zeros are there already
+                } else {                                                            // complex component: fold pixel by pixel
+                    for (int q = 0; q < n; q++) {
+                        const int32_t fl = fold_pixel(a.fold, -val, (int32_t)(a.t_begin + t), y0 + r, w * 64 + b + q);
+                        const int32_t v = ((int64_t)a.ext[a.n_labels + 1 + fl] - (int64_t)a.ext[fl] + 1 < a.persistence) ? 0 : fl;
+                        z |= v == 0;
+                        orow[b + q] = v;
+                    }
                 }
+                mm = (n >= 64 - b) ? 0ull : (mm & ~(((1ull << n) - 1ull) << b));
             }
-            mm = (n >= 64 - b) ? 0ull : (mm & ~(((1ull << n) - 1ull) << b));
         }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (a.plain_stores) { for (int i = tid; i < total; i += 256) dst[i] = outv4[i]; }
+        else for (int i = tid; i < total; i += 256) __builtin_nontemporal_store(outv4[i], dst + i);    // (the rows are contiguous: slot i)
+        if (s0 + sub < rows) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // the image is zeroed again
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int i = tid; i < total; i += 256) __builtin_nontemporal_store(outv4[i], dst + i);    // (the chunk's rows are contiguous: slot i)
     if (__ballot(z) && lane_id() == 0) ctk_zf_set(a.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
 }
 

@@ -1,0 +1,13 @@
+# tools/gpu_profile_all.sh <prefix>: rocprofv3 kernel stats + PMC + bench lines of the three large workloads -> profiles/<prefix>_*
+P=${1:-r03a}
+for pair in "era5_1deg_djf30 1deg" "era5_025deg_480 025deg_480" "era5_025deg_10yr 025deg_10yr"; do
+set -- $pair
+bash tools/profile.sh ${P}_$2 $1 > /dev/null 2>&1
+python tools/summarize_profile.py gpurun_out/${P}_$2 gpurun_out/${P}_$2/sum "$1"
+cp gpurun_out/${P}_$2/sum_kernel_stats.csv gpurun_out/${P}_$2_kernel_stats.csv; cp gpurun_out/${P}_$2/sum_pmc.json gpurun_out/${P}_$2_pmc.json; cp gpurun_out/${P}_$2/sum_pmc.md gpurun_out/${P}_$2_pmc.md
+rm -rf gpurun_out/${P}_$2
+python bench.py --steps 20 --warmup 5 --workload $1 > gpurun_out/${P}_bench_$2.json 2> /dev/null
+done
+python bench.py --steps 20 --warmup 5 --workload era5_1deg_90 > gpurun_out/${P}_bench_1deg_90.json 2>/dev/null
+CTK_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 > gpurun_out/${P}_bench_rccl_world1.json 2>/dev/null
+ls -la gpurun_out | grep $P
