@@ -1286,7 +1286,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         k_rs_labels<<<gc, 256, 0, s>>>(r);
         if (T > 0) {
             k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, h->ny, P<uint8_t>(h->rv_mark), P<int2>(h->rv_seam_res));
-            k_rs_cand_groups<<<(int)T, 64, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), P<uint8_t>(h->rv_mark),
+            k_rs_cand_groups<<<(int)((T + FZ_TW - 1) / FZ_TW), 64 * FZ_TW, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), P<uint8_t>(h->rv_mark),
                                                    h->ny, 0, P<uint32_t>(h->rv_cand_cnt), P<CtkCand>(h->rv_cand_scratch));
         }
         k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_cand_cnt), T, P<uint32_t>(h->rv_cand_off), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
@@ -1719,7 +1719,7 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
             k_rs_labels<<<gc, 256, 0, s>>>(r);
         }
         k_fz_mark<<<(int)T, 64, 0, s>>>(r, sd, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res));
-        k_fz_groups<<<(int)T, 64, 0, s>>>(r, sd, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), 0);
+        k_fz_groups<<<(int)((T + FZ_TW - 1) / FZ_TW), 64 * FZ_TW, 0, s>>>(r, sd, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), 0);
         k_seam_driver<<<(int)std::min<int64_t>(T, 65536), 64, 0, s>>>(sd, 0);
         HIPCHK(hipGetLastError());
     }

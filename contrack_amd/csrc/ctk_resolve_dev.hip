@@ -728,45 +728,75 @@ __global__ __launch_bounds__(256) void k_rs_cand_mark(ResolveDev r, const CtkSea
     }
 }
 
+// Reductions onto HOT addresses (the box of a label that lives for hundreds of timesteps is updated by every one of them, from
+// all eight XCDs; same-address device-scope operations serialise at ~20-80 ns each): the kernels below give a workgroup FZ_TW
+// consecutive timesteps, one wave each, reduce into an LDS hash first and touch global memory once per label and workgroup.
+// (Looking before the atomic does not help by itself: the L2s of the XCDs are not coherent with each other, so the look has to be
+// a device-scope load -- just as hot as the atomic.  2000 x 721 x 1440: 0.4-0.7 ms per kernel before, see profiles/NOTES.md.)
+#define FZ_TW 16             // timesteps (waves) of one workgroup
+#define FZ_HS 512            // slots of the label-box hash
+#define FZ_CS 256            // slots of the cluster-range hash
+#define FZ_PROBES 8
+
+__device__ __forceinline__ int fz_slot(int32_t *keys, int mask, int32_t key)
+{
+    uint32_t s = ((uint32_t)key * 2654435761u) >> 16;
+    for (int p = 0; p < FZ_PROBES; p++, s++) {
+        const int32_t old = atomicCAS(&keys[s & mask], 0, key);
+        if (old == 0 || old == key) return (int)(s & mask);
+    }
+    return -1;
+}
+// global min / max after a device-scope look (six loads in flight together, then only the atomics that still change something)
+__device__ __forceinline__ void fz_box_merge(int32_t *b, const int32_t *v)
+{
+    int32_t cur[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) cur[k] = __hip_atomic_load(&b[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (k & 1) { if (v[k] > cur[k]) atomicMax(&b[k], v[k]); }
+        else if (v[k] < cur[k]) atomicMin(&b[k], v[k]);
+    }
+}
+
 // surviving seam rows of timestep t, run-length grouped: consecutive rows (y, y+1, ...) with the same pair of
 // labels become ONE record {t, y0 | y1 << 16, label at x=0, label at x=nx-1}; (t, y) order.  One wave per
 // timestep, one row per lane, group boundaries from ballots; the groups go into a row-indexed scratch, a scan +
 // gather makes them dense.  The same wave adds the boxes of the timestep's components to the boxes of the labels
-// that have a dense id (the only boxes anyone needs).
-__global__ __launch_bounds__(64) void k_rs_cand_groups(ResolveDev r, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
-                                                       const uint32_t *__restrict__ seam_off, const int2 *__restrict__ res,
-                                                       const uint8_t *__restrict__ mark, int ny, int64_t t_begin, uint32_t *__restrict__ cand_cnt,
-                                                       CtkCand *__restrict__ scratch /* [T][ny] */)
+// that have a dense id (the only boxes anyone needs), through the workgroup's LDS hash.
+__global__ __launch_bounds__(64 * FZ_TW) void k_rs_cand_groups(ResolveDev r, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
+                                                               const uint32_t *__restrict__ seam_off, const int2 *__restrict__ res,
+                                                               const uint8_t *__restrict__ mark, int ny, int64_t t_begin, uint32_t *__restrict__ cand_cnt,
+                                                               CtkCand *__restrict__ scratch /* [T][ny] */)
 {
-    const int64_t t = blockIdx.x;
-    const int lane = (int)threadIdx.x;
-    const uint32_t cb = r.cprefix[t], nct = r.cprefix[t + 1] - cb;
+    __shared__ int32_t hk[FZ_HS], hv[FZ_HS][6];
+    for (int s = (int)threadIdx.x; s < FZ_HS; s += 64 * FZ_TW) {
+        hk[s] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) hv[s][k] = (k & 1) ? INT32_MIN : INT32_MAX;
+    }
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * FZ_TW + (threadIdx.x >> 6);
+    const int lane = (int)(threadIdx.x & 63);
+    const bool live = t < r.T;
+    const uint32_t cb = live ? r.cprefix[t] : 0u, nct = live ? r.cprefix[t + 1] - cb : 0u;
+    const int32_t tt = (int32_t)(t_begin + t);
     for (uint32_t c = lane; c < nct; c += 64) {
         const uint32_t g = cb + c;
         const int32_t l = r.lab[g];
         if (l <= 0) continue;
         const uint32_t d = r.dmap[l];
         if (d == 0) continue;
-        int32_t *b = r.dbox + 6 * (int64_t)(d - 1);
         const uint16_t *q = r.box + 4 * (int64_t)g;
-        const int32_t tt = (int32_t)(t_begin + t);
-        // look first: a long-lived label receives one update per timestep and bound, and same-address atomics serialise
-        // (a contour alive for thousands of steps made this kernel 0.7 ms on the 10-year slab).  Plain loads: a stale
-        // bound is only ever looser than the true one, so it can cause a superfluous atomic, never a missing one.
-        // Device-scope loads: the L2s of the eight XCDs are not coherent with each other -- a plain load keeps returning the bound
-        // this XCD saw first, and every timestep of a long-lived label would issue its six atomics again (0.5 ms on the 10-year slab).
-        const int32_t b0 = __hip_atomic_load(&b[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b1 = __hip_atomic_load(&b[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int32_t b2 = __hip_atomic_load(&b[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b3 = __hip_atomic_load(&b[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int32_t b4 = __hip_atomic_load(&b[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b5 = __hip_atomic_load(&b[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tt < b0) atomicMin(&b[0], tt);
-        if (tt > b1) atomicMax(&b[1], tt);
-        if ((int32_t)q[0] < b2) atomicMin(&b[2], (int32_t)q[0]);
-        if ((int32_t)q[1] > b3) atomicMax(&b[3], (int32_t)q[1]);
-        if ((int32_t)q[2] < b4) atomicMin(&b[4], (int32_t)q[2]);
-        if ((int32_t)q[3] > b5) atomicMax(&b[5], (int32_t)q[3]);
+        const int32_t v[6] = {tt, tt, (int32_t)q[0], (int32_t)q[1], (int32_t)q[2], (int32_t)q[3]};
+        const int s = fz_slot(hk, FZ_HS - 1, (int32_t)d);
+        if (s < 0) { fz_box_merge(r.dbox + 6 * (int64_t)(d - 1), v); continue; }        // (a crowded hash: straight to memory)
+#pragma unroll
+        for (int k = 0; k < 6; k++) { if (k & 1) atomicMax(&hv[s][k], v[k]); else atomicMin(&hv[s][k], v[k]); }
     }
-    const uint32_t n = seam_cnt[t];
-    const CtkSeam *sc = seams + seam_off[t];
+    const uint32_t n = live ? seam_cnt[t] : 0u;
+    const CtkSeam *sc = seams + (live ? seam_off[t] : 0u);
     const int2 *rs = res + t * ny;
     CtkCand *dst = scratch + t * ny;                      // at most one group per seam row
     // 64 rows per step, one per lane.  A row STARTS a group unless the previous row is valid, carries the same pair of
@@ -775,7 +805,6 @@ __global__ __launch_bounds__(64) void k_rs_cand_groups(ResolveDev r, const CtkSe
     uint32_t ng = 0;
     bool c_valid = false;
     int32_t c_ll = 0, c_lr = 0, c_y = 0;
-    const int32_t tt = (int32_t)(t_begin + t);
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + lane;
         int2 v = make_int2(-1, -1);
@@ -804,10 +833,12 @@ __global__ __launch_bounds__(64) void k_rs_cand_groups(ResolveDev r, const CtkSe
         c_valid = (V >> 63) & 1ull;
         c_ll = __shfl(v.x, 63); c_lr = __shfl(v.y, 63); c_y = __shfl(y, 63);
     }
-    if (lane == 0) {
+    if (lane == 0 && live) {
         if (c_valid) reinterpret_cast<uint16_t *>(&dst[ng - 1u].yy)[1] = (uint16_t)c_y;
         cand_cnt[t] = ng;
     }
+    __syncthreads();
+    for (int s = (int)threadIdx.x; s < FZ_HS; s += 64 * FZ_TW) if (hk[s]) fz_box_merge(r.dbox + 6 * (int64_t)(hk[s] - 1), hv[s]);
 }
 
 // What the host needs after the resolver kernels, written by the device straight into pinned host memory (no copy

@@ -81,35 +81,51 @@ __global__ __launch_bounds__(64) void k_fz_mark(ResolveDev r, SeamDev a, const C
 }
 
 // k_rs_cand_groups for the fused path: boxes of the marked labels, surviving seam rows run-length grouped, and for every group
-// record the root of its cluster and the cluster's range of timesteps (the unions are complete: k_fz_mark is a launch of its own)
-__global__ __launch_bounds__(64) void k_fz_groups(ResolveDev r, SeamDev a, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
-                                                  const uint32_t *__restrict__ seam_off, const int2 *__restrict__ res, int64_t t_begin)
+// record the root of its cluster and the cluster's range of timesteps (the unions are complete: k_fz_mark is a launch of its own).
+//
+// A workgroup takes FZ_TW consecutive timesteps, one wave each.  The label boxes and the cluster ranges are min / max reductions
+// whose addresses are HOT: a label that lives for hundreds of timesteps is updated by every one of them, from all eight XCDs,
+// and same-address device-scope operations serialise at ~20-80 ns each (2000 x 721 x 1440: 0.4 ms of this kernel).  The waves of
+// a workgroup therefore reduce into an LDS hash first and the workgroup touches global memory once per label: FZ_TW times fewer
+// hot operations.  (Looking before the atomic does not help by itself: the L2s of the XCDs are not coherent with each other, so
+// the look has to be a device-scope load -- just as hot as the atomic.)
+__device__ __forceinline__ void fz_range_merge(SeamDev &a, uint32_t root, int32_t lo, int32_t hi)
+{
+    if (lo < __hip_atomic_load(&a.cl_tmin[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&a.cl_tmin[root], lo);
+    if (hi > __hip_atomic_load(&a.cl_tmax[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.cl_tmax[root], hi);
+}
+
+__global__ __launch_bounds__(64 * FZ_TW) void k_fz_groups(ResolveDev r, SeamDev a, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
+                                                          const uint32_t *__restrict__ seam_off, const int2 *__restrict__ res, int64_t t_begin)
 {
     if (dev_tables_bad(r)) return;
-    const int64_t t = blockIdx.x;
-    const int lane = (int)threadIdx.x;
+    __shared__ int32_t hk[FZ_HS], hv[FZ_HS][6], ck[FZ_CS], cv[FZ_CS][2];
+    for (int s = (int)threadIdx.x; s < FZ_HS; s += 64 * FZ_TW) {
+        hk[s] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) hv[s][k] = (k & 1) ? INT32_MIN : INT32_MAX;
+    }
+    for (int s = (int)threadIdx.x; s < FZ_CS; s += 64 * FZ_TW) { ck[s] = 0; cv[s][0] = INT32_MAX; cv[s][1] = INT32_MIN; }
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * FZ_TW + (threadIdx.x >> 6);
+    const int lane = (int)(threadIdx.x & 63);
     const int ny = a.ny;
-    const uint32_t cb = r.cprefix[t], nct = r.cprefix[t + 1] - cb;
+    const bool live = t < a.T;
+    const uint32_t cb = live ? r.cprefix[t] : 0u, nct = live ? r.cprefix[t + 1] - cb : 0u;
     const int32_t tt = (int32_t)(t_begin + t);
     for (uint32_t c = lane; c < nct; c += 64) {
         const uint32_t g = cb + c;
         const int32_t l = r.lab[g];
         if (l <= 0 || !a.mark[l]) continue;
-        int32_t *b = a.lbox + 6 * (int64_t)l;
         const uint16_t *q = r.box + 4 * (int64_t)g;
-        // look first (device-scope loads: the L2s of the XCDs are not coherent with each other); a stale bound is only looser
-        const int32_t b0 = __hip_atomic_load(&b[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b1 = __hip_atomic_load(&b[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int32_t b2 = __hip_atomic_load(&b[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b3 = __hip_atomic_load(&b[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int32_t b4 = __hip_atomic_load(&b[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b5 = __hip_atomic_load(&b[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tt < b0) atomicMin(&b[0], tt);
-        if (tt > b1) atomicMax(&b[1], tt);
-        if ((int32_t)q[0] < b2) atomicMin(&b[2], (int32_t)q[0]);
-        if ((int32_t)q[1] > b3) atomicMax(&b[3], (int32_t)q[1]);
-        if ((int32_t)q[2] < b4) atomicMin(&b[4], (int32_t)q[2]);
-        if ((int32_t)q[3] > b5) atomicMax(&b[5], (int32_t)q[3]);
+        const int32_t v[6] = {tt, tt, (int32_t)q[0], (int32_t)q[1], (int32_t)q[2], (int32_t)q[3]};
+        const int s = fz_slot(hk, FZ_HS - 1, l);
+        if (s < 0) { fz_box_merge(a.lbox + 6 * (int64_t)l, v); continue; }        // (a crowded hash: straight to memory)
+#pragma unroll
+        for (int k = 0; k < 6; k++) { if (k & 1) atomicMax(&hv[s][k], v[k]); else atomicMin(&hv[s][k], v[k]); }
     }
-    const uint32_t n = seam_cnt[t];
-    const CtkSeam *sc = seams + seam_off[t];
+    const uint32_t n = live ? seam_cnt[t] : 0u;
+    const CtkSeam *sc = seams + (live ? seam_off[t] : 0u);
     const int2 *rs = res + t * ny;
     CtkCand *dst = a.recs + t * ny;                        // at most one group per seam row
     uint32_t ng = 0;
@@ -136,8 +152,9 @@ __global__ __launch_bounds__(64) void k_fz_groups(ResolveDev r, SeamDev a, const
             CtkCand g; g.t = tt; g.yy = y | (y << 16); g.ll = v.x; g.lr = v.y; dst[idx] = g;
             const uint32_t root = gfind(a.cl_parent, (uint32_t)v.x);
             a.rec_root[t * ny + idx] = root;
-            if ((int32_t)t < __hip_atomic_load(&a.cl_tmin[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&a.cl_tmin[root], (int32_t)t);
-            if ((int32_t)t > __hip_atomic_load(&a.cl_tmax[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.cl_tmax[root], (int32_t)t);
+            const int cs = fz_slot(ck, FZ_CS - 1, (int32_t)root);                  // (roots are labels: >= 1)
+            if (cs < 0) fz_range_merge(a, root, (int32_t)t, (int32_t)t);
+            else { atomicMin(&cv[cs][0], (int32_t)t); atomicMax(&cv[cs][1], (int32_t)t); }
         }
         if (lane == 0 && c_valid && (!valid || start)) reinterpret_cast<uint16_t *>(&dst[ng - 1u].yy)[1] = (uint16_t)c_y;
         if (valid && lane < 63) {
@@ -148,10 +165,13 @@ __global__ __launch_bounds__(64) void k_fz_groups(ResolveDev r, SeamDev a, const
         c_valid = (V >> 63) & 1ull;
         c_ll = __shfl(v.x, 63); c_lr = __shfl(v.y, 63); c_y = __shfl(y, 63);
     }
-    if (lane == 0) {
+    if (lane == 0 && live) {
         if (c_valid) reinterpret_cast<uint16_t *>(&dst[ng - 1u].yy)[1] = (uint16_t)c_y;
         a.rec_cnt[t] = ng;
     }
+    __syncthreads();
+    for (int s = (int)threadIdx.x; s < FZ_HS; s += 64 * FZ_TW) if (hk[s]) fz_box_merge(a.lbox + 6 * (int64_t)hk[s], hv[s]);
+    for (int s = (int)threadIdx.x; s < FZ_CS; s += 64 * FZ_TW) if (ck[s]) fz_range_merge(a, (uint32_t)ck[s], cv[s][0], cv[s][1]);
 }
 
 // wave-wide min / max of one int per lane (every lane gets the result): DPP inside the rows of 16 lanes (quad swaps, half-row and
