@@ -656,7 +656,10 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     const uint32_t scan_stamp = (uint32_t)(h->pass_no & 0x7fffffffu) | 0x80000000u;
     {
         Timer tm(h, CTK_KI_ROWCOUNT);
-        if (T > 0) k_rowcount<<<(int)T, 256, 0, s>>>(P<uint64_t>(h->mask), ny, W, P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart), P<uint32_t>(h->tcount));
+        // one workgroup per timestep: few timesteps of a tall grid leave the chip empty and the rows of a plane in a long chain
+        // (480 x 721 x 1440: 52 us with 4 waves per plane) -- more waves per plane then (first form of the kernel only)
+        const int rc_threads = (W <= 64 && ny <= RC_ROWS && ny > 256) ? (T <= 1024 ? 1024 : T <= 2048 ? 512 : 256) : 256;
+        if (T > 0) k_rowcount<<<(int)T, rc_threads, 0, s>>>(P<uint64_t>(h->mask), ny, W, P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart), P<uint32_t>(h->tcount));
         k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, h->h_mail1,
                                       nullptr, scan_stamp);
         HIPCHK(hipGetLastError());

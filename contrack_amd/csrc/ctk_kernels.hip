@@ -244,11 +244,12 @@ __global__ __launch_bounds__(256) void k_threshold(const TIN *__restrict__ anom,
 //   tcount[t]      = runs of the timestep
 // ------------------------------------------------------------------------------------------------
 #define RC_ROWS 2048
-__global__ __launch_bounds__(256) void k_rowcount(const uint64_t *__restrict__ mask, int ny, int W, uint16_t *__restrict__ wstart,
+__global__ __launch_bounds__(1024) void k_rowcount(const uint64_t *__restrict__ mask, int ny, int W, uint16_t *__restrict__ wstart,
                                                   uint32_t *__restrict__ rowstart, uint32_t *__restrict__ tcount)
 {
     const int t = (int)blockIdx.x, tid = (int)threadIdx.x;
-    __shared__ uint32_t sm[8];
+    __shared__ uint32_t sm[17];
+    const int nthr = (int)blockDim.x, nwv = nthr >> 6;       // 256 threads, or up to 1024 in the first form when the timesteps alone do not fill the chip
     uint32_t carry_rows = 0;
     if (W <= 64 && ny <= RC_ROWS) {
         // Rows to waves: a wave takes floor(64 / W) whole rows per step, RCU steps' words in flight; the prefix inside a row is a
@@ -262,11 +263,11 @@ __global__ __launch_bounds__(256) void k_rowcount(const uint64_t *__restrict__ m
         const int seg = lane / W, wl = lane - seg * W;             // row of the step and word of the row this lane holds
         const bool lane_used = seg < rpw;
         const int64_t base = (int64_t)t * ny;
-        for (int y0 = wv * rpw; y0 < ny; y0 += 4 * rpw * RCU) {
+        for (int y0 = wv * rpw; y0 < ny; y0 += nwv * rpw * RCU) {
             uint64_t m[RCU], pv[RCU];
 #pragma unroll
             for (int u = 0; u < RCU; u++) {
-                const int y = y0 + u * 4 * rpw + seg;
+                const int y = y0 + u * nwv * rpw + seg;
                 m[u] = 0; pv[u] = 0;
                 if (lane_used && y < ny) {
                     const uint64_t *mw = mask + (base + y) * W;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void k_rowcount(const uint64_t *__restrict__ m
             }
 #pragma unroll
             for (int u = 0; u < RCU; u++) {
-                const int y = y0 + u * 4 * rpw + seg;
+                const int y = y0 + u * nwv * rpw + seg;
                 const uint32_t c = (uint32_t)__popcll(m[u] & ~((m[u] << 1) | (pv[u] >> 63)));
                 uint32_t inc = c;                                  // inclusive scan inside the row's W lanes
 #pragma unroll
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void k_rowcount(const uint64_t *__restrict__ m
             }
         }
         __syncthreads();
-        for (int yb = 0; yb < ny; yb += 256) {
+        for (int yb = 0; yb < ny; yb += nthr) {
             const int y = yb + tid;
             uint32_t tot;
             const uint32_t ex = block_excl_scan(y < ny ? rowtot[y] : 0u, sm, &tot);
