@@ -136,8 +136,16 @@ __global__ void k_sh_pack_keep(ResolveDev r, int it_first, int it_count, uint32_
 #define CTK_SHM_MAXFLAGGED 10
 __global__ __launch_bounds__(256) void k_sh_unpack_keep(ResolveDev r, const unsigned char *__restrict__ gathered, unsigned char *__restrict__ prev,
                                                         int first_round, int redo, size_t slot, uint32_t capB, int rank, int world, int it_next,
-                                                        uint8_t *__restrict__ tdirty, uint32_t *__restrict__ mail)
+                                                        uint8_t *__restrict__ tdirty, uint32_t *__restrict__ mail,
+                                                        // speculative X4: the boundary records travel with the bits (offset bound_off inside a
+                                                        // rank's payload, bslot bytes) and go straight into pinned host memory
+                                                        size_t bound_off, size_t bslot, uint32_t *__restrict__ bound_pinned)
 {
+    if (bound_off)
+        for (int q = 0; q < world; q++) {
+            const uint32_t *src = (const uint32_t *)(gathered + (size_t)q * slot + bound_off);
+            for (size_t i = threadIdx.x; i < bslot / 4; i += blockDim.x) bound_pinned[(size_t)q * (bslot / 4) + i] = src[i];
+        }
     if (r.pstate) for (int64_t t = threadIdx.x; t <= r.T; t += blockDim.x) r.pstate[(size_t)t * CTK_PSTATE_STRIDE] = 0u;      // (the next round of k_rs_pass_sys counts from zero)
     __shared__ uint32_t s_diff_any, s_my_diff;
     if (threadIdx.x == 0) { s_diff_any = 0; s_my_diff = 0; }
@@ -165,7 +173,11 @@ __global__ __launch_bounds__(256) void k_sh_unpack_keep(ResolveDev r, const unsi
     }
     if (d) s_diff_any = 1;
     __syncthreads();
-    for (size_t i = threadIdx.x; i < (size_t)world * slot; i += blockDim.x) prev[i] = gathered[i];
+    {
+        const size_t kb = sizeof(KeepHeader) + (size_t)capB;                 // (the bits are all the next round compares)
+        for (int q = 0; q < world; q++)
+            for (size_t i = threadIdx.x; i < kb; i += blockDim.x) prev[(size_t)q * slot + i] = gathered[(size_t)q * slot + i];
+    }
     if (threadIdx.x == 0) {
         uint32_t nc_any = 0, mx = 0, amb = 0, bad = 0, hc = 0, hd_ = 0, mxf = 0;
         uint64_t ncs = 0;
@@ -216,6 +228,12 @@ __global__ void k_sh_pack_boundary(ResolveDev r, uint32_t capB, unsigned char *_
     }
 }
 
+// the tables indexed by GLOBAL ids start empty (one launch instead of three fill commands, ~5 us of stream time each)
+__global__ void k_sh_clear_tables(uint8_t *__restrict__ mark, uint32_t *__restrict__ dmap, int32_t *__restrict__ op_first, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { mark[i] = 0; dmap[i] = 0u; op_first[i] = -1; }
+}
+
 // scipy's ids from the local root ranks and the boundary resolution (pinned staging written by the host):
 //   st[0..1] = off (int64), st[2] = nA, st[3] = nmark, then A[nA], Alab[nA], halo_label[nh], mark_labels[nmark]
 __global__ void k_rs_labels_sh(ResolveDev r, const int32_t *__restrict__ st, uint8_t *__restrict__ mark)
@@ -250,25 +268,90 @@ __global__ void k_rs_labels_sh(ResolveDev r, const int32_t *__restrict__ st, uin
     }
 }
 
-// X6: time extents of the ids shared between shards
-__global__ void k_sh_pack_ext(const int32_t *__restrict__ elist, int32_t ne, const int32_t *__restrict__ ext, int64_t n_labels, int32_t *__restrict__ out)
+// X6 (+ X7): time extents of the ids shared between shards, and the counts.  Payload of one rank:
+//   [alive_own, zero_seen][lo, hi of every shared id]
+// alive_own = ids numbered by THIS shard (l0 < id <= l1) that no other shard knows (not in elist), are present and survive
+// persistence -- their extents are final before the exchange; the shared ids are counted by everybody from the reduced extents.
+// zero_seen = a background pixel in a sample of the shard's mask: the output then certainly holds a 0 (len(np.unique) counts it,
+// contrack.py:793).  Only when NO rank has seen one do the flags of the write pass have to be exchanged afterwards (k_sh_count).
+// SH_PE_BLOCKS workgroups share the ids (a single one walked 33 000 ids in 15 us); each keeps the sorted list of shared ids in
+// LDS for its searches; partial counts meet in two counters (zeroed by k_ops_ingest), the last workgroup writes the header.
+// Lists beyond SH_PE_LDS ids: one workgroup, the list in global memory.
+#define SH_PE_BLOCKS 32
+#define SH_PE_LDS 2048
+__global__ __launch_bounds__(256) void k_sh_pack_ext(const int32_t *__restrict__ elist_pinned, int32_t ne, const int32_t *__restrict__ ext, int64_t n_labels,
+                                                     int64_t l0, int64_t l1, int persistence, const uint64_t *__restrict__ mask, int64_t nsample, int W,
+                                                     uint64_t last_full /* valid bits of a row's last word */, int32_t *__restrict__ elist, int32_t *__restrict__ out,
+                                                     uint32_t *__restrict__ counters)
 {
-    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += gridDim.x * blockDim.x) {
-        const int32_t l = elist[i];
-        out[2 * i] = ext[l]; out[2 * i + 1] = ext[n_labels + 1 + l];
+    __shared__ int32_t el[SH_PE_LDS];
+    const int tid = (int)threadIdx.x;
+    const bool in_lds = ne <= SH_PE_LDS;                                   // (else the launch has one workgroup)
+    for (int32_t i = tid; i < ne; i += 256) { const int32_t l = elist_pinned[i]; if (in_lds) el[i] = l; if (!in_lds || blockIdx.x == 0) elist[i] = l; }
+    __threadfence_block();
+    __syncthreads();
+    const int32_t *E = in_lds ? el : elist;
+    const int64_t gtid = (int64_t)blockIdx.x * 256 + tid, gsize = (int64_t)gridDim.x * 256;
+    for (int64_t i = gtid; i < ne; i += gsize) {
+        const int32_t l = E[i];
+        out[2 + 2 * i] = ext[l]; out[2 + 2 * i + 1] = ext[n_labels + 1 + l];
+    }
+    uint32_t v = 0;
+    for (int64_t l = l0 + 1 + gtid; l <= l1; l += gsize) {
+        const int64_t lo = ext[l], hi = ext[n_labels + 1 + l];
+        if (!(hi >= lo && hi - lo + 1 >= persistence)) continue;
+        int a = 0, b = ne;                                                   // first shared id >= l
+        while (a < b) { const int m = (a + b) >> 1; if (E[m] < (int32_t)l) a = m + 1; else b = m; }
+        if (!(a < ne && E[a] == (int32_t)l)) v++;
+    }
+    bool bg = false;
+    for (int64_t k = gtid; k < nsample; k += gsize) bg = bg || mask[k] != (((int)(k % W) == W - 1) ? last_full : ~0ull);
+    __shared__ uint32_t sm[4], sz[4];
+    __shared__ bool last;
+    const uint32_t sv = wave_sum_u32(v);
+    const bool zany = __ballot(bg) != 0ull;
+    if (lane_id() == 0) { sm[tid >> 6] = sv; sz[tid >> 6] = zany ? 1u : 0u; }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t tot = sm[0] + sm[1] + sm[2] + sm[3], z = sz[0] | sz[1] | sz[2] | sz[3];
+        if (tot) atomicAdd(&counters[CTK_CNT_ALIVE], tot);
+        if (z) atomicOr(&counters[CTK_CNT_WROTE_ZERO], 1u);
+        __threadfence();
+        last = atomicAdd(&counters[CTK_CNT_TICKET], 1u) == gridDim.x - 1;
+        if (last) {
+            out[0] = (int32_t)__hip_atomic_load(&counters[CTK_CNT_ALIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out[1] = (int32_t)__hip_atomic_load(&counters[CTK_CNT_WROTE_ZERO], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
-__global__ void k_sh_reduce_ext(const int32_t *__restrict__ elist, int32_t ne, const int32_t *__restrict__ gathered, int world, int32_t *__restrict__ ext,
-                                int64_t n_labels)
+// after the all-gather: extents of the shared ids = min / max over the shards; the job's count = everybody's own ids + the shared
+// ids that survive; both go straight into pinned host memory (mail[0] = surviving ids, mail[1] = some rank has seen a 0)
+__global__ __launch_bounds__(1024) void k_sh_reduce_ext(const int32_t *__restrict__ elist, int32_t ne, const int32_t *__restrict__ gathered, int world,
+                                                        int32_t *__restrict__ ext, int64_t n_labels, int persistence, uint32_t *__restrict__ mail)
 {
-    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += gridDim.x * blockDim.x) {
+    const size_t sw = 2 + 2 * (size_t)ne;                                  // words of one rank's payload
+    uint32_t v = 0;
+    for (int32_t i = (int32_t)threadIdx.x; i < ne; i += 1024) {
         int32_t lo = INT32_MAX, hi = INT32_MIN;
         for (int q = 0; q < world; q++) {
-            lo = min(lo, gathered[(size_t)q * 2 * ne + 2 * i]);
-            hi = max(hi, gathered[(size_t)q * 2 * ne + 2 * i + 1]);
+            lo = min(lo, gathered[(size_t)q * sw + 2 + 2 * i]);
+            hi = max(hi, gathered[(size_t)q * sw + 2 + 2 * i + 1]);
         }
         const int32_t l = elist[i];
         ext[l] = lo; ext[n_labels + 1 + l] = hi;
+        v += (hi >= lo && (int64_t)hi - (int64_t)lo + 1 >= persistence) ? 1u : 0u;
+    }
+    uint32_t own = 0, z = 0;
+    for (int q = (int)threadIdx.x; q < world; q += 1024) { own += (uint32_t)gathered[(size_t)q * sw]; z |= (uint32_t)gathered[(size_t)q * sw + 1]; }
+    __shared__ uint32_t sm[16], sz[16];
+    const uint32_t sv = wave_sum_u32(v + own);
+    const bool zany = __ballot(z != 0u) != 0ull;
+    if (lane_id() == 0) { sm[threadIdx.x >> 6] = sv; sz[threadIdx.x >> 6] = zany ? 1u : 0u; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0, zz = 0;
+        for (int i = 0; i < 16; i++) { tot += sm[i]; zz |= sz[i]; }
+        mail[0] = tot; mail[1] = zz;
     }
 }
 // ids numbered by THIS shard (l0 < id <= l1) that are present and survive persistence; + "a zero was written"
@@ -540,6 +623,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     }
     SHDBG("rs P1");
     bool fix_changed = false, last_was_fixup = false;
+    bool spec = false, parent_dirty = false;         // see "Speculative X4" below
     int n_fixups = 0;
     for (;;) {
         const int npass = first_round ? h->filter_round : std::max(2, h->filter_round / 2);
@@ -557,16 +641,36 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
             }
             HIPCHK(hipGetLastError());
         }
+        // Speculative X4: if this round turns out to be the last one (nobody changed anything), the 3-D labelling of the shard --
+        // unions, roots, local ranks -- is what X4 would compute next, and its boundary record can travel with the bits: one
+        // exchange less.  A round that is not the last wasted the labelling (~50 us at 1 deg).  The rule has to give the same answer
+        // on every rank (the payload size depends on it), so it uses nothing a handle remembers: with one shard the first
+        // round is the last unless the filter itself needs more passes; with several shards a dropped component on any boundary
+        // means a second round, so the first one does not speculate and every later one does.
+        spec = first_round ? world == 1 : true;
+        if (getenv("CTK_NO_SPEC_X4")) spec = false;                      // (experiments: set it for every rank or for none)
+        if (spec) {
+            Timer tm(h, CTK_K_RESOLVE);
+            if (parent_dirty) k_rs_parent_init<<<gc, 256, 0, s>>>(r);
+            k_rs_unite<<<gp, 256, 0, s>>>(r);
+            k_rs_roots<<<nsb, 256, 0, s>>>(r, P<uint32_t>(h->rv_bsum));                       // (nsb blocks of 256 components)
+            k_rs_rank<<<nsb, 256, 0, s>>>(r.isroot, in.cprefix + T, P<uint32_t>(h->rv_bsum), r.rank, P<uint32_t>(h->rv_boff) + nsb);
+            HIPCHK(hipGetLastError());
+            parent_dirty = true;
+        }
         for (int redo = 0;; redo = 1) {                                  // (repeated only when capB has to grow)
-            const size_t slot = sizeof(KeepHeader) + ctk_align8(capB);
+            const size_t kslot = sizeof(KeepHeader) + ctk_align8(capB), bslot = sizeof(BoundHeader) + (size_t)capB * 8;
+            const size_t slot = kslot + bslot;
             CTKCHK(ensure(h, h->sh_send, slot));
             CTKCHK(ensure(h, h->sh_recv, slot * (size_t)world));
+            CTKCHK(ensure_host(&h->h_shard, &h->h_shard_cap, bslot * (size_t)world + 4096, true));
             if (h->sh_prev.cap < slot * (size_t)world) { CTKCHK(ensure(h, h->sh_prev, slot * (size_t)world)); if (!first_round) return ctk_set_error(CTK_E_INTERNAL, "boundary buffer grew between rounds"); }
             k_sh_pack_keep<<<8, 256, 0, s>>>(r, it_done, npass_grid > 0 ? npass : 0, capB, h->sh_capC, h->sh_capD, fix_changed ? 1u : 0u, (unsigned char *)h->sh_send.p);
+            if (spec) k_sh_pack_boundary<<<8, 256, 0, s>>>(r, capB, (unsigned char *)h->sh_send.p + kslot);
             HIPCHK(hipGetLastError());
             CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, slot));
             k_sh_unpack_keep<<<1, 256, 0, s>>>(r, (const unsigned char *)h->sh_recv.p, (unsigned char *)h->sh_prev.p, first_round ? 1 : 0, redo, slot, capB, rank, world,
-                                               it_done + npass, P<uint8_t>(h->rv_tdirty), mail2);
+                                               it_done + npass, P<uint8_t>(h->rv_tdirty), mail2, spec ? kslot : 0, bslot, (uint32_t *)h->h_shard);
             HIPCHK(hipGetLastError());
             CTKCHK(ctk_comm_wait(c));
             if (mail2[CTK_SHM_MAXNLAST] <= capB) break;
@@ -636,19 +740,23 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     CTKCHK(ensure(h, h->sh_send, bslot));
     CTKCHK(ensure(h, h->sh_recv, bslot * (size_t)world));
     CTKCHK(ensure_host(&h->h_shard, &h->h_shard_cap, bslot * (size_t)world + 4096, true));
-    {
-        Timer tm(h, CTK_K_RESOLVE);
-        k_rs_unite<<<gp, 256, 0, s>>>(r);
-        const uint32_t *ncp = in.cprefix + T;
-        k_rs_roots<<<nsb, 256, 0, s>>>(r, P<uint32_t>(h->rv_bsum));                       // (nsb blocks of 256 components)
-        k_rs_rank<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_bsum), r.rank, P<uint32_t>(h->rv_boff) + nsb);
-        k_sh_pack_boundary<<<8, 256, 0, s>>>(r, capB, (unsigned char *)h->sh_send.p);
-        HIPCHK(hipGetLastError());
+    h->stats[CTK_S_X4_SPECULATED] = spec ? 1 : 0;
+    if (!spec) {                                      // (the last round did not carry the boundary records: X4 as an exchange of its own)
+        {
+            Timer tm(h, CTK_K_RESOLVE);
+            if (parent_dirty) k_rs_parent_init<<<gc, 256, 0, s>>>(r);
+            k_rs_unite<<<gp, 256, 0, s>>>(r);
+            const uint32_t *ncp = in.cprefix + T;
+            k_rs_roots<<<nsb, 256, 0, s>>>(r, P<uint32_t>(h->rv_bsum));                       // (nsb blocks of 256 components)
+            k_rs_rank<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_bsum), r.rank, P<uint32_t>(h->rv_boff) + nsb);
+            k_sh_pack_boundary<<<8, 256, 0, s>>>(r, capB, (unsigned char *)h->sh_send.p);
+            HIPCHK(hipGetLastError());
+        }
+        SHDBG("pack boundary");
+        CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, bslot));
+        HIPCHK(hipMemcpyAsync(h->h_shard, h->sh_recv.p, bslot * (size_t)world, hipMemcpyDeviceToHost, s));
+        CTKCHK(ctk_comm_wait(c));
     }
-    SHDBG("pack boundary");
-    CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, bslot));
-    HIPCHK(hipMemcpyAsync(h->h_shard, h->sh_recv.p, bslot * (size_t)world, hipMemcpyDeviceToHost, s));
-    CTKCHK(ctk_comm_wait(c));
     S.bin.assign((size_t)world, BoundaryIn());
     for (int q = 0; q < world; q++) {
         const unsigned char *p = (const unsigned char *)h->h_shard + (size_t)q * bslot;
@@ -692,9 +800,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     CandMail &mail = pl.mail;
     {
         Timer tm(h, CTK_K_RESOLVE);
-        HIPCHK(hipMemsetAsync(h->rv_mark.p, 0, (size_t)NL + 2, s));
-        HIPCHK(hipMemsetAsync(h->rv_dmap.p, 0, ((size_t)NL + 2) * 4, s));
-        HIPCHK(hipMemsetAsync(h->op_first.p, 0xff, ((size_t)NL + 2) * 4, s));
+        k_sh_clear_tables<<<(int)std::min<int64_t>((NL + 2 + 255) / 256, 2048), 256, 0, s>>>(P<uint8_t>(h->rv_mark), P<uint32_t>(h->rv_dmap), P<int32_t>(h->op_first), NL + 2);
         k_rs_labels_sh<<<gc, 256, 0, s>>>(r, (const int32_t *)h->h_lab, P<uint8_t>(h->rv_mark));
         k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, ny, P<uint8_t>(h->rv_mark), P<int2>(h->rv_seam_res));
         k_rs_cand_groups<<<(int)((T + FZ_TW - 1) / FZ_TW), 64 * FZ_TW, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), P<uint8_t>(h->rv_mark), ny, t_begin,
@@ -733,28 +839,59 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     const CtkCand *hc = (const CtkCand *)dst;
     const int32_t *ho = (const int32_t *)(dst + cb), *hbx = ho + nd;
 
+    static const bool hostprof = getenv("CTK_HOSTPROF") != nullptr;
+    static double hp_acc[8] = {0}; static int hp_n = 0;
+    double hp_t = now_ms();
+    auto HP = [&](int k) { if (hostprof) { const double n = now_ms(); hp_acc[k] += n - hp_t; hp_t = n; } };
     // ---- X5: seam merges.  Candidate groups connected (through shared rows) to a label that reaches a shard boundary are
     // shared: all-gathered and driven identically everywhere; the others are this shard's own. ------------------------------
     const double t_host = now_ms();
-    S.uf.resize(nd);
-    for (size_t i = 0; i < nd; i++) S.uf[i] = (int32_t)i;
-    auto find = [&](int32_t i) { while (S.uf[(size_t)i] != i) { S.uf[(size_t)i] = S.uf[(size_t)S.uf[(size_t)i]]; i = S.uf[(size_t)i]; } return i; };
-    for (int64_t k = 0; k < ncand; k++) {
-        const int32_t a = find(hc[k].ll), b = find(hc[k].lr);
-        if (a != b) S.uf[(size_t)std::max(a, b)] = std::min(a, b);
+    // No label reaches a shard boundary anywhere (always so with one shard): nobody has shared groups -- every rank knows it from
+    // the boundary resolution, which all ranks computed from the same gathered records -- and the exchange is left out; the
+    // candidate records go to the driver as they are.
+    bool any_boundary_label = false;
+    for (int q = 0; q < world && !any_boundary_label; q++) {
+        for (int32_t l : S.bout.halo_label[(size_t)q]) if (l > 0) { any_boundary_label = true; break; }
+        if (q + 1 < world) for (int32_t l : S.bout.last_label[(size_t)q]) if (l > 0) { any_boundary_label = true; break; }
     }
-    S.isglob.assign(nd, 0);
-    for (size_t i = 0; i < nd; i++)
-        if (std::binary_search(S.marks.begin(), S.marks.end(), ho[i])) S.isglob[(size_t)find((int32_t)i)] = 1;
     size_t nGd = 0;
     int64_t nGc = 0;
-    for (size_t i = 0; i < nd; i++) if (S.isglob[(size_t)find((int32_t)i)]) nGd++;
-    for (int64_t k = 0; k < ncand; k++) if (S.isglob[(size_t)find(hc[k].ll)]) nGc++;
+    if (any_boundary_label) {
+        // clusters of labels connected through candidate rows; a cluster holding a boundary label is shared
+        S.uf.resize(nd);
+        for (size_t i = 0; i < nd; i++) S.uf[i] = (int32_t)i;
+        auto find = [&](int32_t i) { while (S.uf[(size_t)i] != i) { S.uf[(size_t)i] = S.uf[(size_t)S.uf[(size_t)i]]; i = S.uf[(size_t)i]; } return i; };
+        for (int64_t k = 0; k < ncand; k++) {
+            const int32_t a = find(hc[k].ll), b = find(hc[k].lr);
+            if (a != b) S.uf[(size_t)std::max(a, b)] = std::min(a, b);
+        }
+        for (size_t i = 0; i < nd; i++) S.uf[i] = find((int32_t)i);                 // flat from here on: S.uf[i] is the root
+        S.isglob.assign(nd, 0);
+        for (size_t i = 0; i < nd; i++)
+            if (std::binary_search(S.marks.begin(), S.marks.end(), ho[i])) S.isglob[(size_t)S.uf[i]] = 1;
+        for (size_t i = 0; i < nd; i++) if (S.isglob[(size_t)S.uf[i]]) nGd++;
+        for (int64_t k = 0; k < ncand; k++) if (S.isglob[(size_t)S.uf[(size_t)hc[k].ll]]) nGc++;
+    }
+    auto shared = [&](int32_t dense) { return S.isglob[(size_t)S.uf[(size_t)dense]] != 0; };       // (only with any_boundary_label)
+    const int32_t *lorig = ho;                         // labels of the groups driven here (all of them without shared groups)
+    size_t n_lorig = nd;
+    HP(0);
     uint32_t capC = std::max<uint32_t>(hint_c, 256), capD = std::max<uint32_t>(hint_d, 256);
     struct SeamHeader { uint32_t ncand, nlab, pad0, pad1; };
     size_t sslot = 0;
     bool local_done = false;
-    for (;;) {
+    auto drive_local = [&]() {
+        // this shard's own groups (dense ids renumbered without the shared labels), driven here
+        S.lmap.assign(nd, -1); S.lorig.clear(); S.lbox.clear(); S.lcand.clear();
+        for (size_t i = 0; i < nd; i++)
+            if (!shared((int32_t)i)) { S.lmap[i] = (int32_t)S.lorig.size(); S.lorig.push_back(ho[i]); S.lbox.insert(S.lbox.end(), hbx + 6 * i, hbx + 6 * i + 6); }
+        for (int64_t k = 0; k < ncand; k++)
+            if (!shared(hc[k].ll)) { CtkCand v = hc[k]; v.ll = S.lmap[(size_t)v.ll]; v.lr = S.lmap[(size_t)v.lr]; S.lcand.push_back(v); }
+        h->sd.run(S.lcand.data(), (int64_t)S.lcand.size(), S.lorig.data(), S.lbox.data(), (int64_t)S.lorig.size(), nx, S.ops_l);
+        lorig = S.lorig.data(); n_lorig = S.lorig.size();
+    };
+    if (!any_boundary_label) h->sd.run(hc, ncand, ho, hbx, (int64_t)nd, nx, S.ops_l);
+    for (; any_boundary_label;) {
         sslot = sizeof(SeamHeader) + (size_t)capC * sizeof(CtkCand) + (size_t)capD * 28;
         CTKCHK(ensure_host(&h->h_seam, &h->h_seam_cap, sslot * (size_t)(world + 1), true));
         CTKCHK(ensure(h, h->sh_send, sslot));
@@ -767,24 +904,15 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
             int32_t *ol = (int32_t *)(sb + sizeof(SeamHeader) + (size_t)capC * sizeof(CtkCand));
             size_t j = 0;
             for (int64_t k = 0; k < ncand; k++)
-                if (S.isglob[(size_t)find(hc[k].ll)]) { CtkCand q = hc[k]; q.ll = ho[q.ll]; q.lr = ho[q.lr]; oc[j++] = q; }      // GLOBAL labels
+                if (shared(hc[k].ll)) { CtkCand q = hc[k]; q.ll = ho[q.ll]; q.lr = ho[q.lr]; oc[j++] = q; }      // GLOBAL labels
             j = 0;
             for (size_t i = 0; i < nd; i++)
-                if (S.isglob[(size_t)find((int32_t)i)]) { ol[7 * j] = ho[i]; memcpy(ol + 7 * j + 1, hbx + 6 * i, 24); j++; }
+                if (shared((int32_t)i)) { ol[7 * j] = ho[i]; memcpy(ol + 7 * j + 1, hbx + 6 * i, 24); j++; }
         }
         HIPCHK(hipMemcpyAsync(h->sh_send.p, sb, sslot, hipMemcpyHostToDevice, s));
         CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, sslot));
         HIPCHK(hipMemcpyAsync(sb + sslot, h->sh_recv.p, sslot * (size_t)world, hipMemcpyDeviceToHost, s));
-        if (!local_done) {
-            // while the shared groups travel: this shard's own groups (dense ids renumbered without the shared labels), driven here
-            local_done = true;
-            S.lmap.assign(nd, -1); S.lorig.clear(); S.lbox.clear(); S.lcand.clear();
-            for (size_t i = 0; i < nd; i++)
-                if (!S.isglob[(size_t)find((int32_t)i)]) { S.lmap[i] = (int32_t)S.lorig.size(); S.lorig.push_back(ho[i]); S.lbox.insert(S.lbox.end(), hbx + 6 * i, hbx + 6 * i + 6); }
-            for (int64_t k = 0; k < ncand; k++)
-                if (!S.isglob[(size_t)find(hc[k].ll)]) { CtkCand v = hc[k]; v.ll = S.lmap[(size_t)v.ll]; v.lr = S.lmap[(size_t)v.lr]; S.lcand.push_back(v); }
-            h->sd.run(S.lcand.data(), (int64_t)S.lcand.size(), S.lorig.data(), S.lbox.data(), (int64_t)S.lorig.size(), nx, S.ops_l);
-        }
+        if (!local_done) { local_done = true; drive_local(); }          // (while the shared groups travel)
         CTKCHK(ctk_comm_wait(c));
         uint32_t mc = 0, md = 0;
         for (int q = 0; q < world; q++) {
@@ -795,10 +923,11 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         capC = std::max(capC, mc + mc / 2 + 64); capD = std::max(capD, md + md / 2 + 64);       // same on every rank
     }
     h->sh_capC = capC; h->sh_capD = capD;
+    HP(1);
     INJECT(5);
     // merged table of the shared labels (boxes: union over the shards) and the shared candidate groups in (t, y) order
     S.glabel.clear(); S.gbox.clear(); S.gcand.clear();
-    {
+    if (any_boundary_label) {
         const unsigned char *gb = (const unsigned char *)h->h_seam + sslot;
         std::vector<std::pair<int32_t, int32_t>> &tmp = h->sh_pairs;      // (label, position) for the merge
         tmp.clear();
@@ -840,6 +969,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     S.elist.erase(std::unique(S.elist.begin(), S.elist.end()), S.elist.end());
     const int32_t ne = (int32_t)S.elist.size();
     h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t_host;
+    HP(2);
 
     // ---- ops -> device (one pinned staging block read by k_ops_ingest), then extents ---------------------------------------
     {
@@ -857,8 +987,8 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         for (int64_t i = 0; i < nl; i++) s_next[ng + i] = h->sd.next[(size_t)i] < 0 ? -1 : (int32_t)(h->sd.next[(size_t)i] + ng);
         for (size_t d = 0; d < S.glabel.size(); d++)
             if (h->sd_glob.first[d] >= 0) { s_label[nf] = S.glabel[d]; s_first[nf] = h->sd_glob.first[d]; nf++; }
-        for (size_t d = 0; d < S.lorig.size(); d++)
-            if (h->sd.first[d] >= 0) { s_label[nf] = S.lorig[d]; s_first[nf] = (int32_t)(h->sd.first[d] + ng); nf++; }
+        for (size_t d = 0; d < n_lorig; d++)
+            if (h->sd.first[d] >= 0) { s_label[nf] = lorig[d]; s_first[nf] = (int32_t)(h->sd.first[d] + ng); nf++; }
         if (ne) memcpy(s_el, S.elist.data(), (size_t)ne * 4);
         int32_t *d_next = (int32_t *)(P<CtkOp>(h->ops) + nops);
         h->d_op_next = d_next;
@@ -868,19 +998,23 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         HIPCHK(hipGetLastError());
         h->state = ST_TABLES;
         h->total_comps = (uint32_t)hs[CTK_MAIL_NC];
+        HP(3);
+        if (hostprof && (++hp_n % 16) == 0) fprintf(stderr, "HOSTPROF uf+glob %.1f  local drive(+exchange) %.1f  merge+glob drive %.1f  staging+ingest %.1f us\n", hp_acc[0] / hp_n * 1e3, hp_acc[1] / hp_n * 1e3, hp_acc[2] / hp_n * 1e3, hp_acc[3] / hp_n * 1e3);
         CTKCHK(launch_extents(h, true, true));                           // + the final id of every own component
     SHDBG("extents");
-        // ---- X6 -----------------------------------------------------------------------------------------------------
-        if (world > 1 && ne > 0) {
-            CTKCHK(ensure(h, h->sh_send, (size_t)ne * 8));
-            CTKCHK(ensure(h, h->sh_recv, (size_t)ne * 8 * (size_t)world));
-            CTKCHK(ensure(h, h->sh_elist, (size_t)ne * 4));
-            HIPCHK(hipMemcpyAsync(h->sh_elist.p, s_el, (size_t)ne * 4, hipMemcpyHostToDevice, s));
-            const int ge = std::min((ne + 255) / 256, 256);
-            k_sh_pack_ext<<<ge, 256, 0, s>>>(P<int32_t>(h->sh_elist), ne, P<int32_t>(h->ext), NL, P<int32_t>(h->sh_send));
+        // ---- X6 + X7: extents of the shared ids and the counts, one exchange ----------------------------------------------
+        {
+            const size_t eslot = 8 + (size_t)ne * 8;
+            CTKCHK(ensure(h, h->sh_send, eslot));
+            CTKCHK(ensure(h, h->sh_recv, eslot * (size_t)world));
+            CTKCHK(ensure(h, h->sh_elist, (size_t)std::max(ne, 1) * 4));
+            const int64_t nsample = std::min<int64_t>((int64_t)T * ny * W, 16384);
+            const uint64_t last_full = (nx & 63) ? ((1ull << (nx & 63)) - 1ull) : ~0ull;
+            k_sh_pack_ext<<<ne <= SH_PE_LDS ? SH_PE_BLOCKS : 1, 256, 0, s>>>(s_el, ne, P<int32_t>(h->ext), NL, lab0, lab1, persistence, P<uint64_t>(h->mask), nsample, W,
+                                                                             last_full, P<int32_t>(h->sh_elist), P<int32_t>(h->sh_send), P<uint32_t>(h->counters));
             HIPCHK(hipGetLastError());
-            CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, (size_t)ne * 8));
-            k_sh_reduce_ext<<<ge, 256, 0, s>>>(P<int32_t>(h->sh_elist), ne, P<int32_t>(h->sh_recv), world, P<int32_t>(h->ext), NL);
+            CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, eslot));
+            k_sh_reduce_ext<<<1, 1024, 0, s>>>(P<int32_t>(h->sh_elist), ne, P<int32_t>(h->sh_recv), world, P<int32_t>(h->ext), NL, persistence, mail2 + 64);
             HIPCHK(hipGetLastError());
         }
         h->state = ST_EXTENTS;
@@ -901,17 +1035,21 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     }
     SHDBG("relabel");
     INJECT(6);
-    // ---- X7: counts ---------------------------------------------------------------------------------------------------
-    CTKCHK(ensure(h, h->sh_send, 64));
-    CTKCHK(ensure(h, h->sh_recv, 64 * (size_t)world));
-    k_sh_count<<<1, 1024, 0, s>>>(P<int32_t>(h->ext), NL, lab0, lab1, persistence, P<uint32_t>(h->counters), P<uint32_t>(h->sh_send));
-    HIPCHK(hipGetLastError());
-    CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, 8));
-    HIPCHK(hipMemcpyAsync(mail2 + 64, h->sh_recv.p, 8 * (size_t)world, hipMemcpyDeviceToHost, s));
+    // ---- counts: written into pinned memory by k_sh_reduce_ext.  A 0 in the output: certain when some rank has seen a background
+    // pixel; otherwise (slabs that are foreground everywhere) the write pass' own flags are exchanged -- same decision on every rank
     CTKCHK(ctk_comm_wait(c));
-    int64_t alive = 0;
-    bool zero = false;
-    for (int q = 0; q < world; q++) { alive += mail2[64 + 2 * q]; zero = zero || mail2[64 + 2 * q + 1] != 0; }
+    int64_t alive = mail2[64];
+    bool zero = mail2[65] != 0;
+    if (!zero) {
+        CTKCHK(ensure(h, h->sh_send, 64));
+        CTKCHK(ensure(h, h->sh_recv, 64 * (size_t)world));
+        k_sh_count<<<1, 1024, 0, s>>>(P<int32_t>(h->ext), NL, lab0, lab1, persistence, P<uint32_t>(h->counters), P<uint32_t>(h->sh_send));
+        HIPCHK(hipGetLastError());
+        CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, 8));
+        HIPCHK(hipMemcpyAsync(mail2 + 128, h->sh_recv.p, 8 * (size_t)world, hipMemcpyDeviceToHost, s));
+        CTKCHK(ctk_comm_wait(c));
+        for (int q = 0; q < world; q++) zero = zero || mail2[128 + 2 * q + 1] != 0;
+    }
     h->last_alive = alive;
     if (n_tracked) *n_tracked = alive + (zero ? 1 : 0) - 1;              // len(np.unique(flag)) - 1, contrack.py:793
     collect_event_times(h);

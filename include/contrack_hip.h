@@ -268,6 +268,8 @@ int ctk_set_timing(ctk_handle *h, int level);
 #define CTK_S_SHARED_ROWS   17  /* time-sharded path: seam candidate groups shared between shards (driven on every rank)        */
 #define CTK_S_RELABEL_KERNEL 19    /* which write kernel ran: 5 = k_relabel_v5, 4 = k_relabel_v4, 0 = generic k_relabel */
 #define CTK_S_FUSED         20    /* 1: the one-call pass ran without a host hand-off (device seam driver, one synchronisation) */
+#define CTK_S_X4_SPECULATED 21    /* time-sharded path: 1 if the boundary records of the 3-D labelling travelled with the last round of
+                                   * the overlap filter's exchange (one all-gather less) */
 #define CTK_NSTATS          24
 int ctk_get_stats(ctk_handle *h, int64_t *out /* [CTK_NSTATS] */);
 /* filter passes launched per round before convergence is checked on the host (default 10, 1..32)   */

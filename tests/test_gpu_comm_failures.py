@@ -63,6 +63,8 @@ def test_injected_failure_in_process_group(stage, bad_rank):
     assert "injected failure" in str(err[bad_rank])
     for r in range(n):
         if r != bad_rank:
+            if stage == 6 and err[r] is None:
+                continue            # (after the last exchange: the others may already hold their complete result)
             assert isinstance(err[r], _native.CommError), (r, err[r])
             assert "rank %d" % bad_rank in str(err[r])
     assert comms[0].failed() is not None
