@@ -632,9 +632,19 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
             const unsigned g4 = (unsigned)nblk4;
             uint64_t *mk = P<uint64_t>(h->mask) + t0 * ny * W;
             uint32_t *zc = t0 == 0 ? P<uint32_t>(h->counters) : nullptr;
+            // ballot form: float32, rows of at most 64 words
+            static const int thr_variant = getenv("CTK_THRESHOLD") ? atoi(getenv("CTK_THRESHOLD")) : 4;
+            const bool v6 = !f64 && W <= 64 && (thr_variant == 6 || !v4);      // ballot form: where the float4 form does not apply (or on request)
+            const int R6 = std::max(1, 64 / W), nchunk_t = (ny + R6 - 1) / R6;
+            const int64_t nchunks = nt * nchunk_t;
+            static const int64_t g6max = getenv("CTK_THR_GRID") ? atoll(getenv("CTK_THR_GRID")) : 16384;
+            const unsigned g6 = (unsigned)std::min<int64_t>((nchunks + 3) / 4, g6max);
 #define LAUNCH_THR(OP)                                                                                                                      \
     do {                                                                                                                                \
-        if (f64) k_threshold<OP, double><<<g, 256, 0, s>>>((const double *)src, P<double>(h->thr32) + t0, rows, ny, nx, W, mk, zc); \
+        if (v6) k_threshold_v6<OP, 8><<<g6, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, R6, nchunk_t, nchunks, zc); \
+        else if (f64) k_threshold<OP, double><<<g, 256, 0, s>>>((const double *)src, P<double>(h->thr32) + t0, rows, ny, nx, W, mk, zc); \
+        else if (v4 && thr_variant == 48) k_threshold_v4<OP, 8><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
+        else if (v4 && thr_variant == 42) k_threshold_v4<OP, 2><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
         else if (v4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
         else k_threshold<OP, float><<<g, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, rows, ny, nx, W, mk, zc); \
     } while (0)

@@ -1,3 +1,4 @@
+#include <utility>
 // ctk_kernels.hip -- gfx950 (MI355X, wave64) kernels of the run_contrack hot path.
 //
 // Data layout in HBM (one shard = T consecutive timesteps of a (ny, nx) grid, W = ceil(nx/64)):
@@ -159,13 +160,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define CTK_RB 16                  // rows per workgroup in the two streaming kernels
 
-template <int OP>
+template <int OP, int U = 4 /* independent 16-byte loads in flight per lane */>
 __global__ __launch_bounds__(256) void k_threshold_v4(const float *__restrict__ anom, const float *__restrict__ thr32,
                                                       int ny, int nx, int W, uint64_t *__restrict__ mask, int rb,
                                                       uint32_t *__restrict__ zero_counters /* the pass' device counters start at zero (or nullptr) */)
 {
     if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_N) zero_counters[threadIdx.x] = 0u;
-    constexpr int U = 4;                                   // independent 16-byte loads in flight per lane
     const int nchunk = (ny + rb - 1) / rb;
     const int t = (int)(blockIdx.x / (unsigned)nchunk), y0 = (int)(blockIdx.x - (unsigned)t * nchunk) * rb, tid = (int)threadIdx.x;
     const int rows = min(rb, ny - y0);
@@ -201,6 +201,72 @@ __global__ __launch_bounds__(256) void k_threshold_v4(const float *__restrict__ 
             hi = row16_or(hi);
             if (sub == 0 && i0 + u * 256 + tid < total) mask[(row0 + rr[u]) * W + (cc[u] >> 4)] = ((uint64_t)hi << 32) | lo;
         }
+    }
+}
+
+// k_threshold_v6 (float32, nx <= 4096, any alignment): the mask word of 64 pixels IS the ballot of one compare when lane l holds
+// pixel 64k + l -- dword loads with the row pointer in scalar registers and the lane offset in one VGPR, one v_cmp per 256 bytes,
+// the 64-bit result moved from the scalar pair into lane k of two VGPRs (v_writelane), so that a wave leaves its chunk of
+// R = 64 / W consecutive rows (R*W words, contiguous in the mask) with ONE coalesced store.  ~10 VALU instructions per KB read
+// (k_threshold_v4: 71 -- nibbles placed, ORed across 16 lanes with 8 DPP steps, per-lane 64-bit addresses).
+// Row by row: the W - 1 full words of a row in batches of U loads (immediate offsets from one row pointer; the remainder batch
+// is picked by a switch on its size, so that no load or compare sits behind a predicate), the row's last word on its own (lanes
+// past the row re-read its last pixel, their bits are cleared).  Word k of the chunk goes to lane k.
+template <int OP, int N>
+__device__ __forceinline__ void thr_batch(const float *p /* per lane */, float th, int lane, int k, uint32_t &mlo, uint32_t &mhi)
+{
+    float v[N > 0 ? N : 1];
+#pragma unroll
+    for (int u = 0; u < N; u++) v[u] = __builtin_nontemporal_load(p + u * 64);
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        const uint64_t b = __ballot(cmp_op<OP, float>(v[u], th));
+        if (lane == k + u) { mlo = (uint32_t)b; mhi = (uint32_t)(b >> 32); }
+    }
+}
+template <int OP, int U /* loads in flight per lane and batch: 8 */>
+__global__ __launch_bounds__(256) void k_threshold_v6(const float *__restrict__ anom, const float *__restrict__ thr32, int ny, int nx, int W,
+                                                      uint64_t *__restrict__ mask, int R, int nchunk_t, int64_t nchunks,
+                                                      uint32_t *__restrict__ zero_counters)
+{
+    static_assert(U == 8, "the remainder switch below lists 1..7");
+    if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_N) zero_counters[threadIdx.x] = 0u;
+    const int lane = (int)(threadIdx.x & 63);
+    // (the wave's index through readfirstlane: the compiler then knows that everything derived from it is wave-uniform and keeps
+    // rows, words and pointers in scalar registers)
+    const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = (int64_t)gridDim.x * 4;
+    const int tail = nx - 64 * (W - 1);                               // valid pixels of a row's last word (1 .. 64)
+    const uint64_t tail_mask = tail == 64 ? ~0ull : ((1ull << tail) - 1ull);
+    const unsigned off_tail = (unsigned)((W - 1) * 64 + min(lane, tail - 1));
+    const int nbatch = (W - 1) / U, rem = (W - 1) - nbatch * U;
+    for (int64_t ch = wave; ch < nchunks; ch += nwaves) {
+        const int t = (int)(ch / nchunk_t), y0 = (int)(ch - (int64_t)t * nchunk_t) * R;
+        const int64_t row0 = (int64_t)t * ny + y0;
+        const int rows = min(R, ny - y0);
+        const float th = thr32[t];
+        const float *rowp = anom + row0 * (int64_t)nx;
+        uint32_t mlo = 0, mhi = 0;
+        int k = 0;                                                     // lane that takes the next word
+        for (int r = 0; r < rows; r++, rowp += nx) {
+            const float vt = __builtin_nontemporal_load(rowp + off_tail);
+            const float *p = rowp + lane;
+            for (int q = 0; q < nbatch; q++, p += U * 64, k += U) thr_batch<OP, U>(p, th, lane, k, mlo, mhi);
+            switch (rem) {
+            case 1: thr_batch<OP, 1>(p, th, lane, k, mlo, mhi); break;
+            case 2: thr_batch<OP, 2>(p, th, lane, k, mlo, mhi); break;
+            case 3: thr_batch<OP, 3>(p, th, lane, k, mlo, mhi); break;
+            case 4: thr_batch<OP, 4>(p, th, lane, k, mlo, mhi); break;
+            case 5: thr_batch<OP, 5>(p, th, lane, k, mlo, mhi); break;
+            case 6: thr_batch<OP, 6>(p, th, lane, k, mlo, mhi); break;
+            case 7: thr_batch<OP, 7>(p, th, lane, k, mlo, mhi); break;
+            default: break;
+            }
+            k += rem;
+            const uint64_t b = __ballot(cmp_op<OP, float>(vt, th)) & tail_mask;
+            if (lane == k) { mlo = (uint32_t)b; mhi = (uint32_t)(b >> 32); }
+            k++;
+        }
+        if (lane < k) mask[row0 * W + lane] = ((uint64_t)mhi << 32) | mlo;
     }
 }
 
