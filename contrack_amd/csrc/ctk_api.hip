@@ -199,7 +199,7 @@ struct ctk_handle {
     int64_t rowoff_T = -1; int rowoff_ny = -1; void *rowoff_p = nullptr;     // what seam_rowoff currently holds
     // speculative launch of the 2-D labelling: capacity (in runs) of the run-indexed buffers, the previous call's variants
     uint32_t runs_cap = 0;
-    struct { bool v1 = false, v2 = false, v3 = false, glb = false; } spec_set;
+    struct { bool v1 = false, v2 = false, v3 = false, glb = false, one = false; } spec_set;
     int spec_ny = -1, spec_nx = -1; int64_t spec_T = -1;
     size_t mail_cap_c = 0, mail_cap_d = 0, mail_want_c = 0, mail_want_d = 0;
     size_t h_ops_cap = 0;
@@ -679,7 +679,10 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     // after the run scan -- but a call on the same kind of data as the previous one needs the same: the launch is made
     // SPECULATIVELY with the previous call's buffers and variant set before the host waits for the scan (every workgroup
     // checks its runs against the buffers' capacity), and only what turns out to be missing is launched afterwards.
-    struct VariantSet { bool v1, v2, v3, glb; };
+    // Few timesteps of a busy grid (T <= 512 workgroups: the chip holds them all at once even at two per CU): ONE launch of the
+    // largest LDS variant for every timestep instead -- 1024 threads per plane finish a plane sooner than 256 or 512, and the
+    // fork / join of the side streams (two events, ~20 us of stream time at 480 x 721 x 1440) disappears.
+    struct VariantSet { bool v1, v2, v3, glb, one; };
     auto launch_label2d = [&](const VariantSet &vs, uint32_t cap_runs) -> int {
         Label2dArgs a;
         a.mask = P<uint64_t>(h->mask); a.wstart = P<uint16_t>(h->wstart); a.rowstart = P<uint32_t>(h->rowstart);
@@ -690,6 +693,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         a.ny = ny; a.nx = nx; a.W = W; a.lds_cap = CTK_LDS_RUNS; a.cap_runs = cap_runs;
         a.g_x0 = P<uint16_t>(h->g_x0); a.g_x1 = P<uint16_t>(h->g_x1); a.g_y = P<uint16_t>(h->g_y);
         a.g_parent = P<uint32_t>(h->g_parent); a.g_root = P<uint32_t>(h->g_root); a.g_idmap = P<uint32_t>(h->g_idmap);
+        if (vs.one) k_label2d_lds<4096, 512, -1, 1024><<<(int)T, 1024, 0, s>>>(a);
         if (vs.v2 || vs.v3) HIPCHK(hipEventRecord(h->ev_fork, s));
         if (vs.v1) {
             static const int l2d = getenv("CTK_L2D_VARIANT") ? atoi(getenv("CTK_L2D_VARIANT")) : 0;
@@ -720,10 +724,10 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     CTKCHK(ensure(h, h->seam_cnt, (size_t)T * 4));
     CTKCHK(ensure(h, h->seam_off, (size_t)(T + 1) * 4));
     const bool spec = T > 0 && h->runs_cap > 0 && h->spec_ny == ny && h->spec_nx == nx && (!h->spec_set.glb || h->spec_T >= T);
-    VariantSet launched = {false, false, false, false};
+    VariantSet launched = {false, false, false, false, false};
     if (spec) {
         Timer tm(h, CTK_K_LABEL2D);
-        launched = {h->spec_set.v1, h->spec_set.v2, h->spec_set.v3, h->spec_set.glb};
+        launched = {h->spec_set.v1, h->spec_set.v2, h->spec_set.v3, h->spec_set.glb, h->spec_set.one};
         CTKCHK(launch_label2d(launched, h->runs_cap));
     }
     // the scan kernel wrote total / maximum / overflow / last count into the pinned mailbox
@@ -767,7 +771,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
             CTKCHK(ensure(h, h->g_parent, Rc * 4)); CTKCHK(ensure(h, h->g_root, Rc * 4)); CTKCHK(ensure(h, h->g_idmap, Rc * 4));
         }
         h->runs_cap = (uint32_t)std::min<size_t>(Rc, 0xffffffffu);
-        launched = {false, false, false, false};                  // whatever ran speculatively ran on too small buffers
+        launched = {false, false, false, false, false};           // whatever ran speculatively ran on too small buffers
     }
     if (defer_compact) {
         // room for the halo's components in front of the shard's own (at most one per two pixels of a row)
@@ -781,14 +785,21 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         CTKCHK(ensure(h, h->g_rs, (size_t)T * (ny + 1) * 4));
     }
     if (T > 0) {
-        const VariantSet need = {true, h->max_runs_step > 1024, h->max_runs_step > 2048, h->need_glb};
-        const VariantSet missing = {need.v1 && !launched.v1, need.v2 && !launched.v2, need.v3 && !launched.v3, need.glb && !launched.glb};
-        if (missing.v1 || missing.v2 || missing.v3 || missing.glb) {
+        static const bool no_one = getenv("CTK_L2D_NO_ONE") != nullptr;
+        const bool prefer_one = !no_one && T <= 512 && h->max_runs_step > 1024;
+        const bool none_lds = !launched.v1 && !launched.v2 && !launched.v3 && !launched.one;
+        VariantSet need = {true, h->max_runs_step > 1024, h->max_runs_step > 2048, h->need_glb, false};
+        if (prefer_one && (none_lds || launched.one)) need = {false, false, false, h->need_glb, true};
+        else if (launched.one) need = {false, false, false, h->need_glb, true};          // (the large variant took every timestep it can take)
+        const VariantSet missing = {need.v1 && !launched.v1, need.v2 && !launched.v2, need.v3 && !launched.v3, need.glb && !launched.glb, need.one && !launched.one};
+        if (missing.v1 || missing.v2 || missing.v3 || missing.glb || missing.one) {
             HT("before label2d launch");
             Timer tm(h, CTK_K_LABEL2D);
             CTKCHK(launch_label2d(missing, h->runs_cap));
         }
-        h->spec_set.v1 = true; h->spec_set.v2 = need.v2; h->spec_set.v3 = need.v3; h->spec_set.glb = need.glb;
+        if (prefer_one) { h->spec_set.v1 = false; h->spec_set.v2 = false; h->spec_set.v3 = false; h->spec_set.one = true; }
+        else { h->spec_set.v1 = true; h->spec_set.v2 = h->max_runs_step > 1024; h->spec_set.v3 = h->max_runs_step > 2048; h->spec_set.one = false; }
+        h->spec_set.glb = need.glb;
         h->spec_ny = ny; h->spec_nx = nx; h->spec_T = T;
     }
     h->fz_init = false;
@@ -930,7 +941,8 @@ static int launch_overlap(ctk_handle *h)
     Timer tm(h, CTK_K_OVERLAP);
     {
         const int nwords = h->ny * h->W, per = (nwords + 255) / 256;                       // words per thread if one step is to cover all
-        if (per <= 4 || per > 8) k_overlap<4><<<(int)h->T, 256, 0, h->stream>>>(a);
+        if (h->T <= 1024 && nwords >= 8192) k_overlap<4, 1024><<<(int)h->T, 1024, 0, h->stream>>>(a);      // few large planes: more waves per plane
+        else if (per <= 4 || per > 8) k_overlap<4><<<(int)h->T, 256, 0, h->stream>>>(a);
         else if (per == 5) k_overlap<5><<<(int)h->T, 256, 0, h->stream>>>(a);
         else if (per == 6) k_overlap<6><<<(int)h->T, 256, 0, h->stream>>>(a);
         else k_overlap<8><<<(int)h->T, 256, 0, h->stream>>>(a);

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(1024) void k_rowcount(const uint64_t *__restrict__ 
         // form below walks the rows 256 / W at a time with a block scan -- two barriers -- per step: a chain of 65 of them for a
         // 721 x 1440 plane, 68 us; 0.8 ms on the 14 600-step slab.)
         __shared__ uint32_t rowtot[RC_ROWS];
-        constexpr int RCU = 4;
+        constexpr int RCU = 8;
         const int lane = tid & 63, wv = tid >> 6;
         const int rpw = 64 / W;                                    // rows per wave step
         const int seg = lane / W, wl = lane - seg * W;             // row of the step and word of the row this lane holds
@@ -338,8 +338,12 @@ __global__ __launch_bounds__(1024) void k_rowcount(const uint64_t *__restrict__ 
                 if (lane_used && y < ny) {
                     const uint64_t *mw = mask + (base + y) * W;
                     m[u] = mw[wl];
-                    pv[u] = wl > 0 ? mw[wl - 1] : 0ull;
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < RCU; u++) {                         // the word to the left: the lane to the left holds it (same row)
+                const uint64_t left = shfl_up_u64(m[u], 1);
+                pv[u] = wl > 0 ? left : 0ull;
             }
 #pragma unroll
             for (int u = 0; u < RCU; u++) {
@@ -728,8 +732,10 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
 //   <1024, 288>: 25.6 KB -> 6 workgroups per CU (typical 1 deg Z500 timestep: 500 runs, 40 components)
 //   <2048, 512>: 46 KB -> 3 workgroups per CU
 //   <4096, 512>: 76 KB -> 2 workgroups per CU (0.25 deg timesteps: ~1600 runs, mask words read through L2)
+// (1024 threads: two workgroups per CU need 8 waves per SIMD, i.e. at most 64 VGPRs -- the compiler takes 71 when left alone, and
+// 480 planes of a 0.25 deg grid then run as two rounds of one workgroup per CU: 86 us instead of ~45)
 template <int RUNS, int COMPS, int RUNS_BELOW, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_label2d_lds(Label2dArgs a)
+__global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void k_label2d_lds(Label2dArgs a)
 {
     const int t = (int)blockIdx.x;
     const uint32_t nruns = a.run_base[t + 1] - a.run_base[t];
@@ -916,8 +922,10 @@ __device__ __forceinline__ void emit_pair(const OverlapArgs &a, uint32_t t, uint
 
 // OVB: mask words per thread and step -- chosen by the host so that ONE step covers the timestep where it can (1086 words at
 // 181 x 360: five per thread; with four a second step ran for the last 62 words)
-template <int OVB>
-__global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
+// THREADS: 256, or 1024 when the timesteps alone leave the chip empty (480 x 721 x 1440: 16 steps of three round trips per plane
+// with 256 threads, 4 with 1024)
+template <int OVB, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
 {
     const int t = (int)blockIdx.x;
     if (t == 0 && !a.has_prev) {
@@ -930,9 +938,9 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
     const uint32_t cbc = a.p_rc ? a.cprefix[t] : 0u, cbd = a.p_rc ? a.cprefix[t - 1] : 0u;
     __shared__ unsigned long long hkey[CTK_HASH_SLOTS];
     __shared__ long long hlo[CTK_HASH_SLOTS], hhi[CTK_HASH_SLOTS];
-    __shared__ uint32_t sm_scan[8];
+    __shared__ uint32_t sm_scan[THREADS / 64 + 1];
     __shared__ uint32_t out_base;
-    for (int i = tid; i < CTK_HASH_SLOTS; i += 256) { hkey[i] = FULL64; hlo[i] = 0; hhi[i] = 0; }
+    for (int i = tid; i < CTK_HASH_SLOTS; i += THREADS) { hkey[i] = FULL64; hlo[i] = 0; hhi[i] = 0; }
     __syncthreads();
 
     const int nwords = ny * W;
@@ -967,14 +975,14 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
         }
         emit_pair(a, (uint32_t)t, cc, cd, lo, hi, cbc, cbd);
     };
-    for (int i0 = tid; i0 < nwords; i0 += 256 * OVB) {
+    for (int i0 = tid; i0 < nwords; i0 += THREADS * OVB) {
         uint64_t c[OVB], p[OVB], cl[OVB], pl[OVB];
         uint32_t ec[OVB], ep[OVB];
         int64_t wl[OVB], wh[OVB];
         int ww[OVB];
 #pragma unroll
         for (int u = 0; u < OVB; u++) {                                  // level 1 (and everything whose address is known already)
-            const int idx = i0 + u * 256, ii = min(idx, nwords - 1), im = max(ii - 1, 0);
+            const int idx = i0 + u * THREADS, ii = min(idx, nwords - 1), im = max(ii - 1, 0);
             const int y = ii / W;
             ww[u] = idx < nwords ? ii - y * W : -1;
             c[u] = mc[ii]; p[u] = mp[ii];
@@ -1021,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
     // flush the table: ONE contiguous block of records per timestep (pair_base[t], pair_cnt[t])
     {
         uint32_t mine = 0;
-        for (int i = tid; i < CTK_HASH_SLOTS; i += 256) mine += (hkey[i] != FULL64) ? 1u : 0u;
+        for (int i = tid; i < CTK_HASH_SLOTS; i += THREADS) mine += (hkey[i] != FULL64) ? 1u : 0u;
         uint32_t tot;
         const uint32_t ex = block_excl_scan(mine, sm_scan, &tot);
         if (tid == 0) {
@@ -1039,7 +1047,7 @@ __global__ __launch_bounds__(256) void k_overlap(OverlapArgs a)
         __syncthreads();
         uint32_t j = out_base + ex;
         const uint32_t jend = a.pslot ? out_base + a.pslot : a.pair_cap;
-        for (int i = tid; i < CTK_HASH_SLOTS; i += 256) {
+        for (int i = tid; i < CTK_HASH_SLOTS; i += THREADS) {
             if (hkey[i] == FULL64) continue;
             if (a.pslot && j >= jend) {                                         // more entries than the timestep's slots: ungrouped
                 emit_pair(a, (uint32_t)t, (uint32_t)(hkey[i] >> 32), (uint32_t)hkey[i], hlo[i], hhi[i], cbc, cbd);
