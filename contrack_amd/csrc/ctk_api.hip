@@ -696,11 +696,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         if (vs.one) k_label2d_lds<4096, 512, -1, 1024><<<(int)T, 1024, 0, s>>>(a);
         if (vs.v2 || vs.v3) HIPCHK(hipEventRecord(h->ev_fork, s));
         if (vs.v1) {
-            static const int l2d = getenv("CTK_L2D_VARIANT") ? atoi(getenv("CTK_L2D_VARIANT")) : 0;
-            if (l2d == 1) k_label2d_lds<1024, 96, -1, 256><<<(int)T, 256, 0, s>>>(a);
-            else if (l2d == 2) k_label2d_lds<1024, 96, -1, 128><<<(int)T, 128, 0, s>>>(a);
-            else if (l2d == 3) k_label2d_lds<1024, 288, -1, 128><<<(int)T, 128, 0, s>>>(a);
-            else k_label2d_lds<1024, 288, -1, 256><<<(int)T, 256, 0, s>>>(a);
+            k_label2d_lds<1024, 288, -1, 256><<<(int)T, 256, 0, s>>>(a);
         }
         if (vs.v2) {
             HIPCHK(hipStreamWaitEvent(h->side[0], h->ev_fork, 0));
@@ -940,6 +936,8 @@ static int launch_overlap(ctk_handle *h)
     }
     Timer tm(h, CTK_K_OVERLAP);
     {
+        // (register budgets that allow more waves per SIMD -- 5, 6, 8 instead of the 3 that 135 VGPRs leave at OVB = 5 -- were
+        // measured: the spills cost more than the occupancy returns, 0.264 -> 0.275-0.32 ms for the middle of the 1 deg pass)
         const int nwords = h->ny * h->W, per = (nwords + 255) / 256;                       // words per thread if one step is to cover all
         if (h->T <= 1024 && nwords >= 8192) k_overlap<4, 1024><<<(int)h->T, 1024, 0, h->stream>>>(a);      // few large planes: more waves per plane
         else if (per <= 4 || per > 8) k_overlap<4><<<(int)h->T, 256, 0, h->stream>>>(a);

@@ -8,6 +8,7 @@ cp gpurun_out/${P}_$2/sum_kernel_stats.csv gpurun_out/${P}_$2_kernel_stats.csv; 
 rm -rf gpurun_out/${P}_$2
 python bench.py --steps 20 --warmup 5 --workload $1 > gpurun_out/${P}_bench_$2.json 2> /dev/null
 done
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload era5_025deg_2k > gpurun_out/${P}_bench_025deg_2k.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --workload era5_1deg_90 > gpurun_out/${P}_bench_1deg_90.json 2>/dev/null
 CTK_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 > gpurun_out/${P}_bench_rccl_world1.json 2>/dev/null
 ls -la gpurun_out | grep $P
