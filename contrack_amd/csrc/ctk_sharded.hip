@@ -282,11 +282,11 @@ __global__ void k_rs_labels_sh(ResolveDev r, const int32_t *__restrict__ st, uin
 __global__ __launch_bounds__(256) void k_sh_pack_ext(const int32_t *__restrict__ elist_pinned, int32_t ne, const int32_t *__restrict__ ext, int64_t n_labels,
                                                      int64_t l0, int64_t l1, int persistence, const uint64_t *__restrict__ mask, int64_t nsample, int W,
                                                      uint64_t last_full /* valid bits of a row's last word */, int32_t *__restrict__ elist, int32_t *__restrict__ out,
-                                                     uint32_t *__restrict__ counters)
+                                                     uint32_t *__restrict__ counters, int lds_cap /* <= SH_PE_LDS (a test hook lowers it) */)
 {
     __shared__ int32_t el[SH_PE_LDS];
     const int tid = (int)threadIdx.x;
-    const bool in_lds = ne <= SH_PE_LDS;                                   // (else the launch has one workgroup)
+    const bool in_lds = ne <= lds_cap;                                     // (else the launch has one workgroup)
     for (int32_t i = tid; i < ne; i += 256) { const int32_t l = elist_pinned[i]; if (in_lds) el[i] = l; if (!in_lds || blockIdx.x == 0) elist[i] = l; }
     __threadfence_block();
     __syncthreads();
@@ -1010,8 +1010,9 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
             CTKCHK(ensure(h, h->sh_elist, (size_t)std::max(ne, 1) * 4));
             const int64_t nsample = std::min<int64_t>((int64_t)T * ny * W, 16384);
             const uint64_t last_full = (nx & 63) ? ((1ull << (nx & 63)) - 1ull) : ~0ull;
-            k_sh_pack_ext<<<ne <= SH_PE_LDS ? SH_PE_BLOCKS : 1, 256, 0, s>>>(s_el, ne, P<int32_t>(h->ext), NL, lab0, lab1, persistence, P<uint64_t>(h->mask), nsample, W,
-                                                                             last_full, P<int32_t>(h->sh_elist), P<int32_t>(h->sh_send), P<uint32_t>(h->counters));
+            const int pe_lds = h->debug_mail_d ? (int)std::min<uint32_t>(h->debug_mail_d, SH_PE_LDS) : SH_PE_LDS;      // (ctk_debug_set_mailbox)
+            k_sh_pack_ext<<<ne <= pe_lds ? SH_PE_BLOCKS : 1, 256, 0, s>>>(s_el, ne, P<int32_t>(h->ext), NL, lab0, lab1, persistence, P<uint64_t>(h->mask), nsample, W,
+                                                                          last_full, P<int32_t>(h->sh_elist), P<int32_t>(h->sh_send), P<uint32_t>(h->counters), pe_lds);
             HIPCHK(hipGetLastError());
             CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, eslot));
             k_sh_reduce_ext<<<1, 1024, 0, s>>>(P<int32_t>(h->sh_elist), ne, P<int32_t>(h->sh_recv), world, P<int32_t>(h->ext), NL, persistence, mail2 + 64);

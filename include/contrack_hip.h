@@ -222,7 +222,8 @@ int ctk_debug_boundary_resolve(int world, const int32_t *nlast, const int32_t *n
 /* test hook: labels / operations of one seam cluster the device seam driver accepts (0 = its limits, 64 each): clusters beyond
  * send the pass to the synchronous path with the host driver, and the grid stays there */
 int ctk_debug_set_seam_caps(ctk_handle *h, int labels, int ops);
-/* test hook: cap the device-written mailbox of the resolver hand-off (0 = no cap), so that the explicit-copy path runs */
+/* test hook: cap the device-written mailbox of the resolver hand-off (0 = no cap), so that the explicit-copy path runs; `labels`
+ * also caps the list of shared ids the time-shard path's extent exchange keeps in LDS (longer lists: its one-workgroup form) */
 int ctk_debug_set_mailbox(ctk_handle *h, uint32_t cand_records, uint32_t labels);
 
 /* ---- timing (HIP events on the handle's stream) ----------------------------------------------- */

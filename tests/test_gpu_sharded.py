@@ -119,6 +119,28 @@ def test_long_slab_many_seam_operations(handles):
     assert st[0]["shared_seam_rows"] < st[0]["seam_rows_to_driver"] + sum(s["seam_rows_to_driver"] for s in st)      # most groups stay local
 
 
+def test_extent_exchange_forms_and_x4_speculation(handles):
+    """the fused extent + count exchange in its one-workgroup form (list of shared ids longer than its LDS copy: forced by the
+    mailbox hook) gives the same result as the 32-workgroup form; the stats say whether the boundary records of the 3-D
+    labelling travelled with the filter's last exchange (several shards: from the second round on)"""
+    g = golden_util.load("busy_s1")
+    T = g["anom"].shape[0]
+    op = _native.CMP_OPS[g["gorl"]]
+    cuts = [0, T // 3, 2 * T // 3, T]
+    args = (g["anom"], g["thr"], op, g["wrow"], g["overlap"], g["persistence"], g["twosided"], cuts)
+    f0, n0, st0 = sharded_threads(handles[:3], *args)
+    try:
+        for h in handles[:3]:
+            h.debug_set_mailbox(0, 1)
+        f1, n1, st1 = sharded_threads(handles[:3], *args)
+    finally:
+        for h in handles[:3]:
+            h.debug_set_mailbox(0, 0)
+    assert np.array_equal(f0, g["flag"]) and np.array_equal(f1, g["flag"]) and n0 == n1 == len(np.unique(g["flag"])) - 1
+    for s in st0:
+        assert s["x4_speculated"] == (1 if s["filter_rounds"] > 1 else 0), s
+
+
 def test_bench_slab_in_eight_shards(handles):
     """BASELINE configs[1] complete (2707 x 181 x 360, the bench slab, compared with the oracle in test_gpu_parity.py) cut into the
     eight time shards an 8-GPU node would hold: the strong-scaling layout of `bench.py --gpus 8 --scaling strong`"""
