@@ -520,6 +520,212 @@ __global__ __launch_bounds__(64) void k_rs_pass_sys(ResolveDev r, int it0, int K
     for (uint32_t i = lane; i < nu; i += 64) { if ((int)r.pairs[r.pair_cap - 1u - i].t == t) link(r.pair_cap - 1u - i); }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_rs_pass_sys with PB_G consecutive timesteps per workgroup, one WAVE each ("blocked systolic").  The hand-shake between
+// neighbouring timesteps -- a word that says how many iterations the predecessor has published and in which of them its bits
+// changed -- costs ~2.5 us through memory (device-scope store, acknowledgement, device-scope poll from another CU) and is paid
+// once per iteration: 12 iterations = 31 us of the bench pass, nearly all of it waiting.  Inside a workgroup the word and the
+// predecessor's keep bits travel through LDS (~0.2 us); only the first wave of a workgroup listens to memory and only the last
+// one publishes there.  A chain of K iterations crosses ceil(K / PB_G) workgroup boundaries.
+// Same iteration, same fixed point (contrack.py:706-742), same outputs (keep bits in memory, changed[], pstate of the
+// workgroups' last timesteps).  Waves synchronise only with themselves after the start-up barrier.
+// ------------------------------------------------------------------------------------------------
+#define PB_G 16
+#define PB_COMPS 128         // components of a timestep whose backward sums and keep bits live in LDS (more: memory, as before)
+// the lanes of ONE wave hand data to each other through LDS (executed in order for a wave) -- or, for timesteps whose sums live
+// in the global scratch, through memory: then the operations have to be complete first
+__device__ __forceinline__ void pb_wave_sync(bool through_memory)
+{
+    if (through_memory) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!through_memory) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0, int K, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_cnt,
+                                                           uint32_t *__restrict__ pstate /* [T + 1], zeroed */, int prep_inline, int do_unite)
+{
+    if (dev_tables_bad(r)) return;
+    __shared__ long long Bl_all[PB_G][2 * PB_COMPS];
+    __shared__ uint8_t kb_all[PB_G][PB_COMPS];                 // current keep bits of the wave's timestep (components < PB_COMPS)
+    __shared__ uint32_t lstate[PB_G];                          // the wave's pstate word
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+    const int Kfull = K;
+    const int t = (int)blockIdx.x * PB_G + w + r.t_lo;
+    const bool live = t < (int)r.T;
+    if (lane == 0) lstate[w] = 0u;
+    uint8_t *keep = r.keep0;
+    long long *Bl = Bl_all[w];
+    uint8_t *kb = kb_all[w];
+    // round trip 1
+    const uint32_t cb = live ? r.cprefix[t] : 0u, ce = live ? r.cprefix[t + 1] : 0u, cbp = live ? r.cprefix[t - 1] : 0u;
+    const uint32_t pb = live ? pair_base[t] : 0u, pn = live ? pair_cnt[t] : 0u;
+    const uint32_t nu = dev_nungrouped(r);
+    const uint32_t nct = ce - cb;
+    const bool filtered = live && t <= r.t_hi;                 // (waves behind t_hi only unite their pairs)
+    if (!filtered) K = 0;
+    const bool lds = nct <= PB_COMPS;
+    long long *B = lds ? Bl : (long long *)(r.B + 2 * (int64_t)cb);
+    // the predecessor's bits and word: through LDS if it is a wave of this workgroup and its components fit there
+    const bool pred_here = w > 0, pred_lds = pred_here && (cb - cbp) <= PB_COMPS;
+    const uint8_t *kbp = kb_all[w > 0 ? w - 1 : 0];
+    // round trip 2: first pair and first component of this lane (constant over the iterations)
+    const bool has_p = (uint32_t)lane < pn, has_c = (uint32_t)lane < nct;
+    const uint32_t k0 = pb + lane, g0 = cb + lane;
+    const uint32_t rd0 = has_p ? r.p_rd[k0] : 0u, rc0 = has_p ? r.p_rc[k0] : 0u;
+    CtkPair p0;
+    if (has_p) p0 = r.pairs[k0]; else { p0.lo = 0; p0.hi = 0; }
+    const uint32_t mrep0 = has_c ? r.mrep[g0] : 0xffffffffu;
+    double inv0 = 0.0, ff0 = 0.0;
+    if (prep_inline && filtered) {
+        for (uint32_t c = lane; c < nct; c += 64) {
+            double a, b;
+            dev_prep_comp(r, cb + c, &a, &b);
+            if (c == (uint32_t)lane) { inv0 = a; ff0 = b; }
+        }
+        if (nct > 64) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }      // (re-read from memory below)
+    } else if (has_c) { inv0 = r.inv[g0]; ff0 = r.ff[g0]; }
+    uint8_t kold0 = has_c ? __hip_atomic_load(&keep[g0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
+    if (lds) for (uint32_t c = lane; c < nct; c += 64) kb[c] = (c == (uint32_t)lane) ? kold0 : __hip_atomic_load(&keep[cb + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                           // lstate = 0 and the initial bits of every wave are in LDS
+    if (!live) return;
+    auto pred_keep = [&](uint32_t rd) -> uint8_t {             // keep bit of a representative of timestep t-1
+        if (pred_lds) return __hip_atomic_load(&kbp[rd - cbp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __hip_atomic_load(&keep[rd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto pred_state = [&]() -> uint32_t {
+        if (pred_here) return __hip_atomic_load(&lstate[w - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __hip_atomic_load(&pstate[(size_t)(t - 1) * CTK_PSTATE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    const bool publish_mem = w == PB_G - 1 || t == (int)r.T - 1 || !lds;      // somebody outside the workgroup (or without my LDS bits) listens
+    const bool dyn_pred = t > r.t_lo;                          // the predecessor is filtered by this launch too
+    uint32_t mybits = 0;
+    for (int k = 0; k < K; k++) {
+        const int it = it0 + k;
+        bool evaluate = k == 0;
+        if (k > 0 && dyn_pred) {
+            uint32_t st;
+            while (((st = pred_state()) >> 24) < (uint32_t)k) __builtin_amdgcn_s_sleep(1);
+            evaluate = (st >> (k - 1)) & 1u;
+        }
+        bool wave_any = false;
+        if (evaluate) {
+            if (lds) for (uint32_t c = lane; c < 2 * nct; c += 64) Bl[c] = 0;
+            const uint8_t kd0 = has_p ? pred_keep(rd0) : (uint8_t)0;
+            pb_wave_sync(!lds);
+            if (has_p && kd0) {
+                const uint32_t c = rc0 - cb;
+                atomicAdd((unsigned long long *)&B[2 * c], (unsigned long long)p0.lo);
+                atomicAdd((unsigned long long *)&B[2 * c + 1], (unsigned long long)p0.hi);
+            }
+            for (uint32_t i = lane + 64; i < pn; i += 64) {            // timesteps with more than 64 pair records
+                const uint32_t kk = pb + i;
+                if (!pred_keep(r.p_rd[kk])) continue;
+                const CtkPair p = r.pairs[kk];
+                const uint32_t c = r.p_rc[kk] - cb;
+                atomicAdd((unsigned long long *)&B[2 * c], (unsigned long long)p.lo);
+                atomicAdd((unsigned long long *)&B[2 * c + 1], (unsigned long long)p.hi);
+            }
+            if (nu) {                                                   // records that bypassed the hash table (rare)
+                for (uint32_t i = lane; i < nu; i += 64) {
+                    const CtkPair p = r.pairs[r.pair_cap - 1u - i];
+                    if ((int)p.t != t) continue;
+                    if (!pred_keep(r.p_rd[r.pair_cap - 1u - i])) continue;
+                    const uint32_t c = r.p_rc[r.pair_cap - 1u - i] - cb;
+                    atomicAdd((unsigned long long *)&B[2 * c], (unsigned long long)p.lo);
+                    atomicAdd((unsigned long long *)&B[2 * c + 1], (unsigned long long)p.hi);
+                }
+            }
+            pb_wave_sync(!lds);
+            bool any = false;
+            for (uint32_t c = lane; c < nct; c += 64) {
+                const uint32_t g = cb + c;
+                const bool first = c == (uint32_t)lane;
+                long long blo, bhi;
+                if (lds) { blo = Bl[2 * c]; bhi = Bl[2 * c + 1]; }
+                else {
+                    blo = __hip_atomic_load(&B[2 * c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bhi = __hip_atomic_load(&B[2 * c + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&B[2 * c], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&B[2 * c + 1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if ((first ? mrep0 : r.mrep[g]) != c) continue;         // representatives only
+                bool inexact = r.inex[g] != 0;
+                const double bwd = dev_limbs_to_double(blo, bhi, r.wshift, r.limb_bits, &inexact);
+                double fb = (first ? inv0 : r.inv[g]) * bwd, ff = first ? ff0 : r.ff[g];
+                const uint32_t os = r.ovr_slot ? r.ovr_slot[g] : 0u;
+                if (os & 0x80000000u) {
+                    const double *v = r.ovr_val + 3 * (size_t)(os & 0x3fffffffu);
+                    const double inv = 1.0 / v[0];
+                    fb = inv * v[2]; ff = inv * v[1];
+                } else if (inexact) {
+                    const double tol = CTK_AMBIG_ULPS * 2.220446049250313e-16 * fabs(r.overlap);
+                    if ((ff != 0 && fabs(ff - r.overlap) <= tol) || (r.twosided && fb != 0 && fabs(fb - r.overlap) <= tol)) {
+                        *r.ambig = 1u;
+                        if (r.ovr_slot && os == 0u) {
+                            const uint32_t idx = atomicAdd(r.amb_cnt, 1u);
+                            if (idx < r.amb_cap) { r.amb_list[idx] = g; r.ovr_slot[g] = 0x40000000u | idx; }
+                        }
+                    }
+                }
+                bool kill = false;
+                if (r.twosided) {
+                    if (fb != 0 && ff != 0) { if (fb < r.overlap || ff < r.overlap) kill = true; }
+                    if (fb != 0 && ff == 0) { if (fb < r.overlap) kill = true; }
+                    if (fb == 0 && ff != 0) { if (ff < r.overlap) kill = true; }
+                } else {
+                    if (ff < r.overlap) kill = true;
+                }
+                const uint8_t kn = kill ? 0 : 1;
+                const uint8_t kold = first ? kold0 : (lds ? kb[c] : __hip_atomic_load(&keep[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (kn != kold) {
+                    __hip_atomic_store(&keep[g], kn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lds) __hip_atomic_store(&kb[c], kn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    any = true;
+                    if (first) kold0 = kn;
+                }
+            }
+            wave_any = __ballot(any) != 0ull;
+            pb_wave_sync(!lds);                                         // (Bl is zeroed again by the next evaluation)
+        }
+        if (wave_any) mybits |= 1u << k;
+        const uint32_t word = ((uint32_t)(k + 1) << 24) | mybits;
+        if (lane == 0) {
+            if (wave_any) r.changed[it * CTK_CHG_SLOTS + (t & (CTK_CHG_SLOTS - 1))] = 1u;
+            if (publish_mem) {
+                // the bits (device-scope stores) before the word that announces them: all stores of this wave acknowledged first
+                __builtin_amdgcn_s_waitcnt(0);
+                __hip_atomic_store(&pstate[(size_t)t * CTK_PSTATE_STRIDE], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // (LDS executes a wave's operations in order: the bits above are there before the word)
+            __hip_atomic_store(&lstate[w], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    if (!do_unite) return;
+    // 3-D links of this timestep (contrack.py:748-750): its kept components with the kept components of t-1 they overlap.  The
+    // predecessor's bits are final once it has published all of its iterations.
+    if (t - 1 >= r.t_lo && t - 1 <= r.t_hi) {
+        const uint32_t need = (uint32_t)Kfull;
+        while ((pred_state() >> 24) < need) __builtin_amdgcn_s_sleep(1);
+    }
+    auto link = [&](uint32_t slot) {
+        const uint32_t rc = r.p_rc[slot], rd = r.p_rd[slot];
+        const uint8_t kc = lds ? kb[rc - cb] : __hip_atomic_load(&keep[rc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!kc || !pred_keep(rd)) return;
+        uint32_t a = r.p_gc[slot], b = r.p_gd[slot];
+        for (;;) {
+            a = gfind(r.parent, a);
+            b = gfind(r.parent, b);
+            if (a == b) break;
+            if (a < b) { const uint32_t q = a; a = b; b = q; }
+            const uint32_t old = atomicMin(&r.parent[a], b);
+            if (old == a) break;
+            a = old;
+        }
+    };
+    for (uint32_t i = lane; i < pn; i += 64) link(pb + i);
+    for (uint32_t i = lane; i < nu; i += 64) { if ((int)r.pairs[r.pair_cap - 1u - i].t == t) link(r.pair_cap - 1u - i); }
+}
+
 __global__ void k_rs_unite(ResolveDev r)
 {
     const uint32_t np = dev_npairs(r), ng = dev_ngrouped(r);

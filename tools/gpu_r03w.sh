@@ -1,0 +1,3 @@
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "not processes" 2>&1 | grep -E "passed|failed"
+bash tools/gpu_trace.sh r03w era5_1deg_djf30 > /dev/null; cat gpurun_out/r03w/timeline_era5_1deg_djf30.txt
+for i in 1 2 3; do python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-extra 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('ms', round(d['ms_per_step'],4), 'thr', round(d['kernels_ms']['k_threshold'],4), 'rel', round(d['kernels_ms']['k_relabel'],4))"; done
