@@ -198,7 +198,7 @@ __global__ void k_rs_pairs(ResolveDev r)
 }
 
 // 1/areacon and the forward fraction do not change between passes
-__device__ __forceinline__ void dev_prep_comp(const ResolveDev &r, uint32_t g, double *inv_out, double *ff_out)
+__device__ __forceinline__ void dev_prep_comp(const ResolveDev &r, uint32_t g, double *inv_out, double *ff_out, bool *inex_out = nullptr)
 {
         bool inexact = false;
         const double areacon = dev_limbs_to_double(r.A[2 * (int64_t)g], r.A[2 * (int64_t)g + 1], r.wshift, r.limb_bits, &inexact);
@@ -215,6 +215,7 @@ __device__ __forceinline__ void dev_prep_comp(const ResolveDev &r, uint32_t g, d
         r.inv[g] = inv;
         r.ff[g] = inv * fwd;
         *inv_out = inv; *ff_out = inv * fwd;
+        if (inex_out) *inex_out = inexact;
 }
 __global__ void k_rs_prep(ResolveDev r)
 {
@@ -575,15 +576,18 @@ __global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0
     CtkPair p0;
     if (has_p) p0 = r.pairs[k0]; else { p0.lo = 0; p0.hi = 0; }
     const uint32_t mrep0 = has_c ? r.mrep[g0] : 0xffffffffu;
+    const uint32_t gc0 = (has_p && do_unite) ? r.p_gc[k0] : 0u, gd0 = (has_p && do_unite) ? r.p_gd[k0] : 0u;      // (for the unions at the end)
     double inv0 = 0.0, ff0 = 0.0;
+    bool inex0 = false;
     if (prep_inline && filtered) {
         for (uint32_t c = lane; c < nct; c += 64) {
             double a, b;
-            dev_prep_comp(r, cb + c, &a, &b);
-            if (c == (uint32_t)lane) { inv0 = a; ff0 = b; }
+            bool ix;
+            dev_prep_comp(r, cb + c, &a, &b, &ix);
+            if (c == (uint32_t)lane) { inv0 = a; ff0 = b; inex0 = ix; }
         }
         if (nct > 64) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }      // (re-read from memory below)
-    } else if (has_c) { inv0 = r.inv[g0]; ff0 = r.ff[g0]; }
+    } else if (has_c) { inv0 = r.inv[g0]; ff0 = r.ff[g0]; inex0 = r.inex[g0] != 0; }
     uint8_t kold0 = has_c ? __hip_atomic_load(&keep[g0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
     if (lds) for (uint32_t c = lane; c < nct; c += 64) kb[c] = (c == (uint32_t)lane) ? kold0 : __hip_atomic_load(&keep[cb + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();                                           // lstate = 0 and the initial bits of every wave are in LDS
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0
                     __hip_atomic_store(&B[2 * c + 1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if ((first ? mrep0 : r.mrep[g]) != c) continue;         // representatives only
-                bool inexact = r.inex[g] != 0;
+                bool inexact = first ? inex0 : (r.inex[g] != 0);
                 const double bwd = dev_limbs_to_double(blo, bhi, r.wshift, r.limb_bits, &inexact);
                 double fb = (first ? inv0 : r.inv[g]) * bwd, ff = first ? ff0 : r.ff[g];
                 const uint32_t os = r.ovr_slot ? r.ovr_slot[g] : 0u;
@@ -707,11 +711,11 @@ __global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0
         const uint32_t need = (uint32_t)Kfull;
         while ((pred_state() >> 24) < need) __builtin_amdgcn_s_sleep(1);
     }
-    auto link = [&](uint32_t slot) {
-        const uint32_t rc = r.p_rc[slot], rd = r.p_rd[slot];
+    auto link = [&](uint32_t slot, bool first) {
+        const uint32_t rc = first ? rc0 : r.p_rc[slot], rd = first ? rd0 : r.p_rd[slot];
         const uint8_t kc = lds ? kb[rc - cb] : __hip_atomic_load(&keep[rc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!kc || !pred_keep(rd)) return;
-        uint32_t a = r.p_gc[slot], b = r.p_gd[slot];
+        uint32_t a = first ? gc0 : r.p_gc[slot], b = first ? gd0 : r.p_gd[slot];
         for (;;) {
             a = gfind(r.parent, a);
             b = gfind(r.parent, b);
@@ -722,8 +726,8 @@ __global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0
             a = old;
         }
     };
-    for (uint32_t i = lane; i < pn; i += 64) link(pb + i);
-    for (uint32_t i = lane; i < nu; i += 64) { if ((int)r.pairs[r.pair_cap - 1u - i].t == t) link(r.pair_cap - 1u - i); }
+    for (uint32_t i = lane; i < pn; i += 64) link(pb + i, i == (uint32_t)lane);
+    for (uint32_t i = lane; i < nu; i += 64) { if ((int)r.pairs[r.pair_cap - 1u - i].t == t) link(r.pair_cap - 1u - i, false); }
 }
 
 __global__ void k_rs_unite(ResolveDev r)
