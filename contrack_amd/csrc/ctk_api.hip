@@ -937,7 +937,8 @@ static int launch_overlap(ctk_handle *h)
     Timer tm(h, CTK_K_OVERLAP);
     {
         // (register budgets that allow more waves per SIMD -- 5, 6, 8 instead of the 3 that 135 VGPRs leave at OVB = 5 -- were
-        // measured: the spills cost more than the occupancy returns, 0.264 -> 0.275-0.32 ms for the middle of the 1 deg pass)
+        // measured, before and after the kernel's live state was cut from 135 to 117 VGPRs: the spills cost more than the occupancy
+        // returns -- 39 us at 4 waves per SIMD, 44 at 5, 60 at 6)
         const int nwords = h->ny * h->W, per = (nwords + 255) / 256;                       // words per thread if one step is to cover all
         if (h->T <= 1024 && nwords >= 8192) k_overlap<4, 1024><<<(int)h->T, 1024, 0, h->stream>>>(a);      // few large planes: more waves per plane
         else if (per <= 4 || per > 8) k_overlap<4><<<(int)h->T, 256, 0, h->stream>>>(a);

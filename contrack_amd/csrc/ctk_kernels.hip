@@ -975,51 +975,72 @@ __global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
         }
         emit_pair(a, (uint32_t)t, cc, cd, lo, hi, cbc, cbd);
     };
+    const int lane = tid & 63;
     for (int i0 = tid; i0 < nwords; i0 += THREADS * OVB) {
-        uint64_t c[OVB], p[OVB], cl[OVB], pl[OVB];
-        uint32_t ec[OVB], ep[OVB];
-        int64_t wl[OVB], wh[OVB];
-        int ww[OVB];
+        // Registers decide how many of these workgroups a CU holds (every load in flight owns its destination): the words to the
+        // left are not loaded -- consecutive threads hold consecutive words, so the carry-in bit comes from the lane to the left
+        // (lane 0 of a wave loads the upper half of its left neighbours) -- and the row weights are requested with the components,
+        // for the one word in ten that has common pixels.
+        uint64_t c[OVB], p[OVB];
+        uint32_t ec[OVB], ep[OVB], lt[OVB];                              // lt: bit 0 / 1 = carry-in of c / p (top bit of the word to the left, same row)
+        int yy[OVB];
 #pragma unroll
         for (int u = 0; u < OVB; u++) {                                  // level 1 (and everything whose address is known already)
             const int idx = i0 + u * THREADS, ii = min(idx, nwords - 1), im = max(ii - 1, 0);
             const int y = ii / W;
-            ww[u] = idx < nwords ? ii - y * W : -1;
+            yy[u] = idx < nwords ? y : -1;
             c[u] = mc[ii]; p[u] = mp[ii];
-            cl[u] = mc[im]; pl[u] = mp[im];
+            lt[u] = 0;
+            if (lane == 0) lt[u] = (reinterpret_cast<const uint32_t *>(mc)[2 * im + 1] >> 31) | ((reinterpret_cast<const uint32_t *>(mp)[2 * im + 1] >> 31) << 1);
             ec[u] = rsc[y] + wsc[ii]; ep[u] = rsp[y] + wsp[ii];          // runs started left of this word
-            wl[u] = a.wlo[y]; wh[u] = a.whi[y];
         }
-        uint64_t o[OVB], sc[OVB], sp[OVB];
+#pragma unroll
+        for (int u = 0; u < OVB; u++) {
+            const uint32_t mine = (uint32_t)(c[u] >> 63) | ((uint32_t)(p[u] >> 63) << 1);
+            const uint32_t left = (uint32_t)__shfl_up((int)mine, 1);
+            if (lane != 0) lt[u] = left;
+            const int ii = min(i0 + u * THREADS, nwords - 1);
+            if (ii - yy[u] * W <= 0) lt[u] = 0;                          // first word of a row: nothing to the left
+            if (yy[u] < 0) c[u] = 0ull;                                  // past the end: no common pixels
+        }
+        // what the table phase needs of a word: c, p, lt (pieces are re-derived from them), the run prefixes, the components of
+        // the first piece and the row weights
         uint32_t cc0[OVB], cd0[OVB];
-        int n0[OVB];
+        int64_t wl[OVB], wh[OVB];
+        auto starts = [&](int u, uint64_t &sc, uint64_t &sp) {
+            sc = c[u] & ~((c[u] << 1) | (uint64_t)(lt[u] & 1u)); sp = p[u] & ~((p[u] << 1) | (uint64_t)(lt[u] >> 1));
+        };
 #pragma unroll
         for (int u = 0; u < OVB; u++) {                                  // level 2: the components of the first common piece
-            o[u] = ww[u] >= 0 ? (c[u] & p[u]) : 0ull;
-            cc0[u] = 0; cd0[u] = 0; n0[u] = 0; sc[u] = 0; sp[u] = 0;
-            if (o[u] == 0ull) continue;
-            const uint64_t cinc = (ww[u] > 0) ? (cl[u] >> 63) : 0ull, cinp = (ww[u] > 0) ? (pl[u] >> 63) : 0ull;
-            sc[u] = c[u] & ~((c[u] << 1) | cinc); sp[u] = p[u] & ~((p[u] << 1) | cinp);
-            const int b = __builtin_ctzll(o[u]);
-            const uint64_t sh = o[u] >> b;
-            n0[u] = (~sh == 0ull) ? 64 : __builtin_ctzll(~sh);
+            const uint64_t o = c[u] & p[u];
+            cc0[u] = 0; cd0[u] = 0; wl[u] = 0; wh[u] = 0;
+            if (o == 0ull) continue;
+            uint64_t sc, sp;
+            starts(u, sc, sp);
+            const int b = __builtin_ctzll(o);
             const uint64_t below = (b + 1 >= 64) ? FULL64 : ((1ull << (b + 1)) - 1ull);   // bits 0..b
-            cc0[u] = rcc[ec[u] + (uint32_t)__popcll(sc[u] & below) - 1u];
-            cd0[u] = rcp[ep[u] + (uint32_t)__popcll(sp[u] & below) - 1u];
+            cc0[u] = rcc[ec[u] + (uint32_t)__popcll(sc & below) - 1u];
+            cd0[u] = rcp[ep[u] + (uint32_t)__popcll(sp & below) - 1u];
+            wl[u] = a.wlo[yy[u]]; wh[u] = a.whi[yy[u]];
         }
 #pragma unroll
         for (int u = 0; u < OVB; u++) {                                  // the table; further pieces of a word (rare) one by one
-            uint64_t ou = o[u];
+            uint64_t ou = c[u] & p[u];
             if (ou == 0ull) continue;
-            int b = __builtin_ctzll(ou), n = n0[u];
+            int b = __builtin_ctzll(ou);
+            uint64_t sh = ou >> b;
+            int n = (~sh == 0ull) ? 64 : __builtin_ctzll(~sh);
             insert(cc0[u], cd0[u], (int64_t)n * wl[u], (int64_t)n * wh[u]);
             ou = (n >= 64 - b) ? 0ull : (ou & ~(((1ull << n) - 1ull) << b));
+            if (ou == 0ull) continue;
+            uint64_t sc, sp;
+            starts(u, sc, sp);
             while (ou) {
                 b = __builtin_ctzll(ou);
-                const uint64_t sh = ou >> b;
+                sh = ou >> b;
                 n = (~sh == 0ull) ? 64 : __builtin_ctzll(~sh);
                 const uint64_t below = (b + 1 >= 64) ? FULL64 : ((1ull << (b + 1)) - 1ull);
-                const uint32_t cc = rcc[ec[u] + (uint32_t)__popcll(sc[u] & below) - 1u], cd = rcp[ep[u] + (uint32_t)__popcll(sp[u] & below) - 1u];
+                const uint32_t cc = rcc[ec[u] + (uint32_t)__popcll(sc & below) - 1u], cd = rcp[ep[u] + (uint32_t)__popcll(sp & below) - 1u];
                 insert(cc, cd, (int64_t)n * wl[u], (int64_t)n * wh[u]);
                 ou = (n >= 64 - b) ? 0ull : (ou & ~(((1ull << n) - 1ull) << b));
             }
