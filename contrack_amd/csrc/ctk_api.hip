@@ -1527,16 +1527,17 @@ static int device_resolve_local(ctk_handle *h, double overlap, int twosided)
 //   2707 x 181 x 360:    990 int4 stores per workgroup (11 rows) 0.147 | 720: 0.159 | 1440: 0.168 | 540: 0.182
 //   480 x 721 x 1440:    720 (2 rows) 0.337 | 2880 (8 rows) 0.343 | 2160: 0.359 | 1440: 0.366
 //   14600 x 721 x 1440:  2880 (8 rows, 1.3 M workgroups) 10.9 | 5760: 11.6 | 1440 (2.6 M): 14.0 | 720 (5.3 M): 17.1
-// -> at most 1024 stores (four per thread) while that keeps the grid below a million workgroups, else at most 3072.
+// (k_relabel_v4, round 1; for k_relabel_v5 see the table inside)
 static int relabel_rows(const ctk_handle *h)
 {
     const int n4r = std::max(1, h->nx / 4);
     int rb = std::min(h->ny, std::max(1, std::min(64, 1024 / n4r)));
-    // Small chunks stop paying once there are more than ~200 000 of them: at 721 x 1440 a 2-row chunk costs 1.9 ns of kernel time
-    // at 480 timesteps (173 k chunks, 6.1 TB/s), 2.8 ns at 1000 and 3.2 ns at 2000 (722 k chunks, 3.6 TB/s), while 8-row chunks
-    // cost 8.4 ns apiece at every size measured (5.4 TB/s; round 3, `tools/gpu_r03h.sh`).  Up to 3072 stores per workgroup.
-    const int rb_max = std::min(h->ny, std::max(rb, std::min(64, 3072 / n4r)));
-    while (rb < rb_max && h->T * ((h->ny + rb - 1) / rb) > 200000) rb++;
+    // Rows per chunk at 721 x 1440, ns of kernel time per ROW (round 3, tools/gpu_r03h.sh / gpu_r03z.sh):
+    //   480 steps: 2 rows 0.98 | 3: 1.06 | 6: 1.10        1000 steps: 2 rows 1.53 | 3: 1.03 | 4: 1.04 | 6: 1.08
+    //   2000 steps: 3 rows 1.37 | 4: 1.31 | 6: 1.02 | 8: 1.12 | 12: 1.10        14 600 steps: 6 rows 1.03 | 8: 1.07 | 9: 1.09
+    // i.e. the smallest chunk that keeps the launch at or below ~250 000 workgroups, and not more than ~2300 stores (6 rows).
+    const int rb_max = std::min(h->ny, std::max(rb, std::min(64, 2304 / n4r)));
+    while (rb < rb_max && h->T * ((h->ny + rb - 1) / rb) > 250000) rb++;
     while (rb < h->ny && h->T * ((h->ny + rb - 1) / rb) >= (1 << 24)) rb++;
     if (getenv("CTK_RELABEL_ROWS")) rb = std::min(h->ny, std::max(1, atoi(getenv("CTK_RELABEL_ROWS"))));
     return rb;
