@@ -190,7 +190,7 @@ def main():
     for _ in range(args.warmup):
         n_tracked = step()
     trk.sync()
-    acc, nmeas = {}, {}          # (level-1 timing measures ONE of the two streaming kernels per pass, alternating)
+    acc, nmeas = {}, {}          # (level-1 timing: an event pair around ONE of the two streaming kernels in every second pass)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         n_tracked = step()
@@ -214,6 +214,15 @@ def main():
     for k, v in acc2.items():
         if k not in ("k_threshold", "k_relabel", "total", "d2h", "h2d", "host_seam_driver"):
             per[k] = v
+    for k in ("k_threshold", "k_relabel"):      # fewer than four timed passes: a streaming kernel may have had no event pair
+        if nmeas.get(k, 0) == 0:
+            if not acc2.get(k):
+                for _ in range(4):
+                    step()
+                    v = trk.timings().get(k, 0.0)
+                    if v > 0:
+                        acc2[k] = v
+            per[k] = acc2.get(k, 0.0)
     # roofline of the dominant kernel (by average duration, HIP events on the library's stream)
     px = T * ny * nx
     alg_bytes = {"k_threshold": 4.0 * px, "k_relabel": 4.0 * px}          # float32 read once / int32 written once

@@ -289,10 +289,11 @@ struct Timer {
     int k;
     // level 1: only the two pixel-streaming kernels carry events (an event record is a command of its own, ~5 us on
     // the stream: twenty of them would stretch the pass they are supposed to measure); level 2: every group
-    // (level 1 times ONE of the two per pass, alternating: two event records per pass instead of four)
+    // (level 1 times ONE of the two in every second pass -- k_threshold in passes 0, 4, 8 ... of the handle, k_relabel in passes
+    // 2, 6, 10 ...: one event pair per two passes; a pair around k_relabel showed as two 6 us bubbles in the kernel timeline)
     bool on() const
     {
-        return h->ev_ready && (h->timing >= 2 || (h->timing == 1 && ((k == CTK_K_THRESHOLD && (h->pass_no & 1) == 0) || (k == CTK_K_RELABEL && (h->pass_no & 1) == 1))));
+        return h->ev_ready && (h->timing >= 2 || (h->timing == 1 && ((k == CTK_K_THRESHOLD && (h->pass_no & 3) == 0) || (k == CTK_K_RELABEL && (h->pass_no & 3) == 2))));
     }
     Timer(ctk_handle *h_, int k_) : h(h_), k(k_)
     {
@@ -731,7 +732,9 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     {   // not the stream: the speculative labelling may still be running
         volatile uint32_t *vm = h->h_mail1;
         for (uint64_t spins = 0; vm[4] != scan_stamp; spins++) {
-            if ((spins & 0xfff) == 0xfff) {
+            // (the health check is rare on purpose: a hipStreamQuery on a busy stream makes the runtime enqueue a marker behind the
+            // speculatively launched labelling kernel -- a 6 us bubble in front of the next kernel of every pass)
+            if ((spins & 0xfffff) == 0xfffff) {
                 const hipError_t q = hipStreamQuery(s);
                 if (q == hipSuccess) { if (vm[4] != scan_stamp) return ctk_set_error(CTK_E_INTERNAL, "stage 1: the run scan did not report"); break; }
                 if (q != hipErrorNotReady) return ctk_set_error(CTK_E_NODEVICE, "stage 1: %s", hipGetErrorString(q));

@@ -414,7 +414,7 @@ def bench_main(args, wl, workloads, hbm_peak):
         n_tracked = step()
     comm.barrier()
     trk.sync()
-    acc, nmeas = {}, {}          # (level-1 timing measures ONE of the two streaming kernels per pass, alternating)
+    acc, nmeas = {}, {}          # (level-1 timing: an event pair around ONE of the two streaming kernels in every second pass)
     ops0 = comm.ops()
     tb = time.perf_counter()
     for _ in range(args.steps):

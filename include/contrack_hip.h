@@ -242,8 +242,9 @@ int ctk_debug_set_mailbox(ctk_handle *h, uint32_t cand_records, uint32_t labels)
 #define CTK_T_H2D          12  /* uploads                                              */
 #define CTK_T_TOTAL        13
 #define CTK_NTIMERS        14
-/* level 0: no HIP events; 1: events around ONE of the two pixel-streaming kernels per pass, alternating (k_threshold on odd
- * passes of the handle, k_relabel on even ones; the other reads 0 for that pass) -- what bench.py keeps on during its timed region; 2: events around every kernel group (each record is a ~5 us command on the stream) */
+/* level 0: no HIP events; 1: events around ONE of the two pixel-streaming kernels in every second pass (k_threshold in passes
+ * 0, 4, 8 ... of the handle, k_relabel in passes 2, 6, 10 ...; whatever was not timed reads 0 for that pass) -- what bench.py keeps
+ * on during its timed region; 2: events around every kernel group (each record is a ~5 us command on the stream) */
 int ctk_set_timing(ctk_handle *h, int level);
 /* workload statistics of the last call (for bench reports: cost depends on them) */
 #define CTK_S_RUNS          0   /* foreground runs in the shard                         */

@@ -1,2 +1,3 @@
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "not processes" 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -5
-for wl in era5_025deg_480 era5_025deg_1k era5_025deg_2k era5_025deg_10yr era5_1deg_djf30; do python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra --workload $wl 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('$wl', 'ms', round(d['ms_per_step'],4), 'thr', round(d['kernels_ms']['k_threshold'],4), 'rel', round(d['kernels_ms']['k_relabel'],4), 'frac', round(d['roofline']['frac'],3), d['roofline']['kernel'])"; done
+bash tools/gpu_trace.sh r03z era5_1deg_djf30 > /dev/null; sed -n 1,6p gpurun_out/r03z/timeline_era5_1deg_djf30.txt
+bash tools/gpu_trace.sh r03z era5_025deg_480 > /dev/null; sed -n 1,6p gpurun_out/r03z/timeline_era5_025deg_480.txt
+for i in 1 2 3; do python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-extra 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('ms', round(d['ms_per_step'],4), 'thr', round(d['kernels_ms']['k_threshold'],4), 'rel', round(d['kernels_ms']['k_relabel'],4))"; done
