@@ -628,13 +628,19 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     for (;;) {
         const int npass = first_round ? h->filter_round : std::max(2, h->filter_round / 2);
         if (it_done + npass > CTK_MAX_JACOBI) COLLECTIVE_FAIL(CTK_E_RANGE, "ctk_track_sharded: overlap filter did not converge within %d passes", CTK_MAX_JACOBI);      // (the rounds are in lockstep)
+        // (decided before the passes: a speculating round lets the filter kernel unite the pairs itself)
+        spec = first_round ? world == 1 : true;
+        if (getenv("CTK_NO_SPEC_X4")) spec = false;                      // (experiments: set it for every rank or for none)
+        bool united = false;
         {
             Timer tm(h, CTK_K_RESOLVE);
             if (npass_grid > 0) {
                 if (sys_pass && npass <= 24) {
-                    // all passes of the round in one launch (neighbour hand-shake through pstate, zeroed by k_rs_init / by the
-                    // previous round's k_sh_unpack_keep)
-                    k_rs_pass_sys<<<npass_grid, 64, 0, s>>>(r, it_done, npass, in.pair_base, in.pair_cnt, r.pstate, 0, 0);
+                    // all passes of the round in one launch (neighbour hand-shake through LDS / pstate, zeroed by k_rs_init / by the
+                    // previous round's k_sh_unpack_keep); with `spec` also the 3-D unions of the surviving pairs
+                    if (spec && parent_dirty) k_rs_parent_init<<<gc, 256, 0, s>>>(r);
+                    k_rs_pass_blk<<<(int)((T - r.t_lo + PB_G - 1) / PB_G), 64 * PB_G, 0, s>>>(r, it_done, npass, in.pair_base, in.pair_cnt, r.pstate, 0, spec ? 1 : 0);
+                    united = spec;
                 } else
                     for (int it = it_done; it < it_done + npass; it++)
                         k_rs_pass<<<npass_grid, 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
@@ -647,12 +653,12 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         // on every rank (the payload size depends on it), so it uses nothing a handle remembers: with one shard the first
         // round is the last unless the filter itself needs more passes; with several shards a dropped component on any boundary
         // means a second round, so the first one does not speculate and every later one does.
-        spec = first_round ? world == 1 : true;
-        if (getenv("CTK_NO_SPEC_X4")) spec = false;                      // (experiments: set it for every rank or for none)
         if (spec) {
             Timer tm(h, CTK_K_RESOLVE);
-            if (parent_dirty) k_rs_parent_init<<<gc, 256, 0, s>>>(r);
-            k_rs_unite<<<gp, 256, 0, s>>>(r);
+            if (!united) {
+                if (parent_dirty) k_rs_parent_init<<<gc, 256, 0, s>>>(r);
+                k_rs_unite<<<gp, 256, 0, s>>>(r);
+            }
             k_rs_roots<<<nsb, 256, 0, s>>>(r, P<uint32_t>(h->rv_bsum));                       // (nsb blocks of 256 components)
             k_rs_rank<<<nsb, 256, 0, s>>>(r.isroot, in.cprefix + T, P<uint32_t>(h->rv_bsum), r.rank, P<uint32_t>(h->rv_boff) + nsb);
             HIPCHK(hipGetLastError());
