@@ -177,6 +177,7 @@ struct ctk_handle {
     uint32_t *h_mail2 = nullptr;                   // pinned, device-written scalars
     void *h_shard = nullptr, *h_lab = nullptr, *h_seam = nullptr;        // pinned: gathered boundary records / label tables / shared seam groups
     size_t h_shard_cap = 0, h_lab_cap = 0, h_seam_cap = 0;
+    bool halo_in_zero = false; void *halo_in_zero_p = nullptr;     // the halo header of a first shard is already zero
     uint32_t sh_capB = 0, sh_capC = 0, sh_capD = 0;     // agreed capacities of the exchanged records (grow-only)
     std::vector<std::pair<int32_t, int32_t>> sh_pairs;
     bool halo_valid = false, halo_v2 = false;

@@ -162,7 +162,7 @@ __global__ void k_rs_init(ResolveDev r)
         r.parent[g] = g;                                   // (k_rs_parent_init, for the first round)
     }
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < (CTK_MAX_JACOBI + 1) * CTK_CHG_SLOTS; i += blockDim.x) r.changed[i] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *r.ambig = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *r.ambig = 0; *r.dcount = 0; if (r.amb_cnt) *r.amb_cnt = 0; }
     if (r.pstate) for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= r.T; t += (int64_t)gridDim.x * blockDim.x) r.pstate[(size_t)t * CTK_PSTATE_STRIDE] = 0u;
 }
 

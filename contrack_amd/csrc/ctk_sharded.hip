@@ -100,9 +100,12 @@ struct KeepHeader {
     uint32_t not_conv, nlast, ambig /* components recorded for the exact fix-up */, tables_bad;
     uint32_t nc_own, passes, hint_c, hint_d;      // hint_*: capacities this rank would like for the shared seam records (X5)
 };
+struct BoundHeader;
+__device__ __forceinline__ void dev_pack_boundary(const ResolveDev &r, uint32_t capB, unsigned char *__restrict__ out);
 __global__ void k_sh_pack_keep(ResolveDev r, int it_first, int it_count, uint32_t capB, uint32_t hint_c, uint32_t hint_d, uint32_t fix_changed,
-                               unsigned char *__restrict__ out)
+                               unsigned char *__restrict__ out, unsigned char *__restrict__ bound_out /* speculative X4: the boundary record too, or nullptr */)
 {
+    if (bound_out) dev_pack_boundary(r, capB, bound_out);
     const int64_t T = r.T;
     const uint32_t cb = r.cprefix[T - 1], nlast = r.cprefix[T] - cb;
     unsigned char *bits = out + sizeof(KeepHeader);
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void k_sh_unpack_keep(ResolveDev r, const unsi
 struct BoundHeader {
     int32_t nlast, nh, nroots, pad;
 };
-__global__ void k_sh_pack_boundary(ResolveDev r, uint32_t capB, unsigned char *__restrict__ out)
+__device__ __forceinline__ void dev_pack_boundary(const ResolveDev &r, uint32_t capB, unsigned char *__restrict__ out)
 {
     const int64_t T = r.T;
     const uint32_t nh = r.nh_ptr ? *r.nh_ptr : 0u;
@@ -227,6 +230,7 @@ __global__ void k_sh_pack_boundary(ResolveDev r, uint32_t capB, unsigned char *_
         *(BoundHeader *)out = hd;
     }
 }
+__global__ void k_sh_pack_boundary(ResolveDev r, uint32_t capB, unsigned char *__restrict__ out) { dev_pack_boundary(r, capB, out); }
 
 // the tables indexed by GLOBAL ids start empty (one launch instead of three fill commands, ~5 us of stream time each)
 __global__ void k_sh_clear_tables(uint8_t *__restrict__ mark, uint32_t *__restrict__ dmap, int32_t *__restrict__ op_first, int64_t n)
@@ -536,7 +540,11 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
                                        halo2_off_runcomp(h), halo2_max_runs(h), (unsigned char *)h->halo_out.p);
         HIPCHK(hipGetLastError());
     }
-    if (!has_prev) HIPCHK(hipMemsetAsync(h->halo_in.p, 0, sizeof(HaloHeader), s));          // no halo: zero components
+    if (!has_prev && !(h->halo_in_zero && h->halo_in_zero_p == h->halo_in.p)) {                // no halo: zero components (kept from call to call)
+        HIPCHK(hipMemsetAsync(h->halo_in.p, 0, sizeof(HaloHeader), s));
+        h->halo_in_zero = true; h->halo_in_zero_p = h->halo_in.p;
+    }
+    if (has_prev) h->halo_in_zero = false;
     CTKCHK(ctk_comm_shift(c, +1, h->halo_out.p, hb, h->halo_in.p, hb));
     CTKCHK(ctk_comm_shift(c, -1, h->mask.p, nw * 8, h->sh_mask_next.p, nw * 8));
     const uint32_t *nh_ptr = &((const HaloHeader *)h->halo_in.p)->ncomp;
@@ -610,17 +618,16 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     bool first_round = true;
     {
         Timer tm(h, CTK_K_RESOLVE);
-        HIPCHK(hipMemsetAsync(h->rv_scalars.p, 0, 64, s));
-        k_rs_init<<<gc, 256, 0, s>>>(r);
+        k_rs_init<<<gc, 256, 0, s>>>(r);                                   // (also zeroes the resolver's scalars)
         k_rs_pairs<<<gp, 256, 0, s>>>(r);
         if (has_next)
             k_sh_fwd_last<<<(int)std::min<size_t>((nw + 255) / 256, 1024), 256, 0, s>>>(r, P<uint64_t>(h->mask), P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart),
                                                                                         P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp),
                                                                                         P<uint64_t>(h->sh_mask_next), P<int64_t>(h->wlo),
                                                                                         P<int64_t>(h->wlo) + ny, ny, W);
-        k_rs_prep<<<gc, 256, 0, s>>>(r);
         HIPCHK(hipGetLastError());
     }
+    bool prepped = false;                             // 1/areacon and the forward fractions: by the first filter launch itself where it can
     SHDBG("rs P1");
     bool fix_changed = false, last_was_fixup = false;
     bool spec = false, parent_dirty = false;         // see "Speculative X4" below
@@ -639,11 +646,15 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
                     // all passes of the round in one launch (neighbour hand-shake through LDS / pstate, zeroed by k_rs_init / by the
                     // previous round's k_sh_unpack_keep); with `spec` also the 3-D unions of the surviving pairs
                     if (spec && parent_dirty) k_rs_parent_init<<<gc, 256, 0, s>>>(r);
-                    k_rs_pass_blk<<<(int)((T - r.t_lo + PB_G - 1) / PB_G), 64 * PB_G, 0, s>>>(r, it_done, npass, in.pair_base, in.pair_cnt, r.pstate, 0, spec ? 1 : 0);
+                    k_rs_pass_blk<<<(int)((T - r.t_lo + PB_G - 1) / PB_G), 64 * PB_G, 0, s>>>(r, it_done, npass, in.pair_base, in.pair_cnt, r.pstate, prepped ? 0 : 1,
+                                                                                              spec ? 1 : 0);
                     united = spec;
-                } else
+                    prepped = true;
+                } else {
+                    if (!prepped) { k_rs_prep<<<gc, 256, 0, s>>>(r); prepped = true; }
                     for (int it = it_done; it < it_done + npass; it++)
                         k_rs_pass<<<npass_grid, 64, 0, s>>>(r, it, in.pair_base, in.pair_cnt, P<uint8_t>(h->rv_tdirty));
+                }
             }
             HIPCHK(hipGetLastError());
         }
@@ -671,8 +682,8 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
             CTKCHK(ensure(h, h->sh_recv, slot * (size_t)world));
             CTKCHK(ensure_host(&h->h_shard, &h->h_shard_cap, bslot * (size_t)world + 4096, true));
             if (h->sh_prev.cap < slot * (size_t)world) { CTKCHK(ensure(h, h->sh_prev, slot * (size_t)world)); if (!first_round) return ctk_set_error(CTK_E_INTERNAL, "boundary buffer grew between rounds"); }
-            k_sh_pack_keep<<<8, 256, 0, s>>>(r, it_done, npass_grid > 0 ? npass : 0, capB, h->sh_capC, h->sh_capD, fix_changed ? 1u : 0u, (unsigned char *)h->sh_send.p);
-            if (spec) k_sh_pack_boundary<<<8, 256, 0, s>>>(r, capB, (unsigned char *)h->sh_send.p + kslot);
+            k_sh_pack_keep<<<8, 256, 0, s>>>(r, it_done, npass_grid > 0 ? npass : 0, capB, h->sh_capC, h->sh_capD, fix_changed ? 1u : 0u, (unsigned char *)h->sh_send.p,
+                                             spec ? (unsigned char *)h->sh_send.p + kslot : nullptr);
             HIPCHK(hipGetLastError());
             CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, slot));
             k_sh_unpack_keep<<<1, 256, 0, s>>>(r, (const unsigned char *)h->sh_recv.p, (unsigned char *)h->sh_prev.p, first_round ? 1 : 0, redo, slot, capB, rank, world,
