@@ -944,7 +944,9 @@ static int launch_overlap(ctk_handle *h)
         // measured, before and after the kernel's live state was cut from 135 to 117 VGPRs: the spills cost more than the occupancy
         // returns -- 39 us at 4 waves per SIMD, 44 at 5, 60 at 6)
         const int nwords = h->ny * h->W, per = (nwords + 255) / 256;                       // words per thread if one step is to cover all
-        if (h->T <= 1024 && nwords >= 8192) k_overlap<4, 1024><<<(int)h->T, 1024, 0, h->stream>>>(a);      // few large planes: more waves per plane
+        // few large planes: more waves per plane (480 x 721 x 1440: 256 threads 60 us, 1024 -- one workgroup per CU at 101 VGPRs,
+        // two rounds -- 53, 512 -- two per CU, one round -- 49.5)
+        if (h->T <= 1024 && nwords >= 8192) k_overlap<4, 512><<<(int)h->T, 512, 0, h->stream>>>(a);
         else if (per <= 4 || per > 8) k_overlap<4><<<(int)h->T, 256, 0, h->stream>>>(a);
         else if (per == 5) k_overlap<5><<<(int)h->T, 256, 0, h->stream>>>(a);
         else if (per == 6) k_overlap<6><<<(int)h->T, 256, 0, h->stream>>>(a);
