@@ -670,7 +670,8 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         Timer tm(h, CTK_KI_ROWCOUNT);
         // one workgroup per timestep: few timesteps of a tall grid leave the chip empty and the rows of a plane in a long chain
         // (480 x 721 x 1440: 52 us with 4 waves per plane) -- more waves per plane then (first form of the kernel only)
-        const int rc_threads = (W <= 64 && ny <= RC_ROWS && ny > 256) ? (T <= 1024 ? 1024 : T <= 2048 ? 512 : 256) : 256;
+        // (71 VGPRs: three 512-thread workgroups per CU, one round for <= 768 planes; 1024 threads ran in two rounds)
+        const int rc_threads = (W <= 64 && ny <= RC_ROWS && ny > 256 && T <= 2048) ? 512 : 256;
         if (T > 0) k_rowcount<<<(int)T, rc_threads, 0, s>>>(P<uint64_t>(h->mask), ny, W, P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart), P<uint32_t>(h->tcount));
         k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, h->h_mail1,
                                       nullptr, scan_stamp);
