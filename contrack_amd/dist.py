@@ -262,6 +262,7 @@ def parity_check(trk, comm, rank, world, members, d_out_local, nloc, t0, T_total
     tracks the concatenated slab with ONE call on its own GPU and checksums the same windows.  `members`: how rank 0 obtains
     member q's input -- ("file", path) written by rank q, or ("fill", seed, t_first, T_q) for the device generator.
     Returns (checked, detail) on rank 0, (None, None) elsewhere.  Collective: every rank must call."""
+    from . import synth
     plane = ny * nx
     mine = np.array(trk.checksum_i32(d_out_local, nloc * plane, t0 * plane), dtype=np.uint64)
     allsum = comm.allgather(mine)                                     # (world, 2)
@@ -277,6 +278,8 @@ def parity_check(trk, comm, rank, world, members, d_out_local, nloc, t0, T_total
                 m = members[q]
                 if m[0] == "file":
                     trk.h2d(_ptr(d_in, tq * plane * 4), np.load(m[1], mmap_mode="r"))
+                elif m[0] == "regen":                                 # (no shared scratch space: rank 0 generates the member again)
+                    trk.h2d(_ptr(d_in, tq * plane * 4), np.ascontiguousarray(synth.smooth_field(m[2], ny, nx, seed=m[1])[m[3]:m[3] + nq]))
                 else:
                     trk.synth_fill(_ptr(d_in, tq * plane * 4), nq, ny, nx, seed=m[1], t0=m[2])
             thr = np.full(T_total, thr_value)
@@ -291,7 +294,7 @@ def parity_check(trk, comm, rank, world, members, d_out_local, nloc, t0, T_total
                           flag_pixels=int(allsum[:, 1].sum()),
                           method="64-bit position-weighted checksum of every rank's flag shard vs the same window of ONE ctk_track_f32_dev "
                                  "call on the concatenated %dx%dx%d slab on rank 0's GPU" % (T_total, ny, nx))
-        except (MemoryError, _native.ContrackHipError, ValueError) as e:
+        except (MemoryError, OSError, _native.ContrackHipError, ValueError) as e:
             detail = dict(error="%s: %s" % (type(e).__name__, e))
         finally:
             for p in (d_in, d_out):
@@ -396,9 +399,20 @@ def bench_main(args, wl, workloads, hbm_peak):
         a = synth.smooth_field(T, ny, nx, seed=rank) if weak else synth.smooth_field(T, ny, nx, seed=0)[t0:t1]
         trk.h2d(d_in, a)
         if check_parity:
-            path = os.path.join(_scratch_dir(), "ctk_bench_%s_member%d.npy" % (launch_key(), rank))
-            np.save(path, a)
-            member = ("file", path)
+            # rank 0 needs every member for the one-call run: through a file in shared scratch space, or -- if that cannot be
+            # written -- by generating it again from (seed, window)
+            member = ("regen", rank if weak else 0, T, 0 if weak else t0)
+            for d in (_scratch_dir(), os.environ.get("TMPDIR", "/tmp")):
+                path = os.path.join(d, "ctk_bench_%s_member%d.npy" % (launch_key(), rank))
+                try:
+                    np.save(path, a)
+                    member = ("file", path)
+                    break
+                except OSError:
+                    try:
+                        os.remove(path)
+                    except OSError:
+                        pass
         del a
     w = _weights(ny, nx)
     thr_value = np.float64(np.float32(wl["threshold"]))
@@ -435,10 +449,19 @@ def bench_main(args, wl, workloads, hbm_peak):
     # ---- untimed: the result proves itself (in-run parity against the one-call path), then the strong-scaling leg -----------
     parity_ok, parity = None, None
     if check_parity:
-        kinds = comm.allgather(np.array([1 if member[0] == "file" else 0, member[1] if member[0] == "fill" else 0,
-                                         member[2] if member[0] == "fill" else 0], dtype=np.int64))
-        members = [("file", os.path.join(_scratch_dir(), "ctk_bench_%s_member%d.npy" % (launch_key(), q))) if int(kinds[q][0]) else
-                   ("fill", int(kinds[q][1]), int(kinds[q][2])) for q in range(world)]
+        code = {"fill": 0, "file": 1, "regen": 3}[member[0]]
+        if member[0] == "file" and os.path.dirname(member[1]) != _scratch_dir():
+            code = 2                                                  # (the file went to TMPDIR)
+        kinds = comm.allgather(np.array([code] + [int(v) for v in member[1:4] if not isinstance(v, str)] + [0] * 3, dtype=np.int64)[:4])
+        members = []
+        for q in range(world):
+            c, k = int(kinds[q][0]), [int(v) for v in kinds[q][1:4]]
+            if c in (1, 2):
+                members.append(("file", os.path.join(_scratch_dir() if c == 1 else os.environ.get("TMPDIR", "/tmp"), "ctk_bench_%s_member%d.npy" % (launch_key(), q))))
+            elif c == 3:
+                members.append(("regen", k[0], k[1], k[2]))
+            else:
+                members.append(("fill", k[0], k[1]))
         parity_ok, parity = parity_check(trk, comm, rank, world, members, d_out, nloc, t0, T_total, ny, nx, thr_value, op, w, wl, n_tracked)
         if member[0] == "file":
             try:
