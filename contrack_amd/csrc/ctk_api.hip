@@ -645,7 +645,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     do {                                                                                                                                \
         if (v6) k_threshold_v6<OP, 8><<<g6, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, R6, nchunk_t, nchunks, zc); \
         else if (f64) k_threshold<OP, double><<<g, 256, 0, s>>>((const double *)src, P<double>(h->thr32) + t0, rows, ny, nx, W, mk, zc); \
-        else if (v4 && thr_variant == 48) k_threshold_v4<OP, 8><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
+        else if (v4 && thr_variant == 44) k_threshold_v4<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
         else if (v4 && thr_variant == 42) k_threshold_v4<OP, 2><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
         else if (v4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
         else k_threshold<OP, float><<<g, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, rows, ny, nx, W, mk, zc); \
