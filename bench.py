@@ -155,8 +155,10 @@ def main():
                          "strong = the single-GPU slab split over the GPUs")
     ap.add_argument("--no-parity-check", action="store_true",
                     help="N > 1: skip the in-run parity check (rank 0 tracks the concatenated slab with one call and compares checksums)")
-    ap.add_argument("--strong-steps", type=int, default=2000,
-                    help="N > 1: timesteps of the device-generated 0.25 deg slab of the strong-scaling block (0 = skip)")
+    ap.add_argument("--strong-steps", type=int, default=-1,
+                    help="N > 1: timesteps of the device-generated 0.25 deg slab of the strong-scaling block (0 = skip; default: the 10-year "
+                         "slab of BASELINE.json configs[2], 14600 steps -- the size the north_star's >= 6x is stated on --, falling back to "
+                         "2000 steps if rank 0's GPU cannot hold it for the one-GPU reference time)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     rank = int(os.environ.get("RANK", "0"))

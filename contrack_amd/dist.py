@@ -339,8 +339,8 @@ def strong_block(trk, comm, rank, world, wl, T, steps, warmup):
                 if p is not None:
                     trk.free(p)
     one = comm.allgather(one)[0]
-    if one[0] <= 0:
-        return dict(error=err or "the one-GPU pass did not run") if rank == 0 else None
+    if one[0] <= 0:                                                    # (every rank sees it: the caller may try a smaller slab)
+        return False, (dict(error=err or "the one-GPU pass did not run", steps_tried=T) if rank == 0 else None)
     t0, t1 = shard_bounds(T, world)[rank]
     nloc = t1 - t0
     d_in, d_out = trk.malloc(nloc * plane * 4), trk.malloc(nloc * plane * 4)
@@ -353,9 +353,9 @@ def strong_block(trk, comm, rank, world, wl, T, steps, warmup):
     trk.free(d_in)
     trk.free(d_out)
     if rank != 0:
-        return None
+        return True, None
     ms = dt * 1e3 / steps
-    return dict(workload="%dx%dx%d float32 (device-generated), threshold %s %g, overlap %g, persistence %d" % (
+    return True, dict(workload="%dx%dx%d float32 (device-generated), threshold %s %g, overlap %g, persistence %d" % (
                     T, ny, nx, wl["gorl"], wl["threshold"], wl["overlap"], wl["persistence"]),
                 n_gpus=world, ms_per_step_1gpu=float(one[0]), ms_per_step=ms, speedup_vs_1gpu=float(one[0]) / ms,
                 timesteps_per_s=T / (ms * 1e-3), n_tracked=int(nN), n_tracked_one_call=int(one[1]), n_tracked_equal=bool(int(one[1]) == int(nN)),
@@ -472,9 +472,18 @@ def bench_main(args, wl, workloads, hbm_peak):
     trk.free(d_out)
     strong = None
     sT = int(getattr(args, "strong_steps", 0) or 0)
-    if sT >= world and world > 1:
-        swl = workloads["era5_025deg_2k"]
-        strong = strong_block(trk, comm, rank, world, swl, sT, max(2, min(args.steps, 5)), 1)
+    if world > 1 and sT != 0:
+        swl = workloads["era5_025deg_2k"]                              # (grid and parameters; the number of steps is sT)
+        tried = []
+        for cand in ([14600, 2000] if sT < 0 else [sT]):
+            if cand < world:
+                continue
+            ok, strong = strong_block(trk, comm, rank, world, swl, cand, max(2, min(args.steps, 5)), 1)
+            if ok:
+                break
+            tried.append(strong)
+        if rank == 0 and strong is not None and tried and "error" not in strong:
+            strong["larger_slab_not_run"] = tried
 
     alg = {"k_threshold": 4.0 * px, "k_relabel": 4.0 * px}
     kern = max(alg, key=lambda k: per.get(k, 0.0))
