@@ -1775,6 +1775,7 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     }
     AsyncMail am;
     am.scal = h->h_amail; am.nlab_ptr = P<uint32_t>(h->rv_boff) + nsb; am.nc_ptr = in.cprefix + T;
+    am.stamp = (uint32_t)(h->pass_no & 0x7fffffffu) | 0x80000000u;
     am.changed = r.changed; am.ambig = r.ambig; am.rec_cnt = P<uint32_t>(h->rv_cand_cnt); am.t_nops = sd.t_nops; am.pair_cnt = in.pair_cnt; am.t_alive = P<uint32_t>(h->seam_off); am.T = T; am.passes = NP;
     {
         Timer tm(h, CTK_K_COUNT);
@@ -1785,10 +1786,29 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
         HIPCHK(hipGetLastError());
     }
     HT("fused pass launched");
-    HIPCHK(hipStreamSynchronize(s));
+    {
+        // The last kernel of the pass writes the block of scalars into pinned memory and its stamp last: the host spins on the
+        // stamp instead of waiting for the stream's completion signal (which arrives several microseconds later); every kernel
+        // of the pass has finished when the stamp is there -- they run in stream order.  The health check is rare (a query on a
+        // busy stream enqueues a marker).
+        static const bool poll = !getenv("CTK_SYNC_STREAM");
+        volatile uint32_t *vm = h->h_amail;
+        bool done = false;
+        if (poll)
+            for (uint64_t spins = 1;; spins++) {
+                if (vm[CTK_AM_DONE] == am.stamp) { done = true; break; }
+                if ((spins & 0xfffff) == 0) {
+                    const hipError_t q = hipStreamQuery(s);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) return ctk_set_error(CTK_E_NODEVICE, "fused pass: %s", hipGetErrorString(q));
+                }
+            }
+        if (!done) HIPCHK(hipStreamSynchronize(s));
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
     HT("fused pass done");
     const uint32_t *m = h->h_amail;
-    if (!m[CTK_AM_DONE]) return ctk_set_error(CTK_E_INTERNAL, "fused pass: the device did not report");
+    if (m[CTK_AM_DONE] != am.stamp) return ctk_set_error(CTK_E_INTERNAL, "fused pass: the device did not report");
     h->state = ST_TABLES;
     const uint32_t *cnt = m + CTK_AM_COUNTERS;
     // ---- validation: anything the host would have seen at one of its (removed) hand-offs -----------------------------------

@@ -1562,6 +1562,7 @@ __global__ __launch_bounds__(256) void k_relabel(RelabelArgs a)
 // host memory (scal[CTK_AM_*]); the host validates it after its only synchronisation.
 struct AsyncMail {
     uint32_t *scal;                 // nullptr: not the fused path
+    uint32_t stamp;                 // written to scal[CTK_AM_DONE] after everything else: the host polls for it
     const uint32_t *nlab_ptr;       // number of fresh 3-D labels (= ids to count; n_labels is then only the offset of ext's second half)
     const uint32_t *nc_ptr;         // cprefix[T]
     const uint32_t *changed;        // [passes][CTK_CHG_SLOTS]
@@ -1597,7 +1598,7 @@ __device__ inline void async_mail_write(const AsyncMail &m, const uint32_t *coun
     else if (lane == CTK_AM_NCAND) { v = ncand; has = true; }
     else if (lane == CTK_AM_NPAIRS) { v = npairs; has = true; }
     else if (lane == CTK_AM_AMBIG) { v = *m.ambig; has = true; }
-    else if (lane == CTK_AM_DONE) { v = 1u; has = true; }
+
     // first filter pass that changed nothing: lane k looks at pass k (and k + 64, ...)
     uint32_t conv = 0xffffffffu;
     for (int k = lane; k < m.passes; k += 64) {
@@ -1608,6 +1609,9 @@ __device__ inline void async_mail_write(const AsyncMail &m, const uint32_t *coun
     for (int o = 32; o > 0; o >>= 1) conv = min(conv, (uint32_t)__shfl_xor((int)conv, o));
     if (lane == CTK_AM_CONV) { v = conv == 0xffffffffu ? 0u : conv + 1u; has = true; }
     if (has) m.scal[lane] = v;
+    // the block is complete (this wave wrote all of it, and the two words of the older mailbox before): then the stamp
+    __threadfence_system();
+    if (lane == CTK_AM_DONE) __hip_atomic_store(&m.scal[CTK_AM_DONE], m.stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__ ext, int64_t n_labels, int persistence,
