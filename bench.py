@@ -192,19 +192,19 @@ def main():
     for _ in range(args.warmup):
         n_tracked = step()
     trk.sync()
-    acc, nmeas = {}, {}          # (level-1 timing: an event pair around ONE of the two streaming kernels in every second pass)
+    # (level-1 timing: an event pair around ONE of the two streaming kernels in every second pass; the library sums the times,
+    # they are read once after the loop -- fetching them after every pass was ~10 us of interpreter time with the GPU idle)
+    trk.timing_sums(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         n_tracked = step()
-        for k, v in trk.timings().items():
-            acc[k] = acc.get(k, 0.0) + v
-            if v > 0:
-                nmeas[k] = nmeas.get(k, 0) + 1
     trk.sync()
     dt = time.perf_counter() - t0
     ms_per_step = dt * 1e3 / args.steps
     value = T * args.steps / dt
-    per = {k: v / max(nmeas.get(k, 0), 1) for k, v in acc.items()}
+    per, nmeas = trk.timing_sums(reset=True)
+    last = trk.timings()                              # (host-side timers of the last pass: informational)
+    per.update({k: last[k] for k in ("host_seam_driver", "total", "d2h", "h2d")})
     # per-group kernel times of the small kernels: a few extra, untimed passes with events around every group (each
     # event record is a command of its own and would stretch the timed passes)
     trk.set_timing(2)

@@ -23,7 +23,7 @@ EXPORTS = [
     "ctk_track_f32_dev", "ctk_track_f64", "ctk_track_f64_dev", "ctk_release_io", "ctk_shard_label2d", "ctk_shard_label2d_f64", "ctk_shard_halo_size", "ctk_shard_halo_export",
     "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_resolve", "ctk_result_free",
     "ctk_result_info", "ctk_result_arrays", "ctk_result_nshards", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
-    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_set_seam_caps", "ctk_debug_np_sum", "ctk_debug_boundary_resolve", "ctk_set_timing", "ctk_get_timings", "ctk_set_device_resolve", "ctk_set_fused_pass", "ctk_set_filter_round", "ctk_get_stats",
+    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_set_seam_caps", "ctk_debug_np_sum", "ctk_debug_boundary_resolve", "ctk_set_timing", "ctk_get_timings", "ctk_get_timing_sums", "ctk_set_device_resolve", "ctk_set_fused_pass", "ctk_set_filter_round", "ctk_get_stats",
     "ctk_dev_malloc", "ctk_dev_free", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
     "ctk_synth_fill",
     "ctk_comm_unique_id", "ctk_comm_init_rccl", "ctk_comm_group_create", "ctk_comm_group_destroy", "ctk_comm_init_local", "ctk_comm_init_shm",
@@ -107,6 +107,7 @@ def lib():
     L.ctk_debug_boundary_resolve.argtypes = [i32, p, p, p, p, p, p, p, p, p]
     L.ctk_set_timing.argtypes = [p, i32]
     L.ctk_get_timings.argtypes = [p, p]
+    L.ctk_get_timing_sums.argtypes = [p, p, p, i32]
     L.ctk_set_device_resolve.argtypes = [p, i32]
     L.ctk_set_fused_pass.argtypes = [p, i32]
     L.ctk_get_stats.argtypes = [p, p]
@@ -661,6 +662,13 @@ class Tracker:
 
     def set_device_resolve(self, on=True):
         check(lib().ctk_set_device_resolve(self._h, int(bool(on))))
+
+    def timing_sums(self, reset=True):
+        """(mean ms per measured call, calls that measured it) per kernel group since the last reset"""
+        sums = np.zeros(len(TIMER_NAMES), dtype=np.float64)
+        cnt = np.zeros(len(TIMER_NAMES), dtype=np.int64)
+        check(lib().ctk_get_timing_sums(self._h, sums.ctypes.data, cnt.ctypes.data, int(bool(reset))))
+        return ({k: (float(v) / int(n) if n else 0.0) for k, v, n in zip(TIMER_NAMES, sums, cnt)}, dict(zip(TIMER_NAMES, cnt.tolist())))
 
     def timings(self):
         ms = np.zeros(len(TIMER_NAMES), dtype=np.float64)

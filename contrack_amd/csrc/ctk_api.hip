@@ -219,6 +219,8 @@ struct ctk_handle {
     std::vector<CtkOp> sd_ops;
     std::vector<unsigned char> sd_cand;
     int64_t stats[CTK_NSTATS] = {0};
+    double ms_sum[CTK_NTIMERS] = {0};                  // HIP-event times of the kernel groups summed over the calls since the last reset
+    int64_t ms_cnt[CTK_NTIMERS] = {0};                 // ... and how many calls measured each group (ctk_get_timing_sums)
     // host (pinned) buffers
     void *h_blob = nullptr;
     size_t h_blob_cap = 0, h_blob_bytes = 0;
@@ -501,9 +503,22 @@ static int collect_event_times(ctk_handle *h)
     for (int k = 0; k <= CTK_KI_ROWCOUNT; k++) {
         if (!h->ev_used[k]) continue;
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->ev[k][0], h->ev[k][1]) == hipSuccess) h->ms[k == CTK_KI_ROWCOUNT ? CTK_K_SCAN : k] += ms;
+        if (hipEventElapsedTime(&ms, h->ev[k][0], h->ev[k][1]) == hipSuccess) {
+            const int kk = k == CTK_KI_ROWCOUNT ? CTK_K_SCAN : k;
+            h->ms[kk] += ms;
+            h->ms_sum[kk] += ms; h->ms_cnt[kk]++;              // (running sums: a caller that times many passes reads them once)
+        }
         h->ev_used[k] = false;
     }
+    return CTK_OK;
+}
+
+extern "C" int ctk_get_timing_sums(ctk_handle *h, double *sums, int64_t *counts, int reset)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    if (sums) memcpy(sums, h->ms_sum, sizeof(h->ms_sum));
+    if (counts) memcpy(counts, h->ms_cnt, sizeof(h->ms_cnt));
+    if (reset) { memset(h->ms_sum, 0, sizeof(h->ms_sum)); memset(h->ms_cnt, 0, sizeof(h->ms_cnt)); }
     return CTK_OK;
 }
 
@@ -1791,7 +1806,8 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
         // stamp instead of waiting for the stream's completion signal (which arrives several microseconds later); every kernel
         // of the pass has finished when the stamp is there -- they run in stream order.  The health check is rare (a query on a
         // busy stream enqueues a marker).
-        static const bool poll = !getenv("CTK_SYNC_STREAM");
+        static const bool poll_env = !getenv("CTK_SYNC_STREAM");
+        const bool poll = poll_env && h->timing < 2;                   // (level-2 timing has an event BEHIND the last kernel: wait for the stream)
         volatile uint32_t *vm = h->h_amail;
         bool done = false;
         if (poll)

@@ -428,21 +428,19 @@ def bench_main(args, wl, workloads, hbm_peak):
         n_tracked = step()
     comm.barrier()
     trk.sync()
-    acc, nmeas = {}, {}          # (level-1 timing: an event pair around ONE of the two streaming kernels in every second pass)
+    trk.timing_sums(reset=True)  # (level-1 timing: an event pair around ONE of the two streaming kernels in every second pass, summed by the library)
     ops0 = comm.ops()
     tb = time.perf_counter()
     for _ in range(args.steps):
         n_tracked = step()
-        for k, v in trk.timings().items():
-            acc[k] = acc.get(k, 0.0) + v
-            if v > 0:
-                nmeas[k] = nmeas.get(k, 0) + 1
     trk.sync()
     comm.barrier()
     dt_local = time.perf_counter() - tb
     dt = float(comm.allgather(np.array([dt_local], dtype=np.float64)).max())
     ops1 = comm.ops()
-    per = {k: v / max(nmeas.get(k, 0), 1) for k, v in acc.items()}
+    per, nmeas = trk.timing_sums(reset=True)
+    last = trk.timings()                              # (host-side timers of the last pass: informational)
+    per.update({k: last[k] for k in ("host_seam_driver", "total", "d2h", "h2d")})
     stats = trk.stats()
     px = nloc * plane
 

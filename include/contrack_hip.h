@@ -246,6 +246,9 @@ int ctk_debug_set_mailbox(ctk_handle *h, uint32_t cand_records, uint32_t labels)
  * 0, 4, 8 ... of the handle, k_relabel in passes 2, 6, 10 ...; whatever was not timed reads 0 for that pass) -- what bench.py keeps
  * on during its timed region; 2: events around every kernel group (each record is a ~5 us command on the stream) */
 int ctk_set_timing(ctk_handle *h, int level);
+/* event times summed over the calls since the last reset, and the number of calls that measured each group ([CTK_NTIMERS] each;
+ * either may be NULL): what a loop that times many passes reads ONCE at its end instead of ctk_get_timings after every call */
+int ctk_get_timing_sums(ctk_handle *h, double *sums, int64_t *counts, int reset);
 /* workload statistics of the last call (for bench reports: cost depends on them) */
 #define CTK_S_RUNS          0   /* foreground runs in the shard                         */
 #define CTK_S_MAX_RUNS_STEP 1   /* most runs in one timestep                            */
