@@ -571,24 +571,34 @@ class Tracker:
     def debug_fail_at(self, stage):
         check(lib().ctk_debug_fail_at(self._h, int(stage)))
 
+    def _thr_w_ptrs(self, thr, wrow):
+        """addresses of the per-step thresholds (float64) and row weights (float32); remembered while the caller passes the very same
+        arrays in the right layout (a loop over passes: the conversions and two ctypes objects per call were ~3 us with the GPU idle)"""
+        c = getattr(self, "_pc", None)
+        if c is not None and c[0] is thr and c[1] is wrow:
+            return c[2], c[3], thr, wrow
+        t = np.ascontiguousarray(thr, dtype=np.float64)
+        w = np.ascontiguousarray(wrow, dtype=np.float32)
+        tp, wp = t.ctypes.data, w.ctypes.data
+        self._pc = (thr, wrow, tp, wp) if (t is thr and w is wrow) else None      # (never the address of a converted copy)
+        return tp, wp, t, w
+
     def track_dev(self, anom_dev, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev):
-        thr = np.ascontiguousarray(thr, dtype=np.float64)
-        wrow = np.ascontiguousarray(wrow, dtype=np.float32)
+        tp, wp, thr, wrow = self._thr_w_ptrs(thr, wrow)
         n = C.c_int64(0)
-        check(lib().ctk_track_f32_dev(self._h, anom_dev, T, ny, nx, thr.ctypes.data, int(cmp_op), wrow.ctypes.data,
+        check(lib().ctk_track_f32_dev(self._h, anom_dev, T, ny, nx, tp, int(cmp_op), wp,
                                       float(overlap), int(persistence), int(bool(twosided)), flag_dev, C.byref(n)))
         return int(n.value)
 
     def track_sharded_dev(self, comm, anom_dev, T_local, t_begin, T_total, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev,
                           f64=False):
         """the whole path on the time shard [t_begin, t_begin + T_local) of T_total steps; every rank of `comm` must call"""
-        thr = np.ascontiguousarray(thr, dtype=np.float64)
-        wrow = np.ascontiguousarray(wrow, dtype=np.float32)
+        tp, wp, thr, wrow = self._thr_w_ptrs(thr, wrow)
         if thr.shape != (T_local,):
             raise ValueError("thr must hold one value per local timestep")
         n = C.c_int64(0)
         fn = lib().ctk_track_sharded_f64_dev if f64 else lib().ctk_track_sharded_f32_dev
-        check(fn(self._h, comm.ptr, anom_dev, int(T_local), int(t_begin), int(T_total), ny, nx, thr.ctypes.data, int(cmp_op), wrow.ctypes.data,
+        check(fn(self._h, comm.ptr, anom_dev, int(T_local), int(t_begin), int(T_total), ny, nx, tp, int(cmp_op), wp,
                  float(overlap), int(persistence), int(bool(twosided)), flag_dev, C.byref(n)))
         return int(n.value)
 
