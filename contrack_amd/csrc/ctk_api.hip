@@ -541,7 +541,8 @@ static bool async_wanted(ctk_handle *h);
 static int threshold_rows(int ny, int nx, int64_t T)
 {
     (void)nx; (void)T;
-    return std::min(ny, 16);
+    static const int env = getenv("CTK_THR_ROWS") ? atoi(getenv("CTK_THR_ROWS")) : 0;
+    return std::min(ny, env > 0 ? env : 16);
 }
 
 // defer_compact (time-sharded path): the dense component tables are built after the halo has arrived, because the halo's
