@@ -1555,7 +1555,7 @@ static int relabel_rows(const ctk_handle *h)
 {
     const int n4r = std::max(1, h->nx / 4);
     int rb = std::min(h->ny, std::max(1, std::min(64, 1024 / n4r)));
-    // Rows per chunk at 721 x 1440, ns of kernel time per ROW (round 3, tools/gpu_r03h.sh / gpu_r03z.sh):
+    // Rows per chunk at 721 x 1440, ns of kernel time per ROW (round 3, `CTK_RELABEL_ROWS` sweeps):
     //   480 steps: 2 rows 0.98 | 3: 1.06 | 6: 1.10        1000 steps: 2 rows 1.53 | 3: 1.03 | 4: 1.04 | 6: 1.08
     //   2000 steps: 3 rows 1.37 | 4: 1.31 | 6: 1.02 | 8: 1.12 | 12: 1.10        14 600 steps: 6 rows 1.03 | 8: 1.07 | 9: 1.09
     // i.e. the smallest chunk that keeps the launch at or below ~250 000 workgroups, and not more than ~2300 stores (6 rows).
