@@ -177,6 +177,7 @@ struct ctk_handle {
     uint32_t *h_mail2 = nullptr;                   // pinned, device-written scalars
     void *h_shard = nullptr, *h_lab = nullptr, *h_seam = nullptr;        // pinned: gathered boundary records / label tables / shared seam groups
     size_t h_shard_cap = 0, h_lab_cap = 0, h_seam_cap = 0;
+    bool sh_slots = false;                             // time-shard path: k_overlap writes its records into fixed per-timestep slots
     bool halo_in_zero = false; void *halo_in_zero_p = nullptr;     // the halo header of a first shard is already zero
     uint32_t sh_capB = 0, sh_capC = 0, sh_capD = 0;     // agreed capacities of the exchanged records (grow-only)
     std::vector<std::pair<int32_t, int32_t>> sh_pairs;
@@ -945,7 +946,7 @@ static int launch_overlap(ctk_handle *h)
     a.cprefix = nullptr; a.mrep = nullptr; a.p_rc = nullptr; a.p_rd = nullptr; a.p_gc = nullptr; a.p_gd = nullptr; a.F = nullptr;
     a.pslot = 0; a.upair_cap = h->pair_cap;
     h->fz_pslot = 0;
-    if (h->fz_init && (uint64_t)h->T * CTK_PSLOT + 4096 <= (uint64_t)h->pair_cap) {
+    if ((h->fz_init || h->sh_slots) && (uint64_t)h->T * CTK_PSLOT + 4096 <= (uint64_t)h->pair_cap) {
         a.pslot = CTK_PSLOT; a.upair_cap = h->pair_cap - (uint32_t)(h->T * CTK_PSLOT);
         h->fz_pslot = CTK_PSLOT;
     }
@@ -981,7 +982,7 @@ extern "C" int ctk_shard_overlap(ctk_handle *h)
     if (h->has_prev && (!h->halo_in.p || !h->halo_valid))
         return ctk_set_error(CTK_E_STATE, "ctk_shard_overlap: has_prev set but no halo imported since ctk_shard_label2d");
     size_t want = (size_t)h->total_runs / 2 + (size_t)h->T * 8 + 4096;
-    if (h->fz_init) want = std::max<size_t>(want, (size_t)h->T * CTK_PSLOT + (size_t)h->T * 8 + 8192);       // fixed slots per timestep + ungrouped
+    if (h->fz_init || h->sh_slots) want = std::max<size_t>(want, (size_t)h->T * CTK_PSLOT + (size_t)h->T * 8 + 8192);       // fixed slots per timestep + ungrouped
     if (want > 0x7fffffffull) want = 0x7fffffffull;
     if (h->pair_cap < want || !h->pairs.p) {
         CTKCHK(ensure(h, h->pairs, want * sizeof(CtkPair)));

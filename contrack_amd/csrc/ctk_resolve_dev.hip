@@ -197,6 +197,38 @@ __global__ void k_rs_pairs(ResolveDev r)
     }
 }
 
+// k_rs_pairs on pair records in fixed per-timestep slots (k_overlap with pslot, time-shard path): thread = slot, + the ungrouped ones
+__global__ void k_rs_pairs_slots(ResolveDev r, const uint32_t *__restrict__ pair_cnt, uint32_t pslot)
+{
+    if (!dev_tables_bad(r)) {
+        const uint64_t nslots = (uint64_t)r.T * pslot;
+        const uint32_t nu = dev_nungrouped(r);
+        for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nslots + nu; k += (uint64_t)gridDim.x * blockDim.x) {
+            uint32_t i;
+            if (k < nslots) {
+                const uint32_t t = (uint32_t)(k / pslot), j = (uint32_t)(k - (uint64_t)t * pslot);
+                if (j >= pair_cnt[t]) continue;
+                i = (uint32_t)k;
+            } else i = r.pair_cap - 1u - (uint32_t)(k - nslots);
+            const CtkPair p = r.pairs[i];
+            const uint32_t cb = r.cprefix[p.t], db = r.cprefix[(int32_t)p.t - 1];
+            const uint32_t gc = cb + p.c, gd = db + p.d;
+            const uint32_t rc = cb + r.mrep[gc], rd = db + r.mrep[gd];
+            r.p_gc[i] = gc; r.p_gd[i] = gd; r.p_rc[i] = rc; r.p_rd[i] = rd;
+            atomicAdd((unsigned long long *)&r.F[2 * (int64_t)rd], (unsigned long long)p.lo);
+            atomicAdd((unsigned long long *)&r.F[2 * (int64_t)rd + 1], (unsigned long long)p.hi);
+        }
+    }
+    const uint32_t nc = dev_tables_bad(r) ? 0u : dev_ncomps(r);
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += gridDim.x * blockDim.x) {
+        const uint16_t *q = r.box + 4 * (int64_t)g;
+        if (r.next_tiny[q[0]] <= (int32_t)q[1]) {
+            const uint32_t rep = r.cprefix[(int32_t)r.comp_t[g]] + r.mrep[g];
+            if (r.touch[rep] == 0u) atomicOr(&r.touch[rep], 1u);
+        }
+    }
+}
+
 // 1/areacon and the forward fraction do not change between passes
 __device__ __forceinline__ void dev_prep_comp(const ResolveDev &r, uint32_t g, double *inv_out, double *ff_out, bool *inex_out = nullptr)
 {

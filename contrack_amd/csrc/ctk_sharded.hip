@@ -137,13 +137,25 @@ __global__ void k_sh_pack_keep(ResolveDev r, int it_first, int it_count, uint32_
 #define CTK_SHM_HINT_D   8
 #define CTK_SHM_MYFLAGGED 9
 #define CTK_SHM_MAXFLAGGED 10
+#define CTK_SHM_NPAIRS 11
 __global__ __launch_bounds__(256) void k_sh_unpack_keep(ResolveDev r, const unsigned char *__restrict__ gathered, unsigned char *__restrict__ prev,
                                                         int first_round, int redo, size_t slot, uint32_t capB, int rank, int world, int it_next,
                                                         uint8_t *__restrict__ tdirty, uint32_t *__restrict__ mail,
                                                         // speculative X4: the boundary records travel with the bits (offset bound_off inside a
                                                         // rank's payload, bslot bytes) and go straight into pinned host memory
-                                                        size_t bound_off, size_t bslot, uint32_t *__restrict__ bound_pinned)
+                                                        size_t bound_off, size_t bslot, uint32_t *__restrict__ bound_pinned,
+                                                        const uint32_t *__restrict__ pair_cnt /* slot mode: grouped records per timestep, else nullptr */)
 {
+    if (pair_cnt) {                                             // how many grouped pair records the shard holds (statistics)
+        __shared__ uint32_t s_np;
+        if (threadIdx.x == 0) s_np = 0;
+        __syncthreads();
+        uint32_t v = 0;
+        for (int64_t t = threadIdx.x; t < r.T; t += blockDim.x) v += pair_cnt[t];
+        atomicAdd(&s_np, v);
+        __syncthreads();
+        if (threadIdx.x == 0) mail[CTK_SHM_NPAIRS] = s_np;
+    }
     if (bound_off)
         for (int q = 0; q < world; q++) {
             const uint32_t *src = (const uint32_t *)(gathered + (size_t)q * slot + bound_off);
@@ -566,7 +578,13 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     SHDBG("compact");
 
     // ---- stage 2: co-occurrence histogram (the first local timestep against the halo) ------------------------------------
-    CTKCHK(shard_overlap_v2(h));
+    // (fixed per-timestep slots for the pair records instead of one global counter that every timestep's workgroup adds to:
+    // same-address atomics from eight XCDs, 11 of that kernel's 50 us at 1 deg)
+    h->sh_slots = !getenv("CTK_SH_NO_SLOTS");
+    const int rc_ov = shard_overlap_v2(h);
+    h->sh_slots = false;
+    CTKCHK(rc_ov);
+    const uint32_t pslot = h->fz_pslot;
     SHDBG("overlap");
 
     // ---- resolver tables ---------------------------------------------------------------------------------------------
@@ -619,7 +637,9 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     {
         Timer tm(h, CTK_K_RESOLVE);
         k_rs_init<<<gc, 256, 0, s>>>(r);                                   // (also zeroes the resolver's scalars)
-        k_rs_pairs<<<gp, 256, 0, s>>>(r);
+        const int gps = (int)std::min<uint64_t>(((uint64_t)T * std::max<uint32_t>(pslot, 1u) + 255) / 256 + 16, 4096);
+        if (pslot) k_rs_pairs_slots<<<gps, 256, 0, s>>>(r, in.pair_cnt, pslot);
+        else k_rs_pairs<<<gp, 256, 0, s>>>(r);
         if (has_next)
             k_sh_fwd_last<<<(int)std::min<size_t>((nw + 255) / 256, 1024), 256, 0, s>>>(r, P<uint64_t>(h->mask), P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart),
                                                                                         P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp),
@@ -668,7 +688,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
             Timer tm(h, CTK_K_RESOLVE);
             if (!united) {
                 if (parent_dirty) k_rs_parent_init<<<gc, 256, 0, s>>>(r);
-                k_rs_unite<<<gp, 256, 0, s>>>(r);
+                { if (pslot) k_rs_unite_slots<<<(int)std::min<uint64_t>(((uint64_t)T * pslot + 255) / 256 + 16, 4096), 256, 0, s>>>(r, in.pair_cnt, pslot); else k_rs_unite<<<gp, 256, 0, s>>>(r); }
             }
             k_rs_roots<<<nsb, 256, 0, s>>>(r, P<uint32_t>(h->rv_bsum));                       // (nsb blocks of 256 components)
             k_rs_rank<<<nsb, 256, 0, s>>>(r.isroot, in.cprefix + T, P<uint32_t>(h->rv_bsum), r.rank, P<uint32_t>(h->rv_boff) + nsb);
@@ -687,7 +707,8 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
             HIPCHK(hipGetLastError());
             CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, slot));
             k_sh_unpack_keep<<<1, 256, 0, s>>>(r, (const unsigned char *)h->sh_recv.p, (unsigned char *)h->sh_prev.p, first_round ? 1 : 0, redo, slot, capB, rank, world,
-                                               it_done + npass, P<uint8_t>(h->rv_tdirty), mail2, spec ? kslot : 0, bslot, (uint32_t *)h->h_shard);
+                                               it_done + npass, P<uint8_t>(h->rv_tdirty), mail2, spec ? kslot : 0, bslot, (uint32_t *)h->h_shard,
+                                               pslot ? in.pair_cnt : nullptr);
             HIPCHK(hipGetLastError());
             CTKCHK(ctk_comm_wait(c));
             if (mail2[CTK_SHM_MAXNLAST] <= capB) break;
@@ -762,7 +783,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         {
             Timer tm(h, CTK_K_RESOLVE);
             if (parent_dirty) k_rs_parent_init<<<gc, 256, 0, s>>>(r);
-            k_rs_unite<<<gp, 256, 0, s>>>(r);
+            { if (pslot) k_rs_unite_slots<<<(int)std::min<uint64_t>(((uint64_t)T * pslot + 255) / 256 + 16, 4096), 256, 0, s>>>(r, in.pair_cnt, pslot); else k_rs_unite<<<gp, 256, 0, s>>>(r); }
             const uint32_t *ncp = in.cprefix + T;
             k_rs_roots<<<nsb, 256, 0, s>>>(r, P<uint32_t>(h->rv_bsum));                       // (nsb blocks of 256 components)
             k_rs_rank<<<nsb, 256, 0, s>>>(r.isroot, ncp, P<uint32_t>(h->rv_bsum), r.rank, P<uint32_t>(h->rv_boff) + nsb);
@@ -833,7 +854,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     SHDBG("labels+cands");
     const int64_t ncand = hs[CTK_MAIL_NCAND];
     const size_t nd = hs[CTK_MAIL_ND];
-    h->stats[CTK_S_COMPONENTS] = (int64_t)hs[CTK_MAIL_NC]; h->stats[CTK_S_PAIRS] = (int64_t)hs[CTK_CNT_PAIRS] + hs[CTK_CNT_UPAIRS];
+    h->stats[CTK_S_COMPONENTS] = (int64_t)hs[CTK_MAIL_NC]; h->stats[CTK_S_PAIRS] = (int64_t)(pslot ? mail2[CTK_SHM_NPAIRS] : hs[CTK_CNT_PAIRS]) + hs[CTK_CNT_UPAIRS];
     h->stats[CTK_S_SEAM_ROWS] = ncand; h->stats[CTK_S_LABELS] = NL; h->stats[CTK_S_UPAIRS] = hs[CTK_CNT_UPAIRS];
     h->mail_want_c = std::max<size_t>(h->mail_want_c, (size_t)ncand + (size_t)ncand / 2);
     h->mail_want_d = std::max<size_t>(h->mail_want_d, nd + nd / 2);
