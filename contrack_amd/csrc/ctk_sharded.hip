@@ -887,7 +887,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     // No label reaches a shard boundary anywhere (always so with one shard): nobody has shared groups -- every rank knows it from
     // the boundary resolution, which all ranks computed from the same gathered records -- and the exchange is left out; the
     // candidate records go to the driver as they are.
-    bool any_boundary_label = false;
+    bool any_boundary_label = getenv("CTK_SH_FORCE_SPLIT") != nullptr;      // (experiments: the split / exchange even without shared groups; every rank or none)
     for (int q = 0; q < world && !any_boundary_label; q++) {
         for (int32_t l : S.bout.halo_label[(size_t)q]) if (l > 0) { any_boundary_label = true; break; }
         if (q + 1 < world) for (int32_t l : S.bout.last_label[(size_t)q]) if (l > 0) { any_boundary_label = true; break; }
@@ -920,13 +920,19 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     bool local_done = false;
     auto drive_local = [&]() {
         // this shard's own groups (dense ids renumbered without the shared labels), driven here
-        S.lmap.assign(nd, -1); S.lorig.clear(); S.lbox.clear(); S.lcand.clear();
-        for (size_t i = 0; i < nd; i++)
-            if (!shared((int32_t)i)) { S.lmap[i] = (int32_t)S.lorig.size(); S.lorig.push_back(ho[i]); S.lbox.insert(S.lbox.end(), hbx + 6 * i, hbx + 6 * i + 6); }
-        for (int64_t k = 0; k < ncand; k++)
-            if (!shared(hc[k].ll)) { CtkCand v = hc[k]; v.ll = S.lmap[(size_t)v.ll]; v.lr = S.lmap[(size_t)v.lr]; S.lcand.push_back(v); }
-        h->sd.run(S.lcand.data(), (int64_t)S.lcand.size(), S.lorig.data(), S.lbox.data(), (int64_t)S.lorig.size(), nx, S.ops_l);
-        lorig = S.lorig.data(); n_lorig = S.lorig.size();
+        // (sized once, filled by index: a push_back / insert per label was a third of this step's time)
+        S.lmap.resize(nd); S.lorig.resize(nd); S.lbox.resize(6 * nd); S.lcand.resize((size_t)ncand);
+        size_t nl = 0, nk = 0;
+        for (size_t i = 0; i < nd; i++) {
+            if (shared((int32_t)i)) { S.lmap[i] = -1; continue; }
+            S.lmap[i] = (int32_t)nl; S.lorig[nl] = ho[i]; memcpy(&S.lbox[6 * nl], hbx + 6 * i, 24); nl++;
+        }
+        for (int64_t k = 0; k < ncand; k++) {
+            if (shared(hc[k].ll)) continue;
+            CtkCand v = hc[k]; v.ll = S.lmap[(size_t)v.ll]; v.lr = S.lmap[(size_t)v.lr]; S.lcand[nk++] = v;
+        }
+        h->sd.run(S.lcand.data(), (int64_t)nk, S.lorig.data(), S.lbox.data(), (int64_t)nl, nx, S.ops_l);
+        lorig = S.lorig.data(); n_lorig = nl;
     };
     if (!any_boundary_label) h->sd.run(hc, ncand, ho, hbx, (int64_t)nd, nx, S.ops_l);
     for (; any_boundary_label;) {
