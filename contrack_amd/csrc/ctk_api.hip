@@ -138,7 +138,7 @@ struct ctk_handle {
     DevBuf pairs, seams, ext, ops, op_first, op_next, op_stage, halo_in, halo_out, dbg;
     DevBuf seam_cnt, seam_off, d_seams, d_comp_t, pair_base, pair_cnt, rv_tdirty, d_blob, seam_rowoff;
     // device resolver work space
-    DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lbox,
+    DevBuf rv_prc, rv_prd, rv_pgc, rv_pgd, rv_F, rv_B, rv_keep0, rv_keep1, rv_changed, rv_parent, rv_isroot, rv_rank, rv_lab, rv_lab_root, rv_lbox,
         rv_bsum, rv_boff, rv_cand_cnt, rv_cand_off, rv_cand, rv_cand_scratch, rv_seam_res, rv_scalars, rv_mark, rv_inv, rv_ff, rv_dmap, rv_dorig, rv_dbox, rv_inex, rv_touch;
     // run_lifecycle reductions
     DevBuf lc_rows, lc_cnt, lc_wlo, lc_whi, lc_w, lc_work, lc_ovf, lc_ekeys, lc_offs, lc_sw, lc_sp, lc_out, lc_cross, lc_gtab, lc_occ, lc_cp;
@@ -399,7 +399,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->comp_label, &h->g_x0, &h->g_x1, &h->g_y, &h->g_parent, &h->g_root, &h->g_idmap, &h->g_rs, &h->pairs, &h->seams,
                       &h->ext, &h->ops, &h->op_first, &h->op_next, &h->op_stage, &h->halo_in, &h->halo_out, &h->dbg, &h->seam_cnt, &h->seam_off, &h->d_seams,
                       &h->d_comp_t, &h->pair_base, &h->pair_cnt, &h->rv_tdirty, &h->d_blob, &h->seam_rowoff, &h->rv_prc, &h->rv_prd, &h->rv_pgc, &h->rv_pgd, &h->rv_F, &h->rv_B, &h->rv_keep0, &h->rv_keep1,
-                      &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
+                      &h->rv_changed, &h->rv_parent, &h->rv_isroot, &h->rv_rank, &h->rv_lab, &h->rv_lab_root, &h->rv_lbox, &h->rv_bsum, &h->rv_boff,
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
                       &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
                       &h->sh_mask_next, &h->sh_send, &h->sh_recv, &h->sh_prev, &h->sh_elist, &h->sh_ovr_slot, &h->sh_ovr_val,
@@ -1268,7 +1268,7 @@ static int rs_prepare(ctk_handle *h, const ResolveIn &in, double overlap, int tw
     r.p_rc = P<uint32_t>(h->rv_prc); r.p_rd = P<uint32_t>(h->rv_prd); r.p_gc = P<uint32_t>(h->rv_pgc); r.p_gd = P<uint32_t>(h->rv_pgd);
     r.F = P<int64_t>(h->rv_F); r.B = P<int64_t>(h->rv_B); r.keep0 = P<uint8_t>(h->rv_keep0); r.keep1 = P<uint8_t>(h->rv_keep1);
     r.changed = P<uint32_t>(h->rv_changed); r.parent = P<uint32_t>(h->rv_parent); r.isroot = P<uint32_t>(h->rv_isroot);
-    r.rank = P<uint32_t>(h->rv_rank); r.lab = P<int32_t>(h->rv_lab);
+    r.rank = P<uint32_t>(h->rv_rank); r.lab = P<int32_t>(h->rv_lab); r.lab_root = nullptr;
     r.mark = P<uint8_t>(h->rv_mark); r.inv = P<double>(h->rv_inv); r.ff = P<double>(h->rv_ff);
     r.dmap = P<uint32_t>(h->rv_dmap); r.dorig = P<int32_t>(h->rv_dorig); r.dbox = P<int32_t>(h->rv_dbox); r.dcount = P<uint32_t>(h->rv_scalars); r.op_first = P<int32_t>(h->op_first);
     r.inex = P<uint8_t>(h->rv_inex); r.ambig = P<uint32_t>(h->rv_scalars) + 1; r.minlsb = h->w_minlsb;
@@ -1726,6 +1726,8 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     h->n_labels = (int64_t)R; h->t_begin = 0;
     r.cl_parent = P<uint32_t>(h->sd_parent); r.cl_tmin = P<int32_t>(h->sd_tmin); r.cl_tmax = P<int32_t>(h->sd_tmax); r.cl_nops = P<uint32_t>(h->sd_nops);
     r.lbox = P<int32_t>(h->sd_lbox);
+    CTKCHK(ensure(h, h->rv_lab_root, (R + 1) * 4));
+    r.lab_root = P<int32_t>(h->rv_lab_root);
     r.ext = P<int32_t>(h->ext); r.ext_off = (int64_t)R + 1; r.counters_w = P<uint32_t>(h->counters);
     SeamDev sd;
     sd.dummy = nullptr;
@@ -1763,13 +1765,23 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
         if (sys && NP > 0) { /* united by k_rs_pass_sys */ }
         else if (h->fz_pslot) k_rs_unite_slots<<<(int)std::min<int64_t>((T * h->fz_pslot + 255) / 256 + 1, 4096), 256, 0, s>>>(r, in.pair_cnt, h->fz_pslot);
         else k_rs_unite<<<gp, 256, 0, s>>>(r);
+        static const bool rank_mark = !getenv("CTK_NO_RANK_MARK");
+        const bool merged = rank_mark && nsb <= CTK_RL_BLOCKS;
+        if (!merged) r.lab_root = nullptr;
         k_rs_roots<<<nsb, 256, 0, s>>>(r, P<uint32_t>(h->rv_bsum));
-        if (nsb <= CTK_RL_BLOCKS) k_rs_rank_labels<<<nsb, 256, (size_t)nsb * 4, s>>>(r, P<uint32_t>(h->rv_bsum), (uint32_t)nsb, P<uint32_t>(h->rv_boff) + nsb);
-        else {
-            k_rs_rank<<<nsb, 256, 0, s>>>(r.isroot, in.cprefix + T, P<uint32_t>(h->rv_bsum), r.rank, P<uint32_t>(h->rv_boff) + nsb);
-            k_rs_labels<<<gc, 256, 0, s>>>(r);
+        if (merged) {
+            // numbering of the components and marking of the seam rows in one launch (the marks derive the labels they need)
+            const int nblk_max = (int)std::min<int64_t>(nsb, ((int64_t)h->total_runs + 255) / 256 + 1);      // (components <= runs)
+            k_fz_rank_mark<<<std::max(nblk_max, (int)((T + 3) / 4)), 256, (size_t)nsb * 4, s>>>(r, sd, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res),
+                                                                                               P<uint32_t>(h->rv_bsum), (uint32_t)nsb, P<uint32_t>(h->rv_boff) + nsb);
+        } else {
+            if (nsb <= CTK_RL_BLOCKS) k_rs_rank_labels<<<nsb, 256, (size_t)nsb * 4, s>>>(r, P<uint32_t>(h->rv_bsum), (uint32_t)nsb, P<uint32_t>(h->rv_boff) + nsb);
+            else {
+                k_rs_rank<<<nsb, 256, 0, s>>>(r.isroot, in.cprefix + T, P<uint32_t>(h->rv_bsum), r.rank, P<uint32_t>(h->rv_boff) + nsb);
+                k_rs_labels<<<gc, 256, 0, s>>>(r);
+            }
+            k_fz_mark<<<(int)T, 64, 0, s>>>(r, sd, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res));
         }
-        k_fz_mark<<<(int)T, 64, 0, s>>>(r, sd, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res));
         k_fz_groups<<<(int)((T + FZ_TW - 1) / FZ_TW), 64 * FZ_TW, 0, s>>>(r, sd, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), 0);
         k_seam_driver<<<(int)std::min<int64_t>(T, 65536), 64, 0, s>>>(sd, 0);
         HIPCHK(hipGetLastError());

@@ -38,6 +38,7 @@ struct ResolveDev {
     uint32_t *parent;                     // [NC]
     uint32_t *isroot, *rank;              // [NC], [NC+1]
     int32_t *lab;                         // [NC] fresh 3-D label of every component (0 = filtered out)
+    int32_t *lab_root;                    // [NC] or nullptr: the root index k_rs_roots found (kept for k_fz_rank_mark)
     uint8_t *mark;                        // [NC+1] label occurs in a seam row with two different labels
     // labels that occur in candidate records get dense ids (claim order), so that the host seam driver works on
     // tables of a few thousand entries instead of one slot per fresh label
@@ -819,6 +820,7 @@ __global__ __launch_bounds__(256) void k_rs_roots(ResolveDev r, uint32_t *__rest
         const bool kept = r.keep0[r.cprefix[t] + r.mrep[g]] != 0;
         const uint32_t root = gfind(r.parent, g);
         r.lab[g] = kept ? (int32_t)root : -1;               // temporarily: root index, -1 = filtered out
+        if (r.lab_root) r.lab_root[g] = kept ? (int32_t)root : -1;      // (fused path: kept while k_fz_rank_mark writes the labels into lab)
         isr = (kept && root == g && g >= (r.nh_ptr ? *r.nh_ptr : 0u)) ? 1u : 0u;       // (a halo root is numbered by an earlier shard)
         r.isroot[g] = isr;
         // labels <= components: candidate mark / dense-id slot g+1 are initialised here

@@ -80,6 +80,65 @@ __global__ __launch_bounds__(64) void k_fz_mark(ResolveDev r, SeamDev a, const C
     }
 }
 
+// k_rs_rank_labels + k_fz_mark in ONE launch.  The marks need the labels of the two seam components of every seam row -- and a
+// label is a cheap function of what k_rs_roots left behind: 1 + (roots in the blocks in front of the root's block) + (roots in
+// front of it inside its block).  So the workgroups that number the components (part A, one per 256 components) and the waves
+// that mark the seam rows (part B, one per timestep) do not wait for each other: every workgroup builds the prefix of the block
+// counts in LDS and the seam waves derive the labels they need from the ROOT indices (lab_root, a copy k_rs_roots keeps while
+// part A overwrites r.lab with the labels).
+__global__ __launch_bounds__(256) void k_fz_rank_mark(ResolveDev r, SeamDev a, const CtkSeam *__restrict__ seams, const uint32_t *__restrict__ seam_cnt,
+                                                      const uint32_t *__restrict__ seam_off, int2 *__restrict__ res, const uint32_t *__restrict__ bsum,
+                                                      uint32_t nsb, uint32_t *__restrict__ total)
+{
+    if (dev_tables_bad(r)) return;
+    extern __shared__ uint32_t pre[];                       // [nsb]
+    __shared__ uint32_t sm[8];
+    const uint32_t nc = dev_ncomps(r);
+    const uint32_t nblk = min((nc + 255u) / 256u, nsb);
+    uint32_t carry = 0;
+    for (uint32_t j0 = 0; j0 < nblk; j0 += 256) {
+        const uint32_t j = j0 + threadIdx.x;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(j < nblk ? bsum[j] : 0u, sm, &tot);
+        if (j < nblk) pre[j] = carry + ex;
+        carry += tot;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *total = carry;
+    __syncthreads();
+    auto label_of = [&](int32_t root) -> int32_t { return root < 0 ? 0 : (int32_t)(pre[(uint32_t)root >> 8] + r.rank[root]) + 1; };
+    // part A: labels of the components
+    if (blockIdx.x < nblk)
+        for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < nc; g += nblk * 256u) r.lab[g] = label_of(r.lab_root[g]);
+    // part B: seam rows of timestep 4 b + wave
+    const int t = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    if (t >= (int)a.T) return;
+    const uint32_t n = seam_cnt[t], cb = r.cprefix[t];
+    const CtkSeam *scratch = seams + seam_off[t];
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        int2 v = make_int2(-1, -1);
+        if (i < n) {
+            const CtkSeam q = scratch[i];
+            if (r.keep0[cb + r.mrep[cb + q.cl]]) { v.x = label_of(r.lab_root[cb + q.cl]); v.y = label_of(r.lab_root[cb + q.cr]); }
+            res[(int64_t)t * a.ny + i] = v;
+        }
+        const int px = __shfl_up(v.x, 1), py = __shfl_up(v.y, 1);
+        if (v.x >= 0 && v.x != v.y && !(lane > 0 && px == v.x && py == v.y)) {      // first row of a stretch with this pair
+            a.mark[v.x] = 1; a.mark[v.y] = 1;
+            uint32_t p = (uint32_t)v.x, q = (uint32_t)v.y;
+            for (;;) {
+                p = gfind(a.cl_parent, p);
+                q = gfind(a.cl_parent, q);
+                if (p == q) break;
+                if (p < q) { const uint32_t s = p; p = q; q = s; }
+                const uint32_t old = atomicMin(&a.cl_parent[p], q);
+                if (old == p) break;
+                p = old;
+            }
+        }
+    }
+}
+
 // k_rs_cand_groups for the fused path: boxes of the marked labels, surviving seam rows run-length grouped, and for every group
 // record the root of its cluster and the cluster's range of timesteps (the unions are complete: k_fz_mark is a launch of its own).
 //
