@@ -631,6 +631,8 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     CTKCHK(ensure(h, h->counters, CTK_CNT_WORDS * 4));
     CTKCHK(ensure_host(&h->h_small, &h->h_small_cap, (size_t)(T + 1) * 4 + 1024));     // run_base copy + scalar downloads
 
+    if (h->pass_no <= 1 && getenv("CTK_PRINT_PTRS"))                     // (placement experiments, tools/thr_handle_probe.py)
+        fprintf(stderr, "PTRS in %p mask %p thr32 %p counters %p wstart %p rowstart %p\n", anom_dev, h->mask.p, h->thr32.p, h->counters.p, h->wstart.p, h->rowstart.p);
     // (the device counters are zeroed by the first threshold launch of the pass; k_rowcount writes every tcount[t])
     if (T == 0) HIPCHK(hipMemsetAsync(h->counters.p, 0, CTK_CNT_N * 4, s));
     if (T > 0) {

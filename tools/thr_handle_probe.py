@@ -13,9 +13,10 @@ t0 = _native.Tracker(0)
 d_in, d_out = t0.malloc(n), t0.malloc(n)
 t0.synth_fill(d_in, T, ny, nx, seed=0)
 keep = []
-for k in range(6):
-    if k:
-        keep.append(t0.malloc((k * 7 + 1) << 20))
+sizes = [0, 8, 15, 22, 29, 36, 1, 64, 3, 100, 17, 256, 5, 33, 2, 512]
+for k in range(int(os.environ.get('NH', '6'))):
+    if sizes[k]:
+        keep.append(t0.malloc(sizes[k] << 20))
     trk = _native.Tracker(0)
     trk.set_timing(1)
     for _ in range(3):
