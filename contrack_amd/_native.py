@@ -28,7 +28,7 @@ EXPORTS = [
     "ctk_synth_fill",
     "ctk_comm_unique_id", "ctk_comm_init_rccl", "ctk_comm_group_create", "ctk_comm_group_destroy", "ctk_comm_init_local", "ctk_comm_init_shm",
     "ctk_comm_destroy", "ctk_comm_rank", "ctk_comm_world", "ctk_comm_barrier", "ctk_comm_allgather_host", "ctk_comm_ops",
-    "ctk_comm_set_timeout", "ctk_comm_failed", "ctk_comm_abort_rank", "ctk_debug_fail_at", "ctk_synth_fill_window", "ctk_checksum_i32_dev",
+    "ctk_comm_set_timeout", "ctk_comm_failed", "ctk_comm_abort_rank", "ctk_debug_fail_at", "ctk_synth_fill_window", "ctk_checksum_i32_dev", "ctk_dev_memset", "ctk_check_flag_dev",
     "ctk_track_sharded_f32_dev", "ctk_track_sharded_f64_dev",
     "ctk_anom_f32", "ctk_anom_f64", "ctk_resident_anom", "ctk_resident_anom_generation", "ctk_track_resident", "ctk_percentile_f32", "ctk_percentile_f64",
     "ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev", "ctk_lifecycle_rows", "ctk_lifecycle_exact",
@@ -122,6 +122,8 @@ def lib():
     L.ctk_synth_fill.argtypes = [p, p, i64, i32, i32, C.c_uint64]
     L.ctk_synth_fill_window.argtypes = [p, p, i64, i64, i32, i32, C.c_uint64]
     L.ctk_checksum_i32_dev.argtypes = [p, p, i64, i64, p]
+    L.ctk_dev_memset.argtypes = [p, p, i32, sz]
+    L.ctk_check_flag_dev.argtypes = [p, p, p, i64, i32, i32, p, i32, i32, i64, p]
     L.ctk_comm_set_timeout.argtypes = [p, dbl]
     L.ctk_comm_failed.argtypes = [p, C.POINTER(i32), C.POINTER(i32)]
     L.ctk_comm_abort_rank.argtypes = [p, i32]
@@ -567,6 +569,19 @@ class Tracker:
         out = np.zeros(2, dtype=np.uint64)
         check(lib().ctk_checksum_i32_dev(self._h, ptr, int(n), int(index0), out.ctypes.data))
         return int(out[0]), int(out[1])
+
+    def memset(self, ptr, byte, nbytes):
+        check(lib().ctk_dev_memset(self._h, ptr, int(byte), int(nbytes)))
+
+    def check_flag(self, anom_dev, flag_dev, T, ny, nx, thr, cmp_op, persistence, max_id):
+        """device-side properties of a result (ctk_check_flag_dev): dict of counts"""
+        thr = np.ascontiguousarray(thr, dtype=np.float64)
+        if thr.shape != (T,):
+            raise ValueError("thr must have shape (T,)")
+        out = np.zeros(6, dtype=np.uint64)
+        check(lib().ctk_check_flag_dev(self._h, anom_dev, flag_dev, int(T), int(ny), int(nx), thr.ctypes.data, int(cmp_op), int(persistence), int(max_id),
+                                       out.ctypes.data))
+        return dict(zip(("flag_outside_mask", "ids_out_of_range", "nonzero", "ids", "ids_below_persistence", "max_id"), (int(v) for v in out)))
 
     def debug_fail_at(self, stage):
         check(lib().ctk_debug_fail_at(self._h, int(stage)))

@@ -46,6 +46,24 @@ static double now_ms_fwd() { return std::chrono::duration<double, std::milli>(st
 #define HT(name) do { if (g_ht < 0) g_ht = getenv("CTK_HOSTTRACE") ? 1 : 0; if (g_ht) { double t_ = now_ms_fwd(); fprintf(stderr, "HT %-28s %9.1f us\n", name, (t_ - g_ht0) * 1e3); } } while (0)
 #define HT0() do { if (g_ht < 0) g_ht = getenv("CTK_HOSTTRACE") ? 1 : 0; if (g_ht) g_ht0 = now_ms_fwd(); } while (0)
 
+// Debug / experiment switches of the environment, read ONCE per process (getenv is a linear scan of environ and not safe against a
+// concurrent setenv from another rank's host thread; the passes shave microseconds).
+struct CtkEnv {
+    int sd_dbg = 0, relabel_rows = 0;
+    bool pass_launches = false, print_ptrs = false, seamstats = false, relabel_plain = false, relabel_v4 = false, hosttrace = false,
+         sh_no_slots = false, no_spec_x4 = false, sh_force_split = false;
+    CtkEnv()
+    {
+        auto num = [](const char *k) { const char *e = getenv(k); return e ? atoi(e) : 0; };
+        auto on = [](const char *k) { return getenv(k) != nullptr; };
+        sd_dbg = num("CTK_SD_DBG"); relabel_rows = num("CTK_RELABEL_ROWS");
+        pass_launches = on("CTK_PASS_LAUNCHES"); print_ptrs = on("CTK_PRINT_PTRS"); seamstats = on("CTK_SEAMSTATS");
+        relabel_plain = on("CTK_RELABEL_PLAIN"); relabel_v4 = on("CTK_RELABEL_V4"); hosttrace = on("CTK_HOSTTRACE");
+        sh_no_slots = on("CTK_SH_NO_SLOTS"); no_spec_x4 = on("CTK_NO_SPEC_X4"); sh_force_split = on("CTK_SH_FORCE_SPLIT");
+    }
+};
+static const CtkEnv &ctk_env() { static const CtkEnv e; return e; }
+
 struct ShardScratch;
 static void shard_scratch_free(ShardScratch *s);            // ctk_sharded.hip
 
@@ -178,7 +196,7 @@ struct ctk_handle {
     void *h_shard = nullptr, *h_lab = nullptr, *h_seam = nullptr;        // pinned: gathered boundary records / label tables / shared seam groups
     size_t h_shard_cap = 0, h_lab_cap = 0, h_seam_cap = 0;
     bool sh_slots = false;                             // time-shard path: k_overlap writes its records into fixed per-timestep slots
-    bool halo_in_zero = false; void *halo_in_zero_p = nullptr;     // the halo header of a first shard is already zero
+    bool halo_in_zero = false; void *halo_in_zero_p = nullptr; size_t halo_in_zero_cap = 0;     // the halo header of a first shard is already zero
     uint32_t sh_capB = 0, sh_capC = 0, sh_capD = 0;     // agreed capacities of the exchanged records (grow-only)
     std::vector<std::pair<int32_t, int32_t>> sh_pairs;
     bool halo_valid = false, halo_v2 = false;
@@ -631,7 +649,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     CTKCHK(ensure(h, h->counters, CTK_CNT_WORDS * 4));
     CTKCHK(ensure_host(&h->h_small, &h->h_small_cap, (size_t)(T + 1) * 4 + 1024));     // run_base copy + scalar downloads
 
-    if (h->pass_no <= 1 && getenv("CTK_PRINT_PTRS"))                     // (placement experiments, tools/thr_handle_probe.py)
+    if (h->pass_no <= 1 && ctk_env().print_ptrs)                     // (placement experiments, tools/thr_handle_probe.py)
         fprintf(stderr, "PTRS in %p mask %p thr32 %p counters %p wstart %p rowstart %p\n", anom_dev, h->mask.p, h->thr32.p, h->counters.p, h->wstart.p, h->rowstart.p);
     // (the device counters are zeroed by the first threshold launch of the pass; k_rowcount writes every tcount[t])
     if (T == 0) HIPCHK(hipMemsetAsync(h->counters.p, 0, CTK_CNT_N * 4, s));
@@ -920,6 +938,7 @@ extern "C" int ctk_shard_halo_import(ctk_handle *h, const void *blob_dev, size_t
     if (nbytes < halo_off_runcomp(h) || nbytes > halo_max_bytes(h)) return ctk_set_error(CTK_E_INVALID, "halo blob has %zu bytes, expected %zu..%zu", nbytes, halo_off_runcomp(h), halo_max_bytes(h));
     HIPCHK(hipSetDevice(h->device));
     CTKCHK(ensure(h, h->halo_in, halo_max_bytes(h)));
+    h->halo_in_zero = false;                                     // (the blob overwrites the HaloHeader a first time shard keeps zeroed)
     HIPCHK(hipMemcpyAsync(h->halo_in.p, blob_dev, nbytes, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->halo_valid = true;
@@ -1399,7 +1418,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
         const CtkCand *hc = (const CtkCand *)dst;
         const int32_t *ho = (const int32_t *)(dst + cb), *hb = ho + nd;
         h->sd.run(hc, ncand, ho, hb, (int64_t)nd, h->nx, ops);
-        if (getenv("CTK_SEAMSTATS")) {
+        if (ctk_env().seamstats) {
             // clusters of candidate labels (connected through shared seam rows): what a parallel device-side driver would see
             std::vector<int32_t> uf(nd);
             for (size_t i = 0; i < nd; i++) uf[i] = (int32_t)i;
@@ -1565,7 +1584,7 @@ static int relabel_rows(const ctk_handle *h)
     const int rb_max = std::min(h->ny, std::max(rb, std::min(64, 2304 / n4r)));
     while (rb < rb_max && h->T * ((h->ny + rb - 1) / rb) > 250000) rb++;
     while (rb < h->ny && h->T * ((h->ny + rb - 1) / rb) >= (1 << 24)) rb++;
-    if (getenv("CTK_RELABEL_ROWS")) rb = std::min(h->ny, std::max(1, atoi(getenv("CTK_RELABEL_ROWS"))));
+    if (ctk_env().relabel_rows > 0) rb = std::min(h->ny, ctk_env().relabel_rows);
     return rb;
 }
 static bool relabel_fast_ok(const ctk_handle *h, const int32_t *flag_dev, int rb)
@@ -1601,7 +1620,7 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
     a.nrows = nt * h->ny; a.ny = h->ny; a.nx = h->nx; a.W = h->W;
     a.chunk_vals = chunk_vals ? chunk_vals + t0 * nchunk * CTK_CV : nullptr;
     a.guard = h->guard_on ? P<uint32_t>(h->counters) : nullptr;
-    a.plain_stores = getenv("CTK_RELABEL_PLAIN") ? 1 : 0;
+    a.plain_stores = ctk_env().relabel_plain ? 1 : 0;
     const int64_t npl = (int64_t)h->ny * h->nx;
     const int rvcap = 2048;
     const size_t lds = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) + (size_t)rvcap * 4;
@@ -1616,7 +1635,7 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
         int sub = rb;
         while (sub > 1 && tab5 + (size_t)sub * h->nx * 4 > 20 * 1024) sub--;
         const size_t lds5 = tab5 + (size_t)sub * h->nx * 4;
-        if (lds5 <= 20 * 1024 && !getenv("CTK_RELABEL_V4")) { k_relabel_v5<<<grid, 256, lds5, h->stream>>>(a, rb, rv5, sub); h->stats[CTK_S_RELABEL_KERNEL] = 5; }
+        if (lds5 <= 20 * 1024 && !ctk_env().relabel_v4) { k_relabel_v5<<<grid, 256, lds5, h->stream>>>(a, rb, rv5, sub); h->stats[CTK_S_RELABEL_KERNEL] = 5; }
         else { k_relabel_v4<<<grid, 256, lds, h->stream>>>(a, rb, rvcap); h->stats[CTK_S_RELABEL_KERNEL] = 4; }
     } else if (nt > 0) {
         a.chunk_vals = nullptr;
@@ -1739,13 +1758,13 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     sd.ops = P<CtkOp>(h->ops); sd.op_next = (int32_t *)(P<CtkOp>(h->ops) + op_cap); sd.op_first = r.op_first;
     sd.op_count = P<uint32_t>(h->counters) + CTK_CNT_NOPS; sd.op_cap = op_cap; sd.own_ids = own_ids;
     sd.poison = P<uint32_t>(h->counters) + CTK_CNT_POISON; sd.ny = h->ny; sd.nx = h->nx; sd.T = T;
-    sd.dbg = getenv("CTK_SD_DBG") ? atoi(getenv("CTK_SD_DBG")) : 0;
+    sd.dbg = ctk_env().sd_dbg;
     sd.lab_cap = h->debug_sd_lab ? std::min(h->debug_sd_lab, SD_LAB) : SD_LAB; sd.ops_cap = h->debug_sd_ops ? std::min(h->debug_sd_ops, 64) : 64;
     h->d_op_next = sd.op_next;
     h->nops = 1;                                                  // (unknown here; nonzero = the folds look at the chains)
     // filter passes: all of them in one launch (k_rs_pass_sys, at most 24 iterations) when every workgroup of the launch can wait
     // for its predecessor, else one launch per pass
-    const bool sys = !getenv("CTK_PASS_LAUNCHES") && h->async_passes <= 24 && T - 2 <= 60000;
+    const bool sys = !ctk_env().pass_launches && h->async_passes <= 24 && T - 2 <= 60000;
     const int NP = T > 2 ? std::min(std::max(h->async_passes, 2), sys ? 24 : CTK_MAX_JACOBI) : 0;
     if (sys) { CTKCHK(ensure(h, h->rv_pstate, (size_t)(T + 1) * 4 * CTK_PSTATE_STRIDE)); r.pstate = P<uint32_t>(h->rv_pstate); }
     h->guard_on = true;
@@ -1848,7 +1867,7 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     const int64_t npairs_grouped = h->fz_pslot ? (int64_t)m[CTK_AM_NPAIRS] : (int64_t)cnt[CTK_CNT_PAIRS];
     if (NP > 0 && m[CTK_AM_CONV] == 0) { h->async_passes = std::min(CTK_MAX_JACOBI, NP * 2); return 1; }          // longer removal cascade than launched for
     if (m[CTK_AM_AMBIG]) return 1;                                                                               // decisions on rounding boundaries
-    if (getenv("CTK_SD_DBG")) fprintf(stderr, "SDDBG max row steps %u, max fold iterations %u, max process time %.2f us, max cluster time %.2f us, fold cycles (clock64) %u\n", cnt[10], cnt[11], cnt[12] * 0.01, cnt[13] * 0.01, cnt[14]);
+    if (ctk_env().sd_dbg) fprintf(stderr, "SDDBG max row steps %u, max fold iterations %u, max process time %.2f us, max cluster time %.2f us, fold cycles (clock64) %u\n", cnt[10], cnt[11], cnt[12] * 0.01, cnt[13] * 0.01, cnt[14]);
     const uint32_t poison = cnt[CTK_CNT_POISON];
     if (poison) {
         if (poison & CTK_POISON_OPCAP) h->op_cap_hint = std::max(h->op_cap_hint * 2, cnt[CTK_CNT_NOPS] + cnt[CTK_CNT_NOPS] / 2 + 1024);
@@ -2038,7 +2057,7 @@ static int track_host_impl(ctk_handle *h, const void *anom, bool f64, int64_t T,
         }
     }
     const double e3 = now_ms();
-    if (getenv("CTK_HOSTTRACE")) fprintf(stderr, "e2e: H2D %.1f ms | device path %.2f ms | D2H %.1f ms\n", e1 - e0, e2 - e1, e3 - e2);
+    if (ctk_env().hosttrace) fprintf(stderr, "e2e: H2D %.1f ms | device path %.2f ms | D2H %.1f ms\n", e1 - e0, e2 - e1, e3 - e2);
     h->ms[CTK_T_H2D] = e1 - e0; h->ms[CTK_T_D2H] = e3 - e2; h->ms[CTK_T_TOTAL] = e3 - e0;      // (whole-call figures of the host entry)
     return rc;
 }
@@ -2591,6 +2610,50 @@ extern "C" int ctk_checksum_i32_dev(ctk_handle *h, const int32_t *p_dev, int64_t
     }
     HIPCHK(hipMemcpyAsync(out2, h->dbg.p, 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return CTK_OK;
+}
+
+extern "C" int ctk_dev_memset(ctk_handle *h, void *p_dev, int byte, size_t nbytes)
+{
+    if (!h || (nbytes && !p_dev)) return ctk_set_error(CTK_E_INVALID, "ctk_dev_memset: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (nbytes) HIPCHK(hipMemsetAsync(p_dev, byte, nbytes, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CTK_OK;
+}
+
+extern "C" int ctk_check_flag_dev(ctk_handle *h, const float *anom_dev, const int32_t *flag_dev, int64_t T, int ny, int nx, const double *thr, int cmp_op,
+                                  int persistence, int64_t max_id, uint64_t *out6)
+{
+    if (!h || !out6 || T < 0 || ny < 1 || nx < 1 || max_id < 0 || max_id > 0x7ffffffell || cmp_op < 0 || cmp_op > 3 || (T > 0 && (!anom_dev || !flag_dev || !thr)))
+        return ctk_set_error(CTK_E_INVALID, "ctk_check_flag_dev: bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const size_t tab = (size_t)(max_id + 1) * 4;
+    void *d_thr = nullptr, *d_tab = nullptr;
+    struct Free { void *&a, *&b; ~Free() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } fr{d_thr, d_tab};
+    HIPCHK(hipMalloc(&d_thr, (size_t)std::max<int64_t>(T, 1) * 8));
+    HIPCHK(hipMalloc(&d_tab, 2 * tab));
+    CTKCHK(ensure(h, h->dbg, 64));
+    HIPCHK(hipMemsetAsync(h->dbg.p, 0, 48, s));
+    if (T > 0) HIPCHK(hipMemcpyAsync(d_thr, thr, (size_t)T * 8, hipMemcpyHostToDevice, s));
+    int32_t *tmin = (int32_t *)d_tab, *tmax = tmin + (max_id + 1);
+    k_fill_minmax<<<(int)std::min<int64_t>((max_id + 256) / 256, 4096), 256, 0, s>>>(tmin, tmax, max_id + 1);
+    const int64_t nrows = T * ny;
+    if (nrows > 0) {
+        const int g = (int)std::min<int64_t>((nrows + 3) / 4, 1 << 16);
+        unsigned long long *o = (unsigned long long *)h->dbg.p;
+        switch (cmp_op) {
+        case 0: k_check_flag<0><<<g, 256, 0, s>>>(anom_dev, flag_dev, nrows, ny, nx, (const double *)d_thr, max_id, tmin, tmax, o); break;
+        case 1: k_check_flag<1><<<g, 256, 0, s>>>(anom_dev, flag_dev, nrows, ny, nx, (const double *)d_thr, max_id, tmin, tmax, o); break;
+        case 2: k_check_flag<2><<<g, 256, 0, s>>>(anom_dev, flag_dev, nrows, ny, nx, (const double *)d_thr, max_id, tmin, tmax, o); break;
+        default: k_check_flag<3><<<g, 256, 0, s>>>(anom_dev, flag_dev, nrows, ny, nx, (const double *)d_thr, max_id, tmin, tmax, o); break;
+        }
+    }
+    k_check_ids<<<(int)std::min<int64_t>((max_id + 256) / 256, 4096), 256, 0, s>>>(tmin, tmax, max_id, persistence, (unsigned long long *)h->dbg.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out6, h->dbg.p, 48, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return CTK_OK;
 }
 

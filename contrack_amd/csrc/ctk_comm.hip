@@ -8,6 +8,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cerrno>
+#include <cstddef>
 #include <csignal>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <string>
 #include <thread>
 
 #include <dlfcn.h>
@@ -112,7 +114,9 @@ struct CtkCtlSeg {
     uint64_t magic;
     int32_t world, pad;
     uint64_t slot;                      // bytes per rank data slot (shm transport), 0 otherwise
-    int32_t failed_code;                // 0 = fine; set once (compare-and-swap), with failed_rank
+    // 0 = fine; else set ONCE by a compare-and-swap of the whole 64-bit word {code (low half, < 0), rank (high half)}: a reader
+    // never sees a code without its rank (ctl_failed)
+    int32_t failed_code;
     int32_t failed_rank;
     uint32_t bar_count, bar_gen;        // central barrier of the shm transport
     uint32_t attached;                  // ranks that have mapped the segment
@@ -122,6 +126,7 @@ namespace {
 constexpr uint64_t kCtlMagic = 0x324c54434b5443ull;      // "CTKCTL2"
 constexpr size_t kCtlBytes = 16384;
 static_assert(sizeof(CtkCtlSeg) <= kCtlBytes, "control segment header");
+static_assert(offsetof(CtkCtlSeg, failed_code) % 8 == 0 && offsetof(CtkCtlSeg, failed_rank) == offsetof(CtkCtlSeg, failed_code) + 4, "failure word");
 constexpr size_t kShmSlot = (size_t)4 << 20;
 
 inline int32_t ld32(const int32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
@@ -146,9 +151,17 @@ bool process_gone(int32_t pid)
 void ctl_publish(CtkCtlSeg *s, int rank, int code)
 {
     if (!s) return;
-    int32_t expect = 0;
-    if (__atomic_compare_exchange_n(&s->failed_code, &expect, (int32_t)code, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
-        __atomic_store_n(&s->failed_rank, (int32_t)rank, __ATOMIC_RELEASE);
+    if (code == 0) code = CTK_E_COMM;
+    uint64_t expect = 0;
+    const uint64_t word = (uint64_t)(uint32_t)(int32_t)code | ((uint64_t)(uint32_t)(int32_t)rank << 32);
+    (void)__atomic_compare_exchange_n((uint64_t *)&s->failed_code, &expect, word, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+}
+// the published failure: code (0 = none) and the rank that gave up first, read together
+inline int32_t ctl_failed(const CtkCtlSeg *s, int32_t *rank)
+{
+    const uint64_t w = __atomic_load_n((const uint64_t *)&s->failed_code, __ATOMIC_ACQUIRE);
+    if (rank) *rank = w ? (int32_t)(uint32_t)(w >> 32) : -1;
+    return (int32_t)(uint32_t)w;
 }
 
 struct WaitState {
@@ -162,9 +175,9 @@ int ctl_poll(ctk_comm *c, WaitState &w, const char *what)
     CtkCtlSeg *s = c->ctl;
     w.spins++;
     if (s) {
-        const int32_t fc = ld32(&s->failed_code);
+        int32_t fr = -1;
+        const int32_t fc = ctl_failed(s, &fr);
         if (fc != 0) {
-            const int32_t fr = ld32(&s->failed_rank);
             return ctk_set_error(CTK_E_COMM, "rank %d: %s abandoned -- rank %d gave up with error %d", c->rank, what, (int)fr, (int)fc);
         }
     }
@@ -387,7 +400,7 @@ void ctk_comm_abort(ctk_comm *c, int code)
 // ------------------------------------------------------------------------------------------------
 // the two primitives
 // ------------------------------------------------------------------------------------------------
-int ctk_comm_shift(ctk_comm *c, int dir, const void *send, size_t sbytes, void *recv, size_t rbytes)
+static int comm_shift_impl(ctk_comm *c, int dir, const void *send, size_t sbytes, void *recv, size_t rbytes)
 {
     if (!c || (dir != 1 && dir != -1)) return ctk_set_error(CTK_E_INVALID, "ctk_comm_shift: bad arguments");
     if (c->dead) return comm_dead_error(c);
@@ -441,7 +454,7 @@ int ctk_comm_shift(ctk_comm *c, int dir, const void *send, size_t sbytes, void *
     return CTK_OK;
 }
 
-int ctk_comm_allgather(ctk_comm *c, const void *send, void *recv, size_t nbytes)
+static int comm_allgather_impl(ctk_comm *c, const void *send, void *recv, size_t nbytes)
 {
     if (!c || (nbytes && (!send || !recv))) return ctk_set_error(CTK_E_INVALID, "ctk_comm_allgather: bad arguments");
     if (c->dead) return comm_dead_error(c);
@@ -477,6 +490,28 @@ int ctk_comm_allgather(ctk_comm *c, const void *send, void *recv, size_t nbytes)
         if (int rc = ctl_barrier(c)) return rc;
     }
     return CTK_OK;
+}
+
+// "A failed communicator stays failed": whatever made a primitive give up on this rank (a HIP error inside the shared-memory
+// transport, a barrier that reported another rank's failure, an RCCL error) is published to the other ranks and retires the
+// communicator -- not only when the caller is the time-shard entry.  Argument errors leave it alone.
+static int comm_fail_sticky(ctk_comm *c, int rc)
+{
+    if (rc != CTK_OK && rc != CTK_E_INVALID && c && !c->dead && c->world > 1) {
+        // (the abort may set its own message: keep the one that explains the failure)
+        std::string keep = ctk_last_error();
+        ctk_comm_abort(c, rc);
+        ctk_set_error(rc, "%s", keep.c_str());
+    }
+    return rc;
+}
+int ctk_comm_shift(ctk_comm *c, int dir, const void *send, size_t sbytes, void *recv, size_t rbytes)
+{
+    return comm_fail_sticky(c, comm_shift_impl(c, dir, send, sbytes, recv, rbytes));
+}
+int ctk_comm_allgather(ctk_comm *c, const void *send, void *recv, size_t nbytes)
+{
+    return comm_fail_sticky(c, comm_allgather_impl(c, send, recv, nbytes));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -652,7 +687,7 @@ extern "C" int ctk_comm_failed(const ctk_comm *c, int *code, int *rank)
     if (!c) return ctk_set_error(CTK_E_INVALID, "null communicator");
     int fc = 0, fr = -1;
     if (c->kind == 0 && c->group) { if (c->group->failed.load()) { fc = c->group->failed_code.load(); fr = c->group->failed_rank.load(); if (!fc) fc = CTK_E_COMM; } }
-    else if (c->ctl) { fc = ld32(&c->ctl->failed_code); fr = ld32(&c->ctl->failed_rank); }
+    else if (c->ctl) { int32_t r32 = -1; fc = ctl_failed(c->ctl, &r32); fr = r32; }
     if (code) *code = fc;
     if (rank) *rank = fr;
     return CTK_OK;
@@ -666,7 +701,7 @@ extern "C" int ctk_comm_abort_rank(ctk_comm *c, int code)
 }
 
 // small host payloads (timings, counts, checksums): staged through a device scratch so that every transport can carry them
-extern "C" int ctk_comm_allgather_host(ctk_comm *c, const void *send, void *recv, size_t nbytes)
+static int allgather_host_impl(ctk_comm *c, const void *send, void *recv, size_t nbytes)
 {
     if (!c || !send || !recv || nbytes == 0 || nbytes > 4096) return ctk_set_error(CTK_E_INVALID, "ctk_comm_allgather_host: 1..4096 bytes per rank");
     if (c->dead) return comm_dead_error(c);
@@ -682,10 +717,15 @@ extern "C" int ctk_comm_allgather_host(ctk_comm *c, const void *send, void *recv
     char *d = (char *)c->scratch;
     HIPCHK(hipMemcpyAsync(d, send, nbytes, hipMemcpyHostToDevice, c->stream));
     if (int rc = ctk_comm_wait(c)) return rc;
-    if (int rc = ctk_comm_allgather(c, d, d + 4096, nbytes)) { ctk_comm_abort(c, rc); return rc; }
+    if (int rc = ctk_comm_allgather(c, d, d + 4096, nbytes)) return rc;
     if (int rc = ctk_comm_wait(c)) return rc;                           // guarded: only then the (blocking) copy to pageable memory
     HIPCHK(hipMemcpy(recv, d + 4096, nbytes * (size_t)c->world, hipMemcpyDeviceToHost));
     return CTK_OK;
+}
+
+extern "C" int ctk_comm_allgather_host(ctk_comm *c, const void *send, void *recv, size_t nbytes)
+{
+    return comm_fail_sticky(c, allgather_host_impl(c, send, recv, nbytes));
 }
 
 extern "C" int ctk_comm_barrier(ctk_comm *c)

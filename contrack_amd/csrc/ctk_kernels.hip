@@ -1808,3 +1808,70 @@ __global__ __launch_bounds__(256) void k_checksum_i32(const int32_t *__restrict_
         if (b) atomicAdd(&out[1], b);
     }
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Size-independent properties of a result, checked on the device (ctk_check_flag_dev; slabs no host can hold):
+//   (1) flag != 0 only where the compare of contrack.py:665 holds -- evaluated here in float64, independently of the float32
+//       threshold adjustment k_threshold uses;
+//   (2) ids lie in [1, max_id];
+//   (3) time extent of every id (contrack.py:765-772: survivors span >= persistence steps) -- tmin / tmax per id, one look-before
+//       atomic pair per horizontal run of an id.
+// One wave per row, grid-stride over the T * ny rows.  out: [0] pixels violating (1), [1] pixels violating (2), [2] nonzero pixels.
+// ------------------------------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(256) void k_check_flag(const float *__restrict__ anom, const int32_t *__restrict__ flag, int64_t nrows, int ny, int nx,
+                                                    const double *__restrict__ thr, int64_t max_id, int32_t *__restrict__ tmin, int32_t *__restrict__ tmax,
+                                                    unsigned long long *__restrict__ out)
+{
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    unsigned long long v1 = 0, v2 = 0, nz = 0;
+    for (int64_t row = wave; row < nrows; row += nwaves) {
+        const int32_t t = (int32_t)(row / ny);
+        const double th = thr[t];
+        const float *a = anom + row * (int64_t)nx;
+        const int32_t *f = flag + row * (int64_t)nx;
+        for (int x = lane; x < nx; x += WAVE) {
+            const int32_t id = f[x];
+            if (id == 0) continue;
+            nz++;
+            if (!cmp_op<OP, double>((double)a[x], th)) v1++;
+            if (id < 0 || (int64_t)id > max_id) { v2++; continue; }
+            if (x > 0 && f[x - 1] == id) continue;                       // not the head of a run of this id
+            if (tmin[id] > t) atomicMin(&tmin[id], t);                   // (a stale look is only looser: at worst a superfluous atomic)
+            if (tmax[id] < t) atomicMax(&tmax[id], t);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { v1 += __shfl_down(v1, o); v2 += __shfl_down(v2, o); nz += __shfl_down(nz, o); }
+    if (lane == 0) {
+        if (v1) atomicAdd(&out[0], v1);
+        if (v2) atomicAdd(&out[1], v2);
+        if (nz) atomicAdd(&out[2], nz);
+    }
+}
+
+// out: [3] ids present, [4] ids present with a time extent below `persistence`, [5] largest id present
+__global__ __launch_bounds__(256) void k_check_ids(const int32_t *__restrict__ tmin, const int32_t *__restrict__ tmax, int64_t max_id, int persistence,
+                                                   unsigned long long *__restrict__ out)
+{
+    unsigned long long n = 0, nshort = 0, big = 0;
+    for (int64_t i = 1 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= max_id; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t a = tmin[i], b = tmax[i];
+        if (b < a) continue;
+        n++;
+        if ((int64_t)b - a + 1 < (int64_t)persistence) nshort++;
+        big = (unsigned long long)i;
+    }
+    for (int o = 32; o > 0; o >>= 1) { n += __shfl_down(n, o); nshort += __shfl_down(nshort, o); const unsigned long long ob = __shfl_down(big, o); big = ob > big ? ob : big; }
+    if (lane_id() == 0) {
+        if (n) atomicAdd(&out[3], n);
+        if (nshort) atomicAdd(&out[4], nshort);
+        if (big) atomicMax(&out[5], big);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_minmax(int32_t *__restrict__ tmin, int32_t *__restrict__ tmax, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { tmin[i] = 0x7fffffff; tmax[i] = -1; }
+}

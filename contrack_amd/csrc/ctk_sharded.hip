@@ -552,9 +552,11 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
                                        halo2_off_runcomp(h), halo2_max_runs(h), (unsigned char *)h->halo_out.p);
         HIPCHK(hipGetLastError());
     }
-    if (!has_prev && !(h->halo_in_zero && h->halo_in_zero_p == h->halo_in.p)) {                // no halo: zero components (kept from call to call)
+    // (the zeroed header is remembered by address AND capacity: a regrown buffer may come back at the same address; every other
+    // writer of halo_in -- ctk_shard_halo_import, a call with has_prev -- clears the flag)
+    if (!has_prev && !(h->halo_in_zero && h->halo_in_zero_p == h->halo_in.p && h->halo_in_zero_cap == h->halo_in.cap)) {       // no halo: zero components (kept from call to call)
         HIPCHK(hipMemsetAsync(h->halo_in.p, 0, sizeof(HaloHeader), s));
-        h->halo_in_zero = true; h->halo_in_zero_p = h->halo_in.p;
+        h->halo_in_zero = true; h->halo_in_zero_p = h->halo_in.p; h->halo_in_zero_cap = h->halo_in.cap;
     }
     if (has_prev) h->halo_in_zero = false;
     CTKCHK(ctk_comm_shift(c, +1, h->halo_out.p, hb, h->halo_in.p, hb));
@@ -580,7 +582,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     // ---- stage 2: co-occurrence histogram (the first local timestep against the halo) ------------------------------------
     // (fixed per-timestep slots for the pair records instead of one global counter that every timestep's workgroup adds to:
     // same-address atomics from eight XCDs, 11 of that kernel's 50 us at 1 deg)
-    h->sh_slots = !getenv("CTK_SH_NO_SLOTS");
+    h->sh_slots = !ctk_env().sh_no_slots;
     const int rc_ov = shard_overlap_v2(h);
     h->sh_slots = false;
     CTKCHK(rc_ov);
@@ -618,7 +620,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     CTKCHK(ensure(h, h->sh_amb_list, (size_t)AMB_CAP * 4));
     r.ovr_slot = P<uint32_t>(h->sh_ovr_slot); r.ovr_val = P<double>(h->sh_ovr_val); r.amb_list = P<uint32_t>(h->sh_amb_list); r.amb_cap = AMB_CAP;
     const int npass_grid = r.t_hi - r.t_lo + 1;
-    const bool sys_pass = !getenv("CTK_PASS_LAUNCHES") && T <= 60000;
+    const bool sys_pass = !ctk_env().pass_launches && T <= 60000;
     if (sys_pass) { CTKCHK(ensure(h, h->rv_pstate, (size_t)(T + 1) * 4 * CTK_PSTATE_STRIDE)); r.pstate = P<uint32_t>(h->rv_pstate); }
     const int gc = pl.gc, gp = pl.gp, nsb = pl.nsb;
 
@@ -657,7 +659,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         if (it_done + npass > CTK_MAX_JACOBI) COLLECTIVE_FAIL(CTK_E_RANGE, "ctk_track_sharded: overlap filter did not converge within %d passes", CTK_MAX_JACOBI);      // (the rounds are in lockstep)
         // (decided before the passes: a speculating round lets the filter kernel unite the pairs itself)
         spec = first_round ? world == 1 : true;
-        if (getenv("CTK_NO_SPEC_X4")) spec = false;                      // (experiments: set it for every rank or for none)
+        if (ctk_env().no_spec_x4) spec = false;                      // (experiments: set it for every rank or for none)
         bool united = false;
         {
             Timer tm(h, CTK_K_RESOLVE);
@@ -887,7 +889,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     // No label reaches a shard boundary anywhere (always so with one shard): nobody has shared groups -- every rank knows it from
     // the boundary resolution, which all ranks computed from the same gathered records -- and the exchange is left out; the
     // candidate records go to the driver as they are.
-    bool any_boundary_label = getenv("CTK_SH_FORCE_SPLIT") != nullptr;      // (experiments: the split / exchange even without shared groups; every rank or none)
+    bool any_boundary_label = ctk_env().sh_force_split;      // (experiments: the split / exchange even without shared groups; every rank or none)
     for (int q = 0; q < world && !any_boundary_label; q++) {
         for (int32_t l : S.bout.halo_label[(size_t)q]) if (l > 0) { any_boundary_label = true; break; }
         if (q + 1 < world) for (int32_t l : S.bout.last_label[(size_t)q]) if (l > 0) { any_boundary_label = true; break; }

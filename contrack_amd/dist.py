@@ -196,25 +196,41 @@ class ShardedTracker:
         self.trk.close()
 
     def track(self, anom_local, t_begin, T_total, thr_local, cmp_op, wrow, overlap, persistence, twosided=True):
-        a = np.ascontiguousarray(anom_local)
-        f64 = a.dtype != np.float32
-        if f64:
-            a = a.astype(np.float64)
-        T, ny, nx = a.shape
+        """Collective.  A rank that fails BEFORE it reaches the C entry (bad arguments, no device memory, a failed upload) aborts the
+        communicator, so that the other ranks raise CommError instead of waiting for it until the deadline; inside the entry the
+        library does that itself -- except for errors every rank derives from the same gathered data, which leave the communicator
+        usable (csrc/ctk_sharded.hip, COLLECTIVE_FAIL)."""
+        d_in = d_out = None
         try:
-            d_in, d_out = self.trk.malloc(max(a.nbytes, 8)), self.trk.malloc(max(T * ny * nx * 4, 8))
-        except BaseException:
-            self.comm.abort(-3)                      # the other ranks must not wait for this one
-            raise
-        try:
-            self.trk.h2d(d_in, a)
+            try:
+                a = np.ascontiguousarray(anom_local)
+                f64 = a.dtype != np.float32
+                if f64:
+                    a = a.astype(np.float64)
+                if a.ndim != 3:
+                    raise ValueError("the local slab must be (time, lat, lon)")
+                T, ny, nx = a.shape
+                if np.shape(thr_local) != (T,):
+                    raise ValueError("thr_local must hold one value per local timestep")
+                if np.shape(wrow) != (ny,):
+                    raise ValueError("wrow must hold one weight per latitude row")
+                d_in = self.trk.malloc(max(a.nbytes, 8))
+                d_out = self.trk.malloc(max(T * ny * nx * 4, 8))
+                self.trk.h2d(d_in, a)
+            except BaseException:
+                try:
+                    self.comm.abort(-5)              # the other ranks must not wait for this one
+                except Exception:                    # noqa: BLE001 -- the original error is the one to report
+                    pass
+                raise
             n = self.trk.track_sharded_dev(self.comm, d_in, T, t_begin, T_total, ny, nx, thr_local, cmp_op, wrow, overlap, persistence,
                                            twosided, d_out, f64=f64)
             flag = np.empty((T, ny, nx), dtype=np.int32)
             self.trk.d2h(flag, d_out)
         finally:
-            self.trk.free(d_in)
-            self.trk.free(d_out)
+            for p in (d_in, d_out):
+                if p is not None:
+                    self.trk.free(p)
         return flag, n
 
 

@@ -302,6 +302,13 @@ int ctk_synth_fill_window(ctk_handle *h, float *anom_dev, int64_t t0, int64_t T,
  * checksums against those of the one-call result).  out[0] = sum over i of (uint32)p[i] * (((index0 + i) * 0x9E3779B97F4A7C15) | 1)
  * mod 2^64, out[1] = number of nonzero elements.  Equal for two arrays iff (up to 2^-64 collisions) the arrays are equal. */
 int ctk_checksum_i32_dev(ctk_handle *h, const int32_t *p_dev, int64_t n, int64_t index0, uint64_t *out2);
+int ctk_dev_memset(ctk_handle *h, void *p_dev, int byte, size_t nbytes);
+/* Size-independent properties of a result that lives in device memory (slabs no host holds: BASELINE.json configs[2], 60.6 GB each
+ * way), for the parity tests: out6 = { pixels with flag != 0 where (double)anom <op> thr[t] is false (contrack.py:665 -- evaluated
+ * in float64, independently of the kernels' float32 form), pixels whose id lies outside [1, max_id], nonzero pixels, distinct ids,
+ * ids whose time extent stop - start is below `persistence` (contrack.py:765-772: none may survive), largest id }. */
+int ctk_check_flag_dev(ctk_handle *h, const float *anom_dev, const int32_t *flag_dev, int64_t T, int ny, int nx, const double *thr, int cmp_op,
+                       int persistence, int64_t max_id, uint64_t *out6);
 
 /* ---- next row N1: contrack.run_lifecycle reductions (contrack/contrack.py:798-906) --------------------------
  * One row per (time step, flag id != 0) of an int32 flag slab (time, lat, lon) and a field of the same shape:

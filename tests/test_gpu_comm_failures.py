@@ -94,6 +94,8 @@ def _proc_worker(rank, world, key, mode, stage, q):
             time.sleep(8)                                 # alive, but never makes the call in time
         if mode == "absent" and rank == 0:
             st.comm.set_timeout(3.0)
+        if mode == "badarg" and rank == 1:
+            args = args[:3] + (g["thr"][t0:t1 - 1],) + args[4:]          # one threshold short: raised in Python, before the C entry
         if mode == "collective":
             # the pair table of rank 1 overflows: every rank learns it from the gathered headers and returns the same error ...
             if rank == 1:
@@ -166,3 +168,12 @@ def test_collective_error_leaves_the_communicator_usable():
     for r in (0, 1):
         assert res[r][0] == "ok", res
         assert "co-occurrence table" in res[r][1], res
+
+
+def test_python_side_argument_error_aborts_the_collective():
+    """a rank whose call fails in Python before it reaches the C entry (wrong threshold shape) must not leave the others waiting for
+    the deadline (advisor finding, round 3)"""
+    res = _run("badarg")
+    assert res[1][0] == "ValueError", res
+    assert res[0][0] == "CommError" and "rank 1" in res[0][1], res
+    assert res[0][2] < 20, res

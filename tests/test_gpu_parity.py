@@ -85,6 +85,9 @@ CASES_VS_ORACLE = [
     (2707, 181, 360, 0, "smooth", 160.0, ">=", 0.5, 5, True),        # configs[1] complete: the bench slab itself, 3305 tracks
     (64, 721, 1440, 5, "smooth", 160.0, ">=", 0.5, 20, True),        # configs[2]'s grid with its persistence of 20 steps
     (240, 192, 288, 7, "smooth", 160.0, ">=", 0.5, 5, True),         # configs[4]'s grid (CESM 0.9 x 1.25 deg), eight months daily
+    # more than 65 536 timesteps: the fused pass without k_compact_init (`!fz_init`), per-pass filter launches beyond 60 000 steps,
+    # the grid-stride form of the device seam driver
+    (70000, 8, 16, 11, "smooth", 120.0, ">=", 0.5, 3, True),
 ]
 
 

@@ -171,6 +171,26 @@ def test_025deg_persistence_20_in_four_shards(handles):
     assert np.array_equal(got, want) and ng == nw and nw > 0
 
 
+def test_staged_import_between_two_first_shard_passes_on_one_handle(handles):
+    """one handle plays: the only / first time shard (its halo header is zeroed once and remembered), then rank 1 of the STAGED
+    protocol (ctk_shard_halo_import writes a v1 blob over that header), then a first shard again -- the remembered zero header
+    must not survive the import (advisor finding, round 3)"""
+    from shard_inproc import sharded
+    g = golden_util.load("busy_s1")
+    T = g["anom"].shape[0]
+    op = _native.CMP_OPS[g["gorl"]]
+    want_n = len(np.unique(g["flag"])) - 1
+    args = (g["anom"], g["thr"], op, g["wrow"], g["overlap"], g["persistence"], g["twosided"])
+    h = handles[0]
+    for rep in range(2):
+        f, n, _ = sharded_threads([h], *args, [0, T])
+        assert np.array_equal(f, g["flag"]) and n == want_n, ("first shard alone", rep)
+        f, n, _ = sharded([handles[1], h], *args, [0, T // 2, T])                  # h imports the halo of handles[1]
+        assert np.array_equal(f, g["flag"]) and n == want_n, ("staged", rep)
+        f, n, _ = sharded_threads([h, handles[2]], *args, [0, T // 3, T])            # h is rank 0 of two
+        assert np.array_equal(f, g["flag"]) and n == want_n, ("rank 0 of two", rep)
+
+
 def test_rccl_world_of_one(oracle_lib):
     """the RCCL transport itself (librccl.so dlopen'ed, ncclCommInitRank, ncclAllGather) with one rank: what a one-GPU box can run"""
     g = golden_util.load("busy_s0")
