@@ -142,6 +142,114 @@ def concurrent_members(wl, a, thr, op, w, nh, steps):
                 note="independent slabs on %d handles / streams / host threads of ONE GPU; not the headline value" % nh)
 
 
+def secondary_025deg(steps, warmup, budget_steps=240):
+    """The grid the north_star's >= 50x is stated on, timed in the same driver-run process: a device-generated 480 x 721 x 1440
+    window of BASELINE.json configs[2] (6-hourly, persistence 20 steps), its own roofline (HIP events around the streaming kernels),
+    and the CPU leg on the first `budget_steps` steps of the very same slab (downloaded), whose flags must equal the GPU's."""
+    from oracle import scipy_port
+    name = "era5_025deg_480"
+    wl = WORKLOADS[name]
+    T, ny, nx = wl["T"], wl["ny"], wl["nx"]
+    px = T * ny * nx
+    trk = _native.Tracker(int(os.environ.get("LOCAL_RANK", "0")))
+    d_in, d_out = trk.malloc(px * 4), trk.malloc(px * 4)
+    try:
+        lat, _ = synth.grid(ny, nx)
+        w = row_weights(lat, np.float32(180.0 / (ny - 1)), np.float32(360.0 / nx))
+        trk.synth_fill(d_in, T, ny, nx, seed=0)
+        thr = np.full(T, np.float64(np.float32(wl["threshold"])))
+        op = _native.CMP_OPS[wl["gorl"]]
+        trk.set_timing(1)
+
+        def step(n=T):
+            return trk.track_dev(d_in, n, ny, nx, thr[:n], op, w, wl["overlap"], wl["persistence"], wl["twosided"], d_out)
+        for _ in range(max(warmup, 2)):
+            n_tracked = step()
+        trk.sync()
+        trk.timing_sums(reset=True)
+        k = max(steps, 8)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            n_tracked = step()
+        trk.sync()
+        dt = time.perf_counter() - t0
+        per, _ = trk.timing_sums(reset=True)
+        ms = dt * 1e3 / k
+        alg = {"k_threshold": 4.0 * px, "k_relabel": 4.0 * px}
+        kern = max(alg, key=lambda q: per.get(q, 0.0))
+        ach = alg[kern] / (per[kern] * 1e-3) / 1e9 if per.get(kern, 0) > 0 else 0.0
+        rk = {5: "k_relabel_v5", 4: "k_relabel_v4"}.get(trk.stats().get("relabel_kernel", 4), "k_relabel")
+        kname = {"k_threshold": "k_threshold_v4", "k_relabel": rk}[kern]
+        out = dict(workload="%s: %dx%dx%d float32 (device-generated), threshold %s %g, overlap %g, persistence %d, twosided %s" % (
+                       name, T, ny, nx, wl["gorl"], wl["threshold"], wl["overlap"], wl["persistence"], wl["twosided"]),
+                   value=T / (ms * 1e-3), unit="timesteps/s", ms_per_step=ms, steps=k, n_tracked=n_tracked,
+                   path_effective_gbs=8.0 * px / (ms * 1e-3) / 1e9,
+                   roofline=dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                                 traffic=pmc_traffic(kname, name), algorithmic_bytes_per_launch=alg[kern], avg_kernel_ms=per.get(kern),
+                                 other_streaming_kernel={q: dict(achieved=alg[q] / (per[q] * 1e-3) / 1e9, avg_kernel_ms=per[q])
+                                                         for q in alg if q != kern and per.get(q, 0) > 0}))
+        # CPU leg: the first n steps of the same slab, downloaded; the GPU's flags of those n steps alongside
+        n = min(budget_steps, T)
+        a = np.empty((n, ny, nx), dtype=np.float32)
+        trk.d2h(a, d_in)
+        trk.set_timing(0)
+        n_gpu = step(n)
+        f_gpu = np.empty((n, ny, nx), dtype=np.int32)
+        trk.d2h(f_gpu, d_out)
+        t1 = time.perf_counter()
+        f_cpu = scipy_port.run_contrack(a, np.float32(wl["threshold"]), wl["gorl"], w, wl["overlap"], wl["persistence"], wl["twosided"])
+        dc = time.perf_counter() - t1
+        f_cpu = f_cpu[0] if isinstance(f_cpu, tuple) else f_cpu
+        out["cpu_baseline"] = dict(value=n / dc, unit="timesteps/s", cores=1, kind="port",
+                                   sample="first %d of %d steps of the same device-generated slab, scipy.ndimage/numpy port of contrack.py:646-796 "
+                                          "(oracle/scipy_port.py), %.2f s" % (n, T, dc),
+                                   flags_equal_gpu=bool(np.array_equal(np.asarray(f_cpu), f_gpu)), n_tracked_gpu_same_sample=n_gpu)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        return out
+    finally:
+        trk.free(d_in)
+        trk.free(d_out)
+        trk.close()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, the environment a launcher would
+    set), pass rank 0's line through, exit non-zero if any rank does.  Never a 1-GPU line for --gpus N."""
+    import socket
+    import subprocess
+    backend = os.environ.get("CTK_DIST_BACKEND", "rccl")
+    ndev = _native.device_count()
+    if backend == "rccl" and ndev < n:
+        print("bench.py: --gpus %d asked for, %d HIP device(s) visible: RCCL wants one device per rank "
+              "(CTK_DIST_BACKEND=shm runs several ranks on one device for plumbing tests)" % (n, ndev), file=sys.stderr)
+        return 2
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), CTK_LAUNCH_PID=str(os.getpid()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else sys.stderr))
+    rc, t_fail = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0) and rc == 0:
+                rc, t_fail = p.returncode, time.time()
+        # a failed rank tells the others through the communicator (they give up within its deadline); whoever still runs long
+        # after that is stopped by PID
+        if t_fail is not None and time.time() - t_fail > float(os.environ.get("CTK_COMM_TIMEOUT_S", "120")) + 30:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    for p in procs:
+        if p.returncode != 0 and rc == 0:
+            rc = p.returncode
+    return rc if rc >= 0 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +258,7 @@ def main():
     ap.add_argument("--workload", default="era5_1deg_djf30")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed passes that time every kernel group (profiling runs)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 0.25 deg block (`secondary_025deg`) of the default N = 1 line")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = one member of the workload per GPU, concatenated on the time axis (default); "
                          "strong = the single-GPU slab split over the GPUs")
@@ -161,11 +270,18 @@ def main():
                          "2000 steps if rank 0's GPU cannot hold it for the one-GPU reference time)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
-    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))                     # no launcher: the ranks are started here
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to print a line for another job size" % (
+            args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     if world > 1 or os.environ.get("CTK_FORCE_DIST") == "1":
         from contrack_amd import dist
-        return dist.bench_main(args, wl, WORKLOADS, HBM_PEAK_GBS)
+        sys.exit(dist.bench_main(args, wl, WORKLOADS, HBM_PEAK_GBS, cpu_baseline=cpu_baseline, pmc_traffic=pmc_traffic) or 0)
 
     T, ny, nx = wl["T"], wl["ny"], wl["nx"]
     thr = np.full(T, np.float64(np.float32(wl["threshold"])))
@@ -274,10 +390,16 @@ def main():
         out["concurrent_members"] = concurrent_members(wl, a, thr, op, w, 4, max(args.steps // 2, 4))
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, a, w)
-    print(json.dumps(out))
     trk.free(d_in)
     trk.free(d_out)
     trk.close()
+    # the 0.25 deg grid (what the north_star's >= 50x is stated on) in the same driver-timed process; `value` stays configs[1]
+    if args.workload == "era5_1deg_djf30" and not args.no_secondary and not args.no_extra and not args.no_cpu_baseline:
+        try:
+            out["secondary_025deg"] = secondary_025deg(args.steps, args.warmup)
+        except (MemoryError, _native.ContrackHipError) as e:
+            out["secondary_025deg"] = dict(error="%s: %s" % (type(e).__name__, e))
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -230,6 +230,11 @@ struct ctk_handle {
     uint32_t debug_mail_c = 0, debug_mail_d = 0;  // test hook: pretend the resolver mailbox holds only this many records / labels
     int debug_sd_lab = 0, debug_sd_ops = 0;       // test hook: labels / operations per cluster the device seam driver accepts
     int debug_fail_stage = 0;                     // test hook (ctk_debug_fail_at): the time-shard path fails at this stage, once
+    // bounded inter-workgroup waits of the systolic filter kernels (ResolveDev::spin_limit): ticks of the 100 MHz wall clock after
+    // which a wait gives up; no_sys: a wait did give up on this handle -- one launch per filter pass (no waits) from then on
+    uint64_t spin_limit = CTK_SPIN_LIMIT_TICKS;
+    int debug_stall = 0;                          // test hook (ctk_debug_set_spin): the first workgroup of the chain is late (1) / never publishes (2)
+    bool no_sys = false, sh_retrying = false;
     bool sh_collective_err = false;               // the time-shard path's error was decided identically on every rank
     ctk_comm *active_comm = nullptr;              // set while the time-shard path runs with more than one rank
     // host scratch of the seam driver, kept between calls (fresh 100+ KB vectors would page-fault every call)
@@ -491,6 +496,15 @@ extern "C" int ctk_debug_set_seam_caps(ctk_handle *h, int labels, int ops)
     if (!h || labels < 0 || ops < 0) return ctk_set_error(CTK_E_INVALID, "ctk_debug_set_seam_caps: null handle or negative capacity");
     h->debug_sd_lab = labels; h->debug_sd_ops = ops;
     h->async_off_ny = -1; h->async_off_nx = -1;          // (a grid that was sent to the host driver gets another try)
+    return CTK_OK;
+}
+
+extern "C" int ctk_debug_set_spin(ctk_handle *h, double limit_ms, int stall_mode)
+{
+    if (!h || stall_mode < 0 || stall_mode > 2 || limit_ms < 0) return ctk_set_error(CTK_E_INVALID, "ctk_debug_set_spin: null handle, negative limit or stall mode not in 0..2");
+    h->spin_limit = limit_ms > 0 ? (uint64_t)(limit_ms * 1e5) : CTK_SPIN_LIMIT_TICKS;      // 100 MHz wall clock
+    h->debug_stall = stall_mode;
+    h->no_sys = false;                                   // (a handle that gave up gets another try)
     return CTK_OK;
 }
 
@@ -1296,6 +1310,7 @@ static int rs_prepare(ctk_handle *h, const ResolveIn &in, double overlap, int tw
     r.next_tiny = (const int32_t *)(P<int64_t>(h->wlo) + 2 * (size_t)h->ny); r.touch = P<uint32_t>(h->rv_touch);
     r.nh_ptr = nullptr; r.t_lo = 1; r.t_hi = (int)T - 2;                // one slab: timesteps 1 .. T-2 are filtered, no halo
     r.ovr_slot = nullptr; r.ovr_val = nullptr; r.amb_cnt = P<uint32_t>(h->rv_scalars) + 2; r.amb_list = nullptr; r.amb_cap = 0;
+    r.spin_limit = h->spin_limit; r.poison = P<uint32_t>(h->counters) + CTK_CNT_POISON; r.dbg_stall = h->debug_stall;
     r.cl_parent = nullptr; r.cl_tmin = nullptr; r.cl_tmax = nullptr; r.cl_nops = nullptr; r.lbox = nullptr; r.pstate = nullptr; r.ext = nullptr; r.ext_off = 0; r.counters_w = nullptr;      // (fused one-call path only)
 
     const int gc = (int)std::min<size_t>((R + 255) / 256, 2048), gp = (int)std::min<size_t>((PC + 255) / 256, 2048);
@@ -1764,7 +1779,7 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     h->nops = 1;                                                  // (unknown here; nonzero = the folds look at the chains)
     // filter passes: all of them in one launch (k_rs_pass_sys, at most 24 iterations) when every workgroup of the launch can wait
     // for its predecessor, else one launch per pass
-    const bool sys = !ctk_env().pass_launches && h->async_passes <= 24 && T - 2 <= 60000;
+    const bool sys = !ctk_env().pass_launches && !h->no_sys && h->async_passes <= 24 && T - 2 <= 60000;
     const int NP = T > 2 ? std::min(std::max(h->async_passes, 2), sys ? 24 : CTK_MAX_JACOBI) : 0;
     if (sys) { CTKCHK(ensure(h, h->rv_pstate, (size_t)(T + 1) * 4 * CTK_PSTATE_STRIDE)); r.pstate = P<uint32_t>(h->rv_pstate); }
     h->guard_on = true;
@@ -1870,6 +1885,9 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     if (ctk_env().sd_dbg) fprintf(stderr, "SDDBG max row steps %u, max fold iterations %u, max process time %.2f us, max cluster time %.2f us, fold cycles (clock64) %u\n", cnt[10], cnt[11], cnt[12] * 0.01, cnt[13] * 0.01, cnt[14]);
     const uint32_t poison = cnt[CTK_CNT_POISON];
     if (poison) {
+        // an inter-workgroup wait of the systolic filter pass gave up (a workgroup waited for was not running): this handle
+        // launches one kernel per filter pass from now on -- no waits between workgroups at all
+        if (poison & CTK_POISON_SPIN) { h->no_sys = true; h->stats[CTK_S_HOST_REASON] |= 8; }
         if (poison & CTK_POISON_OPCAP) h->op_cap_hint = std::max(h->op_cap_hint * 2, cnt[CTK_CNT_NOPS] + cnt[CTK_CNT_NOPS] / 2 + 1024);
         if (poison & CTK_POISON_CLUSTER) { h->async_off_ny = h->ny; h->async_off_nx = h->nx; }                 // this kind of slab: host driver from now on
         return 1;

@@ -77,7 +77,29 @@ struct ResolveDev {
     int64_t ext_off;
     uint32_t *counters_w;                 // the write-stage counters are reset by k_rs_roots as well
     uint32_t *pstate;                     // [T + 1] k_rs_pass_sys: per timestep (iterations done) << 24 | changed bits; zeroed by k_rs_init
+    // Inter-workgroup waits of the systolic filter kernels are BOUNDED (HIP promises nothing about dispatch order; a wait for a
+    // workgroup that is not resident would be a hung GPU): a wait that lasts longer than spin_limit ticks of the 100 MHz wall clock
+    // gives up -- CTK_POISON_SPIN in *poison, the wave publishes a "poisoned" state word so that nobody waits for IT, and the pass is
+    // repeated with one launch per filter pass (no waits).  dbg_stall (test hook): 1 = the first workgroup arrives late (by
+    // spin_limit / 4), 2 = it never publishes.
+    uint64_t spin_limit;
+    uint32_t *poison;
+    int dbg_stall;
 };
+#define CTK_POISON_SPIN    4u    // an inter-workgroup wait of the systolic filter pass gave up (ResolveDev::spin_limit)
+#define CTK_SPIN_LIMIT_TICKS 20000000ull      // 0.2 s of the 100 MHz wall clock: ~10^4 times the longest legitimate wait measured
+
+// one poll of a bounded wait went by: true when the wait has lasted longer than `limit` ticks.  The clock is read once per 1024
+// polls (the first time after ~1 ms of waiting: a pass that runs normally never reads it).
+struct SpinGuard { uint64_t t0 = 0; uint32_t polls = 0; };
+__device__ __forceinline__ bool spin_expired(SpinGuard &g, uint64_t limit)
+{
+    if ((++g.polls & 1023u) != 0u) return false;
+    const uint64_t now = wall_clock64();
+    if (g.t0 == 0) { g.t0 = now; return false; }
+    return now - g.t0 > limit;
+}
+#define CTK_PSTATE_POISONED 0xffffffffu       // "published everything" for whoever waits: the pass is invalid anyway
 
 #define CTK_PSTATE_STRIDE 32        // words between the per-timestep state words of k_rs_pass_sys: one 128-byte line each (the words are
                                     // polled with device-scope loads: neighbours in one line would all hit the same memory channel)
@@ -441,7 +463,16 @@ __global__ __launch_bounds__(64) void k_rs_pass_sys(ResolveDev r, int it0, int K
             uint32_t st;
             // relaxed polls (an acquire load invalidates the caches on EVERY poll: 2705 waves doing that made an iteration cost 95 us);
             // the bits are read with device-scope loads, which need no invalidation
-            while (((st = __hip_atomic_load(&pstate[(size_t)(t - 1) * CTK_PSTATE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 24) < (uint32_t)k) __builtin_amdgcn_s_sleep(2);
+            SpinGuard sg;
+            bool gave_up = false;
+            while (((st = __hip_atomic_load(&pstate[(size_t)(t - 1) * CTK_PSTATE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 24) < (uint32_t)k) {
+                __builtin_amdgcn_s_sleep(2);
+                if (spin_expired(sg, r.spin_limit)) { gave_up = true; break; }
+            }
+            if (gave_up) {
+                if (lane == 0) { atomicOr(r.poison, CTK_POISON_SPIN); __hip_atomic_store(&pstate[(size_t)t * CTK_PSTATE_STRIDE], CTK_PSTATE_POISONED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                return;
+            }
             evaluate = (st >> (k - 1)) & 1u;
         }
         bool wave_any = false;
@@ -534,7 +565,11 @@ __global__ __launch_bounds__(64) void k_rs_pass_sys(ResolveDev r, int it0, int K
     // predecessor's bits are final once it has published all of its iterations.
     if (t - 1 >= r.t_lo && t - 1 <= r.t_hi) {
         const uint32_t need = (uint32_t)Kfull;
-        while ((__hip_atomic_load(&pstate[(size_t)(t - 1) * CTK_PSTATE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 24) < need) __builtin_amdgcn_s_sleep(2);
+        SpinGuard sg;
+        while ((__hip_atomic_load(&pstate[(size_t)(t - 1) * CTK_PSTATE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 24) < need) {
+            __builtin_amdgcn_s_sleep(2);
+            if (spin_expired(sg, r.spin_limit)) { if (lane == 0) atomicOr(r.poison, CTK_POISON_SPIN); return; }
+        }
     }
     auto link = [&](uint32_t slot) {
         if (!__hip_atomic_load(&keep[r.p_rc[slot]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
@@ -625,6 +660,11 @@ __global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0
     if (lds) for (uint32_t c = lane; c < nct; c += 64) kb[c] = (c == (uint32_t)lane) ? kold0 : __hip_atomic_load(&keep[cb + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();                                           // lstate = 0 and the initial bits of every wave are in LDS
     if (!live) return;
+    if (r.dbg_stall && blockIdx.x == 0) {                      // test hook: the head of the chain is late / never publishes
+        if (r.dbg_stall == 2) return;
+        const uint64_t t_in = wall_clock64();
+        while (wall_clock64() - t_in < r.spin_limit / 4) __builtin_amdgcn_s_sleep(8);
+    }
     auto pred_keep = [&](uint32_t rd) -> uint8_t {             // keep bit of a representative of timestep t-1
         if (pred_lds) return __hip_atomic_load(&kbp[rd - cbp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return __hip_atomic_load(&keep[rd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -641,7 +681,21 @@ __global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0
         bool evaluate = k == 0;
         if (k > 0 && dyn_pred) {
             uint32_t st;
-            while (((st = pred_state()) >> 24) < (uint32_t)k) __builtin_amdgcn_s_sleep(1);
+            SpinGuard sg;
+            bool gave_up = false;
+            while (((st = pred_state()) >> 24) < (uint32_t)k) {
+                __builtin_amdgcn_s_sleep(1);
+                if (spin_expired(sg, r.spin_limit)) { gave_up = true; break; }
+            }
+            if (gave_up) {
+                // nobody may wait for this wave either: the poisoned word says "everything published" to the waves behind
+                if (lane == 0) {
+                    atomicOr(r.poison, CTK_POISON_SPIN);
+                    __hip_atomic_store(&pstate[(size_t)t * CTK_PSTATE_STRIDE], CTK_PSTATE_POISONED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&lstate[w], CTK_PSTATE_POISONED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                return;
+            }
             evaluate = (st >> (k - 1)) & 1u;
         }
         bool wave_any = false;
@@ -742,7 +796,11 @@ __global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0
     // predecessor's bits are final once it has published all of its iterations.
     if (t - 1 >= r.t_lo && t - 1 <= r.t_hi) {
         const uint32_t need = (uint32_t)Kfull;
-        while ((pred_state() >> 24) < need) __builtin_amdgcn_s_sleep(1);
+        SpinGuard sg;
+        while ((pred_state() >> 24) < need) {
+            __builtin_amdgcn_s_sleep(1);
+            if (spin_expired(sg, r.spin_limit)) { if (lane == 0) atomicOr(r.poison, CTK_POISON_SPIN); return; }
+        }
     }
     auto link = [&](uint32_t slot, bool first) {
         const uint32_t rc = first ? rc0 : r.p_rc[slot], rd = first ? rd0 : r.p_rd[slot];

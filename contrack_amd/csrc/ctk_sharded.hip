@@ -116,7 +116,7 @@ __global__ void k_sh_pack_keep(ResolveDev r, int it_first, int it_count, uint32_
         const bool any = it_count > 0 && __ballot(r.changed[(it_first + it_count - 1) * CTK_CHG_SLOTS + threadIdx.x] != 0u) != 0ull;
         if (threadIdx.x == 0) {
             KeepHeader hd;
-            hd.not_conv = (any || fix_changed) ? 1u : 0u; hd.nlast = nlast; hd.ambig = *r.amb_cnt; hd.tables_bad = dev_tables_bad(r) ? 1u : 0u;
+            hd.not_conv = (any || fix_changed) ? 1u : 0u; hd.nlast = nlast; hd.ambig = *r.amb_cnt; hd.tables_bad = (dev_tables_bad(r) ? 1u : 0u) | ((__hip_atomic_load(r.poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & CTK_POISON_SPIN) ? 2u : 0u);
             hd.nc_own = r.cprefix[T] - (r.nh_ptr ? *r.nh_ptr : 0u); hd.passes = (uint32_t)(it_first + it_count); hd.hint_c = hint_c; hd.hint_d = hint_d;
             *(KeepHeader *)out = hd;
         }
@@ -620,7 +620,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     CTKCHK(ensure(h, h->sh_amb_list, (size_t)AMB_CAP * 4));
     r.ovr_slot = P<uint32_t>(h->sh_ovr_slot); r.ovr_val = P<double>(h->sh_ovr_val); r.amb_list = P<uint32_t>(h->sh_amb_list); r.amb_cap = AMB_CAP;
     const int npass_grid = r.t_hi - r.t_lo + 1;
-    const bool sys_pass = !ctk_env().pass_launches && T <= 60000;
+    const bool sys_pass = !ctk_env().pass_launches && !h->no_sys && T <= 60000;
     if (sys_pass) { CTKCHK(ensure(h, h->rv_pstate, (size_t)(T + 1) * 4 * CTK_PSTATE_STRIDE)); r.pstate = P<uint32_t>(h->rv_pstate); }
     const int gc = pl.gc, gp = pl.gp, nsb = pl.nsb;
 
@@ -722,6 +722,18 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         rounds++;
         first_round = false;
         INJECT(3);
+        if (mail2[CTK_SHM_BAD] & 2u) {
+            // An inter-workgroup wait of some rank's systolic filter pass gave up (bounded spins, ResolveDev::spin_limit).  Every rank
+            // reads that from the same gathered headers: all repeat the call with one launch per filter pass (no waits), once.
+            h->no_sys = true;
+            h->stats[CTK_S_HOST_REASON] |= 8;
+            if (h->sh_retrying) COLLECTIVE_FAIL(CTK_E_INTERNAL, "ctk_track_sharded: a filter pass reported a wait that gave up although none was launched");
+            h->sh_retrying = true;
+            const int rc2 = track_sharded_impl(h, c, anom_dev, f64, T, t_begin, T_total, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag_dev, n_tracked);
+            h->sh_retrying = false;
+            h->stats[CTK_S_HOST_REASON] |= 8;
+            return rc2;
+        }
         if (mail2[CTK_SHM_BAD]) COLLECTIVE_FAIL(CTK_E_RANGE, "ctk_track_sharded: the co-occurrence table of some rank overflowed");
         nc_sum = (uint64_t)mail2[CTK_SHM_NCSUM_LO] | ((uint64_t)mail2[CTK_SHM_NCSUM_HI] << 32);
         fix_changed = false;

@@ -380,7 +380,7 @@ def strong_block(trk, comm, rank, world, wl, T, steps, warmup):
                      "%d time shards; barrier + sync around the timed calls, max over ranks" % world)
 
 
-def bench_main(args, wl, workloads, hbm_peak):
+def bench_main(args, wl, workloads, hbm_peak, cpu_baseline=None, pmc_traffic=None):
     from . import synth
     # Keep stdout clean for the ONE JSON line: RCCL may print through C stdio at communicator creation.  Everything
     # written to fd 1 until the result is ready goes to stderr instead.
@@ -407,13 +407,17 @@ def bench_main(args, wl, workloads, hbm_peak):
     d_out = trk.malloc(max(nloc * plane * 4, 8))
     check_parity = not getattr(args, "no_parity_check", False) and 2 * T_total * plane * 4 <= (96 << 30)
     member = None
+    cpu_slab = None
     if wl.get("device_fill"):
         seed, tf = (rank, 0) if weak else (0, t0)
         trk.synth_fill(d_in, nloc, ny, nx, seed=seed, t0=tf)
         member = ("fill", seed, tf)
     else:
-        a = synth.smooth_field(T, ny, nx, seed=rank) if weak else synth.smooth_field(T, ny, nx, seed=0)[t0:t1]
+        a_full = synth.smooth_field(T, ny, nx, seed=rank if weak else 0)
+        a = a_full if weak else a_full[t0:t1]
         trk.h2d(d_in, a)
+        if rank == 0 and cpu_baseline is not None and not getattr(args, "no_cpu_baseline", False):
+            cpu_slab = a_full                                          # (the workload's own slab, seed 0: what the N = 1 line times too)
         if check_parity:
             # rank 0 needs every member for the one-call run: through a file in shared scratch space, or -- if that cannot be
             # written -- by generating it again from (seed, window)
@@ -429,7 +433,7 @@ def bench_main(args, wl, workloads, hbm_peak):
                         os.remove(path)
                     except OSError:
                         pass
-        del a
+        del a, a_full
     w = _weights(ny, nx)
     thr_value = np.float64(np.float32(wl["threshold"]))
     thr = np.full(nloc, thr_value)
@@ -499,6 +503,7 @@ def bench_main(args, wl, workloads, hbm_peak):
         if rank == 0 and strong is not None and tried and "error" not in strong:
             strong["larger_slab_not_run"] = tried
 
+    n_devices = len(set(int(v) for v in comm.allgather(np.array([st.device], dtype=np.int64)).ravel()))
     alg = {"k_threshold": 4.0 * px, "k_relabel": 4.0 * px}
     kern = max(alg, key=lambda k: per.get(k, 0.0))
     achieved = alg[kern] / (per[kern] * 1e-3) / 1e9 if per.get(kern, 0) > 0 else 0.0
@@ -521,12 +526,27 @@ def bench_main(args, wl, workloads, hbm_peak):
                                  unit="GB/s", frac=achieved / hbm_peak, traffic=None, algorithmic_bytes_per_launch=alg[kern],
                                  avg_kernel_ms=per.get(kern), note="rank 0's shard"),
                    kernels_ms=per, workload_stats_rank0=stats)
+        out["config"]["distinct_devices"] = n_devices
+        if pmc_traffic is not None and nloc == T:
+            # (HBM bytes per launch from the committed PMC capture of this workload: rank 0's shard IS the workload's slab when every
+            # rank holds one member)
+            out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"], args.workload)
         if strong is not None:
             out["strong_025deg"] = strong
+    st.close()                                       # (nothing collective from here on)
+    rc = 0
+    if rank == 0:
+        if cpu_slab is not None:
+            # the CPU leg: the oracle's scipy port on the workload's own slab, rank 0's host cores, after every collective is done
+            out["cpu_baseline"] = cpu_baseline(wl, cpu_slab, w)
+        # the line must not stand for a result nobody checked: a parity check that ran and failed (or could not run) fails the job
+        if check_parity and not parity_ok:
+            rc = 3
+            print("bench.py: the in-run parity check of the sharded result FAILED or could not run: %s" % json.dumps(parity), file=sys.stderr)
         try:
             C.CDLL(None).fflush(None)            # drain C stdio into stderr before stdout is restored
         except Exception:
             pass
         os.dup2(sys_stdout_fd, 1)
         print(json.dumps(out), flush=True)
-    st.close()
+    return rc

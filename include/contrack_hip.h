@@ -269,7 +269,9 @@ int ctk_get_timing_sums(ctk_handle *h, double *sums, int64_t *counts, int reset)
                                    overlap = 1.0).  Device path: 0/1 flag; host resolver: the number of such decisions. */
 #define CTK_S_HOST_REASON   18  /* why a one-call track left the fused device path: bit 0 the co-occurrence table had to be regrown, bit 1
                                    the overlap filter needed more than 240 passes (both: host resolver, CTK_S_HOST_PATH = 1); 4 = decisions
-                                   on rounding boundaries, re-evaluated on the device through the time-shard path with one rank */
+                                   on rounding boundaries, re-evaluated on the device through the time-shard path with one rank;
+                                   bit 3 (8) = a bounded inter-workgroup wait gave up, the resolution was repeated with one launch per
+                                   filter pass */
 #define CTK_S_SHARED_ROWS   17  /* time-sharded path: seam candidate groups shared between shards (driven on every rank)        */
 #define CTK_S_RELABEL_KERNEL 19    /* which write kernel ran: 5 = k_relabel_v5, 4 = k_relabel_v4, 0 = generic k_relabel */
 #define CTK_S_FUSED         20    /* 1: the one-call pass ran without a host hand-off (device seam driver, one synchronisation) */
@@ -279,6 +281,11 @@ int ctk_get_timing_sums(ctk_handle *h, double *sums, int64_t *counts, int reset)
 int ctk_get_stats(ctk_handle *h, int64_t *out /* [CTK_NSTATS] */);
 /* filter passes launched per round before convergence is checked on the host (default 10, 1..32)   */
 int ctk_set_filter_round(ctk_handle *h, int passes);
+/* Test hook for the BOUNDED inter-workgroup waits of the one-launch ("systolic") filter pass: a wave that has waited longer than
+ * limit_ms (0 = the default, 200 ms) for its predecessor gives up, the pass is marked invalid and the call repeats the resolution
+ * with one launch per filter pass (CTK_S_HOST_REASON bit 3; the handle keeps doing so).  stall_mode 1: the first workgroup of the
+ * chain arrives late (limit / 4); 2: it never publishes; 0: normal.  Also clears the handle's "no one-launch pass" state. */
+int ctk_debug_set_spin(ctk_handle *h, double limit_ms, int stall_mode);
 /* 1 (default; CTK_ASYNC=0 in the environment turns it off): the one-call entries run the whole pass without a host hand-off (device
  * seam driver, one synchronisation at the end, validated from a device-written block of scalars; CTK_S_FUSED) and repeat the
  * resolution on the synchronous path below only if the validation says so; 0: always the synchronous path (host seam driver) */

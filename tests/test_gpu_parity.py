@@ -303,6 +303,58 @@ def test_fused_pass_and_its_fallbacks(name):
             assert np.array_equal(f2, g["flag"]) and t.stats()["fused_pass"] == 0
 
 
+def test_bounded_inter_workgroup_waits_fall_back_instead_of_hanging():
+    """the one-launch ("systolic") filter pass waits for the workgroup of the previous timesteps; HIP promises nothing about
+    dispatch order, so every such wait is bounded: with the head of the chain made late (test hook) the pass still completes
+    normally; with a head that NEVER publishes, the waits give up after the limit, the pass is marked invalid and the call
+    repeats the resolution with one launch per filter pass -- an error-free, bit-exact result instead of a hung GPU -- and the
+    handle stays on per-pass launches (contrack.py:706-742 is what both forms evaluate)"""
+    import time
+    g = golden_util.load("busy_s1")
+    args = (g["anom"], g["thr"], _native.CMP_OPS[g["gorl"]], g["wrow"], g["overlap"], g["persistence"], g["twosided"])
+    want_n = len(np.unique(g["flag"])) - 1
+    with _native.Tracker(0) as t:
+        f, n = t.track(*args)
+        assert np.array_equal(f, g["flag"]) and n == want_n and t.stats()["fused_pass"] == 1
+        t.debug_set_spin(40.0, 1)                              # late by limit / 4: nobody gives up
+        f, n = t.track(*args)
+        st = t.stats()
+        assert np.array_equal(f, g["flag"]) and n == want_n and st["fused_pass"] == 1 and not (st["off_fused_path_reason"] & 8), st
+        t.debug_set_spin(20.0, 2)                              # never: every wave behind the head gives up after 20 ms
+        t0 = time.time()
+        f, n = t.track(*args)
+        took = time.time() - t0
+        st = t.stats()
+        assert np.array_equal(f, g["flag"]) and n == want_n
+        assert st["fused_pass"] == 0 and (st["off_fused_path_reason"] & 8), st
+        assert took < 5.0, took
+        f, n = t.track(*args)                                  # sticky: per-pass launches now, the stalled head no longer matters
+        st = t.stats()
+        assert np.array_equal(f, g["flag"]) and n == want_n and st["fused_pass"] == 1 and not (st["off_fused_path_reason"] & 8), st
+        t.debug_set_spin(0.0, 0)
+        f, n = t.track(*args)
+        assert np.array_equal(f, g["flag"]) and t.stats()["fused_pass"] == 1
+
+
+def test_bounded_waits_on_the_time_shard_path():
+    """the same give-up on ctk_track_sharded_*: every rank reads it from the gathered headers and all repeat the call with one
+    launch per filter pass"""
+    from shard_inproc import sharded_threads
+    g = golden_util.load("busy_s1")
+    T = g["anom"].shape[0]
+    want_n = len(np.unique(g["flag"])) - 1
+    hs = [_native.Tracker(0) for _ in range(3)]
+    try:
+        hs[1].debug_set_spin(20.0, 2)                          # rank 1's chain head never publishes (its shard spans two workgroups)
+        f, n, st = sharded_threads(hs, g["anom"], g["thr"], _native.CMP_OPS[g["gorl"]], g["wrow"], g["overlap"], g["persistence"], g["twosided"],
+                                   [0, 8, T - 8, T])
+        assert np.array_equal(f, g["flag"]) and n == want_n
+        assert all(s["off_fused_path_reason"] & 8 for s in st), st
+    finally:
+        for h in hs:
+            h.close()
+
+
 @pytest.mark.parametrize("shape", [(5, 1, 7), (5, 7, 1), (3, 2, 2), (4, 3, 64), (4, 3, 65), (2, 5, 128), (6, 4, 4), (9, 33, 3), (1, 1, 1),
                                    (7, 2, 4100)], ids=str)
 def test_degenerate_grids(trk, oracle_lib, shape):

@@ -1,7 +1,10 @@
-"""The table-level sharded protocol (tests/gloo_driver.py) under torch.distributed/gloo, world_size 2 and 3, on CPU:
-halo exchange, table all-gather, host resolve (ctk_resolve), extent all-reduce -- with the numpy shard engine standing in
-for the HIP stages.  Every rank's slice must equal the reference golden.  (The product's N > 1 path lives in the library:
-tests/test_gpu_sharded.py; its GPU-free parts -- boundary label resolution, rendezvous -- are tested in tests/test_shard_host.py.)"""
+"""The STAGED, table-level protocol (tests/gloo_driver.py) under torch.distributed / gloo, world_size 2 and 3, on CPU: halo exchange,
+table all-gather, the GPU-free host resolver of the library (ctk_resolve, csrc/ctk_resolve.cpp), extent all-reduce -- with a numpy
+shard engine (tests/cpu_engine.py) standing in for the HIP stages.  What it covers: the table-level specification of the multi-rank
+resolution and ctk_resolve itself.  What it does NOT cover: the product's N > 1 path, ctk_track_sharded_* (csrc/ctk_sharded.hip,
+ctk_comm.hip) -- that needs a GPU and is tested in tests/test_gpu_sharded*.py (threads / processes on one GPU), tests/test_gpu_fullsize.py
+and bench.py's in-run parity check; its GPU-free parts (boundary label resolution, rendezvous) in tests/test_shard_host.py.
+RCCL with more than one rank has not run anywhere yet (one GPU per box here)."""
 import os
 import socket
 
