@@ -5,6 +5,7 @@ The library is the product's only compute path: if it is missing or no GPU is vi
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -24,7 +25,7 @@ EXPORTS = [
     "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_resolve", "ctk_result_free",
     "ctk_result_info", "ctk_result_arrays", "ctk_result_nshards", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
     "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_set_seam_caps", "ctk_debug_set_spin", "ctk_debug_np_sum", "ctk_debug_boundary_resolve", "ctk_set_timing", "ctk_get_timings", "ctk_get_timing_sums", "ctk_set_device_resolve", "ctk_set_fused_pass", "ctk_set_filter_round", "ctk_get_stats",
-    "ctk_dev_malloc", "ctk_dev_free", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
+    "ctk_dev_malloc", "ctk_dev_free", "ctk_host_alloc", "ctk_host_free", "ctk_host_register", "ctk_host_unregister", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
     "ctk_synth_fill",
     "ctk_comm_unique_id", "ctk_comm_init_rccl", "ctk_comm_group_create", "ctk_comm_group_destroy", "ctk_comm_init_local", "ctk_comm_init_shm",
     "ctk_comm_destroy", "ctk_comm_rank", "ctk_comm_world", "ctk_comm_barrier", "ctk_comm_allgather_host", "ctk_comm_ops",
@@ -115,6 +116,10 @@ def lib():
     L.ctk_set_filter_round.argtypes = [p, i32]
     L.ctk_dev_malloc.argtypes = [p, pp, sz]
     L.ctk_dev_free.argtypes = [p, p]
+    L.ctk_host_alloc.argtypes = [p, pp, sz]
+    L.ctk_host_free.argtypes = [p, p]
+    L.ctk_host_register.argtypes = [p, p, sz]
+    L.ctk_host_unregister.argtypes = [p, p]
     L.ctk_memcpy_h2d.argtypes = [p, p, p, sz]
     L.ctk_memcpy_d2h.argtypes = [p, p, p, sz]
     L.ctk_sync.argtypes = [p]
@@ -352,15 +357,88 @@ class Comm:
         self.close()
 
 
+class _ResultPool:
+    """Recycles the memory of result arrays (the `flag` slabs the host-array entries return).
+
+    A fresh np.empty array consists of pages that do not exist yet: the device -> host copy then runs behind first-touch page
+    faults (47 GB/s through eight bounce threads at best; measured, tools/d2h_probe*.py).  Memory that HAS been touched can be
+    registered with HIP in ~1 ms and takes the result in ONE DMA at PCIe rate (57 GB/s) -- so the blocks of results the caller has
+    dropped are kept (a few, CTK_RESULT_POOL_MB in all, default 2048), registered on their first reuse, and handed out again.
+    A loop over ensemble members that writes each result out and drops it gets every result but the first at DMA speed; a
+    caller that keeps every result sees exactly the old behaviour.  The arrays handed out are ordinary numpy arrays; a block
+    returns to the pool when the last view of it is gone (weakref on the buffer all views share)."""
+
+    def __init__(self, tracker):
+        import threading
+        self._trk = weakref.ref(tracker)
+        self._lock = threading.Lock()
+        self._free = []                      # blocks: dict(mem=np.uint8 array, registered=bool)
+        self._leased = {}                    # id(block) -> block
+        self.cap = int(float(os.environ.get("CTK_RESULT_POOL_MB", "2048")) * (1 << 20))
+        self.hits = self.misses = 0
+
+    def take(self, shape, dtype=np.int32):
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        if nbytes < (8 << 20) or self.cap <= 0:            # small results: nothing to gain
+            return np.empty(shape, dtype=dtype)
+        blk = None
+        with self._lock:
+            for i, b in enumerate(self._free):
+                if nbytes <= b["mem"].nbytes <= nbytes + nbytes // 4:
+                    blk = self._free.pop(i)
+                    break
+        if blk is None:
+            self.misses += 1
+            blk = dict(mem=np.empty(nbytes, dtype=np.uint8), registered=False)
+        else:
+            self.hits += 1
+            trk = self._trk()
+            if not blk["registered"] and trk is not None and trk.handle:
+                # (touched by its first use: registration is cheap now; a failure just leaves the block pageable)
+                blk["registered"] = lib().ctk_host_register(trk.handle, blk["mem"].ctypes.data, blk["mem"].nbytes) == 0
+        carr = (C.c_ubyte * nbytes).from_address(blk["mem"].ctypes.data)
+        with self._lock:
+            self._leased[id(blk)] = blk
+        weakref.finalize(carr, self._release, blk)
+        return np.frombuffer(carr, dtype=dtype).reshape(shape)
+
+    def _unregister(self, blk):
+        trk = self._trk()
+        if blk["registered"] and trk is not None and trk.handle:
+            lib().ctk_host_unregister(trk.handle, blk["mem"].ctypes.data)
+        blk["registered"] = False
+
+    def _release(self, blk):
+        with self._lock:
+            self._leased.pop(id(blk), None)
+            held = sum(b["mem"].nbytes for b in self._free)
+            keep = self._trk() is not None and held + blk["mem"].nbytes <= self.cap
+            if keep:
+                self._free.append(blk)
+        if not keep:
+            self._unregister(blk)
+
+    def close(self):
+        """the handle goes away: nothing stays registered (arrays still held by the caller remain valid, pageable memory)"""
+        with self._lock:
+            blocks = self._free + list(self._leased.values())
+            self._free = []
+        for b in blocks:
+            self._unregister(b)
+
+
 class Tracker:
     """One GPU + stream + reusable device workspace (ctk_handle)."""
 
     def __init__(self, device=0):
         self._h = C.c_void_p()
         check(lib().ctk_create(C.byref(self._h), int(device)))
+        self._pool = _ResultPool(self)
 
     def close(self):
         if getattr(self, "_h", None):
+            if getattr(self, "_pool", None) is not None:
+                self._pool.close()
             lib().ctk_destroy(self._h)
             self._h = None
 
@@ -378,14 +456,19 @@ class Tracker:
         return self._h
 
     # ---- one call, host numpy in / out ------------------------------------------------------
-    def track(self, anom, thr, cmp_op, wrow, overlap, persistence, twosided=True, f64=False):
+    def track(self, anom, thr, cmp_op, wrow, overlap, persistence, twosided=True, f64=False, out=None):
         anom = np.ascontiguousarray(anom, dtype=np.float64 if f64 else np.float32)
         T, ny, nx = anom.shape
         thr = np.ascontiguousarray(thr, dtype=np.float64)
         wrow = np.ascontiguousarray(wrow, dtype=np.float32)
         if thr.shape != (T,) or wrow.shape != (ny,):
             raise ValueError("thr must have shape (T,) and wrow (ny,)")
-        flag = np.empty((T, ny, nx), dtype=np.int32)
+        if out is not None:
+            if out.dtype != np.int32 or out.shape != (T, ny, nx) or not out.flags.c_contiguous or not out.flags.writeable:
+                raise ValueError("out must be a writable C-contiguous int32 array of the slab's shape")
+            flag = out
+        else:
+            flag = self._pool.take((T, ny, nx))
         n = C.c_int64(0)
         fn = lib().ctk_track_f64 if f64 else lib().ctk_track_f32
         check(fn(self._h, anom.ctypes.data, T, ny, nx, thr.ctypes.data, int(cmp_op), wrow.ctypes.data,
@@ -511,7 +594,7 @@ class Tracker:
         T, ny, nx, _ = shape
         thr = np.ascontiguousarray(thr, dtype=np.float64)
         wrow = np.ascontiguousarray(wrow, dtype=np.float32)
-        flag = np.empty((T, ny, nx), dtype=np.int32)
+        flag = self._pool.take((T, ny, nx))
         n = C.c_int64(0)
         check(lib().ctk_track_resident(self._h, thr.ctypes.data, int(cmp_op), wrow.ctypes.data, float(overlap), int(persistence),
                                        int(bool(twosided)), flag.ctypes.data, C.byref(n)))

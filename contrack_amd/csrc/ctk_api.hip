@@ -1999,11 +1999,14 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
 //   Populating the pages from helper threads while the input travels (MADV_POPULATE_WRITE) was tried and is worse: the
 //   faults contend with the page pinning of the concurrent H2D copy (H2D 12.6 -> 25-37 ms).
 // ------------------------------------------------------------------------------------------------
+static bool host_is_pinned(const void *p, size_t n);
 namespace {
 // to_device: host -> device, else device -> host.  Lane i moves the chunks i, i + kLanes, ...
+// false = not done: the caller issues a plain hipMemcpy (small copies; pinned / registered host memory, which takes ONE DMA at PCIe
+// rate -- ctk_host_alloc, ctk_host_register: the bounce threads exist for the page faults of fresh pageable arrays)
 bool bounce_copy(BouncePool &pool, int device, void *dev, void *host, size_t bytes, bool to_device)
 {
-    if (bytes < 4 * kBounce || !pool.init()) return false;                      // small copies: plain hipMemcpy
+    if (bytes < 4 * kBounce || host_is_pinned(host, bytes) || !pool.init()) return false;
     const size_t nchunk = (bytes + kBounce - 1) / kBounce;
     std::atomic<bool> ok(true);
     auto work = [&](int li) {
@@ -2578,6 +2581,52 @@ extern "C" int ctk_dev_malloc(ctk_handle *h, void **p, size_t nbytes)
     if (e != hipSuccess) { *p = nullptr; return ctk_set_error(CTK_E_NOMEM, "hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(e)); }
     return CTK_OK;
 }
+// Result buffers for the host-array entries without first-touch page faults: pinned, CPU-cacheable host memory owned by the caller
+// (ctk_host_alloc / ctk_host_free) or a caller array registered once (ctk_host_register / ctk_host_unregister).  ctk_track_f32 /
+// _f64 / ctk_track_resident recognise such a `flag` pointer and copy the result into it with ONE DMA (no bounce buffers).
+extern "C" int ctk_host_alloc(ctk_handle *h, void **p, size_t nbytes)
+{
+    if (!h || !p) return ctk_set_error(CTK_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipError_t e = hipHostMalloc(p, nbytes ? nbytes : 8, hipHostMallocNonCoherent);
+    if (e != hipSuccess) { *p = nullptr; (void)hipGetLastError(); return ctk_set_error(CTK_E_NOMEM, "hipHostMalloc(%zu) failed: %s", nbytes, hipGetErrorString(e)); }
+    return CTK_OK;
+}
+extern "C" int ctk_host_free(ctk_handle *h, void *p)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (p) HIPCHK(hipHostFree(p));
+    return CTK_OK;
+}
+extern "C" int ctk_host_register(ctk_handle *h, void *p, size_t nbytes)
+{
+    if (!h || !p || !nbytes) return ctk_set_error(CTK_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipError_t e = hipHostRegister(p, nbytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return ctk_set_error(CTK_E_NOMEM, "hipHostRegister(%zu bytes) failed: %s", nbytes, hipGetErrorString(e)); }
+    return CTK_OK;
+}
+extern "C" int ctk_host_unregister(ctk_handle *h, void *p)
+{
+    if (!h || !p) return ctk_set_error(CTK_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipHostUnregister(p));
+    return CTK_OK;
+}
+// is [p, p + n) pinned / registered host memory the device can write directly?
+static bool host_is_pinned(const void *p, size_t n)
+{
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (at.type != hipMemoryTypeHost) return false;
+    hipPointerAttribute_t at2;
+    memset(&at2, 0, sizeof(at2));
+    if (n > 1 && hipPointerGetAttributes(&at2, (const char *)p + n - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return n <= 1 || at2.type == hipMemoryTypeHost;
+}
+
 extern "C" int ctk_dev_free(ctk_handle *h, void *p)
 {
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");

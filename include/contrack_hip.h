@@ -300,6 +300,15 @@ int ctk_dev_free(ctk_handle *h, void *p);
 int ctk_memcpy_h2d(ctk_handle *h, void *dst_dev, const void *src, size_t nbytes);
 int ctk_memcpy_d2h(ctk_handle *h, void *dst, const void *src_dev, size_t nbytes);
 int ctk_sync(ctk_handle *h);
+/* Result buffers without first-touch page faults for the host-array entries (ctk_track_f32 / _f64 / ctk_track_resident): a `flag`
+ * pointer into memory from ctk_host_alloc (pinned, CPU-cacheable) or into a caller array registered with ctk_host_register is
+ * recognised and filled with ONE DMA at PCIe rate; an ordinary (pageable, usually fresh) array goes through eight threads draining
+ * pinned bounce buffers, bound by the page faults of its first touch.  What replaces np.empty at contrack.py:776-791 when results
+ * are produced in a loop (ensemble members): contrack_amd/_native.py recycles such blocks. */
+int ctk_host_alloc(ctk_handle *h, void **p, size_t nbytes);
+int ctk_host_free(ctk_handle *h, void *p);
+int ctk_host_register(ctk_handle *h, void *p, size_t nbytes);
+int ctk_host_unregister(ctk_handle *h, void *p);
 void *ctk_stream(ctk_handle *h);                          /* hipStream_t */
 /* deterministic on-device synthetic slab for throughput runs (bench only; not part of the path) */
 int ctk_synth_fill(ctk_handle *h, float *anom_dev, int64_t T, int ny, int nx, uint64_t seed);

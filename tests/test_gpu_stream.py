@@ -95,3 +95,38 @@ def test_stream_exact_fixups_reread_the_input(trk):
     assert np.array_equal(out, g["flag"]) and n == len(np.unique(g["flag"])) - 1
     st = trk.stats()
     assert st["exact_fixups"] > 0 and reads == 2 * list(range(0, T, 4))
+
+
+def test_result_memory_is_recycled_and_results_stay_valid():
+    """the binding recycles the memory of dropped results (registered with HIP on reuse: one DMA instead of bounce buffers behind
+    page faults); arrays still held -- and views of them -- are never overwritten"""
+    import gc
+    from contrack_amd import synth
+    from contrack_amd.contrack import row_weights
+    T, ny, nx = 40, 181, 360                                  # 10.4 MB of flags: above the pool's threshold
+    a = synth.smooth_field(T, ny, nx, seed=3)
+    b = synth.smooth_field(T, ny, nx, seed=4)
+    lat, _ = synth.grid(ny, nx)
+    w = row_weights(lat, np.float32(1.0), np.float32(1.0))
+    thr = np.full(T, 160.0)
+    with _native.Tracker(0) as t:
+        fa, na = t.track(a, thr, 0, w, 0.5, 3, True)
+        keep_a = fa.copy()
+        view = fa[5:7]                                           # a view keeps the block leased
+        addr = fa.ctypes.data
+        del fa
+        gc.collect()
+        fb, nb = t.track(b, thr, 0, w, 0.5, 3, True)             # must NOT land in the block `view` still uses
+        assert fb.ctypes.data != addr and np.array_equal(view, keep_a[5:7])
+        keep_b = fb.copy()
+        del view, fb
+        gc.collect()
+        assert t._pool.hits == 0
+        fa2, na2 = t.track(a, thr, 0, w, 0.5, 3, True)           # recycled block (registered now)
+        assert t._pool.hits == 1 and np.array_equal(fa2, keep_a) and na2 == na
+        fb2, nb2 = t.track(b, thr, 0, w, 0.5, 3, True)
+        assert t._pool.hits == 2 and np.array_equal(fb2, keep_b) and nb2 == nb and np.array_equal(fa2, keep_a)
+        out = np.empty((T, ny, nx), np.int32)
+        fo, _ = t.track(a, thr, 0, w, 0.5, 3, True, out=out)     # a caller-supplied array is used as it is
+        assert fo is out and np.array_equal(out, keep_a)
+    assert np.array_equal(fa2, keep_a) and np.array_equal(fb2, keep_b)       # still valid after the handle is gone
