@@ -49,14 +49,14 @@ static double now_ms_fwd() { return std::chrono::duration<double, std::milli>(st
 // Debug / experiment switches of the environment, read ONCE per process (getenv is a linear scan of environ and not safe against a
 // concurrent setenv from another rank's host thread; the passes shave microseconds).
 struct CtkEnv {
-    int sd_dbg = 0, relabel_rows = 0;
+    int sd_dbg = 0, relabel_rows = 0, xcd_thr = 0, xcd_rel = 0;
     bool pass_launches = false, print_ptrs = false, seamstats = false, relabel_plain = false, relabel_v4 = false, hosttrace = false,
          sh_no_slots = false, no_spec_x4 = false, sh_force_split = false;
     CtkEnv()
     {
         auto num = [](const char *k) { const char *e = getenv(k); return e ? atoi(e) : 0; };
         auto on = [](const char *k) { return getenv(k) != nullptr; };
-        sd_dbg = num("CTK_SD_DBG"); relabel_rows = num("CTK_RELABEL_ROWS");
+        sd_dbg = num("CTK_SD_DBG"); relabel_rows = num("CTK_RELABEL_ROWS"); xcd_thr = getenv("CTK_XCD_THR") ? num("CTK_XCD_THR") : 64; xcd_rel = num("CTK_XCD_REL");      // (tools/xcd_probe.py, NOTES round 4)
         pass_launches = on("CTK_PASS_LAUNCHES"); print_ptrs = on("CTK_PRINT_PTRS"); seamstats = on("CTK_SEAMSTATS");
         relabel_plain = on("CTK_RELABEL_PLAIN"); relabel_v4 = on("CTK_RELABEL_V4"); hosttrace = on("CTK_HOSTTRACE");
         sh_no_slots = on("CTK_SH_NO_SLOTS"); no_spec_x4 = on("CTK_NO_SPEC_X4"); sh_force_split = on("CTK_SH_FORCE_SPLIT");
@@ -235,6 +235,7 @@ struct ctk_handle {
     uint64_t spin_limit = CTK_SPIN_LIMIT_TICKS;
     int debug_stall = 0;                          // test hook (ctk_debug_set_spin): the first workgroup of the chain is late (1) / never publishes (2)
     bool no_sys = false, sh_retrying = false;
+    int xcd_thr = -1, xcd_rel = -1;               // chunk -> XCD mapping of the two streaming kernels (xcd_chunk); -1: the environment's / default
     bool sh_collective_err = false;               // the time-shard path's error was decided identically on every rank
     ctk_comm *active_comm = nullptr;              // set while the time-shard path runs with more than one rank
     // host scratch of the seam driver, kept between calls (fresh 100+ KB vectors would page-fault every call)
@@ -499,6 +500,13 @@ extern "C" int ctk_debug_set_seam_caps(ctk_handle *h, int labels, int ops)
     return CTK_OK;
 }
 
+extern "C" int ctk_debug_set_xcd(ctk_handle *h, int thr_mode, int rel_mode)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    h->xcd_thr = thr_mode; h->xcd_rel = rel_mode;
+    return CTK_OK;
+}
+
 extern "C" int ctk_debug_set_spin(ctk_handle *h, double limit_ms, int stall_mode)
 {
     if (!h || stall_mode < 0 || stall_mode > 2 || limit_ms < 0) return ctk_set_error(CTK_E_INVALID, "ctk_debug_set_spin: null handle, negative limit or stall mode not in 0..2");
@@ -686,8 +694,15 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
             uint64_t *mk = P<uint64_t>(h->mask) + t0 * ny * W;
             uint32_t *zc = t0 == 0 ? P<uint32_t>(h->counters) : nullptr;
             // ballot form: float32, rows of at most 64 words
-            static const int thr_variant = getenv("CTK_THRESHOLD") ? atoi(getenv("CTK_THRESHOLD")) : 4;
+            static const int thr_variant = getenv("CTK_THRESHOLD") ? atoi(getenv("CTK_THRESHOLD")) : 7;
             const bool v6 = !f64 && W <= 64 && (thr_variant == 6 || !v4);      // ballot form: where the float4 form does not apply (or on request)
+            // k_threshold_v7: loads per lane and step such that the steps of a full chunk carry the fewest idle loads
+            int u7 = 8;
+            {
+                const int L = (std::min(rbt, ny) * W * 16 + 255) / 256;
+                int best = 1 << 30;
+                for (int u = 8; u >= 4; u--) { const int waste = (L + u - 1) / u * u - L; if (waste < best) { best = waste; u7 = u; } }
+            }
             const int R6 = std::max(1, 64 / W), nchunk_t = (ny + R6 - 1) / R6;
             const int64_t nchunks = nt * nchunk_t;
             static const int64_t g6max = getenv("CTK_THR_GRID") ? atoll(getenv("CTK_THR_GRID")) : 16384;
@@ -698,7 +713,12 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         else if (f64) k_threshold<OP, double><<<g, 256, 0, s>>>((const double *)src, P<double>(h->thr32) + t0, rows, ny, nx, W, mk, zc); \
         else if (v4 && thr_variant == 44) k_threshold_v4<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
         else if (v4 && thr_variant == 42) k_threshold_v4<OP, 2><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
-        else if (v4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
+        else if (v4 && thr_variant == 4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
+        else if (v4 && u7 == 4) k_threshold_v7<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : ctk_env().xcd_thr); \
+        else if (v4 && u7 == 5) k_threshold_v7<OP, 5><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : ctk_env().xcd_thr); \
+        else if (v4 && u7 == 6) k_threshold_v7<OP, 6><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : ctk_env().xcd_thr); \
+        else if (v4 && u7 == 7) k_threshold_v7<OP, 7><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : ctk_env().xcd_thr); \
+        else if (v4) k_threshold_v7<OP, 8><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : ctk_env().xcd_thr); \
         else k_threshold<OP, float><<<g, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, rows, ny, nx, W, mk, zc); \
     } while (0)
             switch (cmp_op) {
@@ -1636,6 +1656,7 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
     a.chunk_vals = chunk_vals ? chunk_vals + t0 * nchunk * CTK_CV : nullptr;
     a.guard = h->guard_on ? P<uint32_t>(h->counters) : nullptr;
     a.plain_stores = ctk_env().relabel_plain ? 1 : 0;
+    a.xcd_remap = h->xcd_rel >= 0 ? h->xcd_rel : ctk_env().xcd_rel;
     const int64_t npl = (int64_t)h->ny * h->nx;
     const int rvcap = 2048;
     const size_t lds = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) + (size_t)rvcap * 4;

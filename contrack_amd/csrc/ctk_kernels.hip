@@ -156,6 +156,23 @@ __device__ __forceinline__ uint32_t row16_or(uint32_t v)
     return v;
 }
 
+// Workgroup b of a launch lands on XCD b % 8 (round-robin dispatch).  With `on`, the chunk a workgroup takes is remapped so that every
+// XCD streams ONE contiguous eighth of the slab instead of every eighth chunk (experiment, CTK_XCD_REMAP).
+__device__ __forceinline__ unsigned xcd_chunk(unsigned b, unsigned n, int on)
+{
+    if (!on) return b;
+    if (on == 1) {                                         // one contiguous eighth of the launch per XCD
+        const unsigned per = n >> 3;
+        if (b >= (per << 3)) return b;                     // the n % 8 last chunks stay where they are
+        return (b & 7u) * per + (b >> 3);
+    }
+    // tiles of `on` consecutive chunks per XCD: 8 * on chunks form a group inside which XCD x takes chunks [x * on, (x + 1) * on)
+    const unsigned k = (unsigned)on, g = 8u * k, grp = b / g;
+    if ((grp + 1u) * g > n) return b;                      // the incomplete last group stays where it is
+    const unsigned r = b - grp * g;                        // position in the group: XCD r & 7, its (r >> 3)-th chunk
+    return grp * g + (r & 7u) * k + (r >> 3);
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define CTK_RB 16                  // rows per workgroup in the two streaming kernels
@@ -200,6 +217,80 @@ __global__ __launch_bounds__(256) void k_threshold_v4(const float *__restrict__ 
             lo = row16_or(lo);
             hi = row16_or(hi);
             if (sub == 0 && i0 + u * 256 + tid < total) mask[(row0 + rr[u]) * W + (cc[u] >> 4)] = ((uint64_t)hi << 32) | lo;
+        }
+    }
+}
+
+// k_threshold_v7: k_threshold_v4's decomposition (one workgroup per (timestep, rb rows), 16-byte non-temporal loads, a 16-lane
+// DPP row = 64 pixels = one mask word) with a third of its VALU work.  SQ counters (profiles/r04_sq_1deg.md) showed v4 to be
+// VALU-bound, not memory-bound: 446 VALU instructions per wave = 85 % of every SIMD's issue slots for the 125 us the kernel ran --
+// 58 per float4 load, most of them 64-bit address arithmetic, lane predicates and the two-register (lo / hi) 16-lane reduction.
+// Here: 32-bit byte offsets from a wave-uniform base (saddr form), (row, slot) advanced without divisions, the four compare
+// bits of a lane assembled by v_cmp + v_addc_co (nib = 2 nib + vcc: 8 instructions), ONE register reduced over the 8 lanes that
+// share a 32-bit half of the word (3 DPP ORs), the upper half fetched by a row mirror.  ~20 VALU per float4.
+template <int OP>
+__device__ __forceinline__ uint32_t thr_nibble(const f32x4 v, const float th)
+{
+    uint32_t nib = 0;
+    // nib = (((w) 2 + z) 2 + y) 2 + x : bit j = pixel j of the lane's four; NaN compares false in all four forms
+#define CTK_CMP_ADDC(INS)                                                                                                         \
+    asm volatile(INS " vcc, %1, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t" INS " vcc, %2, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t" \
+                 INS " vcc, %3, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t" INS " vcc, %4, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"      \
+                 : "+v"(nib) : "v"(v.w), "v"(v.z), "v"(v.y), "v"(v.x), "v"(th) : "vcc")
+    if (OP == 0) CTK_CMP_ADDC("v_cmp_ge_f32");
+    else if (OP == 1) CTK_CMP_ADDC("v_cmp_le_f32");
+    else if (OP == 2) CTK_CMP_ADDC("v_cmp_gt_f32");
+    else CTK_CMP_ADDC("v_cmp_lt_f32");
+#undef CTK_CMP_ADDC
+    return nib;
+}
+
+// U = loads per lane and step, picked by the host so that the steps of a chunk are (nearly) full: no predicates around the loads
+// (a conditional load made hipcc wait for every load before issuing the next one), lanes beyond the chunk re-read its last row.
+template <int OP, int U>
+__global__ __launch_bounds__(256) void k_threshold_v7(const float *__restrict__ anom, const float *__restrict__ thr32,
+                                                      int ny, int nx, int W, uint64_t *__restrict__ mask, int rb,
+                                                      uint32_t *__restrict__ zero_counters, int xcd)
+{
+    if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_N) zero_counters[threadIdx.x] = 0u;
+    const int nchunk = (ny + rb - 1) / rb;
+    const unsigned bid = xcd_chunk(blockIdx.x, gridDim.x, xcd);
+    const int t = (int)(bid / (unsigned)nchunk), y0 = (int)(bid - (unsigned)t * nchunk) * rb, tid = (int)threadIdx.x;
+    const int rows = min(rb, ny - y0);
+    const float th = thr32[t];
+    const int n4 = nx >> 2, n4p = W << 4;                  // float4 slots per row, padded to whole 16-lane groups (= words)
+    const int total = rows * n4p;
+    const int64_t row0 = (int64_t)t * ny + y0;
+    const char *base = (const char *)(anom + row0 * (int64_t)nx);      // wave-uniform; the lanes add 32-bit byte offsets
+    char *mbase = (char *)(mask + row0 * W);
+    const int sub = tid & 15;
+    const uint32_t shift = (uint32_t)(4 * (sub & 7));
+    // (row, slot) of the lane's next load, advanced by 256 slots at a time without dividing
+    int nr = tid / n4p, nc = tid - nr * n4p;
+    const int dr = 256 / n4p, dc = 256 - dr * n4p;
+    const uint32_t pitch = (uint32_t)nx * 4u, wpitch = (uint32_t)W * 8u;
+    for (int i0 = 0; i0 < total; i0 += 256 * U) {
+        f32x4 v[U];
+        uint32_t moff[U], vm[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int cl = min(nc, n4 - 1);                // padding slots re-read the row's last quad; their bits are cleared
+            const int rl = min(nr, rows - 1);              // lanes beyond the chunk re-read its last row and store nothing
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + ((uint32_t)rl * pitch + (uint32_t)cl * 16u)));
+            vm[u] = nc < n4 ? 0xfu : 0u;
+            moff[u] = nr < rows ? (uint32_t)nr * wpitch + (uint32_t)(nc >> 4) * 8u : 0xffffffffu;
+            nr += dr; nc += dc;
+            if (nc >= n4p) { nc -= n4p; nr++; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t nib = thr_nibble<OP>(v[u], th) & vm[u];
+            uint32_t x = nib << shift;                     // lanes 0-7 of the row build the low half of the word, lanes 8-15 the high half
+            x = dpp_or<0xB1>(x);                           // quad_perm [1,0,3,2]
+            x = dpp_or<0x4E>(x);                           // quad_perm [2,3,0,1]
+            x = dpp_or<0x141>(x);                          // row_half_mirror: every lane of a half row holds its half
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false);      // row_mirror: lane 0 <- lane 15
+            if (sub == 0 && moff[u] != 0xffffffffu) *reinterpret_cast<uint64_t *>(mbase + moff[u]) = ((uint64_t)hi << 32) | x;
         }
     }
 }
@@ -1336,6 +1427,7 @@ struct RelabelArgs {
     const int32_t *chunk_vals;     // [T][nchunk][CTK_CV] (k_run_values) or nullptr
     const uint32_t *guard;         // see ctk_guard_bad
     int plain_stores;              // experiment: plain instead of non-temporal stores
+    int xcd_remap;                 // experiment: every XCD streams one contiguous eighth of the slab (xcd_chunk)
 };
 
 // fast path (nx % 4 == 0, 16-byte aligned flag): one workgroup per (timestep, 16 rows).  The rows' mask
@@ -1419,7 +1511,8 @@ __global__ __launch_bounds__(256) void k_relabel_v5(RelabelArgs a, int rb, int r
     if (ctk_guard_bad(a.guard)) return;
     const int ny = a.ny, nx = a.nx, W = a.W;
     const int nchunk = (ny + rb - 1) / rb;
-    const int t = (int)(blockIdx.x / (unsigned)nchunk), y0 = (int)(blockIdx.x - (unsigned)t * nchunk) * rb, tid = (int)threadIdx.x;
+    const unsigned bid = xcd_chunk(blockIdx.x, gridDim.x, a.xcd_remap);
+    const int t = (int)(bid / (unsigned)nchunk), y0 = (int)(bid - (unsigned)t * nchunk) * rb, tid = (int)threadIdx.x;
     const int rows = min(rb, ny - y0);
     const int64_t row0 = (int64_t)t * ny + y0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1431,7 +1524,7 @@ __global__ __launch_bounds__(256) void k_relabel_v5(RelabelArgs a, int rb, int r
     for (int i = tid; i < rows * W; i += 256) { mrow[i] = a.mask[row0 * W + i]; wst[i] = a.wstart[row0 * W + i]; }
     for (int i = tid; i <= rows; i += 256) rst[i] = (y0 + i < ny) ? a.rowstart[row0 + i] : trun;
     // the chunk's run values in chunk order (k_run_values): loaded together with the tables -- one round trip, one barrier
-    if (a.chunk_vals && tid >= 256 - CTK_CV) rvs[tid - (256 - CTK_CV)] = a.chunk_vals[(int64_t)blockIdx.x * CTK_CV + (tid - (256 - CTK_CV))];
+    if (a.chunk_vals && tid >= 256 - CTK_CV) rvs[tid - (256 - CTK_CV)] = a.chunk_vals[(int64_t)bid * CTK_CV + (tid - (256 - CTK_CV))];
     __syncthreads();
     const uint32_t r0 = rst[0], nr = rst[rows] - r0;
     const int32_t *rvg = a.run_val + a.run_base[t] + r0;

@@ -286,6 +286,9 @@ int ctk_set_filter_round(ctk_handle *h, int passes);
  * with one launch per filter pass (CTK_S_HOST_REASON bit 3; the handle keeps doing so).  stall_mode 1: the first workgroup of the
  * chain arrives late (limit / 4); 2: it never publishes; 0: normal.  Also clears the handle's "no one-launch pass" state. */
 int ctk_debug_set_spin(ctk_handle *h, double limit_ms, int stall_mode);
+/* experiments: which chunk of the slab the workgroups of the two streaming kernels take (0 = in launch order, 1 = one contiguous eighth
+ * per XCD, k > 1 = tiles of k chunks per XCD); -1 = the default */
+int ctk_debug_set_xcd(ctk_handle *h, int thr_mode, int rel_mode);
 /* 1 (default; CTK_ASYNC=0 in the environment turns it off): the one-call entries run the whole pass without a host hand-off (device
  * seam driver, one synchronisation at the end, validated from a device-written block of scalars; CTK_S_FUSED) and repeat the
  * resolution on the synchronous path below only if the validation says so; 0: always the synchronous path (host seam driver) */
