@@ -51,7 +51,7 @@ static double now_ms_fwd() { return std::chrono::duration<double, std::milli>(st
 struct CtkEnv {
     int sd_dbg = 0, relabel_rows = 0, xcd_thr = 0, xcd_rel = 0;
     bool pass_launches = false, print_ptrs = false, seamstats = false, relabel_plain = false, relabel_v4 = false, hosttrace = false,
-         sh_no_slots = false, no_spec_x4 = false, sh_force_split = false;
+         sh_no_slots = false, no_spec_x4 = false, sh_force_split = false, sh_host_seam = false;
     CtkEnv()
     {
         auto num = [](const char *k) { const char *e = getenv(k); return e ? atoi(e) : 0; };
@@ -59,7 +59,7 @@ struct CtkEnv {
         sd_dbg = num("CTK_SD_DBG"); relabel_rows = num("CTK_RELABEL_ROWS"); xcd_thr = getenv("CTK_XCD_THR") ? num("CTK_XCD_THR") : 64; xcd_rel = num("CTK_XCD_REL");      // (tools/xcd_probe.py, NOTES round 4)
         pass_launches = on("CTK_PASS_LAUNCHES"); print_ptrs = on("CTK_PRINT_PTRS"); seamstats = on("CTK_SEAMSTATS");
         relabel_plain = on("CTK_RELABEL_PLAIN"); relabel_v4 = on("CTK_RELABEL_V4"); hosttrace = on("CTK_HOSTTRACE");
-        sh_no_slots = on("CTK_SH_NO_SLOTS"); no_spec_x4 = on("CTK_NO_SPEC_X4"); sh_force_split = on("CTK_SH_FORCE_SPLIT");
+        sh_no_slots = on("CTK_SH_NO_SLOTS"); no_spec_x4 = on("CTK_NO_SPEC_X4"); sh_force_split = on("CTK_SH_FORCE_SPLIT"); sh_host_seam = on("CTK_SH_HOST_SEAM");
     }
 };
 static const CtkEnv &ctk_env() { static const CtkEnv e; return e; }
@@ -190,7 +190,8 @@ struct ctk_handle {
     double stream_ms[4] = {0, 0, 0, 0};
     BouncePool *bounce = nullptr;                  // created on first use
     // time-sharded path (ctk_sharded.hip)
-    DevBuf sh_mask_next, sh_send, sh_recv, sh_prev, sh_elist, sh_ovr_slot, sh_ovr_val, sh_amb_list, sh_counts;
+    DevBuf sh_mask_next, sh_send, sh_recv, sh_prev, sh_elist, sh_ovr_slot, sh_ovr_val, sh_amb_list, sh_counts, sh_cl_shared, sh_cl_sent;
+    int sh_dev_off_ny = -1, sh_dev_off_nx = -1;   // grid whose clusters did not fit the device seam driver on the time-shard path: host-driven from then on
     struct ShardScratch *shard = nullptr;
     uint32_t *h_mail2 = nullptr;                   // pinned, device-written scalars
     void *h_shard = nullptr, *h_lab = nullptr, *h_seam = nullptr;        // pinned: gathered boundary records / label tables / shared seam groups
@@ -427,7 +428,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
                       &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
                       &h->sh_mask_next, &h->sh_send, &h->sh_recv, &h->sh_prev, &h->sh_elist, &h->sh_ovr_slot, &h->sh_ovr_val,
-                      &h->sh_amb_list, &h->sh_counts, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_root, &h->sd_nops, &h->sd_lbox, &h->rv_pstate};
+                      &h->sh_amb_list, &h->sh_counts, &h->sh_cl_shared, &h->sh_cl_sent, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_root, &h->sd_nops, &h->sd_lbox, &h->rv_pstate};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -497,6 +498,7 @@ extern "C" int ctk_debug_set_seam_caps(ctk_handle *h, int labels, int ops)
     if (!h || labels < 0 || ops < 0) return ctk_set_error(CTK_E_INVALID, "ctk_debug_set_seam_caps: null handle or negative capacity");
     h->debug_sd_lab = labels; h->debug_sd_ops = ops;
     h->async_off_ny = -1; h->async_off_nx = -1;          // (a grid that was sent to the host driver gets another try)
+    h->sh_dev_off_ny = -1; h->sh_dev_off_nx = -1;
     return CTK_OK;
 }
 
@@ -1787,7 +1789,7 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     r.lab_root = P<int32_t>(h->rv_lab_root);
     r.ext = P<int32_t>(h->ext); r.ext_off = (int64_t)R + 1; r.counters_w = P<uint32_t>(h->counters);
     SeamDev sd;
-    sd.dummy = nullptr;
+    sd.dummy = nullptr; sd.own_base = 0; sd.cl_shared = nullptr;
     sd.cl_parent = r.cl_parent; sd.cl_tmin = r.cl_tmin; sd.cl_tmax = r.cl_tmax; sd.cl_nops = r.cl_nops; sd.lbox = r.lbox; sd.mark = P<uint8_t>(h->rv_mark);
     sd.rec_root = P<uint32_t>(h->sd_root); sd.recs = P<CtkCand>(h->rv_cand_scratch); sd.rec_cnt = P<uint32_t>(h->rv_cand_cnt);
     sd.t_nops = P<uint32_t>(h->rv_cand_off);              // ([T + 1], unused on this path otherwise)

@@ -57,5 +57,6 @@ int ctk_comm_allgather(ctk_comm *c, const void *send, void *recv, size_t nbytes)
 // the stream has drained -- or a rank failed / died / did not arrive before the deadline (CTK_E_COMM; the RCCL communicator
 // is aborted so that the stream does drain).  The only way the time-sharded path waits for its stream.
 int ctk_comm_wait(ctk_comm *c);
+int ctk_comm_wait_word(ctk_comm *c, const volatile uint32_t *word, uint32_t stamp);     // a stamp written to pinned memory by a kernel on the stream
 // this rank gives up with `code`: tells every other rank (control segment / group flag) and retires the communicator
 void ctk_comm_abort(ctk_comm *c, int code);

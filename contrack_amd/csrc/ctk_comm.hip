@@ -387,6 +387,42 @@ int ctk_comm_wait(ctk_comm *c)
     return CTK_OK;
 }
 
+// Guarded wait for a word in pinned host memory that a kernel on the communicator's stream writes (a stamp): returns as soon as
+// the word is there -- kernels enqueued BEHIND the writer keep running -- or with the error of whoever gave up (same rules as
+// ctk_comm_wait).  A stream that drains without the stamp is an error.
+int ctk_comm_wait_word(ctk_comm *c, const volatile uint32_t *word, uint32_t stamp)
+{
+    if (!c || !word) return ctk_set_error(CTK_E_INVALID, "ctk_comm_wait_word: null argument");
+    if (c->dead) return comm_dead_error(c);
+    WaitState w;
+    for (uint64_t spins = 1;; spins++) {
+        if (*word == stamp) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return CTK_OK; }
+        if ((spins & 0x3fffu) != 0) continue;
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) {
+            if (*word == stamp) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return CTK_OK; }
+            return ctk_set_error(CTK_E_INTERNAL, "rank %d: the stream drained without the expected stamp", c->rank);
+        }
+        if (e != hipErrorNotReady) {
+            ctk_comm_abort(c, CTK_E_NODEVICE);
+            return ctk_set_error(CTK_E_NODEVICE, "rank %d: hipStreamQuery: %s", c->rank, hipGetErrorString(e));
+        }
+        if (c->world == 1) continue;
+        int rc = CTK_OK;
+        if (c->kind == 0) {
+            if (c->group->failed.load()) rc = group_error(c);
+            else if (mono_s() - w.t0 > c->timeout_s) {
+                group_fail(c->group, c->rank, CTK_E_COMM);
+                rc = ctk_set_error(CTK_E_COMM, "rank %d: a kernel of the time-shard path did not report within %.0f s", c->rank, c->timeout_s);
+            }
+        } else {
+            w.spins |= 255u;                                            // (every call here is already one in 2^14 polls: look at everything)
+            rc = ctl_poll(c, w, "a collective of the time-shard path");
+        }
+        if (rc != CTK_OK) { comm_retire(c); return rc; }
+    }
+}
+
 void ctk_comm_abort(ctk_comm *c, int code)
 {
     if (!c) return;

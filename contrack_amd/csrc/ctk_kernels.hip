@@ -676,7 +676,7 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
             // Straight from global memory (L2), P2B words per thread at a time: every load is issued before the first word is
             // looked at.  (Staging bands of rows through LDS first cost a dependent round trip and two barriers per band: eleven
             // bands = 29 of the 54 us a 721 x 1440 timestep took.)
-            constexpr int P2B = 8;
+            constexpr int P2B = THREADS == 1024 ? 4 : 8;          // (the 1024-thread variants run at 64 VGPRs: eight words in flight spilled 20 B per lane)
             for (int k0 = tid; k0 < nwords; k0 += THREADS * P2B) {
                 uint64_t m[P2B], ml[P2B], mr[P2B];
                 uint32_t wp[P2B];

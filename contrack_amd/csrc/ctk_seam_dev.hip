@@ -44,6 +44,11 @@ struct SeamDev {
     int64_t T;
     int dbg;                       // experiments (CTK_SD_DBG): stop after a stage
     int lab_cap, ops_cap;          // labels / operations of one cluster (<= 64; a test hook lowers them)
+    // time-shard path (ctk_sharded.hip): labels are GLOBAL ids; the clusters driven here hold only ids this shard numbered,
+    // (own_base, own_base + own_ids) -- their op slots are indexed by id - own_base -- and a cluster that holds an id reaching a
+    // shard boundary is "shared": all-gathered and driven identically on every rank (host), skipped here.  One-call path: 0 / nullptr.
+    uint32_t own_base;
+    const uint8_t *cl_shared;      // [labels + 1] at cluster roots, or nullptr
 };
 
 // fresh labels of the two seam pixels of every seam row; labels that meet a different label on a row are marked (only they can
@@ -286,6 +291,7 @@ __global__ __launch_bounds__(64) void k_seam_driver(SeamDev a, int64_t t_begin)
           for (uint32_t j = 0; j + 1 < nrec; j++) { const uint32_t rj = (uint32_t)__shfl((int)my_root, (int)j); dup = dup || ((uint32_t)lane > j && rj == my_root); }
           isr = isr && !dup;
       } else if (isr) isr = atomicCAS(&a.cl_nops[my_root], 0xffffffffu, 0u) == 0xffffffffu;       // many records: a claim word per root
+      if (isr && a.cl_shared && a.cl_shared[my_root]) isr = false;         // (time shards: driven with the other ranks' records)
       uint64_t roots = __ballot(isr);
       while (roots) {
         const int src = (int)__builtin_ctzll(roots);
@@ -479,8 +485,8 @@ __global__ __launch_bounds__(64) void k_seam_driver(SeamDev a, int64_t t_begin)
         // first SD_OPS_OWN in the slots that belong to its root id, larger clusters a range of the shared tail.  (One counter for
         // all clusters: a thousand same-address atomics from eight XCDs, ~80 ns each -- 47 of this kernel's 54 us.)
         home_ops += (uint32_t)nops;
-        uint32_t base = R * SD_OPS_OWN;
-        if (nops > SD_OPS_OWN || R >= a.own_ids) {
+        uint32_t base = (R - a.own_base) * SD_OPS_OWN;
+        if (nops > SD_OPS_OWN || R < a.own_base || R - a.own_base >= a.own_ids) {
             if (lane == 0) base = a.own_ids * SD_OPS_OWN + atomicAdd(a.op_count, (uint32_t)nops);
             base = (uint32_t)__shfl((int)base, 0);
         }

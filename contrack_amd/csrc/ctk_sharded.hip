@@ -284,6 +284,147 @@ __global__ void k_rs_labels_sh(ResolveDev r, const int32_t *__restrict__ st, uin
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// X5 on the device (seam merges, contrack.py:753-763).  The clusters of labels that never leave the shard are driven by
+// k_seam_driver exactly as in the one-call pass -- labels are the GLOBAL ids here, the label-indexed tables cover all NL of them --
+// without the host: no synchronisation between the boundary resolution and the end of the pass.  Clusters that hold a label
+// reaching a shard boundary ("shared") are packed by the device, all-gathered, and driven on every rank's HOST from the gathered
+// records while its GPU drives the local clusters.
+// ------------------------------------------------------------------------------------------------
+struct ShSeamTabs {
+    uint8_t *mark, *cl_shared, *cl_sent;
+    uint32_t *dmap, *cl_parent, *cl_nops;
+    int32_t *op_first, *cl_tmin, *cl_tmax, *lbox, *ext;
+};
+// label-indexed tables [0, n) with n = NL + 2, time extents [0, NL], the write-stage counters
+__global__ void k_sh_seam_init(ShSeamTabs tb, int64_t n, int64_t n_labels, uint32_t *__restrict__ counters, uint32_t *__restrict__ scal /* [4] */)
+{
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = i0; i < n; i += st) {
+        tb.mark[i] = 0; tb.cl_shared[i] = 0; tb.cl_sent[i] = 0; tb.dmap[i] = 0u; tb.op_first[i] = -1;
+        tb.cl_parent[i] = (uint32_t)i; tb.cl_nops[i] = 0xffffffffu; tb.cl_tmin[i] = INT32_MAX; tb.cl_tmax[i] = -1;
+        int32_t *b = tb.lbox + 6 * i;
+        b[0] = INT32_MAX; b[1] = -1; b[2] = INT32_MAX; b[3] = -1; b[4] = INT32_MAX; b[5] = -1;
+    }
+    for (int64_t i = i0; i <= n_labels; i += st) { tb.ext[i] = INT32_MAX; tb.ext[n_labels + 1 + i] = INT32_MIN; }
+    for (int64_t i = i0; i < CTK_ZF_SLOTS; i += st) ctk_zf_reset(counters, i);
+    if (i0 == 0) {
+        counters[CTK_CNT_WROTE_ZERO] = 0; counters[CTK_CNT_ALIVE] = 0; counters[CTK_CNT_TICKET] = 0; counters[CTK_CNT_NOPS] = 0;
+        scal[0] = 0; scal[1] = 0; scal[2] = 0; scal[3] = 0;
+    }
+}
+// a cluster that holds a label reaching a shard boundary is shared (st: the staging block of k_rs_labels_sh, whose last list
+// holds those labels)
+__global__ void k_sh_shared_mark(ResolveDev r, const int32_t *__restrict__ st, uint32_t *__restrict__ cl_parent, uint8_t *__restrict__ cl_shared)
+{
+    const uint32_t nh = r.nh_ptr ? *r.nh_ptr : 0u;
+    const int32_t nA = st[2], nmark = st[3];
+    const int32_t *ml = st + 4 + 2 * nA + nh;
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nmark; i += gridDim.x * blockDim.x) cl_shared[gfind(cl_parent, (uint32_t)ml[i])] = 1;
+}
+// The shared clusters' group records (in (t, y) order) and labels (with this shard's part of their boxes) -> one payload of the
+// X5 all-gather: [SeamHeader][CtkCand recs[capC]][{label, box[6]} labs[capD]].  The header carries the true counts: when any
+// rank's exceed the capacities, everybody enlarges them and the exchange is repeated.  ONE workgroup (the order matters).
+// scal[0] = group records of the shard in all (statistics).
+struct ShSeamHeader { uint32_t ncand, nlab, pad0, pad1; };
+__global__ __launch_bounds__(1024) void k_sh_pack_shared(ResolveDev r, SeamDev a, const int32_t *__restrict__ st, uint8_t *__restrict__ cl_sent, uint32_t capC,
+                                                         uint32_t capD, unsigned char *__restrict__ out, uint32_t *__restrict__ toff /* [T] scratch */,
+                                                         uint32_t *__restrict__ scal, int redo /* the claims of a first attempt are cleared first */)
+{
+    __shared__ uint32_t sm[17];
+    __shared__ uint32_t nlab_s, nrec_all;
+    const int tid = (int)threadIdx.x;
+    const int64_t T = a.T;
+    const int ny = a.ny;
+    CtkCand *oc = (CtkCand *)(out + sizeof(ShSeamHeader));
+    int32_t *ol = (int32_t *)(out + sizeof(ShSeamHeader) + (size_t)capC * sizeof(CtkCand));
+    if (tid == 0) { nlab_s = 0; nrec_all = 0; }
+    const uint32_t nh = r.nh_ptr ? *r.nh_ptr : 0u;
+    const int32_t nA = st[2], nmark = st[3];
+    const int32_t *ml = st + 4 + 2 * nA + nh;
+    if (redo) {
+        for (int64_t t = tid; t < T; t += 1024) {
+            const uint32_t n = a.rec_cnt[t];
+            for (uint32_t i = 0; i < n; i++) { const CtkCand c = a.recs[t * ny + i]; cl_sent[c.ll] = 0; cl_sent[c.lr] = 0; }
+        }
+        for (int32_t i = tid; i < nmark; i += 1024) cl_sent[ml[i]] = 0;
+    }
+    __syncthreads();
+    uint32_t carry = 0, all = 0;
+    for (int64_t t0 = 0; t0 < T; t0 += 1024) {
+        const int64_t t = t0 + tid;
+        uint32_t cnt = 0;
+        if (t < T) {
+            const uint32_t n = a.rec_cnt[t];
+            all += n;
+            for (uint32_t i = 0; i < n; i++) cnt += a.cl_shared[a.rec_root[t * ny + i]] ? 1u : 0u;
+        }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(cnt, sm, &tot);
+        if (t < T) toff[t] = carry + ex;
+        carry += tot;
+    }
+    all = wave_sum_u32(all);
+    if ((tid & 63) == 0 && all) atomicAdd(&nrec_all, all);
+    __syncthreads();
+    auto send_label = [&](int32_t l) {
+        // one claim per label: the byte is set by whoever comes first (a byte-wide atomic OR through the containing word)
+        uint32_t *w = (uint32_t *)(cl_sent + ((size_t)l & ~(size_t)3));
+        const uint32_t bit = 1u << (8 * ((uint32_t)l & 3u));
+        if (atomicOr(w, bit) & bit) return;
+        const uint32_t idx = atomicAdd(&nlab_s, 1u);
+        if (idx < capD) {
+            int32_t *q = ol + 7 * (size_t)idx;
+            q[0] = l;
+            const int32_t *b = a.lbox + 6 * (int64_t)l;
+#pragma unroll
+            for (int k = 0; k < 6; k++) q[1 + k] = b[k];
+        }
+    };
+    for (int64_t t = tid; t < T; t += 1024) {
+        const uint32_t n = a.rec_cnt[t];
+        uint32_t j = toff[t];
+        for (uint32_t i = 0; i < n; i++) {
+            if (!a.cl_shared[a.rec_root[t * ny + i]]) continue;
+            const CtkCand c = a.recs[t * ny + i];
+            if (j < capC) oc[j] = c;
+            j++;
+            send_label(c.ll);
+            if (c.lr != c.ll) send_label(c.lr);
+        }
+    }
+    // labels that reach a shard boundary travel even without a record here: another shard may hold the rows, and their boxes
+    // (find_objects over ALL timesteps, contrack.py:753) are the union of every shard's part
+    for (int32_t i = tid; i < nmark; i += 1024) send_label(ml[i]);
+    __syncthreads();
+    if (tid == 0) {
+        ShSeamHeader hd; hd.ncand = carry; hd.nlab = nlab_s; hd.pad0 = 0; hd.pad1 = 0;
+        *(ShSeamHeader *)out = hd;
+        scal[0] = nrec_all;
+    }
+}
+// gathered payloads -> pinned host memory, then a stamp the host polls for (an event or a stream drain would also wait for the
+// kernels enqueued BEHIND this one: the local clusters are driven while the host works on the shared ones).  One workgroup.
+__global__ __launch_bounds__(1024) void k_sh_copy_stamp(const uint4 *__restrict__ src, uint4 *__restrict__ dst_pinned, size_t n16, uint32_t *__restrict__ word,
+                                                        uint32_t stamp)
+{
+    for (size_t i = threadIdx.x; i < n16; i += 1024) dst_pinned[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(word, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// the shared clusters' operations (driven on the host, identical on every rank) join the device's: staging block in pinned host
+// memory [CtkOp ops[ng]] [int32 next[ng]] [int32 label[ng], nf used] [int32 first[ng], nf used], placed at slot `base` of the op arrays
+__global__ void k_sh_ops_append(const int32_t *__restrict__ staging, int32_t ng, int32_t nf, uint32_t base, CtkOp *__restrict__ ops, int32_t *__restrict__ op_next,
+                                int32_t *__restrict__ op_first)
+{
+    const int32_t *sn = staging + 8 * (int64_t)ng, *sl = sn + ng, *sf = sl + ng;      // (CtkOp = 8 words)
+    int32_t *dst = (int32_t *)(ops + base);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 8 * (int64_t)ng; i += (int64_t)gridDim.x * blockDim.x) dst[i] = staging[i];
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ng; i += gridDim.x * blockDim.x) op_next[base + i] = sn[i] < 0 ? -1 : (int32_t)(base + (uint32_t)sn[i]);
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += gridDim.x * blockDim.x) op_first[sl[i]] = (int32_t)(base + (uint32_t)sf[i]);
+}
+
 // X6 (+ X7): time extents of the ids shared between shards, and the counts.  Payload of one rank:
 //   [alive_own, zero_seen][lo, hi of every shared id]
 // alive_own = ids numbered by THIS shard (l0 < id <= l1) that no other shard knows (not in elist), are present and survive
@@ -336,14 +477,19 @@ __global__ __launch_bounds__(256) void k_sh_pack_ext(const int32_t *__restrict__
         last = atomicAdd(&counters[CTK_CNT_TICKET], 1u) == gridDim.x - 1;
         if (last) {
             out[0] = (int32_t)__hip_atomic_load(&counters[CTK_CNT_ALIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out[1] = (int32_t)__hip_atomic_load(&counters[CTK_CNT_WROTE_ZERO], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // bit 0: a background pixel was seen; bit 1: this rank's device seam driver gave up (cluster / op slots beyond its tables)
+            out[1] = (int32_t)((__hip_atomic_load(&counters[CTK_CNT_WROTE_ZERO], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u) |
+                               ((__hip_atomic_load(&counters[CTK_CNT_POISON], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (CTK_POISON_OPCAP | CTK_POISON_CLUSTER)) ? 2u : 0u));
         }
     }
 }
 // after the all-gather: extents of the shared ids = min / max over the shards; the job's count = everybody's own ids + the shared
 // ids that survive; both go straight into pinned host memory (mail[0] = surviving ids, mail[1] = some rank has seen a 0)
 __global__ __launch_bounds__(1024) void k_sh_reduce_ext(const int32_t *__restrict__ elist, int32_t ne, const int32_t *__restrict__ gathered, int world,
-                                                        int32_t *__restrict__ ext, int64_t n_labels, int persistence, uint32_t *__restrict__ mail)
+                                                        int32_t *__restrict__ ext, int64_t n_labels, int persistence, uint32_t *__restrict__ mail,
+                                                        const uint32_t *__restrict__ counters = nullptr, const uint32_t *__restrict__ scal = nullptr,
+                                                        const uint32_t *__restrict__ nc_ptr = nullptr, const uint32_t *__restrict__ t_nops = nullptr,
+                                                        const uint32_t *__restrict__ rec_cnt = nullptr, int64_t T = 0)
 {
     const size_t sw = 2 + 2 * (size_t)ne;                                  // words of one rank's payload
     uint32_t v = 0;
@@ -359,15 +505,30 @@ __global__ __launch_bounds__(1024) void k_sh_reduce_ext(const int32_t *__restric
     }
     uint32_t own = 0, z = 0;
     for (int q = (int)threadIdx.x; q < world; q += 1024) { own += (uint32_t)gathered[(size_t)q * sw]; z |= (uint32_t)gathered[(size_t)q * sw + 1]; }
+    // (statistics of the device seam driver: operations and group records of this shard)
+    __shared__ uint32_t s_ops, s_recs;
+    if (threadIdx.x == 0) { s_ops = 0; s_recs = 0; }
+    __syncthreads();
+    if (t_nops) {
+        uint32_t a = 0, b = 0;
+        for (int64_t t = threadIdx.x; t < T; t += 1024) { a += t_nops[t]; b += rec_cnt[t]; }
+        a = wave_sum_u32(a); b = wave_sum_u32(b);
+        if (lane_id() == 0) { if (a) atomicAdd(&s_ops, a); if (b) atomicAdd(&s_recs, b); }
+    }
     __shared__ uint32_t sm[16], sz[16];
     const uint32_t sv = wave_sum_u32(v + own);
-    const bool zany = __ballot(z != 0u) != 0ull;
-    if (lane_id() == 0) { sm[threadIdx.x >> 6] = sv; sz[threadIdx.x >> 6] = zany ? 1u : 0u; }
+    const bool zany = __ballot((z & 1u) != 0u) != 0ull, pany = __ballot((z & 2u) != 0u) != 0ull;
+    if (lane_id() == 0) { sm[threadIdx.x >> 6] = sv; sz[threadIdx.x >> 6] = (zany ? 1u : 0u) | (pany ? 2u : 0u); }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t tot = 0, zz = 0;
         for (int i = 0; i < 16; i++) { tot += sm[i]; zz |= sz[i]; }
-        mail[0] = tot; mail[1] = zz;
+        // [0] surviving ids of the job, [1] some rank has seen a background pixel, [2] some rank's device seam driver gave up,
+        // [3] this rank's poison bits, [4] its operations, [5] its group records
+        mail[0] = tot; mail[1] = zz & 1u; mail[2] = (zz >> 1) & 1u;
+        // [6] its components, [7] / [8] its ungrouped / counted co-occurrence records
+        mail[3] = counters ? counters[CTK_CNT_POISON] : 0u; mail[4] = t_nops ? s_ops : 0u; mail[5] = t_nops ? s_recs : (scal ? scal[0] : 0u);
+        mail[6] = nc_ptr ? *nc_ptr : 0u; mail[7] = counters ? counters[CTK_CNT_UPAIRS] : 0u; mail[8] = counters ? counters[CTK_CNT_PAIRS] : 0u;
     }
 }
 // ids numbered by THIS shard (l0 < id <= l1) that are present and survive persistence; + "a zero was written"
@@ -506,6 +667,185 @@ static int g_shdbg = -1;
 #define SHDBG(name) do { if (g_shdbg < 0) g_shdbg = getenv("CTK_SHDEBUG") ? 1 : 0; if (g_shdbg) { hipError_t e_ = hipStreamSynchronize(s); \
     fprintf(stderr, "[shard %d/%d] %-24s %s\n", rank, world, name, hipGetErrorString(e_)); } } while (0)
 
+// X5 + X6 with the seam merges of the shard's own clusters driven on the DEVICE (see k_sh_seam_init).  Everything up to the extent
+// exchange is enqueued here; the only wait is for the gathered shared clusters, and it ends as soon as their copy has reached
+// pinned memory -- k_seam_driver, enqueued behind that copy, runs underneath the host's work on them.  mail2[64..69] are written
+// by k_sh_reduce_ext at the end (the caller waits for the stream after the write pass).
+#define CTK_SH_GOPS 16384            // op slots reserved for the shared clusters' operations (more: every rank falls back alike)
+static int sharded_seam_device(ctk_handle *h, ctk_comm *c, ShardScratch &S, ResolveDev &r, const ResolveIn &in, ResolvePlan &pl, int64_t T, int64_t t_begin,
+                               int ny, int nx, int W, int persistence, int64_t NL, int64_t lab0, int64_t lab1, bool any_boundary, uint32_t hint_c,
+                               uint32_t hint_d, uint32_t *mail2, bool *too_many_shared_ops)
+{
+    hipStream_t s = h->stream;
+    const int rank = c->rank, world = c->world;
+    (void)rank; (void)W;
+    *too_many_shared_ops = false;
+    const size_t NT = (size_t)NL + 2;
+    CTKCHK(ensure(h, h->rv_mark, NT)); CTKCHK(ensure(h, h->rv_dmap, NT * 4)); CTKCHK(ensure(h, h->op_first, NT * 4));
+    CTKCHK(ensure(h, h->ext, ((size_t)NL + 1) * 8));
+    CTKCHK(ensure(h, h->sd_parent, NT * 4)); CTKCHK(ensure(h, h->sd_tmin, NT * 4)); CTKCHK(ensure(h, h->sd_tmax, NT * 4));
+    CTKCHK(ensure(h, h->sd_nops, NT * 4)); CTKCHK(ensure(h, h->sd_lbox, NT * 24));
+    CTKCHK(ensure(h, h->sh_cl_shared, NT + 8)); CTKCHK(ensure(h, h->sh_cl_sent, NT + 8));
+    CTKCHK(ensure(h, h->sd_root, (size_t)std::max<int64_t>(T * ny, 1) * 4));
+    CTKCHK(ensure(h, h->seam_off, (size_t)(T + 1) * 4));
+    r.mark = P<uint8_t>(h->rv_mark); r.dmap = P<uint32_t>(h->rv_dmap); r.op_first = P<int32_t>(h->op_first);
+    // op slots: SD_OPS_OWN per id this shard numbered, a shared tail, and a reserve for the shared clusters' operations
+    const uint32_t own_ids = (uint32_t)std::max<int64_t>(lab1 - lab0, 0);
+    const uint64_t cap_dev = (uint64_t)own_ids * SD_OPS_OWN + h->op_cap_hint, cap_all = cap_dev + CTK_SH_GOPS;
+    if (cap_all > 0x7ffffff0ull) return ctk_set_error(CTK_E_RANGE, "ctk_track_sharded: more op slots than 2^31");
+    CTKCHK(ensure(h, h->ops, (size_t)cap_all * (sizeof(CtkOp) + 4)));
+    uint32_t *scal = P<uint32_t>(h->rv_scalars) + 8;
+    SeamDev sd;
+    sd.dummy = nullptr;
+    sd.cl_parent = P<uint32_t>(h->sd_parent); sd.cl_tmin = P<int32_t>(h->sd_tmin); sd.cl_tmax = P<int32_t>(h->sd_tmax); sd.cl_nops = P<uint32_t>(h->sd_nops);
+    sd.lbox = P<int32_t>(h->sd_lbox); sd.mark = P<uint8_t>(h->rv_mark);
+    sd.rec_root = P<uint32_t>(h->sd_root); sd.recs = P<CtkCand>(h->rv_cand_scratch); sd.rec_cnt = P<uint32_t>(h->rv_cand_cnt);
+    sd.t_nops = P<uint32_t>(h->rv_cand_off);
+    sd.ops = P<CtkOp>(h->ops); sd.op_next = (int32_t *)(P<CtkOp>(h->ops) + cap_all); sd.op_first = r.op_first;
+    sd.op_count = P<uint32_t>(h->counters) + CTK_CNT_NOPS; sd.op_cap = (uint32_t)cap_dev; sd.own_ids = own_ids; sd.own_base = (uint32_t)(lab0 + 1);
+    sd.cl_shared = any_boundary ? P<uint8_t>(h->sh_cl_shared) : nullptr;
+    sd.poison = P<uint32_t>(h->counters) + CTK_CNT_POISON; sd.ny = ny; sd.nx = nx; sd.T = T;
+    sd.dbg = 0;
+    sd.lab_cap = h->debug_sd_lab ? std::min(h->debug_sd_lab, SD_LAB) : SD_LAB; sd.ops_cap = h->debug_sd_ops ? std::min(h->debug_sd_ops, 64) : 64;
+    h->d_op_next = sd.op_next;
+    h->nops = 1;                                                       // (nonzero: the folds look at the chains)
+    const int32_t *st = (const int32_t *)h->h_lab;
+    {
+        Timer tm(h, CTK_K_RESOLVE);
+        ShSeamTabs tb;
+        tb.mark = P<uint8_t>(h->rv_mark); tb.cl_shared = P<uint8_t>(h->sh_cl_shared); tb.cl_sent = P<uint8_t>(h->sh_cl_sent);
+        tb.dmap = P<uint32_t>(h->rv_dmap); tb.cl_parent = sd.cl_parent; tb.cl_nops = sd.cl_nops; tb.op_first = r.op_first;
+        tb.cl_tmin = sd.cl_tmin; tb.cl_tmax = sd.cl_tmax; tb.lbox = sd.lbox; tb.ext = P<int32_t>(h->ext);
+        k_sh_seam_init<<<(int)std::min<size_t>((NT + 255) / 256, 2048), 256, 0, s>>>(tb, (int64_t)NT, NL, P<uint32_t>(h->counters), scal);
+        k_rs_labels_sh<<<pl.gc, 256, 0, s>>>(r, st, P<uint8_t>(h->rv_mark));
+        k_fz_mark<<<(int)T, 64, 0, s>>>(r, sd, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res));
+        k_fz_groups<<<(int)((T + FZ_TW - 1) / FZ_TW), 64 * FZ_TW, 0, s>>>(r, sd, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), t_begin);
+        HIPCHK(hipGetLastError());
+    }
+    auto launch_driver = [&]() -> int {
+        Timer tm(h, CTK_K_RESOLVE);
+        k_seam_driver<<<(int)std::min<int64_t>(T, 65536), 64, 0, s>>>(sd, t_begin);
+        HIPCHK(hipGetLastError());
+        return CTK_OK;
+    };
+    S.glabel.clear(); S.gbox.clear(); S.gcand.clear(); S.ops_g.clear();
+    if (!any_boundary) {
+        CTKCHK(launch_driver());
+        if (h->debug_fail_stage == 5) { h->debug_fail_stage = 0; return ctk_set_error(CTK_E_INTERNAL, "injected failure at stage 5 (test hook)"); }
+    } else {
+        k_sh_shared_mark<<<8, 256, 0, s>>>(r, st, sd.cl_parent, P<uint8_t>(h->sh_cl_shared));
+        HIPCHK(hipGetLastError());
+        uint32_t capC = std::max<uint32_t>(hint_c, 256), capD = (std::max<uint32_t>(hint_d, 256) + 3u) & ~3u;
+        size_t sslot = 0;
+        bool driver_launched = false;
+        for (int redo = 0;; redo = 1) {
+            sslot = sizeof(ShSeamHeader) + (size_t)capC * sizeof(CtkCand) + (size_t)capD * 28;      // (a multiple of 16: capD is one of 4)
+            CTKCHK(ensure_host(&h->h_seam, &h->h_seam_cap, sslot * (size_t)(world + 1), true));
+            CTKCHK(ensure(h, h->sh_send, sslot));
+            CTKCHK(ensure(h, h->sh_recv, sslot * (size_t)world));
+            unsigned char *sb = (unsigned char *)h->h_seam;
+            const uint32_t stamp = (uint32_t)((h->pass_no << 4) | (uint32_t)(redo ? 2 + (capC & 7u) : 1)) | 0x80000000u;
+            mail2[100] = 0;
+            k_sh_pack_shared<<<1, 1024, 0, s>>>(r, sd, st, P<uint8_t>(h->sh_cl_sent), capC, capD, (unsigned char *)h->sh_send.p, P<uint32_t>(h->seam_off), scal, redo);
+            HIPCHK(hipGetLastError());
+            CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, sslot));
+            k_sh_copy_stamp<<<1, 1024, 0, s>>>((const uint4 *)h->sh_recv.p, (uint4 *)(sb + sslot), sslot * (size_t)world / 16, mail2 + 100, stamp);
+            HIPCHK(hipGetLastError());
+            if (!driver_launched) { driver_launched = true; CTKCHK(launch_driver()); }      // runs while the host works on the shared clusters
+            CTKCHK(ctk_comm_wait_word(c, mail2 + 100, stamp));
+            uint32_t mc = 0, md = 0;
+            for (int q = 0; q < world; q++) {
+                const ShSeamHeader *qh = (const ShSeamHeader *)(sb + sslot * (size_t)(q + 1));
+                mc = std::max(mc, qh->ncand); md = std::max(md, qh->nlab);
+            }
+            if (mc <= capC && md <= capD) break;
+            capC = std::max(capC, mc + mc / 2 + 64); capD = (std::max(capD, md + md / 2 + 64) + 3u) & ~3u;       // same on every rank
+        }
+        h->sh_capC = capC; h->sh_capD = capD;
+        if (h->debug_fail_stage == 5) { h->debug_fail_stage = 0; return ctk_set_error(CTK_E_INTERNAL, "injected failure at stage 5 (test hook)"); }
+        // merged table of the shared labels (boxes: union over the shards) and the shared candidate groups in (t, y) order
+        const double t_host = now_ms();
+        const unsigned char *gb = (const unsigned char *)h->h_seam + sslot;
+        std::vector<std::pair<int32_t, int32_t>> &tmp = h->sh_pairs;      // (label, position) for the merge
+        tmp.clear();
+        for (int q = 0; q < world; q++) {
+            const unsigned char *p = gb + sslot * (size_t)q;
+            const ShSeamHeader *qh = (const ShSeamHeader *)p;
+            const int32_t *ql = (const int32_t *)(p + sizeof(ShSeamHeader) + (size_t)capC * sizeof(CtkCand));
+            for (uint32_t i = 0; i < qh->nlab; i++) tmp.emplace_back(ql[7 * i], (int32_t)(q * (int64_t)capD + i));
+        }
+        std::sort(tmp.begin(), tmp.end());
+        for (size_t i = 0; i < tmp.size(); i++) {
+            const int q = tmp[i].second / (int32_t)capD, k = tmp[i].second % (int32_t)capD;
+            const int32_t *ql = (const int32_t *)(gb + sslot * (size_t)q + sizeof(ShSeamHeader) + (size_t)capC * sizeof(CtkCand)) + 7 * (size_t)k;
+            if (S.glabel.empty() || S.glabel.back() != tmp[i].first) {
+                S.glabel.push_back(tmp[i].first);
+                S.gbox.insert(S.gbox.end(), ql + 1, ql + 7);
+            } else {
+                int32_t *b = &S.gbox[S.gbox.size() - 6];
+                b[0] = std::min(b[0], ql[1]); b[1] = std::max(b[1], ql[2]); b[2] = std::min(b[2], ql[3]);
+                b[3] = std::max(b[3], ql[4]); b[4] = std::min(b[4], ql[5]); b[5] = std::max(b[5], ql[6]);
+            }
+        }
+        auto gid = [&](int32_t l) { return (int32_t)(std::lower_bound(S.glabel.begin(), S.glabel.end(), l) - S.glabel.begin()); };
+        for (int q = 0; q < world; q++) {                                 // rank order = time order
+            const unsigned char *p = gb + sslot * (size_t)q;
+            const ShSeamHeader *qh = (const ShSeamHeader *)p;
+            const CtkCand *qc = (const CtkCand *)(p + sizeof(ShSeamHeader));
+            for (uint32_t i = 0; i < qh->ncand; i++) { CtkCand v = qc[i]; v.ll = gid(v.ll); v.lr = gid(v.lr); S.gcand.push_back(v); }
+        }
+        h->sd_glob.run(S.gcand.data(), (int64_t)S.gcand.size(), S.glabel.data(), S.gbox.data(), (int64_t)S.glabel.size(), nx, S.ops_g);
+        h->ms[CTK_T_HOST_RESOLVE] += now_ms() - t_host;
+    }
+    h->stats[9] = h->sd_glob.loop_ns; h->stats[10] = h->sd_glob.nfold;
+    h->stats[CTK_S_SHARED_ROWS] = (int64_t)S.gcand.size();
+    // ids whose time extent is shared between shards: everything that reaches a boundary + the shared seam labels
+    S.elist = S.bout.crossing;
+    S.elist.insert(S.elist.end(), S.glabel.begin(), S.glabel.end());
+    std::sort(S.elist.begin(), S.elist.end());
+    S.elist.erase(std::unique(S.elist.begin(), S.elist.end()), S.elist.end());
+    const int32_t ne = (int32_t)S.elist.size();
+    const int64_t ng = (int64_t)S.ops_g.size();
+    if (ng > CTK_SH_GOPS) { *too_many_shared_ops = true; return CTK_OK; }      // (the same list on every rank: everybody takes the host-driven form)
+    // the shared clusters' operations + the list of shared ids -> pinned staging read by the kernels
+    const size_t bytes = (size_t)std::max<int64_t>(ng, 1) * (sizeof(CtkOp) + 4 + 8) + (size_t)ne * 4 + 64;
+    CTKCHK(ensure_host(&h->h_ops, &h->h_ops_cap, bytes));
+    CtkOp *s_ops = (CtkOp *)h->h_ops;
+    int32_t *s_next = (int32_t *)(s_ops + ng), *s_label = s_next + ng, *s_first = s_label + ng, *s_el = s_first + ng;
+    int32_t nf = 0;
+    if (ng) memcpy(s_ops, S.ops_g.data(), (size_t)ng * sizeof(CtkOp));
+    for (int64_t i = 0; i < ng; i++) s_next[i] = h->sd_glob.next[(size_t)i];
+    if (ng)
+        for (size_t d = 0; d < S.glabel.size(); d++)
+            if (h->sd_glob.first[d] >= 0) { s_label[nf] = S.glabel[d]; s_first[nf] = h->sd_glob.first[d]; nf++; }
+    if (ne) memcpy(s_el, S.elist.data(), (size_t)ne * 4);
+    h->stats[CTK_S_OPS] = ng;                                          // (+ the device's own, added when the pass has ended)
+    if (ng) {
+        k_sh_ops_append<<<(int)std::min<int64_t>((ng * 8 + 255) / 256, 256), 256, 0, s>>>((const int32_t *)h->h_ops, (int32_t)ng, nf, (uint32_t)cap_dev, sd.ops, sd.op_next, r.op_first);
+        HIPCHK(hipGetLastError());
+    }
+    h->state = ST_TABLES;
+    CTKCHK(launch_extents(h, true, true));                             // + the final id of every own component
+    {
+        const size_t eslot = 8 + (size_t)ne * 8;
+        CTKCHK(ensure(h, h->sh_send, eslot));
+        CTKCHK(ensure(h, h->sh_recv, eslot * (size_t)world));
+        CTKCHK(ensure(h, h->sh_elist, (size_t)std::max(ne, 1) * 4));
+        const int64_t nsample = std::min<int64_t>((int64_t)T * ny * h->W, 16384);
+        const uint64_t last_full = (nx & 63) ? ((1ull << (nx & 63)) - 1ull) : ~0ull;
+        const int pe_lds = h->debug_mail_d ? (int)std::min<uint32_t>(h->debug_mail_d, SH_PE_LDS) : SH_PE_LDS;      // (ctk_debug_set_mailbox)
+        k_sh_pack_ext<<<ne <= pe_lds ? SH_PE_BLOCKS : 1, 256, 0, s>>>(s_el, ne, P<int32_t>(h->ext), NL, lab0, lab1, persistence, P<uint64_t>(h->mask), nsample, h->W,
+                                                                      last_full, P<int32_t>(h->sh_elist), P<int32_t>(h->sh_send), P<uint32_t>(h->counters), pe_lds);
+        HIPCHK(hipGetLastError());
+        CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, eslot));
+        k_sh_reduce_ext<<<1, 1024, 0, s>>>(P<int32_t>(h->sh_elist), ne, P<int32_t>(h->sh_recv), world, P<int32_t>(h->ext), NL, persistence, mail2 + 64,
+                                           P<uint32_t>(h->counters), scal, in.cprefix + T, sd.t_nops, sd.rec_cnt, T);
+        HIPCHK(hipGetLastError());
+    }
+    h->state = ST_EXTENTS;
+    return CTK_OK;
+}
+
 static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, bool f64, int64_t T, int64_t t_begin, int64_t T_total, int ny, int nx,
                               const double *thr, int cmp_op, const float *wrow, double overlap, int persistence, int twosided, int32_t *flag_dev,
                               int64_t *n_tracked)
@@ -612,6 +952,8 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     CTKCHK(rs_prepare(h, in, overlap, twosided, pl));
     ResolveDev &r = pl.r;
     r.nh_ptr = nh_ptr;
+    CTKCHK(ensure(h, h->rv_lab_root, R * 4));
+    r.lab_root = P<int32_t>(h->rv_lab_root);            // (k_rs_roots keeps a copy of the root indices: a second attempt of X5 starts from them)
     r.t_lo = has_prev ? 0 : 1;                       // global timesteps 1 .. T_total-2 are filtered
     r.t_hi = has_next ? (int)T - 1 : (int)T - 2;
     const uint32_t AMB_CAP = 1u << 16;
@@ -841,6 +1183,34 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         if (!A.empty()) { memcpy(p, A.data(), A.size() * 4); p += A.size(); memcpy(p, AL.data(), A.size() * 4); p += A.size(); }
         if (!HL.empty()) { memcpy(p, HL.data(), HL.size() * 4); p += HL.size(); }
         if (!S.marks.empty()) memcpy(p, S.marks.data(), S.marks.size() * 4);
+    }
+    // ---- X5 .. X7.  First attempt: seam merges of the shard's own clusters ON THE DEVICE (k_seam_driver, as in the one-call pass),
+    // nothing between the boundary resolution and the end of the pass waits for the host; only the clusters shared between shards
+    // -- gathered records, driven identically on every rank -- pass through it, underneath the device's work on the local ones.
+    // A cluster beyond the device driver's tables (or beyond the op slots) poisons the attempt; the flag travels with the extent
+    // exchange, so EVERY rank repeats X5 .. X7 on the host-driven form below (second attempt), and the grid stays there.
+    const bool any_boundary_label_all = [&]() {
+        if (ctk_env().sh_force_split) return true;        // (experiments: the split / exchange even without shared groups; every rank or none)
+        for (int q = 0; q < world; q++) {
+            for (int32_t l : S.bout.halo_label[(size_t)q]) if (l > 0) return true;
+            if (q + 1 < world) for (int32_t l : S.bout.last_label[(size_t)q]) if (l > 0) return true;
+        }
+        return false;
+    }();
+    int64_t alive = 0;
+    bool zero = false;
+    for (int attempt = 0;; attempt++) {
+    const bool dev_seam = attempt == 0 && !ctk_env().sh_host_seam && !(h->sh_dev_off_ny == ny && h->sh_dev_off_nx == nx) && T <= 65536 &&
+                          NL + 2 < 0x7fffffffll;
+    if (dev_seam) {
+        bool too_many = false;
+        CTKCHK(sharded_seam_device(h, c, S, r, in, pl, T, t_begin, ny, nx, W, persistence, NL, lab0, lab1, any_boundary_label_all, hint_c, hint_d, mail2, &too_many));
+        if (too_many) { h->stats[CTK_S_HOST_REASON] |= 16; continue; }       // (decided alike on every rank, nothing of X6 launched yet)
+    } else {
+    if (attempt > 0) {
+        // the first attempt turned the root indices in r.lab into labels and handed out dense ids to the boundary labels: start over
+        HIPCHK(hipMemcpyAsync(r.lab, r.lab_root, R * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemsetAsync(r.dcount, 0, 4, s));
     }
     // label-indexed tables are indexed by GLOBAL ids here
     CTKCHK(ensure(h, h->rv_mark, (size_t)NL + 2));
@@ -1079,6 +1449,8 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         h->state = ST_EXTENTS;
     }
 
+    }   // (host-driven X5 / X6)
+
     // ---- persistence + write ----------------------------------------------------------------------------------------
     int cv_rows = 0;
     int32_t *cv = chunk_vals_for(h, flag_dev, &cv_rows);
@@ -1097,8 +1469,8 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     // ---- counts: written into pinned memory by k_sh_reduce_ext.  A 0 in the output: certain when some rank has seen a background
     // pixel; otherwise (slabs that are foreground everywhere) the write pass' own flags are exchanged -- same decision on every rank
     CTKCHK(ctk_comm_wait(c));
-    int64_t alive = mail2[64];
-    bool zero = mail2[65] != 0;
+    alive = mail2[64];
+    zero = mail2[65] != 0;
     if (!zero) {
         CTKCHK(ensure(h, h->sh_send, 64));
         CTKCHK(ensure(h, h->sh_recv, 64 * (size_t)world));
@@ -1109,6 +1481,24 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         CTKCHK(ctk_comm_wait(c));
         for (int q = 0; q < world; q++) zero = zero || mail2[128 + 2 * q + 1] != 0;
     }
+    if (dev_seam && mail2[66]) {
+        // some rank's device driver gave up (every rank reads the same gathered word): the whole of X5 .. X7 again, host-driven
+        const uint32_t pz = mail2[67];                                    // this rank's own poison bits
+        if (pz & CTK_POISON_OPCAP) h->op_cap_hint = std::max<uint32_t>(h->op_cap_hint * 2, mail2[68] + mail2[68] / 2 + 1024);
+        if (pz & CTK_POISON_CLUSTER) { h->sh_dev_off_ny = ny; h->sh_dev_off_nx = nx; }
+        h->stats[CTK_S_HOST_REASON] |= 16;
+        continue;
+    }
+    if (dev_seam) {
+        h->stats[CTK_S_OPS] += (int64_t)mail2[68]; h->stats[CTK_S_SEAM_ROWS] = (int64_t)mail2[69]; h->stats[CTK_S_LABELS] = NL;
+        h->stats[CTK_S_COMPONENTS] = (int64_t)mail2[70]; h->stats[CTK_S_UPAIRS] = (int64_t)mail2[71];
+        h->stats[CTK_S_PAIRS] = (int64_t)(pslot ? mail2[CTK_SHM_NPAIRS] : mail2[72]) + mail2[71];
+        h->total_comps = mail2[70];
+        h->op_cap_hint = std::max<uint32_t>(h->op_cap_hint, mail2[68] * 2 + 1024);
+    }
+    h->stats[CTK_S_FUSED] = dev_seam ? 1 : 0;
+    break;
+    }   // attempts
     h->last_alive = alive;
     if (n_tracked) *n_tracked = alive + (zero ? 1 : 0) - 1;              // len(np.unique(flag)) - 1, contrack.py:793
     collect_event_times(h);

@@ -191,6 +191,33 @@ def test_staged_import_between_two_first_shard_passes_on_one_handle(handles):
         assert np.array_equal(f, g["flag"]) and n == want_n, ("rank 0 of two", rep)
 
 
+def test_device_seam_driver_on_shards_and_its_collective_fallback(handles):
+    """the shard path drives the seam merges of its own clusters on the device (no host hand-off behind the boundary resolution) and
+    only the clusters shared between shards on the host; a rank whose device driver cannot hold a cluster (tables cut down by the
+    test hook) says so through the extent exchange and EVERY rank repeats X5 .. X7 host-driven -- same result"""
+    from contrack_amd.contrack import row_weights
+    T, ny, nx = 400, 91, 180
+    anom = synth.smooth_field(T, ny, nx, seed=12)
+    lat, _ = synth.grid(ny, nx)
+    wrow = row_weights(lat, np.float32(2.0), np.float32(2.0))
+    thr = np.full(T, 120.0)
+    want, nw = handles[6].track(anom, thr, 0, wrow, 0.5, 3, True)
+    assert handles[6].stats()["seam_ops"] > 20
+    cuts = [0, 90, 91, 250, T]
+    got, ng, st = sharded_threads(handles[:4], anom, thr, 0, wrow, 0.5, 3, True, cuts)
+    assert np.array_equal(got, want) and ng == nw
+    assert all(s["fused_pass"] == 1 and not (s["off_fused_path_reason"] & 16) for s in st), st
+    try:
+        handles[2].debug_set_seam_caps(1, 1)                   # rank 2's device driver holds one label per cluster: every real cluster poisons it
+        got, ng, st = sharded_threads(handles[:4], anom, thr, 0, wrow, 0.5, 3, True, cuts)
+        assert np.array_equal(got, want) and ng == nw
+        assert all(s["fused_pass"] == 0 and (s["off_fused_path_reason"] & 16) for s in st), st
+        got, ng, st = sharded_threads(handles[:4], anom, thr, 0, wrow, 0.5, 3, True, cuts)       # rank 2 stays host-driven on this grid, the others try again
+        assert np.array_equal(got, want) and ng == nw
+    finally:
+        handles[2].debug_set_seam_caps(0, 0)
+
+
 def test_rccl_world_of_one(oracle_lib):
     """the RCCL transport itself (librccl.so dlopen'ed, ncclCommInitRank, ncclAllGather) with one rank: what a one-GPU box can run"""
     g = golden_util.load("busy_s0")
