@@ -191,6 +191,7 @@ struct ctk_handle {
     BouncePool *bounce = nullptr;                  // created on first use
     // time-sharded path (ctk_sharded.hip)
     DevBuf sh_mask_next, sh_send, sh_recv, sh_prev, sh_elist, sh_ovr_slot, sh_ovr_val, sh_amb_list, sh_counts, sh_cl_shared, sh_cl_sent;
+    uint32_t sh_stamp_seq = 0;
     int sh_dev_off_ny = -1, sh_dev_off_nx = -1;   // grid whose clusters did not fit the device seam driver on the time-shard path: host-driven from then on
     struct ShardScratch *shard = nullptr;
     uint32_t *h_mail2 = nullptr;                   // pinned, device-written scalars

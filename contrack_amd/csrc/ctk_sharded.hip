@@ -138,13 +138,15 @@ __global__ void k_sh_pack_keep(ResolveDev r, int it_first, int it_count, uint32_
 #define CTK_SHM_MYFLAGGED 9
 #define CTK_SHM_MAXFLAGGED 10
 #define CTK_SHM_NPAIRS 11
+#define CTK_SHM_STAMP 12         // written last: the host polls for it instead of draining the stream
 __global__ __launch_bounds__(256) void k_sh_unpack_keep(ResolveDev r, const unsigned char *__restrict__ gathered, unsigned char *__restrict__ prev,
                                                         int first_round, int redo, size_t slot, uint32_t capB, int rank, int world, int it_next,
                                                         uint8_t *__restrict__ tdirty, uint32_t *__restrict__ mail,
                                                         // speculative X4: the boundary records travel with the bits (offset bound_off inside a
                                                         // rank's payload, bslot bytes) and go straight into pinned host memory
                                                         size_t bound_off, size_t bslot, uint32_t *__restrict__ bound_pinned,
-                                                        const uint32_t *__restrict__ pair_cnt /* slot mode: grouped records per timestep, else nullptr */)
+                                                        const uint32_t *__restrict__ pair_cnt /* slot mode: grouped records per timestep, else nullptr */,
+                                                        uint32_t stamp)
 {
     if (pair_cnt) {                                             // how many grouped pair records the shard holds (statistics)
         __shared__ uint32_t s_np;
@@ -215,6 +217,10 @@ __global__ __launch_bounds__(256) void k_sh_unpack_keep(ResolveDev r, const unsi
         dother[0] = 0;
         if (s_my_diff && it_next > 0) r.changed[(it_next - 1) * CTK_CHG_SLOTS] = 1u;
     }
+    // everything this kernel wrote into pinned host memory (the scalars above, the boundary records) is complete before the stamp
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&mail[CTK_SHM_STAMP], stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // X4 payload of one rank: [BoundHeader][int32 last[capB]][int32 halo[capB]]  (see boundary_resolve in ctk_seam.h)
@@ -252,8 +258,19 @@ __global__ void k_sh_clear_tables(uint8_t *__restrict__ mark, uint32_t *__restri
 
 // scipy's ids from the local root ranks and the boundary resolution (pinned staging written by the host):
 //   st[0..1] = off (int64), st[2] = nA, st[3] = nmark, then A[nA], Alab[nA], halo_label[nh], mark_labels[nmark]
-__global__ void k_rs_labels_sh(ResolveDev r, const int32_t *__restrict__ st, uint8_t *__restrict__ mark)
+__global__ void k_rs_labels_sh(ResolveDev r, const int32_t *__restrict__ st, uint8_t *__restrict__ mark,
+                               // device seam path: the time extents and the write-stage counters are reset here (k_sh_seam_init's second half)
+                               int32_t *__restrict__ ext = nullptr, int64_t n_labels = 0, uint32_t *__restrict__ counters = nullptr, uint32_t *__restrict__ scal = nullptr)
 {
+    if (ext) {
+        const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stp = (int64_t)gridDim.x * blockDim.x;
+        for (int64_t i = i0; i <= n_labels; i += stp) { ext[i] = INT32_MAX; ext[n_labels + 1 + i] = INT32_MIN; }
+        for (int64_t i = i0; i < CTK_ZF_SLOTS; i += stp) ctk_zf_reset(counters, i);
+        if (i0 == 0) {
+            counters[CTK_CNT_WROTE_ZERO] = 0; counters[CTK_CNT_ALIVE] = 0; counters[CTK_CNT_TICKET] = 0; counters[CTK_CNT_NOPS] = 0;
+            scal[0] = 0; scal[1] = 0; scal[2] = 0; scal[3] = 0;
+        }
+    }
     const uint32_t nc = dev_ncomps(r);
     const uint32_t nh = r.nh_ptr ? *r.nh_ptr : 0u;
     const int64_t off = *(const int64_t *)st;
@@ -297,6 +314,8 @@ struct ShSeamTabs {
     int32_t *op_first, *cl_tmin, *cl_tmax, *lbox, *ext;
 };
 // label-indexed tables [0, n) with n = NL + 2, time extents [0, NL], the write-stage counters
+// (the tables alone -- n_labels < 0 -- can be initialised before the boundary resolution says how many labels there are: for as
+// many as the buffers hold; the extents, whose layout depends on that number, and the counters then follow in k_rs_labels_sh)
 __global__ void k_sh_seam_init(ShSeamTabs tb, int64_t n, int64_t n_labels, uint32_t *__restrict__ counters, uint32_t *__restrict__ scal /* [4] */)
 {
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
@@ -306,6 +325,7 @@ __global__ void k_sh_seam_init(ShSeamTabs tb, int64_t n, int64_t n_labels, uint3
         int32_t *b = tb.lbox + 6 * i;
         b[0] = INT32_MAX; b[1] = -1; b[2] = INT32_MAX; b[3] = -1; b[4] = INT32_MAX; b[5] = -1;
     }
+    if (n_labels < 0) return;
     for (int64_t i = i0; i <= n_labels; i += st) { tb.ext[i] = INT32_MAX; tb.ext[n_labels + 1 + i] = INT32_MIN; }
     for (int64_t i = i0; i < CTK_ZF_SLOTS; i += st) ctk_zf_reset(counters, i);
     if (i0 == 0) {
@@ -674,7 +694,7 @@ static int g_shdbg = -1;
 #define CTK_SH_GOPS 16384            // op slots reserved for the shared clusters' operations (more: every rank falls back alike)
 static int sharded_seam_device(ctk_handle *h, ctk_comm *c, ShardScratch &S, ResolveDev &r, const ResolveIn &in, ResolvePlan &pl, int64_t T, int64_t t_begin,
                                int ny, int nx, int W, int persistence, int64_t NL, int64_t lab0, int64_t lab1, bool any_boundary, uint32_t hint_c,
-                               uint32_t hint_d, uint32_t *mail2, bool *too_many_shared_ops)
+                               uint32_t hint_d, uint32_t *mail2, bool *too_many_shared_ops, size_t pre_inited, const void *const *pre_ptrs)
 {
     hipStream_t s = h->stream;
     const int rank = c->rank, world = c->world;
@@ -716,8 +736,13 @@ static int sharded_seam_device(ctk_handle *h, ctk_comm *c, ShardScratch &S, Reso
         tb.mark = P<uint8_t>(h->rv_mark); tb.cl_shared = P<uint8_t>(h->sh_cl_shared); tb.cl_sent = P<uint8_t>(h->sh_cl_sent);
         tb.dmap = P<uint32_t>(h->rv_dmap); tb.cl_parent = sd.cl_parent; tb.cl_nops = sd.cl_nops; tb.op_first = r.op_first;
         tb.cl_tmin = sd.cl_tmin; tb.cl_tmax = sd.cl_tmax; tb.lbox = sd.lbox; tb.ext = P<int32_t>(h->ext);
-        k_sh_seam_init<<<(int)std::min<size_t>((NT + 255) / 256, 2048), 256, 0, s>>>(tb, (int64_t)NT, NL, P<uint32_t>(h->counters), scal);
-        k_rs_labels_sh<<<pl.gc, 256, 0, s>>>(r, st, P<uint8_t>(h->rv_mark));
+        // the tables were initialised ahead of the boundary resolution (seam_tables_preinit) unless they were too small or moved
+        const void *now_ptrs[10] = {h->rv_mark.p, h->rv_dmap.p, h->op_first.p, h->sd_parent.p, h->sd_tmin.p, h->sd_tmax.p, h->sd_nops.p, h->sd_lbox.p,
+                                    h->sh_cl_shared.p, h->sh_cl_sent.p};
+        bool pre_ok = NT <= pre_inited;
+        for (int k = 0; k < 10 && pre_ok; k++) pre_ok = pre_ptrs && pre_ptrs[k] == now_ptrs[k];
+        if (!pre_ok) k_sh_seam_init<<<(int)std::min<size_t>((NT + 255) / 256, 2048), 256, 0, s>>>(tb, (int64_t)NT, -1, P<uint32_t>(h->counters), scal);
+        k_rs_labels_sh<<<pl.gc, 256, 0, s>>>(r, st, P<uint8_t>(h->rv_mark), P<int32_t>(h->ext), NL, P<uint32_t>(h->counters), scal);
         k_fz_mark<<<(int)T, 64, 0, s>>>(r, sd, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res));
         k_fz_groups<<<(int)((T + FZ_TW - 1) / FZ_TW), 64 * FZ_TW, 0, s>>>(r, sd, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), t_begin);
         HIPCHK(hipGetLastError());
@@ -991,6 +1016,28 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
                                                                                         P<int64_t>(h->wlo) + ny, ny, W);
         HIPCHK(hipGetLastError());
     }
+    // Device seam path (X5): its label-indexed tables are initialised NOW -- for as many labels as the buffers held after the previous
+    // call -- so that nothing but the labelling itself has to be launched behind the boundary resolution (a 4 us kernel there left
+    // the GPU idle for the 12 us until the next launch arrived).  Buffers that turn out too small are initialised again there.
+    size_t seam_pre_n = 0;
+    const void *seam_pre_ptrs[10] = {h->rv_mark.p, h->rv_dmap.p, h->op_first.p, h->sd_parent.p, h->sd_tmin.p, h->sd_tmax.p, h->sd_nops.p, h->sd_lbox.p,
+                                     h->sh_cl_shared.p, h->sh_cl_sent.p};
+    if (!ctk_env().sh_host_seam && !(h->sh_dev_off_ny == ny && h->sh_dev_off_nx == nx) && T <= 65536) {
+        size_t n = std::min(h->rv_mark.cap, std::min(h->sh_cl_shared.cap, h->sh_cl_sent.cap));
+        for (const DevBuf *b : {&h->rv_dmap, &h->op_first, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_nops}) n = std::min(n, b->cap / 4);
+        n = std::min(n, h->sd_lbox.cap / 24);
+        bool have = n >= 1024;
+        for (int k = 0; k < 10; k++) have = have && seam_pre_ptrs[k] != nullptr;
+        if (have) {
+            ShSeamTabs tb;
+            tb.mark = P<uint8_t>(h->rv_mark); tb.cl_shared = P<uint8_t>(h->sh_cl_shared); tb.cl_sent = P<uint8_t>(h->sh_cl_sent);
+            tb.dmap = P<uint32_t>(h->rv_dmap); tb.cl_parent = P<uint32_t>(h->sd_parent); tb.cl_nops = P<uint32_t>(h->sd_nops); tb.op_first = P<int32_t>(h->op_first);
+            tb.cl_tmin = P<int32_t>(h->sd_tmin); tb.cl_tmax = P<int32_t>(h->sd_tmax); tb.lbox = P<int32_t>(h->sd_lbox); tb.ext = nullptr;
+            k_sh_seam_init<<<(int)std::min<size_t>((n + 255) / 256, 2048), 256, 0, s>>>(tb, (int64_t)n, -1, nullptr, nullptr);
+            HIPCHK(hipGetLastError());
+            seam_pre_n = n;
+        }
+    }
     bool prepped = false;                             // 1/areacon and the forward fractions: by the first filter launch itself where it can
     SHDBG("rs P1");
     bool fix_changed = false, last_was_fixup = false;
@@ -1046,15 +1093,18 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
             CTKCHK(ensure(h, h->sh_recv, slot * (size_t)world));
             CTKCHK(ensure_host(&h->h_shard, &h->h_shard_cap, bslot * (size_t)world + 4096, true));
             if (h->sh_prev.cap < slot * (size_t)world) { CTKCHK(ensure(h, h->sh_prev, slot * (size_t)world)); if (!first_round) return ctk_set_error(CTK_E_INTERNAL, "boundary buffer grew between rounds"); }
+            const uint32_t keep_stamp = (++h->sh_stamp_seq) | 0x80000000u;
+            mail2[CTK_SHM_STAMP] = 0;
             k_sh_pack_keep<<<8, 256, 0, s>>>(r, it_done, npass_grid > 0 ? npass : 0, capB, h->sh_capC, h->sh_capD, fix_changed ? 1u : 0u, (unsigned char *)h->sh_send.p,
                                              spec ? (unsigned char *)h->sh_send.p + kslot : nullptr);
             HIPCHK(hipGetLastError());
             CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, slot));
             k_sh_unpack_keep<<<1, 256, 0, s>>>(r, (const unsigned char *)h->sh_recv.p, (unsigned char *)h->sh_prev.p, first_round ? 1 : 0, redo, slot, capB, rank, world,
                                                it_done + npass, P<uint8_t>(h->rv_tdirty), mail2, spec ? kslot : 0, bslot, (uint32_t *)h->h_shard,
-                                               pslot ? in.pair_cnt : nullptr);
+                                               pslot ? in.pair_cnt : nullptr, keep_stamp);
             HIPCHK(hipGetLastError());
-            CTKCHK(ctk_comm_wait(c));
+            // (not a drain of the stream: the kernel's stamp in pinned memory arrives several microseconds before the completion signal)
+            CTKCHK(ctk_comm_wait_word(c, mail2 + CTK_SHM_STAMP, keep_stamp));
             if (mail2[CTK_SHM_MAXNLAST] <= capB) break;
             if (!first_round) return ctk_set_error(CTK_E_INTERNAL, "boundary component count changed between rounds");
             capB = mail2[CTK_SHM_MAXNLAST] + mail2[CTK_SHM_MAXNLAST] / 2 + 64;      // same decision on every rank; nothing was imported
@@ -1204,7 +1254,8 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
                           NL + 2 < 0x7fffffffll;
     if (dev_seam) {
         bool too_many = false;
-        CTKCHK(sharded_seam_device(h, c, S, r, in, pl, T, t_begin, ny, nx, W, persistence, NL, lab0, lab1, any_boundary_label_all, hint_c, hint_d, mail2, &too_many));
+        CTKCHK(sharded_seam_device(h, c, S, r, in, pl, T, t_begin, ny, nx, W, persistence, NL, lab0, lab1, any_boundary_label_all, hint_c, hint_d, mail2, &too_many,
+                                   seam_pre_n, seam_pre_ptrs));
         if (too_many) { h->stats[CTK_S_HOST_REASON] |= 16; continue; }       // (decided alike on every rank, nothing of X6 launched yet)
     } else {
     if (attempt > 0) {
