@@ -894,6 +894,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         ci.ambig = P<uint32_t>(h->rv_scalars) + 1; ci.pstate = P<uint32_t>(h->rv_pstate);
         ci.next_tiny = (const int32_t *)(P<int64_t>(h->wlo) + 2 * (size_t)h->ny);
         ci.nchanged = (CTK_MAX_JACOBI + 1) * CTK_CHG_SLOTS; ci.pstride = CTK_PSTATE_STRIDE; ci.T = T;
+        ci.base_ptr = nullptr; ci.ovr_slot = nullptr; ci.amb_cnt = nullptr; ci.dcount = nullptr;
         Timer tm(h, CTK_K_SCAN);
         k_compact_init<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
                                               P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box), P<int64_t>(h->d_area),

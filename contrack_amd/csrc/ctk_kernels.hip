@@ -897,6 +897,11 @@ struct CompInit {
     const int32_t *next_tiny;       // [ny + 1]
     int nchanged, pstride;
     int64_t T;
+    // time shards: the components of the previous shard's last timestep (the halo, *base_ptr of them) come first -- "timestep -1",
+    // cprefix[-1] = 0, cprefix[0] = *base_ptr -- and are initialised here as their own representatives; nullptr: no halo
+    const uint32_t *base_ptr;
+    uint32_t *ovr_slot;             // [NC] or nullptr
+    uint32_t *amb_cnt, *dcount;     // scalars reset with *ambig, or nullptr
 };
 __global__ __launch_bounds__(256) void k_compact_init(const uint32_t *__restrict__ run_base, const uint32_t *__restrict__ ncomp,
                                                       uint32_t *__restrict__ cprefix, const uint32_t *__restrict__ cs_mrep,
@@ -910,8 +915,19 @@ __global__ __launch_bounds__(256) void k_compact_init(const uint32_t *__restrict
     for (int u = tid; u < t; u += 256) s += ncomp[u];
     uint32_t cb;
     (void)block_excl_scan(s, sm, &cb);
+    const uint32_t nh = ci.base_ptr ? *ci.base_ptr : 0u;
+    cb += nh;
     const uint32_t n = ncomp[t], rb = run_base[t];
-    if (tid == 0) { cprefix[t] = cb; if (t == ci.T - 1) cprefix[ci.T] = cb + n; }
+    if (tid == 0) { cprefix[t] = cb; if (t == ci.T - 1) cprefix[ci.T] = cb + n; if (t == 0 && ci.base_ptr) cprefix[-1] = 0u; }
+    if (t == 0)
+        for (uint32_t g = tid; g < nh; g += 256) {              // halo components: each its own (already seam-resolved) representative
+            d_mrep[g] = g; d_comp_t[g] = 0xffffffffu;
+            for (int k = 0; k < 4; k++) d_box[(int64_t)g * 4 + k] = 0;
+            d_area[(int64_t)g * 2] = 0; d_area[(int64_t)g * 2 + 1] = 0;
+            ci.F[2 * (int64_t)g] = 0; ci.F[2 * (int64_t)g + 1] = 0; ci.B[2 * (int64_t)g] = 0; ci.B[2 * (int64_t)g + 1] = 0;
+            ci.keep0[g] = 1; ci.keep1[g] = 1; ci.touch[g] = 0; ci.parent[g] = g;
+            if (ci.ovr_slot) ci.ovr_slot[g] = 0;
+        }
     for (uint32_t c = tid; c < n; c += 256) {
         const uint32_t g = cb + c;
         d_mrep[g] = cs_mrep[rb + c];
@@ -924,6 +940,7 @@ __global__ __launch_bounds__(256) void k_compact_init(const uint32_t *__restrict
         ci.keep0[g] = 1; ci.keep1[g] = 1;
         ci.touch[g] = 0;
         ci.parent[g] = g;
+        if (ci.ovr_slot) ci.ovr_slot[g] = 0;
     }
     __syncthreads();
     // seam-merged components that hold a row with very low weight bits (ResolveDev::next_tiny): flag at the representative
@@ -933,7 +950,7 @@ __global__ __launch_bounds__(256) void k_compact_init(const uint32_t *__restrict
     }
     if (t == 0) {
         for (int i = tid; i < ci.nchanged; i += 256) ci.changed[i] = 0u;
-        if (tid == 0) *ci.ambig = 0u;
+        if (tid == 0) { *ci.ambig = 0u; if (ci.amb_cnt) *ci.amb_cnt = 0u; if (ci.dcount) *ci.dcount = 0u; }
     }
     if (ci.pstate && tid == 0) { ci.pstate[(size_t)t * ci.pstride] = 0u; if (t == ci.T - 1) ci.pstate[(size_t)ci.T * ci.pstride] = 0u; }
 }

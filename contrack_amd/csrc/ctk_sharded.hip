@@ -932,13 +932,40 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     INJECT(2);
 
     // ---- component tables: halo components first ("timestep -1"), then the shard's own in (t, c) order ------------------
+    // One launch (k_compact_init, as in the one-call pass): every timestep's workgroup sums the component counts in front of it
+    // itself, compacts its tables and initialises the resolver's per-component arrays; k_overlap then prepares every pair record
+    // as it writes it.  (Before: scan, compaction, halo rows, k_rs_init and k_rs_pairs_slots -- five launches, ~29 us at 1 deg.)
+    const bool sys_pass = !ctk_env().pass_launches && !h->no_sys && T <= 60000;
+    const bool one_init = T <= 65536 && !ctk_env().sh_no_slots;
     {
         Timer tm(h, CTK_K_SCAN);
-        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->ncomp), T, CPX(h), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, nullptr, nh_ptr);
-        k_compact_comps<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
-                                               P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box), P<int64_t>(h->d_area),
-                                               P<uint32_t>(h->d_comp_t));
-        k_halo_comps_init<<<16, 256, 0, s>>>(nh_ptr, P<uint32_t>(h->d_mrep), P<uint32_t>(h->d_comp_t), P<uint16_t>(h->d_box), P<int64_t>(h->d_area));
+        if (one_init) {
+            const size_t R0 = (size_t)(h->total_runs ? h->total_runs : 1) + halo2_max_runs(h);
+            CTKCHK(ensure(h, h->rv_F, R0 * 16)); CTKCHK(ensure(h, h->rv_B, R0 * 16));
+            CTKCHK(ensure(h, h->rv_keep0, R0)); CTKCHK(ensure(h, h->rv_keep1, R0));
+            CTKCHK(ensure(h, h->rv_touch, R0 * 4)); CTKCHK(ensure(h, h->rv_parent, R0 * 4));
+            CTKCHK(ensure(h, h->rv_changed, (size_t)(CTK_MAX_JACOBI + 8) * CTK_CHG_SLOTS * 4));
+            CTKCHK(ensure(h, h->rv_scalars, 64));
+            CTKCHK(ensure(h, h->sh_ovr_slot, R0 * 4));
+            if (sys_pass) CTKCHK(ensure(h, h->rv_pstate, (size_t)(T + 1) * 4 * CTK_PSTATE_STRIDE));
+            CompInit ci;
+            ci.F = P<int64_t>(h->rv_F); ci.B = P<int64_t>(h->rv_B); ci.keep0 = P<uint8_t>(h->rv_keep0); ci.keep1 = P<uint8_t>(h->rv_keep1);
+            ci.touch = P<uint32_t>(h->rv_touch); ci.parent = P<uint32_t>(h->rv_parent); ci.changed = P<uint32_t>(h->rv_changed);
+            ci.ambig = P<uint32_t>(h->rv_scalars) + 1; ci.pstate = sys_pass ? P<uint32_t>(h->rv_pstate) : nullptr;
+            ci.next_tiny = (const int32_t *)(P<int64_t>(h->wlo) + 2 * (size_t)h->ny);
+            ci.nchanged = (CTK_MAX_JACOBI + 1) * CTK_CHG_SLOTS; ci.pstride = CTK_PSTATE_STRIDE; ci.T = T;
+            ci.base_ptr = nh_ptr; ci.ovr_slot = P<uint32_t>(h->sh_ovr_slot); ci.amb_cnt = P<uint32_t>(h->rv_scalars) + 2; ci.dcount = P<uint32_t>(h->rv_scalars);
+            k_compact_init<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
+                                                  P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box), P<int64_t>(h->d_area),
+                                                  P<uint32_t>(h->d_comp_t), ci);
+            h->fz_init = true;                        // (k_overlap: the resolver's view of every pair record is written with the record)
+        } else {
+            k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->ncomp), T, CPX(h), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, nullptr, nh_ptr);
+            k_compact_comps<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
+                                                   P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box), P<int64_t>(h->d_area),
+                                                   P<uint32_t>(h->d_comp_t));
+            k_halo_comps_init<<<16, 256, 0, s>>>(nh_ptr, P<uint32_t>(h->d_mrep), P<uint32_t>(h->d_comp_t), P<uint16_t>(h->d_box), P<int64_t>(h->d_area));
+        }
         HIPCHK(hipGetLastError());
     }
     h->state = ST_LABELLED;
@@ -950,6 +977,8 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     h->sh_slots = !ctk_env().sh_no_slots;
     const int rc_ov = shard_overlap_v2(h);
     h->sh_slots = false;
+    const bool tables_ready = h->fz_init;             // (k_compact_init + k_overlap did what k_rs_init and k_rs_pairs* do)
+    h->fz_init = false;
     CTKCHK(rc_ov);
     const uint32_t pslot = h->fz_pslot;
     SHDBG("overlap");
@@ -987,7 +1016,6 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     CTKCHK(ensure(h, h->sh_amb_list, (size_t)AMB_CAP * 4));
     r.ovr_slot = P<uint32_t>(h->sh_ovr_slot); r.ovr_val = P<double>(h->sh_ovr_val); r.amb_list = P<uint32_t>(h->sh_amb_list); r.amb_cap = AMB_CAP;
     const int npass_grid = r.t_hi - r.t_lo + 1;
-    const bool sys_pass = !ctk_env().pass_launches && !h->no_sys && T <= 60000;
     if (sys_pass) { CTKCHK(ensure(h, h->rv_pstate, (size_t)(T + 1) * 4 * CTK_PSTATE_STRIDE)); r.pstate = P<uint32_t>(h->rv_pstate); }
     const int gc = pl.gc, gp = pl.gp, nsb = pl.nsb;
 
@@ -1005,10 +1033,12 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     bool first_round = true;
     {
         Timer tm(h, CTK_K_RESOLVE);
-        k_rs_init<<<gc, 256, 0, s>>>(r);                                   // (also zeroes the resolver's scalars)
-        const int gps = (int)std::min<uint64_t>(((uint64_t)T * std::max<uint32_t>(pslot, 1u) + 255) / 256 + 16, 4096);
-        if (pslot) k_rs_pairs_slots<<<gps, 256, 0, s>>>(r, in.pair_cnt, pslot);
-        else k_rs_pairs<<<gp, 256, 0, s>>>(r);
+        if (!tables_ready) {
+            k_rs_init<<<gc, 256, 0, s>>>(r);                               // (also zeroes the resolver's scalars)
+            const int gps = (int)std::min<uint64_t>(((uint64_t)T * std::max<uint32_t>(pslot, 1u) + 255) / 256 + 16, 4096);
+            if (pslot) k_rs_pairs_slots<<<gps, 256, 0, s>>>(r, in.pair_cnt, pslot);
+            else k_rs_pairs<<<gp, 256, 0, s>>>(r);
+        }
         if (has_next)
             k_sh_fwd_last<<<(int)std::min<size_t>((nw + 255) / 256, 1024), 256, 0, s>>>(r, P<uint64_t>(h->mask), P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart),
                                                                                         P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp),
