@@ -862,8 +862,9 @@ static int sharded_seam_device(ctk_handle *h, ctk_comm *c, ShardScratch &S, Reso
         k_sh_pack_ext<<<ne <= pe_lds ? SH_PE_BLOCKS : 1, 256, 0, s>>>(s_el, ne, P<int32_t>(h->ext), NL, lab0, lab1, persistence, P<uint64_t>(h->mask), nsample, h->W,
                                                                       last_full, P<int32_t>(h->sh_elist), P<int32_t>(h->sh_send), P<uint32_t>(h->counters), pe_lds);
         HIPCHK(hipGetLastError());
-        CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, eslot));
-        k_sh_reduce_ext<<<1, 1024, 0, s>>>(P<int32_t>(h->sh_elist), ne, P<int32_t>(h->sh_recv), world, P<int32_t>(h->ext), NL, persistence, mail2 + 64,
+        void *gath = world == 1 ? h->sh_send.p : h->sh_recv.p;
+        CTKCHK(ctk_comm_allgather(c, h->sh_send.p, gath, eslot));
+        k_sh_reduce_ext<<<1, 1024, 0, s>>>(P<int32_t>(h->sh_elist), ne, (const int32_t *)gath, world, P<int32_t>(h->ext), NL, persistence, mail2 + 64,
                                            P<uint32_t>(h->counters), scal, in.cprefix + T, sd.t_nops, sd.rec_cnt, T);
         HIPCHK(hipGetLastError());
     }
@@ -1128,8 +1129,10 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
             k_sh_pack_keep<<<8, 256, 0, s>>>(r, it_done, npass_grid > 0 ? npass : 0, capB, h->sh_capC, h->sh_capD, fix_changed ? 1u : 0u, (unsigned char *)h->sh_send.p,
                                              spec ? (unsigned char *)h->sh_send.p + kslot : nullptr);
             HIPCHK(hipGetLastError());
-            CTKCHK(ctk_comm_allgather(c, h->sh_send.p, h->sh_recv.p, slot));
-            k_sh_unpack_keep<<<1, 256, 0, s>>>(r, (const unsigned char *)h->sh_recv.p, (unsigned char *)h->sh_prev.p, first_round ? 1 : 0, redo, slot, capB, rank, world,
+            // (one rank: what was "gathered" is what was packed -- no copy of the buffer onto itself)
+            void *gath = world == 1 ? h->sh_send.p : h->sh_recv.p;
+            CTKCHK(ctk_comm_allgather(c, h->sh_send.p, gath, slot));
+            k_sh_unpack_keep<<<1, 256, 0, s>>>(r, (const unsigned char *)gath, (unsigned char *)h->sh_prev.p, first_round ? 1 : 0, redo, slot, capB, rank, world,
                                                it_done + npass, P<uint8_t>(h->rv_tdirty), mail2, spec ? kslot : 0, bslot, (uint32_t *)h->h_shard,
                                                pslot ? in.pair_cnt : nullptr, keep_stamp);
             HIPCHK(hipGetLastError());
