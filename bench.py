@@ -179,7 +179,7 @@ def secondary_025deg(steps, warmup, budget_steps=240):
         kern = max(alg, key=lambda q: per.get(q, 0.0))
         ach = alg[kern] / (per[kern] * 1e-3) / 1e9 if per.get(kern, 0) > 0 else 0.0
         rk = {5: "k_relabel_v5", 4: "k_relabel_v4"}.get(trk.stats().get("relabel_kernel", 4), "k_relabel")
-        kname = {"k_threshold": "k_threshold_v4", "k_relabel": rk}[kern]
+        kname = {"k_threshold": "k_threshold_v4" if os.environ.get("CTK_THRESHOLD") == "4" else "k_threshold_v7", "k_relabel": rk}[kern]
         out = dict(workload="%s: %dx%dx%d float32 (device-generated), threshold %s %g, overlap %g, persistence %d, twosided %s" % (
                        name, T, ny, nx, wl["gorl"], wl["threshold"], wl["overlap"], wl["persistence"], wl["twosided"]),
                    value=T / (ms * 1e-3), unit="timesteps/s", ms_per_step=ms, steps=k, n_tracked=n_tracked,
@@ -347,7 +347,7 @@ def main():
     kern = max(alg_bytes, key=lambda k: per.get(k, 0.0))
     achieved = alg_bytes[kern] / (per[kern] * 1e-3) / 1e9 if per.get(kern, 0) > 0 else 0.0
     rk = {5: "k_relabel_v5", 4: "k_relabel_v4"}.get(trk.stats().get("relabel_kernel", 4), "k_relabel")
-    kname = {"k_threshold": "k_threshold_v4", "k_relabel": rk}[kern]
+    kname = {"k_threshold": "k_threshold_v4" if os.environ.get("CTK_THRESHOLD") == "4" else "k_threshold_v7", "k_relabel": rk}[kern]
     out = dict(metric="timesteps/sec labeled+tracked", value=value, unit="timesteps/s", n_gpus=1, steps=args.steps,
                warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f32 compare / int32 labels / int64 exact areas", data="synthetic",

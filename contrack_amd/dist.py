@@ -522,7 +522,7 @@ def bench_main(args, wl, workloads, hbm_peak, cpu_baseline=None, pmc_traffic=Non
                        parity_checked=bool(parity_ok) if parity_ok is not None else False, parity=parity,
                        collectives_per_step=dict(neighbour_exchanges=(ops1["neighbour_exchanges"] - ops0["neighbour_exchanges"]) / nsteps,
                                                  allgathers=(ops1["allgathers"] - ops0["allgathers"] - 2) / nsteps)),      # (- the closing barrier and the time gather)
-                   roofline=dict(bound="hbm", kernel={"k_threshold": "k_threshold_v4", "k_relabel": {5: "k_relabel_v5", 4: "k_relabel_v4"}.get(stats.get("relabel_kernel", 4), "k_relabel")}[kern], achieved=achieved, peak=hbm_peak,
+                   roofline=dict(bound="hbm", kernel={"k_threshold": "k_threshold_v4" if os.environ.get("CTK_THRESHOLD") == "4" else "k_threshold_v7", "k_relabel": {5: "k_relabel_v5", 4: "k_relabel_v4"}.get(stats.get("relabel_kernel", 4), "k_relabel")}[kern], achieved=achieved, peak=hbm_peak,
                                  unit="GB/s", frac=achieved / hbm_peak, traffic=None, algorithmic_bytes_per_launch=alg[kern],
                                  avg_kernel_ms=per.get(kern), note="rank 0's shard"),
                    kernels_ms=per, workload_stats_rank0=stats)

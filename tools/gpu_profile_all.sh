@@ -11,4 +11,6 @@ done
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload era5_025deg_2k > gpurun_out/${P}_bench_025deg_2k.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --workload era5_1deg_90 > gpurun_out/${P}_bench_1deg_90.json 2>/dev/null
 CTK_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 > gpurun_out/${P}_bench_rccl_world1.json 2>/dev/null
+CTK_SH_FORCE_SPLIT=1 CTK_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${P}_bench_rccl_world1_force_split.json 2>/dev/null
+CTK_DIST_BACKEND=shm python bench.py --gpus 2 --steps 10 --warmup 3 > gpurun_out/${P}_bench_shm_2ranks_one_gpu.json 2>/dev/null
 ls -la gpurun_out | grep $P
