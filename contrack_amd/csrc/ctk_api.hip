@@ -49,14 +49,14 @@ static double now_ms_fwd() { return std::chrono::duration<double, std::milli>(st
 // Debug / experiment switches of the environment, read ONCE per process (getenv is a linear scan of environ and not safe against a
 // concurrent setenv from another rank's host thread; the passes shave microseconds).
 struct CtkEnv {
-    int sd_dbg = 0, relabel_rows = 0, xcd_thr = 0, xcd_rel = 0;
+    int sd_dbg = 0, relabel_rows = 0, xcd_thr = 0, xcd_rel = 0, relabel_threads = 0;
     bool pass_launches = false, print_ptrs = false, seamstats = false, relabel_plain = false, relabel_v4 = false, hosttrace = false,
          sh_no_slots = false, no_spec_x4 = false, sh_force_split = false, sh_host_seam = false;
     CtkEnv()
     {
         auto num = [](const char *k) { const char *e = getenv(k); return e ? atoi(e) : 0; };
         auto on = [](const char *k) { return getenv(k) != nullptr; };
-        sd_dbg = num("CTK_SD_DBG"); relabel_rows = num("CTK_RELABEL_ROWS"); xcd_thr = getenv("CTK_XCD_THR") ? num("CTK_XCD_THR") : 64; xcd_rel = num("CTK_XCD_REL");      // (tools/xcd_probe.py, NOTES round 4)
+        sd_dbg = num("CTK_SD_DBG"); relabel_rows = num("CTK_RELABEL_ROWS"); xcd_thr = getenv("CTK_XCD_THR") ? num("CTK_XCD_THR") : 64; xcd_rel = num("CTK_XCD_REL"); relabel_threads = num("CTK_RELABEL_THREADS");      // (tools/xcd_probe.py, NOTES round 4)
         pass_launches = on("CTK_PASS_LAUNCHES"); print_ptrs = on("CTK_PRINT_PTRS"); seamstats = on("CTK_SEAMSTATS");
         relabel_plain = on("CTK_RELABEL_PLAIN"); relabel_v4 = on("CTK_RELABEL_V4"); hosttrace = on("CTK_HOSTTRACE");
         sh_no_slots = on("CTK_SH_NO_SLOTS"); no_spec_x4 = on("CTK_NO_SPEC_X4"); sh_force_split = on("CTK_SH_FORCE_SPLIT"); sh_host_seam = on("CTK_SH_HOST_SEAM");
@@ -237,6 +237,7 @@ struct ctk_handle {
     uint64_t spin_limit = CTK_SPIN_LIMIT_TICKS;
     int debug_stall = 0;                          // test hook (ctk_debug_set_spin): the first workgroup of the chain is late (1) / never publishes (2)
     bool no_sys = false, sh_retrying = false;
+    int relabel_threads = 0, relabel_rows_dbg = 0;  // experiments (ctk_debug_set_relabel): threads / rows per workgroup of k_relabel_v5, 0 = default
     int xcd_thr = -1, xcd_rel = -1;               // chunk -> XCD mapping of the two streaming kernels (xcd_chunk); -1: the environment's / default
     bool sh_collective_err = false;               // the time-shard path's error was decided identically on every rank
     ctk_comm *active_comm = nullptr;              // set while the time-shard path runs with more than one rank
@@ -507,6 +508,13 @@ extern "C" int ctk_debug_set_xcd(ctk_handle *h, int thr_mode, int rel_mode)
 {
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
     h->xcd_thr = thr_mode; h->xcd_rel = rel_mode;
+    return CTK_OK;
+}
+
+extern "C" int ctk_debug_set_relabel(ctk_handle *h, int threads, int rows)
+{
+    if (!h || (threads != 0 && threads != 128 && threads != 256 && threads != 257 && threads != 512 && threads != 1024) || rows < 0) return ctk_set_error(CTK_E_INVALID, "ctk_debug_set_relabel: threads 0 / 256 / 512 / 1024, rows >= 0");
+    h->relabel_threads = threads; h->relabel_rows_dbg = rows;
     return CTK_OK;
 }
 
@@ -1624,6 +1632,7 @@ static int relabel_rows(const ctk_handle *h)
     while (rb < rb_max && h->T * ((h->ny + rb - 1) / rb) > 250000) rb++;
     while (rb < h->ny && h->T * ((h->ny + rb - 1) / rb) >= (1 << 24)) rb++;
     if (ctk_env().relabel_rows > 0) rb = std::min(h->ny, ctk_env().relabel_rows);
+    if (h->relabel_rows_dbg > 0) rb = std::min(h->ny, h->relabel_rows_dbg);
     return rb;
 }
 static bool relabel_fast_ok(const ctk_handle *h, const int32_t *flag_dev, int rb)
@@ -1661,6 +1670,7 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
     a.guard = h->guard_on ? P<uint32_t>(h->counters) : nullptr;
     a.plain_stores = ctk_env().relabel_plain ? 1 : 0;
     a.xcd_remap = h->xcd_rel >= 0 ? h->xcd_rel : ctk_env().xcd_rel;
+    a.fast_zero = h->relabel_threads == 257 ? 1 : 0;       // (experiment, off: NOTES round 4)
     const int64_t npl = (int64_t)h->ny * h->nx;
     const int rvcap = 2048;
     const size_t lds = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) + (size_t)rvcap * 4;
@@ -1672,10 +1682,20 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
         const int rv5 = 512;
         const size_t tab5 = (size_t)rb * h->W * 8 + (((size_t)rb * h->W * 2 + 7) & ~(size_t)7) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7) +
                             (((size_t)rv5 * 4 + 15) & ~(size_t)15) + 16;
+        // threads per workgroup: 256; wider (experiment, CTK_RELABEL_THREADS / ctk_debug_set_relabel_threads) gives a tall chunk fewer
+        // stores per lane at the same number of workgroups -- the LDS budget grows with the waves (same occupancy in waves per CU)
+        const int th = h->relabel_threads > 0 ? h->relabel_threads : (ctk_env().relabel_threads > 0 ? ctk_env().relabel_threads : 256);
+        const size_t budget = (size_t)20 * 1024 * (size_t)th / 256;
         int sub = rb;
-        while (sub > 1 && tab5 + (size_t)sub * h->nx * 4 > 20 * 1024) sub--;
+        while (sub > 1 && tab5 + (size_t)sub * h->nx * 4 > budget) sub--;
         const size_t lds5 = tab5 + (size_t)sub * h->nx * 4;
-        if (lds5 <= 20 * 1024 && !ctk_env().relabel_v4) { k_relabel_v5<<<grid, 256, lds5, h->stream>>>(a, rb, rv5, sub); h->stats[CTK_S_RELABEL_KERNEL] = 5; }
+        if (lds5 <= budget && !ctk_env().relabel_v4) {
+            if (th == 1024) k_relabel_v5<1024><<<grid, 1024, lds5, h->stream>>>(a, rb, rv5, sub);
+            else if (th == 512) k_relabel_v5<512><<<grid, 512, lds5, h->stream>>>(a, rb, rv5, sub);
+            else if (th == 128) k_relabel_v5<128><<<grid, 128, lds5, h->stream>>>(a, rb, rv5, sub);
+            else k_relabel_v5<256><<<grid, 256, lds5, h->stream>>>(a, rb, rv5, sub);
+            h->stats[CTK_S_RELABEL_KERNEL] = 5;
+        }
         else { k_relabel_v4<<<grid, 256, lds, h->stream>>>(a, rb, rvcap); h->stats[CTK_S_RELABEL_KERNEL] = 4; }
     } else if (nt > 0) {
         a.chunk_vals = nullptr;

@@ -1445,6 +1445,7 @@ struct RelabelArgs {
     const uint32_t *guard;         // see ctk_guard_bad
     int plain_stores;              // experiment: plain instead of non-temporal stores
     int xcd_remap;                 // experiment: every XCD streams one contiguous eighth of the slab (xcd_chunk)
+    int fast_zero;                 // k_relabel_v5: a chunk without a run is written as zeros straight from registers (no LDS image)
 };
 
 // fast path (nx % 4 == 0, 16-byte aligned flag): one workgroup per (timestep, 16 rows).  The rows' mask
@@ -1523,7 +1524,8 @@ __global__ __launch_bounds__(256) void k_relabel_v4(RelabelArgs a, int rb, int r
 // assembled in LDS (dynamic LDS: the tables + rvcap * 4 + rows * nx * 4 bytes) and stored from there.  Used while that image
 // leaves room for eight workgroups per CU (1 degree: 11 rows = 15.8 KB; 0.25 degree: 2 rows = 11.5 KB); the 8-row chunks of
 // slabs with millions of chunks stay with k_relabel_v4.
-__global__ __launch_bounds__(256) void k_relabel_v5(RelabelArgs a, int rb, int rvcap, int sub /* rows per LDS image: rb, or less for tall chunks */)
+template <int TH /* threads: 256; 512 / 1024 for tall chunks (fewer stores per lane at the same number of workgroups) */>
+__global__ __launch_bounds__(TH) void k_relabel_v5(RelabelArgs a, int rb, int rvcap, int sub /* rows per LDS image: rb, or less for tall chunks */)
 {
     if (ctk_guard_bad(a.guard)) return;
     const int ny = a.ny, nx = a.nx, W = a.W;
@@ -1538,16 +1540,25 @@ __global__ __launch_bounds__(256) void k_relabel_v5(RelabelArgs a, int rb, int r
     uint32_t *rst = reinterpret_cast<uint32_t *>(smem + (size_t)rb * W * 8 + (((size_t)rb * W * 2 + 7) & ~(size_t)7));
     int32_t *rvs = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(rst) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7));
     const uint32_t trun = a.run_base[t + 1] - a.run_base[t];
-    for (int i = tid; i < rows * W; i += 256) { mrow[i] = a.mask[row0 * W + i]; wst[i] = a.wstart[row0 * W + i]; }
-    for (int i = tid; i <= rows; i += 256) rst[i] = (y0 + i < ny) ? a.rowstart[row0 + i] : trun;
+    for (int i = tid; i < rows * W; i += TH) { mrow[i] = a.mask[row0 * W + i]; wst[i] = a.wstart[row0 * W + i]; }
+    for (int i = tid; i <= rows; i += TH) rst[i] = (y0 + i < ny) ? a.rowstart[row0 + i] : trun;
     // the chunk's run values in chunk order (k_run_values): loaded together with the tables -- one round trip, one barrier
-    if (a.chunk_vals && tid >= 256 - CTK_CV) rvs[tid - (256 - CTK_CV)] = a.chunk_vals[(int64_t)bid * CTK_CV + (tid - (256 - CTK_CV))];
+    if (a.chunk_vals && tid >= TH - CTK_CV) rvs[tid - (TH - CTK_CV)] = a.chunk_vals[(int64_t)bid * CTK_CV + (tid - (TH - CTK_CV))];
     __syncthreads();
     const uint32_t r0 = rst[0], nr = rst[rows] - r0;
+    if (nr == 0u && a.fast_zero) {
+        // no run in the chunk (a third of the 6-row chunks of a 0.25 deg slab): zeros straight from registers -- no LDS image, no
+        // further barrier
+        i32x4 *dst = reinterpret_cast<i32x4 *>(a.flag + row0 * (int64_t)nx);
+        const int total = rows * (nx >> 2);
+        for (int i = tid; i < total; i += TH) __builtin_nontemporal_store((i32x4)(0), dst + i);
+        if (lane_id() == 0) ctk_zf_set(a.counters, blockIdx.x * (unsigned)(TH / 64) + (threadIdx.x >> 6));
+        return;
+    }
     const int32_t *rvg = a.run_val + a.run_base[t] + r0;
     const bool staged = nr <= (uint32_t)rvcap;
     if (!(a.chunk_vals && nr <= (uint32_t)CTK_CV)) {                    // more runs than the chunk-ordered copy holds (or no copy)
-        if (staged) for (uint32_t i = tid; i < nr; i += 256) rvs[i] = rvg[i];
+        if (staged) for (uint32_t i = tid; i < nr; i += TH) rvs[i] = rvg[i];
         __syncthreads();
     }
     // Word-centric: the chunk's flag values are assembled in LDS and stored from there, `sub` rows at a time.
@@ -1566,10 +1577,10 @@ __global__ __launch_bounds__(256) void k_relabel_v5(RelabelArgs a, int rb, int r
     for (int s0 = 0; s0 < rows; s0 += sub) {
         const int srows = min(sub, rows - s0), total = srows * n4;
         i32x4 *dst = reinterpret_cast<i32x4 *>(a.flag + (row0 + s0) * (int64_t)nx);
-        for (int i = tid; i < total; i += 256) outv4[i] = (i32x4)(0);
+        for (int i = tid; i < total; i += TH) outv4[i] = (i32x4)(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const int nw = srows * W;
-        for (int k = tid; k < nw; k += 256) {
+        for (int k = tid; k < nw; k += TH) {
             const int idx = s0 * W + k;                                         // word of the chunk
             const uint64_t m = mrow[idx];
             const int rr = k / W, w = k - rr * W, r = s0 + rr;
@@ -1609,11 +1620,11 @@ __global__ __launch_bounds__(256) void k_relabel_v5(RelabelArgs a, int rb, int r
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (a.plain_stores) { for (int i = tid; i < total; i += 256) dst[i] = outv4[i]; }
-        else for (int i = tid; i < total; i += 256) __builtin_nontemporal_store(outv4[i], dst + i);    // (the rows are contiguous: slot i)
+        if (a.plain_stores) { for (int i = tid; i < total; i += TH) dst[i] = outv4[i]; }
+        else for (int i = tid; i < total; i += TH) __builtin_nontemporal_store(outv4[i], dst + i);    // (the rows are contiguous: slot i)
         if (s0 + sub < rows) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // the image is zeroed again
     }
-    if (__ballot(z) && lane_id() == 0) ctk_zf_set(a.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (__ballot(z) && lane_id() == 0) ctk_zf_set(a.counters, blockIdx.x * (unsigned)(TH / 64) + (threadIdx.x >> 6));
 }
 
 __global__ __launch_bounds__(256) void k_relabel(RelabelArgs a)

@@ -289,6 +289,8 @@ int ctk_debug_set_spin(ctk_handle *h, double limit_ms, int stall_mode);
 /* experiments: which chunk of the slab the workgroups of the two streaming kernels take (0 = in launch order, 1 = one contiguous eighth
  * per XCD, k > 1 = tiles of k chunks per XCD); -1 = the default */
 int ctk_debug_set_xcd(ctk_handle *h, int thr_mode, int rel_mode);
+/* experiments: threads (0 = default, 256 / 512 / 1024) and rows (0 = default) per workgroup of the write kernel k_relabel_v5 */
+int ctk_debug_set_relabel(ctk_handle *h, int threads, int rows);
 /* 1 (default; CTK_ASYNC=0 in the environment turns it off): the one-call entries run the whole pass without a host hand-off (device
  * seam driver, one synchronisation at the end, validated from a device-written block of scalars; CTK_S_FUSED) and repeat the
  * resolution on the synchronous path below only if the validation says so; 0: always the synchronous path (host seam driver) */
