@@ -237,6 +237,7 @@ struct ctk_handle {
     uint64_t spin_limit = CTK_SPIN_LIMIT_TICKS;
     int debug_stall = 0;                          // test hook (ctk_debug_set_spin): the first workgroup of the chain is late (1) / never publishes (2)
     bool no_sys = false, sh_retrying = false;
+    int small_threads[3] = {0, 0, 0};              // experiments (ctk_debug_set_small_threads): threads of k_extent / k_run_values / k_compact_init, 0 = default
     int relabel_threads = 0, relabel_rows_dbg = 0;  // experiments (ctk_debug_set_relabel): threads / rows per workgroup of k_relabel_v5, 0 = default
     int xcd_thr = -1, xcd_rel = -1;               // chunk -> XCD mapping of the two streaming kernels (xcd_chunk); -1: the environment's / default
     bool sh_collective_err = false;               // the time-shard path's error was decided identically on every rank
@@ -508,6 +509,14 @@ extern "C" int ctk_debug_set_xcd(ctk_handle *h, int thr_mode, int rel_mode)
 {
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
     h->xcd_thr = thr_mode; h->xcd_rel = rel_mode;
+    return CTK_OK;
+}
+
+extern "C" int ctk_debug_set_small_threads(ctk_handle *h, int extent, int run_values, int compact_init)
+{
+    for (int v : {extent, run_values, compact_init}) if (v != 0 && v != 64 && v != 128 && v != 256) return ctk_set_error(CTK_E_INVALID, "ctk_debug_set_small_threads: 0 / 64 / 128 / 256");
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    h->small_threads[0] = extent; h->small_threads[1] = run_values; h->small_threads[2] = compact_init;
     return CTK_OK;
 }
 
@@ -904,7 +913,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         ci.nchanged = (CTK_MAX_JACOBI + 1) * CTK_CHG_SLOTS; ci.pstride = CTK_PSTATE_STRIDE; ci.T = T;
         ci.base_ptr = nullptr; ci.ovr_slot = nullptr; ci.amb_cnt = nullptr; ci.dcount = nullptr;
         Timer tm(h, CTK_K_SCAN);
-        k_compact_init<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
+        k_compact_init<<<(int)T, h->small_threads[2] > 0 ? h->small_threads[2] : 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
                                               P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box), P<int64_t>(h->d_area),
                                               P<uint32_t>(h->d_comp_t), ci);
         HIPCHK(hipGetLastError());
@@ -1241,7 +1250,9 @@ static int launch_extents(ctk_handle *h, bool ext_filled = false, bool with_fina
         a.comp_label = P<int32_t>(h->comp_label); a.lab = with_final ? P<int32_t>(h->rv_lab) : nullptr; a.comp_label_w = P<int32_t>(h->comp_label);
         a.box = P<uint16_t>(h->d_box); a.ext = P<int32_t>(h->ext); a.n_labels = h->n_labels; a.t_begin = h->t_begin;
         a.fold = fold_args(h); a.ny = h->ny; a.nx = h->nx; a.W = h->W;
-        k_extent<<<(int)h->T, 256, 0, s>>>(a);
+        // (a timestep has ~40 components: one wave per timestep puts every plane of a long slab on the chip at once -- 11.2 instead of
+        // 14.0 us at 2707 x 181 x 360, equal at 480 x 721 x 1440; tools/small_probe.py)
+        k_extent<<<(int)h->T, h->small_threads[0] > 0 ? h->small_threads[0] : (h->T > 2048 ? 64 : 256), 0, s>>>(a);
         HIPCHK(hipGetLastError());
     }
     return CTK_OK;
@@ -1873,7 +1884,7 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     int32_t *cv = chunk_vals_for(h, flag_dev, &cv_rows);
     {
         Timer tm(h, CTK_K_RUNLABEL);
-        k_run_values<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), CPX(h), P<int32_t>(h->comp_label),
+        k_run_values<<<(int)T, h->small_threads[1] > 0 ? h->small_threads[1] : 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), CPX(h), P<int32_t>(h->comp_label),
                                             P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->d_mrep), 0, 0, P<int32_t>(h->run_val),
                                             P<uint32_t>(h->rowstart), h->ny, cv_rows, cv, P<uint32_t>(h->counters),
                                             P<uint32_t>(h->rv_boff) + nsb, P<uint32_t>(h->seam_off) /* t_alive: [T + 1], unused on this path otherwise */);

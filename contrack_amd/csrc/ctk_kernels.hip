@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256) void k_compact_init(const uint32_t *__restrict
     const int t = (int)blockIdx.x, tid = (int)threadIdx.x;
     __shared__ uint32_t sm[8];
     uint32_t s = 0;
-    for (int u = tid; u < t; u += 256) s += ncomp[u];
+    for (int u = tid; u < t; u += blockDim.x) s += ncomp[u];
     uint32_t cb;
     (void)block_excl_scan(s, sm, &cb);
     const uint32_t nh = ci.base_ptr ? *ci.base_ptr : 0u;
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256) void k_compact_init(const uint32_t *__restrict
     const uint32_t n = ncomp[t], rb = run_base[t];
     if (tid == 0) { cprefix[t] = cb; if (t == ci.T - 1) cprefix[ci.T] = cb + n; if (t == 0 && ci.base_ptr) cprefix[-1] = 0u; }
     if (t == 0)
-        for (uint32_t g = tid; g < nh; g += 256) {              // halo components: each its own (already seam-resolved) representative
+        for (uint32_t g = tid; g < nh; g += blockDim.x) {              // halo components: each its own (already seam-resolved) representative
             d_mrep[g] = g; d_comp_t[g] = 0xffffffffu;
             for (int k = 0; k < 4; k++) d_box[(int64_t)g * 4 + k] = 0;
             d_area[(int64_t)g * 2] = 0; d_area[(int64_t)g * 2 + 1] = 0;
@@ -928,7 +928,7 @@ __global__ __launch_bounds__(256) void k_compact_init(const uint32_t *__restrict
             ci.keep0[g] = 1; ci.keep1[g] = 1; ci.touch[g] = 0; ci.parent[g] = g;
             if (ci.ovr_slot) ci.ovr_slot[g] = 0;
         }
-    for (uint32_t c = tid; c < n; c += 256) {
+    for (uint32_t c = tid; c < n; c += blockDim.x) {
         const uint32_t g = cb + c;
         d_mrep[g] = cs_mrep[rb + c];
         for (int k = 0; k < 4; k++) d_box[(int64_t)g * 4 + k] = (uint16_t)cs_box[(int64_t)(rb + c) * 4 + k];
@@ -944,12 +944,12 @@ __global__ __launch_bounds__(256) void k_compact_init(const uint32_t *__restrict
     }
     __syncthreads();
     // seam-merged components that hold a row with very low weight bits (ResolveDev::next_tiny): flag at the representative
-    for (uint32_t c = tid; c < n; c += 256) {
+    for (uint32_t c = tid; c < n; c += blockDim.x) {
         const uint32_t y0 = cs_box[(int64_t)(rb + c) * 4], y1 = cs_box[(int64_t)(rb + c) * 4 + 1];
         if (ci.next_tiny[y0] <= (int32_t)y1) ci.touch[cb + cs_mrep[rb + c]] = 1u;
     }
     if (t == 0) {
-        for (int i = tid; i < ci.nchanged; i += 256) ci.changed[i] = 0u;
+        for (int i = tid; i < ci.nchanged; i += blockDim.x) ci.changed[i] = 0u;
         if (tid == 0) { *ci.ambig = 0u; if (ci.amb_cnt) *ci.amb_cnt = 0u; if (ci.dcount) *ci.dcount = 0u; }
     }
     if (ci.pstate && tid == 0) { ci.pstate[(size_t)t * ci.pstride] = 0u; if (t == ci.T - 1) ci.pstate[(size_t)ci.T * ci.pstride] = 0u; }
@@ -1331,7 +1331,7 @@ __global__ __launch_bounds__(256) void k_extent(ExtentArgs a)
     __shared__ int ylo, yhi;                               // rows that hold pixels of complex components
     if (tid == 0) { ylo = 0x7fffffff; yhi = -1; }
     __syncthreads();
-    for (uint32_t c = tid; c < n; c += 256) {
+    for (uint32_t c = tid; c < n; c += blockDim.x) {
         int32_t l;
         if (a.lab) {                                       // single-GPU path: k_rs_final's work, one launch less
             l = a.lab[cb + c];
@@ -1344,8 +1344,8 @@ __global__ __launch_bounds__(256) void k_extent(ExtentArgs a)
     __syncthreads();
     if (yhi < 0) return;
     const uint32_t *rc = a.run_comp + a.run_base[t];
-    const int wv = tid >> 6;
-    for (int y = ylo + wv; y <= yhi && y < a.ny; y += 4) {
+    const int wv = tid >> 6, nwv = (int)(blockDim.x >> 6);
+    for (int y = ylo + wv; y <= yhi && y < a.ny; y += nwv) {
         const uint64_t *mw = a.mask + ((int64_t)t * a.ny + y) * a.W;
         for_each_fg_pixel_in_row(mw, a.W, a.rowstart[(int64_t)t * a.ny + y], [&](int x, uint32_t run) {
             int32_t l = a.comp_label[cb + rc[run]];

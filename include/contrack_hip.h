@@ -291,6 +291,9 @@ int ctk_debug_set_spin(ctk_handle *h, double limit_ms, int stall_mode);
 int ctk_debug_set_xcd(ctk_handle *h, int thr_mode, int rel_mode);
 /* experiments: threads (0 = default, 256 / 512 / 1024) and rows (0 = default) per workgroup of the write kernel k_relabel_v5 */
 int ctk_debug_set_relabel(ctk_handle *h, int threads, int rows);
+/* experiments: threads per workgroup (0 = default, 64 / 128 / 256) of the one-workgroup-per-timestep kernels k_extent, k_run_values,
+ * k_compact_init of the one-call pass */
+int ctk_debug_set_small_threads(ctk_handle *h, int extent, int run_values, int compact_init);
 /* 1 (default; CTK_ASYNC=0 in the environment turns it off): the one-call entries run the whole pass without a host hand-off (device
  * seam driver, one synchronisation at the end, validated from a device-written block of scalars; CTK_S_FUSED) and repeat the
  * resolution on the synchronous path below only if the validation says so; 0: always the synchronous path (host seam driver) */
