@@ -121,10 +121,12 @@ struct CtkCtlSeg {
     uint32_t bar_count, bar_gen;        // central barrier of the shm transport
     uint32_t attached;                  // ranks that have mapped the segment
     int32_t pid[CTK_CTL_MAXWORLD];      // process of every rank (0: not there yet)
+    uint32_t pidns[CTK_CTL_MAXWORLD];   // ... and the PID namespace it lives in (inode of /proc/self/ns/pid; 0: unknown): a pid means
+                                        // something only to a process of the same namespace (one container per GPU sharing /dev/shm)
 };
 namespace {
 constexpr uint64_t kCtlMagic = 0x324c54434b5443ull;      // "CTKCTL2"
-constexpr size_t kCtlBytes = 16384;
+constexpr size_t kCtlBytes = 32768;
 static_assert(sizeof(CtkCtlSeg) <= kCtlBytes, "control segment header");
 static_assert(offsetof(CtkCtlSeg, failed_code) % 8 == 0 && offsetof(CtkCtlSeg, failed_rank) == offsetof(CtkCtlSeg, failed_code) + 4, "failure word");
 constexpr size_t kShmSlot = (size_t)4 << 20;
@@ -145,6 +147,16 @@ bool process_gone(int32_t pid)
     buf[n] = 0;
     const char *q = strrchr(buf, ')');
     return q && q[1] == ' ' && (q[2] == 'Z' || q[2] == 'X');
+}
+
+// inode of this process' PID namespace (0 if it cannot be read)
+uint32_t my_pidns()
+{
+    static const uint32_t v = [] {
+        struct stat st;
+        return stat("/proc/self/ns/pid", &st) == 0 ? (uint32_t)st.st_ino : 0u;
+    }();
+    return v;
 }
 
 // publish a failure (first one wins); code < 0
@@ -188,6 +200,9 @@ int ctl_poll(ctk_comm *c, WaitState &w, const char *what)
         for (int r = 0; r < c->world; r++) {
             if (r == c->rank) continue;
             const int32_t pid = ld32(&s->pid[r]);
+            // (a pid of another PID namespace names nothing -- or somebody else -- here: such a rank is covered by the deadline only)
+            const uint32_t ns = ldu32(&s->pidns[r]);
+            if (ns == 0u || ns != my_pidns()) continue;
             if (process_gone(pid)) {
                 ctl_publish(s, r, CTK_E_COMM);
                 return ctk_set_error(CTK_E_COMM, "rank %d: %s abandoned -- the process of rank %d (pid %d) is gone", c->rank, what, r, (int)pid);
@@ -235,6 +250,7 @@ int ctl_open(ctk_comm *c, const char *name, size_t bytes, uint64_t slot, void **
     if (c->rank == 0) {
         memset(s, 0, sizeof(CtkCtlSeg));
         s->world = c->world; s->slot = slot;
+        s->pidns[0] = my_pidns();
         s->pid[0] = (int32_t)getpid();
         __atomic_store_n(&s->magic, kCtlMagic, __ATOMIC_RELEASE);
     } else {
@@ -243,6 +259,7 @@ int ctl_open(ctk_comm *c, const char *name, size_t bytes, uint64_t slot, void **
             nap_us(1000);
         }
         if (s->world != c->world) { munmap(p, bytes); return ctk_set_error(CTK_E_COMM, "segment %s belongs to a communicator of %d ranks, not %d", name, s->world, c->world); }
+        __atomic_store_n(&s->pidns[c->rank], my_pidns(), __ATOMIC_RELEASE);
         __atomic_store_n(&s->pid[c->rank], (int32_t)getpid(), __ATOMIC_RELEASE);
     }
     __atomic_fetch_add(&s->attached, 1u, __ATOMIC_ACQ_REL);
