@@ -211,3 +211,38 @@ def test_dist_module_is_torch_free():
         for node in ast.walk(ast.parse(open(path).read())):
             names = [a.name for a in node.names] if isinstance(node, ast.Import) else ([node.module or ""] if isinstance(node, ast.ImportFrom) else [])
             assert not any(n.split(".")[0] == "torch" for n in names), path
+
+
+def test_result_pool_recycles_only_memory_nobody_holds():
+    """the binding's pool of result memory (contrack_amd/_native._ResultPool), GPU-free: a block returns to the pool when the LAST
+    view of the array handed out is gone, is handed out again for a result of the same size, and the pool never holds more than
+    its cap"""
+    import gc
+    from contrack_amd import _native
+
+    class FakeTracker:                       # (no handle: the pool then never registers anything with HIP)
+        handle = None
+    trk = FakeTracker()
+    pool = _native._ResultPool(trk)
+    shape = (40, 181, 360)                   # 10.4 MB: above the pool's threshold
+    a = pool.take(shape)
+    assert a.shape == shape and a.dtype == np.int32 and a.flags.writeable and a.flags.c_contiguous
+    a[...] = 7
+    addr = a.ctypes.data
+    v = a[3:5, 10]                           # a view keeps the block leased
+    del a
+    gc.collect()
+    b = pool.take(shape)
+    assert b.ctypes.data != addr and pool.hits == 0 and int(v[0, 0]) == 7
+    del v
+    gc.collect()
+    c = pool.take(shape)                     # now the first block is free again
+    assert c.ctypes.data == addr and pool.hits == 1
+    small = pool.take((4, 5, 6))             # small results are plain arrays
+    assert small.base is None or small.nbytes < (8 << 20)
+    pool.cap = b.nbytes                      # room for one block only
+    del b, c
+    gc.collect()
+    assert sum(x["mem"].nbytes for x in pool._free) <= pool.cap
+    pool.close()
+    assert pool._free == []
