@@ -387,14 +387,24 @@ def main():
                     keep.append(f)
                 del f
             return dict(ms_per_call=e2e * 1e3, timesteps_per_s=T / e2e, h2d_ms=lib["h2d"], h2d_gb_per_s=4.0 * px / lib["h2d"] / 1e6,
-                        d2h_ms=lib["d2h"], d2h_gb_per_s=4.0 * px / lib["d2h"] / 1e6)
+                        result_ms=lib["d2h"], result_gb_per_s=4.0 * px / lib["d2h"] / 1e6)
         rec = e2e_leg(False)
         fresh = e2e_leg(True)
-        out["e2e"] = dict(rec, fresh_result_arrays=fresh,
-                          note="pageable numpy slab in (plain hipMemcpy), numpy flag out over PCIe, includes the %.2f ms device pass.  Headline of "
-                               "this block: results dropped between calls (a loop over members) -- the binding recycles their memory, "
-                               "registered with HIP: ONE DMA.  fresh_result_arrays: every result kept alive, each call writes into pages that "
-                               "do not exist yet (8 threads draining pinned bounce buffers behind first-touch page faults)" % ms_per_step)
+        as_runs = trk.stats()["result_as_runs"]
+        # the same with the dense result slab written by k_relabel and copied over PCIe (ctk_set_result_transfer 0): the scheme of rounds 1-4
+        trk.set_result_transfer(0)
+        trk.track(a, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"])
+        dense = e2e_leg(False)
+        trk.set_result_transfer(-1)
+        out["e2e"] = dict(rec, result_transfer=("run tables, %d block(s) through the write kernel" % (as_runs - 1)) if as_runs else "dense copy",
+                          fresh_result_arrays=fresh, dense_copy=dense,
+                          note="pageable numpy slab in (plain hipMemcpy at PCIe rate), numpy flag out, includes the %.2f ms device pass.  The result "
+                               "crosses PCIe as the pass's run tables (bit mask + first run of every row + value of every run: 1/23 of the int32 "
+                               "slab here) and sixteen host threads expand them into the array -- result_gb_per_s is the array's size over that "
+                               "leg, bound by the host's DRAM writes, not a PCIe rate.  Headline of this block: results dropped between calls (a "
+                               "loop over members; the binding recycles their memory).  fresh_result_arrays: every result kept alive, each call "
+                               "writes into pages that do not exist yet.  dense_copy: k_relabel writes the slab in HBM, one DMA into the recycled, "
+                               "registered array" % ms_per_step)
     # ensemble members side by side: four handles (own streams and work spaces) driven by four host threads on this one GPU.
     # Not `value` (that is one pass after the other on one handle): what a job with many independent slabs -- BASELINE.json
     # configs[4], 35 members -- gets from the latency-bound middle of one pass running underneath the streaming of another.

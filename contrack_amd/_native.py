@@ -24,7 +24,7 @@ EXPORTS = [
     "ctk_track_f32_dev", "ctk_track_f64", "ctk_track_f64_dev", "ctk_release_io", "ctk_shard_label2d", "ctk_shard_label2d_f64", "ctk_shard_halo_size", "ctk_shard_halo_export",
     "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_resolve", "ctk_result_free",
     "ctk_result_info", "ctk_result_arrays", "ctk_result_nshards", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
-    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_set_seam_caps", "ctk_debug_set_spin", "ctk_debug_set_xcd", "ctk_debug_set_relabel", "ctk_debug_set_small_threads", "ctk_debug_np_sum", "ctk_debug_boundary_resolve", "ctk_set_timing", "ctk_get_timings", "ctk_get_timing_sums", "ctk_set_device_resolve", "ctk_set_fused_pass", "ctk_set_filter_round", "ctk_get_stats",
+    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_set_seam_caps", "ctk_debug_set_spin", "ctk_debug_set_xcd", "ctk_debug_set_relabel", "ctk_debug_set_small_threads", "ctk_debug_np_sum", "ctk_debug_boundary_resolve", "ctk_set_timing", "ctk_get_timings", "ctk_get_timing_sums", "ctk_set_device_resolve", "ctk_set_fused_pass", "ctk_set_result_transfer", "ctk_set_filter_round", "ctk_get_stats",
     "ctk_dev_malloc", "ctk_dev_free", "ctk_host_alloc", "ctk_host_free", "ctk_host_register", "ctk_host_unregister", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
     "ctk_synth_fill",
     "ctk_comm_unique_id", "ctk_comm_init_rccl", "ctk_comm_group_create", "ctk_comm_group_destroy", "ctk_comm_init_local", "ctk_comm_init_shm",
@@ -115,6 +115,7 @@ def lib():
     L.ctk_get_timing_sums.argtypes = [p, p, p, i32]
     L.ctk_set_device_resolve.argtypes = [p, i32]
     L.ctk_set_fused_pass.argtypes = [p, i32]
+    L.ctk_set_result_transfer.argtypes = [p, i32]
     L.ctk_get_stats.argtypes = [p, p]
     L.ctk_set_filter_round.argtypes = [p, i32]
     L.ctk_dev_malloc.argtypes = [p, pp, sz]
@@ -396,8 +397,9 @@ class _ResultPool:
         else:
             self.hits += 1
             trk = self._trk()
-            if not blk["registered"] and trk is not None and trk.handle:
-                # (touched by its first use: registration is cheap now; a failure just leaves the block pageable)
+            if not blk["registered"] and trk is not None and trk.handle and not trk.result_as_runs:
+                # (touched by its first use: registration is cheap now; a failure just leaves the block pageable.  With the
+                # result travelling as run tables -- the default -- host threads write the block: nothing to register)
                 blk["registered"] = lib().ctk_host_register(trk.handle, blk["mem"].ctypes.data, blk["mem"].nbytes) == 0
         carr = (C.c_ubyte * nbytes).from_address(blk["mem"].ctypes.data)
         with self._lock:
@@ -752,12 +754,28 @@ class Tracker:
         """the one-call entries without a host hand-off (default) or always on the synchronous path"""
         check(lib().ctk_set_fused_pass(self._h, int(bool(enable))))
 
+    def set_result_transfer(self, mode=-1):
+        """how the host-array entries bring the result over PCIe: 1 run tables expanded by host threads (default), 0 the dense
+        slab written by k_relabel, -1 the environment's choice (CTK_RLE_OUT)"""
+        check(lib().ctk_set_result_transfer(self._h, int(mode)))
+        self._transfer_mode = int(mode)
+
+    @property
+    def result_as_runs(self):
+        m = getattr(self, "_transfer_mode", -1)
+        if m >= 0:
+            return m == 1
+        import re
+        v = os.environ.get("CTK_RLE_OUT")                      # (as the library reads it: atoi)
+        mt = re.match(r"\s*[+-]?\d+", v) if v is not None else None
+        return v is None or (mt is not None and int(mt.group(0)) != 0)
+
     def stats(self):
         v = np.zeros(24, dtype=np.int64)
         check(lib().ctk_get_stats(self._h, v.ctypes.data))
         names = ["runs", "max_runs_per_step", "components", "pairs", "seam_rows_to_driver", "labels_3d", "seam_ops",
                  "filter_passes", "host_path", "seam_loop_ns", "seam_folds", "seam_copy_ns", "ungrouped_pairs", "pair_table_regrows", "filter_rounds",
-                 "ambiguous_decisions", "exact_fixups", "shared_seam_rows", "off_fused_path_reason", "relabel_kernel", "fused_pass", "x4_speculated"]
+                 "ambiguous_decisions", "exact_fixups", "shared_seam_rows", "off_fused_path_reason", "relabel_kernel", "fused_pass", "x4_speculated", "result_as_runs"]
         return dict(zip(names, v.tolist()))
 
     def debug_set_pair_capacity(self, records):

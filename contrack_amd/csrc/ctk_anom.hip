@@ -281,14 +281,7 @@ extern "C" int ctk_track_resident(ctk_handle *h, const double *thr, int cmp_op, 
     if (!h || !flag) return ctk_set_error(CTK_E_INVALID, "null argument");
     if (h->an_T < 1) return ctk_set_error(CTK_E_STATE, "ctk_track_resident: no anomaly slab is resident (ctk_anom_* with keep_resident)");
     HIPCHK(hipSetDevice(h->device));
-    const int64_t T = h->an_T;
-    const size_t n = (size_t)T * h->an_ny * h->an_nx;
-    CTKCHK(ensure(h, h->io_out, n * 4));
-    int rc = track_dev_impl(h, h->an_out.p, h->an_f64, T, h->an_ny, h->an_nx, thr, cmp_op, wrow, overlap, persistence, twosided, P<int32_t>(h->io_out), n_tracked);
-    if (rc != CTK_OK) return rc;
-    if (!h->bounce) h->bounce = new (std::nothrow) BouncePool();
-    if (!h->bounce || !bounce_copy(*h->bounce, h->device, h->io_out.p, flag, n * 4, false)) HIPCHK(hipMemcpy(flag, h->io_out.p, n * 4, hipMemcpyDeviceToHost));
-    return CTK_OK;
+    return track_to_host(h, h->an_out.p, h->an_f64, h->an_T, h->an_ny, h->an_nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag, n_tracked, nullptr);
 }
 
 template <typename VT, typename KT>

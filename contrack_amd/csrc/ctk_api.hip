@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <vector>
 #include <sys/mman.h>
+#include <emmintrin.h>
 #include <atomic>
 #include <thread>
 #include <functional>
@@ -51,7 +52,8 @@ static double now_ms_fwd() { return std::chrono::duration<double, std::milli>(st
 struct CtkEnv {
     int sd_dbg = 0, relabel_rows = 0, xcd_thr = 0, xcd_rel = 0, relabel_threads = 0;
     bool pass_launches = false, print_ptrs = false, seamstats = false, relabel_plain = false, relabel_v4 = false, hosttrace = false,
-         sh_no_slots = false, no_spec_x4 = false, sh_force_split = false, sh_host_seam = false;
+         sh_no_slots = false, no_spec_x4 = false, sh_force_split = false, sh_host_seam = false, rle_out = true;
+    int rle_lanes = 0, rle_per_lane = 0;
     CtkEnv()
     {
         auto num = [](const char *k) { const char *e = getenv(k); return e ? atoi(e) : 0; };
@@ -60,6 +62,8 @@ struct CtkEnv {
         pass_launches = on("CTK_PASS_LAUNCHES"); print_ptrs = on("CTK_PRINT_PTRS"); seamstats = on("CTK_SEAMSTATS");
         relabel_plain = on("CTK_RELABEL_PLAIN"); relabel_v4 = on("CTK_RELABEL_V4"); hosttrace = on("CTK_HOSTTRACE");
         sh_no_slots = on("CTK_SH_NO_SLOTS"); no_spec_x4 = on("CTK_NO_SPEC_X4"); sh_force_split = on("CTK_SH_FORCE_SPLIT"); sh_host_seam = on("CTK_SH_HOST_SEAM");
+        rle_out = !(getenv("CTK_RLE_OUT") && num("CTK_RLE_OUT") == 0);
+        rle_lanes = num("CTK_RLE_LANES"); rle_per_lane = num("CTK_RLE_PER_LANE");
     }
 };
 static const CtkEnv &ctk_env() { static const CtkEnv e; return e; }
@@ -109,6 +113,45 @@ struct BouncePool {
     void destroy()
     {
         for (int i = 0; i < kLanes; i++) {
+            for (int b = 0; b < 2; b++) {
+                if (lane[i].pin[b]) (void)hipHostFree(lane[i].pin[b]);
+                if (lane[i].ev[b]) (void)hipEventDestroy(lane[i].ev[b]);
+                lane[i].pin[b] = nullptr; lane[i].ev[b] = nullptr;
+            }
+            if (lane[i].st) (void)hipStreamDestroy(lane[i].st);
+            lane[i].st = nullptr;
+        }
+        ready = false;
+    }
+};
+
+// Run-length transfer of the result (host-array entries, deliver_runs): lanes that fetch the tables of a block of timesteps
+// into their pinned buffers and expand them into the caller's array
+constexpr int kRleLanes = 16;
+constexpr size_t kRleBuf = (size_t)2 << 20;
+struct RleBlock { int64_t t0, nt; uint32_t r0, nr; };          // timesteps [t0, t0 + nt), runs [r0, r0 + nr) of run_val
+struct RlePool {
+    BounceLane lane[kRleLanes];
+    bool ready = false;
+    size_t cap = 0;                                 // bytes per buffer: kRleBuf, or one timestep's tables if those are larger
+    bool init(size_t need)
+    {
+        if (ready && need <= cap) return true;
+        destroy();
+        cap = std::max(kRleBuf, (need + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1));
+        for (int i = 0; i < kRleLanes; i++) {
+            bool ok = true;
+            for (int b = 0; b < 2 && ok; b++)
+                ok = hipHostMalloc(&lane[i].pin[b], cap, hipHostMallocNonCoherent) == hipSuccess && hipEventCreateWithFlags(&lane[i].ev[b], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipStreamCreateWithFlags(&lane[i].st, hipStreamNonBlocking) == hipSuccess;
+            if (!ok) { destroy(); return false; }
+        }
+        ready = true;
+        return true;
+    }
+    void destroy()
+    {
+        for (int i = 0; i < kRleLanes; i++) {
             for (int b = 0; b < 2; b++) {
                 if (lane[i].pin[b]) (void)hipHostFree(lane[i].pin[b]);
                 if (lane[i].ev[b]) (void)hipEventDestroy(lane[i].ev[b]);
@@ -189,6 +232,11 @@ struct ctk_handle {
     size_t pin_in_cap = 0, pin_out_cap = 0;
     double stream_ms[4] = {0, 0, 0, 0};
     BouncePool *bounce = nullptr;                  // created on first use
+    RlePool *rle = nullptr;                        // created on first use (deliver_runs)
+    std::vector<uint32_t> rle_run_base;            // host copy of run_base (deliver_runs)
+    std::vector<RleBlock> rle_blocks;
+    bool rle_out = false;                          // this call's result leaves the device as run tables: launch_relabel is a no-op
+    int rle_mode = -1;                             // ctk_set_result_transfer: -1 environment (CTK_RLE_OUT, default on), 0 dense copy, 1 runs
     // time-sharded path (ctk_sharded.hip)
     DevBuf sh_mask_next, sh_send, sh_recv, sh_prev, sh_elist, sh_ovr_slot, sh_ovr_val, sh_amb_list, sh_counts, sh_cl_shared, sh_cl_sent;
     uint32_t sh_stamp_seq = 0;
@@ -439,6 +487,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
     if (h->h_ops) (void)hipHostFree(h->h_ops);
     if (h->h_mail) (void)hipHostFree(h->h_mail);
     if (h->bounce) { h->bounce->destroy(); delete h->bounce; }
+    if (h->rle) { h->rle->destroy(); delete h->rle; }
     stream_teardown(h);
     if (h->h_mail1) (void)hipHostFree(h->h_mail1);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -541,6 +590,13 @@ extern "C" int ctk_set_filter_round(ctk_handle *h, int passes)
     if (!h || passes < 1 || passes > 32) return ctk_set_error(CTK_E_INVALID, "ctk_set_filter_round: 1..32 passes per round");
     h->filter_round = passes;
     h->async_passes = passes;                            // (the fused pass launches this many; it adapts from there)
+    return CTK_OK;
+}
+
+extern "C" int ctk_set_result_transfer(ctk_handle *h, int mode)
+{
+    if (!h || mode < -1 || mode > 1) return ctk_set_error(CTK_E_INVALID, "ctk_set_result_transfer: mode -1 (environment), 0 (dense copy) or 1 (run tables)");
+    h->rle_mode = mode;
     return CTK_OK;
 }
 
@@ -1657,6 +1713,7 @@ static int32_t *chunk_vals_for(ctk_handle *h, const int32_t *flag_dev, int *rows
 {
     const int rb = relabel_rows(h);
     *rows = rb;
+    if (h->rle_out) return nullptr;                                   // (no write kernel in this call)
     const int64_t nchunk = (h->ny + rb - 1) / rb;
     if (!relabel_fast_ok(h, flag_dev, rb) || nchunk > CTK_CV_MAXCHUNK) return nullptr;
     if (ensure(h, h->chunk_vals, (size_t)h->T * (size_t)nchunk * CTK_CV * 4) != CTK_OK) return nullptr;
@@ -1666,6 +1723,7 @@ static int32_t *chunk_vals_for(ctk_handle *h, const int32_t *flag_dev, int *rows
 // timesteps [t0, t0 + nt) of the shard into flag_dev (which starts at t0); nt < 0: the whole shard
 static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, bool with_fold, const int32_t *chunk_vals = nullptr, int64_t t0 = 0, int64_t nt = -1)
 {
+    if (h->rle_out) return CTK_OK;                                    // the result leaves as run tables (deliver_runs expands them on the host)
     if (nt < 0) nt = h->T;
     RelabelArgs a;
     const int rb = relabel_rows(h);                                   // (of the whole shard: the chunk values were built for it)
@@ -2100,6 +2158,248 @@ bool bounce_copy(BouncePool &pool, int device, void *dev, void *host, size_t byt
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// The result of a host-array entry over PCIe.  The device pass ends with the value of every foreground RUN (k_run_values) and the
+// bit mask the runs were cut from: 30 MB at 2707 x 181 x 360, where the dense int32 slab k_relabel would write is 706 MB -- 12.4 ms
+// of a 25.8 ms call at PCIe rate.  So the host entries do not launch the write kernel at all: the tables of a block of timesteps
+// (mask words, first run of every row, run values) travel into a lane's pinned buffer and the lane writes the block of the
+// caller's array from them -- zeros, then each run's id over its pixels.  No labelling happens here: every value was computed on the
+// device, this is the decoder of a run-length transfer format.  Runs of "complex" components (negative value: their pixels are
+// folded one by one through the seam operations, fold_pixel) are left to the device: the blocks that hold one are written by
+// k_relabel into a block-sized device buffer afterwards and copied densely.
+//   device-resident entries (ctk_track_*_dev, the time-shard path, the streaming entries): unchanged, k_relabel_v5 writes `flag`.
+//   CTK_RLE_OUT=0 / ctk_set_result_transfer(h, 0): the dense copy for the host entries too.
+// ------------------------------------------------------------------------------------------------
+namespace {
+// A row of the result leaves the core through non-temporal stores: the zeros of an empty row straight from a register, a row with
+// runs from a scratch row in L1.  Plain stores (memset + fills) into the array take a read-for-ownership of every line first and
+// hold a core at ~15 GB/s: 5 ms for the 706 MB of the 1 degree slab on sixteen lanes; only the partial lines at both ends of a
+// row are written that way.
+inline void stream_row(int32_t *dst, const int32_t *src /* nullptr: zeros */, size_t n)
+{
+    unsigned char *d = reinterpret_cast<unsigned char *>(dst);
+    const unsigned char *s = reinterpret_cast<const unsigned char *>(src);
+    size_t bytes = n * 4;
+    size_t head = (64 - ((uintptr_t)d & 63)) & 63;
+    if (head > bytes) head = bytes;
+    if (head) { if (s) { memcpy(d, s, head); s += head; } else memset(d, 0, head); d += head; bytes -= head; }
+    const size_t body = bytes & ~(size_t)63;
+    if (s) {
+        for (size_t i = 0; i < body; i += 64) {
+            const __m128i a0 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + i)), a1 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + i + 16));
+            const __m128i a2 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + i + 32)), a3 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s + i + 48));
+            _mm_stream_si128(reinterpret_cast<__m128i *>(d + i), a0); _mm_stream_si128(reinterpret_cast<__m128i *>(d + i + 16), a1);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(d + i + 32), a2); _mm_stream_si128(reinterpret_cast<__m128i *>(d + i + 48), a3);
+        }
+        if (bytes > body) memcpy(d + body, s + body, bytes - body);
+    } else {
+        const __m128i z = _mm_setzero_si128();
+        for (size_t i = 0; i < body; i += 64) {
+            _mm_stream_si128(reinterpret_cast<__m128i *>(d + i), z); _mm_stream_si128(reinterpret_cast<__m128i *>(d + i + 16), z);
+            _mm_stream_si128(reinterpret_cast<__m128i *>(d + i + 32), z); _mm_stream_si128(reinterpret_cast<__m128i *>(d + i + 48), z);
+        }
+        if (bytes > body) memset(d + body, 0, bytes - body);
+    }
+}
+
+// one block: tables in `buf` ([mask nt*ny*W u64][rowstart nt*ny u32, padded to 8][run values nr i32]) -> flag rows
+void rle_expand_block(const unsigned char *buf, const RleBlock &c, const uint32_t *run_base, int ny, int nx, int W, int32_t *flag, int32_t *scratch /* [W * 64] */,
+                      bool &zero, bool &complex_run)
+{
+    const size_t nrow = (size_t)c.nt * ny;
+    const uint64_t *mask = reinterpret_cast<const uint64_t *>(buf);
+    const uint32_t *rowstart = reinterpret_cast<const uint32_t *>(buf + nrow * W * 8);
+    const int32_t *rv = reinterpret_cast<const int32_t *>(buf + nrow * W * 8 + ((nrow * 4 + 7) & ~(size_t)7));
+    const int tail = nx - (W - 1) * 64;
+    const uint64_t last_valid = tail < 64 ? ((1ull << tail) - 1ull) : ~0ull;
+    bool z = false, cx = false;
+    for (int64_t t = 0; t < c.nt; t++) {
+        const int32_t *rvt = rv + (run_base[c.t0 + t] - c.r0);
+        for (int y = 0; y < ny; y++) {
+            const size_t row = (size_t)t * ny + y;
+            int32_t *out = flag + ((size_t)(c.t0 + t) * ny + y) * (size_t)nx;
+            const uint64_t *mw = mask + row * W;
+            uint64_t any = 0;
+            for (int w = 0; w < W; w++) any |= mw[w];
+            if (!any) { stream_row(out, nullptr, (size_t)nx); z = true; continue; }
+            memset(scratch, 0, (size_t)nx * 4);
+            uint32_t k = rowstart[row];
+            uint64_t prev = 0;
+            int32_t cur = 0;
+            int fg = 0;
+            for (int w = 0; w < W; w++) {
+                uint64_t m = mw[w];
+                if (w == W - 1) m &= last_valid;
+                if (!m) { prev = 0; continue; }
+                fg += __builtin_popcountll(m);
+                uint64_t mm = m;
+                int32_t *ow = scratch + (size_t)w * 64;
+                while (mm) {
+                    const int b = __builtin_ctzll(mm);
+                    const uint64_t sh = mm >> b;
+                    const int n = (~sh == 0ull) ? 64 : __builtin_ctzll(~sh);
+                    if (!(b == 0 && prev)) cur = rvt[k++];                      // a new run (else: the run continues from the word before)
+                    if (cur > 0) { for (int q = b; q < b + n; q++) ow[q] = cur; }
+                    else if (cur == 0) z = true;                               // filtered out (persistence): the zeros are there
+                    else cx = true;
+                    mm = (n >= 64 - b) ? 0ull : (mm & ~(((1ull << n) - 1ull) << b));
+                }
+                prev = m >> 63;
+            }
+            if (fg != nx) z = true;
+            stream_row(out, scratch, (size_t)nx);
+        }
+    }
+    _mm_sfence();
+    if (z) zero = true;
+    if (cx) complex_run = true;
+}
+}  // namespace
+
+// blocks of timesteps whose tables fit a lane buffer of `cap` bytes (a single timestep always does: rle_need)
+static size_t rle_per_t(int ny, int W) { return (size_t)ny * W * 8 + (size_t)ny * 4 + 16; }
+static size_t rle_need(const uint32_t *run_base, int64_t T, int ny, int W)
+{
+    uint32_t mx = 0;
+    for (int64_t t = 0; t < T; t++) mx = std::max(mx, run_base[t + 1] - run_base[t]);
+    return rle_per_t(ny, W) + (size_t)mx * 4;
+}
+static bool rle_blocks(const uint32_t *run_base, int64_t T, int ny, int W, size_t cap, std::vector<RleBlock> &out)
+{
+    const size_t per_t = rle_per_t(ny, W);
+    const int lanes_cfg = ctk_env().rle_lanes > 0 ? std::min(ctk_env().rle_lanes, kRleLanes) : kRleLanes, per_lane = ctk_env().rle_per_lane > 0 ? ctk_env().rle_per_lane : 8;
+    const int64_t want = std::max<int64_t>(1, (T + lanes_cfg * per_lane - 1) / (lanes_cfg * per_lane));        // ~8 blocks per lane (probe: tools/exp/rle_probe.py)
+    out.clear();
+    for (int64_t t0 = 0; t0 < T;) {
+        int64_t nt = 0;
+        while (t0 + nt < T && nt < want) {
+            const size_t bytes = (size_t)(nt + 1) * per_t + (size_t)(run_base[t0 + nt + 1] - run_base[t0]) * 4;
+            if (bytes > cap) break;
+            nt++;
+        }
+        if (nt == 0) return false;
+        out.push_back(RleBlock{t0, nt, run_base[t0], run_base[t0 + nt] - run_base[t0]});
+        t0 += nt;
+    }
+    return true;
+}
+
+// The pass is over (tables in ST_TABLES state, nothing running on the handle's stream): expand the result into `flag`.
+static int deliver_runs(ctk_handle *h, int persistence, int32_t *flag, int *wrote_background)
+{
+    const int64_t T = h->T;
+    const int ny = h->ny, nx = h->nx, W = h->W;
+    const double tr_begin = now_ms();
+    std::vector<uint32_t> &rb = h->rle_run_base;
+    rb.resize((size_t)T + 1);
+    HIPCHK(hipMemcpy(rb.data(), h->run_base.p, (size_t)(T + 1) * 4, hipMemcpyDeviceToHost));
+    std::vector<RleBlock> &blocks = h->rle_blocks;
+    if (!h->rle) h->rle = new (std::nothrow) RlePool();
+    if (!h->rle || !h->rle->init(rle_need(rb.data(), T, ny, W))) return ctk_set_error(CTK_E_NOMEM, "result transfer: no pinned memory for the lane buffers");
+    if (!rle_blocks(rb.data(), T, ny, W, h->rle->cap, blocks)) return ctk_set_error(CTK_E_INTERNAL, "result transfer: a timestep's tables do not fit a lane buffer");
+    const size_t nb = blocks.size();
+    const int lanes = (int)std::min<size_t>(ctk_env().rle_lanes > 0 ? std::min(ctk_env().rle_lanes, kRleLanes) : kRleLanes, nb);
+    std::atomic<int64_t> wait_us(0), exp_us(0);
+    std::atomic<bool> ok(true), zero(false);
+    std::vector<unsigned char> cx(nb, 0);                                          // blocks that hold a run of a complex component
+    const uint64_t *d_mask = P<uint64_t>(h->mask);
+    const uint32_t *d_rowstart = P<uint32_t>(h->rowstart);
+    const int32_t *d_rv = P<int32_t>(h->run_val);
+    auto work = [&](int li) {
+        if (hipSetDevice(h->device) != hipSuccess) { ok = false; return; }
+        BounceLane &L = h->rle->lane[li];
+        auto fetch = [&](size_t bi, int b) {
+            const RleBlock &c = blocks[bi];
+            const size_t nrow = (size_t)c.nt * ny;
+            unsigned char *dst = (unsigned char *)L.pin[b];
+            bool good = hipMemcpyAsync(dst, d_mask + (size_t)c.t0 * ny * W, nrow * W * 8, hipMemcpyDeviceToHost, L.st) == hipSuccess;
+            good = good && hipMemcpyAsync(dst + nrow * W * 8, d_rowstart + (size_t)c.t0 * ny, nrow * 4, hipMemcpyDeviceToHost, L.st) == hipSuccess;
+            if (c.nr) good = good && hipMemcpyAsync(dst + nrow * W * 8 + ((nrow * 4 + 7) & ~(size_t)7), d_rv + c.r0, (size_t)c.nr * 4, hipMemcpyDeviceToHost, L.st) == hipSuccess;
+            good = good && hipEventRecord(L.ev[b], L.st) == hipSuccess;
+            if (!good) ok = false;
+        };
+        int b = 0;
+        std::vector<int32_t> scratch((size_t)W * 64 + 16);
+        if ((size_t)li < nb) fetch((size_t)li, 0);
+        for (size_t bi = (size_t)li; bi < nb && ok; bi += (size_t)lanes, b ^= 1) {
+            if (bi + (size_t)lanes < nb) fetch(bi + (size_t)lanes, b ^ 1);              // the next block travels while this one is expanded
+            const double w0 = now_ms();
+            if (hipEventSynchronize(L.ev[b]) != hipSuccess) { ok = false; break; }
+            const double w1 = now_ms();
+            bool z = false, c1 = false;
+            rle_expand_block((const unsigned char *)L.pin[b], blocks[bi], rb.data(), ny, nx, W, flag, scratch.data(), z, c1);
+            if (ctk_env().hosttrace) { wait_us += (int64_t)((w1 - w0) * 1e3); exp_us += (int64_t)((now_ms() - w1) * 1e3); }
+            if (z) zero = true;
+            if (c1) cx[bi] = 1;
+        }
+        (void)hipStreamSynchronize(L.st);                                             // (nothing of this call is left in flight on an error path)
+    };
+    std::vector<std::thread> th;
+    th.reserve((size_t)lanes);
+    for (int i = 0; i < lanes; i++) th.emplace_back(work, i);
+    const double tr1 = now_ms();
+    for (auto &t : th) t.join();
+    if (ctk_env().hosttrace) fprintf(stderr, "runs: %zu blocks on %d lanes | setup %.2f ms, lanes %.2f ms (per lane: waiting %.2f, expanding %.2f)\n", nb, lanes, tr1 - tr_begin, now_ms() - tr1, wait_us / 1e3 / lanes, exp_us / 1e3 / lanes);
+    if (!ok) return ctk_set_error(CTK_E_NODEVICE, "result transfer (run tables) failed: %s", hipGetErrorString(hipGetLastError()));
+    // blocks with complex components: the write kernel, block by block
+    int64_t ndense = 0;
+    const size_t plane = (size_t)ny * nx;
+    for (size_t bi = 0; bi < nb; bi++) {
+        if (!cx[bi]) continue;
+        const RleBlock &c = blocks[bi];
+        CTKCHK(ensure(h, h->io_out, (size_t)c.nt * plane * 4));
+        h->rle_out = false;
+        const int rc = launch_relabel(h, persistence, P<int32_t>(h->io_out), true, nullptr, c.t0, c.nt);
+        h->rle_out = true;
+        CTKCHK(rc);
+        int32_t *dst = flag + (size_t)c.t0 * plane;
+        HIPCHK(hipMemcpyAsync(dst, h->io_out.p, (size_t)c.nt * plane * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (!zero) { for (size_t i = 0; i < (size_t)c.nt * plane; i++) if (dst[i] == 0) { zero = true; break; } }
+        ndense++;
+    }
+    h->stats[CTK_S_RLE_OUT] = 1 + ndense;
+    *wrote_background = zero ? 1 : 0;
+    return 0;
+}
+
+// device pass + delivery of the result into the caller's host array (ctk_track_f32 / _f64 / ctk_track_resident)
+static int track_to_host(ctk_handle *h, const void *a_dev, bool f64, int64_t T, int ny, int nx, const double *thr, int cmp_op, const float *wrow,
+                         double overlap, int persistence, int twosided, int32_t *flag, int64_t *n_tracked, double *t_pass_end)
+{
+    const size_t n = (size_t)T * ny * nx;
+    // (grids beyond 8 M pixels per timestep: the dense copy -- a timestep's tables are meant to fit a lane buffer of a few MB)
+    const bool want_runs = n > 0 && (h->rle_mode < 0 ? ctk_env().rle_out : h->rle_mode == 1) && rle_per_t(ny, (nx + 63) / 64) <= kRleBuf / 2;
+    // the dense result lives in the handle (grow-only); with the run transfer only the blocks of complex components ever need it
+    CTKCHK(ensure(h, h->io_out, want_runs ? 256 : std::max<size_t>(n * 4, 256)));
+    int32_t *f_dev = P<int32_t>(h->io_out);
+    h->stats[CTK_S_RLE_OUT] = 0;
+    int rc;
+    {
+        h->rle_out = want_runs;
+        struct RleOff { ctk_handle *h; ~RleOff() { h->rle_out = false; } } rle_off{h};
+        rc = track_dev_impl(h, a_dev, f64, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, f_dev, n_tracked);
+        if (t_pass_end) *t_pass_end = now_ms();
+        if (rc != CTK_OK || !n) return rc;
+        // huge pages where the allocation allows (the pages of a fresh result do not exist yet)
+        const uintptr_t a0 = ((uintptr_t)flag + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1), a1 = ((uintptr_t)flag + n * 4) & ~(((uintptr_t)2 << 20) - 1);
+        if (a1 > a0) (void)madvise((void *)a0, a1 - a0, MADV_HUGEPAGE);
+        if (want_runs) {
+            int wrote0 = 0;
+            CTKCHK(deliver_runs(h, persistence, flag, &wrote0));
+            if (n_tracked) *n_tracked = h->last_alive + (wrote0 ? 1 : 0) - 1;              // len(np.unique(flag)) - 1, contrack.py:793
+            return CTK_OK;
+        }
+    }
+    // the parallel copy; plain hipMemcpy for small results / if the lanes fail
+    if (!h->bounce) h->bounce = new (std::nothrow) BouncePool();
+    if (!h->bounce || !bounce_copy(*h->bounce, h->device, f_dev, flag, n * 4, false)) {
+        hipError_t e = hipMemcpy(flag, f_dev, n * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return ctk_set_error(CTK_E_NODEVICE, "D2H copy failed: %s", hipGetErrorString(e));
+    }
+    return CTK_OK;
+}
+
 static int track_host_impl(ctk_handle *h, const void *anom, bool f64, int64_t T, int ny, int nx, const double *thr, int cmp_op, const float *wrow,
                            double overlap, int persistence, int twosided, int32_t *flag, int64_t *n_tracked)
 {
@@ -2108,12 +2408,10 @@ static int track_host_impl(ctk_handle *h, const void *anom, bool f64, int64_t T,
     HIPCHK(hipSetDevice(h->device));
     const size_t n = (size_t)T * ny * nx, esz = f64 ? 8 : 4;
     void *a_dev = nullptr;
-    int32_t *f_dev = nullptr;
     if (n) {
-        // device copies of the caller's slab and of the result live in the handle (grow-only), like every other buffer
+        // the device copy of the caller's slab lives in the handle (grow-only), like every other buffer
         CTKCHK(ensure(h, h->io_in, n * esz));
-        CTKCHK(ensure(h, h->io_out, n * 4));
-        a_dev = h->io_in.p; f_dev = P<int32_t>(h->io_out);
+        a_dev = h->io_in.p;
     }
     const double e0 = now_ms();
     if (n) {
@@ -2121,20 +2419,10 @@ static int track_host_impl(ctk_handle *h, const void *anom, bool f64, int64_t T,
         if (e != hipSuccess) return ctk_set_error(CTK_E_NODEVICE, "H2D copy failed: %s", hipGetErrorString(e));
     }
     const double e1 = now_ms();
-    int rc = track_dev_impl(h, a_dev, f64, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, f_dev, n_tracked);
-    const double e2 = now_ms();
-    if (rc == CTK_OK && n) {
-        // huge pages where the allocation allows, then the parallel copy; plain hipMemcpy for small results / if the lanes fail
-        const uintptr_t a0 = ((uintptr_t)flag + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1), a1 = ((uintptr_t)flag + n * 4) & ~(((uintptr_t)2 << 20) - 1);
-        if (a1 > a0) (void)madvise((void *)a0, a1 - a0, MADV_HUGEPAGE);
-        if (!h->bounce) h->bounce = new (std::nothrow) BouncePool();
-        if (!h->bounce || !bounce_copy(*h->bounce, h->device, f_dev, flag, n * 4, false)) {
-            hipError_t e = hipMemcpy(flag, f_dev, n * 4, hipMemcpyDeviceToHost);
-            if (e != hipSuccess) rc = ctk_set_error(CTK_E_NODEVICE, "D2H copy failed: %s", hipGetErrorString(e));
-        }
-    }
+    double e2 = e1;
+    const int rc = track_to_host(h, a_dev, f64, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, flag, n_tracked, &e2);
     const double e3 = now_ms();
-    if (ctk_env().hosttrace) fprintf(stderr, "e2e: H2D %.1f ms | device path %.2f ms | D2H %.1f ms\n", e1 - e0, e2 - e1, e3 - e2);
+    if (ctk_env().hosttrace) fprintf(stderr, "e2e: H2D %.1f ms | device path %.2f ms | result %.1f ms (%s)\n", e1 - e0, e2 - e1, e3 - e2, h->stats[CTK_S_RLE_OUT] ? "runs" : "dense");
     h->ms[CTK_T_H2D] = e1 - e0; h->ms[CTK_T_D2H] = e3 - e2; h->ms[CTK_T_TOTAL] = e3 - e0;      // (whole-call figures of the host entry)
     return rc;
 }
@@ -2312,6 +2600,7 @@ extern "C" int ctk_release_io(ctk_handle *h)
     for (DevBuf *b : {&h->io_in, &h->io_out, &h->an_out, &h->an_raw}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     h->an_T = -1; h->an_gen++;
     if (h->bounce) { h->bounce->destroy(); delete h->bounce; h->bounce = nullptr; }
+    if (h->rle) { h->rle->destroy(); delete h->rle; h->rle = nullptr; }
     stream_teardown(h);
     return CTK_OK;
 }

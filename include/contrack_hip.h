@@ -277,6 +277,9 @@ int ctk_get_timing_sums(ctk_handle *h, double *sums, int64_t *counts, int reset)
 #define CTK_S_FUSED         20    /* 1: the one-call pass ran without a host hand-off (device seam driver, one synchronisation) */
 #define CTK_S_X4_SPECULATED 21    /* time-sharded path: 1 if the boundary records of the 3-D labelling travelled with the last round of
                                    * the overlap filter's exchange (one all-gather less) */
+#define CTK_S_RLE_OUT       22    /* host-array entries: 0 = the result was written by k_relabel and copied densely; n > 0 = it travelled as
+                                   * run tables and was expanded on the host, n - 1 blocks of timesteps (those holding complex
+                                   * components) went through the write kernel */
 #define CTK_NSTATS          24
 int ctk_get_stats(ctk_handle *h, int64_t *out /* [CTK_NSTATS] */);
 /* filter passes launched per round before convergence is checked on the host (default 10, 1..32)   */
@@ -315,6 +318,14 @@ int ctk_sync(ctk_handle *h);
  * are produced in a loop (ensemble members): contrack_amd/_native.py recycles such blocks. */
 int ctk_host_alloc(ctk_handle *h, void **p, size_t nbytes);
 int ctk_host_free(ctk_handle *h, void *p);
+/* How the result of the host-array entries crosses PCIe.  1 (default; CTK_RLE_OUT=0 in the environment turns it off): as the
+ * pass's own run tables -- the bit mask, the first run of every row and the final value of every foreground run (k_run_values),
+ * 1/23 of the dense int32 slab at 2707 x 181 x 360 --, expanded into `flag` by sixteen host threads; the write kernel does not
+ * run (blocks of timesteps that hold a "complex" component, whose pixels are folded one by one, still go through it).  Every
+ * value is computed on the device; the host only decodes.  0: k_relabel writes the dense slab in HBM and it is copied (the
+ * scheme above).  -1: back to the environment's choice.  The device-resident entries always write `flag_dev` densely.
+ * CTK_S_RLE_OUT reports what a call did.  (contrack.py:776-791: where the reference materialises `flag`) */
+int ctk_set_result_transfer(ctk_handle *h, int mode);
 int ctk_host_register(ctk_handle *h, void *p, size_t nbytes);
 int ctk_host_unregister(ctk_handle *h, void *p);
 void *ctk_stream(ctk_handle *h);                          /* hipStream_t */

@@ -97,9 +97,11 @@ def test_stream_exact_fixups_reread_the_input(trk):
     assert st["exact_fixups"] > 0 and reads == 2 * list(range(0, T, 4))
 
 
-def test_result_memory_is_recycled_and_results_stay_valid():
-    """the binding recycles the memory of dropped results (registered with HIP on reuse: one DMA instead of bounce buffers behind
-    page faults); arrays still held -- and views of them -- are never overwritten"""
+@pytest.mark.parametrize("mode", [1, 0], ids=["runs", "dense"])
+def test_result_memory_is_recycled_and_results_stay_valid(mode):
+    """the binding recycles the memory of dropped results (with the dense copy: registered with HIP on reuse, one DMA instead of
+    bounce buffers behind page faults; with the run transfer: touched pages for the host threads that write it); arrays still
+    held -- and views of them -- are never overwritten"""
     import gc
     from contrack_amd import synth
     from contrack_amd.contrack import row_weights
@@ -110,6 +112,8 @@ def test_result_memory_is_recycled_and_results_stay_valid():
     w = row_weights(lat, np.float32(1.0), np.float32(1.0))
     thr = np.full(T, 160.0)
     with _native.Tracker(0) as t:
+        t.set_result_transfer(mode)
+        assert t.result_as_runs == (mode == 1)
         fa, na = t.track(a, thr, 0, w, 0.5, 3, True)
         keep_a = fa.copy()
         view = fa[5:7]                                           # a view keeps the block leased
@@ -122,8 +126,9 @@ def test_result_memory_is_recycled_and_results_stay_valid():
         del view, fb
         gc.collect()
         assert t._pool.hits == 0
-        fa2, na2 = t.track(a, thr, 0, w, 0.5, 3, True)           # recycled block (registered now)
+        fa2, na2 = t.track(a, thr, 0, w, 0.5, 3, True)           # recycled block (registered now if the copy is dense)
         assert t._pool.hits == 1 and np.array_equal(fa2, keep_a) and na2 == na
+        assert (t.stats()["result_as_runs"] >= 1) == (mode == 1)
         fb2, nb2 = t.track(b, thr, 0, w, 0.5, 3, True)
         assert t._pool.hits == 2 and np.array_equal(fb2, keep_b) and nb2 == nb and np.array_equal(fa2, keep_a)
         out = np.empty((T, ny, nx), np.int32)
