@@ -2363,13 +2363,18 @@ static int deliver_runs(ctk_handle *h, int persistence, int32_t *flag, int *wrot
     return 0;
 }
 
+// (grids beyond 8 M pixels per timestep: the dense copy -- a timestep's tables are meant to fit a lane buffer of a few MB)
+static bool runs_wanted(const ctk_handle *h, int ny, int nx)
+{
+    return (h->rle_mode < 0 ? ctk_env().rle_out : h->rle_mode == 1) && rle_per_t(ny, (nx + 63) / 64) <= kRleBuf / 2;
+}
+
 // device pass + delivery of the result into the caller's host array (ctk_track_f32 / _f64 / ctk_track_resident)
 static int track_to_host(ctk_handle *h, const void *a_dev, bool f64, int64_t T, int ny, int nx, const double *thr, int cmp_op, const float *wrow,
                          double overlap, int persistence, int twosided, int32_t *flag, int64_t *n_tracked, double *t_pass_end)
 {
     const size_t n = (size_t)T * ny * nx;
-    // (grids beyond 8 M pixels per timestep: the dense copy -- a timestep's tables are meant to fit a lane buffer of a few MB)
-    const bool want_runs = n > 0 && (h->rle_mode < 0 ? ctk_env().rle_out : h->rle_mode == 1) && rle_per_t(ny, (nx + 63) / 64) <= kRleBuf / 2;
+    const bool want_runs = n > 0 && runs_wanted(h, ny, nx);
     // the dense result lives in the handle (grow-only); with the run transfer only the blocks of complex components ever need it
     CTKCHK(ensure(h, h->io_out, want_runs ? 256 : std::max<size_t>(n * 4, 256)));
     int32_t *f_dev = P<int32_t>(h->io_out);
@@ -2495,6 +2500,7 @@ static int stream_in(ctk_handle *h, bool f64, int64_t T, int ny, int nx, const s
 // output phase: k_relabel writes chunk k+1 into one device buffer while chunk k leaves the other
 static int stream_out(ctk_handle *h, int persistence, const int32_t *chunk_vals)
 {
+    if (h->rle_out) return CTK_OK;                                               // (array sink: the result leaves as run tables after the pass)
     StreamIO &io = *h->sio;
     const int64_t T = h->T;
     const size_t plane = (size_t)h->ny * h->nx * 4, cbytes = (size_t)io.chunk * plane;
@@ -2555,8 +2561,23 @@ static int track_stream_impl(ctk_handle *h, StreamIO &io, bool f64, int64_t T, i
     io.chunk = std::max<int64_t>(1, std::min<int64_t>(io.chunk, std::max<int64_t>(T, 1)));
     const double t0 = now_ms();
     h->sio = &io;
-    const int rc = track_dev_impl(h, nullptr, f64, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, nullptr, n_tracked);
+    // an array as the sink: the result needs no chunks -- the run tables of the whole slab are resident when the pass is over
+    // (deliver_runs); a writer callback gets dense chunks in pinned buffers as before
+    h->rle_out = T > 0 && io.host_out && runs_wanted(h, ny, nx);
+    h->stats[CTK_S_RLE_OUT] = 0;
+    int rc = track_dev_impl(h, nullptr, f64, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, nullptr, n_tracked);
     h->sio = nullptr;
+    if (rc == CTK_OK && h->rle_out) {
+        const double o0 = now_ms();
+        const size_t nb = (size_t)T * ny * nx * 4;
+        const uintptr_t a0 = ((uintptr_t)io.host_out + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1), a1 = ((uintptr_t)io.host_out + nb) & ~(((uintptr_t)2 << 20) - 1);
+        if (a1 > a0) (void)madvise((void *)a0, a1 - a0, MADV_HUGEPAGE);
+        int wrote0 = 0;
+        rc = deliver_runs(h, persistence, io.host_out, &wrote0);
+        if (rc == CTK_OK && n_tracked) *n_tracked = h->last_alive + (wrote0 ? 1 : 0) - 1;      // len(np.unique(flag)) - 1, contrack.py:793
+        io.ms_out += now_ms() - o0;
+    }
+    h->rle_out = false;
     h->stream_ms[0] = io.ms_read; h->stream_ms[1] = io.ms_write; h->stream_ms[2] = io.ms_in; h->stream_ms[3] = io.ms_out;
     h->ms[CTK_T_H2D] = io.ms_in; h->ms[CTK_T_D2H] = io.ms_out; h->ms[CTK_T_TOTAL] = now_ms() - t0;
     return rc;

@@ -103,3 +103,20 @@ def test_f64_entry(trk):
     f0, n0 = trk.track(anom, np.full(T, 150.0), _native.CMP_OPS[">="], wrow, 0.5, 3, True, f64=True)
     trk.set_result_transfer(-1)
     assert n0 == n1 and np.array_equal(f0, f1) and n1 > 0
+
+
+@pytest.mark.parametrize("chunk", [7, 64])
+def test_streaming_entry_with_an_array_sink(trk, chunk):
+    """ctk_track_stream_*: the slab arrives in chunks, the result leaves as run tables once the pass is over (a writer callback
+    still gets dense chunks)"""
+    T, ny, nx = 150, 91, 180
+    anom = synth.smooth_field(T, ny, nx, seed=31)
+    wrow = np.cos(np.deg2rad(np.linspace(-89, 89, ny))).astype(np.float32)
+    thr = np.full(T, 150.0)
+    want, nw = trk.track(anom, thr, 0, wrow, 0.5, 4, True)
+    for mode in (1, 0):
+        trk.set_result_transfer(mode)
+        f, n = trk.track_stream(anom, thr, 0, wrow, 0.5, 4, True, chunk_steps=chunk)
+        assert (trk.stats()["result_as_runs"] >= 1) == (mode == 1)
+        assert n == nw and np.array_equal(f, want)
+    trk.set_result_transfer(-1)
