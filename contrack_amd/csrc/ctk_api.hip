@@ -2692,6 +2692,20 @@ extern "C" int ctk_debug_label2d(ctk_handle *h, int before_seam, int32_t *lab)
 // ------------------------------------------------------------------------------------------------
 static_assert(sizeof(ctk_life_row) == sizeof(CtkLifeRowDev), "row layouts must agree");
 
+// Rows per wave of k_life_strips: four waves (one workgroup) cover a band of the strip, `g` bands cover the ny rows without idle
+// waves at the end (181 rows: 4 x 46; 721 rows: 20 x 37).  Measured (us, 2707 x 181 x 360 | 480 x 721 x 1440): 16 rows 316 | 509,
+// 23: 291 | 474, 31: 379 (a quarter of the waves idle) | 441, 37: | 436, 46: 281 | 458, 61: | 433 -- long streams per wave, as long
+// as the launch keeps a few thousand workgroups.
+static int life_rows_per_wave(int64_t T, int ny, int nx)
+{
+    static const int env = getenv("CTK_LIFE_ROWS") ? atoi(getenv("CTK_LIFE_ROWS")) : 0;
+    if (env > 0) return env;
+    const int64_t nsx = (nx + LB_SW - 1) / LB_SW;
+    int g = std::max(1, (ny + 80) / 160);
+    while (T * nsx * g < 2048 && (ny + 4 * g - 1) / (4 * g) > 8) g++;
+    return std::max(1, (ny + 4 * g - 1) / (4 * g));
+}
+
 static int lifecycle_dev_impl(ctk_handle *h, const int32_t *flag_dev, const void *field_dev, bool f64, int64_t T, int ny, int nx, const float *wrow,
                               int64_t *nrows)
 {
@@ -2735,7 +2749,8 @@ static int lifecycle_dev_impl(ctk_handle *h, const int32_t *flag_dev, const void
     };
     // Banded form first (every byte read once, T x chunks workgroups); the time steps it gives up (more ids than its tables
     // hold) are redone by k_lifecycle, which splits further by residue classes of the ids.
-    const int nsx = (nx + LB_SW - 1) / LB_SW, nby = (ny + LB_R * (LB_THREADS / 64) - 1) / (LB_R * (LB_THREADS / 64)), nb = nsx * nby;
+    const int rw = life_rows_per_wave(T, ny, nx);
+    const int nsx = (nx + LB_SW - 1) / LB_SW, nby = (ny + rw * (LB_THREADS / 64) - 1) / (rw * (LB_THREADS / 64)), nb = nsx * nby;
     const size_t gkey_bytes = (size_t)T * LB_GH * 4, gacc_bytes = (size_t)T * LB_GH * sizeof(CtkLifeAcc);
     const size_t occ_bytes = (size_t)T * LB_KS * nxw * 4, cp_bytes = (size_t)T * LB_KS * nx * 8;
     if ((uint64_t)T * (uint64_t)nb > 0x7fffffffull) return ctk_set_error(CTK_E_RANGE, "ctk_lifecycle: %lld time steps x %d chunks beyond one launch", (long long)T, nb);
@@ -2755,14 +2770,17 @@ static int lifecycle_dev_impl(ctk_handle *h, const int32_t *flag_dev, const void
         HIPCHK(hipMemsetAsync(h->lc_occ.p, 0, occ_bytes, h->stream));
         HIPCHK(hipMemsetAsync(h->lc_cp.p, 0, cp_bytes, h->stream));
         k_life_seam<<<(unsigned)T, 64, 0, h->stream>>>(flag_dev, ny, nx, P<int32_t>(h->lc_cross), P<unsigned char>(h->lc_ovf));
-        if (f64)
-            k_life_strips<double><<<(unsigned)(T * nb), LB_THREADS, 0, h->stream>>>(flag_dev, (const double *)field_dev, ny, nx, nxw, nsx, nby, P<int64_t>(h->lc_wlo),
-                                                                                   P<int64_t>(h->lc_whi), P<float>(h->lc_w), P<int32_t>(h->lc_cross), gkey, gacc,
-                                                                                   P<unsigned>(h->lc_occ), P<double>(h->lc_cp), P<unsigned char>(h->lc_ovf));
-        else
-            k_life_strips<float><<<(unsigned)(T * nb), LB_THREADS, 0, h->stream>>>(flag_dev, (const float *)field_dev, ny, nx, nxw, nsx, nby, P<int64_t>(h->lc_wlo),
-                                                                                  P<int64_t>(h->lc_whi), P<float>(h->lc_w), P<int32_t>(h->lc_cross), gkey, gacc,
-                                                                                  P<unsigned>(h->lc_occ), P<double>(h->lc_cp), P<unsigned char>(h->lc_ovf));
+        {
+            const bool vec = (nx & 3) == 0 && (((uintptr_t)flag_dev) & 15u) == 0 && (((uintptr_t)field_dev) & (f64 ? 31u : 15u)) == 0;
+            const unsigned grid = (unsigned)(T * nb);
+#define CTK_LIFE_STRIPS(VT, VEC)                                                                                                                       \
+    k_life_strips<VT, VEC><<<grid, LB_THREADS, 0, h->stream>>>(flag_dev, (const VT *)field_dev, ny, nx, nxw, nsx, nby, rw, P<int64_t>(h->lc_wlo),      \
+                                                               P<int64_t>(h->lc_whi), P<float>(h->lc_w), P<int32_t>(h->lc_cross), gkey, gacc,         \
+                                                               P<unsigned>(h->lc_occ), P<double>(h->lc_cp), P<unsigned char>(h->lc_ovf))
+            if (f64) { if (vec) CTK_LIFE_STRIPS(double, true); else CTK_LIFE_STRIPS(double, false); }
+            else { if (vec) CTK_LIFE_STRIPS(float, true); else CTK_LIFE_STRIPS(float, false); }
+#undef CTK_LIFE_STRIPS
+        }
         k_life_finish<<<(unsigned)T, LB_GH, 0, h->stream>>>(nx, nxw, P<int32_t>(h->lc_cross), gkey, gacc, P<unsigned>(h->lc_occ), P<double>(h->lc_cp), wshift,
                                                             limb_bits, P<CtkLifeRowDev>(h->lc_rows), cap, P<unsigned long long>(h->lc_cnt),
                                                             P<unsigned char>(h->lc_ovf));

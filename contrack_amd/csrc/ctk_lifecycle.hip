@@ -273,8 +273,8 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
 
 
 // ------------------------------------------------------------------------------------------------
-// Strip form: the plane of one time step is cut into strips of LB_SW columns x 4 * LB_R rows, one workgroup each (one wave per
-// LB_R rows), so that a few hundred time steps of a 0.25-degree grid (10^6 pixels per plane) fill the chip, and every byte of
+// Strip form: the plane of one time step is cut into strips of LB_SW columns x 4 * rw rows, one workgroup each (one wave per
+// rw rows), so that a few hundred time steps of a 0.25-degree grid (10^6 pixels per plane) fill the chip, and every byte of
 // flag / field is read once.
 //   k_life_seam   per time step: the ids present in BOTH seam columns (x = 0, x = nx-1)               -> cross[t][LB_KS]
 //   k_life_strips a lane owns four columns and walks down the rows: inside a contour it adds to registers (no table look-up, no
@@ -289,13 +289,18 @@ __global__ __launch_bounds__(LC_THREADS) void k_lifecycle(const int32_t *__restr
 // ------------------------------------------------------------------------------------------------
 #define LB_THREADS 256
 #define LB_SW 256         // columns per strip: one wave, four per lane
-#define LB_R 16           // rows per wave; a workgroup = 4 waves = 64 rows of one strip
+// (rows per wave: a launch parameter -- life_rows_per_wave in ctk_api.hip; a workgroup = 4 waves = 4 x that many rows of one strip)
 #define LB_LH 128         // LDS hash slots per chunk (<= LB_LN ids)
 #define LB_LN 64
 #define LB_GH 256         // global hash slots per time step (<= LB_GN ids)
 #define LB_GN 128
 #define LB_KS 4           // seam-crossing ids per time step
-#define LB_BATCH 4        // flag loads in flight per lane
+#ifndef LB_PIPE
+#define LB_PIPE 1         // 1: three-stage load pipeline (k_life_strips), 0: one batch at a time
+#endif
+#ifndef LB_BATCH
+#define LB_BATCH 1        // rows per pipeline stage
+#endif
 
 struct CtkLifeAcc {
     unsigned long long lo, hi;      // area limbs
@@ -373,8 +378,10 @@ __device__ inline double row16_sum(double v)
     return v;
 }
 
-template <typename VT>
-__global__ __launch_bounds__(LB_THREADS) void k_life_strips(const int32_t *__restrict__ flag, const VT *__restrict__ field, int ny, int nx, int nxw, int nsx, int nby,
+// VEC: nx a multiple of 4 and both slabs aligned for one 16- / 32-byte request per lane and row (the host checks); a compile-time
+// choice so that no branch stands between the loads of the pipeline below
+template <typename VT, bool VEC>
+__global__ __launch_bounds__(LB_THREADS) void k_life_strips(const int32_t *__restrict__ flag, const VT *__restrict__ field, int ny, int nx, int nxw, int nsx, int nby, int rw,
                                                             const int64_t *__restrict__ wlo, const int64_t *__restrict__ whi, const float *__restrict__ wrow,
                                                             const int32_t *__restrict__ cross, int32_t *__restrict__ gkey, CtkLifeAcc *__restrict__ gacc,
                                                             unsigned *__restrict__ occ, double *__restrict__ cp, unsigned char *__restrict__ ovf)
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_life_strips(const int32_t *__res
     const int64_t t = blockIdx.x / per_t;
     const unsigned rem = blockIdx.x % per_t;
     const int x0 = (int)(rem % (unsigned)nsx) * LB_SW + lane * 4;          // this lane's four columns, the same in every row
-    const int ya = ((int)(rem / (unsigned)nsx) * (LB_THREADS / 64) + wave) * LB_R, yb = min(ny, ya + LB_R);
+    const int ya = ((int)(rem / (unsigned)nsx) * (LB_THREADS / 64) + wave) * rw, yb = min(ny, ya + rw);
     for (int s = tid; s < LB_LH; s += LB_THREADS) { hkey[s] = 0; alo[s] = 0; ahi[s] = 0; swv[s] = 0.0; swvy[s] = 0.0; swvx[s] = 0.0; ytop[s] = 0u; ybot[s] = 0u; }
     if (tid == 0) { bad = 0; skip = ovf[t]; }                              // the seam kernel (or a sibling) already gave the time step up
     __syncthreads();
@@ -398,8 +405,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_life_strips(const int32_t *__res
     const uint32_t npx = (uint32_t)ny * (uint32_t)nx;
     const int32_t *fp = flag + t * (int64_t)npx;
     const VT *vp = field + t * (int64_t)npx;
-    const bool vec = (nx & 3) == 0 && (((uintptr_t)flag) & 15u) == 0;
-    const bool vecv = vec && (((uintptr_t)field) & (4 * sizeof(VT) - 1)) == 0;
+    constexpr bool vec = VEC, vecv = VEC;
     const int32_t *cr = cross + t * (LB_KS + 1);
     const int ncr = cr[0];
     int32_t cid[LB_KS];
@@ -444,47 +450,76 @@ __global__ __launch_bounds__(LB_THREADS) void k_life_strips(const int32_t *__res
         hc[0] = hc[1] = hc[2] = hc[3] = 0.0;
     };
 
-    // uniform loops: whole waves take part in the ballots.  The flags of LB_BATCH rows are requested before the first is looked
-    // at, then the field values of the rows that hold foreground (one load in flight per lane = bound by latency, not bandwidth).
+    // uniform loops: whole waves take part in the ballots.  A three-stage pipeline over batches of LB_BATCH rows: while batch i is
+    // added up, the field values of batch i + 1 and the flags of batch i + 2 are in flight.  Nothing around the loads is
+    // conditional (a branch makes hipcc wait for every outstanding load at the join): rows beyond the wave's last read row yb - 1
+    // again, lanes beyond the grid read column 0, and a lane whose four flags are all background reads the plane's first field
+    // values -- one cached line for the whole wave -- instead of its own (9 in 10 lanes: the field costs a fraction of its 4 B per
+    // pixel in HBM traffic).
+    const int xl = x0 < nx ? x0 : 0;
+    auto load_flags = [&](int4 (&q)[LB_BATCH], int y0) {
+#pragma unroll
+        for (int u = 0; u < LB_BATCH; ++u) {
+            const int yy = min(y0 + u, yb - 1);
+            const int32_t *rp = fp + (size_t)yy * nx + xl;
+            if (vec) {
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+                const i32x4 qq = __builtin_nontemporal_load((const i32x4 *)rp);
+                q[u] = make_int4(qq.x, qq.y, qq.z, qq.w);
+            } else {
+                q[u].x = rp[0];
+                q[u].y = (xl + 1 < nx) ? rp[1] : 0;
+                q[u].z = (xl + 2 < nx) ? rp[2] : 0;
+                q[u].w = (xl + 3 < nx) ? rp[3] : 0;
+            }
+        }
+    };
+    // (what was read for rows beyond yb or columns beyond nx is masked where it is USED: overwriting a register a load is still
+    // filling would make the wave wait for that load right there)
+    const bool lane_in = x0 < nx;
+    auto load_fields = [&](VT (&v)[LB_BATCH][4], const int4 (&q)[LB_BATCH], int y0) {
+#pragma unroll
+        for (int u = 0; u < LB_BATCH; ++u) {
+            const bool any = lane_in && y0 + u < yb && (q[u].x | q[u].y | q[u].z | q[u].w) != 0;
+            if (vecv) {
+                const VT *rp = any ? vp + (size_t)(y0 + u) * nx + x0 : vp;
+                __builtin_memcpy(v[u], (const void *)rp, sizeof(v[u]));                    // one 16- / 32-byte request
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[u][k] = (VT)0;
+                if (any) {
+                    const VT *rp = vp + (size_t)(y0 + u) * nx + x0;
+                    if (q[u].x) v[u][0] = rp[0];
+                    if (q[u].y) v[u][1] = rp[1];
+                    if (q[u].z) v[u][2] = rp[2];
+                    if (q[u].w) v[u][3] = rp[3];
+                }
+            }
+        }
+    };
+#if LB_PIPE
+    int4 qb[LB_BATCH], qn[LB_BATCH], qnn[LB_BATCH];
+    VT vb[LB_BATCH][4], vn[LB_BATCH][4];
+    load_flags(qb, ya);
+    load_flags(qn, ya + LB_BATCH);
+    load_fields(vb, qb, ya);
+#else
+    int4 qb[LB_BATCH];
+    VT vb[LB_BATCH][4];
+#endif
     for (int yq = ya; yq < yb; yq += LB_BATCH) {
-        int4 qb[LB_BATCH];
-        VT vb[LB_BATCH][4];
-#pragma unroll
-        for (int u = 0; u < LB_BATCH; ++u) {
-            qb[u] = make_int4(0, 0, 0, 0);
-            if (yq + u < yb && x0 < nx) {
-                const int32_t *rp = fp + (size_t)(yq + u) * nx + x0;
-                if (vec) {
-                    typedef int i32x4 __attribute__((ext_vector_type(4)));
-                    const i32x4 q = __builtin_nontemporal_load((const i32x4 *)rp);
-                    qb[u] = make_int4(q.x, q.y, q.z, q.w);
-                } else {
-                    qb[u].x = rp[0];
-                    qb[u].y = (x0 + 1 < nx) ? rp[1] : 0;
-                    qb[u].z = (x0 + 2 < nx) ? rp[2] : 0;
-                    qb[u].w = (x0 + 3 < nx) ? rp[3] : 0;
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < LB_BATCH; ++u) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) vb[u][k] = (VT)0;
-            if ((qb[u].x | qb[u].y | qb[u].z | qb[u].w) != 0) {
-                const VT *rp = vp + (size_t)(yq + u) * nx + x0;
-                if (vecv) __builtin_memcpy(vb[u], (const void *)rp, sizeof(vb[u]));        // one 16- / 32-byte request
-                else {
-                    if (qb[u].x) vb[u][0] = rp[0];
-                    if (qb[u].y) vb[u][1] = rp[1];
-                    if (qb[u].z) vb[u][2] = rp[2];
-                    if (qb[u].w) vb[u][3] = rp[3];
-                }
-            }
-        }
+#if LB_PIPE
+        load_flags(qnn, yq + 2 * LB_BATCH);
+        load_fields(vn, qn, yq + LB_BATCH);
+#else
+        load_flags(qb, yq);
+        load_fields(vb, qb, yq);
+#endif
 #pragma unroll
         for (int u = 0; u < LB_BATCH; ++u) {
             const int y = yq + u;                                          // (wave-uniform)
-            const int32_t l[4] = {qb[u].x, qb[u].y, qb[u].z, qb[u].w};
+            if (y >= yb) continue;
+            const int32_t l[4] = {lane_in ? qb[u].x : 0, lane_in ? qb[u].y : 0, lane_in ? qb[u].z : 0, lane_in ? qb[u].w : 0};
             const bool anyfg = (l[0] | l[1] | l[2] | l[3]) != 0;
             if (__ballot(anyfg) == 0ull) continue;
             if (!anyfg) continue;
@@ -536,6 +571,14 @@ __global__ __launch_bounds__(LB_THREADS) void k_life_strips(const int32_t *__res
             h_hi += (long long)cnt * hi_y;
             if (cnt) h_y1 = y;
         }
+#if LB_PIPE
+#pragma unroll
+        for (int u = 0; u < LB_BATCH; ++u) {
+            qb[u] = qn[u]; qn[u] = qnn[u];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vb[u][k] = vn[u][k];
+        }
+#endif
     }
     // what the lanes still hold: column data lane by lane, the five sums combined per row of 16 lanes first (same-address LDS
     // atomics serialise; DPP moves run at VALU speed)
