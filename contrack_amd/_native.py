@@ -24,7 +24,7 @@ EXPORTS = [
     "ctk_track_f32_dev", "ctk_track_f64", "ctk_track_f64_dev", "ctk_release_io", "ctk_shard_label2d", "ctk_shard_label2d_f64", "ctk_shard_halo_size", "ctk_shard_halo_export",
     "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_resolve", "ctk_result_free",
     "ctk_result_info", "ctk_result_arrays", "ctk_result_nshards", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
-    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_set_seam_caps", "ctk_debug_set_spin", "ctk_debug_set_xcd", "ctk_debug_set_relabel", "ctk_debug_set_small_threads", "ctk_debug_np_sum", "ctk_debug_boundary_resolve", "ctk_set_timing", "ctk_get_timings", "ctk_get_timing_sums", "ctk_set_device_resolve", "ctk_set_fused_pass", "ctk_set_result_transfer", "ctk_set_filter_round", "ctk_get_stats",
+    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_set_seam_caps", "ctk_debug_set_spin", "ctk_debug_set_xcd", "ctk_debug_set_relabel", "ctk_debug_set_small_threads", "ctk_debug_np_sum", "ctk_debug_boundary_resolve", "ctk_set_timing", "ctk_get_timings", "ctk_get_timing_sums", "ctk_set_device_resolve", "ctk_set_fused_pass", "ctk_set_result_transfer", "ctk_expand_runs_host", "ctk_set_filter_round", "ctk_get_stats",
     "ctk_dev_malloc", "ctk_dev_free", "ctk_host_alloc", "ctk_host_free", "ctk_host_register", "ctk_host_unregister", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
     "ctk_synth_fill",
     "ctk_comm_unique_id", "ctk_comm_init_rccl", "ctk_comm_group_create", "ctk_comm_group_destroy", "ctk_comm_init_local", "ctk_comm_init_shm",
@@ -116,6 +116,7 @@ def lib():
     L.ctk_set_device_resolve.argtypes = [p, i32]
     L.ctk_set_fused_pass.argtypes = [p, i32]
     L.ctk_set_result_transfer.argtypes = [p, i32]
+    L.ctk_expand_runs_host.argtypes = [p, p, p, p, i64, i32, i32, p, p, p]
     L.ctk_get_stats.argtypes = [p, p]
     L.ctk_set_filter_round.argtypes = [p, i32]
     L.ctk_dev_malloc.argtypes = [p, pp, sz]
@@ -195,6 +196,24 @@ def weights_to_limbs(wrow, npix=1 << 16, with_bits=False):
     sh, lb = C.c_int32(0), C.c_int32(0)
     check(lib().ctk_weights_to_limbs(wrow.ctypes.data, wrow.shape[0], int(npix), lo.ctypes.data, hi.ctypes.data, C.byref(sh), C.byref(lb)))
     return (lo, hi, int(sh.value), int(lb.value)) if with_bits else (lo, hi, int(sh.value))
+
+
+def expand_runs_host(mask, rowstart, run_base, run_val, nx):
+    """the host-side decoder of the run-table result transfer on its own (no device call): mask uint64 (T, ny, ceil(nx / 64)),
+    rowstart uint32 (T, ny), run_base uint32 (T + 1,), run_val int32 (runs,) -> (flag int32 (T, ny, nx), a zero was written,
+    a negative run value was met)"""
+    mask = np.ascontiguousarray(mask, dtype=np.uint64)
+    rowstart = np.ascontiguousarray(rowstart, dtype=np.uint32)
+    run_base = np.ascontiguousarray(run_base, dtype=np.uint32)
+    run_val = np.ascontiguousarray(run_val, dtype=np.int32)
+    T, ny, W = mask.shape
+    if W != (nx + 63) // 64 or rowstart.shape != (T, ny) or run_base.shape != (T + 1,) or (T and run_val.shape[0] < int(run_base[-1])):
+        raise ValueError("table shapes do not fit (T, ny, nx)")
+    flag = np.empty((T, ny, nx), dtype=np.int32)
+    z, cx = C.c_int(0), C.c_int(0)
+    check(lib().ctk_expand_runs_host(mask.ctypes.data, rowstart.ctypes.data, run_base.ctypes.data, run_val.ctypes.data if run_val.size else None,
+                                     T, ny, nx, flag.ctypes.data, C.byref(z), C.byref(cx)))
+    return flag, bool(z.value), bool(cx.value)
 
 
 class Result:

@@ -1723,7 +1723,7 @@ static int32_t *chunk_vals_for(ctk_handle *h, const int32_t *flag_dev, int *rows
 // timesteps [t0, t0 + nt) of the shard into flag_dev (which starts at t0); nt < 0: the whole shard
 static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, bool with_fold, const int32_t *chunk_vals = nullptr, int64_t t0 = 0, int64_t nt = -1)
 {
-    if (h->rle_out) return CTK_OK;                                    // the result leaves as run tables (deliver_runs expands them on the host)
+    if (h->rle_out) { h->stats[CTK_S_RELABEL_KERNEL] = -1; return CTK_OK; }      // the result leaves as run tables (deliver_runs expands them on the host)
     if (nt < 0) nt = h->T;
     RelabelArgs a;
     const int rb = relabel_rows(h);                                   // (of the whole shard: the chunk values were built for it)
@@ -2282,6 +2282,31 @@ static bool rle_blocks(const uint32_t *run_base, int64_t T, int ny, int W, size_
         t0 += nt;
     }
     return true;
+}
+
+// The decoder alone, on host tables (no device involved): what the CPU tests hold against a dense expansion in numpy.
+extern "C" int ctk_expand_runs_host(const uint64_t *mask, const uint32_t *rowstart, const uint32_t *run_base, const int32_t *run_val, int64_t T, int ny, int nx,
+                                    int32_t *flag, int *wrote_background, int *complex_runs)
+{
+    if (T < 0 || ny < 1 || nx < 1 || (T > 0 && (!mask || !rowstart || !run_base || !flag))) return ctk_set_error(CTK_E_INVALID, "ctk_expand_runs_host: bad argument");
+    const int W = (nx + 63) / 64;
+    const size_t nrow = (size_t)ny;
+    std::vector<unsigned char> buf;
+    std::vector<int32_t> scratch((size_t)W * 64 + 16);
+    bool z = false, cx = false;
+    for (int64_t t = 0; t < T; t++) {
+        const uint32_t r0 = run_base[t], nr = run_base[t + 1] - r0;
+        if (nr && !run_val) return ctk_set_error(CTK_E_INVALID, "ctk_expand_runs_host: runs without values");
+        const size_t off_rs = nrow * W * 8, off_rv = off_rs + ((nrow * 4 + 7) & ~(size_t)7);
+        buf.resize(off_rv + (size_t)nr * 4 + 8);
+        memcpy(buf.data(), mask + (size_t)t * nrow * W, nrow * W * 8);
+        memcpy(buf.data() + off_rs, rowstart + (size_t)t * nrow, nrow * 4);
+        if (nr) memcpy(buf.data() + off_rv, run_val + r0, (size_t)nr * 4);
+        rle_expand_block(buf.data(), RleBlock{t, 1, r0, nr}, run_base, ny, nx, W, flag, scratch.data(), z, cx);
+    }
+    if (wrote_background) *wrote_background = z ? 1 : 0;
+    if (complex_runs) *complex_runs = cx ? 1 : 0;
+    return CTK_OK;
 }
 
 // The pass is over (tables in ST_TABLES state, nothing running on the handle's stream): expand the result into `flag`.

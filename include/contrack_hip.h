@@ -273,7 +273,7 @@ int ctk_get_timing_sums(ctk_handle *h, double *sums, int64_t *counts, int reset)
                                    bit 3 (8) = a bounded inter-workgroup wait gave up, the resolution was repeated with one launch per
                                    filter pass */
 #define CTK_S_SHARED_ROWS   17  /* time-sharded path: seam candidate groups shared between shards (driven on every rank)        */
-#define CTK_S_RELABEL_KERNEL 19    /* which write kernel ran: 5 = k_relabel_v5, 4 = k_relabel_v4, 0 = generic k_relabel */
+#define CTK_S_RELABEL_KERNEL 19    /* which write kernel ran: 5 = k_relabel_v5, 4 = k_relabel_v4, 0 = generic k_relabel, -1 = none (run transfer) */
 #define CTK_S_FUSED         20    /* 1: the one-call pass ran without a host hand-off (device seam driver, one synchronisation) */
 #define CTK_S_X4_SPECULATED 21    /* time-sharded path: 1 if the boundary records of the 3-D labelling travelled with the last round of
                                    * the overlap filter's exchange (one all-gather less) */
@@ -326,6 +326,11 @@ int ctk_host_free(ctk_handle *h, void *p);
  * scheme above).  -1: back to the environment's choice.  The device-resident entries always write `flag_dev` densely.
  * CTK_S_RLE_OUT reports what a call did.  (contrack.py:776-791: where the reference materialises `flag`) */
 int ctk_set_result_transfer(ctk_handle *h, int mode);
+/* The decoder of that transfer on its own, on tables in host memory (no device call; for tests): mask u64 [T][ny][ceil(nx/64)],
+ * rowstart u32 [T][ny] (first run of the row, relative to its time step), run_base u32 [T + 1], run_val i32 [runs] -> flag
+ * [T][ny][nx]; *wrote_background: a zero was written; *complex_runs: a negative run value was met (its pixels are not decoded). */
+int ctk_expand_runs_host(const uint64_t *mask, const uint32_t *rowstart, const uint32_t *run_base, const int32_t *run_val, int64_t T, int ny, int nx,
+                         int32_t *flag, int *wrote_background, int *complex_runs);
 int ctk_host_register(ctk_handle *h, void *p, size_t nbytes);
 int ctk_host_unregister(ctk_handle *h, void *p);
 void *ctk_stream(ctk_handle *h);                          /* hipStream_t */
