@@ -102,7 +102,7 @@ def lifecycle_columns(rows, lat, lon, dates, tracker=None):
     The device sums are float64 but in another order than the reference's (np.sum pairwise, np.bincount sequential).  That shows
     only where a result sits on a rounding boundary: a centre of mass that is an integer up to rounding (contours one pixel wide
     or high: int() then gives the cell or its neighbour) or a value at the edge of two decimals.  With the Tracker that produced
-    `rows` at hand those rows -- about 1 % in practice -- are re-evaluated ON THE DEVICE in the reference's own summation orders
+    `rows` at hand those rows -- a few per cent in practice -- are re-evaluated ON THE DEVICE in the reference's own summation orders
     (ctk_lifecycle_exact)."""
     nx, ny = len(lon), len(lat)
     if (rows["shift"] == -2).any():
@@ -115,11 +115,14 @@ def lifecycle_columns(rows, lat, lon, dates, tracker=None):
         def near_int(v):
             return np.abs(v - np.rint(v)) <= 1e-9 * np.maximum(1.0, np.abs(v))
 
-        def near_half(v):                                   # v * 100 close to k + 0.5: round(v, 2) could go either way
+        def near_half(v, rel):                              # v * 100 close to k + 0.5: round(v, 2) could go either way
             s = np.abs(v) * 100.0
-            return np.abs(s - np.floor(s) - 0.5) <= 1e-6 * np.maximum(1.0, s)
+            return np.abs(s - np.floor(s) - 0.5) <= rel * np.maximum(1.0, s)
+        # The area is a sum of POSITIVE float64 terms: the device's value (exact integers, rounded once) and numpy's pairwise sum
+        # differ by less than 5e-15 of it (depth of the pairwise tree x 2^-53) -- 1e-11 is generous, while 1e-6 would flag every
+        # contour beyond 5000 km^2 (a quarter of all rows).  Sums of field values can cancel: their window stays wide.
         with np.errstate(invalid="ignore"):
-            fragile = near_int(com_y) | near_int(com_x) | near_half(intensity) | near_half(area) | ~np.isfinite(com_y) | ~np.isfinite(com_x)
+            fragile = near_int(com_y) | near_int(com_x) | near_half(intensity, 1e-6) | near_half(area, 1e-11) | ~np.isfinite(com_y) | ~np.isfinite(com_x)
         idx = np.nonzero(fragile)[0]
         if len(idx):
             ex = tracker.lifecycle_exact(idx)
