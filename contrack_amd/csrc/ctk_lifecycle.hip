@@ -767,28 +767,38 @@ __device__ inline double np_walk(uint32_t cn, Leaf leaf, NpFrame *f)
     }
     return val;
 }
-// the same sum by a workgroup of 256: thread 0 lists the leaves of a block, the threads sum one leaf each, thread 0 combines them
-// in the tree's order.  Result valid in thread 0.  lo / ln / lv: LDS scratch for 128 leaves.
-__device__ inline double wg_np_sum(const double *a, size_t n, uint32_t *lo, uint32_t *ln, double *lv, int *nleaf, NpFrame *frames)
+// The sum over a long list by a workgroup of 256: thread 0 lists the leaves of a block of 8192, the threads sum one leaf each, thread 0
+// combines them in the tree's order.  lo / ln: LDS scratch for 128 leaves.
+// Two such sums over lists of the same length at once (k_life_exact: the area and the weighted sum of one contour): the tree, and
+// so the list of leaves, depends on the length only -- it is listed once per chunk LENGTH (every chunk but the last is 8192 long),
+// the leaves of both lists are summed side by side (threads 0..127 / 128..255) and combined by two waves at the same time.
+// lv: 256 doubles, frames: 2 x 16.  Results valid in thread 0 (ra) and thread 64 (rb).
+__device__ inline void wg_np_sum2(const double *a, const double *b, size_t n, uint32_t *lo, uint32_t *ln, double *lv, int *nleaf, NpFrame *frames, double &ra, double &rb)
 {
     double acc = 0.0;
+    uint32_t listed = 0;
+    const int tid = (int)threadIdx.x;
     for (size_t c0 = 0; c0 < n; c0 += 8192) {
         const uint32_t cn = (uint32_t)(n - c0 < 8192 ? n - c0 : 8192);
-        if (threadIdx.x == 0) {
-            int k = 0;
-            (void)np_walk(cn, [&](uint32_t off, uint32_t m) { lo[k] = off; ln[k] = m; k++; return 0.0; }, frames);
-            *nleaf = k;
+        if (cn != listed) {                                                  // (uniform)
+            if (tid == 0) {
+                int k = 0;
+                (void)np_walk(cn, [&](uint32_t off, uint32_t m) { lo[k] = off; ln[k] = m; k++; return 0.0; }, frames);
+                *nleaf = k;
+            }
+            listed = cn;
         }
         __syncthreads();
-        if ((int)threadIdx.x < *nleaf) lv[threadIdx.x] = dev_np_leaf(a + c0 + lo[threadIdx.x], ln[threadIdx.x]);
+        const int nl = *nleaf;
+        if (tid < nl) lv[tid] = dev_np_leaf(a + c0 + lo[tid], ln[tid]);
+        else if (tid >= 128 && tid - 128 < nl) lv[tid] = dev_np_leaf(b + c0 + lo[tid - 128], ln[tid - 128]);
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int k = 0;
-            acc += np_walk(cn, [&](uint32_t, uint32_t) { return lv[k++]; }, frames);
-        }
+        if (tid == 0) { int k = 0; acc += np_walk(cn, [&](uint32_t, uint32_t) { return lv[k++]; }, frames); }
+        else if (tid == 64) { int k = 128; acc += np_walk(cn, [&](uint32_t, uint32_t) { return lv[k++]; }, frames + 16); }
         __syncthreads();
     }
-    return acc;
+    if (tid == 0) ra = acc;
+    if (tid == 64) rb = acc;
 }
 
 struct CtkLifeKey {
@@ -831,9 +841,9 @@ __global__ __launch_bounds__(256) void k_life_exact(const int32_t *__restrict__ 
 {
     __shared__ uint32_t part[256];
     __shared__ uint32_t lo[128], ln[128];
-    __shared__ double lv[128];
+    __shared__ double lv[256];
     __shared__ int nleaf;
-    __shared__ NpFrame frames[16];
+    __shared__ NpFrame frames[32];
     __shared__ double stage[3][LX_STAGE];
     __shared__ double res[5];
     const CtkLifeKey k = keys[blockIdx.x];
@@ -916,9 +926,12 @@ __global__ __launch_bounds__(256) void k_life_exact(const int32_t *__restrict__ 
     }
     __syncthreads();
     // D: np.sum over the raster-order lists
-    const double area = wg_np_sum(gw, total, lo, ln, lv, &nleaf, frames);
-    const double swv = wg_np_sum(gp, total, lo, ln, lv, &nleaf, frames);
-    if (tid == 0) { res[0] = area; res[1] = swv; }
+    {
+        double area = 0.0, swv = 0.0;
+        wg_np_sum2(gw, gp, total, lo, ln, lv, &nleaf, frames, area, swv);
+        if (tid == 0) res[0] = area;
+        if (tid == 64) res[1] = swv;
+    }
     // E: np.bincount's strictly sequential sums over the rolled lists: blocks staged in LDS, one lane per sum
     double acc = 0.0;
     for (size_t c0 = 0; c0 < total; c0 += LX_STAGE) {
