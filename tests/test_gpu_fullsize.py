@@ -11,7 +11,8 @@ pixel offset is 64-bit and the ids stay int32 (they are counted, not addressed).
   (c) size-independent properties of that result, evaluated on the device: flag is a subset of the mask (float64 compare,
       contrack.py:665), ids in range, number of distinct ids = n_tracked, no id with a time extent below `persistence`
       (contrack.py:765-772).
-Needs ~130 GB of the 288 GB of HBM."""
+  (d) the host-array entry on a 2.18e9-element host slab (both result transfers) against the device-resident entry.
+Needs ~150 GB of the 288 GB of HBM and ~30 GB of host memory."""
 import ctypes as C
 import threading
 
@@ -153,3 +154,33 @@ def test_configs2_slab_one_call_vs_four_shards_and_properties(big):
     assert res == [n_one] * world, (res, n_one)
     got = [trk.checksum_i32(_off(d_out, t0 * PLANE * 4), (t1 - t0) * PLANE, t0 * PLANE) for t0, t1 in bounds]
     assert got == ref
+
+
+def test_host_array_entry_past_2p31_elements(big):
+    """ctk_track_f32 on a host slab of 2.18e9 elements (2100 x 721 x 1440): the result as run tables expanded by host threads, and the
+    dense copy, against the device-resident entry on the same slab (position-weighted checksums of the whole result)."""
+    trk, d_in, d_out, w = big
+    T2 = 2100
+    n = T2 * PLANE
+    assert n > 2 ** 31
+    trk.synth_fill(d_in, T2, NY, NX, seed=5)
+    thr = np.full(T2, np.float64(np.float32(160.0)))
+    trk.memset(d_out, 0xff, n * 4)
+    n_dev = trk.track_dev(d_in, T2, NY, NX, thr, 0, w, 0.5, PERSISTENCE, True, d_out)
+    ref = trk.checksum_i32(d_out, n, 0)
+    assert n_dev > 10 and ref[1] > 0
+    a = np.empty((T2, NY, NX), dtype=np.float32)
+    trk.d2h(a, d_in)
+    try:
+        for mode in (1, 0):
+            trk.set_result_transfer(mode)
+            flag, n_host = trk.track(a, thr, 0, w, 0.5, PERSISTENCE, True)
+            assert (trk.stats()["result_as_runs"] >= 1) == (mode == 1)
+            assert n_host == n_dev
+            trk.memset(d_out, 0xff, n * 4)
+            trk.h2d(d_out, flag)
+            assert trk.checksum_i32(d_out, n, 0) == ref, mode
+            del flag
+    finally:
+        trk.set_result_transfer(-1)
+        trk.release_io()
