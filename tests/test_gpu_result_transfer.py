@@ -58,6 +58,8 @@ CASES = [
     (40, 64, 128, 16, "smooth", 120.0, 0.3, 1, False),      # nx a multiple of 64: runs that end on a word boundary
     (30, 33, 67, 17, "smooth", 140.0, 0.5, 2, True),        # odd width (the generic write kernel on the dense side)
     (12, 16, 64, 18, "noise", 0.2, 0.5, 1, True),           # mostly foreground: full words, runs across words
+    (3, 4, 4100, 19, "noise", 0.5, 0.5, 1, True),           # wider than 4096: the generic threshold / labelling kernels, 65 words per row
+    (2, 700, 130, 20, "smooth", 120.0, 0.5, 1, False),      # tall and narrow
 ]
 
 
