@@ -1402,15 +1402,7 @@ __global__ __launch_bounds__(256) void k_run_values(const uint32_t *__restrict__
         for (int q = threadIdx.x; q <= nchunk; q += blockDim.x) qb[q] = q < nchunk ? rowstart[(int64_t)t * ny + (int64_t)q * rows] : n;
         __syncthreads();
     }
-    for (uint32_t r = threadIdx.x; r < n; r += blockDim.x) {
-        uint32_t c = run_comp[rb + r];
-        int32_t v;
-        if (mode == 0) {
-            int32_t l = comp_label[cb + c];
-            if (l > 0) v = ((int64_t)ext[n_labels + 1 + l] - (int64_t)ext[l] + 1 < persistence) ? 0 : l;
-            else v = l;
-        } else if (mode == 1) v = (int32_t)(comp_id_base + cb + c + 1);
-        else v = (int32_t)(comp_id_base + cb + d_mrep[cb + c] + 1);
+    auto emit = [&](uint32_t r, int32_t v) {
         run_val[rb + r] = v;
         if (chunk_vals) {
             int lo = 0, hi = nchunk - 1;                                // last chunk whose first run is <= r
@@ -1418,6 +1410,36 @@ __global__ __launch_bounds__(256) void k_run_values(const uint32_t *__restrict__
             const uint32_t pos = r - qb[lo];
             if (pos < CTK_CV) chunk_vals[((int64_t)t * nchunk + lo) * CTK_CV + pos] = v;
         }
+    };
+    if (mode == 0) {
+        // Four runs per thread and step, level by level: run -> component -> label -> time extent is a chain of dependent loads,
+        // and a plane's ~500 runs would walk it two or three times in a row with one run per thread and step.  Nothing around the
+        // loads is conditional (indices clamped instead).
+        if (n == 0u) return;
+        constexpr int RV = 4;
+        for (uint32_t r0 = threadIdx.x; r0 < n; r0 += RV * blockDim.x) {
+            uint32_t c[RV];
+            int32_t l[RV], e0[RV], e1[RV];
+#pragma unroll
+            for (int j = 0; j < RV; j++) c[j] = run_comp[rb + min(r0 + (uint32_t)j * blockDim.x, n - 1u)];
+#pragma unroll
+            for (int j = 0; j < RV; j++) l[j] = comp_label[cb + c[j]];
+#pragma unroll
+            for (int j = 0; j < RV; j++) { const int32_t lc = max(l[j], 0); e0[j] = ext[lc]; e1[j] = ext[n_labels + 1 + lc]; }
+#pragma unroll
+            for (int j = 0; j < RV; j++) {
+                const uint32_t r = r0 + (uint32_t)j * blockDim.x;
+                if (r >= n) break;
+                int32_t v = l[j];
+                if (v > 0 && (int64_t)e1[j] - (int64_t)e0[j] + 1 < persistence) v = 0;
+                emit(r, v);
+            }
+        }
+        return;
+    }
+    for (uint32_t r = threadIdx.x; r < n; r += blockDim.x) {
+        const uint32_t c = run_comp[rb + r];
+        emit(r, mode == 1 ? (int32_t)(comp_id_base + cb + c + 1) : (int32_t)(comp_id_base + cb + d_mrep[cb + c] + 1));
     }
 }
 
