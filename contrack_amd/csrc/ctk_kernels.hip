@@ -612,22 +612,28 @@ __device__ unsigned long long g_phase_t[16];
 #define PHASE_MARK(k) do { } while (0)
 #endif
 
-template <int THREADS, typename IT /* uint16_t when run / component indices fit, else uint32_t */, int LDS_COMPS>
+// What k_label2d_lds fetched for a timestep whose mask it stages in LDS, before it knew anything but t: the run prefixes of the
+// thread's words (word k = tid + u * THREADS).  NW = 0: nothing was fetched.
+template <int NW> struct L2dPrefetch { uint16_t w[NW > 0 ? NW : 1]; };
+
+template <int THREADS, typename IT /* uint16_t when run / component indices fit, else uint32_t */, int LDS_COMPS, int NW = 0>
 __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, const uint32_t nruns,
                                              uint16_t *x0, uint16_t *x1, uint16_t *yrow, uint32_t *parent,
                                              IT *root, IT *idmap, IT *rs /* rowstart within the timestep, ny+1 */,
                                              uint32_t *sm_scan, const uint64_t *mrow /* the timestep's mask words (LDS or global) */,
                                              const bool mrow_staged /* mrow is the whole timestep in LDS */,
-                                             void *lds_tab /* LDS_COMPS x 32 B of LDS: band staging, then the component tables; or nullptr */)
+                                             void *lds_tab /* LDS_COMPS x 32 B of LDS: band staging, then the component tables; or nullptr */,
+                                             const uint32_t rbase, const L2dPrefetch<NW> &pf)
 {
     const int tid = (int)threadIdx.x;
     const int ny = a.ny, nx = a.nx, W = a.W;
-    const uint32_t rbase = a.run_base[t];
 
     PHASE_MARK(0);
     // ---- phase 1: rowstart (computed by k_rowcount) -> LDS/scratch -------------------------------
-    for (int y = tid; y < ny; y += THREADS) rs[y] = (IT)a.rowstart[(int64_t)t * ny + y];
-    if (tid == 0) rs[ny] = (IT)nruns;
+    if (NW == 0) {                                                      // (else: the caller did, together with the mask words)
+        for (int y = tid; y < ny; y += THREADS) rs[y] = (IT)a.rowstart[(int64_t)t * ny + y];
+        if (tid == 0) rs[ny] = (IT)nruns;
+    }
     __syncthreads();
 
     PHASE_MARK(1);
@@ -665,7 +671,16 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
                 ei++;
             }
         };
-        if (mrow_staged) {                                           // the timestep's words (and prefixes) are in LDS
+        if (NW > 0) {                                                // the timestep's words are in LDS, the prefixes of this thread's in registers
+#pragma unroll
+            for (int u = 0; u < (NW > 0 ? NW : 1); u++) {
+                const int k = tid + u * THREADS;
+                if (k >= nwords) break;
+                const uint64_t m = mrow[k];
+                if (m == 0ull) continue;
+                extract(k, m, k > 0 ? mrow[k - 1] : 0ull, k + 1 < nwords ? mrow[k + 1] : 0ull, pf.w[u]);
+            }
+        } else if (mrow_staged) {                                    // the timestep's words are in LDS
             const uint16_t *ws = wglob;
             for (int k = tid; k < nwords; k += THREADS) {
                 const uint64_t m = mrow[k];
@@ -767,20 +782,34 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
         carea[c * 2] = 0; carea[c * 2 + 1] = 0;
     }
     __syncthreads();
-    for (uint32_t r = tid; r < nruns; r += THREADS) {
-        const uint32_t rt = root[r];
-        const uint32_t c = idmap[rt];
-        a.run_comp[rbase + r] = c;
-        const int y = yrow[r];
-        const int64_t len = (int64_t)x1[r] - (int64_t)x0[r] + 1;
-        const uint32_t cm = idmap[parent[r]];              // seam-merged component: its area is what contrack.py:717 sums
-        atomicAdd((unsigned long long *)&carea[cm * 2], (unsigned long long)(len * a.wlo[y]));
-        atomicAdd((unsigned long long *)&carea[cm * 2 + 1], (unsigned long long)(len * a.whi[y]));
-        atomicMin(&cbox[c * 4 + 0], (uint32_t)y);
-        atomicMax(&cbox[c * 4 + 1], (uint32_t)y);
-        atomicMin(&cbox[c * 4 + 2], (uint32_t)x0[r]);
-        atomicMax(&cbox[c * 4 + 3], (uint32_t)x1[r]);
-        if (rt == r) cmrep[c] = idmap[parent[r]];          // merged root is itself a no-wrap root (smallest run)
+    // (the weight limbs of four runs' rows are requested before the first is used: a plane's ~500 runs would otherwise walk
+    // row -> weights -> atomics two or three times in a row)
+    constexpr int TBN = THREADS == 1024 ? 2 : 4;                  // (the 1024-thread variants run at 64 VGPRs)
+    for (uint32_t r0 = tid; r0 < nruns; r0 += TBN * THREADS) {
+        int yy[TBN];
+        int64_t wl[TBN], wh[TBN];
+#pragma unroll
+        for (int j = 0; j < TBN; j++) yy[j] = yrow[min(r0 + (uint32_t)j * THREADS, nruns - 1u)];
+#pragma unroll
+        for (int j = 0; j < TBN; j++) { wl[j] = a.wlo[yy[j]]; wh[j] = a.whi[yy[j]]; }
+#pragma unroll
+        for (int j = 0; j < TBN; j++) {
+            const uint32_t r = r0 + (uint32_t)j * THREADS;
+            if (r >= nruns) break;
+            const uint32_t rt = root[r];
+            const uint32_t c = idmap[rt];
+            a.run_comp[rbase + r] = c;
+            const int y = yy[j];
+            const int64_t len = (int64_t)x1[r] - (int64_t)x0[r] + 1;
+            const uint32_t cm = idmap[parent[r]];              // seam-merged component: its area is what contrack.py:717 sums
+            atomicAdd((unsigned long long *)&carea[cm * 2], (unsigned long long)(len * wl[j]));
+            atomicAdd((unsigned long long *)&carea[cm * 2 + 1], (unsigned long long)(len * wh[j]));
+            atomicMin(&cbox[c * 4 + 0], (uint32_t)y);
+            atomicMax(&cbox[c * 4 + 1], (uint32_t)y);
+            atomicMin(&cbox[c * 4 + 2], (uint32_t)x0[r]);
+            atomicMax(&cbox[c * 4 + 3], (uint32_t)x1[r]);
+            if (rt == r) cmrep[c] = idmap[parent[r]];          // merged root is itself a no-wrap root (smallest run)
+        }
     }
     if (tab_lds) {
         __syncthreads();
@@ -829,13 +858,6 @@ template <int RUNS, int COMPS, int RUNS_BELOW, int THREADS>
 __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void k_label2d_lds(Label2dArgs a)
 {
     const int t = (int)blockIdx.x;
-    const uint32_t nruns = a.run_base[t + 1] - a.run_base[t];
-    if (nruns > RUNS || (int64_t)nruns <= (int64_t)RUNS_BELOW || a.ny > CTK_LDS_NY) return;        // another variant takes it
-    if (a.run_base[t + 1] > a.cap_runs) return;                    // buffers too small: the host relaunches after growing them
-    if (nruns == 0) {
-        if (threadIdx.x == 0) { a.ncomp[t] = 0; a.seam_cnt[t] = 0; }
-        return;
-    }
     __shared__ uint16_t x0[RUNS], x1[RUNS], yrow[RUNS], root[RUNS], idmap[RUNS];
     __shared__ uint32_t parent[RUNS];
     __shared__ uint16_t rs[CTK_LDS_NY + 2];
@@ -843,13 +865,51 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void k_label2d_ld
     __shared__ uint32_t sm_scan[THREADS / 64 + 1];
     const int nwords = a.ny * a.W;
     const uint64_t *mg = a.mask + (int64_t)t * nwords;
-    const uint64_t *mrow = mg;
-    const bool staged = nwords <= COMPS * 4;
-    if (staged) {                                                   // stage the timestep's mask (8.7 KB at 1 deg)
-        for (int i = (int)threadIdx.x; i < nwords; i += THREADS) mlds[i] = mg[i];
-        mrow = mlds;
+    constexpr int NW = (COMPS * 4 + THREADS - 1) / THREADS;        // words per thread of a staged timestep
+    if (THREADS < 1024 && nwords <= COMPS * 4 && NW <= 8) {     // (the 1024-thread variants serve planes far beyond their table area and run at 64 VGPRs)
+        // A timestep whose mask is staged in LDS (8.7 KB at 1 deg).  Everything that depends on t alone is requested at once -- the
+        // run range, the thread's mask words and their run prefixes, its rows' first runs -- and waited for once: as a chain
+        // (range -> words -> first runs -> a prefix per word inside the extraction loop) these were up to eight dependent trips to
+        // L2 in front of and inside phase 2.  Indices are clamped, nothing is conditional; a plane another variant takes
+        // returns with its loads in flight.
+        const uint32_t rb0 = a.run_base[t], rb1 = a.run_base[t + 1];
+        const uint16_t *wg = a.wstart + (int64_t)t * nwords;
+        const uint32_t *rg = a.rowstart + (int64_t)t * a.ny;
+        uint64_t mreg[NW];
+        uint32_t rreg[NW];
+        L2dPrefetch<NW> pf;
+#pragma unroll
+        for (int u = 0; u < NW; u++) {
+            const int k = min((int)threadIdx.x + u * THREADS, nwords - 1);
+            mreg[u] = mg[k];
+            pf.w[u] = wg[k];
+            rreg[u] = rg[min((int)threadIdx.x + u * THREADS, a.ny - 1)];       // (ny <= nwords: NW rows per thread cover them)
+        }
+        const uint32_t nruns = rb1 - rb0;
+        if (nruns > RUNS || (int64_t)nruns <= (int64_t)RUNS_BELOW || a.ny > CTK_LDS_NY) return;    // another variant takes it
+        if (rb1 > a.cap_runs) return;                                  // buffers too small: the host relaunches after growing them
+        if (nruns == 0) {
+            if (threadIdx.x == 0) { a.ncomp[t] = 0; a.seam_cnt[t] = 0; }
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < NW; u++) {
+            const int k = (int)threadIdx.x + u * THREADS;
+            if (k < nwords) mlds[k] = mreg[u];
+            if (k < a.ny) rs[k] = (uint16_t)rreg[u];
+        }
+        if (threadIdx.x == 0) rs[a.ny] = (uint16_t)nruns;
+        label2d_body<THREADS, uint16_t, COMPS, NW>(a, t, nruns, x0, x1, yrow, parent, root, idmap, rs, sm_scan, mlds, true, mlds, rb0, pf);
+        return;
     }
-    label2d_body<THREADS, uint16_t, COMPS>(a, t, nruns, x0, x1, yrow, parent, root, idmap, rs, sm_scan, mrow, staged, mlds);
+    const uint32_t nruns = a.run_base[t + 1] - a.run_base[t];
+    if (nruns > RUNS || (int64_t)nruns <= (int64_t)RUNS_BELOW || a.ny > CTK_LDS_NY) return;        // another variant takes it
+    if (a.run_base[t + 1] > a.cap_runs) return;                    // buffers too small: the host relaunches after growing them
+    if (nruns == 0) {
+        if (threadIdx.x == 0) { a.ncomp[t] = 0; a.seam_cnt[t] = 0; }
+        return;
+    }
+    label2d_body<THREADS, uint16_t, COMPS>(a, t, nruns, x0, x1, yrow, parent, root, idmap, rs, sm_scan, mg, false, mlds, a.run_base[t], L2dPrefetch<0>());
 }
 
 __global__ __launch_bounds__(256) void k_label2d_glb(Label2dArgs a, uint32_t *g_rs /* [T][ny+1] scratch */)
@@ -861,7 +921,7 @@ __global__ __launch_bounds__(256) void k_label2d_glb(Label2dArgs a, uint32_t *g_
     if (a.run_base[t + 1] > a.cap_runs) return;
     __shared__ uint32_t sm_scan[8];
     label2d_body<256, uint32_t, 1>(a, t, nruns, a.g_x0 + rb, a.g_x1 + rb, a.g_y + rb, a.g_parent + rb, a.g_root + rb,
-                                   a.g_idmap + rb, g_rs + (int64_t)t * (a.ny + 1), sm_scan, a.mask + (int64_t)t * a.ny * a.W, false, nullptr);
+                                   a.g_idmap + rb, g_rs + (int64_t)t * (a.ny + 1), sm_scan, a.mask + (int64_t)t * a.ny * a.W, false, nullptr, rb, L2dPrefetch<0>());
 }
 
 // ------------------------------------------------------------------------------------------------
