@@ -1151,6 +1151,7 @@ __global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
         // for the one word in ten that has common pixels.
         uint64_t c[OVB], p[OVB];
         uint32_t ec[OVB], ep[OVB], lt[OVB];                              // lt: bit 0 / 1 = carry-in of c / p (top bit of the word to the left, same row)
+        uint32_t ltc[OVB], ltp[OVB];
         int yy[OVB];
 #pragma unroll
         for (int u = 0; u < OVB; u++) {                                  // level 1 (and everything whose address is known already)
@@ -1158,15 +1159,18 @@ __global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
             const int y = ii / W;
             yy[u] = idx < nwords ? y : -1;
             c[u] = mc[ii]; p[u] = mp[ii];
-            lt[u] = 0;
-            if (lane == 0) lt[u] = (reinterpret_cast<const uint32_t *>(mc)[2 * im + 1] >> 31) | ((reinterpret_cast<const uint32_t *>(mp)[2 * im + 1] >> 31) << 1);
+            // lane 0's left neighbours: requested by EVERY lane (the others ask for the first word of the plane, one cached line) --
+            // a load under `if (lane == 0)` made hipcc wait for every outstanding load right behind it, word after word
+            const int il = lane == 0 ? 2 * im + 1 : 1;
+            ltc[u] = reinterpret_cast<const uint32_t *>(mc)[il];
+            ltp[u] = reinterpret_cast<const uint32_t *>(mp)[il];
             ec[u] = rsc[y] + wsc[ii]; ep[u] = rsp[y] + wsp[ii];          // runs started left of this word
         }
 #pragma unroll
         for (int u = 0; u < OVB; u++) {
             const uint32_t mine = (uint32_t)(c[u] >> 63) | ((uint32_t)(p[u] >> 63) << 1);
             const uint32_t left = (uint32_t)__shfl_up((int)mine, 1);
-            if (lane != 0) lt[u] = left;
+            lt[u] = lane != 0 ? left : ((ltc[u] >> 31) | ((ltp[u] >> 31) << 1));
             const int ii = min(i0 + u * THREADS, nwords - 1);
             if (ii - yy[u] * W <= 0) lt[u] = 0;                          // first word of a row: nothing to the left
             if (yy[u] < 0) c[u] = 0ull;                                  // past the end: no common pixels
