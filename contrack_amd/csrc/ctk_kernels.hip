@@ -1626,10 +1626,24 @@ __global__ __launch_bounds__(TH) void k_relabel_v5(RelabelArgs a, int rb, int rv
     uint32_t *rst = reinterpret_cast<uint32_t *>(smem + (size_t)rb * W * 8 + (((size_t)rb * W * 2 + 7) & ~(size_t)7));
     int32_t *rvs = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(rst) + ((((size_t)rb + 1) * 4 + 7) & ~(size_t)7));
     const uint32_t trun = a.run_base[t + 1] - a.run_base[t];
-    for (int i = tid; i < rows * W; i += TH) { mrow[i] = a.mask[row0 * W + i]; wst[i] = a.wstart[row0 * W + i]; }
-    for (int i = tid; i <= rows; i += TH) rst[i] = (y0 + i < ny) ? a.rowstart[row0 + i] : trun;
-    // the chunk's run values in chunk order (k_run_values): loaded together with the tables -- one round trip, one barrier
-    if (a.chunk_vals && tid >= TH - CTK_CV) rvs[tid - (TH - CTK_CV)] = a.chunk_vals[(int64_t)bid * CTK_CV + (tid - (TH - CTK_CV))];
+    // The tables of the chunk: mask words, run prefixes, row starts and the chunk's run values in chunk order (k_run_values) --
+    // ONE round trip, one barrier.  Every load is issued before the first is used and none stands under a per-lane condition
+    // (indices clamped, the LDS stores masked): written as three guarded loops, hipcc waited for all outstanding loads behind
+    // each of them -- three trips to L2 in a row at the start of every workgroup.
+    {
+        const int nw = rows * W;
+        const int iw = min(tid, nw - 1), ir = min(tid, rows), irc = min(ir, ny - 1 - y0);
+        const uint64_t m0 = a.mask[row0 * W + iw];
+        const uint16_t w0 = a.wstart[row0 * W + iw];
+        const uint32_t rs0 = a.rowstart[row0 + irc];
+        int32_t cv0 = 0;
+        if (a.chunk_vals) cv0 = a.chunk_vals[(int64_t)bid * CTK_CV + max(tid - (TH - CTK_CV), 0)];       // (uniform condition, last load)
+        if (tid < nw) { mrow[tid] = m0; wst[tid] = w0; }
+        if (tid <= rows) rst[tid] = (y0 + ir < ny) ? rs0 : trun;
+        if (a.chunk_vals && tid >= TH - CTK_CV) rvs[tid - (TH - CTK_CV)] = cv0;
+        for (int i = tid + TH; i < nw; i += TH) { mrow[i] = a.mask[row0 * W + i]; wst[i] = a.wstart[row0 * W + i]; }      // (chunks of more than TH words)
+        for (int i = tid + TH; i <= rows; i += TH) rst[i] = (y0 + i < ny) ? a.rowstart[row0 + i] : trun;
+    }
     __syncthreads();
     const uint32_t r0 = rst[0], nr = rst[rows] - r0;
     if (nr == 0u && a.fast_zero) {
