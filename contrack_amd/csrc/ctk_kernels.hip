@@ -1328,7 +1328,7 @@ __device__ __forceinline__ void for_each_fg_pixel_in_row(const uint64_t *mw, int
 // R5: final id of a component with fresh label l (> 0), box q = {y0, y1, x0, x1}, at timestep t.  All of a component's
 // pixels move together through an op whose box contains the component's box, none moves when the boxes are disjoint;
 // anything else is resolved per pixel (returns -l).
-__device__ inline int32_t comp_final_label(const FoldArgs &f, int32_t l, int32_t t, const uint16_t *q)
+__device__ inline int32_t comp_final_label(const FoldArgs &f, int32_t l, int32_t t, int q0, int q1, int q2, int q3 /* the box, in registers */)
 {
     if (f.nops == 0) return l;
     int32_t cur = l, s = 0;
@@ -1338,8 +1338,8 @@ __device__ inline int32_t comp_final_label(const FoldArgs &f, int32_t l, int32_t
             if (idx < s) continue;
             const CtkOp o = f.ops[idx];
             const bool t_in = t >= o.t0 && t <= o.t1;
-            const bool inside = t_in && q[0] >= o.y0 && q[1] <= o.y1 && q[2] >= o.x0 && q[3] <= o.x1;
-            const bool disjoint = !t_in || q[1] < o.y0 || q[0] > o.y1 || q[3] < o.x0 || q[2] > o.x1;
+            const bool inside = t_in && q0 >= o.y0 && q1 <= o.y1 && q2 >= o.x0 && q3 <= o.x1;
+            const bool disjoint = !t_in || q1 < o.y0 || q0 > o.y1 || q3 < o.x0 || q2 > o.x1;
             if (inside) { cur = o.lo; s = idx + 1; again = true; break; }
             if (!disjoint) return -l;
         }
@@ -1398,8 +1398,11 @@ __global__ __launch_bounds__(256) void k_extent(ExtentArgs a)
     for (uint32_t c = tid; c < n; c += blockDim.x) {
         int32_t l;
         if (a.lab) {                                       // single-GPU path: k_rs_final's work, one launch less
+            // (the box travels with the label, as one 8-byte load: read element by element inside the short-circuit comparisons
+            // of the fold it was up to eight more dependent trips to L2 for every component of a contour that crosses the seam)
             l = a.lab[cb + c];
-            if (l > 0) l = comp_final_label(a.fold, l, tg, a.box + 4 * (int64_t)(cb + c));
+            const uint2 bq = *reinterpret_cast<const uint2 *>(a.box + 4 * (int64_t)(cb + c));
+            if (l > 0) l = comp_final_label(a.fold, l, tg, (int)(bq.x & 0xffffu), (int)(bq.x >> 16), (int)(bq.y & 0xffffu), (int)(bq.y >> 16));
             a.comp_label_w[cb + c] = l;
         } else l = a.comp_label[cb + c];
         if (l > 0) { ext_update(tmin, tmax, l, tg); }
