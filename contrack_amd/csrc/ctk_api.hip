@@ -52,7 +52,7 @@ static double now_ms_fwd() { return std::chrono::duration<double, std::milli>(st
 struct CtkEnv {
     int sd_dbg = 0, relabel_rows = 0, xcd_thr = 0, xcd_rel = 0, relabel_threads = 0;
     bool pass_launches = false, print_ptrs = false, seamstats = false, relabel_plain = false, relabel_v4 = false, hosttrace = false,
-         sh_no_slots = false, no_spec_x4 = false, sh_force_split = false, sh_host_seam = false, rle_out = true;
+         sh_no_slots = false, no_spec_x4 = false, sh_force_split = false, sh_host_seam = false, rle_out = true, mask_tune = true;
     int rle_lanes = 0, rle_per_lane = 0;
     CtkEnv()
     {
@@ -63,6 +63,7 @@ struct CtkEnv {
         relabel_plain = on("CTK_RELABEL_PLAIN"); relabel_v4 = on("CTK_RELABEL_V4"); hosttrace = on("CTK_HOSTTRACE");
         sh_no_slots = on("CTK_SH_NO_SLOTS"); no_spec_x4 = on("CTK_NO_SPEC_X4"); sh_force_split = on("CTK_SH_FORCE_SPLIT"); sh_host_seam = on("CTK_SH_HOST_SEAM");
         rle_out = !(getenv("CTK_RLE_OUT") && num("CTK_RLE_OUT") == 0);
+        mask_tune = !(getenv("CTK_MASK_TUNE") && num("CTK_MASK_TUNE") == 0);
         rle_lanes = num("CTK_RLE_LANES"); rle_per_lane = num("CTK_RLE_PER_LANE");
     }
 };
@@ -76,6 +77,7 @@ namespace {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    void *base = nullptr;                           // the allocation p lies in when p was placed inside a larger one (ensure_placed); else nullptr
 };
 
 enum State { ST_IDLE = 0, ST_LABELLED, ST_OVERLAPPED, ST_TABLES, ST_EXTENTS };
@@ -236,6 +238,7 @@ struct ctk_handle {
     std::vector<uint32_t> rle_run_base;            // host copy of run_base (deliver_runs)
     std::vector<RleBlock> rle_blocks;
     bool rle_out = false;                          // this call's result leaves the device as run tables: launch_relabel is a no-op
+    int64_t mask_off_dbg = -1;                     // ctk_debug_set_mask_offset: the mask placed this many bytes into a larger allocation (-1: plain)
     int rle_mode = -1;                             // ctk_set_result_transfer: -1 environment (CTK_RLE_OUT, default on), 0 dense copy, 1 runs
     // time-sharded path (ctk_sharded.hip)
     DevBuf sh_mask_next, sh_send, sh_recv, sh_prev, sh_elist, sh_ovr_slot, sh_ovr_val, sh_amb_list, sh_counts, sh_cl_shared, sh_cl_sent;
@@ -323,7 +326,7 @@ int ensure(ctk_handle *h, DevBuf &b, size_t need)
     if (b.cap >= need) return CTK_OK;
     // hipFree waits for the device: with a collective in flight that wait must be the communicator's guarded one
     if (b.p && h && h->active_comm) { if (int rc = ctk_comm_wait(h->active_comm)) return rc; }
-    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    if (b.p) { (void)hipFree(b.base ? b.base : b.p); b.p = nullptr; b.base = nullptr; b.cap = 0; }
     size_t cap = need + need / 8 + 256;                   // a little head room: sizes vary between calls
     hipError_t e = hipMalloc(&b.p, cap);
     if (e != hipSuccess) {
@@ -336,6 +339,22 @@ int ensure(ctk_handle *h, DevBuf &b, size_t need)
     }
     b.cap = cap;
     (void)h;
+    return CTK_OK;
+}
+
+// the same with the buffer placed `off` bytes into an allocation that is `slack` bytes larger (placement experiments / tuning:
+// where a buffer lies decides which HBM channels its stream meets)
+int ensure_placed(ctk_handle *h, DevBuf &b, size_t need, size_t off, size_t slack)
+{
+    if (need == 0) need = 8;
+    if (b.cap >= need && b.base && (size_t)((char *)b.p - (char *)b.base) == off) return CTK_OK;
+    if (b.p && h && h->active_comm) { if (int rc = ctk_comm_wait(h->active_comm)) return rc; }
+    if (b.p) { (void)hipFree(b.base ? b.base : b.p); b.p = nullptr; b.base = nullptr; b.cap = 0; }
+    const size_t cap = need + need / 8 + 256;
+    void *q = nullptr;
+    const hipError_t e = hipMalloc(&q, cap + slack);
+    if (e != hipSuccess) return ctk_set_error(CTK_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", cap + slack, hipGetErrorString(e));
+    b.base = q; b.p = (char *)q + off; b.cap = cap;
     return CTK_OK;
 }
 
@@ -480,7 +499,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
                       &h->sh_mask_next, &h->sh_send, &h->sh_recv, &h->sh_prev, &h->sh_elist, &h->sh_ovr_slot, &h->sh_ovr_val,
                       &h->sh_amb_list, &h->sh_counts, &h->sh_cl_shared, &h->sh_cl_sent, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_root, &h->sd_nops, &h->sd_lbox, &h->rv_pstate};
-    for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
+    for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->base ? b->base : b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
     if (h->h_cand) (void)hipHostFree(h->h_cand);
@@ -590,6 +609,13 @@ extern "C" int ctk_set_filter_round(ctk_handle *h, int passes)
     if (!h || passes < 1 || passes > 32) return ctk_set_error(CTK_E_INVALID, "ctk_set_filter_round: 1..32 passes per round");
     h->filter_round = passes;
     h->async_passes = passes;                            // (the fused pass launches this many; it adapts from there)
+    return CTK_OK;
+}
+
+extern "C" int ctk_debug_set_mask_offset(ctk_handle *h, int64_t off)
+{
+    if (!h || off < -1 || off > ((int64_t)64 << 20) || (off > 0 && (off & 255))) return ctk_set_error(CTK_E_INVALID, "ctk_debug_set_mask_offset: -1 or a multiple of 256 up to 64 MB");
+    h->mask_off_dbg = off;
     return CTK_OK;
 }
 
@@ -735,7 +761,10 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         for (int y = ny - 1; y >= 0; y--) next_tiny[y] = (lsb[(size_t)y] < maxbl + lg - 53) ? y : next_tiny[y + 1];
     }
 
-    CTKCHK(ensure(h, h->mask, (size_t)nrows * W * 8));
+    const void *mask_before = h->mask.p;
+    if (h->mask_off_dbg >= 0) CTKCHK(ensure_placed(h, h->mask, (size_t)nrows * W * 8, (size_t)h->mask_off_dbg, (size_t)64 << 20));
+    else CTKCHK(ensure(h, h->mask, (size_t)nrows * W * 8));
+    const bool mask_fresh = h->mask.p != mask_before;
     CTKCHK(ensure(h, h->wstart, (size_t)nrows * W * 2));
     CTKCHK(ensure(h, h->rowstart, (size_t)nrows * 4));
     CTKCHK(ensure(h, h->tcount, (size_t)T * 4));
@@ -807,6 +836,50 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
             HIPCHK(hipGetLastError());
             return CTK_OK;
         };
+        // Where the bit mask lies decides how fast the read stream of the threshold kernel runs: 0.106 or 0.119 ms at 2707 x 181 x 360,
+        // 0.315 or 0.36 at 480 x 721 x 1440 -- per ALLOCATION (not per offset inside one: tools/mask_place_probe.py; every
+        // re-allocation flipped the mode), for as long as the handle lives.  This was the "bimodal board" of rounds 2-4.  So a freshly
+        // allocated mask is tried: the kernel is timed on it, and unless it streams at >= 6.2 TB/s up to three more allocations are
+        // timed and the fastest kept.  Once per handle and slab size (~1-3 ms); CTK_MASK_TUNE=0 turns it off.
+        if (anom_dev && mask_fresh && h->mask_off_dbg < 0 && ctk_env().mask_tune && (size_t)T * ny * nx * (f64 ? 8 : 4) >= ((size_t)128 << 20)) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                const size_t mbytes = (size_t)nrows * W * 8;
+                const double gb = (double)T * ny * nx * (f64 ? 8 : 4) / 1e9;
+                auto time_it = [&](double *ms) -> int {
+                    CTKCHK(launch_threshold(anom_dev, 0, T));
+                    HIPCHK(hipEventRecord(e0, s));
+                    CTKCHK(launch_threshold(anom_dev, 0, T));
+                    CTKCHK(launch_threshold(anom_dev, 0, T));
+                    HIPCHK(hipEventRecord(e1, s));
+                    HIPCHK(hipEventSynchronize(e1));
+                    float f = 0.f;
+                    HIPCHK(hipEventElapsedTime(&f, e0, e1));
+                    *ms = 0.5 * f;
+                    return CTK_OK;
+                };
+                DevBuf best = h->mask;
+                double best_ms = 0.0;
+                int rc = time_it(&best_ms);
+                h->stats[CTK_S_MASK_TRIES] = 1;
+                for (int k = 0; rc == CTK_OK && k < 3 && gb / best_ms < 6.2; k++) {         // (GB / ms = TB/s)
+                    DevBuf nb;
+                    if (ensure(h, nb, mbytes) != CTK_OK) break;                        // (no memory for another try: keep what there is)
+                    h->mask = nb;
+                    double ms = 0.0;
+                    rc = time_it(&ms);
+                    h->stats[CTK_S_MASK_TRIES]++;
+                    if (rc == CTK_OK && ms < best_ms) { (void)hipFree(best.base ? best.base : best.p); best = nb; best_ms = ms; }
+                    else (void)hipFree(nb.p);
+                    h->mask = best;
+                }
+                h->mask = best;
+                if (ctk_env().hosttrace) fprintf(stderr, "mask placement: %d allocation(s) tried, threshold stream %.2f TB/s\n", (int)h->stats[CTK_S_MASK_TRIES], gb / best_ms);
+                if (rc != CTK_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+            }
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
         if (anom_dev) CTKCHK(launch_threshold(anom_dev, 0, T));
         else CTKCHK(stream_in(h, f64, T, ny, nx, launch_threshold));                     // the slab arrives in chunks (ctk_track_stream_*)
     }

@@ -280,6 +280,7 @@ int ctk_get_timing_sums(ctk_handle *h, double *sums, int64_t *counts, int reset)
 #define CTK_S_RLE_OUT       22    /* host-array entries: 0 = the result was written by k_relabel and copied densely; n > 0 = it travelled as
                                    * run tables and was expanded on the host, n - 1 blocks of timesteps (those holding complex
                                    * components) went through the write kernel */
+#define CTK_S_MASK_TRIES    23    /* allocations of the bit mask that were timed when it was last (re)allocated (0: not tuned) */
 #define CTK_NSTATS          24
 int ctk_get_stats(ctk_handle *h, int64_t *out /* [CTK_NSTATS] */);
 /* filter passes launched per round before convergence is checked on the host (default 10, 1..32)   */
@@ -326,6 +327,8 @@ int ctk_host_free(ctk_handle *h, void *p);
  * scheme above).  -1: back to the environment's choice.  The device-resident entries always write `flag_dev` densely.
  * CTK_S_RLE_OUT reports what a call did.  (contrack.py:776-791: where the reference materialises `flag`) */
 int ctk_set_result_transfer(ctk_handle *h, int mode);
+/* placement experiment: the bit mask `off` bytes (a multiple of 256, up to 64 MB) into a larger allocation from the next call on; -1: plain */
+int ctk_debug_set_mask_offset(ctk_handle *h, int64_t off);
 /* The decoder of that transfer on its own, on tables in host memory (no device call; for tests): mask u64 [T][ny][ceil(nx/64)],
  * rowstart u32 [T][ny] (first run of the row, relative to its time step), run_base u32 [T + 1], run_val i32 [runs] -> flag
  * [T][ny][nx]; *wrote_background: a zero was written; *complex_runs: a negative run value was met (its pixels are not decoded). */
