@@ -619,6 +619,28 @@ extern "C" int ctk_debug_set_mask_offset(ctk_handle *h, int64_t off)
     return CTK_OK;
 }
 
+// placement experiments: frees one work-space buffer, so that the next call allocates it anew (somewhere else)
+extern "C" int ctk_debug_drop_buffer(ctk_handle *h, int which)
+{
+    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
+    DevBuf *b = nullptr;
+    switch (which) {
+    case 0: b = &h->mask; break;
+    case 1: b = &h->wstart; break;
+    case 2: b = &h->rowstart; break;
+    case 3: b = &h->chunk_vals; break;
+    case 4: b = &h->run_val; break;
+    case 5: b = &h->run_base; break;
+    default: return ctk_set_error(CTK_E_INVALID, "ctk_debug_drop_buffer: 0..5");
+    }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (b->p) { (void)hipFree(b->base ? b->base : b->p); b->p = nullptr; b->base = nullptr; b->cap = 0; }
+    h->c_thr_valid = false; h->c_w_valid = false; h->fz_init = false;
+    h->runs_cap = 0;                                          // (the run-indexed buffers are looked at again: no speculative launch into a dropped one)
+    return CTK_OK;
+}
+
 extern "C" int ctk_set_result_transfer(ctk_handle *h, int mode)
 {
     if (!h || mode < -1 || mode > 1) return ctk_set_error(CTK_E_INVALID, "ctk_set_result_transfer: mode -1 (environment), 0 (dense copy) or 1 (run tables)");

@@ -329,6 +329,8 @@ int ctk_host_free(ctk_handle *h, void *p);
 int ctk_set_result_transfer(ctk_handle *h, int mode);
 /* placement experiment: the bit mask `off` bytes (a multiple of 256, up to 64 MB) into a larger allocation from the next call on; -1: plain */
 int ctk_debug_set_mask_offset(ctk_handle *h, int64_t off);
+/* placement experiment: frees one work-space buffer (0 mask, 1 wstart, 2 rowstart, 3 chunk_vals, 4 run_val, 5 run_base); the next call allocates it anew */
+int ctk_debug_drop_buffer(ctk_handle *h, int which);
 /* The decoder of that transfer on its own, on tables in host memory (no device call; for tests): mask u64 [T][ny][ceil(nx/64)],
  * rowstart u32 [T][ny] (first run of the row, relative to its time step), run_base u32 [T + 1], run_val i32 [runs] -> flag
  * [T][ny][nx]; *wrote_background: a zero was written; *complex_runs: a negative run value was met (its pixels are not decoded). */
