@@ -884,7 +884,12 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                 double best_ms = 0.0;
                 int rc = time_it(&best_ms);
                 h->stats[CTK_S_MASK_TRIES] = 1;
-                for (int k = 0; rc == CTK_OK && k < 3 && gb / best_ms < 6.2; k++) {         // (GB / ms = TB/s)
+                static const int max_tries = getenv("CTK_MASK_TRIES") ? atoi(getenv("CTK_MASK_TRIES")) : 3;
+                static const size_t spacer_mb = getenv("CTK_MASK_SPACER_MB") ? (size_t)atoll(getenv("CTK_MASK_SPACER_MB")) : 0;
+                std::vector<void *> spacers;
+                struct FreeSpacers { std::vector<void *> &v; ~FreeSpacers() { for (void *q : v) (void)hipFree(q); } } free_spacers{spacers};
+                for (int k = 0; rc == CTK_OK && k < max_tries && gb / best_ms < 6.2; k++) {         // (GB / ms = TB/s)
+                    if (spacer_mb) { void *q = nullptr; if (hipMalloc(&q, spacer_mb << 20) == hipSuccess) spacers.push_back(q); }
                     DevBuf nb;
                     if (ensure(h, nb, mbytes) != CTK_OK) break;                        // (no memory for another try: keep what there is)
                     h->mask = nb;
@@ -896,7 +901,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                     h->mask = best;
                 }
                 h->mask = best;
-                if (ctk_env().hosttrace) fprintf(stderr, "mask placement: %d allocation(s) tried, threshold stream %.2f TB/s\n", (int)h->stats[CTK_S_MASK_TRIES], gb / best_ms);
+                if (ctk_env().hosttrace) fprintf(stderr, "mask placement: %d allocation(s) tried, threshold stream %.2f TB/s, mask at %p, slab at %p\n", (int)h->stats[CTK_S_MASK_TRIES], gb / best_ms, h->mask.p, anom_dev);
                 if (rc != CTK_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
             }
             if (e0) (void)hipEventDestroy(e0);
