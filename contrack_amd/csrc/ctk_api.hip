@@ -291,6 +291,7 @@ struct ctk_handle {
     int small_threads[3] = {0, 0, 0};              // experiments (ctk_debug_set_small_threads): threads of k_extent / k_run_values / k_compact_init, 0 = default
     int relabel_threads = 0, relabel_rows_dbg = 0;  // experiments (ctk_debug_set_relabel): threads / rows per workgroup of k_relabel_v5, 0 = default
     int xcd_thr = -1, xcd_rel = -1;               // chunk -> XCD mapping of the two streaming kernels (xcd_chunk); -1: the environment's / default
+    int xcd_thr_tuned = -1;                       // tile size the mask-placement tuning found fastest (-1: not tuned)
     bool sh_collective_err = false;               // the time-shard path's error was decided identically on every rank
     ctk_comm *active_comm = nullptr;              // set while the time-shard path runs with more than one rank
     // host scratch of the seam driver, kept between calls (fresh 100+ KB vectors would page-fault every call)
@@ -841,11 +842,11 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         else if (v4 && thr_variant == 44) k_threshold_v4<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
         else if (v4 && thr_variant == 42) k_threshold_v4<OP, 2><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
         else if (v4 && thr_variant == 4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
-        else if (v4 && u7 == 4) k_threshold_v7<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : ctk_env().xcd_thr); \
-        else if (v4 && u7 == 5) k_threshold_v7<OP, 5><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : ctk_env().xcd_thr); \
-        else if (v4 && u7 == 6) k_threshold_v7<OP, 6><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : ctk_env().xcd_thr); \
-        else if (v4 && u7 == 7) k_threshold_v7<OP, 7><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : ctk_env().xcd_thr); \
-        else if (v4) k_threshold_v7<OP, 8><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : ctk_env().xcd_thr); \
+        else if (v4 && u7 == 4) k_threshold_v7<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr)); \
+        else if (v4 && u7 == 5) k_threshold_v7<OP, 5><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr)); \
+        else if (v4 && u7 == 6) k_threshold_v7<OP, 6><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr)); \
+        else if (v4 && u7 == 7) k_threshold_v7<OP, 7><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr)); \
+        else if (v4) k_threshold_v7<OP, 8><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr)); \
         else k_threshold<OP, float><<<g, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, rows, ny, nx, W, mk, zc); \
     } while (0)
             switch (cmp_op) {
@@ -880,28 +881,47 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                     *ms = 0.5 * f;
                     return CTK_OK;
                 };
+                // ... and so does the size of the tiles in which the chunks are dealt to the XCDs (NOTES: -5 % with 64 on one placement; in
+                // another process 16 ran at 6.6 TB/s where 64 stayed at 6.0): every allocation is timed with the tile sizes in turn
+                const bool tune_xcd = h->xcd_thr < 0;
+                const int modes[4] = {ctk_env().xcd_thr, 16, 256, 4};
+                const int nmodes = tune_xcd ? 4 : 1;
                 DevBuf best = h->mask;
-                double best_ms = 0.0;
-                int rc = time_it(&best_ms);
+                double best_ms = 1e30;
+                int best_mode = h->xcd_thr, rc = CTK_OK;
+                auto try_modes = [&](const DevBuf &cand, bool *took) -> int {
+                    *took = false;
+                    for (int m = 0; m < nmodes && gb / best_ms < 6.2; m++) {                 // (GB / ms = TB/s)
+                        if (m > 0 && modes[m] == modes[0]) continue;
+                        if (tune_xcd) h->xcd_thr = modes[m];
+                        double ms = 0.0;
+                        CTKCHK(time_it(&ms));
+                        if (ms < best_ms) { best_ms = ms; best_mode = tune_xcd ? modes[m] : h->xcd_thr; *took = true; }
+                    }
+                    (void)cand;
+                    return CTK_OK;
+                };
+                bool took = false;
+                rc = try_modes(best, &took);
                 h->stats[CTK_S_MASK_TRIES] = 1;
                 static const int max_tries = getenv("CTK_MASK_TRIES") ? atoi(getenv("CTK_MASK_TRIES")) : 3;
                 static const size_t spacer_mb = getenv("CTK_MASK_SPACER_MB") ? (size_t)atoll(getenv("CTK_MASK_SPACER_MB")) : 0;
                 std::vector<void *> spacers;
                 struct FreeSpacers { std::vector<void *> &v; ~FreeSpacers() { for (void *q : v) (void)hipFree(q); } } free_spacers{spacers};
-                for (int k = 0; rc == CTK_OK && k < max_tries && gb / best_ms < 6.2; k++) {         // (GB / ms = TB/s)
+                for (int k = 0; rc == CTK_OK && k < max_tries && gb / best_ms < 6.2; k++) {
                     if (spacer_mb) { void *q = nullptr; if (hipMalloc(&q, spacer_mb << 20) == hipSuccess) spacers.push_back(q); }
                     DevBuf nb;
                     if (ensure(h, nb, mbytes) != CTK_OK) break;                        // (no memory for another try: keep what there is)
                     h->mask = nb;
-                    double ms = 0.0;
-                    rc = time_it(&ms);
+                    rc = try_modes(nb, &took);
                     h->stats[CTK_S_MASK_TRIES]++;
-                    if (rc == CTK_OK && ms < best_ms) { (void)hipFree(best.base ? best.base : best.p); best = nb; best_ms = ms; }
+                    if (rc == CTK_OK && took) { (void)hipFree(best.base ? best.base : best.p); best = nb; }
                     else (void)hipFree(nb.p);
                     h->mask = best;
                 }
+                if (tune_xcd) { h->xcd_thr = -1; h->xcd_thr_tuned = best_mode; }
                 h->mask = best;
-                if (ctk_env().hosttrace) fprintf(stderr, "mask placement: %d allocation(s) tried, threshold stream %.2f TB/s, mask at %p, slab at %p\n", (int)h->stats[CTK_S_MASK_TRIES], gb / best_ms, h->mask.p, anom_dev);
+                if (ctk_env().hosttrace) fprintf(stderr, "mask placement: %d allocation(s) tried, tiles of %d chunks per XCD, threshold stream %.2f TB/s, mask at %p, slab at %p\n", (int)h->stats[CTK_S_MASK_TRIES], best_mode, gb / best_ms, h->mask.p, anom_dev);
                 if (rc != CTK_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
             }
             if (e0) (void)hipEventDestroy(e0);
