@@ -292,6 +292,8 @@ struct ctk_handle {
     int relabel_threads = 0, relabel_rows_dbg = 0;  // experiments (ctk_debug_set_relabel): threads / rows per workgroup of k_relabel_v5, 0 = default
     int xcd_thr = -1, xcd_rel = -1;               // chunk -> XCD mapping of the two streaming kernels (xcd_chunk); -1: the environment's / default
     int xcd_thr_tuned = -1;                       // tile size the mask-placement tuning found fastest (-1: not tuned)
+    int xcd_rel_tuned = -1;                       // the same for the write kernel (tune_relabel), for the shape below
+    int64_t rel_tuned_T = -1; int rel_tuned_ny = 0, rel_tuned_nx = 0; const void *rel_tuned_flag = nullptr;
     bool sh_collective_err = false;               // the time-shard path's error was decided identically on every rank
     ctk_comm *active_comm = nullptr;              // set while the time-shard path runs with more than one rank
     // host scratch of the seam driver, kept between calls (fresh 100+ KB vectors would page-fault every call)
@@ -1858,7 +1860,7 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
     a.chunk_vals = chunk_vals ? chunk_vals + t0 * nchunk * CTK_CV : nullptr;
     a.guard = h->guard_on ? P<uint32_t>(h->counters) : nullptr;
     a.plain_stores = ctk_env().relabel_plain ? 1 : 0;
-    a.xcd_remap = h->xcd_rel >= 0 ? h->xcd_rel : ctk_env().xcd_rel;
+    a.xcd_remap = h->xcd_rel >= 0 ? h->xcd_rel : (h->xcd_rel_tuned >= 0 ? h->xcd_rel_tuned : ctk_env().xcd_rel);
     a.fast_zero = h->relabel_threads == 257 ? 1 : 0;       // (experiment, off: NOTES round 4)
     a.tab_batched = nt * nchunk < 200000 ? 1 : 0;          // (1 deg, 480 x 0.25 deg: -4 %; 14 600 x 0.25 deg: +2.7 % -- NOTES round 4)
     const int64_t npl = (int64_t)h->ny * h->nx;
@@ -2152,6 +2154,39 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
                               const double *thr, int cmp_op, const float *wrow, double overlap, int persistence, int twosided, int32_t *flag_dev,
                               int64_t *n_tracked);                                                      // ctk_sharded.hip
 
+// How the chunks of the write kernel are dealt to the XCDs decides a few per cent of its time, and which way is best depends on the
+// grid and on where the caller's `flag` lies (2707 x 181 x 360: one contiguous eighth per XCD -5 ... -8 % against launch order,
+// 480 x 721 x 1440: launch order best by 2-5 %; tools/xcd_probe.py).  After the first pass on a new shape / output buffer the kernel is
+// timed in the three ways on the finished tables (it writes the same flags again) and the fastest kept.  ~1 ms, once.
+static void tune_relabel(ctk_handle *h, int persistence, int32_t *flag_dev)
+{
+    if (h->xcd_rel >= 0 || !ctk_env().mask_tune || h->sio || h->rle_out || !flag_dev || h->state != ST_TABLES) return;
+    if (h->rel_tuned_T == h->T && h->rel_tuned_ny == h->ny && h->rel_tuned_nx == h->nx && h->rel_tuned_flag == flag_dev) return;
+    if ((size_t)h->T * h->ny * h->nx * 4 < ((size_t)128 << 20)) return;
+    h->rel_tuned_T = h->T; h->rel_tuned_ny = h->ny; h->rel_tuned_nx = h->nx; h->rel_tuned_flag = flag_dev;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); return; }
+    int rows = 0;
+    const int32_t *cv = chunk_vals_for(h, flag_dev, &rows);
+    const int modes[3] = {0, 1, 16};
+    double best = 1e30;
+    int best_mode = -1;
+    bool ok = true;
+    for (int m = 0; m < 3 && ok; m++) {
+        h->xcd_rel_tuned = modes[m];
+        ok = launch_relabel(h, persistence, flag_dev, true, cv) == CTK_OK && hipEventRecord(e0, h->stream) == hipSuccess;
+        ok = ok && launch_relabel(h, persistence, flag_dev, true, cv) == CTK_OK && launch_relabel(h, persistence, flag_dev, true, cv) == CTK_OK;
+        ok = ok && hipEventRecord(e1, h->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+        float f = 0.f;
+        ok = ok && hipEventElapsedTime(&f, e0, e1) == hipSuccess;
+        if (ok && f < best) { best = f; best_mode = modes[m]; }
+    }
+    h->xcd_rel_tuned = ok ? best_mode : -1;
+    if (ctk_env().hosttrace) fprintf(stderr, "write kernel: chunk -> XCD mode %d, %.2f TB/s\n", h->xcd_rel_tuned, (double)h->T * h->ny * h->nx * 4 / 1e9 / (0.5 * best));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipStreamSynchronize(h->stream);
+}
+
 static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t T, int ny, int nx, const double *thr, int cmp_op,
                           const float *wrow, double overlap, int persistence, int twosided, int32_t *flag_dev, int64_t *n_tracked)
 {
@@ -2166,7 +2201,7 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
     HT("overlap launched");
     if (h->use_device_resolve && async_wanted(h) && T > 0) {
         const int ra = resolve_async(h, overlap, twosided, persistence, flag_dev, n_tracked);
-        if (ra <= 0) { h->ms[CTK_T_TOTAL] += now_ms() - t0; return ra; }
+        if (ra <= 0) { if (ra == 0) tune_relabel(h, persistence, flag_dev); h->ms[CTK_T_TOTAL] += now_ms() - t0; return ra; }
         h->stats[CTK_S_FUSED] = 0;                           // fell off the fused path: the synchronous one resolves the same tables
         if (h->fz_pslot) {
             // ... which wants the co-occurrence records in one contiguous range: the histogram again, ranges from the counter
@@ -2217,6 +2252,7 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
     int wrote0 = 0;
     CTKCHK(ctk_shard_write(h, persistence, flag_dev, &alive, &wrote0));
     if (n_tracked) *n_tracked = alive + (wrote0 ? 1 : 0) - 1;       // len(np.unique(flag)) - 1, contrack.py:793
+    tune_relabel(h, persistence, flag_dev);
     h->ms[CTK_T_TOTAL] += now_ms() - t0;
     return CTK_OK;
 }
