@@ -210,7 +210,7 @@ struct ctk_handle {
     DevBuf chunk_vals;                             // run values in the chunk order of k_relabel_v4
     // fused one-call path (ctk_seam_dev.hip): clusters of candidate labels, cluster root per group record; the pass runs without a
     // host hand-off and is validated from a device-written block of scalars after its only synchronisation
-    DevBuf sd_parent, sd_tmin, sd_tmax, sd_root, sd_nops, sd_lbox, rv_pstate;
+    DevBuf sd_parent, sd_tmin, sd_tmax, sd_root, sd_nops, sd_lbox, rv_pstate, ci_bsum;
     uint32_t *h_amail = nullptr;                   // pinned: AsyncMail scalars
     uint32_t op_cap_hint = 4096;                   // operation slots of the next fused pass (grows with what the passes needed)
     uint32_t nd_hint = 4096;                       // dense candidate labels of the last pass: grid of k_seam_driver
@@ -501,7 +501,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
                       &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
                       &h->sh_mask_next, &h->sh_send, &h->sh_recv, &h->sh_prev, &h->sh_elist, &h->sh_ovr_slot, &h->sh_ovr_val,
-                      &h->sh_amb_list, &h->sh_counts, &h->sh_cl_shared, &h->sh_cl_sent, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_root, &h->sd_nops, &h->sd_lbox, &h->rv_pstate};
+                      &h->sh_amb_list, &h->sh_counts, &h->sh_cl_shared, &h->sh_cl_sent, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_root, &h->sd_nops, &h->sd_lbox, &h->rv_pstate, &h->ci_bsum};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->base ? b->base : b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -1073,7 +1073,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         h->spec_ny = ny; h->spec_nx = nx; h->spec_T = T;
     }
     h->fz_init = false;
-    if (!defer_compact && T > 0 && T <= 65536 && h->use_device_resolve && async_wanted(h)) {
+    if (!defer_compact && T > 0 && h->use_device_resolve && async_wanted(h)) {
         // fused one-call path: prefix of the component counts, compaction and the initialisation of the resolver's per-component
         // arrays in one launch (k_compact_init)
         const size_t R = h->total_runs ? h->total_runs : 1;
@@ -1089,8 +1089,14 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         ci.ambig = P<uint32_t>(h->rv_scalars) + 1; ci.pstate = P<uint32_t>(h->rv_pstate);
         ci.next_tiny = (const int32_t *)(P<int64_t>(h->wlo) + 2 * (size_t)h->ny);
         ci.nchanged = (CTK_MAX_JACOBI + 1) * CTK_CHG_SLOTS; ci.pstride = CTK_PSTATE_STRIDE; ci.T = T;
-        ci.base_ptr = nullptr; ci.ovr_slot = nullptr; ci.amb_cnt = nullptr; ci.dcount = nullptr;
+        ci.base_ptr = nullptr; ci.ovr_slot = nullptr; ci.amb_cnt = nullptr; ci.dcount = nullptr; ci.bsum = nullptr;
         Timer tm(h, CTK_K_SCAN);
+        if (T > 4 * CTK_CI_BLOCK) {                                // (every workgroup sums the counts in front of it: two levels beyond a few thousand steps)
+            const int nb = (int)((T + CTK_CI_BLOCK - 1) / CTK_CI_BLOCK);
+            CTKCHK(ensure(h, h->ci_bsum, (size_t)nb * 4));
+            k_sum_blocks<<<nb, CTK_CI_BLOCK, 0, s>>>(P<uint32_t>(h->ncomp), T, P<uint32_t>(h->ci_bsum));
+            ci.bsum = P<uint32_t>(h->ci_bsum);
+        }
         k_compact_init<<<(int)T, h->small_threads[2] > 0 ? h->small_threads[2] : 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
                                               P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box), P<int64_t>(h->d_area),
                                               P<uint32_t>(h->d_comp_t), ci);
@@ -1989,7 +1995,11 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     CTKCHK(ensure(h, h->sd_nops, (R + 1) * 4)); CTKCHK(ensure(h, h->sd_lbox, (R + 1) * 24));
     CTKCHK(ensure(h, h->sd_root, (size_t)std::max<int64_t>(T * h->ny, 1) * 4));
     // op slots: SD_OPS_OWN per label id (sized after the previous pass) + a shared tail for the clusters with more and the ids beyond
-    const uint32_t own_ids = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)h->last_nlab + h->last_nlab / 4, 8192), R + 1);
+    // (before any pass has said how many ids this kind of slab has: one per 32 runs -- the bench slabs have one per 80-90)
+    const size_t ids_guess = h->last_nlab ? (size_t)h->last_nlab + h->last_nlab / 4 : R / 32;
+    const uint32_t own_ids = (uint32_t)std::min<size_t>(std::max<size_t>(ids_guess, 8192), R + 1);
+    if (!h->last_nlab) h->op_cap_hint = std::max<uint32_t>(h->op_cap_hint, (uint32_t)std::min<size_t>(R / 256, 1u << 24));
+    if ((uint64_t)own_ids * SD_OPS_OWN + h->op_cap_hint > 0x7ffffff0ull) return ctk_set_error(CTK_E_RANGE, "more op slots than 2^31");
     const uint32_t op_cap = own_ids * SD_OPS_OWN + h->op_cap_hint;
     CTKCHK(ensure(h, h->ops, (size_t)op_cap * (sizeof(CtkOp) + 4)));
     // ids <= components <= runs: R + 1 is the offset of the second half of ext (only the entries of real ids are ever touched)
@@ -2016,7 +2026,7 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     h->nops = 1;                                                  // (unknown here; nonzero = the folds look at the chains)
     // filter passes: all of them in one launch (k_rs_pass_sys, at most 24 iterations) when every workgroup of the launch can wait
     // for its predecessor, else one launch per pass
-    const bool sys = !ctk_env().pass_launches && !h->no_sys && h->async_passes <= 24 && T - 2 <= 60000;
+    const bool sys = !ctk_env().pass_launches && !h->no_sys && h->async_passes <= 24;
     const int NP = T > 2 ? std::min(std::max(h->async_passes, 2), sys ? 24 : CTK_MAX_JACOBI) : 0;
     if (sys) { CTKCHK(ensure(h, h->rv_pstate, (size_t)(T + 1) * 4 * CTK_PSTATE_STRIDE)); r.pstate = P<uint32_t>(h->rv_pstate); }
     h->guard_on = true;
@@ -2115,17 +2125,20 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     h->state = ST_TABLES;
     const uint32_t *cnt = m + CTK_AM_COUNTERS;
     // ---- validation: anything the host would have seen at one of its (removed) hand-offs -----------------------------------
-    if ((cnt[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) || (uint64_t)cnt[CTK_CNT_PAIRS] + cnt[CTK_CNT_UPAIRS] > in.pair_cap) return 1;      // (the synchronous path regrows the table)
+    if ((cnt[CTK_CNT_OVERFLOW] & CTK_OVF_PAIRS) || (uint64_t)cnt[CTK_CNT_PAIRS] + cnt[CTK_CNT_UPAIRS] > in.pair_cap) { h->stats[CTK_S_HOST_REASON] |= 32; return 1; }      // (the synchronous path regrows the table)
     const int64_t npairs_grouped = h->fz_pslot ? (int64_t)m[CTK_AM_NPAIRS] : (int64_t)cnt[CTK_CNT_PAIRS];
-    if (NP > 0 && m[CTK_AM_CONV] == 0) { h->async_passes = std::min(CTK_MAX_JACOBI, NP * 2); return 1; }          // longer removal cascade than launched for
-    if (m[CTK_AM_AMBIG]) return 1;                                                                               // decisions on rounding boundaries
+    if (NP > 0 && m[CTK_AM_CONV] == 0) { h->async_passes = std::min(CTK_MAX_JACOBI, NP * 2); h->stats[CTK_S_HOST_REASON] |= 64; return 1; }          // longer removal cascade than launched for
+    if (m[CTK_AM_AMBIG]) { h->stats[CTK_S_HOST_REASON] |= 128; return 1; }                                                                               // decisions on rounding boundaries
     if (ctk_env().sd_dbg) fprintf(stderr, "SDDBG max row steps %u, max fold iterations %u, max process time %.2f us, max cluster time %.2f us, fold cycles (clock64) %u\n", cnt[10], cnt[11], cnt[12] * 0.01, cnt[13] * 0.01, cnt[14]);
     const uint32_t poison = cnt[CTK_CNT_POISON];
     if (poison) {
         // an inter-workgroup wait of the systolic filter pass gave up (a workgroup waited for was not running): this handle
         // launches one kernel per filter pass from now on -- no waits between workgroups at all
         if (poison & CTK_POISON_SPIN) { h->no_sys = true; h->stats[CTK_S_HOST_REASON] |= 8; }
+        if (poison & CTK_POISON_OPCAP) h->stats[CTK_S_HOST_REASON] |= 256;
+        if (poison & CTK_POISON_CLUSTER) h->stats[CTK_S_HOST_REASON] |= 512;
         if (poison & CTK_POISON_OPCAP) h->op_cap_hint = std::max(h->op_cap_hint * 2, cnt[CTK_CNT_NOPS] + cnt[CTK_CNT_NOPS] / 2 + 1024);
+        if (m[CTK_AM_NLAB] && m[CTK_AM_NLAB] <= 0x7ffffffeu) h->last_nlab = m[CTK_AM_NLAB];      // (the ids were numbered in front of the seam driver: the next pass sizes its own slots by them)
         if (poison & CTK_POISON_CLUSTER) { h->async_off_ny = h->ny; h->async_off_nx = h->nx; }                 // this kind of slab: host driver from now on
         return 1;
     }

@@ -962,7 +962,20 @@ struct CompInit {
     const uint32_t *base_ptr;
     uint32_t *ovr_slot;             // [NC] or nullptr
     uint32_t *amb_cnt, *dcount;     // scalars reset with *ambig, or nullptr
+    // long shards: sums of ncomp over blocks of CTK_CI_BLOCK timesteps (k_sum_blocks), so that the workgroup of timestep t adds up
+    // t / CTK_CI_BLOCK block sums + < CTK_CI_BLOCK counts instead of t counts (438 000 steps: 10^11 loads otherwise); nullptr: short shard
+    const uint32_t *bsum;
 };
+#define CTK_CI_BLOCK 1024
+__global__ __launch_bounds__(CTK_CI_BLOCK) void k_sum_blocks(const uint32_t *__restrict__ in, int64_t n, uint32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * CTK_CI_BLOCK + threadIdx.x;
+    __shared__ uint32_t sm[CTK_CI_BLOCK / 64];
+    const uint32_t s = wave_sum_u32(i < n ? in[i] : 0u);
+    if (lane_id() == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < CTK_CI_BLOCK / 64; k++) t += sm[k]; out[blockIdx.x] = t; }
+}
 __global__ __launch_bounds__(256) void k_compact_init(const uint32_t *__restrict__ run_base, const uint32_t *__restrict__ ncomp,
                                                       uint32_t *__restrict__ cprefix, const uint32_t *__restrict__ cs_mrep,
                                                       const uint32_t *__restrict__ cs_box, const int64_t *__restrict__ cs_area,
@@ -972,7 +985,9 @@ __global__ __launch_bounds__(256) void k_compact_init(const uint32_t *__restrict
     const int t = (int)blockIdx.x, tid = (int)threadIdx.x;
     __shared__ uint32_t sm[8];
     uint32_t s = 0;
-    for (int u = tid; u < t; u += blockDim.x) s += ncomp[u];
+    int u0 = 0;
+    if (ci.bsum) { const int nb = t / CTK_CI_BLOCK; for (int u = tid; u < nb; u += blockDim.x) s += ci.bsum[u]; u0 = nb * CTK_CI_BLOCK; }
+    for (int u = u0 + tid; u < t; u += blockDim.x) s += ncomp[u];
     uint32_t cb;
     (void)block_excl_scan(s, sm, &cb);
     const uint32_t nh = ci.base_ptr ? *ci.base_ptr : 0u;
@@ -1849,7 +1864,7 @@ __global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__
                                                      uint32_t *counters, uint32_t *mail, AsyncMail am)
 {
     if (ctk_guard_bad(am.scal ? counters : nullptr)) {
-        if (blockIdx.x == 0) async_mail_write(am, counters, 0u, 0u);
+        if (blockIdx.x == 0) async_mail_write(am, counters, 0u, __hip_atomic_load(&counters[CTK_CNT_NOPS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));      // (a poisoned pass: the op slots the shared tail was asked for, so that the host can size the next pass)
         return;
     }
     const int64_t nl = am.scal ? (int64_t)*am.nlab_ptr : n_labels;
@@ -1895,7 +1910,7 @@ __global__ __launch_bounds__(1024) void k_count_alive_1(const int32_t *__restric
                                                         uint32_t *counters, uint32_t *mail, AsyncMail am)
 {
     if (ctk_guard_bad(am.scal ? counters : nullptr)) {
-        async_mail_write(am, counters, 0u, 0u);
+        async_mail_write(am, counters, 0u, __hip_atomic_load(&counters[CTK_CNT_NOPS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));      // (a poisoned pass: the op slots the shared tail was asked for, so that the host can size the next pass)
         return;
     }
     uint32_t v = 0, nc = 0, no = 0, np = 0;

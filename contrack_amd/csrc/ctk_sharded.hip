@@ -936,8 +936,8 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
     // One launch (k_compact_init, as in the one-call pass): every timestep's workgroup sums the component counts in front of it
     // itself, compacts its tables and initialises the resolver's per-component arrays; k_overlap then prepares every pair record
     // as it writes it.  (Before: scan, compaction, halo rows, k_rs_init and k_rs_pairs_slots -- five launches, ~29 us at 1 deg.)
-    const bool sys_pass = !ctk_env().pass_launches && !h->no_sys && T <= 60000;
-    const bool one_init = T <= 65536 && !ctk_env().sh_no_slots;
+    const bool sys_pass = !ctk_env().pass_launches && !h->no_sys;
+    const bool one_init = !ctk_env().sh_no_slots;
     {
         Timer tm(h, CTK_K_SCAN);
         if (one_init) {
@@ -956,6 +956,13 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
             ci.next_tiny = (const int32_t *)(P<int64_t>(h->wlo) + 2 * (size_t)h->ny);
             ci.nchanged = (CTK_MAX_JACOBI + 1) * CTK_CHG_SLOTS; ci.pstride = CTK_PSTATE_STRIDE; ci.T = T;
             ci.base_ptr = nh_ptr; ci.ovr_slot = P<uint32_t>(h->sh_ovr_slot); ci.amb_cnt = P<uint32_t>(h->rv_scalars) + 2; ci.dcount = P<uint32_t>(h->rv_scalars);
+            ci.bsum = nullptr;
+            if (T > 4 * CTK_CI_BLOCK) {
+                const int nb = (int)((T + CTK_CI_BLOCK - 1) / CTK_CI_BLOCK);
+                CTKCHK(ensure(h, h->ci_bsum, (size_t)nb * 4));
+                k_sum_blocks<<<nb, CTK_CI_BLOCK, 0, s>>>(P<uint32_t>(h->ncomp), T, P<uint32_t>(h->ci_bsum));
+                ci.bsum = P<uint32_t>(h->ci_bsum);
+            }
             k_compact_init<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
                                                   P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box), P<int64_t>(h->d_area),
                                                   P<uint32_t>(h->d_comp_t), ci);
