@@ -395,10 +395,13 @@ class _ResultPool:
 
     def __init__(self, tracker):
         import threading
+        import collections
         self._trk = weakref.ref(tracker)
-        self._lock = threading.Lock()
+        self._lock = threading.RLock()       # re-entrant: belt and braces, see _release
         self._free = []                      # blocks: dict(mem=np.uint8 array, registered=bool)
         self._leased = {}                    # id(block) -> block
+        self._returned = collections.deque()  # blocks whose last view died; filed under the lock by _drain
+        self._closed = False
         self.cap = int(float(os.environ.get("CTK_RESULT_POOL_MB", "2048")) * (1 << 20))
         self.hits = self.misses = 0
 
@@ -408,10 +411,14 @@ class _ResultPool:
             return np.empty(shape, dtype=dtype)
         blk = None
         with self._lock:
-            for i, b in enumerate(self._free):
+            self._drain()
+            i = 0
+            while i < len(self._free):
+                b = self._free[i]
                 if nbytes <= b["mem"].nbytes <= nbytes + nbytes // 4:
                     blk = self._free.pop(i)
                     break
+                i += 1
         if blk is None:
             self.misses += 1
             blk = dict(mem=np.empty(nbytes, dtype=np.uint8), registered=False)
@@ -435,20 +442,39 @@ class _ResultPool:
         blk["registered"] = False
 
     def _release(self, blk):
-        with self._lock:
+        """weakref.finalize callback: runs wherever the last reference dies -- possibly inside a cyclic-GC pass that a
+        thread triggered while it held the pool's lock.  So it takes no lock and allocates nothing GC-tracked: the block goes
+        onto a deque (append is atomic) and is filed by the next take() / close()."""
+        self._returned.append(blk)
+
+    def _drain(self):
+        """file the returned blocks (caller holds the lock)"""
+        drop = []
+        while True:
+            try:
+                blk = self._returned.popleft()
+            except IndexError:
+                break
             self._leased.pop(id(blk), None)
-            held = sum(b["mem"].nbytes for b in self._free)
-            keep = self._trk() is not None and held + blk["mem"].nbytes <= self.cap
-            if keep:
+            held = 0
+            for b in self._free:
+                held += b["mem"].nbytes
+            if not self._closed and self._trk() is not None and held + blk["mem"].nbytes <= self.cap:
                 self._free.append(blk)
-        if not keep:
+            else:
+                drop.append(blk)
+        for blk in drop:
             self._unregister(blk)
 
     def close(self):
-        """the handle goes away: nothing stays registered (arrays still held by the caller remain valid, pageable memory)"""
+        """the handle goes away: nothing stays registered (arrays still held by the caller remain valid, pageable memory)
+        and nothing that comes back afterwards is kept"""
         with self._lock:
+            self._closed = True
+            self._drain()
             blocks = self._free + list(self._leased.values())
             self._free = []
+            self._leased = {}
         for b in blocks:
             self._unregister(b)
 
