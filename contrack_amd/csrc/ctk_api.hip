@@ -214,7 +214,9 @@ struct ctk_handle {
     uint32_t *h_amail = nullptr;                   // pinned: AsyncMail scalars
     uint32_t op_cap_hint = 4096;                   // operation slots of the next fused pass (grows with what the passes needed)
     uint32_t nd_hint = 4096;                       // dense candidate labels of the last pass: grid of k_seam_driver
-    int async_passes = CTK_JACOBI_ROUND;           // filter passes the next fused pass launches
+    int async_passes = 24;                         // filter passes the next fused pass launches.  Before any pass has said how long this kind of slab's
+                                                   // removal cascades are: all that the one-launch form carries (an unneeded pass is one hop of its chain, ~0.3 us;
+                                                   // the longest cascade grows with T -- 9 passes at 2707 steps, 11 at 438 000); then what the last pass needed + 2
     int use_async = -1;                            // -1: not decided (env CTK_ASYNC), 0 / 1
     int async_off_ny = -1, async_off_nx = -1;      // grid whose clusters did not fit the device seam driver: synchronous path from then on
     uint32_t fz_pslot = 0;                         // k_overlap wrote the pair records into fixed per-timestep slots of this size
@@ -787,7 +789,9 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     }
 
     const void *mask_before = h->mask.p;
-    if (h->mask_off_dbg >= 0) CTKCHK(ensure_placed(h, h->mask, (size_t)nrows * W * 8, (size_t)h->mask_off_dbg, (size_t)64 << 20));
+    static const size_t mask_slack_mb = getenv("CTK_MASK_SLACK_MB") ? (size_t)atoll(getenv("CTK_MASK_SLACK_MB")) : 0;      // experiment: the mask at the head of a larger allocation
+    if (mask_slack_mb) CTKCHK(ensure_placed(h, h->mask, (size_t)nrows * W * 8, 0, mask_slack_mb << 20));
+    else if (h->mask_off_dbg >= 0) CTKCHK(ensure_placed(h, h->mask, (size_t)nrows * W * 8, (size_t)h->mask_off_dbg, (size_t)64 << 20));
     else CTKCHK(ensure(h, h->mask, (size_t)nrows * W * 8));
     const bool mask_fresh = h->mask.p != mask_before;
     CTKCHK(ensure(h, h->wstart, (size_t)nrows * W * 2));

@@ -143,7 +143,7 @@ def test_configs4_slab_fused_pass_properties_and_eight_shards(big):
         assert n_one == n_first and n_one > 100000, (n_first, n_one, st)
         # the same fused pass as at 2707 steps: one launch for all filter passes, device seam driver, no host hand-off
         assert st["fused_pass"] == 1 and st["off_fused_path_reason"] == 0 and st["host_path"] == 0, (first, st)
-        assert first["fused_pass"] == 1, first                                   # ... on a fresh handle already (first-call sizing)
+        assert first["fused_pass"] == 1, (first["off_fused_path_reason"], first["filter_passes"])                                   # ... on a fresh handle already (first-call sizing)
         pr = trk.check_flag(d_in, d_out, T, NY, NX, thr, 0, PERSISTENCE, st["labels_3d"])
         assert pr["flag_outside_mask"] == 0 and pr["ids_out_of_range"] == 0, pr
         assert pr["ids_below_persistence"] == 0 and pr["ids"] == n_one, (pr, n_one)
