@@ -818,11 +818,11 @@ class Tracker:
         return v is None or (mt is not None and int(mt.group(0)) != 0)
 
     def stats(self):
-        v = np.zeros(24, dtype=np.int64)
+        v = np.zeros(25, dtype=np.int64)
         check(lib().ctk_get_stats(self._h, v.ctypes.data))
         names = ["runs", "max_runs_per_step", "components", "pairs", "seam_rows_to_driver", "labels_3d", "seam_ops",
                  "filter_passes", "host_path", "seam_loop_ns", "seam_folds", "seam_copy_ns", "ungrouped_pairs", "pair_table_regrows", "filter_rounds",
-                 "ambiguous_decisions", "exact_fixups", "shared_seam_rows", "off_fused_path_reason", "relabel_kernel", "fused_pass", "x4_speculated", "result_as_runs", "mask_allocations_tried"]
+                 "ambiguous_decisions", "exact_fixups", "shared_seam_rows", "off_fused_path_reason", "relabel_kernel", "fused_pass", "x4_speculated", "result_as_runs", "mask_allocations_tried", "mask_ratio_x1000"]
         return dict(zip(names, v.tolist()))
 
     def debug_set_pair_capacity(self, records):

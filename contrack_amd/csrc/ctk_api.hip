@@ -182,6 +182,7 @@ struct StreamIO {
 
 struct ctk_handle {
     int device = 0;
+    int n_cus = 256;                              // compute units of the device (grids of the persistent kernels)
     hipStream_t stream = nullptr;
     hipStream_t side[2] = {nullptr, nullptr};      // the labelling variants of one shard run concurrently
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
@@ -293,7 +294,9 @@ struct ctk_handle {
     int small_threads[3] = {0, 0, 0};              // experiments (ctk_debug_set_small_threads): threads of k_extent / k_run_values / k_compact_init, 0 = default
     int relabel_threads = 0, relabel_rows_dbg = 0;  // experiments (ctk_debug_set_relabel): threads / rows per workgroup of k_relabel_v5, 0 = default
     int xcd_thr = -1, xcd_rel = -1;               // chunk -> XCD mapping of the two streaming kernels (xcd_chunk); -1: the environment's / default
-    int xcd_thr_tuned = -1;                       // tile size the mask-placement tuning found fastest (-1: not tuned)
+    int xcd_thr_tuned = -1;                       // tile size the mask placement check found faster on a placement it could not improve (-1: the default)
+    bool thr_nostore = false;                     // the threshold kernel without its mask stores: the yardstick of the mask placement check
+    int mask_tries = 0; double mask_ratio = 0.0;  // allocations of the mask that were checked when it was last (re)allocated; kernel time / its time without stores
     int xcd_rel_tuned = -1;                       // the same for the write kernel (tune_relabel), for the shape below
     int64_t rel_tuned_T = -1; int rel_tuned_ny = 0, rel_tuned_nx = 0; const void *rel_tuned_flag = nullptr;
     bool sh_collective_err = false;               // the time-shard path's error was decided identically on every rank
@@ -475,6 +478,7 @@ extern "C" int ctk_create(ctk_handle **out, int device)
     ctk_handle *h = new (std::nothrow) ctk_handle();
     if (!h) return ctk_set_error(CTK_E_NOMEM, "ctk_create: out of memory");
     h->device = device;
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) h->n_cus = cu; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return ctk_set_error(CTK_E_NODEVICE, "hipStreamCreate failed"); }
     for (int k = 0; k < 2; k++) {
         if (hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking) != hipSuccess ||
@@ -789,9 +793,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     }
 
     const void *mask_before = h->mask.p;
-    static const size_t mask_slack_mb = getenv("CTK_MASK_SLACK_MB") ? (size_t)atoll(getenv("CTK_MASK_SLACK_MB")) : 0;      // experiment: the mask at the head of a larger allocation
-    if (mask_slack_mb) CTKCHK(ensure_placed(h, h->mask, (size_t)nrows * W * 8, 0, mask_slack_mb << 20));
-    else if (h->mask_off_dbg >= 0) CTKCHK(ensure_placed(h, h->mask, (size_t)nrows * W * 8, (size_t)h->mask_off_dbg, (size_t)64 << 20));
+    if (h->mask_off_dbg >= 0) CTKCHK(ensure_placed(h, h->mask, (size_t)nrows * W * 8, (size_t)h->mask_off_dbg, (size_t)64 << 20));
     else CTKCHK(ensure(h, h->mask, (size_t)nrows * W * 8));
     const bool mask_fresh = h->mask.p != mask_before;
     CTKCHK(ensure(h, h->wstart, (size_t)nrows * W * 2));
@@ -839,6 +841,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
             }
             const int R6 = std::max(1, 64 / W), nchunk_t = (ny + R6 - 1) / R6;
             const int64_t nchunks = nt * nchunk_t;
+            static const bool thr_nostore_env = getenv("CTK_THR_STORE") && atoi(getenv("CTK_THR_STORE")) == 2;      // (probes: the kernel without its stores)
             static const int64_t g6max = getenv("CTK_THR_GRID") ? atoll(getenv("CTK_THR_GRID")) : 16384;
             const unsigned g6 = (unsigned)std::min<int64_t>((nchunks + 3) / 4, g6max);
 #define LAUNCH_THR(OP)                                                                                                                      \
@@ -848,11 +851,11 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         else if (v4 && thr_variant == 44) k_threshold_v4<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
         else if (v4 && thr_variant == 42) k_threshold_v4<OP, 2><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
         else if (v4 && thr_variant == 4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
-        else if (v4 && u7 == 4) k_threshold_v7<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr)); \
-        else if (v4 && u7 == 5) k_threshold_v7<OP, 5><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr)); \
-        else if (v4 && u7 == 6) k_threshold_v7<OP, 6><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr)); \
-        else if (v4 && u7 == 7) k_threshold_v7<OP, 7><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr)); \
-        else if (v4) k_threshold_v7<OP, 8><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr)); \
+        else if (v4 && u7 == 4) k_threshold_v7<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr), (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
+        else if (v4 && u7 == 5) k_threshold_v7<OP, 5><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr), (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
+        else if (v4 && u7 == 6) k_threshold_v7<OP, 6><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr), (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
+        else if (v4 && u7 == 7) k_threshold_v7<OP, 7><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr), (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
+        else if (v4) k_threshold_v7<OP, 8><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr), (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
         else k_threshold<OP, float><<<g, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, rows, ny, nx, W, mk, zc); \
     } while (0)
             switch (cmp_op) {
@@ -865,69 +868,79 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
             HIPCHK(hipGetLastError());
             return CTK_OK;
         };
-        // Where the bit mask lies decides how fast the read stream of the threshold kernel runs: 0.106 or 0.119 ms at 2707 x 181 x 360,
-        // 0.315 or 0.36 at 480 x 721 x 1440 -- per ALLOCATION (not per offset inside one: tools/mask_place_probe.py; every
-        // re-allocation flipped the mode), for as long as the handle lives.  This was the "bimodal board" of rounds 2-4.  So a freshly
-        // allocated mask is tried: the kernel is timed on it, and unless it streams at >= 6.2 TB/s up to three more allocations are
-        // timed and the fastest kept.  Once per handle and slab size (~1-3 ms); CTK_MASK_TUNE=0 turns it off.
-        if (anom_dev && mask_fresh && h->mask_off_dbg < 0 && ctk_env().mask_tune && (size_t)T * ny * nx * (f64 ? 8 : 4) >= ((size_t)128 << 20)) {
+        // Where the bit mask lies against the SLAB decides what its 1/32 write stream costs the 4 B/pixel read stream: device memory comes
+        // in two classes of physical regions (each hundreds of MB to many GB long, invisible in the virtual address), and a read stream
+        // and a write stream that run in the SAME class disturb each other -- k_threshold is then 11-18 % above its read-only time
+        // instead of 4-6 % (0.119 vs 0.106 ms at 2707 x 181 x 360, 0.36 vs 0.315 at 480 x 721 x 1440; profiles/NOTES.md round 5 and
+        // profiles/r05_rwmix_*.txt: slab region x mask region matrix, consistent with the write-to-read turnaround inside one DRAM rank).
+        // Allocations made right after each other usually share a class -- the "bimodal board" of rounds 2-4.  So a freshly allocated
+        // mask is checked against the slab: the kernel's time WITHOUT its stores (on the first 4 GB of a larger slab) is the yardstick,
+        // and while the kernel with its stores is more than 8.5 % above it, another mask is allocated behind a spacer that is held in
+        // between (0.5, 1, 2, 4 GB: hipMalloc of these costs 0.02-0.3 ms) -- memory from somewhere else.  Two launches per measurement, 4 in
+        // the usual case (the first mask is fine), at most 12; once per handle and mask size; CTK_MASK_TUNE=0 turns it off.
+        h->mask_tries = mask_fresh ? 0 : h->mask_tries;
+        const bool v7_path = !f64 && (nx % 4 == 0) && (((uintptr_t)anom_dev & 15) == 0);
+        if (anom_dev && mask_fresh && h->mask_off_dbg < 0 && ctk_env().mask_tune && v7_path && (size_t)T * ny * nx * 4 >= ((size_t)128 << 20)) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
                 const size_t mbytes = (size_t)nrows * W * 8;
-                const double gb = (double)T * ny * nx * (f64 ? 8 : 4) / 1e9;
+                // (the whole slab up to 4 GB: the classes change along a slab and along a mask, a window of 256 MB told little about
+                // the whole kernel -- measured)
+                const int64_t nt_probe = std::min<int64_t>(T, std::max<int64_t>(1, ((int64_t)4 << 30) / ((int64_t)ny * nx * 4)));
                 auto time_it = [&](double *ms) -> int {
-                    CTKCHK(launch_threshold(anom_dev, 0, T));
+                    CTKCHK(launch_threshold(anom_dev, 0, nt_probe));
                     HIPCHK(hipEventRecord(e0, s));
-                    CTKCHK(launch_threshold(anom_dev, 0, T));
-                    CTKCHK(launch_threshold(anom_dev, 0, T));
+                    CTKCHK(launch_threshold(anom_dev, 0, nt_probe));
                     HIPCHK(hipEventRecord(e1, s));
                     HIPCHK(hipEventSynchronize(e1));
                     float f = 0.f;
                     HIPCHK(hipEventElapsedTime(&f, e0, e1));
-                    *ms = 0.5 * f;
+                    *ms = f;
                     return CTK_OK;
                 };
-                // ... and so does the size of the tiles in which the chunks are dealt to the XCDs (NOTES: -5 % with 64 on one placement; in
-                // another process 16 ran at 6.6 TB/s where 64 stayed at 6.0): every allocation is timed with the tile sizes in turn
-                const bool tune_xcd = h->xcd_thr < 0;
-                const int modes[4] = {ctk_env().xcd_thr, 16, 256, 4};
-                const int nmodes = tune_xcd ? 4 : 1;
+                int rc = CTK_OK;
+                double ro_ms = 0.0, best_ms = 1e30;
+                h->thr_nostore = true;                                                  // the yardstick: the same kernel without its stores
+                rc = time_it(&ro_ms);
+                h->thr_nostore = false;
                 DevBuf best = h->mask;
-                double best_ms = 1e30;
-                int best_mode = h->xcd_thr, rc = CTK_OK;
-                auto try_modes = [&](const DevBuf &cand, bool *took) -> int {
-                    *took = false;
-                    for (int m = 0; m < nmodes && gb / best_ms < 6.2; m++) {                 // (GB / ms = TB/s)
-                        if (m > 0 && modes[m] == modes[0]) continue;
-                        if (tune_xcd) h->xcd_thr = modes[m];
-                        double ms = 0.0;
-                        CTKCHK(time_it(&ms));
-                        if (ms < best_ms) { best_ms = ms; best_mode = tune_xcd ? modes[m] : h->xcd_thr; *took = true; }
-                    }
-                    (void)cand;
-                    return CTK_OK;
-                };
-                bool took = false;
-                rc = try_modes(best, &took);
-                h->stats[CTK_S_MASK_TRIES] = 1;
-                static const int max_tries = getenv("CTK_MASK_TRIES") ? atoi(getenv("CTK_MASK_TRIES")) : 3;
-                static const size_t spacer_mb = getenv("CTK_MASK_SPACER_MB") ? (size_t)atoll(getenv("CTK_MASK_SPACER_MB")) : 0;
-                std::vector<void *> spacers;
-                struct FreeSpacers { std::vector<void *> &v; ~FreeSpacers() { for (void *q : v) (void)hipFree(q); } } free_spacers{spacers};
-                for (int k = 0; rc == CTK_OK && k < max_tries && gb / best_ms < 6.2; k++) {
-                    if (spacer_mb) { void *q = nullptr; if (hipMalloc(&q, spacer_mb << 20) == hipSuccess) spacers.push_back(q); }
+                if (rc == CTK_OK) rc = time_it(&best_ms);
+                h->mask_tries = 1;
+                static const int max_tries = getenv("CTK_MASK_TRIES") ? atoi(getenv("CTK_MASK_TRIES")) : 4;
+                static const double accept = getenv("CTK_MASK_ACCEPT") ? atof(getenv("CTK_MASK_ACCEPT")) : 1.085;
+                std::vector<void *> held;                                               // spacers and rejected masks: freed when the search is over
+                struct FreeHeld { std::vector<void *> &v; ~FreeHeld() { for (void *q : v) (void)hipFree(q); } } free_held{held};
+                for (int k = 0; rc == CTK_OK && k < max_tries && best_ms > accept * ro_ms; k++) {
+                    void *sp = nullptr;
+                    if (hipMalloc(&sp, (size_t)512 << (20 + k)) == hipSuccess) held.push_back(sp);
+                    else (void)hipGetLastError();
                     DevBuf nb;
-                    if (ensure(h, nb, mbytes) != CTK_OK) break;                        // (no memory for another try: keep what there is)
+                    if (ensure(h, nb, mbytes) != CTK_OK) break;                         // (no memory for another try: keep what there is)
                     h->mask = nb;
-                    rc = try_modes(nb, &took);
-                    h->stats[CTK_S_MASK_TRIES]++;
-                    if (rc == CTK_OK && took) { (void)hipFree(best.base ? best.base : best.p); best = nb; }
-                    else (void)hipFree(nb.p);
+                    double ms = 0.0;
+                    rc = time_it(&ms);
+                    h->mask_tries++;
+                    if (rc == CTK_OK && ms < best_ms) { held.push_back(best.base ? best.base : best.p); best = nb; best_ms = ms; }
+                    else held.push_back(nb.p);
                     h->mask = best;
                 }
-                if (tune_xcd) { h->xcd_thr = -1; h->xcd_thr_tuned = best_mode; }
                 h->mask = best;
-                if (ctk_env().hosttrace) fprintf(stderr, "mask placement: %d allocation(s) tried, tiles of %d chunks per XCD, threshold stream %.2f TB/s, mask at %p, slab at %p\n", (int)h->stats[CTK_S_MASK_TRIES], best_mode, gb / best_ms, h->mask.p, anom_dev);
+                // last resort (3 of 24 handles in tools/mask_check_probe.sh: every allocation in the slab's class): the size of the tiles in
+                // which the chunks are dealt to the XCDs moves the kernel on such a placement (round 4: 16 ran at 6.6 TB/s where 64 stayed at 6.0)
+                if (rc == CTK_OK && best_ms > accept * ro_ms && h->xcd_thr < 0) {
+                    const int modes[3] = {16, 256, 4};
+                    int best_mode = -1;
+                    for (int m = 0; m < 3 && rc == CTK_OK && best_ms > accept * ro_ms; m++) {
+                        h->xcd_thr = modes[m];
+                        double ms = 0.0;
+                        rc = time_it(&ms);
+                        if (rc == CTK_OK && ms < best_ms) { best_ms = ms; best_mode = modes[m]; }
+                    }
+                    h->xcd_thr = -1;
+                    h->xcd_thr_tuned = best_mode;
+                } else if (h->xcd_thr < 0) h->xcd_thr_tuned = -1;
+                h->mask_ratio = ro_ms > 0 ? best_ms / ro_ms : 0.0;
+                if (ctk_env().hosttrace) fprintf(stderr, "mask placement: %d allocation(s) tried, threshold kernel on a %lld-step window %.4f ms = %.3f x its time without stores (%.4f), mask at %p, slab at %p\n", h->mask_tries, (long long)nt_probe, best_ms, h->mask_ratio, ro_ms, h->mask.p, anom_dev);
                 if (rc != CTK_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
             }
             if (e0) (void)hipEventDestroy(e0);
@@ -1026,6 +1039,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     h->need_glb = (h->max_runs_step > CTK_LDS_RUNS) || (ny > CTK_LDS_NY);
     memset(h->stats, 0, sizeof(h->stats));
     h->stats[CTK_S_RUNS] = h->total_runs; h->stats[CTK_S_MAX_RUNS_STEP] = h->max_runs_step;
+    h->stats[CTK_S_MASK_TRIES] = h->mask_tries; h->stats[CTK_S_MASK_RATIO] = (int64_t)(h->mask_ratio * 1000.0 + 0.5);      // (sticky: of the last placement check)
     const size_t R = h->total_runs;
     const bool fits = spec && R <= h->runs_cap;
     if (!fits) {

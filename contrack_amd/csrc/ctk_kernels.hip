@@ -250,7 +250,7 @@ __device__ __forceinline__ uint32_t thr_nibble(const f32x4 v, const float th)
 template <int OP, int U>
 __global__ __launch_bounds__(256) void k_threshold_v7(const float *__restrict__ anom, const float *__restrict__ thr32,
                                                       int ny, int nx, int W, uint64_t *__restrict__ mask, int rb,
-                                                      uint32_t *__restrict__ zero_counters, int xcd)
+                                                      uint32_t *__restrict__ zero_counters, int xcd, int nostore)
 {
     if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_N) zero_counters[threadIdx.x] = 0u;
     const int nchunk = (ny + rb - 1) / rb;
@@ -290,7 +290,8 @@ __global__ __launch_bounds__(256) void k_threshold_v7(const float *__restrict__ 
             x = dpp_or<0x4E>(x);                           // quad_perm [2,3,0,1]
             x = dpp_or<0x141>(x);                          // row_half_mirror: every lane of a half row holds its half
             const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false);      // row_mirror: lane 0 <- lane 15
-            if (sub == 0 && moff[u] != 0xffffffffu) *reinterpret_cast<uint64_t *>(mbase + moff[u]) = ((uint64_t)hi << 32) | x;
+            // (nostore: the kernel without its 1/32 write stream -- the yardstick of the mask placement check, ctk_api.hip)
+            if (sub == 0 && moff[u] != 0xffffffffu && !nostore) *reinterpret_cast<uint64_t *>(mbase + moff[u]) = ((uint64_t)hi << 32) | x;
         }
     }
 }

@@ -280,8 +280,9 @@ int ctk_get_timing_sums(ctk_handle *h, double *sums, int64_t *counts, int reset)
 #define CTK_S_RLE_OUT       22    /* host-array entries: 0 = the result was written by k_relabel and copied densely; n > 0 = it travelled as
                                    * run tables and was expanded on the host, n - 1 blocks of timesteps (those holding complex
                                    * components) went through the write kernel */
-#define CTK_S_MASK_TRIES    23    /* allocations of the bit mask that were timed when it was last (re)allocated (0: not tuned) */
-#define CTK_NSTATS          24
+#define CTK_S_MASK_TRIES    23    /* allocations of the bit mask that were checked against the slab when it was last (re)allocated (0: not checked); sticky */
+#define CTK_S_MASK_RATIO    24    /* 1000 x (threshold kernel on the kept mask / the same kernel without its stores), from that check; sticky */
+#define CTK_NSTATS          25
 int ctk_get_stats(ctk_handle *h, int64_t *out /* [CTK_NSTATS] */);
 /* filter passes launched per round before convergence is checked on the host (default 10, 1..32)   */
 int ctk_set_filter_round(ctk_handle *h, int passes);

@@ -1,6 +1,6 @@
-"""Round 5, root cause of the slow mode of k_threshold: does the SIZE of the allocation that backs the bit mask decide it?
-Eight handles per setting, tuner off (run with CTK_MASK_TUNE=0); CTK_MASK_SLACK_MB is read once per process, so one process per
-setting (tools/mask_slack_probe.sh)."""
+"""Round 5: the time of k_threshold (and k_relabel) on eight handles of one process, on the same slab -- the "modes" of the kernel per
+handle.  CTK_MASK_TUNE=0: without the mask placement check; CTK_THR_STORE=2: the kernel without its stores; SHAPE=T,ny,nx; NH handles.
+(tools/mask_check_probe.sh, tools/mask_store_probe.sh)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,5 +26,5 @@ for k in range(int(os.environ.get('NH', '8'))):
     per, _ = trk.timing_sums(reset=True)
     out.append((per["k_threshold"], per["k_relabel"]))
     keep.append(trk)
-print("slack_mb=%s tune=%s  thr: %s   rel: %s" % (os.environ.get("CTK_MASK_SLACK_MB", "-"), os.environ.get("CTK_MASK_TUNE", "1"),
+print("tune=%s  thr: %s   rel: %s" % (os.environ.get("CTK_MASK_TUNE", "1"),
                                                   " ".join("%.4f" % a for a, _ in out), " ".join("%.4f" % b for _, b in out)))
