@@ -9,7 +9,7 @@ resident in HBM.  For N > 1 (launched as the contract says, one rank per GPU; on
 axis is sharded across ranks -- weak scaling by default: every GPU holds one member of the workload (2707 steps at 1 deg),
 the members are concatenated on the time axis (BASELINE.json configs[4] layout) and tracked as ONE slab of N x T steps by
 ctk_track_sharded_* (one-timestep halo + boundary records over RCCL, shard-local resolver); `--scaling strong` splits the
-single-GPU slab instead -- see contrack_amd/dist.py.
+single-GPU slab instead -- see bench_dist.py (the bench leg) and contrack_amd/dist.py (the product driver).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -280,8 +280,8 @@ def main():
             args.gpus, world), file=sys.stderr)
         sys.exit(2)
     if world > 1 or os.environ.get("CTK_FORCE_DIST") == "1":
-        from contrack_amd import dist
-        sys.exit(dist.bench_main(args, wl, WORKLOADS, HBM_PEAK_GBS, cpu_baseline=cpu_baseline, pmc_traffic=pmc_traffic) or 0)
+        import bench_dist
+        sys.exit(bench_dist.bench_main(args, wl, WORKLOADS, HBM_PEAK_GBS, cpu_baseline=cpu_baseline, pmc_traffic=pmc_traffic) or 0)
 
     T, ny, nx = wl["T"], wl["ny"], wl["nx"]
     thr = np.full(T, np.float64(np.float32(wl["threshold"])))

@@ -697,7 +697,7 @@ class Tracker:
         check(lib().ctk_sync(self._h))
 
     def synth_fill(self, dst, T, ny, nx, seed=0, t0=0):
-        """deterministic synthetic slab (bench only); t0 > 0: the window [t0, t0 + T) of the same slab"""
+        """deterministic synthetic slab (measurements and tests only); t0 > 0: the window [t0, t0 + T) of the same slab"""
         check(lib().ctk_synth_fill_window(self._h, dst, int(t0), T, ny, nx, int(seed)))
 
     def checksum_i32(self, ptr, n, index0=0):
@@ -803,7 +803,8 @@ class Tracker:
 
     def set_result_transfer(self, mode=-1):
         """how the host-array entries bring the result over PCIe: 1 run tables expanded by host threads (default), 0 the dense
-        slab written by k_relabel, -1 the environment's choice (CTK_RLE_OUT)"""
+        slab written by k_relabel, -1 the environment's choice (CTK_RLE_OUT); 2: test hook -- run tables wanted but made unavailable (the
+        library then repeats the pass with the dense copy)"""
         check(lib().ctk_set_result_transfer(self._h, int(mode)))
         self._transfer_mode = int(mode)
 

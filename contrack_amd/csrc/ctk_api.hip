@@ -7,7 +7,7 @@
 #include "ctk_lifecycle.hip"
 #include "ctk_seam.h"
 #include "ctk_comm.h"
-#include "../../include/contrack_hip.h"
+#include "../../include/contrack_hip_debug.h"
 
 #include <chrono>
 #include <cmath>
@@ -242,7 +242,7 @@ struct ctk_handle {
     std::vector<RleBlock> rle_blocks;
     bool rle_out = false;                          // this call's result leaves the device as run tables: launch_relabel is a no-op
     int64_t mask_off_dbg = -1;                     // ctk_debug_set_mask_offset: the mask placed this many bytes into a larger allocation (-1: plain)
-    int rle_mode = -1;                             // ctk_set_result_transfer: -1 environment (CTK_RLE_OUT, default on), 0 dense copy, 1 runs
+    int rle_mode = -1;                             // ctk_set_result_transfer: -1 environment (CTK_RLE_OUT, default on), 0 dense copy, 1 runs, 2 runs wanted but made unavailable (test hook)
     // time-sharded path (ctk_sharded.hip)
     DevBuf sh_mask_next, sh_send, sh_recv, sh_prev, sh_elist, sh_ovr_slot, sh_ovr_val, sh_amb_list, sh_counts, sh_cl_shared, sh_cl_sent;
     uint32_t sh_stamp_seq = 0;
@@ -294,7 +294,7 @@ struct ctk_handle {
     int small_threads[3] = {0, 0, 0};              // experiments (ctk_debug_set_small_threads): threads of k_extent / k_run_values / k_compact_init, 0 = default
     int relabel_threads = 0, relabel_rows_dbg = 0;  // experiments (ctk_debug_set_relabel): threads / rows per workgroup of k_relabel_v5, 0 = default
     int xcd_thr = -1, xcd_rel = -1;               // chunk -> XCD mapping of the two streaming kernels (xcd_chunk); -1: the environment's / default
-    int xcd_thr_tuned = -1;                       // tile size the mask placement check found faster on a placement it could not improve (-1: the default)
+    int xcd_thr_tuned = -1;                       // (round 4 tuned the XCD tile size of the threshold kernel per placement; no longer: -1)
     bool thr_nostore = false;                     // the threshold kernel without its mask stores: the yardstick of the mask placement check
     int mask_tries = 0; double mask_ratio = 0.0;  // allocations of the mask that were checked when it was last (re)allocated; kernel time / its time without stores
     int xcd_rel_tuned = -1;                       // the same for the write kernel (tune_relabel), for the shape below
@@ -652,7 +652,7 @@ extern "C" int ctk_debug_drop_buffer(ctk_handle *h, int which)
 
 extern "C" int ctk_set_result_transfer(ctk_handle *h, int mode)
 {
-    if (!h || mode < -1 || mode > 1) return ctk_set_error(CTK_E_INVALID, "ctk_set_result_transfer: mode -1 (environment), 0 (dense copy) or 1 (run tables)");
+    if (!h || mode < -1 || mode > 2) return ctk_set_error(CTK_E_INVALID, "ctk_set_result_transfer: mode -1 (environment), 0 (dense copy), 1 (run tables) or 2 (test hook: run tables made unavailable)");
     h->rle_mode = mode;
     return CTK_OK;
 }
@@ -876,8 +876,8 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         // Allocations made right after each other usually share a class -- the "bimodal board" of rounds 2-4.  So a freshly allocated
         // mask is checked against the slab: the kernel's time WITHOUT its stores (on the first 4 GB of a larger slab) is the yardstick,
         // and while the kernel with its stores is more than 8.5 % above it, another mask is allocated behind a spacer that is held in
-        // between (0.5, 1, 2, 4 GB: hipMalloc of these costs 0.02-0.3 ms) -- memory from somewhere else.  Two launches per measurement, 4 in
-        // the usual case (the first mask is fine), at most 12; once per handle and mask size; CTK_MASK_TUNE=0 turns it off.
+        // between (1, 4, 8, 8, 8, 8 GB: hipMalloc of these costs 0.02-0.3 ms; one that fails is skipped) -- memory from somewhere else.  Two
+        // launches per measurement, 4 in the usual case (the first mask is fine), at most 14; once per handle and mask size; CTK_MASK_TUNE=0 turns it off.
         h->mask_tries = mask_fresh ? 0 : h->mask_tries;
         const bool v7_path = !f64 && (nx % 4 == 0) && (((uintptr_t)anom_dev & 15) == 0);
         if (anom_dev && mask_fresh && h->mask_off_dbg < 0 && ctk_env().mask_tune && v7_path && (size_t)T * ny * nx * 4 >= ((size_t)128 << 20)) {
@@ -906,14 +906,23 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                 DevBuf best = h->mask;
                 if (rc == CTK_OK) rc = time_it(&best_ms);
                 h->mask_tries = 1;
-                static const int max_tries = getenv("CTK_MASK_TRIES") ? atoi(getenv("CTK_MASK_TRIES")) : 4;
+                static const int max_tries = getenv("CTK_MASK_TRIES") ? atoi(getenv("CTK_MASK_TRIES")) : 6;
                 static const double accept = getenv("CTK_MASK_ACCEPT") ? atof(getenv("CTK_MASK_ACCEPT")) : 1.085;
                 std::vector<void *> held;                                               // spacers and rejected masks: freed when the search is over
                 struct FreeHeld { std::vector<void *> &v; ~FreeHeld() { for (void *q : v) (void)hipFree(q); } } free_held{held};
                 for (int k = 0; rc == CTK_OK && k < max_tries && best_ms > accept * ro_ms; k++) {
-                    void *sp = nullptr;
-                    if (hipMalloc(&sp, (size_t)512 << (20 + k)) == hipSuccess) held.push_back(sp);
-                    else (void)hipGetLastError();
+                    // (1, 4, 8, 8, 8, 8 GB: a class can hold for many GB -- on one box five candidates within 7.5 GB all shared the slab's)
+                    static const std::vector<int> sched = [] {
+                        std::vector<int> v;
+                        if (const char *e = getenv("CTK_MASK_SPACERS_GB")) { for (const char *q = e; *q;) { v.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; } }
+                        else v = {1, 4, 8, 8, 8, 8};
+                        return v;
+                    }();
+                    for (int gb = k < (int)sched.size() ? sched[(size_t)k] : 8; gb > 0; gb -= 8) {      // (in pieces of <= 8 GB: hipMalloc of 16 GB takes 0.5-1.4 s)
+                        void *sp = nullptr;
+                        if (hipMalloc(&sp, (size_t)std::min(gb, 8) << 30) == hipSuccess) held.push_back(sp);
+                        else { (void)hipGetLastError(); break; }
+                    }
                     DevBuf nb;
                     if (ensure(h, nb, mbytes) != CTK_OK) break;                         // (no memory for another try: keep what there is)
                     h->mask = nb;
@@ -925,20 +934,6 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                     h->mask = best;
                 }
                 h->mask = best;
-                // last resort (3 of 24 handles in tools/mask_check_probe.sh: every allocation in the slab's class): the size of the tiles in
-                // which the chunks are dealt to the XCDs moves the kernel on such a placement (round 4: 16 ran at 6.6 TB/s where 64 stayed at 6.0)
-                if (rc == CTK_OK && best_ms > accept * ro_ms && h->xcd_thr < 0) {
-                    const int modes[3] = {16, 256, 4};
-                    int best_mode = -1;
-                    for (int m = 0; m < 3 && rc == CTK_OK && best_ms > accept * ro_ms; m++) {
-                        h->xcd_thr = modes[m];
-                        double ms = 0.0;
-                        rc = time_it(&ms);
-                        if (rc == CTK_OK && ms < best_ms) { best_ms = ms; best_mode = modes[m]; }
-                    }
-                    h->xcd_thr = -1;
-                    h->xcd_thr_tuned = best_mode;
-                } else if (h->xcd_thr < 0) h->xcd_thr_tuned = -1;
                 h->mask_ratio = ro_ms > 0 ? best_ms / ro_ms : 0.0;
                 if (ctk_env().hosttrace) fprintf(stderr, "mask placement: %d allocation(s) tried, threshold kernel on a %lld-step window %.4f ms = %.3f x its time without stores (%.4f), mask at %p, slab at %p\n", h->mask_tries, (long long)nt_probe, best_ms, h->mask_ratio, ro_ms, h->mask.p, anom_dev);
                 if (rc != CTK_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
@@ -2192,9 +2187,13 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
 static void tune_relabel(ctk_handle *h, int persistence, int32_t *flag_dev)
 {
     if (h->xcd_rel >= 0 || !ctk_env().mask_tune || h->sio || h->rle_out || !flag_dev || h->state != ST_TABLES) return;
-    if (h->rel_tuned_T == h->T && h->rel_tuned_ny == h->ny && h->rel_tuned_nx == h->nx && h->rel_tuned_flag == flag_dev) return;
+    // once per SHAPE (round 4 also keyed on the output pointer: a caller that alternates output buffers re-tuned on every call --
+    // advisor finding); slabs beyond 8 GB keep the launch order (nine extra passes of the write kernel would cost ~100 ms at
+    // 14 600 x 721 x 1440, where launch order measured best anyway)
+    if (h->rel_tuned_T == h->T && h->rel_tuned_ny == h->ny && h->rel_tuned_nx == h->nx) return;
     if ((size_t)h->T * h->ny * h->nx * 4 < ((size_t)128 << 20)) return;
     h->rel_tuned_T = h->T; h->rel_tuned_ny = h->ny; h->rel_tuned_nx = h->nx; h->rel_tuned_flag = flag_dev;
+    if ((size_t)h->T * h->ny * h->nx * 4 > ((size_t)8 << 30)) { h->xcd_rel_tuned = -1; return; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); return; }
     int rows = 0;
@@ -2498,6 +2497,7 @@ extern "C" int ctk_expand_runs_host(const uint64_t *mask, const uint32_t *rowsta
 }
 
 // The pass is over (tables in ST_TABLES state, nothing running on the handle's stream): expand the result into `flag`.
+#define CTK_RLE_UNAVAILABLE 2          // deliver_runs: the run transfer could not be set up / carried out; the pass itself is fine
 static int deliver_runs(ctk_handle *h, int persistence, int32_t *flag, int *wrote_background)
 {
     const int64_t T = h->T;
@@ -2508,8 +2508,11 @@ static int deliver_runs(ctk_handle *h, int persistence, int32_t *flag, int *wrot
     HIPCHK(hipMemcpy(rb.data(), h->run_base.p, (size_t)(T + 1) * 4, hipMemcpyDeviceToHost));
     std::vector<RleBlock> &blocks = h->rle_blocks;
     if (!h->rle) h->rle = new (std::nothrow) RlePool();
-    if (!h->rle || !h->rle->init(rle_need(rb.data(), T, ny, W))) return ctk_set_error(CTK_E_NOMEM, "result transfer: no pinned memory for the lane buffers");
-    if (!rle_blocks(rb.data(), T, ny, W, h->rle->cap, blocks)) return ctk_set_error(CTK_E_INTERNAL, "result transfer: a timestep's tables do not fit a lane buffer");
+    // What can go wrong HERE leaves the device pass intact: the caller repeats it with the dense result (CTK_RLE_UNAVAILABLE; until round 5
+    // a shortage of pinned memory failed the whole call -- advisor finding).  rle_mode 2: a test hook that takes this exit.
+    if (h->rle_mode == 2) { (void)ctk_set_error(CTK_E_NOMEM, "result transfer: made unavailable (test hook)"); return CTK_RLE_UNAVAILABLE; }
+    if (!h->rle || !h->rle->init(rle_need(rb.data(), T, ny, W))) { (void)ctk_set_error(CTK_E_NOMEM, "result transfer: no pinned memory for the lane buffers"); return CTK_RLE_UNAVAILABLE; }
+    if (!rle_blocks(rb.data(), T, ny, W, h->rle->cap, blocks)) { (void)ctk_set_error(CTK_E_INTERNAL, "result transfer: a timestep's tables do not fit a lane buffer"); return CTK_RLE_UNAVAILABLE; }
     const size_t nb = blocks.size();
     const int lanes = (int)std::min<size_t>(ctk_env().rle_lanes > 0 ? std::min(ctk_env().rle_lanes, kRleLanes) : kRleLanes, nb);
     std::atomic<int64_t> wait_us(0), exp_us(0);
@@ -2553,7 +2556,7 @@ static int deliver_runs(ctk_handle *h, int persistence, int32_t *flag, int *wrot
     const double tr1 = now_ms();
     for (auto &t : th) t.join();
     if (ctk_env().hosttrace) fprintf(stderr, "runs: %zu blocks on %d lanes | setup %.2f ms, lanes %.2f ms (per lane: waiting %.2f, expanding %.2f)\n", nb, lanes, tr1 - tr_begin, now_ms() - tr1, wait_us / 1e3 / lanes, exp_us / 1e3 / lanes);
-    if (!ok) return ctk_set_error(CTK_E_NODEVICE, "result transfer (run tables) failed: %s", hipGetErrorString(hipGetLastError()));
+    if (!ok) { (void)ctk_set_error(CTK_E_NODEVICE, "result transfer (run tables) failed: %s", hipGetErrorString(hipGetLastError())); return CTK_RLE_UNAVAILABLE; }
     // blocks with complex components: the write kernel, block by block
     int64_t ndense = 0;
     const size_t plane = (size_t)ny * nx;
@@ -2579,7 +2582,7 @@ static int deliver_runs(ctk_handle *h, int persistence, int32_t *flag, int *wrot
 // (grids beyond 8 M pixels per timestep: the dense copy -- a timestep's tables are meant to fit a lane buffer of a few MB)
 static bool runs_wanted(const ctk_handle *h, int ny, int nx)
 {
-    return (h->rle_mode < 0 ? ctk_env().rle_out : h->rle_mode == 1) && rle_per_t(ny, (nx + 63) / 64) <= kRleBuf / 2;
+    return (h->rle_mode < 0 ? ctk_env().rle_out : h->rle_mode >= 1) && rle_per_t(ny, (nx + 63) / 64) <= kRleBuf / 2;
 }
 
 // device pass + delivery of the result into the caller's host array (ctk_track_f32 / _f64 / ctk_track_resident)
@@ -2587,13 +2590,14 @@ static int track_to_host(ctk_handle *h, const void *a_dev, bool f64, int64_t T, 
                          double overlap, int persistence, int twosided, int32_t *flag, int64_t *n_tracked, double *t_pass_end)
 {
     const size_t n = (size_t)T * ny * nx;
-    const bool want_runs = n > 0 && runs_wanted(h, ny, nx);
-    // the dense result lives in the handle (grow-only); with the run transfer only the blocks of complex components ever need it
-    CTKCHK(ensure(h, h->io_out, want_runs ? 256 : std::max<size_t>(n * 4, 256)));
-    int32_t *f_dev = P<int32_t>(h->io_out);
-    h->stats[CTK_S_RLE_OUT] = 0;
+    bool want_runs = n > 0 && runs_wanted(h, ny, nx);
+    int32_t *f_dev = nullptr;
     int rc;
-    {
+    for (int attempt = 0; attempt < 2; attempt++) {
+        // the dense result lives in the handle (grow-only); with the run transfer only the blocks of complex components ever need it
+        CTKCHK(ensure(h, h->io_out, want_runs ? 256 : std::max<size_t>(n * 4, 256)));
+        f_dev = P<int32_t>(h->io_out);
+        h->stats[CTK_S_RLE_OUT] = 0;
         h->rle_out = want_runs;
         struct RleOff { ctk_handle *h; ~RleOff() { h->rle_out = false; } } rle_off{h};
         rc = track_dev_impl(h, a_dev, f64, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, f_dev, n_tracked);
@@ -2604,10 +2608,13 @@ static int track_to_host(ctk_handle *h, const void *a_dev, bool f64, int64_t T, 
         if (a1 > a0) (void)madvise((void *)a0, a1 - a0, MADV_HUGEPAGE);
         if (want_runs) {
             int wrote0 = 0;
-            CTKCHK(deliver_runs(h, persistence, flag, &wrote0));
+            rc = deliver_runs(h, persistence, flag, &wrote0);
+            if (rc == CTK_RLE_UNAVAILABLE) { want_runs = false; continue; }                // the pass again, with the write kernel and the dense copy
+            if (rc != CTK_OK) return rc;
             if (n_tracked) *n_tracked = h->last_alive + (wrote0 ? 1 : 0) - 1;              // len(np.unique(flag)) - 1, contrack.py:793
             return CTK_OK;
         }
+        break;
     }
     // the parallel copy; plain hipMemcpy for small results / if the lanes fail
     if (!h->bounce) h->bounce = new (std::nothrow) BouncePool();
@@ -2779,7 +2786,6 @@ static int track_stream_impl(ctk_handle *h, StreamIO &io, bool f64, int64_t T, i
     h->rle_out = T > 0 && io.host_out && runs_wanted(h, ny, nx);
     h->stats[CTK_S_RLE_OUT] = 0;
     int rc = track_dev_impl(h, nullptr, f64, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, nullptr, n_tracked);
-    h->sio = nullptr;
     if (rc == CTK_OK && h->rle_out) {
         const double o0 = now_ms();
         const size_t nb = (size_t)T * ny * nx * 4;
@@ -2789,7 +2795,13 @@ static int track_stream_impl(ctk_handle *h, StreamIO &io, bool f64, int64_t T, i
         rc = deliver_runs(h, persistence, io.host_out, &wrote0);
         if (rc == CTK_OK && n_tracked) *n_tracked = h->last_alive + (wrote0 ? 1 : 0) - 1;      // len(np.unique(flag)) - 1, contrack.py:793
         io.ms_out += now_ms() - o0;
+        if (rc == CTK_RLE_UNAVAILABLE) {                       // the slab streams through once more, the result leaves in dense chunks
+            h->rle_out = false;
+            h->stats[CTK_S_RLE_OUT] = 0;
+            rc = track_dev_impl(h, nullptr, f64, T, ny, nx, thr, cmp_op, wrow, overlap, persistence, twosided, nullptr, n_tracked);
+        }
     }
+    h->sio = nullptr;
     h->rle_out = false;
     h->stream_ms[0] = io.ms_read; h->stream_ms[1] = io.ms_write; h->stream_ms[2] = io.ms_in; h->stream_ms[3] = io.ms_out;
     h->ms[CTK_T_H2D] = io.ms_in; h->ms[CTK_T_D2H] = io.ms_out; h->ms[CTK_T_TOTAL] = now_ms() - t0;

@@ -1,6 +1,6 @@
 // ctk_comm.hip -- transports of the time-sharded path's communicator (see ctk_comm.h).  Host code only.
 #include "ctk_comm.h"
-#include "../../include/contrack_hip.h"
+#include "../../include/contrack_hip_debug.h"
 
 #include <rccl/rccl.h>          // types and prototypes only: librccl.so is dlopen'ed, never linked
 
@@ -125,7 +125,7 @@ struct CtkCtlSeg {
                                         // something only to a process of the same namespace (one container per GPU sharing /dev/shm)
 };
 namespace {
-constexpr uint64_t kCtlMagic = 0x324c54434b5443ull;      // "CTKCTL2"
+constexpr uint64_t kCtlMagic = 0x334c54434b5443ull;      // "CTKCTL3": bumped whenever the layout or size of CtkCtlSeg changes (round 4 changed both under "CTKCTL2")
 constexpr size_t kCtlBytes = 32768;
 static_assert(sizeof(CtkCtlSeg) <= kCtlBytes, "control segment header");
 static_assert(offsetof(CtkCtlSeg, failed_code) % 8 == 0 && offsetof(CtkCtlSeg, failed_rank) == offsetof(CtkCtlSeg, failed_code) + 4, "failure word");
@@ -236,6 +236,10 @@ int ctl_open(ctk_comm *c, const char *name, size_t bytes, uint64_t slot, void **
         while (fd < 0) {
             fd = shm_open(name, O_RDWR, 0600);
             struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size > bytes) {      // a segment of another library build (or a stale one of this name)
+                close(fd);
+                return ctk_set_error(CTK_E_COMM, "rank %d: shared-memory segment %s has %lld bytes, this library maps %zu: another build of the library, or a stale segment", c->rank, name, (long long)st.st_size, bytes);
+            }
             if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes)) { close(fd); fd = -1; }
             if (fd < 0) {
                 if (mono_s() - t0 > c->timeout_s) return ctk_set_error(CTK_E_COMM, "rank %d: shared-memory segment %s did not appear within %.0f s", c->rank, name, c->timeout_s);

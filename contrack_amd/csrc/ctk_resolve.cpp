@@ -13,7 +13,7 @@
 // co-occurrence areas, and the rows whose two seam pixels are both set.
 #include "ctk_tables.h"
 #include "ctk_seam.h"
-#include "../../include/contrack_hip.h"
+#include "../../include/contrack_hip_debug.h"
 
 #include <algorithm>
 #include <cmath>

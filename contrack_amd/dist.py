@@ -1,7 +1,7 @@
 """Time-sharded multi-GPU driver of the run_contrack hot path -- no torch.
 
 One process per GPU (any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT, e.g. torch.distributed.run as
-bench.py's contract prescribes -- the launcher is the only thing taken from it); rank r owns the contiguous timesteps
+the driver's launch contract prescribes -- the launcher is the only thing taken from it); rank r owns the contiguous timesteps
 [t0_r, t1_r).  Everything that follows happens inside libcontrack_hip.so (csrc/ctk_sharded.hip, ctk_comm.hip): the
 ranks exchange a one-timestep label-map halo with their neighbours and a few hundred boundary records per step
 through RCCL (ncclSend/ncclRecv, ncclAllGather over xGMI); the overlap filter, the 3-D labelling and the seam merges are
@@ -19,10 +19,8 @@ raise _native.CommError within milliseconds.  Dead ranks are noticed by pid; eve
 (CTK_COMM_TIMEOUT_S, default 120 s).
 """
 import ctypes as C
-import json
 import os
 import struct
-import sys
 import time
 
 import numpy as np
@@ -232,321 +230,3 @@ class ShardedTracker:
                 if p is not None:
                     self.trk.free(p)
         return flag, n
-
-
-# ------------------------------------------------------------------------------------------------
-# bench.py leg for N > 1 (one rank per GPU, launched as the bench contract says)
-# ------------------------------------------------------------------------------------------------
-def _ptr(p, off):
-    return C.c_void_p((p.value if hasattr(p, "value") else int(p)) + int(off))
-
-
-def _scratch_dir():
-    d = os.environ.get("CTK_BENCH_TMP") or ("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else os.environ.get("TMPDIR", "/tmp"))
-    return d
-
-
-def _weights(ny, nx):
-    from . import synth
-    lat, _ = synth.grid(ny, nx)
-    return np.array((111 * np.float32(180.0 / (ny - 1)) * 111 * np.float32(360.0 / nx) * np.cos(lat * np.pi / 180))).astype(np.float32)
-
-
-def _timed_sharded(trk, comm, step, steps, warmup):
-    """barrier + sync | `steps` calls | sync + barrier; max over ranks (the bench contract's timing)"""
-    n = None
-    for _ in range(max(warmup, 0)):
-        n = step()
-    comm.barrier()
-    trk.sync()
-    ops0 = comm.ops()
-    tb = time.perf_counter()
-    for _ in range(steps):
-        n = step()
-    trk.sync()
-    comm.barrier()
-    dt_local = time.perf_counter() - tb
-    dt = float(comm.allgather(np.array([dt_local], dtype=np.float64)).max())
-    ops1 = comm.ops()
-    k = max(steps, 1)
-    return n, dt, dict(neighbour_exchanges=(ops1["neighbour_exchanges"] - ops0["neighbour_exchanges"]) / k,
-                       allgathers=(ops1["allgathers"] - ops0["allgathers"] - 2) / k)       # (- the two barriers / the time gather)
-
-
-def parity_check(trk, comm, rank, world, members, d_out_local, nloc, t0, T_total, ny, nx, thr_value, op, w, wl, n_tracked):
-    """In-run proof that the sharded result is the one-call result: every rank checksums its shard of `flag` on its GPU; rank 0
-    tracks the concatenated slab with ONE call on its own GPU and checksums the same windows.  `members`: how rank 0 obtains
-    member q's input -- ("file", path) written by rank q, or ("fill", seed, t_first, T_q) for the device generator.
-    Returns (checked, detail) on rank 0, (None, None) elsewhere.  Collective: every rank must call."""
-    from . import synth
-    plane = ny * nx
-    mine = np.array(trk.checksum_i32(d_out_local, nloc * plane, t0 * plane), dtype=np.uint64)
-    allsum = comm.allgather(mine)                                     # (world, 2)
-    bounds = comm.allgather(np.array([t0, nloc], dtype=np.int64))
-    detail = None
-    if rank == 0:
-        d_in = d_out = None
-        try:
-            d_in = trk.malloc(T_total * plane * 4)
-            d_out = trk.malloc(T_total * plane * 4)
-            for q in range(world):
-                tq, nq = int(bounds[q][0]), int(bounds[q][1])
-                m = members[q]
-                if m[0] == "file":
-                    trk.h2d(_ptr(d_in, tq * plane * 4), np.load(m[1], mmap_mode="r"))
-                elif m[0] == "regen":                                 # (no shared scratch space: rank 0 generates the member again)
-                    trk.h2d(_ptr(d_in, tq * plane * 4), np.ascontiguousarray(synth.smooth_field(m[2], ny, nx, seed=m[1])[m[3]:m[3] + nq]))
-                else:
-                    trk.synth_fill(_ptr(d_in, tq * plane * 4), nq, ny, nx, seed=m[1], t0=m[2])
-            thr = np.full(T_total, thr_value)
-            trk.set_timing(0)
-            n_one = trk.track_dev(d_in, T_total, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], d_out)
-            equal = []
-            for q in range(world):
-                tq, nq = int(bounds[q][0]), int(bounds[q][1])
-                ref = trk.checksum_i32(_ptr(d_out, tq * plane * 4), nq * plane, tq * plane)
-                equal.append(bool(ref[0] == int(allsum[q][0]) and ref[1] == int(allsum[q][1])))
-            detail = dict(shards_equal=equal, n_tracked_one_call=int(n_one), n_tracked_sharded=int(n_tracked),
-                          flag_pixels=int(allsum[:, 1].sum()),
-                          method="64-bit position-weighted checksum of every rank's flag shard vs the same window of ONE ctk_track_f32_dev "
-                                 "call on the concatenated %dx%dx%d slab on rank 0's GPU" % (T_total, ny, nx))
-        except (MemoryError, OSError, _native.ContrackHipError, ValueError) as e:
-            detail = dict(error="%s: %s" % (type(e).__name__, e))
-        finally:
-            for p in (d_in, d_out):
-                if p is not None:
-                    trk.free(p)
-    comm.barrier()
-    if rank != 0:
-        return None, None
-    ok = bool(detail.get("shards_equal")) and all(detail["shards_equal"]) and detail["n_tracked_one_call"] == detail["n_tracked_sharded"]
-    return ok, detail
-
-
-def strong_block(trk, comm, rank, world, wl, T, steps, warmup):
-    """Strong scaling of ONE device-generated slab of T steps (the north_star's >= 6x target is stated on 0.25 deg): rank 0 times
-    the one-call path on the whole slab on its GPU, then all ranks track their windows of the same slab; speed-up = the ratio."""
-    ny, nx = wl["ny"], wl["nx"]
-    plane = ny * nx
-    w = _weights(ny, nx)
-    op = _native.CMP_OPS[wl["gorl"]]
-    thr_value = np.float64(np.float32(wl["threshold"]))
-    one = np.zeros(2, dtype=np.float64)                                # ms per pass on one GPU, tracked count
-    err = None
-    if rank == 0:
-        d_in = d_out = None
-        try:
-            d_in, d_out = trk.malloc(T * plane * 4), trk.malloc(T * plane * 4)
-            trk.synth_fill(d_in, T, ny, nx, seed=0)
-            thr = np.full(T, thr_value)
-            trk.set_timing(0)
-            for _ in range(max(warmup, 1)):
-                n1 = trk.track_dev(d_in, T, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], d_out)
-            trk.sync()
-            tb = time.perf_counter()
-            for _ in range(steps):
-                n1 = trk.track_dev(d_in, T, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], d_out)
-            trk.sync()
-            one[:] = ((time.perf_counter() - tb) * 1e3 / steps, n1)
-        except (MemoryError, _native.ContrackHipError, ValueError) as e:
-            err = "%s: %s" % (type(e).__name__, e)
-        finally:
-            for p in (d_in, d_out):
-                if p is not None:
-                    trk.free(p)
-    one = comm.allgather(one)[0]
-    if one[0] <= 0:                                                    # (every rank sees it: the caller may try a smaller slab)
-        return False, (dict(error=err or "the one-GPU pass did not run", steps_tried=T) if rank == 0 else None)
-    t0, t1 = shard_bounds(T, world)[rank]
-    nloc = t1 - t0
-    d_in, d_out = trk.malloc(nloc * plane * 4), trk.malloc(nloc * plane * 4)
-    trk.synth_fill(d_in, nloc, ny, nx, seed=0, t0=t0)
-    thr = np.full(nloc, thr_value)
-
-    def step():
-        return trk.track_sharded_dev(comm, d_in, nloc, t0, T, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], d_out)
-    nN, dt, coll = _timed_sharded(trk, comm, step, steps, warmup)
-    trk.free(d_in)
-    trk.free(d_out)
-    if rank != 0:
-        return True, None
-    ms = dt * 1e3 / steps
-    return True, dict(workload="%dx%dx%d float32 (device-generated), threshold %s %g, overlap %g, persistence %d" % (
-                    T, ny, nx, wl["gorl"], wl["threshold"], wl["overlap"], wl["persistence"]),
-                n_gpus=world, ms_per_step_1gpu=float(one[0]), ms_per_step=ms, speedup_vs_1gpu=float(one[0]) / ms,
-                timesteps_per_s=T / (ms * 1e-3), n_tracked=int(nN), n_tracked_one_call=int(one[1]), n_tracked_equal=bool(int(one[1]) == int(nN)),
-                collectives_per_step=coll, steps=steps,
-                note="same launch: the one-call time is measured on rank 0's GPU (the whole slab resident), then the slab is split into "
-                     "%d time shards; barrier + sync around the timed calls, max over ranks" % world)
-
-
-def bench_main(args, wl, workloads, hbm_peak, cpu_baseline=None, pmc_traffic=None):
-    from . import synth
-    # Keep stdout clean for the ONE JSON line: RCCL may print through C stdio at communicator creation.  Everything
-    # written to fd 1 until the result is ready goes to stderr instead.
-    sys_stdout_fd = os.dup(1)
-    os.dup2(2, 1)
-    rank, world, local = env_rank_world()
-    backend = os.environ.get("CTK_DIST_BACKEND", "rccl")
-    st = ShardedTracker(rank=rank, world=world, backend=backend)
-    trk, comm = st.trk, st.comm
-    backend = getattr(comm, "transport", backend)
-    T, ny, nx = wl["T"], wl["ny"], wl["nx"]
-    plane = ny * nx
-    weak = getattr(args, "scaling", "weak") == "weak"
-    if weak:
-        # weak scaling: one member of wl["T"] steps per GPU, members concatenated on the time axis (the layout of
-        # BASELINE.json configs[4]); rank r holds member r = synthetic slab with seed r, global steps [r T, (r+1) T).
-        t0, t1 = rank * T, (rank + 1) * T
-        T_total = T * world
-    else:
-        t0, t1 = shard_bounds(T, world)[rank]
-        T_total = T
-    nloc = t1 - t0
-    d_in = trk.malloc(max(nloc * plane * 4, 8))
-    d_out = trk.malloc(max(nloc * plane * 4, 8))
-    check_parity = not getattr(args, "no_parity_check", False) and 2 * T_total * plane * 4 <= (96 << 30)
-    member = None
-    cpu_slab = None
-    if wl.get("device_fill"):
-        seed, tf = (rank, 0) if weak else (0, t0)
-        trk.synth_fill(d_in, nloc, ny, nx, seed=seed, t0=tf)
-        member = ("fill", seed, tf)
-    else:
-        a_full = synth.smooth_field(T, ny, nx, seed=rank if weak else 0)
-        a = a_full if weak else a_full[t0:t1]
-        trk.h2d(d_in, a)
-        if rank == 0 and cpu_baseline is not None and not getattr(args, "no_cpu_baseline", False):
-            cpu_slab = a_full                                          # (the workload's own slab, seed 0: what the N = 1 line times too)
-        if check_parity:
-            # rank 0 needs every member for the one-call run: through a file in shared scratch space, or -- if that cannot be
-            # written -- by generating it again from (seed, window)
-            member = ("regen", rank if weak else 0, T, 0 if weak else t0)
-            for d in (_scratch_dir(), os.environ.get("TMPDIR", "/tmp")):
-                path = os.path.join(d, "ctk_bench_%s_member%d.npy" % (launch_key(), rank))
-                try:
-                    np.save(path, a)
-                    member = ("file", path)
-                    break
-                except OSError:
-                    try:
-                        os.remove(path)
-                    except OSError:
-                        pass
-        del a, a_full
-    w = _weights(ny, nx)
-    thr_value = np.float64(np.float32(wl["threshold"]))
-    thr = np.full(nloc, thr_value)
-    op = _native.CMP_OPS[wl["gorl"]]
-    trk.set_timing(1)            # HIP events around the two streaming kernels only (see bench.py)
-
-    def step():
-        return trk.track_sharded_dev(comm, d_in, nloc, t0, T_total, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], d_out)
-
-    n_tracked = None
-    for _ in range(max(args.warmup, 0)):
-        n_tracked = step()
-    comm.barrier()
-    trk.sync()
-    trk.timing_sums(reset=True)  # (level-1 timing: an event pair around ONE of the two streaming kernels in every second pass, summed by the library)
-    ops0 = comm.ops()
-    tb = time.perf_counter()
-    for _ in range(args.steps):
-        n_tracked = step()
-    trk.sync()
-    comm.barrier()
-    dt_local = time.perf_counter() - tb
-    dt = float(comm.allgather(np.array([dt_local], dtype=np.float64)).max())
-    ops1 = comm.ops()
-    per, nmeas = trk.timing_sums(reset=True)
-    last = trk.timings()                              # (host-side timers of the last pass: informational)
-    per.update({k: last[k] for k in ("host_seam_driver", "total", "d2h", "h2d")})
-    stats = trk.stats()
-    px = nloc * plane
-
-    # ---- untimed: the result proves itself (in-run parity against the one-call path), then the strong-scaling leg -----------
-    parity_ok, parity = None, None
-    if check_parity:
-        code = {"fill": 0, "file": 1, "regen": 3}[member[0]]
-        if member[0] == "file" and os.path.dirname(member[1]) != _scratch_dir():
-            code = 2                                                  # (the file went to TMPDIR)
-        kinds = comm.allgather(np.array([code] + [int(v) for v in member[1:4] if not isinstance(v, str)] + [0] * 3, dtype=np.int64)[:4])
-        members = []
-        for q in range(world):
-            c, k = int(kinds[q][0]), [int(v) for v in kinds[q][1:4]]
-            if c in (1, 2):
-                members.append(("file", os.path.join(_scratch_dir() if c == 1 else os.environ.get("TMPDIR", "/tmp"), "ctk_bench_%s_member%d.npy" % (launch_key(), q))))
-            elif c == 3:
-                members.append(("regen", k[0], k[1], k[2]))
-            else:
-                members.append(("fill", k[0], k[1]))
-        parity_ok, parity = parity_check(trk, comm, rank, world, members, d_out, nloc, t0, T_total, ny, nx, thr_value, op, w, wl, n_tracked)
-        if member[0] == "file":
-            try:
-                os.remove(member[1])
-            except OSError:
-                pass
-    trk.free(d_in)
-    trk.free(d_out)
-    strong = None
-    sT = int(getattr(args, "strong_steps", 0) or 0)
-    if world > 1 and sT != 0:
-        swl = workloads["era5_025deg_2k"]                              # (grid and parameters; the number of steps is sT)
-        tried = []
-        for cand in ([14600, 2000] if sT < 0 else [sT]):
-            if cand < world:
-                continue
-            ok, strong = strong_block(trk, comm, rank, world, swl, cand, max(2, min(args.steps, 5)), 1)
-            if ok:
-                break
-            tried.append(strong)
-        if rank == 0 and strong is not None and tried and "error" not in strong:
-            strong["larger_slab_not_run"] = tried
-
-    n_devices = len(set(int(v) for v in comm.allgather(np.array([st.device], dtype=np.int64)).ravel()))
-    alg = {"k_threshold": 4.0 * px, "k_relabel": 4.0 * px}
-    kern = max(alg, key=lambda k: per.get(k, 0.0))
-    achieved = alg[kern] / (per[kern] * 1e-3) / 1e9 if per.get(kern, 0) > 0 else 0.0
-    if rank == 0:
-        nsteps = max(args.steps, 1)
-        out = dict(metric="timesteps/sec labeled+tracked", value=T_total * args.steps / dt, unit="timesteps/s", n_gpus=world,
-                   steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3 / nsteps, higher_is_better=True,
-                   scaling="weak" if weak else "strong", vs_baseline=None, dtype="f32 compare / int32 labels / int64 exact areas", data="synthetic",
-                   config=dict(workload="%s: %s%dx%dx%d float32, threshold %s %g, overlap %g, persistence %d, twosided %s" % (
-                       args.workload, ("%d members concatenated on the time axis, each " % world) if weak else "", T, ny, nx, wl["gorl"],
-                       wl["threshold"], wl["overlap"], wl["persistence"], wl["twosided"]),
-                       total_timesteps=T_total,
-                       parallelism="time-sharded x%d: one-timestep halo + boundary records, shard-local resolver (%s)" % (
-                           world, "RCCL ncclSend/Recv + ncclAllGather" if backend == "rccl" else "shared-memory transport (host staging; several ranks may share a GPU)"),
-                       transport=backend, rccl_ranks=world if backend == "rccl" else 0, n_tracked=n_tracked,
-                       parity_checked=bool(parity_ok) if parity_ok is not None else False, parity=parity,
-                       collectives_per_step=dict(neighbour_exchanges=(ops1["neighbour_exchanges"] - ops0["neighbour_exchanges"]) / nsteps,
-                                                 allgathers=(ops1["allgathers"] - ops0["allgathers"] - 2) / nsteps)),      # (- the closing barrier and the time gather)
-                   roofline=dict(bound="hbm", kernel={"k_threshold": "k_threshold_v4" if os.environ.get("CTK_THRESHOLD") == "4" else "k_threshold_v7", "k_relabel": {5: "k_relabel_v5", 4: "k_relabel_v4"}.get(stats.get("relabel_kernel", 4), "k_relabel")}[kern], achieved=achieved, peak=hbm_peak,
-                                 unit="GB/s", frac=achieved / hbm_peak, traffic=None, algorithmic_bytes_per_launch=alg[kern],
-                                 avg_kernel_ms=per.get(kern), note="rank 0's shard"),
-                   kernels_ms=per, workload_stats_rank0=stats)
-        out["config"]["distinct_devices"] = n_devices
-        if pmc_traffic is not None and nloc == T:
-            # (HBM bytes per launch from the committed PMC capture of this workload: rank 0's shard IS the workload's slab when every
-            # rank holds one member)
-            out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"], args.workload)
-        if strong is not None:
-            out["strong_025deg"] = strong
-    st.close()                                       # (nothing collective from here on)
-    rc = 0
-    if rank == 0:
-        if cpu_slab is not None:
-            # the CPU leg: the oracle's scipy port on the workload's own slab, rank 0's host cores, after every collective is done
-            out["cpu_baseline"] = cpu_baseline(wl, cpu_slab, w)
-        # the line must not stand for a result nobody checked: a parity check that ran and failed (or could not run) fails the job
-        if check_parity and not parity_ok:
-            rc = 3
-            print("bench.py: the in-run parity check of the sharded result FAILED or could not run: %s" % json.dumps(parity), file=sys.stderr)
-        try:
-            C.CDLL(None).fflush(None)            # drain C stdio into stderr before stdout is restored
-        except Exception:
-            pass
-        os.dup2(sys_stdout_fd, 1)
-        print(json.dumps(out), flush=True)
-    return rc

@@ -1,7 +1,7 @@
 """Deterministic synthetic Z500-anomaly-like slabs.
 
 White noise -> Gaussian filter sigma = (2 steps, 6 deg, 6 deg) with longitude wrap -> std 100 -> +offset.
-Used by bench.py and the tests; not on the hot path.
+Used by the measurement scripts and the tests; not on the hot path.
 """
 import numpy as np
 

@@ -122,3 +122,23 @@ def test_streaming_entry_with_an_array_sink(trk, chunk):
         assert (trk.stats()["result_as_runs"] >= 1) == (mode == 1)
         assert n == nw and np.array_equal(f, want)
     trk.set_result_transfer(-1)
+
+
+def test_unavailable_run_transfer_falls_back_to_the_dense_copy(trk):
+    """a shortage of pinned memory for the lane buffers (or a failed lane copy) must not fail the call: the pass is repeated with the
+    write kernel and the dense copy (mode 2 = the run transfer wanted but made unavailable; round-4 advisor finding)"""
+    T, ny, nx = 120, 91, 180
+    anom = synth.smooth_field(T, ny, nx, seed=77)
+    wrow = np.cos(np.deg2rad(np.linspace(-89, 89, ny))).astype(np.float32)
+    thr = np.full(T, 150.0)
+    trk.set_result_transfer(1)
+    want, nw = trk.track(anom, thr, 0, wrow, 0.5, 4, True)
+    assert trk.stats()["result_as_runs"] >= 1 and nw > 0
+    trk.set_result_transfer(2)
+    f, n = trk.track(anom, thr, 0, wrow, 0.5, 4, True)
+    st = trk.stats()
+    assert st["result_as_runs"] == 0 and st["relabel_kernel"] >= 0
+    assert n == nw and np.array_equal(f, want)
+    f, n = trk.track_stream(anom, thr, 0, wrow, 0.5, 4, True, chunk_steps=16)
+    assert trk.stats()["result_as_runs"] == 0 and n == nw and np.array_equal(f, want)
+    trk.set_result_transfer(-1)
