@@ -37,6 +37,11 @@ WORKLOADS["era5_025deg_10yr"] = dict(T=14600, ny=721, nx=1440, threshold=160.0, 
                                      device_fill=True)      # BASELINE.json configs[2]: 60.6 GB in + 60.6 GB out, generated on the device
 WORKLOADS["era5_025deg_1k"] = dict(T=1000, ny=721, nx=1440, threshold=160.0, gorl=">=", overlap=0.5, persistence=20, twosided=True, device_fill=True)
 WORKLOADS["era5_025deg_2k"] = dict(T=2000, ny=721, nx=1440, threshold=160.0, gorl=">=", overlap=0.5, persistence=20, twosided=True, device_fill=True)
+# BASELINE.json configs[4]: CESM-LE Z500, 40 members x 10 950 daily steps concatenated on the time axis, 192 x 288, float64 irregular latitudes
+# (the reference needs set_up(force=True): dlat = round(mean spacing, 2), contrack.py:357-370); 96.9 GB in + 96.9 GB out on one GPU,
+# every member its own device-generated field
+WORKLOADS["cesm_le_40x30yr"] = dict(T=438000, ny=192, nx=288, threshold=160.0, gorl=">=", overlap=0.5, persistence=5, twosided=True,
+                                    device_fill=True, members=40, cesm_grid=True)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -52,6 +57,56 @@ def make_slab(wl, seed=0):
     dlat = np.float32(180.0 / (wl["ny"] - 1))
     dlon = np.float32(360.0 / wl["nx"])
     return a, row_weights(lat, dlat, dlon)
+
+
+def cesm_latitudes(ny):
+    """Gaussian-like float64 latitudes with irregular spacing (tests/golden/make_golden.py::cesm_grid, tests/test_gpu_fullsize_cesm.py)"""
+    k = np.arange(ny)
+    return (90.0 - 180.0 * (k + 0.5) / ny + 0.3 * np.sin(np.pi * k / (ny - 1))).astype(np.float64)
+
+
+def workload_weights(wl):
+    """row weights as the reference's set_up + contrack.py:703-704 give them for the workload's grid"""
+    ny, nx = wl["ny"], wl["nx"]
+    if wl.get("cesm_grid"):
+        lat = cesm_latitudes(ny)
+        dlat = np.float64(round(float(np.abs(np.diff(lat)).mean()), 2))       # contrack.py:365 (force=True)
+        return row_weights(lat, dlat, np.float64(360.0 / nx))
+    lat, _ = synth.grid(ny, nx)
+    return row_weights(lat, np.float32(180.0 / (ny - 1)), np.float32(360.0 / nx))
+
+
+def device_fill(trk, d_in, wl):
+    """the workload's slab generated on the device; `members` > 1: every member of the concatenated slab its own field"""
+    import ctypes as C
+    T, ny, nx = wl["T"], wl["ny"], wl["nx"]
+    m = int(wl.get("members", 1))
+    if m <= 1:
+        trk.synth_fill(d_in, T, ny, nx, seed=0)
+        return
+    per = (T + m - 1) // m
+    for q, tb in enumerate(range(0, T, per)):
+        trk.synth_fill(C.c_void_p(d_in.value + tb * ny * nx * 4), min(per, T - tb), ny, nx, seed=100 + q)
+
+
+def pmc_traffic_source(kernel, workload):
+    """(bytes, where they come from) -- see pmc_traffic"""
+    import glob
+    best = (None, None)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            doc = json.load(open(path))
+            k = doc["kernels"]
+        except Exception:
+            continue
+        if ("workload " + workload) not in doc.get("note", ""):
+            continue
+        for name, v in k.items():
+            if name.split("<")[0] == kernel:
+                best = (v["fetch_bytes_corrected"] + v["write_bytes"],
+                        "profiles/%s: committed rocprofv3 --pmc capture of this workload (FETCH_SIZE x 2 + WRITE_SIZE per launch, tools/profile.sh); "
+                        "NOT measured in this run" % os.path.basename(path))
+    return best
 
 
 def pmc_traffic(kernel, workload):
@@ -185,9 +240,11 @@ def secondary_025deg(steps, warmup, budget_steps=240):
                    value=T / (ms * 1e-3), unit="timesteps/s", ms_per_step=ms, steps=k, n_tracked=n_tracked,
                    path_effective_gbs=8.0 * px / (ms * 1e-3) / 1e9,
                    roofline=dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                                 traffic=pmc_traffic(kname, name), algorithmic_bytes_per_launch=alg[kern], avg_kernel_ms=per.get(kern),
+                                 traffic=pmc_traffic_source(kname, name)[0], traffic_source=pmc_traffic_source(kname, name)[1],
+                                 algorithmic_bytes_per_launch=alg[kern], avg_kernel_ms=per.get(kern),
                                  other_streaming_kernel={q: dict(achieved=alg[q] / (per[q] * 1e-3) / 1e9, avg_kernel_ms=per[q])
                                                          for q in alg if q != kern and per.get(q, 0) > 0}))
+        out["workload_stats"] = trk.stats()
         # CPU leg: the first n steps of the same slab, downloaded; the GPU's flags of those n steps alongside
         n = min(budget_steps, T)
         a = np.empty((n, ny, nx), dtype=np.float32)
@@ -205,6 +262,7 @@ def secondary_025deg(steps, warmup, budget_steps=240):
                                           "(oracle/scipy_port.py), %.2f s" % (n, T, dc),
                                    flags_equal_gpu=bool(np.array_equal(np.asarray(f_cpu), f_gpu)), n_tracked_gpu_same_sample=n_gpu)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        out["coverage_first_%d_steps" % n] = float((a >= np.float32(wl["threshold"])).mean())
         return out
     finally:
         trk.free(d_in)
@@ -293,9 +351,8 @@ def main():
     if wl.get("device_fill"):
         # slabs beyond host RAM: deterministic on-device generator (ctk_synth_fill), no CPU baseline / coverage
         a = None
-        lat, _ = synth.grid(ny, nx)
-        w = row_weights(lat, np.float32(180.0 / (ny - 1)), np.float32(360.0 / nx))
-        trk.synth_fill(d_in, T, ny, nx, seed=0)
+        w = workload_weights(wl)
+        device_fill(trk, d_in, wl)
         args.no_cpu_baseline = True
     else:
         a, w = make_slab(wl)
@@ -348,15 +405,17 @@ def main():
     achieved = alg_bytes[kern] / (per[kern] * 1e-3) / 1e9 if per.get(kern, 0) > 0 else 0.0
     rk = {5: "k_relabel_v5", 4: "k_relabel_v4"}.get(trk.stats().get("relabel_kernel", 4), "k_relabel")
     kname = {"k_threshold": "k_threshold_v4" if os.environ.get("CTK_THRESHOLD") == "4" else "k_threshold_v7", "k_relabel": rk}[kern]
+    coverage = float((a >= np.float32(wl["threshold"])).mean()) if a is not None else None      # (device-generated slabs: filled in at the end)
+    traffic, traffic_source = pmc_traffic_source(kname, args.workload)
     out = dict(metric="timesteps/sec labeled+tracked", value=value, unit="timesteps/s", n_gpus=1, steps=args.steps,
                warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f32 compare / int32 labels / int64 exact areas", data="synthetic",
                config=dict(workload="%s: %dx%dx%d float32, threshold %s %g, overlap %g, persistence %d, twosided %s" % (
                    args.workload, T, ny, nx, wl["gorl"], wl["threshold"], wl["overlap"], wl["persistence"], wl["twosided"]),
                    parallelism="1 GPU", n_tracked=n_tracked,
-                   coverage=float((a >= np.float32(wl["threshold"])).mean()) if a is not None else None),
+                   coverage=coverage),
                roofline=dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                             traffic=pmc_traffic(kname, args.workload), algorithmic_bytes_per_launch=alg_bytes[kern],
+                             traffic=traffic, traffic_source=traffic_source, algorithmic_bytes_per_launch=alg_bytes[kern],
                              avg_kernel_ms=per.get(kern),
                              other_streaming_kernel={k: dict(achieved=alg_bytes[k] / (per[k] * 1e-3) / 1e9, avg_kernel_ms=per[k])
                                                      for k in alg_bytes if k != kern and per.get(k, 0) > 0}),
@@ -387,7 +446,8 @@ def main():
                     keep.append(f)
                 del f
             return dict(ms_per_call=e2e * 1e3, timesteps_per_s=T / e2e, h2d_ms=lib["h2d"], h2d_gb_per_s=4.0 * px / lib["h2d"] / 1e6,
-                        result_ms=lib["d2h"], result_gb_per_s=4.0 * px / lib["d2h"] / 1e6)
+                        result_ms=lib["d2h"], result_gb_per_s=4.0 * px / lib["d2h"] / 1e6,
+                        d2h_ms=lib["d2h"], d2h_gb_per_s=4.0 * px / lib["d2h"] / 1e6)       # (the names of rounds 1-3 for the result leg)
         rec = e2e_leg(False)
         fresh = e2e_leg(True)
         as_runs = trk.stats()["result_as_runs"]
@@ -396,7 +456,9 @@ def main():
         trk.track(a, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"])
         dense = e2e_leg(False)
         trk.set_result_transfer(-1)
-        out["e2e"] = dict(rec, result_transfer=("run tables, %d block(s) through the write kernel" % (as_runs - 1)) if as_runs else "dense copy",
+        out["e2e"] = dict(rec, schema="r4: ms_per_call = results dropped between calls (their memory recycled: ms_per_call_recycled); the quantity "
+                                      "rounds 1-3 called ms_per_call (every result a fresh array) is fresh_result_arrays.ms_per_call; d2h_* = result_*",
+                          ms_per_call_recycled=rec["ms_per_call"], result_transfer=("run tables, %d block(s) through the write kernel" % (as_runs - 1)) if as_runs else "dense copy",
                           fresh_result_arrays=fresh, dense_copy=dense,
                           note="pageable numpy slab in (plain hipMemcpy at PCIe rate), numpy flag out, includes the %.2f ms device pass.  The result "
                                "crosses PCIe as the pass's run tables (bit mask + first run of every row + value of every run: 1/23 of the int32 "
@@ -412,6 +474,13 @@ def main():
         out["concurrent_members"] = concurrent_members(wl, a, thr, op, w, 4, max(args.steps // 2, 4))
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, a, w)
+    if a is None:
+        # coverage of a device-generated slab: one untimed pass that keeps every foreground pixel (overlap 0, persistence 0) -- its
+        # nonzero flags ARE the mask.  Last, on a handle of its own behind the measurements (its tables are not the workload's).
+        trk.close()
+        trk = _native.Tracker(int(os.environ.get("LOCAL_RANK", "0")))
+        trk.track_dev(d_in, T, ny, nx, thr, op, w, 0.0, 0, wl["twosided"], d_out)
+        out["config"]["coverage"] = trk.checksum_i32(d_out, px, 0)[1] / float(px)
     trk.free(d_in)
     trk.free(d_out)
     trk.close()

@@ -211,7 +211,7 @@ struct ctk_handle {
     DevBuf chunk_vals;                             // run values in the chunk order of k_relabel_v4
     // fused one-call path (ctk_seam_dev.hip): clusters of candidate labels, cluster root per group record; the pass runs without a
     // host hand-off and is validated from a device-written block of scalars after its only synchronisation
-    DevBuf sd_parent, sd_tmin, sd_tmax, sd_root, sd_nops, sd_lbox, rv_pstate, ci_bsum;
+    DevBuf sd_parent, sd_tmin, sd_tmax, sd_root, sd_nops, sd_lbox, rv_pstate, ci_bsum, scan_bsum;
     uint32_t *h_amail = nullptr;                   // pinned: AsyncMail scalars
     uint32_t op_cap_hint = 4096;                   // operation slots of the next fused pass (grows with what the passes needed)
     uint32_t nd_hint = 4096;                       // dense candidate labels of the last pass: grid of k_seam_driver
@@ -507,7 +507,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
                       &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
                       &h->sh_mask_next, &h->sh_send, &h->sh_recv, &h->sh_prev, &h->sh_elist, &h->sh_ovr_slot, &h->sh_ovr_val,
-                      &h->sh_amb_list, &h->sh_counts, &h->sh_cl_shared, &h->sh_cl_sent, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_root, &h->sd_nops, &h->sd_lbox, &h->rv_pstate, &h->ci_bsum};
+                      &h->sh_amb_list, &h->sh_counts, &h->sh_cl_shared, &h->sh_cl_sent, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_root, &h->sd_nops, &h->sd_lbox, &h->rv_pstate, &h->ci_bsum, &h->scan_bsum};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->base ? b->base : b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -712,6 +712,22 @@ static int stream_in(ctk_handle *h, bool f64, int64_t T, int ny, int nx, const s
 static int stream_out(ctk_handle *h, int persistence, const int32_t *chunk_vals);
 
 static bool async_wanted(ctk_handle *h);
+// exclusive scan of n uint32 items into out[0 .. n] (out[n] = the total): one workgroup for short shards, block sums + one workgroup
+// per 1024 items for long ones (k_scan_blocks)
+static int launch_scan_u32(ctk_handle *h, const uint32_t *in, int64_t n, uint32_t *out, uint32_t *mail = nullptr, uint32_t stamp = 0)
+{
+    hipStream_t s = h->stream;
+    uint32_t *ovf = (uint32_t *)h->counters.p + CTK_CNT_OVERFLOW;
+    if (n <= 16 * CTK_SCAN_BLOCK) { k_scan_u32<<<1, 1024, 0, s>>>(in, n, out, ovf, mail, nullptr, stamp); return CTK_OK; }
+    const int nb = (int)((n + CTK_SCAN_BLOCK - 1) / CTK_SCAN_BLOCK);
+    CTKCHK(ensure(h, h->scan_bsum, (size_t)nb * 12));
+    uint64_t *bsum = (uint64_t *)h->scan_bsum.p;
+    uint32_t *bmax = (uint32_t *)(bsum + nb);
+    k_scan_blocks_sum<<<nb, CTK_SCAN_BLOCK, 0, s>>>(in, n, bsum, bmax);
+    k_scan_blocks<<<nb, CTK_SCAN_BLOCK, 0, s>>>(in, n, out, ovf, bsum, bmax, mail, stamp);
+    return CTK_OK;
+}
+
 static int threshold_rows(int ny, int nx, int64_t T)
 {
     (void)nx; (void)T;
@@ -810,7 +826,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     if (h->pass_no <= 1 && ctk_env().print_ptrs)                     // (placement experiments, tools/thr_handle_probe.py)
         fprintf(stderr, "PTRS in %p mask %p thr32 %p counters %p wstart %p rowstart %p\n", anom_dev, h->mask.p, h->thr32.p, h->counters.p, h->wstart.p, h->rowstart.p);
     // (the device counters are zeroed by the first threshold launch of the pass; k_rowcount writes every tcount[t])
-    if (T == 0) HIPCHK(hipMemsetAsync(h->counters.p, 0, CTK_CNT_N * 4, s));
+    if (T == 0) HIPCHK(hipMemsetAsync(h->counters.p, 0, CTK_CNT_ZEROED * 4, s));
     if (T > 0) {
         if (!same_thr) { HIPCHK(hipMemcpyAsync(h->thr32.p, thr32, (size_t)T * (f64 ? 8 : 4), hipMemcpyHostToDevice, s)); h->c_thr_valid = true; }
     }
@@ -954,8 +970,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         // (71 VGPRs: three 512-thread workgroups per CU, one round for <= 768 planes; 1024 threads ran in two rounds)
         const int rc_threads = (W <= 64 && ny <= RC_ROWS && ny > 256 && T <= 2048) ? 512 : 256;
         if (T > 0) k_rowcount<<<(int)T, rc_threads, 0, s>>>(P<uint64_t>(h->mask), ny, W, P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart), P<uint32_t>(h->tcount));
-        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW, h->h_mail1,
-                                      nullptr, scan_stamp);
+        CTKCHK(launch_scan_u32(h, P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), h->h_mail1, scan_stamp));
         HIPCHK(hipGetLastError());
     }
     // 2-D labelling.  The variants take disjoint sets of timesteps (by run count; nruns == 0 goes to the small one) and
@@ -1117,7 +1132,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         h->fz_init = true;
     } else if (!defer_compact) {
         Timer tm(h, CTK_K_SCAN);
-        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->ncomp), T, CPX(h), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+        CTKCHK(launch_scan_u32(h, P<uint32_t>(h->ncomp), T, CPX(h)));
         HIPCHK(hipGetLastError());
         if (T > 0) {
             k_compact_comps<<<(int)T, 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep),
@@ -1282,7 +1297,7 @@ static int build_tables_blob(ctk_handle *h, bool to_device, const void **blob, s
     uint32_t *hc = (uint32_t *)h->h_small + (h->T + 2);                       // after the run_base copy
     uint32_t cnt[CTK_CNT_N], ctot = 0, stot = 0;
     // seam rows: row-indexed scratch -> dense (t, y) order
-    k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->seam_cnt), h->T, P<uint32_t>(h->seam_off), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+    CTKCHK(launch_scan_u32(h, P<uint32_t>(h->seam_cnt), h->T, P<uint32_t>(h->seam_off)));
     HIPCHK(hipGetLastError());
     for (int attempt = 0;; attempt++) {
         HIPCHK(hipMemcpyAsync(hc, h->counters.p, CTK_CNT_N * 4, hipMemcpyDeviceToHost, s));
@@ -1613,7 +1628,7 @@ static int device_resolve(ctk_handle *h, const ResolveIn &in, double overlap, in
             k_rs_cand_groups<<<(int)((T + FZ_TW - 1) / FZ_TW), 64 * FZ_TW, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), P<uint8_t>(h->rv_mark),
                                                    h->ny, 0, P<uint32_t>(h->rv_cand_cnt), P<CtkCand>(h->rv_cand_scratch));
         }
-        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_cand_cnt), T, P<uint32_t>(h->rv_cand_off), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+        CTKCHK(launch_scan_u32(h, P<uint32_t>(h->rv_cand_cnt), T, P<uint32_t>(h->rv_cand_off)));
         k_compact_cands<<<(int)std::max<int64_t>(T, 1), 64, 0, s>>>(r, P<CtkCand>(h->rv_cand_scratch), P<uint32_t>(h->rv_cand_cnt), P<uint32_t>(h->rv_cand_off),
                                                                     h->ny, P<CtkCand>(h->rv_cand), P<uint32_t>(h->rv_boff) + nsb, it_done - ROUND, ROUND, mail);
         HIPCHK(hipGetLastError());
@@ -1836,7 +1851,10 @@ static int relabel_rows(const ctk_handle *h)
     //   480 steps: 2 rows 0.98 | 3: 1.06 | 6: 1.10        1000 steps: 2 rows 1.53 | 3: 1.03 | 4: 1.04 | 6: 1.08
     //   2000 steps: 3 rows 1.37 | 4: 1.31 | 6: 1.02 | 8: 1.12 | 12: 1.10        14 600 steps: 6 rows 1.03 | 8: 1.07 | 9: 1.09
     // i.e. the smallest chunk that keeps the launch at or below ~250 000 workgroups, and not more than ~2300 stores (6 rows).
-    const int rb_max = std::min(h->ny, std::max(rb, std::min(64, 2304 / n4r)));
+    // Narrow rows (192 x 288, configs[4]: 72 stores per row), 438 000 steps, ms per launch: 32 rows 21.6 | 48: 20.2 | 64: 18.9 | 96: 18.5 | 192: 22.8
+    // (tools/cesm_relabel_sweep.py) -- the cap of ~2300 stores was found on 1440-wide rows (360 stores each); up to ~6900 where a row is short.
+    const int store_cap = n4r >= 256 ? 2304 : 6912;
+    const int rb_max = std::min(h->ny, std::max(rb, std::min(96, store_cap / n4r)));
     while (rb < rb_max && h->T * ((h->ny + rb - 1) / rb) > 250000) rb++;
     while (rb < h->ny && h->T * ((h->ny + rb - 1) / rb) >= (1 << 24)) rb++;
     if (ctk_env().relabel_rows > 0) rb = std::min(h->ny, ctk_env().relabel_rows);

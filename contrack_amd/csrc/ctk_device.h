@@ -14,6 +14,12 @@
                                   host-driven path (CTK_POISON_* bits, ctk_seam_dev.hip) */
 #define CTK_CNT_NOPS       9   /* fused one-call path: relabel operations recorded by k_seam_driver */
 #define CTK_CNT_N          16
+/* behind the mailed counters, zeroed with them at the start of a pass: sums over the timesteps that k_count_alive's workgroups add up
+ * together (candidate records, operations, pair records: the fused pass' mail) -- one workgroup summing 438 000 timesteps took 1.5 ms */
+#define CTK_CNT_SUM_NC     16
+#define CTK_CNT_SUM_NOPS   17
+#define CTK_CNT_SUM_NP     18
+#define CTK_CNT_ZEROED     24
 /* "a background value was written" (the + 1 of len(np.unique(flag)), contrack.py:793) is recorded by the write kernels in one of
  * CTK_ZF_SLOTS words, 64 bytes apart, picked by the workgroup index -- behind the counters, in the same buffer.  One word for all
  * workgroups was an atomicOr on ONE address from every workgroup of eight XCDs (each XCD's L2 keeps showing its stale zero, so the

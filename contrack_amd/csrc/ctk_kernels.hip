@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_threshold_v4(const float *__restrict__ 
                                                       int ny, int nx, int W, uint64_t *__restrict__ mask, int rb,
                                                       uint32_t *__restrict__ zero_counters /* the pass' device counters start at zero (or nullptr) */)
 {
-    if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_N) zero_counters[threadIdx.x] = 0u;
+    if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_ZEROED) zero_counters[threadIdx.x] = 0u;
     const int nchunk = (ny + rb - 1) / rb;
     const int t = (int)(blockIdx.x / (unsigned)nchunk), y0 = (int)(blockIdx.x - (unsigned)t * nchunk) * rb, tid = (int)threadIdx.x;
     const int rows = min(rb, ny - y0);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_threshold_v7(const float *__restrict__ 
                                                       int ny, int nx, int W, uint64_t *__restrict__ mask, int rb,
                                                       uint32_t *__restrict__ zero_counters, int xcd, int nostore)
 {
-    if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_N) zero_counters[threadIdx.x] = 0u;
+    if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_ZEROED) zero_counters[threadIdx.x] = 0u;
     const int nchunk = (ny + rb - 1) / rb;
     const unsigned bid = xcd_chunk(blockIdx.x, gridDim.x, xcd);
     const int t = (int)(bid / (unsigned)nchunk), y0 = (int)(bid - (unsigned)t * nchunk) * rb, tid = (int)threadIdx.x;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_threshold_v6(const float *__restrict__ 
                                                       uint32_t *__restrict__ zero_counters)
 {
     static_assert(U == 8, "the remainder switch below lists 1..7");
-    if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_N) zero_counters[threadIdx.x] = 0u;
+    if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_ZEROED) zero_counters[threadIdx.x] = 0u;
     const int lane = (int)(threadIdx.x & 63);
     // (the wave's index through readfirstlane: the compiler then knows that everything derived from it is wave-uniform and keeps
     // rows, words and pointers in scalar registers)
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_threshold(const TIN *__restrict__ anom,
                                                    int64_t nrows, int ny, int nx, int W, uint64_t *__restrict__ mask,
                                                    uint32_t *__restrict__ zero_counters)
 {
-    if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_N) zero_counters[threadIdx.x] = 0u;
+    if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_ZEROED) zero_counters[threadIdx.x] = 0u;
     const int lane = lane_id();
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -563,6 +563,68 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ 
             uint32_t m = 0;
             for (int i = 0; i < 16; i++) m = max(m, wmax[i]);
             mail[0] = (uint32_t)run; mail[1] = m; mail[2] = run > 0xffffffffull ? CTK_OVF_RUNS : 0u; mail[3] = n > 0 ? in[n - 1] : 0u;
+            if (stamp) { __threadfence_system(); __hip_atomic_store(&mail[4], stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        }
+    }
+}
+
+// Long shards (438 000 timesteps: the one-workgroup scan above takes 0.87 ms, each thread walking 428 items twice, uncoalesced): block
+// sums and maxima first (k_scan_blocks_sum), then every workgroup scans its 1024 items behind the sum of the blocks in front of it.
+// The mail (total, largest item, overflow, last item, stamp) is written by the workgroup of the last block, from the block sums alone.
+#define CTK_SCAN_BLOCK 1024
+__global__ __launch_bounds__(CTK_SCAN_BLOCK) void k_scan_blocks_sum(const uint32_t *__restrict__ in, int64_t n, uint64_t *__restrict__ bsum, uint32_t *__restrict__ bmax)
+{
+    __shared__ uint64_t ws[CTK_SCAN_BLOCK / 64];
+    __shared__ uint32_t wm[CTK_SCAN_BLOCK / 64];
+    const int64_t i = (int64_t)blockIdx.x * CTK_SCAN_BLOCK + threadIdx.x;
+    const uint32_t v = i < n ? in[i] : 0u;
+    uint64_t s = v;
+    uint32_t m = v;
+    for (int o = 32; o > 0; o >>= 1) { s += (uint64_t)__shfl_xor((unsigned long long)s, o); m = max(m, (uint32_t)__shfl_xor((int)m, o)); }
+    if (lane_id() == 0) { ws[threadIdx.x >> 6] = s; wm[threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0; uint32_t mm = 0;
+        for (int k = 0; k < CTK_SCAN_BLOCK / 64; k++) { t += ws[k]; mm = max(mm, wm[k]); }
+        bsum[blockIdx.x] = t; bmax[blockIdx.x] = mm;
+    }
+}
+__global__ __launch_bounds__(CTK_SCAN_BLOCK) void k_scan_blocks(const uint32_t *__restrict__ in, int64_t n, uint32_t *__restrict__ out, uint32_t *ovf,
+                                                                const uint64_t *__restrict__ bsum, const uint32_t *__restrict__ bmax, uint32_t *mail, uint32_t stamp)
+{
+    __shared__ uint64_t ws[CTK_SCAN_BLOCK / 64];
+    __shared__ uint32_t wm[CTK_SCAN_BLOCK / 64];
+    __shared__ uint64_t sbase;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+    // sum (and, in the last workgroup, maximum) over the blocks in front
+    uint64_t s = 0;
+    uint32_t m = 0;
+    for (int k = tid; k < b; k += CTK_SCAN_BLOCK) s += bsum[k];
+    if (b == nb - 1 && mail) for (int k = tid; k < nb; k += CTK_SCAN_BLOCK) m = max(m, bmax[k]);
+    for (int o = 32; o > 0; o >>= 1) { s += (uint64_t)__shfl_xor((unsigned long long)s, o); m = max(m, (uint32_t)__shfl_xor((int)m, o)); }
+    if (lane == 0) { ws[wv] = s; wm[wv] = m; }
+    __syncthreads();
+    if (tid == 0) { uint64_t t = 0; for (int k = 0; k < CTK_SCAN_BLOCK / 64; k++) t += ws[k]; sbase = t; }
+    __syncthreads();
+    const uint64_t base = sbase;
+    uint32_t mall = 0;
+    for (int k = 0; k < CTK_SCAN_BLOCK / 64; k++) mall = max(mall, wm[k]);
+    __syncthreads();
+    const int64_t i = (int64_t)b * CTK_SCAN_BLOCK + tid;
+    const uint32_t v = i < n ? in[i] : 0u;
+    const uint64_t inc = wave_incl_scan_u64((uint64_t)v);
+    if (lane == WAVE - 1) ws[wv] = inc;
+    __syncthreads();
+    uint64_t run = base + inc - v;
+    for (int k = 0; k < wv; k++) run += ws[k];
+    if (i < n) out[i] = (uint32_t)run;
+    if (b == nb - 1 && i == n - 1) {
+        const uint64_t total = run + v;
+        out[n] = (uint32_t)total;
+        if (total > 0xffffffffull) atomicOr(ovf, CTK_OVF_RUNS);
+        if (mail) {
+            mail[0] = (uint32_t)total; mail[1] = mall; mail[2] = total > 0xffffffffull ? CTK_OVF_RUNS : 0u; mail[3] = v;
             if (stamp) { __threadfence_system(); __hip_atomic_store(&mail[4], stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
         }
     }
@@ -1876,6 +1938,16 @@ __global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__
     }
     uint32_t s = wave_sum_u32(v);
     if (lane_id() == 0 && s) atomicAdd(&counters[CTK_CNT_ALIVE], s);
+    if (am.scal) {                                          // the mail's sums over the timesteps: every workgroup its share
+        uint32_t nc = 0, no = 0, np = 0;
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < am.T; t += (int64_t)gridDim.x * blockDim.x) { nc += am.rec_cnt[t]; no += am.t_nops[t]; np += am.pair_cnt[t]; }
+        nc = wave_sum_u32(nc); no = wave_sum_u32(no); np = wave_sum_u32(np);
+        if (lane_id() == 0) {
+            if (nc) atomicAdd(&counters[CTK_CNT_SUM_NC], nc);
+            if (no) atomicAdd(&counters[CTK_CNT_SUM_NOPS], no);
+            if (np) atomicAdd(&counters[CTK_CNT_SUM_NP], np);
+        }
+    }
     // the last workgroup to finish publishes the results in pinned host memory (no copy command)
     __shared__ bool last;
     __threadfence();
@@ -1896,14 +1968,10 @@ __global__ __launch_bounds__(256) void k_count_alive(const int32_t *__restrict__
         }
         __syncthreads();
     }
-    if (last && am.scal) {
-        uint32_t nc = 0, no = 0, np = 0;
-        if (threadIdx.x < 64) {
-            for (int64_t t = threadIdx.x; t < am.T; t += 64) { nc += am.rec_cnt[t]; no += am.t_nops[t]; np += am.pair_cnt[t]; }
-            nc = wave_sum_u32(nc); no = wave_sum_u32(no); np = wave_sum_u32(np);
-        }
-        async_mail_write(am, counters, nc, no, np);
-    }
+    if (last && am.scal)
+        async_mail_write(am, counters, __hip_atomic_load(&counters[CTK_CNT_SUM_NC], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                         __hip_atomic_load(&counters[CTK_CNT_SUM_NOPS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                         __hip_atomic_load(&counters[CTK_CNT_SUM_NP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
 // the same in ONE workgroup (up to a few hundred thousand ids): no atomics, no ticket

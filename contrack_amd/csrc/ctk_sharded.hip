@@ -1318,7 +1318,7 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
         k_rs_cand_mark<<<(int)T, 256, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, ny, P<uint8_t>(h->rv_mark), P<int2>(h->rv_seam_res));
         k_rs_cand_groups<<<(int)((T + FZ_TW - 1) / FZ_TW), 64 * FZ_TW, 0, s>>>(r, in.seams, in.seam_cnt, in.seam_off, P<int2>(h->rv_seam_res), P<uint8_t>(h->rv_mark), ny, t_begin,
                                                P<uint32_t>(h->rv_cand_cnt), P<CtkCand>(h->rv_cand_scratch));
-        k_scan_u32<<<1, 1024, 0, s>>>(P<uint32_t>(h->rv_cand_cnt), T, P<uint32_t>(h->rv_cand_off), P<uint32_t>(h->counters) + CTK_CNT_OVERFLOW);
+        CTKCHK(launch_scan_u32(h, P<uint32_t>(h->rv_cand_cnt), T, P<uint32_t>(h->rv_cand_off)));
         k_compact_cands<<<(int)T, 64, 0, s>>>(r, P<CtkCand>(h->rv_cand_scratch), P<uint32_t>(h->rv_cand_cnt), P<uint32_t>(h->rv_cand_off), ny,
                                               P<CtkCand>(h->rv_cand), P<uint32_t>(h->rv_boff) + nsb, 0, 0, mail);
         HIPCHK(hipGetLastError());
