@@ -3153,7 +3153,7 @@ extern "C" int ctk_lifecycle_exact(ctk_handle *h, const int64_t *row_idx, int64_
     CTKCHK(ensure(h, h->lc_out, (size_t)n * sizeof(CtkLifeExact)));
     HIPCHK(hipMemcpy(h->lc_ekeys.p, keys.data(), (size_t)n * sizeof(CtkLifeKey), hipMemcpyHostToDevice));
     uint32_t *d_counts = (uint32_t *)h->lc_out.p;                            // (reused below for the results)
-    k_life_count<<<(unsigned)n, 256, 0, s>>>(h->lc_flag, P<CtkLifeKey>(h->lc_ekeys), h->lc_ny, h->lc_nx, d_counts);
+    k_life_count<<<(unsigned)n, 1024, 0, s>>>(h->lc_flag, P<CtkLifeKey>(h->lc_ekeys), h->lc_ny, h->lc_nx, d_counts);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> counts((size_t)n);
     HIPCHK(hipMemcpyAsync(counts.data(), d_counts, (size_t)n * 4, hipMemcpyDeviceToHost, s));
@@ -3167,6 +3167,9 @@ extern "C" int ctk_lifecycle_exact(ctk_handle *h, const int64_t *row_idx, int64_
         if (yb < ya) return ctk_set_error(CTK_E_INTERNAL, "ctk_lifecycle_exact: row %lld has no row extent", (long long)row_idx[i]);
         offs[(size_t)(n + i)] = rtotal; rtotal += 3 * (uint64_t)(yb - ya + 1);
     }
+    uint32_t max_count = 0;
+    for (int64_t i = 0; i < n; ++i) max_count = std::max(max_count, counts[(size_t)i]);
+    const int lx_threads = max_count > 8192 ? 1024 : 256;      // (large contours: sixteen waves share the row scans)
     const size_t px = (size_t)std::max<uint64_t>(total, 1) * 8;
     CTKCHK(ensure(h, h->lc_sw, 5 * px));                                      // sw | sp | sq | sqy | sqx
     CTKCHK(ensure(h, h->lc_sp, (size_t)std::max<uint64_t>(rtotal, 1) * 4));   // the row tables
@@ -3174,11 +3177,11 @@ extern "C" int ctk_lifecycle_exact(ctk_handle *h, const int64_t *row_idx, int64_
     double *d_sw = P<double>(h->lc_sw);
     const size_t st = px / 8;
     if (h->lc_f64)
-        k_life_exact<double><<<(unsigned)n, 256, 0, s>>>(h->lc_flag, (const double *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),
+        k_life_exact<double><<<(unsigned)n, lx_threads, 0, s>>>(h->lc_flag, (const double *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),
                                                          P<uint64_t>(h->lc_offs) + n, h->lc_ny, h->lc_nx, d_sw, d_sw + st, d_sw + 2 * st, d_sw + 3 * st, d_sw + 4 * st,
                                                          P<uint32_t>(h->lc_sp), P<CtkLifeExact>(h->lc_out));
     else
-        k_life_exact<float><<<(unsigned)n, 256, 0, s>>>(h->lc_flag, (const float *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),
+        k_life_exact<float><<<(unsigned)n, lx_threads, 0, s>>>(h->lc_flag, (const float *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),
                                                         P<uint64_t>(h->lc_offs) + n, h->lc_ny, h->lc_nx, d_sw, d_sw + st, d_sw + 2 * st, d_sw + 3 * st, d_sw + 4 * st,
                                                         P<uint32_t>(h->lc_sp), P<CtkLifeExact>(h->lc_out));
     HIPCHK(hipGetLastError());

@@ -767,34 +767,46 @@ __device__ inline double np_walk(uint32_t cn, Leaf leaf, NpFrame *f)
     }
     return val;
 }
-// The sum over a long list by a workgroup of 256: thread 0 lists the leaves of a block of 8192, the threads sum one leaf each, thread 0
+// The sum over a long list by (the first 256 threads of) a workgroup: thread 0 lists the leaves of a block of 8192, the threads sum one leaf each, thread 0
 // combines them in the tree's order.  lo / ln: LDS scratch for 128 leaves.
 // Two such sums over lists of the same length at once (k_life_exact: the area and the weighted sum of one contour): the tree, and
 // so the list of leaves, depends on the length only -- it is listed once per chunk LENGTH (every chunk but the last is 8192 long),
 // the leaves of both lists are summed side by side (threads 0..127 / 128..255) and combined by two waves at the same time.
 // lv: 256 doubles, frames: 2 x 16.  Results valid in thread 0 (ra) and thread 64 (rb).
-__device__ inline void wg_np_sum2(const double *a, const double *b, size_t n, uint32_t *lo, uint32_t *ln, double *lv, int *nleaf, NpFrame *frames, double &ra, double &rb)
+// Round 5: a workgroup of 1024 threads takes FOUR blocks per round (groups of 256 threads, each with its own leaf list, leaf sums and
+// the two threads that walk the trees); the block sums are added in the order of the blocks by thread 0 / thread 64, as numpy's
+// buffered reduction adds its 8192-element buffers one after the other.
+// lo / ln: [G][128], lv: [G][256], nleaf: [G], frames: [G][32], cres: [2][4]   (G = blockDim / 256 <= 4)
+__device__ inline void wg_np_sum2(const double *a, const double *b, size_t n, uint32_t *lo_all, uint32_t *ln_all, double *lv_all, int *nleaf_all, NpFrame *frames_all,
+                                  double *cres, double &ra, double &rb)
 {
     double acc = 0.0;
-    uint32_t listed = 0;
-    const int tid = (int)threadIdx.x;
-    for (size_t c0 = 0; c0 < n; c0 += 8192) {
-        const uint32_t cn = (uint32_t)(n - c0 < 8192 ? n - c0 : 8192);
-        if (cn != listed) {                                                  // (uniform)
-            if (tid == 0) {
+    const int tid = (int)threadIdx.x, G = (int)(blockDim.x >> 8) > 0 ? (int)(blockDim.x >> 8) : 1, grp = tid >> 8, t8 = tid & 255;
+    uint32_t *lo = lo_all + grp * 128, *ln = ln_all + grp * 128;
+    double *lv = lv_all + grp * 256;
+    NpFrame *frames = frames_all + grp * 32;
+    uint32_t listed = 0;                                                     // (of this thread's group; uniform within the group)
+    for (size_t r0 = 0; r0 < n; r0 += (size_t)8192 * G) {
+        const size_t c0 = r0 + (size_t)8192 * grp;
+        const uint32_t cn = c0 < n ? (uint32_t)(n - c0 < 8192 ? n - c0 : 8192) : 0u;
+        if (cn && cn != listed) {
+            if (t8 == 0) {
                 int k = 0;
                 (void)np_walk(cn, [&](uint32_t off, uint32_t m) { lo[k] = off; ln[k] = m; k++; return 0.0; }, frames);
-                *nleaf = k;
+                nleaf_all[grp] = k;
             }
             listed = cn;
         }
         __syncthreads();
-        const int nl = *nleaf;
-        if (tid < nl) lv[tid] = dev_np_leaf(a + c0 + lo[tid], ln[tid]);
-        else if (tid >= 128 && tid - 128 < nl) lv[tid] = dev_np_leaf(b + c0 + lo[tid - 128], ln[tid - 128]);
+        const int nl = cn ? nleaf_all[grp] : 0;
+        if (t8 < nl) lv[t8] = dev_np_leaf(a + c0 + lo[t8], ln[t8]);
+        else if (t8 >= 128 && t8 - 128 < nl) lv[t8] = dev_np_leaf(b + c0 + lo[t8 - 128], ln[t8 - 128]);
         __syncthreads();
-        if (tid == 0) { int k = 0; acc += np_walk(cn, [&](uint32_t, uint32_t) { return lv[k++]; }, frames); }
-        else if (tid == 64) { int k = 128; acc += np_walk(cn, [&](uint32_t, uint32_t) { return lv[k++]; }, frames + 16); }
+        if (cn && t8 == 0) { int k = 0; cres[grp] = np_walk(cn, [&](uint32_t, uint32_t) { return lv[k++]; }, frames); }
+        else if (cn && t8 == 64) { int k = 128; cres[4 + grp] = np_walk(cn, [&](uint32_t, uint32_t) { return lv[k++]; }, frames + 16); }
+        __syncthreads();
+        if (tid == 0) { for (int g = 0; g < G; g++) if (r0 + (size_t)8192 * g < n) acc += cres[g]; }
+        else if (tid == 64) { for (int g = 0; g < G; g++) if (r0 + (size_t)8192 * g < n) acc += cres[4 + g]; }
         __syncthreads();
     }
     if (tid == 0) ra = acc;
@@ -806,58 +818,63 @@ struct CtkLifeKey {
 };
 
 // members of every listed (time step, id)
-__global__ __launch_bounds__(256) void k_life_count(const int32_t *__restrict__ flag, const CtkLifeKey *__restrict__ keys, int ny, int nx, uint32_t *__restrict__ counts)
+__global__ __launch_bounds__(1024) void k_life_count(const int32_t *__restrict__ flag, const CtkLifeKey *__restrict__ keys, int ny, int nx, uint32_t *__restrict__ counts)
 {
-    __shared__ uint32_t part[4];
+    __shared__ uint32_t part[16];
     const CtkLifeKey k = keys[blockIdx.x];
     const uint32_t npx = (uint32_t)ny * (uint32_t)nx;
     const int32_t *fp = flag + (int64_t)k.t * npx;
     uint32_t c = 0;
     const uint32_t pa = ((uint32_t)k.pad & 0xffffu) * (uint32_t)nx, pb = min(npx, (((uint32_t)k.pad >> 16) + 1u) * (uint32_t)nx);
-    for (uint32_t p = pa + threadIdx.x; p < pb; p += 4 * 256) {               // four loads in flight per lane (latency-bound scan)
+    const uint32_t nt = blockDim.x;
+    for (uint32_t p = pa + threadIdx.x; p < pb; p += 4 * nt) {                // four loads in flight per lane (latency-bound scan)
         int32_t v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = (p + u * 256 < pb) ? fp[p + u * 256] : 0;
+        for (int u = 0; u < 4; ++u) v[u] = (p + u * nt < pb) ? fp[p + u * nt] : 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) c += (p + u * 256 < pb && v[u] == k.label) ? 1u : 0u;
+        for (int u = 0; u < 4; ++u) c += (p + u * nt < pb && v[u] == k.label) ? 1u : 0u;
     }
     c = wave_sum_u32(c);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t i = 0; i < (nt >> 6); ++i) t += part[i]; counts[blockIdx.x] = t; }
 }
 
 // One workgroup per listed row.  rowtab (per key, 2 * nrows words): pixels of the id per row -> their offset in the compact
 // lists, and how many of them lie left of the roll edge.  sw / sp: the weights and products in raster order of the plane (what
 // np.sum sees, contrack.py:874-875); sq / sqy / sqx: p, p*y, p*x' in raster order of the ROLLED plane (np.bincount's order inside
 // ndimage.center_of_mass, :886 / :892).
+// Round 5 (one contour of 105 000 pixels at 0.25 deg cost 2.8 ms: row scans 1.2, pairwise sums 0.6, sequential sums 1.3): launched with
+// 1024 threads when a listed row is large -- sixteen waves share the two scans over the rows --, and the sequential sums read their
+// block from LDS two values per load, eight values ahead of the add chain, while ALL threads already hold the next block's values in
+// registers (the global loads travel underneath the chain; two LDS buffers, one barrier per block).
 #define LX_STAGE 1024
 template <typename VT>
-__global__ __launch_bounds__(256) void k_life_exact(const int32_t *__restrict__ flag, const VT *__restrict__ field, const float *__restrict__ wrow,
+__global__ __launch_bounds__(1024) void k_life_exact(const int32_t *__restrict__ flag, const VT *__restrict__ field, const float *__restrict__ wrow,
                                                     const CtkLifeKey *__restrict__ keys, const uint64_t *__restrict__ offs, const uint64_t *__restrict__ roffs,
                                                     int ny, int nx, double *__restrict__ sw, double *__restrict__ sp_, double *__restrict__ sq,
                                                     double *__restrict__ sqy, double *__restrict__ sqx, uint32_t *__restrict__ rowtab,
                                                     CtkLifeExact *__restrict__ out)
 {
     __shared__ uint32_t part[256];
-    __shared__ uint32_t lo[128], ln[128];
-    __shared__ double lv[256];
-    __shared__ int nleaf;
-    __shared__ NpFrame frames[32];
-    __shared__ double stage[3][LX_STAGE];
+    __shared__ uint32_t lo[4 * 128], ln[4 * 128];
+    __shared__ double lv[4 * 256], cres[8];
+    __shared__ int nleaf[4];
+    __shared__ NpFrame frames[4 * 32];
+    __shared__ __attribute__((aligned(16))) double stage[2][3][LX_STAGE];
     __shared__ double res[5];
     const CtkLifeKey k = keys[blockIdx.x];
     const uint32_t npx = (uint32_t)ny * (uint32_t)nx;
     const int32_t *fp = flag + (int64_t)k.t * npx;
     const VT *vp = field + (int64_t)k.t * npx;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)(blockDim.x >> 6), nthr = (int)blockDim.x;
     const int ya = (int)((uint32_t)k.pad & 0xffffu), yb = min(ny - 1, (int)((uint32_t)k.pad >> 16)), nrows = yb - ya + 1;
     const int shift = k.shift > 0 ? k.shift : 0;
     double *gw = sw + offs[blockIdx.x], *gp = sp_ + offs[blockIdx.x], *gq = sq + offs[blockIdx.x], *gqy = sqy + offs[blockIdx.x], *gqx = sqx + offs[blockIdx.x];
     uint32_t *rcnt = rowtab + roffs[blockIdx.x], *rleft = rcnt + nrows, *roff = rleft + nrows;
 
     // A: per row the id's pixels, and those left of the roll edge (one wave per row, round robin)
-    for (int r = wave; r < nrows; r += 4) {
+    for (int r = wave; r < nrows; r += nw) {
         const int32_t *rp = fp + (size_t)(ya + r) * nx;
         uint32_t c = 0, cl = 0;
         for (int x0 = 0; x0 < nx; x0 += 4 * 64) {                            // four loads in flight per lane
@@ -878,19 +895,29 @@ __global__ __launch_bounds__(256) void k_life_exact(const int32_t *__restrict__ 
     // B: exclusive scan of the row counts
     {
         const int per = (nrows + 255) / 256, r0 = tid * per, r1 = min(nrows, r0 + per);
-        uint32_t sum = 0;
-        for (int r = r0; r < r1; ++r) sum += rcnt[r];
-        part[tid] = sum;
+        if (tid < 256) {
+            uint32_t sum = 0;
+            for (int r = r0; r < r1; ++r) sum += rcnt[r];
+            part[tid] = sum;
+        }
         __syncthreads();
         if (tid == 0) { uint32_t run = 0; for (int i = 0; i < 256; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; } }
         __syncthreads();
-        uint32_t run = part[tid];
-        for (int r = r0; r < r1; ++r) { roff[r] = run; run += rcnt[r]; }
+        if (tid < 256) {
+            uint32_t run = part[tid];
+            for (int r = r0; r < r1; ++r) { roff[r] = run; run += rcnt[r]; }
+        }
     }
     __syncthreads();
     const size_t total = (size_t)roff[nrows - 1] + rcnt[nrows - 1];
+#ifdef CTK_PHASE_TIMING
+#define LX_MARK(k) do { if (total > 50000 && tid == 0) g_phase_t[k] = wall_clock64(); } while (0)
+#else
+#define LX_MARK(k) do { } while (0)
+#endif
+    LX_MARK(0);
     // C: the compact lists.  Rolled row = the pixels right of the edge (x >= shift) first, then those left of it.
-    for (int r = wave; r < nrows; r += 4) {
+    for (int r = wave; r < nrows; r += nw) {
         const int y = ya + r;
         const int32_t *rp = fp + (size_t)y * nx;
         const VT *rv = vp + (size_t)y * nx;
@@ -925,22 +952,73 @@ __global__ __launch_bounds__(256) void k_life_exact(const int32_t *__restrict__ 
         }
     }
     __syncthreads();
+    LX_MARK(1);
     // D: np.sum over the raster-order lists
     {
         double area = 0.0, swv = 0.0;
-        wg_np_sum2(gw, gp, total, lo, ln, lv, &nleaf, frames, area, swv);
+        wg_np_sum2(gw, gp, total, lo, ln, lv, nleaf, frames, cres, area, swv);
         if (tid == 0) res[0] = area;
         if (tid == 64) res[1] = swv;
     }
+    LX_MARK(2);
     // E: np.bincount's strictly sequential sums over the rolled lists: blocks staged in LDS, one lane per sum
     double acc = 0.0;
-    for (size_t c0 = 0; c0 < total; c0 += LX_STAGE) {
-        const int cn = (int)min((size_t)LX_STAGE, total - c0);
-        for (int i = tid; i < cn; i += 256) { stage[0][i] = gq[c0 + i]; stage[1][i] = gqy[c0 + i]; stage[2][i] = gqx[c0 + i]; }
+    {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const int per = LX_STAGE / nthr > 0 ? LX_STAGE / nthr : 1;           // values per thread and list of a block (4 at 256 threads, 1 at 1024)
+        double hq[4], hy[4], hx[4];
+        auto fetch = [&](size_t c0) {                                        // the block at c0 into registers (zeros behind the end)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t i = c0 + (size_t)u * nthr + tid;
+                const bool in = u < per && i < total && (size_t)u * nthr + tid < LX_STAGE;
+                hq[u] = in ? gq[i] : 0.0; hy[u] = in ? gqy[i] : 0.0; hx[u] = in ? gqx[i] : 0.0;
+            }
+        };
+        auto put = [&](int b) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = u * nthr + tid;
+                if (u < per && i < LX_STAGE) { stage[b][0][i] = hq[u]; stage[b][1][i] = hy[u]; stage[b][2][i] = hx[u]; }
+            }
+        };
+        int cur = 0;
+        if (total > 0) { fetch(0); put(0); }
         __syncthreads();
-        if (lane == 0 && wave < 3) { const double *sv = stage[wave]; for (int i = 0; i < cn; ++i) acc += sv[i]; }
-        __syncthreads();
+        for (size_t c0 = 0; c0 < total; c0 += LX_STAGE) {
+            const int cn = (int)min((size_t)LX_STAGE, total - c0);
+            const bool more = c0 + LX_STAGE < total;
+            if (more) fetch(c0 + LX_STAGE);                                  // (in flight underneath the chain below)
+            if (lane == 0 && wave < 3) {
+                const double *sv = stage[cur][wave];                         // (behind the end of the list: zeros are NOT added -- cn bounds the loop)
+                int i = 0;
+                if (cn >= 8) {
+                    // two register sets, loaded sixteen values ahead in turn.  (With one set and a copy at the end of the iteration hipcc
+                    // merged the two and issued the loads right in front of their use: ~120 cycles of LDS latency per eight adds.  The empty
+                    // asm statements -- the chain's value passes through them -- keep the loads in front of the adds that are meant to cover them.)
+#define LX_LD(o) (*reinterpret_cast<const d2 *>(sv + (o)))
+#define LX_ADD(q0, q1, q2, q3) do { acc += q0.x; acc += q0.y; acc += q1.x; acc += q1.y; acc += q2.x; acc += q2.y; acc += q3.x; acc += q3.y; } while (0)
+                    d2 a0 = LX_LD(0), a1 = LX_LD(2), a2 = LX_LD(4), a3 = LX_LD(6);
+                    for (i = 8; i + 16 <= cn; i += 16) {
+                        const d2 b0 = LX_LD(i), b1 = LX_LD(i + 2), b2 = LX_LD(i + 4), b3 = LX_LD(i + 6);
+                        asm volatile("" : "+v"(acc) : : "memory");
+                        LX_ADD(a0, a1, a2, a3);
+                        a0 = LX_LD(i + 8); a1 = LX_LD(i + 10); a2 = LX_LD(i + 12); a3 = LX_LD(i + 14);
+                        asm volatile("" : "+v"(acc) : : "memory");
+                        LX_ADD(b0, b1, b2, b3);
+                    }
+                    LX_ADD(a0, a1, a2, a3);
+#undef LX_LD
+#undef LX_ADD
+                }
+                for (; i < cn; ++i) acc += sv[i];
+            }
+            if (more) put(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
+    LX_MARK(3);
     if (lane == 0 && wave < 3) res[2 + wave] = acc;
     __syncthreads();
     if (tid == 0) {
