@@ -21,6 +21,8 @@
 #include <atomic>
 #include <thread>
 #include <functional>
+#include <mutex>
+#include <condition_variable>
 #include <string>
 
 int ctk_set_error(int code, const char *fmt, ...);            // ctk_resolve.cpp
@@ -132,8 +134,57 @@ struct BouncePool {
 constexpr int kRleLanes = 16;
 constexpr size_t kRleBuf = (size_t)2 << 20;
 struct RleBlock { int64_t t0, nt; uint32_t r0, nr; };          // timesteps [t0, t0 + nt), runs [r0, r0 + nr) of run_val
+// The lanes' host threads, kept between calls (until round 5 every call started sixteen threads: ~0.45 ms of an 18.5 ms call, and 0.35 ms
+// until the first tables arrived).  run(n, f) lets threads 0 .. n-1 execute f(i) and returns when all are done.
+struct LaneCrew {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    std::function<void(int)> job;
+    uint64_t gen = 0;
+    int want = 0, active = 0;
+    bool stop = false;
+    void loop(int i)
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv_go.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            if (i >= want) continue;
+            std::function<void(int)> f = job;
+            lk.unlock();
+            f(i);
+            lk.lock();
+            if (--active == 0) cv_done.notify_one();
+        }
+    }
+    bool run(int n, const std::function<void(int)> &f)
+    {
+        try { while ((int)th.size() < n) { const int i = (int)th.size(); th.emplace_back([this, i] { loop(i); }); } }
+        catch (...) { if ((int)th.size() == 0) return false; n = std::min(n, (int)th.size()); }
+        {
+            std::lock_guard<std::mutex> g(m);
+            job = f; want = n; active = n; gen++;
+        }
+        cv_go.notify_all();
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return active == 0; });
+        return true;
+    }
+    void shutdown()
+    {
+        { std::lock_guard<std::mutex> g(m); stop = true; }
+        cv_go.notify_all();
+        for (auto &t : th) if (t.joinable()) t.join();
+        th.clear();
+        stop = false;
+    }
+};
 struct RlePool {
     BounceLane lane[kRleLanes];
+    LaneCrew crew;
     bool ready = false;
     size_t cap = 0;                                 // bytes per buffer: kRleBuf, or one timestep's tables if those are larger
     bool init(size_t need)
@@ -515,7 +566,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
     if (h->h_ops) (void)hipHostFree(h->h_ops);
     if (h->h_mail) (void)hipHostFree(h->h_mail);
     if (h->bounce) { h->bounce->destroy(); delete h->bounce; }
-    if (h->rle) { h->rle->destroy(); delete h->rle; }
+    if (h->rle) { h->rle->crew.shutdown(); h->rle->destroy(); delete h->rle; }
     stream_teardown(h);
     if (h->h_mail1) (void)hipHostFree(h->h_mail1);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -2568,11 +2619,14 @@ static int deliver_runs(ctk_handle *h, int persistence, int32_t *flag, int *wrot
         }
         (void)hipStreamSynchronize(L.st);                                             // (nothing of this call is left in flight on an error path)
     };
-    std::vector<std::thread> th;
-    th.reserve((size_t)lanes);
-    for (int i = 0; i < lanes; i++) th.emplace_back(work, i);
     const double tr1 = now_ms();
-    for (auto &t : th) t.join();
+    static const bool fresh_threads = getenv("CTK_RLE_FRESH_THREADS") != nullptr;      // (round 4's form, for comparison)
+    if (fresh_threads) {
+        std::vector<std::thread> th;
+        th.reserve((size_t)lanes);
+        for (int i = 0; i < lanes; i++) th.emplace_back(work, i);
+        for (auto &t : th) t.join();
+    } else if (!h->rle->crew.run(lanes, work)) ok = false;
     if (ctk_env().hosttrace) fprintf(stderr, "runs: %zu blocks on %d lanes | setup %.2f ms, lanes %.2f ms (per lane: waiting %.2f, expanding %.2f)\n", nb, lanes, tr1 - tr_begin, now_ms() - tr1, wait_us / 1e3 / lanes, exp_us / 1e3 / lanes);
     if (!ok) { (void)ctk_set_error(CTK_E_NODEVICE, "result transfer (run tables) failed: %s", hipGetErrorString(hipGetLastError())); return CTK_RLE_UNAVAILABLE; }
     // blocks with complex components: the write kernel, block by block
@@ -2864,7 +2918,7 @@ extern "C" int ctk_release_io(ctk_handle *h)
     for (DevBuf *b : {&h->io_in, &h->io_out, &h->an_out, &h->an_raw}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     h->an_T = -1; h->an_gen++;
     if (h->bounce) { h->bounce->destroy(); delete h->bounce; h->bounce = nullptr; }
-    if (h->rle) { h->rle->destroy(); delete h->rle; h->rle = nullptr; }
+    if (h->rle) { h->rle->crew.shutdown(); h->rle->destroy(); delete h->rle; h->rle = nullptr; }
     stream_teardown(h);
     return CTK_OK;
 }
