@@ -347,6 +347,7 @@ struct ctk_handle {
     int xcd_thr = -1, xcd_rel = -1;               // chunk -> XCD mapping of the two streaming kernels (xcd_chunk); -1: the environment's / default
     int xcd_thr_tuned = -1;                       // (round 4 tuned the XCD tile size of the threshold kernel per placement; no longer: -1)
     bool thr_nostore = false;                     // the threshold kernel without its mask stores: the yardstick of the mask placement check
+    bool thr_probe = false;                       // the launches of that check run under their own kernel name (k_threshold_probe)
     int mask_tries = 0; double mask_ratio = 0.0;  // allocations of the mask that were checked when it was last (re)allocated; kernel time / its time without stores
     int xcd_rel_tuned = -1;                       // the same for the write kernel (tune_relabel), for the shape below
     int64_t rel_tuned_T = -1; int rel_tuned_ny = 0, rel_tuned_nx = 0; const void *rel_tuned_flag = nullptr;
@@ -908,7 +909,9 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
             }
             const int R6 = std::max(1, 64 / W), nchunk_t = (ny + R6 - 1) / R6;
             const int64_t nchunks = nt * nchunk_t;
+            const int thr_xcd = h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr);
             static const bool thr_nostore_env = getenv("CTK_THR_STORE") && atoi(getenv("CTK_THR_STORE")) == 2;      // (probes: the kernel without its stores)
+            const bool thr_probe = h->thr_probe || h->thr_nostore || thr_nostore_env;                       // a launch of the mask placement check: its own kernel name
             static const int64_t g6max = getenv("CTK_THR_GRID") ? atoll(getenv("CTK_THR_GRID")) : 16384;
             const unsigned g6 = (unsigned)std::min<int64_t>((nchunks + 3) / 4, g6max);
 #define LAUNCH_THR(OP)                                                                                                                      \
@@ -918,11 +921,16 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         else if (v4 && thr_variant == 44) k_threshold_v4<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
         else if (v4 && thr_variant == 42) k_threshold_v4<OP, 2><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
         else if (v4 && thr_variant == 4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
-        else if (v4 && u7 == 4) k_threshold_v7<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr), (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
-        else if (v4 && u7 == 5) k_threshold_v7<OP, 5><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr), (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
-        else if (v4 && u7 == 6) k_threshold_v7<OP, 6><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr), (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
-        else if (v4 && u7 == 7) k_threshold_v7<OP, 7><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr), (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
-        else if (v4) k_threshold_v7<OP, 8><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr), (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
+        else if (v4 && u7 == 4 && thr_probe) k_threshold_probe<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd, (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
+        else if (v4 && u7 == 4) k_threshold_v7<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd); \
+        else if (v4 && u7 == 5 && thr_probe) k_threshold_probe<OP, 5><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd, (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
+        else if (v4 && u7 == 5) k_threshold_v7<OP, 5><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd); \
+        else if (v4 && u7 == 6 && thr_probe) k_threshold_probe<OP, 6><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd, (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
+        else if (v4 && u7 == 6) k_threshold_v7<OP, 6><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd); \
+        else if (v4 && u7 == 7 && thr_probe) k_threshold_probe<OP, 7><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd, (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
+        else if (v4 && u7 == 7) k_threshold_v7<OP, 7><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd); \
+        else if (v4 && thr_probe) k_threshold_probe<OP, 8><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd, (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
+        else if (v4) k_threshold_v7<OP, 8><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd); \
         else k_threshold<OP, float><<<g, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, rows, ny, nx, W, mk, zc); \
     } while (0)
             switch (cmp_op) {
@@ -967,6 +975,8 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                 };
                 int rc = CTK_OK;
                 double ro_ms = 0.0, best_ms = 1e30;
+                h->thr_probe = true;
+                struct ProbeOff { ctk_handle *h; ~ProbeOff() { h->thr_probe = false; h->thr_nostore = false; } } probe_off{h};
                 h->thr_nostore = true;                                                  // the yardstick: the same kernel without its stores
                 rc = time_it(&ro_ms);
                 h->thr_nostore = false;

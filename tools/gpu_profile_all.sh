@@ -1,10 +1,11 @@
-# tools/gpu_profile_all.sh <prefix>: rocprofv3 kernel stats + PMC + bench lines of the three large workloads -> profiles/<prefix>_*
+# tools/gpu_profile_all.sh <prefix>: rocprofv3 kernel stats + PMC + bench lines of the four large workloads -> profiles/<prefix>_*
+# (<prefix>_bench_<wl>_traced.json: the line of the very process the kernel stats were taken from; <prefix>_bench_<wl>.json: an untraced run)
 P=${1:-r03a}
-for pair in "era5_1deg_djf30 1deg" "era5_025deg_480 025deg_480" "era5_025deg_10yr 025deg_10yr"; do
+for pair in "era5_1deg_djf30 1deg" "era5_025deg_480 025deg_480" "era5_025deg_10yr 025deg_10yr" "cesm_le_40x30yr cesm_40x30yr"; do
 set -- $pair
 bash tools/profile.sh ${P}_$2 $1 > /dev/null 2>&1
 python tools/summarize_profile.py gpurun_out/${P}_$2 gpurun_out/${P}_$2/sum "$1"
-cp gpurun_out/${P}_$2/sum_kernel_stats.csv gpurun_out/${P}_$2_kernel_stats.csv; cp gpurun_out/${P}_$2/sum_pmc.json gpurun_out/${P}_$2_pmc.json; cp gpurun_out/${P}_$2/sum_pmc.md gpurun_out/${P}_$2_pmc.md
+cp gpurun_out/${P}_$2/traced_bench.json gpurun_out/${P}_bench_$2_traced.json; cp gpurun_out/${P}_$2/sum_kernel_stats.csv gpurun_out/${P}_$2_kernel_stats.csv; cp gpurun_out/${P}_$2/sum_pmc.json gpurun_out/${P}_$2_pmc.json; cp gpurun_out/${P}_$2/sum_pmc.md gpurun_out/${P}_$2_pmc.md
 rm -rf gpurun_out/${P}_$2
 python bench.py --steps 20 --warmup 5 --workload $1 > gpurun_out/${P}_bench_$2.json 2> /dev/null
 done
