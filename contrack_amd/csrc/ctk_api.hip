@@ -951,8 +951,8 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         // Allocations made right after each other usually share a class -- the "bimodal board" of rounds 2-4.  So a freshly allocated
         // mask is checked against the slab: the kernel's time WITHOUT its stores (on the first 4 GB of a larger slab) is the yardstick,
         // and while the kernel with its stores is more than 8.5 % above it, another mask is allocated behind a spacer that is held in
-        // between (1, 4, 8, 8, 8, 8 GB: hipMalloc of these costs 0.02-0.3 ms; one that fails is skipped) -- memory from somewhere else.  Two
-        // launches per measurement, 4 in the usual case (the first mask is fine), at most 14; once per handle and mask size; CTK_MASK_TUNE=0 turns it off.
+        // between (1, 4, 8, 8 GB: hipMalloc of these costs 0.02-0.3 ms; one that fails is skipped) -- memory from somewhere else; then
+        // the arenas below.  Two launches per measurement, 4 in the usual case (the first mask is fine), at most 20; once per handle and mask size; CTK_MASK_TUNE=0 turns it off.
         h->mask_tries = mask_fresh ? 0 : h->mask_tries;
         const bool v7_path = !f64 && (nx % 4 == 0) && (((uintptr_t)anom_dev & 15) == 0);
         if (anom_dev && mask_fresh && h->mask_off_dbg < 0 && ctk_env().mask_tune && v7_path && (size_t)T * ny * nx * 4 >= ((size_t)128 << 20)) {
@@ -983,16 +983,16 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                 DevBuf best = h->mask;
                 if (rc == CTK_OK) rc = time_it(&best_ms);
                 h->mask_tries = 1;
-                static const int max_tries = getenv("CTK_MASK_TRIES") ? atoi(getenv("CTK_MASK_TRIES")) : 6;
+                static const int max_tries = getenv("CTK_MASK_TRIES") ? atoi(getenv("CTK_MASK_TRIES")) : 4;
                 static const double accept = getenv("CTK_MASK_ACCEPT") ? atof(getenv("CTK_MASK_ACCEPT")) : 1.085;
                 std::vector<void *> held;                                               // spacers and rejected masks: freed when the search is over
                 struct FreeHeld { std::vector<void *> &v; ~FreeHeld() { for (void *q : v) (void)hipFree(q); } } free_held{held};
                 for (int k = 0; rc == CTK_OK && k < max_tries && best_ms > accept * ro_ms; k++) {
-                    // (1, 4, 8, 8, 8, 8 GB: a class can hold for many GB -- on one box five candidates within 7.5 GB all shared the slab's)
+                    // (1, 4, 8, 8 GB: a class can hold for many GB -- on one box five candidates within 7.5 GB all shared the slab's)
                     static const std::vector<int> sched = [] {
                         std::vector<int> v;
                         if (const char *e = getenv("CTK_MASK_SPACERS_GB")) { for (const char *q = e; *q;) { v.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; } }
-                        else v = {1, 4, 8, 8, 8, 8};
+                        else v = {1, 4, 8, 8};
                         return v;
                     }();
                     for (int gb = k < (int)sched.size() ? sched[(size_t)k] : 8; gb > 0; gb -= 8) {      // (in pieces of <= 8 GB: hipMalloc of 16 GB takes 0.5-1.4 s)
@@ -1009,6 +1009,34 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                     if (rc == CTK_OK && ms < best_ms) { held.push_back(best.base ? best.base : best.p); best = nb; best_ms = ms; }
                     else held.push_back(nb.p);
                     h->mask = best;
+                }
+                h->mask = best;
+                // Last resort -- every small candidate in the slab's class (the first handle of a process on some boxes: thirteen of
+                // thirteen over 230 GB): the mask at the head / the tail of up to two 6 GB allocations, whose buddy blocks come from
+                // other places than small allocations do (tools/mask_check_probe.sh: found memory of the other class for 8 of 21 handles whose
+                // small candidates had all failed).  A hit keeps its whole arena alive for as long as the mask lives -- so only while the
+                // device stays at least a third empty behind it (CTK_MASK_ARENA_GB=0: never; n: arenas of n GB).
+                static const int arena_gb = getenv("CTK_MASK_ARENA_GB") ? atoi(getenv("CTK_MASK_ARENA_GB")) : 6;
+                for (int a = 0; rc == CTK_OK && arena_gb > 0 && a < 2 && best_ms > accept * ro_ms && mbytes + mbytes / 8 <= (((size_t)arena_gb << 30) * 2) / 5; a++) {
+                    size_t mem_free = 0, mem_total = 0;
+                    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || mem_free < ((size_t)arena_gb << 30) + mem_total / 3) { (void)hipGetLastError(); break; }
+                    void *arena = nullptr;
+                    if (hipMalloc(&arena, (size_t)arena_gb << 30) != hipSuccess) { (void)hipGetLastError(); break; }
+                    bool kept = false;
+                    for (int k = 0; k < 2 && rc == CTK_OK && best_ms > accept * ro_ms; k++) {
+                        const size_t off = k == 0 ? 0 : (((size_t)arena_gb << 30) - (((size_t)mbytes + mbytes / 8 + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1)));      // head and tail: its two largest buddy blocks
+                        DevBuf nb; nb.base = arena; nb.p = (char *)arena + off; nb.cap = mbytes + mbytes / 8;
+                        h->mask = nb;
+                        double ms = 0.0;
+                        rc = time_it(&ms);
+                        h->mask_tries++;
+                        if (rc == CTK_OK && ms < best_ms) {
+                            if (!(kept && best.base == arena)) held.push_back(best.base ? best.base : best.p);
+                            best = nb; best_ms = ms; kept = true;
+                        }
+                        h->mask = best;
+                    }
+                    if (!kept) held.push_back(arena);
                 }
                 h->mask = best;
                 h->mask_ratio = ro_ms > 0 ? best_ms / ro_ms : 0.0;
