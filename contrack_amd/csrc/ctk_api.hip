@@ -2003,9 +2003,20 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
         // threads per workgroup: 256; wider (experiment, CTK_RELABEL_THREADS / ctk_debug_set_relabel_threads) gives a tall chunk fewer
         // stores per lane at the same number of workgroups -- the LDS budget grows with the waves (same occupancy in waves per CU)
         const int th = h->relabel_threads > 0 ? h->relabel_threads : (ctk_env().relabel_threads > 0 ? ctk_env().relabel_threads : 256);
-        const size_t budget = (size_t)20 * 1024 * (size_t)th / 256;
-        int sub = rb;
-        while (sub > 1 && tab5 + (size_t)sub * h->nx * 4 > budget) sub--;
+        // 20 KB = eight workgroups of 256 threads per CU.  A chunk that needs three or more images at that size gets 24 or 28 KB (six / five
+        // workgroups per CU) if that brings it down to two: 14 600 x 721 x 1440 in 6-row chunks (34 KB of values) 11.46 -> 10.55 ms,
+        // 2000 steps 1.55 -> 1.47; 32 KB: 14.1 ms (four per CU); 438 000 x 192 x 288 in 96-row chunks: 9 or 6 images, no difference
+        // (tools/cesm_relabel_sweep.py, CTK_RELABEL_LDS_KB)
+        static const int lds_kb_env = getenv("CTK_RELABEL_LDS_KB") ? atoi(getenv("CTK_RELABEL_LDS_KB")) : 0;
+        auto rows_per_image = [&](size_t bud) { int q = rb; while (q > 1 && tab5 + (size_t)q * h->nx * 4 > bud) q--; return q; };
+        size_t budget = (size_t)(lds_kb_env > 0 ? lds_kb_env : 20) * 1024 * (size_t)th / 256;
+        int sub = rows_per_image(budget);
+        if (lds_kb_env <= 0 && (rb + sub - 1) / sub > 2)
+            for (int kb = 24; kb <= 28; kb += 4) {
+                const size_t b2 = (size_t)kb * 1024 * (size_t)th / 256;
+                const int s2 = rows_per_image(b2);
+                if ((rb + s2 - 1) / s2 <= 2) { budget = b2; sub = s2; break; }
+            }
         const size_t lds5 = tab5 + (size_t)sub * h->nx * 4;
         if (lds5 <= budget && !ctk_env().relabel_v4) {
             if (th == 1024) k_relabel_v5<1024><<<grid, 1024, lds5, h->stream>>>(a, rb, rv5, sub);

@@ -1,6 +1,7 @@
 """configs[4] grid (192 x 288), T steps (default 438 000): time of the write kernel against rows / threads per workgroup
 (ctk_debug_set_relabel), and of every kernel group at the default.  gpurun: python tools/cesm_relabel_sweep.py [T]"""
 import ctypes as C
+import os
 import sys
 
 import numpy as np
@@ -10,7 +11,10 @@ import bench                                           # noqa: E402
 from contrack_amd import _native                      # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 438000
-wl = dict(bench.WORKLOADS["cesm_le_40x30yr"], T=T, members=max(1, T // 10950))
+wl = dict(bench.WORKLOADS[os.environ.get("WL", "cesm_le_40x30yr")])
+if len(sys.argv) > 1:
+    wl = dict(wl, T=T, members=max(1, T // 10950))
+T = wl["T"]
 ny, nx = wl["ny"], wl["nx"]
 trk = _native.Tracker(0)
 d_in, d_out = trk.malloc(T * ny * nx * 4), trk.malloc(T * ny * nx * 4)
@@ -32,8 +36,8 @@ trk.set_timing(2)
 run(2)
 base = run()
 print("default:", {k: round(v, 3) for k, v in base.items() if v}, flush=True)
-for threads in (0, 512):
-    for rows in (8, 12, 16, 24, 32, 48, 64, 96, 192):
+for threads in (0,):
+    for rows in [int(x) for x in os.environ.get("ROWS", "48,64,96").split(",")]:
         _native.check(_native.lib().ctk_debug_set_relabel(trk.handle, threads, rows))
         try:
             r = run(2)
