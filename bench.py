@@ -475,12 +475,10 @@ def main():
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, a, w)
     if a is None:
-        # coverage of a device-generated slab: one untimed pass that keeps every foreground pixel (overlap 0, persistence 0) -- its
-        # nonzero flags ARE the mask.  Last, on a handle of its own behind the measurements (its tables are not the workload's).
-        trk.close()
-        trk = _native.Tracker(int(os.environ.get("LOCAL_RANK", "0")))
-        trk.track_dev(d_in, T, ny, nx, thr, op, w, 0.0, 0, wl["twosided"], d_out)
-        out["config"]["coverage"] = trk.checksum_i32(d_out, px, 0)[1] / float(px)
+        # coverage of a device-generated slab without a tracking pass: ctk_check_flag_dev counts the pixels whose flag is nonzero where
+        # (double)anom <op> thr[t] is FALSE -- against a "flag" that is nonzero everywhere that is the background (contrack.py:665)
+        trk.memset(d_out, 1, px * 4)
+        out["config"]["coverage"] = 1.0 - trk.check_flag(d_in, d_out, T, ny, nx, thr, op, 0, 0x01010101)["flag_outside_mask"] / float(px)
     trk.free(d_in)
     trk.free(d_out)
     trk.close()

@@ -26,12 +26,20 @@ f = agg(src + "/pmc_fetch/r_counter_collection.csv", "FETCH_SIZE")
 w = agg(src + "/pmc_write/r_counter_collection.csv", "WRITE_SIZE")
 stats = {r["Name"].split("(")[0].replace("void ", ""): r for r in csv.DictReader(open(src + "/trace/r_kernel_stats.csv"))}
 out = {}
+def full_size(v):
+    """the launches of the passes: a kernel is also launched on part of the slab now and then (a first call that repeats a stage, a
+    placement check on a window) -- launches below half of the largest are left out of the per-launch mean"""
+    m = max(v) if v else 0.0
+    keep = [x for x in v if x >= 0.5 * m]
+    return keep or v
+
+
 for k in set(f) | set(w):
-    fs, ws = f.get(k, [0.0]), w.get(k, [0.0])
+    fs, ws = full_size(f.get(k, [0.0])), full_size(w.get(k, [0.0]))
     out[k] = dict(launches=len(fs), fetch_size_kb=sum(fs) / len(fs), write_size_kb=sum(ws) / max(1, len(ws)),
                   fetch_bytes_corrected=2.0 * 1024 * sum(fs) / len(fs), write_bytes=1024.0 * sum(ws) / max(1, len(ws)),
                   avg_ns=float(stats[k]["AverageNs"]) if k in stats else None)
-json.dump(dict(note="per launch; fetch_bytes_corrected = FETCH_SIZE*1024*2 (gfx950 counts wide coalesced reads at half), "
+json.dump(dict(note="per launch (launches below half of the largest left out); fetch_bytes_corrected = FETCH_SIZE*1024*2 (gfx950 counts wide coalesced reads at half), "
                     "write_bytes = WRITE_SIZE*1024 (uncalibrated); workload " + workload,
                kernels=out), open(dst + "_pmc.json", "w"), indent=1, sort_keys=True)
 with open(dst + "_pmc.md", "w") as fh:
