@@ -155,6 +155,10 @@ def strong_block(trk, comm, rank, world, wl, T, steps, warmup):
                 n_gpus=world, ms_per_step_1gpu=float(one[0]), ms_per_step=ms, speedup_vs_1gpu=float(one[0]) / ms,
                 timesteps_per_s=T / (ms * 1e-3), n_tracked=int(nN), n_tracked_one_call=int(one[1]), n_tracked_equal=bool(int(one[1]) == int(nN)),
                 collectives_per_step=coll, steps=steps,
+                # the one-GPU time splits with the shard down to a floor of one-round launches (0.25 ms), plus the exchanges
+                predicted=dict(ms_per_step=(max(float(one[0]) - 0.25, 0.0) / world + 0.25 + (0.15 if world > 1 else 0.0)),
+                               speedup_vs_1gpu=float(one[0]) / (max(float(one[0]) - 0.25, 0.0) / world + 0.25 + (0.15 if world > 1 else 0.0)),
+                               model="(t1 - 0.25 ms) / N + 0.25 ms + 0.15 ms of exchanges (DESIGN.md section 10; never measured on N > 1 GPUs before this run)"),
                 note="same launch: the one-call time is measured on rank 0's GPU (the whole slab resident), then the slab is split into "
                      "%d time shards; barrier + sync around the timed calls, max over ranks" % world)
 
