@@ -996,6 +996,10 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                         return v;
                     }();
                     for (int gb = k < (int)sched.size() ? sched[(size_t)k] : 8; gb > 0; gb -= 8) {      // (in pieces of <= 8 GB: hipMalloc of 16 GB takes 0.5-1.4 s)
+                        // (never into the last eighth of the device: other handles -- eight time shards of one slab on one GPU in the
+                        // tests -- allocate their work spaces at the same time)
+                        size_t mem_free = 0, mem_total = 0;
+                        if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || mem_free < ((size_t)std::min(gb, 8) << 30) + mem_total / 8) { (void)hipGetLastError(); break; }
                         void *sp = nullptr;
                         if (hipMalloc(&sp, (size_t)std::min(gb, 8) << 30) == hipSuccess) held.push_back(sp);
                         else { (void)hipGetLastError(); break; }
