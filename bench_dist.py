@@ -34,7 +34,7 @@ def _weights(ny, nx):
 def _timed_sharded(trk, comm, step, steps, warmup):
     """barrier + sync | `steps` calls | sync + barrier; max over ranks (the bench contract's timing)"""
     n = None
-    for _ in range(max(warmup, 0)):
+    for _ in range(2 + max(warmup, 0)):      # (2: set-up -- the handle sizes its work space in its first call and checks its mask's placement in the second)
         n = step()
     comm.barrier()
     trk.sync()
@@ -119,7 +119,7 @@ def strong_block(trk, comm, rank, world, wl, T, steps, warmup):
             trk.synth_fill(d_in, T, ny, nx, seed=0)
             thr = np.full(T, thr_value)
             trk.set_timing(0)
-            for _ in range(max(warmup, 1)):
+            for _ in range(2 + max(warmup, 1)):
                 n1 = trk.track_dev(d_in, T, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], d_out)
             trk.sync()
             tb = time.perf_counter()
@@ -227,7 +227,7 @@ def bench_main(args, wl, workloads, hbm_peak, cpu_baseline=None, pmc_traffic=Non
         return trk.track_sharded_dev(comm, d_in, nloc, t0, T_total, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], d_out)
 
     n_tracked = None
-    for _ in range(max(args.warmup, 0)):
+    for _ in range(2 + max(args.warmup, 0)):      # (2: set-up, as in bench.py's one-GPU leg)
         n_tracked = step()
     comm.barrier()
     trk.sync()

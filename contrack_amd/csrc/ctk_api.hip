@@ -348,9 +348,12 @@ struct ctk_handle {
     int xcd_thr_tuned = -1;                       // (round 4 tuned the XCD tile size of the threshold kernel per placement; no longer: -1)
     bool thr_nostore = false;                     // the threshold kernel without its mask stores: the yardstick of the mask placement check
     bool thr_probe = false;                       // the launches of that check run under their own kernel name (k_threshold_probe)
+    bool mask_check_pending = false;              // the mask was (re)allocated and has not been checked against a slab yet
+    int mask_check_retries = 0;                   // checks that found the device busy with other work (their times meant nothing)
     int mask_tries = 0; double mask_ratio = 0.0;  // allocations of the mask that were checked when it was last (re)allocated; kernel time / its time without stores
     int xcd_rel_tuned = -1;                       // the same for the write kernel (tune_relabel), for the shape below
     int64_t rel_tuned_T = -1; int rel_tuned_ny = 0, rel_tuned_nx = 0; const void *rel_tuned_flag = nullptr;
+    int64_t rel_seen_T = -1; int rel_seen_ny = 0, rel_seen_nx = 0;      // the shape of the previous pass (tuning waits for the second pass on a shape)
     bool sh_collective_err = false;               // the time-shard path's error was decided identically on every rank
     ctk_comm *active_comm = nullptr;              // set while the time-shard path runs with more than one rank
     // host scratch of the seam driver, kept between calls (fresh 100+ KB vectors would page-fault every call)
@@ -953,9 +956,15 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         // and while the kernel with its stores is more than 8.5 % above it, another mask is allocated behind a spacer that is held in
         // between (1, 4, 8, 8 GB: hipMalloc of these costs 0.02-0.3 ms; one that fails is skipped) -- memory from somewhere else; then
         // the arenas below.  Two launches per measurement, 4 in the usual case (the first mask is fine), at most 20; once per handle and mask size; CTK_MASK_TUNE=0 turns it off.
-        h->mask_tries = mask_fresh ? 0 : h->mask_tries;
+        // WHEN: not in the call that allocated the mask but in the next one that uses it -- a one-shot run_contrack never pays for it (a
+        // few launches mean nothing to a handle that is used again and again, and are pure overhead for one that is not: round-4
+        // verdict); CTK_MASK_CHECK_FIRST=1: in the first call, as in round 4.
+        if (mask_fresh) { h->mask_tries = 0; h->mask_ratio = 0.0; h->mask_check_pending = true; h->mask_check_retries = 0; }
+        static const bool check_first = getenv("CTK_MASK_CHECK_FIRST") != nullptr;
         const bool v7_path = !f64 && (nx % 4 == 0) && (((uintptr_t)anom_dev & 15) == 0);
-        if (anom_dev && mask_fresh && h->mask_off_dbg < 0 && ctk_env().mask_tune && v7_path && (size_t)T * ny * nx * 4 >= ((size_t)128 << 20)) {
+        if (anom_dev && h->mask_check_pending && (check_first || !mask_fresh) && h->mask_off_dbg < 0 && ctk_env().mask_tune && v7_path &&
+            (size_t)T * ny * nx * 4 >= ((size_t)128 << 20)) {
+            h->mask_check_pending = false;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
                 const size_t mbytes = (size_t)nrows * W * 8;
@@ -975,6 +984,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                 };
                 int rc = CTK_OK;
                 double ro_ms = 0.0, best_ms = 1e30;
+                static const double accept_first = getenv("CTK_MASK_ACCEPT") ? atof(getenv("CTK_MASK_ACCEPT")) : 1.085;
                 h->thr_probe = true;
                 struct ProbeOff { ctk_handle *h; ~ProbeOff() { h->thr_probe = false; h->thr_nostore = false; } } probe_off{h};
                 h->thr_nostore = true;                                                  // the yardstick: the same kernel without its stores
@@ -983,8 +993,19 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                 DevBuf best = h->mask;
                 if (rc == CTK_OK) rc = time_it(&best_ms);
                 h->mask_tries = 1;
+                // Is the device ours?  With other work on it (other handles tracking their members at the same time) the times mean
+                // nothing -- the kernel "with stores" came out at 0.3-0.85 of the one without in bench.py's four-handle block.  The
+                // yardstick once more: apart by more than 4 %, or slower than the kernel with its stores, and the mask stays where it is.
+                if (rc == CTK_OK && best_ms > accept_first * ro_ms) {
+                    double ro2 = 0.0;
+                    h->thr_nostore = true;
+                    rc = time_it(&ro2);
+                    h->thr_nostore = false;
+                    if (rc == CTK_OK && (ro2 > 1.04 * ro_ms || ro_ms > 1.04 * ro2 || best_ms < 0.98 * std::min(ro_ms, ro2))) { best_ms = 0.0; h->mask_tries = 0; if (++h->mask_check_retries <= 3) h->mask_check_pending = true; }      // (inconclusive: no search now; up to three later calls try again)
+                    else ro_ms = std::min(ro_ms, ro2);
+                } else if (rc == CTK_OK && best_ms < 0.98 * ro_ms) h->mask_tries = 0;
                 static const int max_tries = getenv("CTK_MASK_TRIES") ? atoi(getenv("CTK_MASK_TRIES")) : 4;
-                static const double accept = getenv("CTK_MASK_ACCEPT") ? atof(getenv("CTK_MASK_ACCEPT")) : 1.085;
+                const double accept = accept_first;
                 std::vector<void *> held;                                               // spacers and rejected masks: freed when the search is over
                 struct FreeHeld { std::vector<void *> &v; ~FreeHeld() { for (void *q : v) (void)hipFree(q); } } free_held{held};
                 for (int k = 0; rc == CTK_OK && k < max_tries && best_ms > accept * ro_ms; k++) {
@@ -2314,6 +2335,8 @@ static void tune_relabel(ctk_handle *h, int persistence, int32_t *flag_dev)
     // 14 600 x 721 x 1440, where launch order measured best anyway)
     if (h->rel_tuned_T == h->T && h->rel_tuned_ny == h->ny && h->rel_tuned_nx == h->nx) return;
     if ((size_t)h->T * h->ny * h->nx * 4 < ((size_t)128 << 20)) return;
+    // (like the mask check: at the SECOND pass on a shape, so that a one-shot call does not pay nine extra launches)
+    if (!(h->rel_seen_T == h->T && h->rel_seen_ny == h->ny && h->rel_seen_nx == h->nx)) { h->rel_seen_T = h->T; h->rel_seen_ny = h->ny; h->rel_seen_nx = h->nx; return; }
     h->rel_tuned_T = h->T; h->rel_tuned_ny = h->ny; h->rel_tuned_nx = h->nx; h->rel_tuned_flag = flag_dev;
     if ((size_t)h->T * h->ny * h->nx * 4 > ((size_t)8 << 30)) { h->xcd_rel_tuned = -1; return; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
