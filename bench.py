@@ -168,7 +168,8 @@ def concurrent_members(wl, a, thr, op, w, nh, steps):
         else:
             t.synth_fill(di, T, ny, nx, seed=0)
         t.set_timing(0)
-        t.track_dev(di, T, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], do)      # warm-up: work spaces
+        for _ in range(2):                                    # set-up: work spaces (1st call), placement check / write-kernel tuning (2nd)
+            t.track_dev(di, T, ny, nx, thr, op, w, wl["overlap"], wl["persistence"], wl["twosided"], do)
         bufs.append((di, do))
     for t in trks:
         t.sync()
