@@ -1239,7 +1239,8 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
             k_sum_blocks<<<nb, CTK_CI_BLOCK, 0, s>>>(P<uint32_t>(h->ncomp), T, P<uint32_t>(h->ci_bsum));
             ci.bsum = P<uint32_t>(h->ci_bsum);
         }
-        k_compact_init<<<(int)T, h->small_threads[2] > 0 ? h->small_threads[2] : 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
+        // (threads: one wave per plane in the throughput regime -- 438 000 x 192 x 288: 0.81 -> 0.55 ms; 256 in the latency regime, NOTES round 4)
+        k_compact_init<<<(int)T, h->small_threads[2] > 0 ? h->small_threads[2] : (T > 65536 ? 64 : 256), 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
                                               P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box), P<int64_t>(h->d_area),
                                               P<uint32_t>(h->d_comp_t), ci);
         HIPCHK(hipGetLastError());
@@ -1578,7 +1579,8 @@ static int launch_extents(ctk_handle *h, bool ext_filled = false, bool with_fina
         a.fold = fold_args(h); a.ny = h->ny; a.nx = h->nx; a.W = h->W;
         // (a timestep has ~40 components: one wave per timestep puts every plane of a long slab on the chip at once -- 11.2 instead of
         // 14.0 us at 2707 x 181 x 360, equal at 480 x 721 x 1440; tools/small_probe.py)
-        k_extent<<<(int)h->T, h->small_threads[0] > 0 ? h->small_threads[0] : (h->T > 2048 ? 64 : 256), 0, s>>>(a);
+        // (one wave per plane beyond 2048 planes; two on wide grids, whose complex components are folded row by row: 14 600 x 721 x 1440 0.40 -> 0.26 ms)
+        k_extent<<<(int)h->T, h->small_threads[0] > 0 ? h->small_threads[0] : (h->T > 2048 ? (h->nx >= 1024 ? 128 : 64) : 256), 0, s>>>(a);
         HIPCHK(hipGetLastError());
     }
     return CTK_OK;
@@ -2231,7 +2233,8 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     int32_t *cv = chunk_vals_for(h, flag_dev, &cv_rows);
     {
         Timer tm(h, CTK_K_RUNLABEL);
-        k_run_values<<<(int)T, h->small_threads[1] > 0 ? h->small_threads[1] : 256, 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), CPX(h), P<int32_t>(h->comp_label),
+        // (one wave per plane in the throughput regime with few runs per plane: 438 000 x 192 x 288 1.19 -> 0.63 ms)
+        k_run_values<<<(int)T, h->small_threads[1] > 0 ? h->small_threads[1] : ((T > 65536 && h->total_runs / (size_t)T < 1024) ? 64 : 256), 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->run_comp), CPX(h), P<int32_t>(h->comp_label),
                                             P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->d_mrep), 0, 0, P<int32_t>(h->run_val),
                                             P<uint32_t>(h->rowstart), h->ny, cv_rows, cv, P<uint32_t>(h->counters),
                                             P<uint32_t>(h->rv_boff) + nsb, P<uint32_t>(h->seam_off) /* t_alive: [T + 1], unused on this path otherwise */);
