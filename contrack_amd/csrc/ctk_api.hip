@@ -326,7 +326,7 @@ struct ctk_handle {
     int64_t rowoff_T = -1; int rowoff_ny = -1; void *rowoff_p = nullptr;     // what seam_rowoff currently holds
     // speculative launch of the 2-D labelling: capacity (in runs) of the run-indexed buffers, the previous call's variants
     uint32_t runs_cap = 0;
-    struct { bool v1 = false, v2 = false, v3 = false, glb = false, one = false; } spec_set;
+    struct { bool v1 = false, v2 = false, v3 = false, glb = false, one = false, v1hi = false; } spec_set;
     int spec_ny = -1, spec_nx = -1; int64_t spec_T = -1;
     size_t mail_cap_c = 0, mail_cap_d = 0, mail_want_c = 0, mail_want_d = 0;
     size_t h_ops_cap = 0;
@@ -1082,7 +1082,9 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         // one workgroup per timestep: few timesteps of a tall grid leave the chip empty and the rows of a plane in a long chain
         // (480 x 721 x 1440: 52 us with 4 waves per plane) -- more waves per plane then (first form of the kernel only)
         // (71 VGPRs: three 512-thread workgroups per CU, one round for <= 768 planes; 1024 threads ran in two rounds)
-        const int rc_threads = (W <= 64 && ny <= RC_ROWS && ny > 256 && T <= 2048) ? 512 : 256;
+        static const int rc_env = getenv("CTK_RC_THREADS") ? atoi(getenv("CTK_RC_THREADS")) : 0;      // (experiments)
+        // (throughput regime, small planes -- 438 000 x 192 x 288: 128 threads 1.39 -> 0.86 ms, 64: 1.02)
+        const int rc_threads = rc_env > 0 ? rc_env : ((W <= 64 && ny <= RC_ROWS && ny > 256 && T <= 2048) ? 512 : ((T > 65536 && (int64_t)ny * W <= 2048) ? 128 : 256));
         if (T > 0) k_rowcount<<<(int)T, rc_threads, 0, s>>>(P<uint64_t>(h->mask), ny, W, P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart), P<uint32_t>(h->tcount));
         CTKCHK(launch_scan_u32(h, P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), h->h_mail1, scan_stamp));
         HIPCHK(hipGetLastError());
@@ -1095,7 +1097,11 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     // Few timesteps of a busy grid (T <= 512 workgroups: the chip holds them all at once even at two per CU): ONE launch of the
     // largest LDS variant for every timestep instead -- 1024 threads per plane finish a plane sooner than 256 or 512, and the
     // fork / join of the side streams (two events, ~20 us of stream time at 480 x 721 x 1440) disappears.
-    struct VariantSet { bool v1, v2, v3, glb, one; };
+    // (v1hi: small planes in long shards are labelled by the 20 KB variant, which carries 832 runs -- the planes with 833 .. 1024 runs
+    // then need the 1024-run variant behind it; v0_ok depends on the shape alone, so a speculative launch and the later check agree)
+    struct VariantSet { bool v1, v2, v3, glb, one, v1hi; };
+    static const bool v0_env = !getenv("CTK_L2D_NO_SMALL");
+    const bool v0_ok = v0_env && T > 65536 && ny <= 256 && (int64_t)ny * W <= 960;
     auto launch_label2d = [&](const VariantSet &vs, uint32_t cap_runs) -> int {
         Label2dArgs a;
         a.mask = P<uint64_t>(h->mask); a.wstart = P<uint16_t>(h->wstart); a.rowstart = P<uint32_t>(h->rowstart);
@@ -1109,8 +1115,10 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         if (vs.one) k_label2d_lds<4096, 512, -1, 1024><<<(int)T, 1024, 0, s>>>(a);
         if (vs.v2 || vs.v3) HIPCHK(hipEventRecord(h->ev_fork, s));
         if (vs.v1) {
-            k_label2d_lds<1024, 288, -1, 256><<<(int)T, 256, 0, s>>>(a);
+            if (v0_ok) k_label2d_lds<832, 240, -1, 256, 256><<<(int)T, 256, 0, s>>>(a);
+            else k_label2d_lds<1024, 288, -1, 256><<<(int)T, 256, 0, s>>>(a);
         }
+        if (vs.v1hi) k_label2d_lds<1024, 288, 832, 256><<<(int)T, 256, 0, s>>>(a);
         if (vs.v2) {
             HIPCHK(hipStreamWaitEvent(h->side[0], h->ev_fork, 0));
             k_label2d_lds<2048, 512, 1024, 512><<<(int)T, 512, 0, h->side[0]>>>(a);
@@ -1133,10 +1141,10 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     CTKCHK(ensure(h, h->seam_cnt, (size_t)T * 4));
     CTKCHK(ensure(h, h->seam_off, (size_t)(T + 1) * 4));
     const bool spec = T > 0 && h->runs_cap > 0 && h->spec_ny == ny && h->spec_nx == nx && (!h->spec_set.glb || h->spec_T >= T);
-    VariantSet launched = {false, false, false, false, false};
+    VariantSet launched = {false, false, false, false, false, false};
     if (spec) {
         Timer tm(h, CTK_K_LABEL2D);
-        launched = {h->spec_set.v1, h->spec_set.v2, h->spec_set.v3, h->spec_set.glb, h->spec_set.one};
+        launched = {h->spec_set.v1, h->spec_set.v2, h->spec_set.v3, h->spec_set.glb, h->spec_set.one, h->spec_set.v1hi && v0_ok};
         CTKCHK(launch_label2d(launched, h->runs_cap));
     }
     // the scan kernel wrote total / maximum / overflow / last count into the pinned mailbox
@@ -1200,17 +1208,19 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         static const bool no_one = getenv("CTK_L2D_NO_ONE") != nullptr;
         const bool prefer_one = !no_one && T <= 512 && h->max_runs_step > 1024;
         const bool none_lds = !launched.v1 && !launched.v2 && !launched.v3 && !launched.one;
-        VariantSet need = {true, h->max_runs_step > 1024, h->max_runs_step > 2048, h->need_glb, false};
-        if (prefer_one && (none_lds || launched.one)) need = {false, false, false, h->need_glb, true};
-        else if (launched.one) need = {false, false, false, h->need_glb, true};          // (the large variant took every timestep it can take)
-        const VariantSet missing = {need.v1 && !launched.v1, need.v2 && !launched.v2, need.v3 && !launched.v3, need.glb && !launched.glb, need.one && !launched.one};
-        if (missing.v1 || missing.v2 || missing.v3 || missing.glb || missing.one) {
+        VariantSet need = {true, h->max_runs_step > 1024, h->max_runs_step > 2048, h->need_glb, false, v0_ok && h->max_runs_step > 832};
+        if (prefer_one && (none_lds || launched.one)) need = {false, false, false, h->need_glb, true, false};
+        else if (launched.one) need = {false, false, false, h->need_glb, true, false};          // (the large variant took every timestep it can take)
+        const VariantSet missing = {need.v1 && !launched.v1, need.v2 && !launched.v2, need.v3 && !launched.v3, need.glb && !launched.glb, need.one && !launched.one,
+                                    need.v1hi && !launched.v1hi};
+        if (missing.v1 || missing.v2 || missing.v3 || missing.glb || missing.one || missing.v1hi) {
             HT("before label2d launch");
             Timer tm(h, CTK_K_LABEL2D);
             CTKCHK(launch_label2d(missing, h->runs_cap));
         }
         if (prefer_one) { h->spec_set.v1 = false; h->spec_set.v2 = false; h->spec_set.v3 = false; h->spec_set.one = true; }
         else { h->spec_set.v1 = true; h->spec_set.v2 = h->max_runs_step > 1024; h->spec_set.v3 = h->max_runs_step > 2048; h->spec_set.one = false; }
+        h->spec_set.v1hi = need.v1hi;
         h->spec_set.glb = need.glb;
         h->spec_ny = ny; h->spec_nx = nx; h->spec_T = T;
     }
@@ -1367,7 +1377,11 @@ static int launch_overlap(ctk_handle *h)
         const int nwords = h->ny * h->W, per = (nwords + 255) / 256;                       // words per thread if one step is to cover all
         // few large planes: more waves per plane (480 x 721 x 1440: 256 threads 60 us, 1024 -- one workgroup per CU at 101 VGPRs,
         // two rounds -- 53, 512 -- two per CU, one round -- 49.5)
-        if (h->T <= 1024 && nwords >= 8192) k_overlap<4, 512><<<(int)h->T, 512, 0, h->stream>>>(a);
+        // many small planes (throughput regime): two waves per plane, ten workgroups per CU at 101 VGPRs -- 438 000 x 192 x 288: 3.95 -> 3.50 ms
+        // (eight words per thread in one step: 169 VGPRs, 5.5 ms); CTK_OVERLAP_SMALL=1 / 0 forces / forbids it
+        static const int ov_small = getenv("CTK_OVERLAP_SMALL") ? atoi(getenv("CTK_OVERLAP_SMALL")) : -1;
+        if (ov_small == 1 || (ov_small < 0 && h->T > 65536 && nwords <= 2048)) k_overlap<4, 128><<<(int)h->T, 128, 0, h->stream>>>(a);
+        else if (h->T <= 1024 && nwords >= 8192) k_overlap<4, 512><<<(int)h->T, 512, 0, h->stream>>>(a);
         else if (per <= 4 || per > 8) k_overlap<4><<<(int)h->T, 256, 0, h->stream>>>(a);
         else if (per == 5) k_overlap<5><<<(int)h->T, 256, 0, h->stream>>>(a);
         else if (per == 6) k_overlap<6><<<(int)h->T, 256, 0, h->stream>>>(a);

@@ -933,13 +933,16 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
 //   <4096, 512>: 76 KB -> 2 workgroups per CU (0.25 deg timesteps: ~1600 runs, mask words read through L2)
 // (1024 threads: two workgroups per CU need 8 waves per SIMD, i.e. at most 64 VGPRs -- the compiler takes 71 when left alone, and
 // 480 planes of a 0.25 deg grid then run as two rounds of one workgroup per CU: 86 us instead of ~45)
-template <int RUNS, int COMPS, int RUNS_BELOW, int THREADS>
-__global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void k_label2d_lds(Label2dArgs a)
+//   <832, 240, ..., 256, 256>: 19.9 KB -> 8 workgroups per CU: small planes (ny <= 256, at most 960 mask words: 192 x 288) in long shards,
+//   where the kernel is bound by the planes in flight, not by a plane's chain (round 5; the planes with 833 .. 1024 runs go to
+//   <1024, 288, 832, 256>)
+template <int RUNS, int COMPS, int RUNS_BELOW, int THREADS, int NYCAP = CTK_LDS_NY>
+__global__ __launch_bounds__(THREADS, (THREADS == 1024 || NYCAP < CTK_LDS_NY) ? 8 : 1) void k_label2d_lds(Label2dArgs a)
 {
     const int t = (int)blockIdx.x;
     __shared__ uint16_t x0[RUNS], x1[RUNS], yrow[RUNS], root[RUNS], idmap[RUNS];
     __shared__ uint32_t parent[RUNS];
-    __shared__ uint16_t rs[CTK_LDS_NY + 2];
+    __shared__ uint16_t rs[NYCAP + 2];
     __shared__ uint64_t mlds[COMPS * 4];
     __shared__ uint32_t sm_scan[THREADS / 64 + 1];
     const int nwords = a.ny * a.W;
@@ -965,7 +968,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void k_label2d_ld
             rreg[u] = rg[min((int)threadIdx.x + u * THREADS, a.ny - 1)];       // (ny <= nwords: NW rows per thread cover them)
         }
         const uint32_t nruns = rb1 - rb0;
-        if (nruns > RUNS || (int64_t)nruns <= (int64_t)RUNS_BELOW || a.ny > CTK_LDS_NY) return;    // another variant takes it
+        if (nruns > RUNS || (int64_t)nruns <= (int64_t)RUNS_BELOW || a.ny > NYCAP) return;    // another variant takes it
         if (rb1 > a.cap_runs) return;                                  // buffers too small: the host relaunches after growing them
         if (nruns == 0) {
             if (threadIdx.x == 0) { a.ncomp[t] = 0; a.seam_cnt[t] = 0; }
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) void k_label2d_ld
         return;
     }
     const uint32_t nruns = a.run_base[t + 1] - a.run_base[t];
-    if (nruns > RUNS || (int64_t)nruns <= (int64_t)RUNS_BELOW || a.ny > CTK_LDS_NY) return;        // another variant takes it
+    if (nruns > RUNS || (int64_t)nruns <= (int64_t)RUNS_BELOW || a.ny > NYCAP) return;        // another variant takes it
     if (a.run_base[t + 1] > a.cap_runs) return;                    // buffers too small: the host relaunches after growing them
     if (nruns == 0) {
         if (threadIdx.x == 0) { a.ncomp[t] = 0; a.seam_cnt[t] = 0; }

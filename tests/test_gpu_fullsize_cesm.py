@@ -184,3 +184,41 @@ def test_configs4_slab_fused_pass_properties_and_eight_shards(big):
     assert res == [n_one] * world, (res, n_one)
     got = [mem.checksum_i32(_off(d_out, a * PLANE * 4), (b - a) * PLANE, a * PLANE) for a, b in bounds]
     assert got == ref
+
+
+def test_small_plane_variant_and_its_remainder_833_to_1024_runs(big, oracle_lib):
+    """Long shards of small planes (ny <= 256, <= 960 mask words, more than 65 536 steps) are labelled by the 20 KB variant of the 2-D
+    labelling kernel, which carries 832 runs per plane; planes with 833 .. 1024 runs go to the 1024-run variant behind it (round 5).
+    A 66 000-step slab (the head of the big buffers) that is background except a window of speckled planes with ~900 runs each."""
+    mem, d_in, d_out, w = big
+    T2, n, t0 = 66000, 6, 41000
+    rng = np.random.default_rng(5)
+    speck = rng.random((NY, NX)) < 900.0 / PLANE
+    a = np.full((n + 2, NY, NX), -1000.0, dtype=np.float32)
+    for k in range(1, n + 1):
+        m = speck ^ (rng.random((NY, NX)) < 20.0 / PLANE)                      # a few pixels come and go
+        a[k][m] = 200.0
+    fg = a[1:-1] >= 160.0
+    runs = (fg & ~np.concatenate([np.zeros((n, NY, 1), bool), fg[:, :, :-1]], axis=2)).sum(axis=(1, 2))
+    assert runs.max() <= 1024 and runs.min() > 832, runs
+    thr_small = oracle_lib.prepare_thresholds(160.0, n + 2)
+    want, nw = oracle_lib.run_contrack(a, thr_small, ">=", w, 0.5, 2, True)
+    assert nw > 100
+    trk = _native.Tracker(0)
+    try:
+        mem.memset(d_in, 0, T2 * PLANE * 4)
+        mem.memset(d_out, 0xff, T2 * PLANE * 4)
+        mem.h2d(_off(d_in, t0 * PLANE * 4), a)
+        thr = oracle_lib.prepare_thresholds(160.0, T2)
+        for _ in range(2):                                                      # (the second call launches the variants speculatively)
+            ng = trk.track_dev(d_in, T2, NY, NX, thr, 0, w, 0.5, 2, True, d_out)
+            st = trk.stats()
+            assert 832 < st["max_runs_per_step"] <= 1024, st
+            assert ng == nw
+            got = np.empty(want.shape, dtype=np.int32)
+            mem.d2h(got, _off(d_out, t0 * PLANE * 4))
+            assert np.array_equal(got, want)
+            assert mem.checksum_i32(d_out, T2 * PLANE, 0)[1] == int(np.count_nonzero(want))
+            mem.memset(d_out, 0xff, T2 * PLANE * 4)
+    finally:
+        trk.close()
