@@ -203,6 +203,21 @@ int main(int argc, char **argv)
             }
         }
     }
+    if (!strcmp(test, "bigmap")) {
+        // the large-scale structure: ONE allocation of argv[2] GB (default 48), the mask every 256 MB against the original slab; a
+        // physically contiguous block would show the address pattern of the classes, if there is one
+        const size_t gb = argc > 2 ? (size_t)atoll(argv[2]) : 48;
+        const size_t A = gb << 30, step = (size_t)(argc > 3 ? atoll(argv[3]) : 256) << 20;
+        char *arena; CHK(hipMalloc(&arena, A));
+        printf("arena %p, %zu GB, one letter per %zu MB (F fast / m / s slow), 32 per line\n", (void *)arena, gb, step >> 20);
+        int n = 0;
+        for (size_t off = 0; off + mbytes <= A; off += step, n++) {
+            const float f = time_it((const f4 *)slab, (uint64_t *)(arena + off), nwg, 0, 3);
+            printf("%c", f < 0.1105 ? 'F' : (f < 0.1135 ? 'm' : 's'));
+            if ((n & 31) == 31) printf("\n");
+        }
+        printf("\n");
+    }
     if (!strcmp(test, "allocs")) {
         // (A) separate allocations, kept alive
         std::vector<uint64_t *> keep;
