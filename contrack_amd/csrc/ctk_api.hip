@@ -954,8 +954,8 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         // Allocations made right after each other usually share a class -- the "bimodal board" of rounds 2-4.  So a freshly allocated
         // mask is checked against the slab: the kernel's time WITHOUT its stores (on the first 4 GB of a larger slab) is the yardstick,
         // and while the kernel with its stores is more than 8.5 % above it, another mask is allocated behind a spacer that is held in
-        // between (1, 4, 8, 8 GB: hipMalloc of these costs 0.02-0.3 ms; one that fails is skipped) -- memory from somewhere else; then
-        // the arenas below.  Two launches per measurement, 4 in the usual case (the first mask is fine), at most 20; once per handle and mask size; CTK_MASK_TUNE=0 turns it off.
+        // between (1, 4, 8, 8, 8 GB: hipMalloc of these costs 0.02-0.3 ms; one that fails is skipped) -- memory from somewhere else; then
+        // the arenas below.  Two launches per measurement, 4 in the usual case (the first mask is fine), at most 22; once per handle and mask size; CTK_MASK_TUNE=0 turns it off.
         // WHEN: not in the call that allocated the mask but in the next one that uses it -- a one-shot run_contrack never pays for it (a
         // few launches mean nothing to a handle that is used again and again, and are pure overhead for one that is not: round-4
         // verdict); CTK_MASK_CHECK_FIRST=1: in the first call, as in round 4.
@@ -1004,7 +1004,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                     if (rc == CTK_OK && (ro2 > 1.04 * ro_ms || ro_ms > 1.04 * ro2 || best_ms < 0.98 * std::min(ro_ms, ro2))) { best_ms = 0.0; h->mask_tries = 0; if (++h->mask_check_retries <= 3) h->mask_check_pending = true; }      // (inconclusive: no search now; up to three later calls try again)
                     else ro_ms = std::min(ro_ms, ro2);
                 } else if (rc == CTK_OK && best_ms < 0.98 * ro_ms) h->mask_tries = 0;
-                static const int max_tries = getenv("CTK_MASK_TRIES") ? atoi(getenv("CTK_MASK_TRIES")) : 4;
+                static const int max_tries = getenv("CTK_MASK_TRIES") ? atoi(getenv("CTK_MASK_TRIES")) : 5;
                 const double accept = accept_first;
                 std::vector<void *> held;                                               // spacers and rejected masks: freed when the search is over
                 struct FreeHeld { std::vector<void *> &v; ~FreeHeld() { for (void *q : v) (void)hipFree(q); } } free_held{held};
@@ -1013,7 +1013,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                     static const std::vector<int> sched = [] {
                         std::vector<int> v;
                         if (const char *e = getenv("CTK_MASK_SPACERS_GB")) { for (const char *q = e; *q;) { v.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; } }
-                        else v = {1, 4, 8, 8};
+                        else v = {1, 4, 8, 8, 8};      // (29 GB in all: the slab's class comes in runs of up to ~20 GB, tools/rw_mix_probe.hip bigmap)
                         return v;
                     }();
                     for (int gb = k < (int)sched.size() ? sched[(size_t)k] : 8; gb > 0; gb -= 8) {      // (in pieces of <= 8 GB: hipMalloc of 16 GB takes 0.5-1.4 s)
