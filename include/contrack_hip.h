@@ -253,7 +253,7 @@ int ctk_get_timing_sums(ctk_handle *h, double *sums, int64_t *counts, int reset)
                                    bit 3 (8) = a bounded inter-workgroup wait gave up, the resolution was repeated with one launch per
                                    filter pass */
 #define CTK_S_SHARED_ROWS   17  /* time-sharded path: seam candidate groups shared between shards (driven on every rank)        */
-#define CTK_S_RELABEL_KERNEL 19    /* which write kernel ran: 5 = k_relabel_v5, 4 = k_relabel_v4, 0 = generic k_relabel, -1 = none (run transfer) */
+#define CTK_S_RELABEL_KERNEL 19    /* which write kernel ran: 6 = k_relabel_sparse behind k_flag_zero, 5 = k_relabel_v5, 4 = k_relabel_v4, 0 = generic k_relabel, -1 = none (run transfer) */
 #define CTK_S_FUSED         20    /* 1: the one-call pass ran without a host hand-off (device seam driver, one synchronisation) */
 #define CTK_S_X4_SPECULATED 21    /* time-sharded path: 1 if the boundary records of the 3-D labelling travelled with the last round of
                                    * the overlap filter's exchange (one all-gather less) */
@@ -262,8 +262,15 @@ int ctk_get_timing_sums(ctk_handle *h, double *sums, int64_t *counts, int reset)
                                    * components) went through the write kernel */
 #define CTK_S_MASK_TRIES    23    /* allocations of the bit mask that were checked against the slab when it was last (re)allocated (0: not checked); sticky */
 #define CTK_S_MASK_RATIO    24    /* 1000 x (threshold kernel on the kept mask / the same kernel without its stores), from that check; sticky */
-#define CTK_NSTATS          25
+#define CTK_NSTATS          25    /* what ctk_get_stats writes: FROZEN at 25 (a host built against this header is never overrun by a newer library) */
 int ctk_get_stats(ctk_handle *h, int64_t *out /* [CTK_NSTATS] */);
+/* statistics added after that are read with an explicit length: writes min(n, CTK_NSTATS_ALL) entries, returns CTK_OK */
+#define CTK_S_MASK_CHECK_US 25    /* host time of the last mask placement check, microseconds (bounded: at most one other allocation); sticky */
+#define CTK_S_MASK_SPACER_MB 26   /* device memory that check held as a spacer while it ran (freed before the call went on), MB; sticky */
+#define CTK_S_EARLY_ZERO    27    /* 1: the background of `flag` was written by k_flag_zero on a side stream underneath the table kernels and the
+                                   * write kernel stored the foreground words only (CTK_S_RELABEL_KERNEL = 6) */
+#define CTK_NSTATS_ALL      32
+int ctk_get_stats_n(ctk_handle *h, int64_t *out, int n);
 int ctk_get_timings(ctk_handle *h, double *ms /* [CTK_NTIMERS] */);
 
 /* ---- thin device-memory helpers so that a ctypes host needs no other HIP binding -------------- */
