@@ -24,7 +24,7 @@ EXPORTS = [
     "ctk_track_f32_dev", "ctk_track_f64", "ctk_track_f64_dev", "ctk_release_io", "ctk_shard_label2d", "ctk_shard_label2d_f64", "ctk_shard_halo_size", "ctk_shard_halo_export",
     "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_resolve", "ctk_result_free",
     "ctk_result_info", "ctk_result_arrays", "ctk_result_nshards", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
-    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_set_seam_caps", "ctk_debug_set_spin", "ctk_debug_set_xcd", "ctk_debug_set_relabel", "ctk_debug_set_small_threads", "ctk_debug_np_sum", "ctk_debug_boundary_resolve", "ctk_set_timing", "ctk_get_timings", "ctk_get_timing_sums", "ctk_set_device_resolve", "ctk_set_fused_pass", "ctk_set_result_transfer", "ctk_debug_set_mask_offset", "ctk_debug_drop_buffer", "ctk_expand_runs_host", "ctk_set_filter_round", "ctk_get_stats", "ctk_get_stats_n", "ctk_debug_zero_fill_ms",
+    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_set_seam_caps", "ctk_debug_set_spin", "ctk_debug_set_xcd", "ctk_debug_set_relabel", "ctk_debug_set_small_threads", "ctk_debug_np_sum", "ctk_debug_boundary_resolve", "ctk_set_timing", "ctk_get_timings", "ctk_get_timing_sums", "ctk_set_device_resolve", "ctk_set_fused_pass", "ctk_set_result_transfer", "ctk_debug_set_mask_offset", "ctk_debug_drop_buffer", "ctk_expand_runs_host", "ctk_set_filter_round", "ctk_get_stats", "ctk_get_stats_n",
     "ctk_dev_malloc", "ctk_dev_free", "ctk_host_alloc", "ctk_host_free", "ctk_host_register", "ctk_host_unregister", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
     "ctk_synth_fill",
     "ctk_comm_unique_id", "ctk_comm_init_rccl", "ctk_comm_group_create", "ctk_comm_group_destroy", "ctk_comm_init_local", "ctk_comm_init_shm",
@@ -121,7 +121,6 @@ def lib():
     L.ctk_expand_runs_host.argtypes = [p, p, p, p, i64, i32, i32, p, p, p]
     L.ctk_get_stats.argtypes = [p, p]
     L.ctk_get_stats_n.argtypes = [p, p, i32]
-    L.ctk_debug_zero_fill_ms.argtypes = [p, p, p, i32]
     L.ctk_set_filter_round.argtypes = [p, i32]
     L.ctk_dev_malloc.argtypes = [p, pp, sz]
     L.ctk_dev_free.argtypes = [p, p]
@@ -821,12 +820,12 @@ class Tracker:
         return v is None or (mt is not None and int(mt.group(0)) != 0)
 
     def stats(self):
-        v = np.zeros(28, dtype=np.int64)
-        check(lib().ctk_get_stats_n(self._h, v.ctypes.data, 28))
+        v = np.zeros(27, dtype=np.int64)
+        check(lib().ctk_get_stats_n(self._h, v.ctypes.data, 27))
         names = ["runs", "max_runs_per_step", "components", "pairs", "seam_rows_to_driver", "labels_3d", "seam_ops",
                  "filter_passes", "host_path", "seam_loop_ns", "seam_folds", "seam_copy_ns", "ungrouped_pairs", "pair_table_regrows", "filter_rounds",
                  "ambiguous_decisions", "exact_fixups", "shared_seam_rows", "off_fused_path_reason", "relabel_kernel", "fused_pass", "x4_speculated", "result_as_runs", "mask_allocations_tried", "mask_ratio_x1000",
-                 "mask_check_us", "mask_spacer_mb", "early_zero_fill"]
+                 "mask_check_us", "mask_spacer_mb"]
         return dict(zip(names, v.tolist()))
 
     def debug_set_pair_capacity(self, records):
@@ -854,12 +853,6 @@ class Tracker:
         cnt = np.zeros(len(TIMER_NAMES), dtype=np.int64)
         check(lib().ctk_get_timing_sums(self._h, sums.ctypes.data, cnt.ctypes.data, int(bool(reset))))
         return ({k: (float(v) / int(n) if n else 0.0) for k, v, n in zip(TIMER_NAMES, sums, cnt)}, dict(zip(TIMER_NAMES, cnt.tolist())))
-
-    def zero_fill_ms(self, reset=True):
-        """(mean ms, calls measured) of k_flag_zero -- the background of `flag`, written on a side stream (timing level >= 1)"""
-        s, n = C.c_double(0.0), C.c_int64(0)
-        check(lib().ctk_debug_zero_fill_ms(self._h, C.byref(s), C.byref(n), int(bool(reset))))
-        return (s.value / n.value if n.value else 0.0), n.value
 
     def timings(self):
         ms = np.zeros(len(TIMER_NAMES), dtype=np.float64)

@@ -260,18 +260,6 @@ struct ctk_handle {
     const int32_t *lc_flag = nullptr; const void *lc_field = nullptr;       // slabs of the last ctk_lifecycle_* call (for the exact rows)
     bool lc_f64 = false; int64_t lc_T = 0; int lc_ny = 0, lc_nx = 0;
     DevBuf chunk_vals;                             // run values in the chunk order of k_relabel_v4
-    // round 6: run counts produced by the threshold kernel (k_threshold_v7rc), row starts written by k_label2d
-    DevBuf rowrel, chunkcnt;
-    bool rc_mode = false;                          // this shard's threshold launches wrote wstart / rowrel / chunkcnt (no k_rowcount)
-    // round 6: the background of `flag` is written early, on its own stream, underneath the table kernels (k_flag_zero); the write
-    // kernel behind the resolver then stores only the words that hold foreground (k_relabel_sparse)
-    hipStream_t zstream = nullptr;
-    hipEvent_t ev_zfork = nullptr, ev_zjoin = nullptr, ev_z[2] = {nullptr, nullptr};
-    int32_t *early_flag = nullptr;                 // this call's output slab when the early zero fill applies, else nullptr
-    bool zero_pending = false;                     // k_flag_zero is in flight on zstream: whoever writes `flag` next waits for ev_zjoin first
-    bool ev_z_used = false;
-    double zero_ms_sum = 0; int64_t zero_ms_cnt = 0;
-    double mask_check_ms = 0; double mask_spacer_gb = 0;        // host time / most spacer memory held by the last mask placement check
     // fused one-call path (ctk_seam_dev.hip): clusters of candidate labels, cluster root per group record; the pass runs without a
     // host hand-off and is validated from a device-written block of scalars after its only synchronisation
     DevBuf sd_parent, sd_tmin, sd_tmax, sd_root, sd_nops, sd_lbox, rv_pstate, ci_bsum, scan_bsum;
@@ -363,6 +351,7 @@ struct ctk_handle {
     bool mask_check_pending = false;              // the mask was (re)allocated and has not been checked against a slab yet
     int mask_check_retries = 0;                   // checks that found the device busy with other work (their times meant nothing)
     int mask_tries = 0; double mask_ratio = 0.0;  // allocations of the mask that were checked when it was last (re)allocated; kernel time / its time without stores
+    double mask_check_ms = 0; double mask_spacer_gb = 0;        // host time / spacer memory held by the last mask placement check
     int xcd_rel_tuned = -1;                       // the same for the write kernel (tune_relabel), for the shape below
     int64_t rel_tuned_T = -1; int rel_tuned_ny = 0, rel_tuned_nx = 0; const void *rel_tuned_flag = nullptr;
     int64_t rel_seen_T = -1; int rel_seen_ny = 0, rel_seen_nx = 0;      // the shape of the previous pass (tuning waits for the second pass on a shape)
@@ -553,8 +542,6 @@ extern "C" int ctk_create(ctk_handle **out, int device)
     }
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_scan, hipEventDisableTiming) != hipSuccess) { ctk_destroy(h); return ctk_set_error(CTK_E_NODEVICE, "hipEventCreate failed"); }
-    if (hipStreamCreateWithFlags(&h->zstream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_zfork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_zjoin, hipEventDisableTiming) != hipSuccess) { ctk_destroy(h); return ctk_set_error(CTK_E_NODEVICE, "hipStreamCreate failed"); }
     if (hipHostMalloc((void **)&h->h_mail1, 256, hipHostMallocDefault) != hipSuccess) { ctk_destroy(h); return ctk_set_error(CTK_E_NOMEM, "hipHostMalloc failed"); }
     memset(h->h_mail1, 0, 256);
     memset(h->ms, 0, sizeof(h->ms));
@@ -576,7 +563,7 @@ extern "C" void ctk_destroy(ctk_handle *h)
                       &h->rv_cand_cnt, &h->rv_cand_off, &h->rv_cand, &h->rv_cand_scratch, &h->rv_seam_res, &h->rv_scalars, &h->rv_mark, &h->rv_inv, &h->rv_ff,
                       &h->lc_rows, &h->lc_cnt, &h->lc_wlo, &h->lc_whi, &h->lc_w, &h->rv_dmap, &h->rv_dorig, &h->rv_dbox, &h->rv_inex, &h->rv_touch, &h->io_in, &h->io_out,
                       &h->sh_mask_next, &h->sh_send, &h->sh_recv, &h->sh_prev, &h->sh_elist, &h->sh_ovr_slot, &h->sh_ovr_val,
-                      &h->sh_amb_list, &h->sh_counts, &h->sh_cl_shared, &h->sh_cl_sent, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_root, &h->sd_nops, &h->sd_lbox, &h->rv_pstate, &h->ci_bsum, &h->scan_bsum, &h->rowrel, &h->chunkcnt};
+                      &h->sh_amb_list, &h->sh_counts, &h->sh_cl_shared, &h->sh_cl_sent, &h->chunk_vals, &h->lc_work, &h->lc_ovf, &h->lc_ekeys, &h->lc_offs, &h->lc_sw, &h->lc_sp, &h->lc_out, &h->lc_cross, &h->lc_gtab, &h->lc_occ, &h->lc_cp, &h->an_out, &h->an_clim, &h->an_raw, &h->an_idx, &h->sd_parent, &h->sd_tmin, &h->sd_tmax, &h->sd_root, &h->sd_nops, &h->sd_lbox, &h->rv_pstate, &h->ci_bsum, &h->scan_bsum};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->base ? b->base : b->p);
     if (h->h_blob) (void)hipHostFree(h->h_blob);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -598,8 +585,6 @@ extern "C" void ctk_destroy(ctk_handle *h)
     for (int k = 0; k < 2; k++) { if (h->side[k]) (void)hipStreamDestroy(h->side[k]); if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_scan) (void)hipEventDestroy(h->ev_scan);
-    if (h->zstream) { (void)hipStreamSynchronize(h->zstream); (void)hipStreamDestroy(h->zstream); }
-    for (hipEvent_t e : {h->ev_zfork, h->ev_zjoin, h->ev_z[0], h->ev_z[1]}) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -610,7 +595,6 @@ extern "C" int ctk_set_timing(ctk_handle *h, int enable)
     HIPCHK(hipSetDevice(h->device));
     if (enable && !h->ev_ready) {
         for (int k = 0; k <= CTK_KI_ROWCOUNT; k++) { HIPCHK(hipEventCreate(&h->ev[k][0])); HIPCHK(hipEventCreate(&h->ev[k][1])); }
-        HIPCHK(hipEventCreate(&h->ev_z[0])); HIPCHK(hipEventCreate(&h->ev_z[1]));
         h->ev_ready = true;
     }
     h->timing = enable;
@@ -762,11 +746,6 @@ static int collect_event_times(ctk_handle *h)
         }
         h->ev_used[k] = false;
     }
-    if (h->ev_z_used) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->ev_z[0], h->ev_z[1]) == hipSuccess) { h->zero_ms_sum += ms; h->zero_ms_cnt++; }
-        h->ev_z_used = false;
-    }
     return CTK_OK;
 }
 
@@ -776,16 +755,6 @@ extern "C" int ctk_get_timing_sums(ctk_handle *h, double *sums, int64_t *counts,
     if (sums) memcpy(sums, h->ms_sum, sizeof(h->ms_sum));
     if (counts) memcpy(counts, h->ms_cnt, sizeof(h->ms_cnt));
     if (reset) { memset(h->ms_sum, 0, sizeof(h->ms_sum)); memset(h->ms_cnt, 0, sizeof(h->ms_cnt)); }
-    return CTK_OK;
-}
-
-/* k_flag_zero runs on its own stream: its event times (timing level >= 1) are kept apart from the kernel groups of the pass */
-extern "C" int ctk_debug_zero_fill_ms(ctk_handle *h, double *sum_ms, int64_t *count, int reset)
-{
-    if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
-    if (sum_ms) *sum_ms = h->zero_ms_sum;
-    if (count) *count = h->zero_ms_cnt;
-    if (reset) { h->zero_ms_sum = 0; h->zero_ms_cnt = 0; }
     return CTK_OK;
 }
 
@@ -807,21 +776,20 @@ static int stream_out(ctk_handle *h, int persistence, const int32_t *chunk_vals)
 static bool async_wanted(ctk_handle *h);
 // exclusive scan of n uint32 items into out[0 .. n] (out[n] = the total): one workgroup for short shards, block sums + one workgroup
 // per 1024 items for long ones (k_scan_blocks)
-static int launch_scan_u32(ctk_handle *h, const uint32_t *in, int64_t n, uint32_t *out, uint32_t *mail = nullptr, uint32_t stamp = 0, int nsub = 1 /* values per item (scan_item) */)
+static int launch_scan_u32(ctk_handle *h, const uint32_t *in, int64_t n, uint32_t *out, uint32_t *mail = nullptr, uint32_t stamp = 0)
 {
     hipStream_t s = h->stream;
     uint32_t *ovf = (uint32_t *)h->counters.p + CTK_CNT_OVERFLOW;
-    if (n <= 16 * CTK_SCAN_BLOCK) { k_scan_u32<<<1, 1024, 0, s>>>(in, n, out, ovf, mail, nullptr, stamp, nsub); return CTK_OK; }
+    if (n <= 16 * CTK_SCAN_BLOCK) { k_scan_u32<<<1, 1024, 0, s>>>(in, n, out, ovf, mail, nullptr, stamp); return CTK_OK; }
     const int nb = (int)((n + CTK_SCAN_BLOCK - 1) / CTK_SCAN_BLOCK);
     CTKCHK(ensure(h, h->scan_bsum, (size_t)nb * 12));
     uint64_t *bsum = (uint64_t *)h->scan_bsum.p;
     uint32_t *bmax = (uint32_t *)(bsum + nb);
-    k_scan_blocks_sum<<<nb, CTK_SCAN_BLOCK, 0, s>>>(in, n, bsum, bmax, nsub);
-    k_scan_blocks<<<nb, CTK_SCAN_BLOCK, 0, s>>>(in, n, out, ovf, bsum, bmax, mail, stamp, nsub);
+    k_scan_blocks_sum<<<nb, CTK_SCAN_BLOCK, 0, s>>>(in, n, bsum, bmax);
+    k_scan_blocks<<<nb, CTK_SCAN_BLOCK, 0, s>>>(in, n, out, ovf, bsum, bmax, mail, stamp);
     return CTK_OK;
 }
 
-static int thr_variant_env() { static const int v = getenv("CTK_THRESHOLD") ? atoi(getenv("CTK_THRESHOLD")) : 7; return v; }
 static int threshold_rows(int ny, int nx, int64_t T)
 {
     (void)nx; (void)T;
@@ -909,16 +877,6 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     CTKCHK(ensure(h, h->wstart, (size_t)nrows * W * 2));
     CTKCHK(ensure(h, h->rowstart, (size_t)nrows * 4));
     CTKCHK(ensure(h, h->tcount, (size_t)T * 4));
-    // round 6: the float4 threshold kernel delivers the run counts with the mask (k_threshold_v7rc) where its chunk of rows fits
-    // the kernel's LDS tables and a plane has at most 64 chunks; k_rowcount serves the rest.  k_label2d loads both kinds of table
-    // unconditionally, so both exist.
-    const int rbt_rc = threshold_rows(ny, nx, T);
-    const int nchunk_rc = (ny + rbt_rc - 1) / rbt_rc;
-    static const bool rc_env = !(getenv("CTK_THR_RC") && atoi(getenv("CTK_THR_RC")) == 0);
-    h->rc_mode = rc_env && T > 0 && !f64 && (nx % 4 == 0) && (!anom_dev || (((uintptr_t)anom_dev & 15) == 0)) && T * nchunk_rc < (1 << 24) &&
-                 thr_variant_env() == 7 && (rbt_rc & (rbt_rc - 1)) == 0 && rbt_rc <= 64 && rbt_rc * W <= CTK_RC_WORDS && nchunk_rc <= 64;
-    CTKCHK(ensure(h, h->rowrel, (size_t)nrows * 2));
-    CTKCHK(ensure(h, h->chunkcnt, (size_t)std::max<int64_t>(T * nchunk_rc, 1) * 4));
     CTKCHK(ensure(h, h->run_base, (size_t)(T + 1) * 4));
     CTKCHK(ensure(h, h->ncomp, (size_t)T * 4));
     CTKCHK(ensure(h, h->cprefix, (size_t)(T + 2) * 4));                  // [-1] = 0: the halo components of a time shard come first
@@ -950,7 +908,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
             uint64_t *mk = P<uint64_t>(h->mask) + t0 * ny * W;
             uint32_t *zc = t0 == 0 ? P<uint32_t>(h->counters) : nullptr;
             // ballot form: float32, rows of at most 64 words
-            const int thr_variant = thr_variant_env();
+            static const int thr_variant = getenv("CTK_THRESHOLD") ? atoi(getenv("CTK_THRESHOLD")) : 7;
             const bool v6 = !f64 && W <= 64 && (thr_variant == 6 || !v4);      // ballot form: where the float4 form does not apply (or on request)
             // k_threshold_v7: loads per lane and step such that the steps of a full chunk carry the fewest idle loads
             int u7 = 8;
@@ -964,10 +922,6 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
             const int thr_xcd = h->xcd_thr >= 0 ? h->xcd_thr : (h->xcd_thr_tuned >= 0 ? h->xcd_thr_tuned : ctk_env().xcd_thr);
             static const bool thr_nostore_env = getenv("CTK_THR_STORE") && atoi(getenv("CTK_THR_STORE")) == 2;      // (probes: the kernel without its stores)
             const bool thr_probe = h->thr_probe || h->thr_nostore || thr_nostore_env;                       // a launch of the mask placement check: its own kernel name
-            // (the launches of the mask placement check keep the plain form: the pass' own launch follows and writes the tables)
-            const bool rc_launch = h->rc_mode && !thr_probe;
-            if (h->rc_mode && !v4) return ctk_set_error(CTK_E_INTERNAL, "stage 1: a chunk of the slab does not fit the float4 threshold kernel");
-            const ThrRC trc = {P<uint16_t>(h->wstart) + t0 * ny * W, P<uint16_t>(h->rowrel) + t0 * ny, P<uint32_t>(h->chunkcnt) + t0 * nchunk_rc};
             static const int64_t g6max = getenv("CTK_THR_GRID") ? atoll(getenv("CTK_THR_GRID")) : 16384;
             const unsigned g6 = (unsigned)std::min<int64_t>((nchunks + 3) / 4, g6max);
 #define LAUNCH_THR(OP)                                                                                                                      \
@@ -977,11 +931,6 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         else if (v4 && thr_variant == 44) k_threshold_v4<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
         else if (v4 && thr_variant == 42) k_threshold_v4<OP, 2><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
         else if (v4 && thr_variant == 4) k_threshold_v4<OP><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc); \
-        else if (v4 && rc_launch && u7 == 4) k_threshold_v7rc<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd, trc); \
-        else if (v4 && rc_launch && u7 == 5) k_threshold_v7rc<OP, 5><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd, trc); \
-        else if (v4 && rc_launch && u7 == 6) k_threshold_v7rc<OP, 6><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd, trc); \
-        else if (v4 && rc_launch && u7 == 7) k_threshold_v7rc<OP, 7><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd, trc); \
-        else if (v4 && rc_launch) k_threshold_v7rc<OP, 8><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd, trc); \
         else if (v4 && u7 == 4 && thr_probe) k_threshold_probe<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd, (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
         else if (v4 && u7 == 4) k_threshold_v7<OP, 4><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd); \
         else if (v4 && u7 == 5 && thr_probe) k_threshold_probe<OP, 5><<<g4, 256, 0, s>>>((const float *)src, P<float>(h->thr32) + t0, ny, nx, W, mk, rbt, zc, thr_xcd, (h->thr_nostore || thr_nostore_env) ? 1 : 0); \
@@ -1023,9 +972,8 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         if (anom_dev && h->mask_check_pending && (check_first || !mask_fresh) && h->mask_off_dbg < 0 && ctk_env().mask_tune && v7_path &&
             (size_t)T * ny * nx * 4 >= ((size_t)128 << 20)) {
             h->mask_check_pending = false;
-            const double check_t0 = now_ms();
             h->mask_spacer_gb = 0.0;
-            struct CheckTime { ctk_handle *h; double t0; ~CheckTime() { h->mask_check_ms = now_ms() - t0; } } check_time{h, check_t0};
+            struct CheckTime { ctk_handle *h; double t0; ~CheckTime() { h->mask_check_ms = now_ms() - t0; } } check_time{h, now_ms()};
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
                 const size_t mbytes = (size_t)nrows * W * 8;
@@ -1065,8 +1013,8 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                     if (rc == CTK_OK && (ro2 > 1.04 * ro_ms || ro_ms > 1.04 * ro2 || best_ms < 0.98 * std::min(ro_ms, ro2))) { best_ms = 0.0; h->mask_tries = 0; if (++h->mask_check_retries <= 3) h->mask_check_pending = true; }      // (inconclusive: no search now; up to three later calls try again)
                     else ro_ms = std::min(ro_ms, ro2);
                 } else if (rc == CTK_OK && best_ms < 0.98 * ro_ms) h->mask_tries = 0;
-                // Round 6 (verdict item 4): the search is BOUNDED -- at most one other allocation, behind one spacer of at most 1 GB that is
-                // released before the call goes on, nothing is ever kept alive besides the mask itself (round 5 tried up to five
+                // Round 6 (verdict item 4): the search is BOUNDED -- at most one other allocation, behind one spacer of 1 GB that is
+                // released before the call goes on; nothing is ever kept alive besides the mask itself (round 5 tried up to five
                 // allocations behind 29 GB of spacers and two 6 GB arenas; on the boxes where it mattered it found nothing, and what it
                 // cost a caller's second call was recorded nowhere).  Its host time and the spacer it held are in the statistics
                 // (CTK_S_MASK_CHECK_US, CTK_S_MASK_SPACER_MB).  Where the first two candidates share the slab's class the kernel runs
@@ -1104,21 +1052,6 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         if (anom_dev) CTKCHK(launch_threshold(anom_dev, 0, T));
         else CTKCHK(stream_in(h, f64, T, ny, nx, launch_threshold));                     // the slab arrives in chunks (ctk_track_stream_*)
     }
-    if (T > 0 && h->early_flag) {
-        // the background of `flag`, on its own stream, underneath everything between here and the write kernel (k_flag_zero)
-        static const int zgrid_env = getenv("CTK_ZERO_GRID") ? atoi(getenv("CTK_ZERO_GRID")) : 0;
-        const int64_t n16 = T * (int64_t)ny * (nx / 4);
-        const int zgrid = (int)std::min<int64_t>(zgrid_env > 0 ? zgrid_env : 4 * h->n_cus, std::max<int64_t>(1, (n16 + 2047) / 2048));
-        HIPCHK(hipEventRecord(h->ev_zfork, s));
-        HIPCHK(hipStreamWaitEvent(h->zstream, h->ev_zfork, 0));
-        const bool tz = h->ev_ready && h->timing >= 1;
-        if (tz) (void)hipEventRecord(h->ev_z[0], h->zstream);
-        k_flag_zero<<<zgrid, 256, 0, h->zstream>>>(reinterpret_cast<i32x4 *>(h->early_flag), n16);
-        if (tz) { (void)hipEventRecord(h->ev_z[1], h->zstream); h->ev_z_used = true; }
-        HIPCHK(hipEventRecord(h->ev_zjoin, h->zstream));
-        HIPCHK(hipGetLastError());
-        h->zero_pending = true;
-    }
     // The host learns the run totals from the scan kernel's block of scalars in pinned memory and knows that it is complete by
     // the stamp the kernel writes last (an event record after the kernel is a command of its own: 5 us of stream time).
     const uint32_t scan_stamp = (uint32_t)(h->pass_no & 0x7fffffffu) | 0x80000000u;
@@ -1130,9 +1063,8 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         static const int rc_env = getenv("CTK_RC_THREADS") ? atoi(getenv("CTK_RC_THREADS")) : 0;      // (experiments)
         // (throughput regime, small planes -- 438 000 x 192 x 288: 128 threads 1.39 -> 0.86 ms, 64: 1.02)
         const int rc_threads = rc_env > 0 ? rc_env : ((W <= 64 && ny <= RC_ROWS && ny > 256 && T <= 2048) ? 512 : ((T > 65536 && (int64_t)ny * W <= 2048) ? 128 : 256));
-        if (T > 0 && !h->rc_mode) k_rowcount<<<(int)T, rc_threads, 0, s>>>(P<uint64_t>(h->mask), ny, W, P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart), P<uint32_t>(h->tcount));
-        if (h->rc_mode) CTKCHK(launch_scan_u32(h, P<uint32_t>(h->chunkcnt), T, P<uint32_t>(h->run_base), h->h_mail1, scan_stamp, nchunk_rc));
-        else CTKCHK(launch_scan_u32(h, P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), h->h_mail1, scan_stamp));
+        if (T > 0) k_rowcount<<<(int)T, rc_threads, 0, s>>>(P<uint64_t>(h->mask), ny, W, P<uint16_t>(h->wstart), P<uint32_t>(h->rowstart), P<uint32_t>(h->tcount));
+        CTKCHK(launch_scan_u32(h, P<uint32_t>(h->tcount), T, P<uint32_t>(h->run_base), h->h_mail1, scan_stamp));
         HIPCHK(hipGetLastError());
     }
     // 2-D labelling.  The variants take disjoint sets of timesteps (by run count; nruns == 0 goes to the small one) and
@@ -1158,9 +1090,6 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         a.ny = ny; a.nx = nx; a.W = W; a.lds_cap = CTK_LDS_RUNS; a.cap_runs = cap_runs;
         a.g_x0 = P<uint16_t>(h->g_x0); a.g_x1 = P<uint16_t>(h->g_x1); a.g_y = P<uint16_t>(h->g_y);
         a.g_parent = P<uint32_t>(h->g_parent); a.g_root = P<uint32_t>(h->g_root); a.g_idmap = P<uint32_t>(h->g_idmap);
-        a.rowrel = P<uint16_t>(h->rowrel); a.rowstart_w = P<uint32_t>(h->rowstart); a.rc = h->rc_mode ? 1 : 0;
-        a.chunkcnt = h->rc_mode ? P<uint32_t>(h->chunkcnt) : P<uint32_t>(h->tcount); a.nchunk = h->rc_mode ? nchunk_rc : 1;
-        a.cshift = 0; while ((1 << a.cshift) < rbt_rc) a.cshift++;
         if (vs.one) k_label2d_lds<4096, 512, -1, 1024><<<(int)T, 1024, 0, s>>>(a);
         if (vs.v2 || vs.v3) HIPCHK(hipEventRecord(h->ev_fork, s));
         if (vs.v1) {
@@ -1222,7 +1151,6 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     h->stats[CTK_S_RUNS] = h->total_runs; h->stats[CTK_S_MAX_RUNS_STEP] = h->max_runs_step;
     h->stats[CTK_S_MASK_TRIES] = h->mask_tries; h->stats[CTK_S_MASK_RATIO] = (int64_t)(h->mask_ratio * 1000.0 + 0.5);      // (sticky: of the last placement check)
     h->stats[CTK_S_MASK_CHECK_US] = (int64_t)(h->mask_check_ms * 1000.0 + 0.5); h->stats[CTK_S_MASK_SPACER_MB] = (int64_t)(h->mask_spacer_gb * 1024.0 + 0.5);
-    h->stats[CTK_S_EARLY_ZERO] = h->zero_pending ? 1 : 0;
     const size_t R = h->total_runs;
     const bool fits = spec && R <= h->runs_cap;
     if (!fits) {
@@ -2060,40 +1988,11 @@ static int32_t *chunk_vals_for(ctk_handle *h, const int32_t *flag_dev, int *rows
     return P<int32_t>(h->chunk_vals);
 }
 
-// the write kernel of the fused one-call pass when k_flag_zero wrote the background (round 6): only the words that hold foreground
-static int launch_relabel_sparse(ctk_handle *h, int persistence, int32_t *flag_dev)
-{
-    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_zjoin, 0));
-    h->zero_pending = false;
-    Timer tm(h, CTK_K_RELABEL);
-    RelabelArgs a;
-    memset(&a, 0, sizeof(a));
-    a.mask = P<uint64_t>(h->mask); a.wstart = P<uint16_t>(h->wstart); a.rowstart = P<uint32_t>(h->rowstart); a.run_base = P<uint32_t>(h->run_base);
-    a.run_val = P<int32_t>(h->run_val); a.ext = P<int32_t>(h->ext); a.n_labels = h->n_labels; a.persistence = persistence; a.t_begin = h->t_begin;
-    a.fold = fold_args(h); a.flag = flag_dev; a.counters = P<uint32_t>(h->counters);
-    a.nrows = h->T * h->ny; a.ny = h->ny; a.nx = h->nx; a.W = h->W;
-    a.guard = h->guard_on ? P<uint32_t>(h->counters) : nullptr;
-    static const int iters_env = getenv("CTK_SPARSE_ITERS") ? atoi(getenv("CTK_SPARSE_ITERS")) : 0;
-    static const bool all16 = !(getenv("CTK_SPARSE_ALL16") && atoi(getenv("CTK_SPARSE_ALL16")) == 0);
-    const int64_t nwp = (int64_t)h->ny * h->W;
-    int iters = iters_env > 0 ? (iters_env + 3) / 4 * 4 : 4;
-    while (iters_env <= 0 && h->T * ((nwp + 16 * iters - 1) / (16 * iters)) > (1 << 21)) iters *= 2;      // (long shards of small planes: fewer, longer workgroups)
-    const int64_t nseg = (nwp + 16 * (int64_t)iters - 1) / (16 * (int64_t)iters);
-    if (h->T * nseg >= (1 << 24)) return ctk_set_error(CTK_E_RANGE, "write kernel: more than 2^24 workgroups");
-    const unsigned grid = (unsigned)(h->T * nseg);
-    if (all16) k_relabel_sparse<true><<<grid, 256, 0, h->stream>>>(a, (int)nseg, iters, 16 / h->W, 16 % h->W);
-    else k_relabel_sparse<false><<<grid, 256, 0, h->stream>>>(a, (int)nseg, iters, 16 / h->W, 16 % h->W);
-    h->stats[CTK_S_RELABEL_KERNEL] = 6;
-    HIPCHK(hipGetLastError());
-    return CTK_OK;
-}
-
 // timesteps [t0, t0 + nt) of the shard into flag_dev (which starts at t0); nt < 0: the whole shard
 static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, bool with_fold, const int32_t *chunk_vals = nullptr, int64_t t0 = 0, int64_t nt = -1)
 {
     if (h->rle_out) { h->stats[CTK_S_RELABEL_KERNEL] = -1; return CTK_OK; }      // the result leaves as run tables (deliver_runs expands them on the host)
     if (nt < 0) nt = h->T;
-    if (h->zero_pending) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_zjoin, 0)); h->zero_pending = false; }      // (the dense kernel writes every pixel: only the order matters)
     RelabelArgs a;
     const int rb = relabel_rows(h);                                   // (of the whole shard: the chunk values were built for it)
     const int64_t nchunk = (h->ny + rb - 1) / rb;
@@ -2323,9 +2222,8 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     }
     CTKCHK(launch_extents(h, true, true));
     h->state = ST_EXTENTS;
-    const bool sparse = h->zero_pending && flag_dev && flag_dev == h->early_flag;      // (k_flag_zero is writing the background: the write kernel stores foreground words only)
     int cv_rows = 0;
-    int32_t *cv = sparse ? nullptr : chunk_vals_for(h, flag_dev, &cv_rows);
+    int32_t *cv = chunk_vals_for(h, flag_dev, &cv_rows);
     {
         Timer tm(h, CTK_K_RUNLABEL);
         // (one wave per plane in the throughput regime with few runs per plane: 438 000 x 192 x 288 1.19 -> 0.63 ms)
@@ -2335,8 +2233,7 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
                                             P<uint32_t>(h->rv_boff) + nsb, P<uint32_t>(h->seam_off) /* t_alive: [T + 1], unused on this path otherwise */);
         HIPCHK(hipGetLastError());
     }
-    if (sparse) CTKCHK(launch_relabel_sparse(h, persistence, flag_dev));
-    else {
+    {
         Timer tm(h, CTK_K_RELABEL);
         CTKCHK(launch_relabel(h, persistence, flag_dev, true, cv));
     }
@@ -2429,7 +2326,6 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
 static void tune_relabel(ctk_handle *h, int persistence, int32_t *flag_dev)
 {
     if (h->xcd_rel >= 0 || !ctk_env().mask_tune || h->sio || h->rle_out || !flag_dev || h->state != ST_TABLES) return;
-    if (h->stats[CTK_S_RELABEL_KERNEL] == 6) return;                  // (the sparse write kernel has no chunk -> XCD mapping)
     // once per SHAPE (round 4 also keyed on the output pointer: a caller that alternates output buffers re-tuned on every call --
     // advisor finding); slabs beyond 8 GB keep the launch order (nine extra passes of the write kernel would cost ~100 ms at
     // 14 600 x 721 x 1440, where launch order measured best anyway)
@@ -2469,20 +2365,7 @@ static int track_dev_impl(ctk_handle *h, const void *anom_dev, bool f64, int64_t
     const double t0 = now_ms();
     HT0();
     h->in_one_call = true;
-    // (never leaves with the zero fill in flight: the caller owns `flag` again when the call returns, whatever the return code)
-    struct OneCall { ctk_handle *h; ~OneCall() { h->in_one_call = false; h->early_flag = nullptr; if (h->zero_pending) { (void)hipStreamSynchronize(h->zstream); h->zero_pending = false; } } } one_call{h};
-    {
-        // Early zero fill + sparse write kernel: a dense device-resident result of the fused one-call pass, 16-byte rows; from 32 MB
-        // (below that the fork / join of the side stream costs what the overlap returns).  CTK_EARLY_ZERO=0: the dense write kernel.
-        static const int ez_env = getenv("CTK_EARLY_ZERO") ? atoi(getenv("CTK_EARLY_ZERO")) : 1;
-        static const int64_t ez_min = getenv("CTK_EARLY_ZERO_MIN_MB") ? atoll(getenv("CTK_EARLY_ZERO_MIN_MB")) : 32;
-        if (h->use_async < 0) { const char *e = getenv("CTK_ASYNC"); h->use_async = (e && atoi(e) == 0) ? 0 : 1; }
-        const bool fused_wanted = h->use_device_resolve && h->use_async == 1 && !h->sio && T >= 1 && !(h->async_off_ny == ny && h->async_off_nx == nx);
-        h->early_flag = nullptr;
-        if (ez_env && fused_wanted && flag_dev && anom_dev && !h->rle_out && (nx % 4 == 0) && (((uintptr_t)flag_dev & 15) == 0) && (int64_t)ny * nx < 0x7fffffff &&
-            T * (int64_t)ny * nx * 4 >= (ez_min << 20) && ctk_env().relabel_rows == 0 && !ctk_env().relabel_v4)
-            h->early_flag = flag_dev;
-    }
+    struct OneCall { ctk_handle *h; ~OneCall() { h->in_one_call = false; } } one_call{h};
     CTKCHK(shard_label2d_impl(h, anom_dev, f64, T, ny, nx, thr, cmp_op, wrow, 0));
     HT("label2d stage done");
     CTKCHK(ctk_shard_overlap(h));

@@ -247,26 +247,11 @@ __device__ __forceinline__ uint32_t thr_nibble(const f32x4 v, const float th)
 
 // U = loads per lane and step, picked by the host so that the steps of a chunk are (nearly) full: no predicates around the loads
 // (a conditional load made hipcc wait for every load before issuing the next one), lanes beyond the chunk re-read its last row.
-// RC (round 6): the run counts leave with the mask.  A workgroup owns whole rows, so once its words are assembled it knows, per word,
-// the run starts to the left in the row (wstart), per row the run starts above it inside the chunk (rowrel) and the chunk's total
-// (chunkcnt) -- what k_rowcount derived from a second pass over the mask (14 us and a 23 MB re-read at 2707 x 181 x 360).  The words
-// are kept in LDS on their way out (at most CTK_RC_WORDS per chunk: 8 KB); three barriers at the end of a workgroup that streamed
-// 23 KB.  The prefix over a plane's chunks is a dozen additions that k_label2d does on its way in (it writes rowstart); the run scan
-// sums the chunk counts.
-#define CTK_RC_WORDS 1024
-struct ThrRC {
-    uint16_t *wstart;              // [T][ny][W]
-    uint16_t *rowrel;              // [T][ny]      run starts in the rows above, inside the chunk of rb rows
-    uint32_t *chunkcnt;            // [T][nchunk]  run starts of the chunk
-};
-template <int OP, int U, bool RC = false>
+template <int OP, int U>
 __device__ __forceinline__ void threshold_v7_body(const float *__restrict__ anom, const float *__restrict__ thr32,
                                                   int ny, int nx, int W, uint64_t *__restrict__ mask, int rb,
-                                                  uint32_t *__restrict__ zero_counters, int xcd, int nostore, const ThrRC rc = ThrRC{nullptr, nullptr, nullptr})
+                                                  uint32_t *__restrict__ zero_counters, int xcd, int nostore)
 {
-    __shared__ uint64_t lw[RC ? CTK_RC_WORDS : 1];
-    __shared__ uint16_t lcnt[RC ? CTK_RC_WORDS : 1];
-    __shared__ uint32_t lrow[RC ? 64 : 1];
     if (zero_counters && blockIdx.x == 0 && threadIdx.x < CTK_CNT_ZEROED) zero_counters[threadIdx.x] = 0u;
     const int nchunk = (ny + rb - 1) / rb;
     const unsigned bid = xcd_chunk(blockIdx.x, gridDim.x, xcd);
@@ -306,45 +291,9 @@ __device__ __forceinline__ void threshold_v7_body(const float *__restrict__ anom
             x = dpp_or<0x141>(x);                          // row_half_mirror: every lane of a half row holds its half
             const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false);      // row_mirror: lane 0 <- lane 15
             // (nostore: the kernel without its 1/32 write stream -- the yardstick of the mask placement check, ctk_api.hip)
-            if (sub == 0 && moff[u] != 0xffffffffu && !nostore) {
-                const uint64_t word = ((uint64_t)hi << 32) | x;
-                *reinterpret_cast<uint64_t *>(mbase + moff[u]) = word;
-                if (RC) lw[moff[u] >> 3] = word;
-            }
+            if (sub == 0 && moff[u] != 0xffffffffu && !nostore) *reinterpret_cast<uint64_t *>(mbase + moff[u]) = ((uint64_t)hi << 32) | x;
         }
     }
-    if (RC) {
-        __syncthreads();
-        const int nwc = rows * W;
-        for (int k = tid; k < nwc; k += 256) {
-            const uint64_t m = lw[k];
-            const int y = k / W, w = k - y * W;
-            const uint64_t left = w > 0 ? (lw[k - 1] >> 63) : 0ull;
-            lcnt[k] = (uint16_t)__popcll(m & ~((m << 1) | left));
-        }
-        __syncthreads();
-        for (int k = tid; k < nwc; k += 256) {
-            const int y = k / W, w = k - y * W;
-            uint32_t pre = 0;
-            for (int j = 0; j < w; j++) pre += lcnt[y * W + j];
-            rc.wstart[row0 * W + k] = (uint16_t)pre;
-            if (w == W - 1) lrow[y] = pre + lcnt[k];
-        }
-        __syncthreads();
-        if (tid < rows) {
-            uint32_t rel = 0;
-            for (int j = 0; j < tid; j++) rel += lrow[j];
-            rc.rowrel[row0 + tid] = (uint16_t)rel;
-            if (tid == rows - 1) rc.chunkcnt[bid] = rel + lrow[tid];
-        }
-    }
-}
-template <int OP, int U>
-__global__ __launch_bounds__(256) void k_threshold_v7rc(const float *__restrict__ anom, const float *__restrict__ thr32,
-                                                        int ny, int nx, int W, uint64_t *__restrict__ mask, int rb,
-                                                        uint32_t *__restrict__ zero_counters, int xcd, ThrRC rc)
-{
-    threshold_v7_body<OP, U, true>(anom, thr32, ny, nx, W, mask, rb, zero_counters, xcd, 0, rc);
 }
 template <int OP, int U>
 __global__ __launch_bounds__(256) void k_threshold_v7(const float *__restrict__ anom, const float *__restrict__ thr32,
@@ -597,19 +546,9 @@ __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v)
 }
 
 // base_ptr (time shards): the scan starts at *base_ptr (the number of halo components) and out[-1] = 0
-// item i of a scan: in[i], or -- nsub > 1: the chunk counts of k_threshold_v7rc -- the sum of the nsub values of timestep i
-__device__ __forceinline__ uint32_t scan_item(const uint32_t *__restrict__ in, int64_t i, int nsub)
-{
-    if (nsub <= 1) return in[i];
-    uint32_t v = 0;
-    const uint32_t *q = in + i * nsub;
-    for (int j = 0; j < nsub; j++) v += q[j];
-    return v;
-}
 __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ in, int64_t n,
                                                    uint32_t *__restrict__ out, uint32_t *ovf, uint32_t *mail = nullptr,
-                                                   const uint32_t *base_ptr = nullptr, uint32_t stamp = 0 /* written to mail[4] after the rest: the host polls for it */,
-                                                   int nsub = 1)
+                                                   const uint32_t *base_ptr = nullptr, uint32_t stamp = 0 /* written to mail[4] after the rest: the host polls for it */)
 {
     __shared__ uint64_t wsum[16];
     __shared__ uint32_t wmax[16];
@@ -618,7 +557,7 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ 
     const int64_t b = min(n, (int64_t)tid * per), e = min(n, b + per);
     uint64_t s = 0;
     uint32_t mx = 0;
-    for (int64_t i = b; i < e; i++) { const uint32_t v = scan_item(in, i, nsub); s += v; mx = max(mx, v); }
+    for (int64_t i = b; i < e; i++) { const uint32_t v = in[i]; s += v; mx = max(mx, v); }
     uint64_t inc = wave_incl_scan_u64(s);
     if (lane == WAVE - 1) wsum[wv] = inc;
     if (mail) {
@@ -630,7 +569,7 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ 
     if (base_ptr && tid == 0) out[-1] = 0u;
     for (int i = 0; i < wv; i++) base += wsum[i];
     uint64_t run = base + inc - s;
-    for (int64_t i = b; i < e; i++) { out[i] = (uint32_t)run; run += scan_item(in, i, nsub); }
+    for (int64_t i = b; i < e; i++) { out[i] = (uint32_t)run; run += in[i]; }
     if (tid == 1023) {
         out[n] = (uint32_t)run;
         if (run > 0xffffffffull) atomicOr(ovf, CTK_OVF_RUNS);
@@ -639,7 +578,7 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ 
             // and the last item (total - last = out[n-1])
             uint32_t m = 0;
             for (int i = 0; i < 16; i++) m = max(m, wmax[i]);
-            mail[0] = (uint32_t)run; mail[1] = m; mail[2] = run > 0xffffffffull ? CTK_OVF_RUNS : 0u; mail[3] = n > 0 ? scan_item(in, n - 1, nsub) : 0u;
+            mail[0] = (uint32_t)run; mail[1] = m; mail[2] = run > 0xffffffffull ? CTK_OVF_RUNS : 0u; mail[3] = n > 0 ? in[n - 1] : 0u;
             if (stamp) { __threadfence_system(); __hip_atomic_store(&mail[4], stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
         }
     }
@@ -649,12 +588,12 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ 
 // sums and maxima first (k_scan_blocks_sum), then every workgroup scans its 1024 items behind the sum of the blocks in front of it.
 // The mail (total, largest item, overflow, last item, stamp) is written by the workgroup of the last block, from the block sums alone.
 #define CTK_SCAN_BLOCK 1024
-__global__ __launch_bounds__(CTK_SCAN_BLOCK) void k_scan_blocks_sum(const uint32_t *__restrict__ in, int64_t n, uint64_t *__restrict__ bsum, uint32_t *__restrict__ bmax, int nsub = 1)
+__global__ __launch_bounds__(CTK_SCAN_BLOCK) void k_scan_blocks_sum(const uint32_t *__restrict__ in, int64_t n, uint64_t *__restrict__ bsum, uint32_t *__restrict__ bmax)
 {
     __shared__ uint64_t ws[CTK_SCAN_BLOCK / 64];
     __shared__ uint32_t wm[CTK_SCAN_BLOCK / 64];
     const int64_t i = (int64_t)blockIdx.x * CTK_SCAN_BLOCK + threadIdx.x;
-    const uint32_t v = i < n ? scan_item(in, i, nsub) : 0u;
+    const uint32_t v = i < n ? in[i] : 0u;
     uint64_t s = v;
     uint32_t m = v;
     for (int o = 32; o > 0; o >>= 1) { s += (uint64_t)__shfl_xor((unsigned long long)s, o); m = max(m, (uint32_t)__shfl_xor((int)m, o)); }
@@ -667,7 +606,7 @@ __global__ __launch_bounds__(CTK_SCAN_BLOCK) void k_scan_blocks_sum(const uint32
     }
 }
 __global__ __launch_bounds__(CTK_SCAN_BLOCK) void k_scan_blocks(const uint32_t *__restrict__ in, int64_t n, uint32_t *__restrict__ out, uint32_t *ovf,
-                                                                const uint64_t *__restrict__ bsum, const uint32_t *__restrict__ bmax, uint32_t *mail, uint32_t stamp, int nsub = 1)
+                                                                const uint64_t *__restrict__ bsum, const uint32_t *__restrict__ bmax, uint32_t *mail, uint32_t stamp)
 {
     __shared__ uint64_t ws[CTK_SCAN_BLOCK / 64];
     __shared__ uint32_t wm[CTK_SCAN_BLOCK / 64];
@@ -689,7 +628,7 @@ __global__ __launch_bounds__(CTK_SCAN_BLOCK) void k_scan_blocks(const uint32_t *
     for (int k = 0; k < CTK_SCAN_BLOCK / 64; k++) mall = max(mall, wm[k]);
     __syncthreads();
     const int64_t i = (int64_t)b * CTK_SCAN_BLOCK + tid;
-    const uint32_t v = i < n ? scan_item(in, i, nsub) : 0u;
+    const uint32_t v = i < n ? in[i] : 0u;
     const uint64_t inc = wave_incl_scan_u64((uint64_t)v);
     if (lane == WAVE - 1) ws[wv] = inc;
     __syncthreads();
@@ -743,23 +682,7 @@ struct Label2dArgs {
     // global scratch for the fallback variant (indexed by run_base[t] + r)
     uint16_t *g_x0, *g_x1, *g_y;
     uint32_t *g_parent, *g_root, *g_idmap;
-    // round 6: the row starts come from k_threshold_v7rc's tables -- rowstart[t][y] = (runs of the plane's chunks in front of the
-    // row's chunk) + rowrel[t][y] -- and are written to rowstart_w for everybody behind this kernel.  rowrel == nullptr: k_rowcount
-    // wrote `rowstart` (grids the float4 threshold kernel does not take).  Chunks of 1 << cshift rows, nchunk <= 64 per plane.
-    const uint16_t *rowrel;
-    const uint32_t *chunkcnt;
-    uint32_t *rowstart_w;
-    int rc, cshift, nchunk;        // (both sets of pointers are always valid and both are loaded -- a load under a condition costs a full wait -- `rc` selects)
 };
-
-// lane j of every wave: runs of the plane in the chunks in front of chunk j (exclusive prefix of the plane's chunk counts)
-__device__ __forceinline__ uint32_t l2d_chunk_prefix(const Label2dArgs &a, int t)
-{
-    const int lane = lane_id();
-    const uint32_t c = a.chunkcnt[(int64_t)t * a.nchunk + min(lane, a.nchunk - 1)];
-    const uint32_t v = lane < a.nchunk ? c : 0u;
-    return wave_incl_scan_u32(v) - v;
-}
 
 #ifdef CTK_PHASE_TIMING
 __device__ unsigned long long g_phase_t[16];
@@ -787,15 +710,7 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
     PHASE_MARK(0);
     // ---- phase 1: rowstart (computed by k_rowcount) -> LDS/scratch -------------------------------
     if (NW == 0) {                                                      // (else: the caller did, together with the mask words)
-        if (a.rc) {
-            const uint32_t cpre = l2d_chunk_prefix(a, t);
-            for (int y0 = 0; y0 < ny; y0 += THREADS) {                  // (whole waves enter: the prefix travels by shuffle)
-                const int y = y0 + tid, yc = min(y, ny - 1);
-                const uint32_t v = (uint32_t)__shfl((int)cpre, yc >> a.cshift) + a.rowrel[(int64_t)t * ny + yc];
-                if (y < ny) { rs[y] = (IT)v; a.rowstart_w[(int64_t)t * ny + y] = v; }
-            }
-        } else
-            for (int y = tid; y < ny; y += THREADS) rs[y] = (IT)a.rowstart[(int64_t)t * ny + y];
+        for (int y = tid; y < ny; y += THREADS) rs[y] = (IT)a.rowstart[(int64_t)t * ny + y];
         if (tid == 0) rs[ny] = (IT)nruns;
     }
     __syncthreads();
@@ -1045,35 +960,19 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 || NYCAP < CTK_LDS_NY) ? 
         uint64_t mreg[NW];
         uint32_t rreg[NW];
         L2dPrefetch<NW> pf;
-        const bool rc = a.rc != 0;
-        const uint16_t *rr = a.rowrel + (int64_t)t * a.ny;
-        const uint32_t cc = a.chunkcnt[(int64_t)t * a.nchunk + min((int)(threadIdx.x & 63), a.nchunk - 1)];
 #pragma unroll
         for (int u = 0; u < NW; u++) {
             const int k = min((int)threadIdx.x + u * THREADS, nwords - 1);
             mreg[u] = mg[k];
             pf.w[u] = wg[k];
-            const int yk = min((int)threadIdx.x + u * THREADS, a.ny - 1);       // (ny <= nwords: NW rows per thread cover them)
-            const uint32_t v16 = rr[yk], v32 = rg[yk];
-            rreg[u] = rc ? v16 : v32;
+            rreg[u] = rg[min((int)threadIdx.x + u * THREADS, a.ny - 1)];       // (ny <= nwords: NW rows per thread cover them)
         }
         const uint32_t nruns = rb1 - rb0;
         if (nruns > RUNS || (int64_t)nruns <= (int64_t)RUNS_BELOW || a.ny > NYCAP) return;    // another variant takes it
         if (rb1 > a.cap_runs) return;                                  // buffers too small: the host relaunches after growing them
         if (nruns == 0) {
             if (threadIdx.x == 0) { a.ncomp[t] = 0; a.seam_cnt[t] = 0; }
-            if (rc) for (int y = (int)threadIdx.x; y < a.ny; y += THREADS) a.rowstart_w[(int64_t)t * a.ny + y] = 0u;
             return;
-        }
-        if (rc) {                                                       // row start = runs of the chunks in front + runs above inside the chunk
-            const uint32_t cv = (int)(threadIdx.x & 63) < a.nchunk ? cc : 0u;
-            const uint32_t cpre = wave_incl_scan_u32(cv) - cv;
-#pragma unroll
-            for (int u = 0; u < NW; u++) {
-                const int yk = min((int)threadIdx.x + u * THREADS, a.ny - 1);
-                rreg[u] += (uint32_t)__shfl((int)cpre, yk >> a.cshift);
-                if ((int)threadIdx.x + u * THREADS < a.ny) a.rowstart_w[(int64_t)t * a.ny + yk] = rreg[u];
-            }
         }
 #pragma unroll
         for (int u = 0; u < NW; u++) {
@@ -1090,7 +989,6 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 || NYCAP < CTK_LDS_NY) ? 
     if (a.run_base[t + 1] > a.cap_runs) return;                    // buffers too small: the host relaunches after growing them
     if (nruns == 0) {
         if (threadIdx.x == 0) { a.ncomp[t] = 0; a.seam_cnt[t] = 0; }
-        if (a.rc) for (int y = (int)threadIdx.x; y < a.ny; y += THREADS) a.rowstart_w[(int64_t)t * a.ny + y] = 0u;
         return;
     }
     label2d_body<THREADS, uint16_t, COMPS>(a, t, nruns, x0, x1, yrow, parent, root, idmap, rs, sm_scan, mg, false, mlds, a.run_base[t], L2dPrefetch<0>());
@@ -1934,105 +1832,6 @@ __global__ __launch_bounds__(TH) void k_relabel_v5(RelabelArgs a, int rb, int rv
         if (s0 + sub < rows) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // the image is zeroed again
     }
     if (__ballot(z) && lane_id() == 0) ctk_zf_set(a.counters, blockIdx.x * (unsigned)(TH / 64) + (threadIdx.x >> 6));
-}
-
-// ------------------------------------------------------------------------------------------------
-// K7s  (round 6) the write pass in two parts.  Nine of ten pixels of `flag` are background, and which they are is irrelevant to
-// their value: k_flag_zero streams zeros over the whole slab on a SIDE stream, forked right behind k_threshold, while the
-// latency-bound middle of the pass (labelling, co-occurrence, resolver: ~0.2 ms that move ~0.3 TB/s) leaves the memory system idle;
-// k_relabel_sparse then writes only the 64-pixel words that hold foreground (a fifth of them).  The dense k_relabel_v5 -- 4 B/pixel
-// behind the last table kernel, 0.125 ms of the 0.46 ms pass at 2707 x 181 x 360 -- stays for the staged / time-shard / streaming
-// entries and as the fallback.
-//
-// k_relabel_sparse: 16 lanes per mask word (64 pixels = 256 B = one 16-byte store per lane), no LDS, no barrier: every wave is
-// independent and the kernel hides its two dependent trips (tables -> run values) by occupancy.  A workgroup takes `iters` x 16
-// consecutive words of one plane.  A lane's four pixels: run index = row start + run starts left of the word + run starts at or
-// below the pixel inside the word - 1 (as everywhere).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_flag_zero(i32x4 *__restrict__ dst, int64_t n16 /* 16-byte slots */)
-{
-    constexpr int U = 8;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + (U - 1) * stride < n16; i += U * stride) {
-#pragma unroll
-        for (int u = 0; u < U; u++) __builtin_nontemporal_store((i32x4)(0), dst + i + u * stride);
-    }
-    for (; i < n16; i += stride) __builtin_nontemporal_store((i32x4)(0), dst + i);
-}
-
-template <bool ALL16 /* every lane of a foreground word stores (whole 256-byte segments), not only the lanes that hold foreground */>
-__global__ __launch_bounds__(256) void k_relabel_sparse(RelabelArgs a, int nseg /* workgroups per plane */, int iters /* words per 16-lane group */,
-                                                        int q16, int r16 /* 16 / W, 16 % W */)
-{
-    if (ctk_guard_bad(a.guard)) return;
-    const int ny = a.ny, nx = a.nx, W = a.W;
-    const int t = (int)(blockIdx.x / (unsigned)nseg), seg = (int)(blockIdx.x - (unsigned)t * nseg);
-    const int tid = (int)threadIdx.x, grp = tid >> 4, sub = tid & 15;
-    const int nwp = ny * W;
-    const int64_t wbase = (int64_t)t * nwp;
-    const uint64_t *mk = a.mask + wbase;
-    const uint16_t *ws = a.wstart + wbase;
-    const uint32_t *rsp = a.rowstart + (int64_t)t * ny;
-    const int32_t *rv = a.run_val + a.run_base[t];
-    int32_t *frow = a.flag + (int64_t)t * ny * nx;
-    int idx = seg * iters * 16 + grp;
-    int y = idx / W, w = idx - y * W;                          // (once per thread; advanced without dividing)
-    const int tail = nx - (W - 1) * 64;
-    bool z = false;
-    constexpr int UN = 4;
-    for (int it = 0; it < iters; it += UN) {
-        uint64_t m[UN], ml[UN];
-        uint32_t pre[UN];
-        int yy[UN], ww[UN];
-#pragma unroll
-        for (int u = 0; u < UN; u++) {                         // trip 1: everything whose address is known
-            const int ic = min(idx, nwp - 1), yc = min(y, ny - 1);
-            m[u] = mk[ic];
-            ml[u] = mk[max(ic - 1, 0)];
-            pre[u] = rsp[yc] + ws[ic];
-            yy[u] = idx < nwp ? y : -1; ww[u] = w;
-            idx += 16; y += q16; w += r16;
-            if (w >= W) { w -= W; y++; }
-        }
-#pragma unroll
-        for (int u = 0; u < UN; u++) {
-            if (yy[u] < 0) continue;
-            const uint64_t mm = m[u];
-            const uint64_t valid = (ww[u] == W - 1 && tail < 64) ? ((1ull << tail) - 1ull) : FULL64;
-            if (mm != valid) z = true;                         // a background pixel in this word
-            if (mm == 0ull) continue;
-            const int x = ww[u] * 64 + sub * 4;
-            const uint32_t nib = (uint32_t)(mm >> (sub * 4)) & 0xfu;
-            if (x >= nx || (!ALL16 && nib == 0u)) continue;
-            i32x4 out = (i32x4)(0);
-            if (nib) {
-                const uint64_t cin = ww[u] > 0 ? (ml[u] >> 63) : 0ull;
-                const uint64_t st = mm & ~((mm << 1) | cin);
-                int32_t v[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {                  // trip 2: the run values (clamped index: nothing conditional around the loads)
-                    const int bit = sub * 4 + j;
-                    const uint64_t below = (bit == 63) ? FULL64 : ((1ull << (bit + 1)) - 1ull);
-                    const uint32_t k = (uint32_t)max((int)(pre[u] + (uint32_t)__popcll(st & below)) - 1, 0);      // (a set pixel: >= 0 by construction)
-                    v[j] = rv[k];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    int32_t val = ((nib >> j) & 1u) ? v[j] : 0;
-                    if (val < 0) {                             // complex component: fold this pixel
-                        const int32_t fl = fold_pixel(a.fold, -val, (int32_t)(a.t_begin + t), yy[u], x + j);
-                        val = ((int64_t)a.ext[a.n_labels + 1 + fl] - (int64_t)a.ext[fl] + 1 < a.persistence) ? 0 : fl;
-                    }
-                    if (((nib >> j) & 1u) && val == 0) z = true;
-                    v[j] = val;
-                }
-                out.x = v[0]; out.y = v[1]; out.z = v[2]; out.w = v[3];
-            }
-            __builtin_nontemporal_store(out, reinterpret_cast<i32x4 *>(frow + (int64_t)yy[u] * nx + x));
-        }
-    }
-    if (__ballot(z) && lane_id() == 0) ctk_zf_set(a.counters, blockIdx.x * 4u + (threadIdx.x >> 6));
 }
 
 __global__ __launch_bounds__(256) void k_relabel(RelabelArgs a)

@@ -267,8 +267,6 @@ int ctk_get_stats(ctk_handle *h, int64_t *out /* [CTK_NSTATS] */);
 /* statistics added after that are read with an explicit length: writes min(n, CTK_NSTATS_ALL) entries, returns CTK_OK */
 #define CTK_S_MASK_CHECK_US 25    /* host time of the last mask placement check, microseconds (bounded: at most one other allocation); sticky */
 #define CTK_S_MASK_SPACER_MB 26   /* device memory that check held as a spacer while it ran (freed before the call went on), MB; sticky */
-#define CTK_S_EARLY_ZERO    27    /* 1: the background of `flag` was written by k_flag_zero on a side stream underneath the table kernels and the
-                                   * write kernel stored the foreground words only (CTK_S_RELABEL_KERNEL = 6) */
 #define CTK_NSTATS_ALL      32
 int ctk_get_stats_n(ctk_handle *h, int64_t *out, int n);
 int ctk_get_timings(ctk_handle *h, double *ms /* [CTK_NTIMERS] */);

@@ -61,10 +61,6 @@ int ctk_debug_set_xcd(ctk_handle *h, int thr_mode, int rel_mode);
 /* experiments: threads (0 = default, 256 / 512 / 1024) and rows (0 = default) per workgroup of the write kernel k_relabel_v5 */
 int ctk_debug_set_relabel(ctk_handle *h, int threads, int rows);
 
-/* measurement support: event times of k_flag_zero (round 6: the background of `flag`, written on a side stream underneath the table
- * kernels; timing level >= 1), summed over the calls since the last reset, and the number of calls measured */
-int ctk_debug_zero_fill_ms(ctk_handle *h, double *sum_ms, int64_t *count, int reset);
-
 /* experiments: threads per workgroup (0 = default, 64 / 128 / 256) of the one-workgroup-per-timestep kernels k_extent, k_run_values,
  * k_compact_init of the one-call pass */
 int ctk_debug_set_small_threads(ctk_handle *h, int extent, int run_values, int compact_init);
