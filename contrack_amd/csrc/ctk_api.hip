@@ -273,6 +273,8 @@ struct ctk_handle {
     int async_off_ny = -1, async_off_nx = -1;      // grid whose clusters did not fit the device seam driver: synchronous path from then on
     uint32_t fz_pslot = 0;                         // k_overlap wrote the pair records into fixed per-timestep slots of this size
     bool fz_init = false;                          // k_compact_init ran (the resolver arrays are initialised), k_overlap prepared the pair arrays
+    bool fz_in_overlap = false;                    // round 6: ... k_compact_init's work is done by k_overlap itself (OverlapArgs::fuse)
+    CompInit fz_ci;                                // what it needs for that
     bool in_one_call = false;                      // inside ctk_track_*_dev (the staged entries never take the fused path)
     bool guard_on = false;                         // kernels behind the resolver check the device counters before touching the tables
     // calc_anom / percentile (ctk_anom.hip): resident anomaly slab, climatology, scratch
@@ -1228,8 +1230,12 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
             k_sum_blocks<<<nb, CTK_CI_BLOCK, 0, s>>>(P<uint32_t>(h->ncomp), T, P<uint32_t>(h->ci_bsum));
             ci.bsum = P<uint32_t>(h->ci_bsum);
         }
+        // round 6: the compaction rides in k_overlap (one launch less); CTK_COMPACT_LAUNCH=1: its own launch, as before
+        static const bool compact_launch = getenv("CTK_COMPACT_LAUNCH") != nullptr;
+        h->fz_in_overlap = !compact_launch;
+        h->fz_ci = ci;
         // (threads: one wave per plane in the throughput regime -- 438 000 x 192 x 288: 0.81 -> 0.55 ms; 256 in the latency regime, NOTES round 4)
-        k_compact_init<<<(int)T, h->small_threads[2] > 0 ? h->small_threads[2] : (T > 65536 ? 64 : 256), 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
+        if (compact_launch) k_compact_init<<<(int)T, h->small_threads[2] > 0 ? h->small_threads[2] : (T > 65536 ? 64 : 256), 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
                                               P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box), P<int64_t>(h->d_area),
                                               P<uint32_t>(h->d_comp_t), ci);
         HIPCHK(hipGetLastError());
@@ -1337,6 +1343,8 @@ static int launch_overlap(ctk_handle *h)
     a.ny = h->ny; a.nx = h->nx; a.W = h->W;
     a.cprefix = nullptr; a.mrep = nullptr; a.p_rc = nullptr; a.p_rd = nullptr; a.p_gc = nullptr; a.p_gd = nullptr; a.F = nullptr;
     a.pslot = 0; a.upair_cap = h->pair_cap;
+    a.fuse = 0; a.ncomp = nullptr; a.cs_mrep = nullptr; a.cs_box = nullptr; a.cs_area = nullptr; a.cprefix_w = nullptr; a.d_mrep = nullptr; a.d_comp_t = nullptr;
+    a.d_box = nullptr; a.d_area = nullptr; memset(&a.ci, 0, sizeof(a.ci));
     h->fz_pslot = 0;
     if ((h->fz_init || h->sh_slots) && (uint64_t)h->T * CTK_PSLOT + 4096 <= (uint64_t)h->pair_cap) {
         a.pslot = CTK_PSLOT; a.upair_cap = h->pair_cap - (uint32_t)(h->T * CTK_PSLOT);
@@ -1347,6 +1355,11 @@ static int launch_overlap(ctk_handle *h)
         CTKCHK(ensure(h, h->rv_prc, PC * 4)); CTKCHK(ensure(h, h->rv_prd, PC * 4)); CTKCHK(ensure(h, h->rv_pgc, PC * 4)); CTKCHK(ensure(h, h->rv_pgd, PC * 4));
         a.cprefix = CPX(h); a.mrep = P<uint32_t>(h->d_mrep); a.F = P<int64_t>(h->rv_F);
         a.p_rc = P<uint32_t>(h->rv_prc); a.p_rd = P<uint32_t>(h->rv_prd); a.p_gc = P<uint32_t>(h->rv_pgc); a.p_gd = P<uint32_t>(h->rv_pgd);
+        if (h->fz_in_overlap) {
+            a.fuse = 1; a.ci = h->fz_ci;
+            a.ncomp = P<uint32_t>(h->ncomp); a.cs_mrep = P<uint32_t>(h->cs_mrep); a.cs_box = P<uint32_t>(h->cs_box); a.cs_area = P<int64_t>(h->cs_area);
+            a.cprefix_w = CPX(h); a.d_mrep = P<uint32_t>(h->d_mrep); a.d_comp_t = P<uint32_t>(h->d_comp_t); a.d_box = P<uint16_t>(h->d_box); a.d_area = P<int64_t>(h->d_area);
+        }
     }
     Timer tm(h, CTK_K_OVERLAP);
     {
@@ -2243,7 +2256,10 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     am.changed = r.changed; am.ambig = r.ambig; am.rec_cnt = P<uint32_t>(h->rv_cand_cnt); am.t_nops = sd.t_nops; am.pair_cnt = in.pair_cnt; am.t_alive = P<uint32_t>(h->seam_off); am.T = T; am.passes = NP;
     {
         Timer tm(h, CTK_K_COUNT);
-        if (h->last_nlab <= 1000000)                  // (the previous pass' id count: a slab of the same kind)
+        static const bool count_f = !getenv("CTK_COUNT_OLD");
+        if (h->last_nlab <= 1000000 && NP <= 32 && count_f)      // (one round of loads, one barrier: round 6)
+            k_count_alive_f<<<1, 1024, 0, s>>>(P<uint32_t>(h->counters), h->h_mail1 + 8, am);
+        else if (h->last_nlab <= 1000000)             // (the previous pass' id count: a slab of the same kind)
             k_count_alive_1<<<1, 1024, 0, s>>>(P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->counters), h->h_mail1 + 8, am);
         else
             k_count_alive<<<1024, 256, 0, s>>>(P<int32_t>(h->ext), h->n_labels, persistence, P<uint32_t>(h->counters), h->h_mail1 + 8, am);

@@ -940,6 +940,11 @@ template <int RUNS, int COMPS, int RUNS_BELOW, int THREADS, int NYCAP = CTK_LDS_
 __global__ __launch_bounds__(THREADS, (THREADS == 1024 || NYCAP < CTK_LDS_NY) ? 8 : 1) void k_label2d_lds(Label2dArgs a)
 {
     const int t = (int)blockIdx.x;
+#ifdef CTK_PHASE_TIMING
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_phase_t[15] = wall_clock64();      // kernel entry of the probed workgroup
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_phase_t[14] = wall_clock64();                  // ... and of the first one
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) g_phase_t[13] = wall_clock64();      // ... and of the last one
+#endif
     __shared__ uint16_t x0[RUNS], x1[RUNS], yrow[RUNS], root[RUNS], idmap[RUNS];
     __shared__ uint32_t parent[RUNS];
     __shared__ uint16_t rs[NYCAP + 2];
@@ -1163,25 +1168,47 @@ struct OverlapArgs {
     // (~20 ns per add, serialised: 54 us).  0: ranges from the counter (the synchronous resolver wants them contiguous).
     uint32_t pslot;
     uint32_t upair_cap;            // ungrouped records the end of the buffer may hold
+    // round 6, fused one-call path (fuse != 0): k_compact_init's work is done HERE -- the workgroup of timestep t sums the component
+    // counts in front of it, compacts the tables of ITS components into dense (t, c) order and initialises their resolver arrays;
+    // cprefix / mrep above are then unused (the prefixes are computed, the representatives read from k_label2d's slots).  The
+    // forward sums F of the components of t - 1 come from this workgroup alone (every record of timestep t is made here): they are
+    // accumulated in LDS and stored, no global atomics and nobody else's zeroing to wait for.  One launch less (9 us at 2707 x 181 x 360).
+    int fuse;
+    const uint32_t *ncomp, *cs_mrep, *cs_box;
+    const int64_t *cs_area;
+    uint32_t *cprefix_w, *d_mrep, *d_comp_t;
+    uint16_t *d_box;
+    int64_t *d_area;
+    CompInit ci;
 };
+#define CTK_OV_FCAP 256                 // components of t - 1 whose forward sums live in LDS (more: global atomics, as before)
 
-__device__ __forceinline__ void pair_prepare(const OverlapArgs &a, uint32_t slot, uint32_t cb, uint32_t db, uint32_t c, uint32_t d, int64_t lo, int64_t hi)
+// fl: the LDS forward sums of the fused form (nullptr: global atomics); mc / md: representatives of the components of t / t - 1
+__device__ __forceinline__ void pair_prepare(const OverlapArgs &a, uint32_t slot, uint32_t cb, uint32_t db, uint32_t c, uint32_t d, int64_t lo, int64_t hi,
+                                             const uint32_t *mc = nullptr, const uint32_t *md = nullptr, long long *fl = nullptr)
 {
     const uint32_t gc = cb + c, gd = db + d;
-    const uint32_t rd = db + a.mrep[gd];
-    a.p_gc[slot] = gc; a.p_gd[slot] = gd; a.p_rc[slot] = cb + a.mrep[gc]; a.p_rd[slot] = rd;
-    atomicAdd((unsigned long long *)&a.F[2 * (int64_t)rd], (unsigned long long)lo);
-    atomicAdd((unsigned long long *)&a.F[2 * (int64_t)rd + 1], (unsigned long long)hi);
+    const uint32_t rdl = md ? md[d] : a.mrep[gd], rcl = mc ? mc[c] : a.mrep[gc];
+    const uint32_t rd = db + rdl;
+    a.p_gc[slot] = gc; a.p_gd[slot] = gd; a.p_rc[slot] = cb + rcl; a.p_rd[slot] = rd;
+    if (fl) {
+        atomicAdd((unsigned long long *)&fl[2 * rdl], (unsigned long long)lo);
+        atomicAdd((unsigned long long *)&fl[2 * rdl + 1], (unsigned long long)hi);
+    } else {
+        atomicAdd((unsigned long long *)&a.F[2 * (int64_t)rd], (unsigned long long)lo);
+        atomicAdd((unsigned long long *)&a.F[2 * (int64_t)rd + 1], (unsigned long long)hi);
+    }
 }
 
-__device__ __forceinline__ void emit_pair(const OverlapArgs &a, uint32_t t, uint32_t c, uint32_t d, int64_t lo, int64_t hi, uint32_t cb = 0, uint32_t db = 0)
+__device__ __forceinline__ void emit_pair(const OverlapArgs &a, uint32_t t, uint32_t c, uint32_t d, int64_t lo, int64_t hi, uint32_t cb = 0, uint32_t db = 0,
+                                          const uint32_t *mc = nullptr, const uint32_t *md = nullptr, long long *fl = nullptr)
 {
     uint32_t i = atomicAdd(&a.counters[CTK_CNT_UPAIRS], 1u);
     if (i < a.upair_cap) {
         CtkPair p;
         p.t = t; p.c = c; p.d = d; p.pad = 0; p.lo = lo; p.hi = hi;
         a.pairs[a.pair_cap - 1u - i] = p;
-        if (a.p_rc) pair_prepare(a, a.pair_cap - 1u - i, cb, db, c, d, lo, hi);
+        if (a.p_rc) pair_prepare(a, a.pair_cap - 1u - i, cb, db, c, d, lo, hi, mc, md, fl);
     } else atomicOr(&a.counters[CTK_CNT_OVERFLOW], CTK_OVF_PAIRS);
 }
 
@@ -1193,18 +1220,69 @@ template <int OVB, int THREADS = 256>
 __global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
 {
     const int t = (int)blockIdx.x;
-    if (t == 0 && !a.has_prev) {
+    if (t == 0 && !a.has_prev && !a.fuse) {
         if (threadIdx.x == 0) { a.pair_base[t] = 0; a.pair_cnt[t] = 0; }
         return;
     }
     const int tid = (int)threadIdx.x;
     const int ny = a.ny, W = a.W;
-    // (fused path: the component prefixes of t and t-1, needed when the table is flushed -- requested now, used then)
-    const uint32_t cbc = a.p_rc ? a.cprefix[t] : 0u, cbd = a.p_rc ? a.cprefix[t - 1] : 0u;
     __shared__ unsigned long long hkey[CTK_HASH_SLOTS];
     __shared__ long long hlo[CTK_HASH_SLOTS], hhi[CTK_HASH_SLOTS];
     __shared__ uint32_t sm_scan[THREADS / 64 + 1];
     __shared__ uint32_t out_base;
+    __shared__ long long Fl[2 * CTK_OV_FCAP];
+    // (fused path: the component prefixes of t and t-1, needed when the table is flushed)
+    uint32_t cbc = 0u, cbd = 0u, nprev = 0u;
+    const uint32_t *mrc = nullptr, *mrd = nullptr;            // representatives of the components of t / t - 1 in k_label2d's slots
+    long long *fl = nullptr;
+    if (a.fuse) {
+        // k_compact_init's prefix: the component counts of the timesteps in front (T^2 / 2 cached loads in all; long shards: block sums first)
+        const CompInit &ci = a.ci;
+        uint32_t s = 0;
+        int u0 = 0;
+        if (ci.bsum) { const int nb = t / CTK_CI_BLOCK; for (int u = tid; u < nb; u += THREADS) s += ci.bsum[u]; u0 = nb * CTK_CI_BLOCK; }
+        for (int u = u0 + tid; u < t; u += THREADS) s += a.ncomp[u];
+        const uint32_t n = a.ncomp[t], rb = a.run_base[t];
+        nprev = t > 0 ? a.ncomp[t - 1] : 0u;
+        const uint32_t rbp = t > 0 ? a.run_base[t - 1] : 0u;
+        uint32_t cb;
+        (void)block_excl_scan(s, sm_scan, &cb);
+        cbc = cb; cbd = cb - nprev;
+        mrc = a.cs_mrep + rb; mrd = a.cs_mrep + rbp;
+        if (tid == 0) { a.cprefix_w[t] = cb; if (t == ci.T - 1) a.cprefix_w[ci.T] = cb + n; }
+        // this timestep's components: dense tables + resolver arrays
+        for (uint32_t c = tid; c < n; c += THREADS) {
+            const uint32_t g = cb + c;
+            a.d_mrep[g] = a.cs_mrep[rb + c];
+            for (int k = 0; k < 4; k++) a.d_box[(int64_t)g * 4 + k] = (uint16_t)a.cs_box[(int64_t)(rb + c) * 4 + k];
+            a.d_area[(int64_t)g * 2] = a.cs_area[(int64_t)(rb + c) * 2];
+            a.d_area[(int64_t)g * 2 + 1] = a.cs_area[(int64_t)(rb + c) * 2 + 1];
+            a.d_comp_t[g] = (uint32_t)t;
+            ci.B[2 * (int64_t)g] = 0; ci.B[2 * (int64_t)g + 1] = 0;
+            ci.keep0[g] = 1; ci.keep1[g] = 1;
+            ci.touch[g] = 0;
+            ci.parent[g] = g;
+            if (t == ci.T - 1) { ci.F[2 * (int64_t)g] = 0; ci.F[2 * (int64_t)g + 1] = 0; }      // (nothing follows the last timestep)
+        }
+        // the forward sums of t - 1: in LDS when they fit, else zeroed here and accumulated with global atomics (behind the barrier below)
+        if (nprev <= CTK_OV_FCAP) { fl = Fl; for (uint32_t i = tid; i < 2 * nprev; i += THREADS) Fl[i] = 0; }
+        else for (uint32_t i = tid; i < 2 * nprev; i += THREADS) ci.F[2 * (int64_t)cbd + i] = 0;
+        if (t == 0) {
+            for (int i = tid; i < ci.nchanged; i += THREADS) ci.changed[i] = 0u;
+            if (tid == 0) { *ci.ambig = 0u; if (ci.amb_cnt) *ci.amb_cnt = 0u; if (ci.dcount) *ci.dcount = 0u; }
+        }
+        if (ci.pstate && tid == 0) { ci.pstate[(size_t)t * ci.pstride] = 0u; if (t == ci.T - 1) ci.pstate[(size_t)ci.T * ci.pstride] = 0u; }
+        __syncthreads();                                           // touch[] is zero, F of t - 1 is zero
+        // seam-merged components that hold a row with very low weight bits (ResolveDev::next_tiny): flag at the representative
+        for (uint32_t c = tid; c < n; c += THREADS) {
+            const uint32_t y0 = a.cs_box[(int64_t)(rb + c) * 4], y1 = a.cs_box[(int64_t)(rb + c) * 4 + 1];
+            if (ci.next_tiny[y0] <= (int32_t)y1) ci.touch[cb + a.cs_mrep[rb + c]] = 1u;
+        }
+        if (t == 0 && !a.has_prev) {
+            if (tid == 0) { a.pair_base[t] = 0; a.pair_cnt[t] = 0; }
+            return;
+        }
+    } else if (a.p_rc) { cbc = a.cprefix[t]; cbd = a.cprefix[t - 1]; }
     for (int i = tid; i < CTK_HASH_SLOTS; i += THREADS) { hkey[i] = FULL64; hlo[i] = 0; hhi[i] = 0; }
     __syncthreads();
 
@@ -1238,7 +1316,7 @@ __global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
             }
             h = (h + 1) & (CTK_HASH_SLOTS - 1);
         }
-        emit_pair(a, (uint32_t)t, cc, cd, lo, hi, cbc, cbd);
+        emit_pair(a, (uint32_t)t, cc, cd, lo, hi, cbc, cbd, mrc, mrd, fl);
     };
     const int lane = tid & 63;
     for (int i0 = tid; i0 < nwords; i0 += THREADS * OVB) {
@@ -1340,7 +1418,7 @@ __global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
         for (int i = tid; i < CTK_HASH_SLOTS; i += THREADS) {
             if (hkey[i] == FULL64) continue;
             if (a.pslot && j >= jend) {                                         // more entries than the timestep's slots: ungrouped
-                emit_pair(a, (uint32_t)t, (uint32_t)(hkey[i] >> 32), (uint32_t)hkey[i], hlo[i], hhi[i], cbc, cbd);
+                emit_pair(a, (uint32_t)t, (uint32_t)(hkey[i] >> 32), (uint32_t)hkey[i], hlo[i], hhi[i], cbc, cbd, mrc, mrd, fl);
                 j++;
                 continue;
             }
@@ -1349,10 +1427,14 @@ __global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
                 p.t = (uint32_t)t; p.c = (uint32_t)(hkey[i] >> 32); p.d = (uint32_t)hkey[i]; p.pad = 0;
                 p.lo = hlo[i]; p.hi = hhi[i];
                 a.pairs[j] = p;
-                if (a.p_rc) pair_prepare(a, j, cbc, cbd, p.c, p.d, p.lo, p.hi);
+                if (a.p_rc) pair_prepare(a, j, cbc, cbd, p.c, p.d, p.lo, p.hi, mrc, mrd, fl);
             }
             j++;
         }
+    }
+    if (fl) {                                                      // the forward sums of t - 1 leave LDS (zeros included)
+        __syncthreads();
+        for (uint32_t i = tid; i < 2 * nprev; i += THREADS) a.F[2 * (int64_t)cbd + i] = Fl[i];
     }
 }
 
@@ -2036,6 +2118,58 @@ __global__ __launch_bounds__(1024) void k_count_alive_1(const int32_t *__restric
         __syncthreads();                                   // (counters[CTK_CNT_ALIVE] is one of the words mailed)
         async_mail_write(am, counters, ncand, nops, npairs);
     }
+}
+
+// k_count_alive_1 for the fused one-call pass (round 6): the same block of scalars, but every global load of the kernel is issued
+// before the first one is used -- the per-timestep sums, the zero flags, the device counters, the filter's change words were four
+// dependent rounds of loads behind three barriers (6.8-7.8 us for a few KB; it is the last kernel of the pass: the host waits for its
+// stamp).  One barrier.  (The ids that survive were counted per timestep slice by k_run_values: t_alive.)
+__global__ __launch_bounds__(1024) void k_count_alive_f(uint32_t *counters, uint32_t *mail, AsyncMail am)
+{
+    if (ctk_guard_bad(counters)) {
+        async_mail_write(am, counters, 0u, __hip_atomic_load(&counters[CTK_CNT_NOPS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));      // (a poisoned pass: the op slots the shared tail was asked for)
+        return;
+    }
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // ---- all loads ------------------------------------------------------------------------------------------
+    uint32_t v = 0, nc = 0, no = 0, np = 0;
+    for (int64_t t = tid; t < am.T; t += 1024) { v += am.t_alive[t]; nc += am.rec_cnt[t]; no += am.t_nops[t]; np += am.pair_cnt[t]; }
+    const uint32_t zv = ctk_zf_mine(counters, tid, 1024);
+    // filter pass k changed something?  word j of pass k is looked at by thread k * 64 + j (passes <= 32: two per thread)
+    const int np1 = am.passes;
+    const uint32_t ch0 = (tid < np1 * 64) ? am.changed[tid] : 0u, ch1 = (tid + 1024 < np1 * 64) ? am.changed[tid + 1024] : 0u;
+    uint32_t cval = 0;                                       // wave 0: what lane `lane` mails besides the sums
+    if (wv == 0) {
+        if (lane < CTK_CNT_N) cval = __hip_atomic_load(&counters[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (lane == CTK_AM_NC) cval = *am.nc_ptr;
+        else if (lane == CTK_AM_NLAB) cval = *am.nlab_ptr;
+        else if (lane == CTK_AM_AMBIG) cval = *am.ambig;
+    }
+    // ---- reductions --------------------------------------------------------------------------------------------
+    __shared__ uint32_t sm[16], sn[16], so[16], sp[16], sz[16], sc[32];
+    const uint32_t s1 = wave_sum_u32(v), s2 = wave_sum_u32(nc), s3 = wave_sum_u32(no), s4 = wave_sum_u32(np);
+    const bool zany = __ballot(zv != 0u) != 0ull, c0 = __ballot(ch0 != 0u) != 0ull, c1 = __ballot(ch1 != 0u) != 0ull;
+    if (lane == 0) { sm[wv] = s1; sn[wv] = s2; so[wv] = s3; sp[wv] = s4; sz[wv] = zany ? 1u : 0u; sc[wv] = c0 ? 1u : 0u; sc[wv + 16] = c1 ? 1u : 0u; }
+    __syncthreads();
+    if (wv != 0) return;
+    uint32_t tot = 0, ncand = 0, nops = 0, npairs = 0, z = 0;
+    for (int i = 0; i < 16; i++) { tot += sm[i]; ncand += sn[i]; nops += so[i]; npairs += sp[i]; z |= sz[i]; }
+    uint32_t conv = 0;                                       // first pass that changed nothing, + 1; 0 = none of those launched
+    for (int k = np1 - 1; k >= 0; k--) if (!sc[k]) conv = (uint32_t)k + 1u;
+    if (np1 > 32) conv = 0;                                  // (never launched with more: the synchronous path takes over)
+    if (lane == 0) { counters[CTK_CNT_ALIVE] = tot; counters[CTK_CNT_WROTE_ZERO] = z; mail[0] = tot; mail[1] = z; }
+    // ---- the block of scalars (async_mail_write's layout), one word per lane ---------------------------------------------
+    uint32_t out = cval;
+    bool has = lane < CTK_CNT_N || lane == CTK_AM_NC || lane == CTK_AM_NLAB || lane == CTK_AM_AMBIG;
+    if (lane == CTK_CNT_ALIVE) out = tot;
+    else if (lane == CTK_CNT_WROTE_ZERO) out = z;
+    else if (lane == CTK_CNT_NOPS) out = nops;
+    else if (lane == CTK_AM_NCAND) { out = ncand; has = true; }
+    else if (lane == CTK_AM_NPAIRS) { out = npairs; has = true; }
+    else if (lane == CTK_AM_CONV) { out = conv; has = true; }
+    if (has) am.scal[lane] = out;
+    __threadfence_system();
+    if (lane == CTK_AM_DONE) __hip_atomic_store(&am.scal[CTK_AM_DONE], am.stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // time extents of the ids start empty; the counters of the write stage start at zero

@@ -14,3 +14,5 @@ buf = (C.c_ulonglong * 16)()
 _native.lib().ctk_debug_phase_times(buf)
 t = np.array(list(buf), dtype=np.int64)
 print("phase durations (us, wall_clock64 @100MHz):", [(i, (t[i + 1] - t[i]) / 100.0) for i in range(8)])
+print("entry of the probed workgroup -> phase mark 0: %.2f us; first workgroup's entry -> probed one's: %.2f us; -> last one's: %.2f us; probed workgroup entry -> its last mark: %.2f us" % (
+    (t[0] - t[15]) / 100.0, (t[15] - t[14]) / 100.0, (t[13] - t[14]) / 100.0, (t[8] - t[15]) / 100.0))
