@@ -162,8 +162,10 @@ struct LaneCrew {
     }
     bool run(int n, const std::function<void(int)> &f)
     {
+        // (all n lanes or none: the job strides its blocks by the lane count it asked for -- with fewer threads the blocks of the
+        // missing lanes would never be written; the caller falls back to the dense copy.  Round-5 advisor finding.)
         try { while ((int)th.size() < n) { const int i = (int)th.size(); th.emplace_back([this, i] { loop(i); }); } }
-        catch (...) { if ((int)th.size() == 0) return false; n = std::min(n, (int)th.size()); }
+        catch (...) { return false; }
         {
             std::lock_guard<std::mutex> g(m);
             job = f; want = n; active = n; gen++;
@@ -273,8 +275,6 @@ struct ctk_handle {
     int async_off_ny = -1, async_off_nx = -1;      // grid whose clusters did not fit the device seam driver: synchronous path from then on
     uint32_t fz_pslot = 0;                         // k_overlap wrote the pair records into fixed per-timestep slots of this size
     bool fz_init = false;                          // k_compact_init ran (the resolver arrays are initialised), k_overlap prepared the pair arrays
-    bool fz_in_overlap = false;                    // round 6: ... k_compact_init's work is done by k_overlap itself (OverlapArgs::fuse)
-    CompInit fz_ci;                                // what it needs for that
     bool in_one_call = false;                      // inside ctk_track_*_dev (the staged entries never take the fused path)
     bool guard_on = false;                         // kernels behind the resolver check the device counters before touching the tables
     // calc_anom / percentile (ctk_anom.hip): resident anomaly slab, climatology, scratch
@@ -1230,12 +1230,10 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
             k_sum_blocks<<<nb, CTK_CI_BLOCK, 0, s>>>(P<uint32_t>(h->ncomp), T, P<uint32_t>(h->ci_bsum));
             ci.bsum = P<uint32_t>(h->ci_bsum);
         }
-        // round 6: the compaction rides in k_overlap (one launch less); CTK_COMPACT_LAUNCH=1: its own launch, as before
-        static const bool compact_launch = getenv("CTK_COMPACT_LAUNCH") != nullptr;
-        h->fz_in_overlap = !compact_launch;
-        h->fz_ci = ci;
+        // (round 6: the same work inside k_overlap -- one launch less -- was built and measured: k_scan group -6.5 us, k_overlap +8.3 us; the
+        // small kernels of this pass cost their dependent loads and their instructions, not their launches.  NOTES round 6.)
         // (threads: one wave per plane in the throughput regime -- 438 000 x 192 x 288: 0.81 -> 0.55 ms; 256 in the latency regime, NOTES round 4)
-        if (compact_launch) k_compact_init<<<(int)T, h->small_threads[2] > 0 ? h->small_threads[2] : (T > 65536 ? 64 : 256), 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
+        k_compact_init<<<(int)T, h->small_threads[2] > 0 ? h->small_threads[2] : (T > 65536 ? 64 : 256), 0, s>>>(P<uint32_t>(h->run_base), P<uint32_t>(h->ncomp), CPX(h), P<uint32_t>(h->cs_mrep), P<uint32_t>(h->cs_box),
                                               P<int64_t>(h->cs_area), P<uint32_t>(h->d_mrep), P<uint16_t>(h->d_box), P<int64_t>(h->d_area),
                                               P<uint32_t>(h->d_comp_t), ci);
         HIPCHK(hipGetLastError());
@@ -1343,8 +1341,6 @@ static int launch_overlap(ctk_handle *h)
     a.ny = h->ny; a.nx = h->nx; a.W = h->W;
     a.cprefix = nullptr; a.mrep = nullptr; a.p_rc = nullptr; a.p_rd = nullptr; a.p_gc = nullptr; a.p_gd = nullptr; a.F = nullptr;
     a.pslot = 0; a.upair_cap = h->pair_cap;
-    a.fuse = 0; a.ncomp = nullptr; a.cs_mrep = nullptr; a.cs_box = nullptr; a.cs_area = nullptr; a.cprefix_w = nullptr; a.d_mrep = nullptr; a.d_comp_t = nullptr;
-    a.d_box = nullptr; a.d_area = nullptr; memset(&a.ci, 0, sizeof(a.ci));
     h->fz_pslot = 0;
     if ((h->fz_init || h->sh_slots) && (uint64_t)h->T * CTK_PSLOT + 4096 <= (uint64_t)h->pair_cap) {
         a.pslot = CTK_PSLOT; a.upair_cap = h->pair_cap - (uint32_t)(h->T * CTK_PSLOT);
@@ -1355,11 +1351,6 @@ static int launch_overlap(ctk_handle *h)
         CTKCHK(ensure(h, h->rv_prc, PC * 4)); CTKCHK(ensure(h, h->rv_prd, PC * 4)); CTKCHK(ensure(h, h->rv_pgc, PC * 4)); CTKCHK(ensure(h, h->rv_pgd, PC * 4));
         a.cprefix = CPX(h); a.mrep = P<uint32_t>(h->d_mrep); a.F = P<int64_t>(h->rv_F);
         a.p_rc = P<uint32_t>(h->rv_prc); a.p_rd = P<uint32_t>(h->rv_prd); a.p_gc = P<uint32_t>(h->rv_pgc); a.p_gd = P<uint32_t>(h->rv_pgd);
-        if (h->fz_in_overlap) {
-            a.fuse = 1; a.ci = h->fz_ci;
-            a.ncomp = P<uint32_t>(h->ncomp); a.cs_mrep = P<uint32_t>(h->cs_mrep); a.cs_box = P<uint32_t>(h->cs_box); a.cs_area = P<int64_t>(h->cs_area);
-            a.cprefix_w = CPX(h); a.d_mrep = P<uint32_t>(h->d_mrep); a.d_comp_t = P<uint32_t>(h->d_comp_t); a.d_box = P<uint16_t>(h->d_box); a.d_area = P<int64_t>(h->d_area);
-        }
     }
     Timer tm(h, CTK_K_OVERLAP);
     {
@@ -1586,7 +1577,13 @@ static int launch_extents(ctk_handle *h, bool ext_filled = false, bool with_fina
         // (a timestep has ~40 components: one wave per timestep puts every plane of a long slab on the chip at once -- 11.2 instead of
         // 14.0 us at 2707 x 181 x 360, equal at 480 x 721 x 1440; tools/small_probe.py)
         // (one wave per plane beyond 2048 planes; two on wide grids, whose complex components are folded row by row: 14 600 x 721 x 1440 0.40 -> 0.26 ms)
-        k_extent<<<(int)h->T, h->small_threads[0] > 0 ? h->small_threads[0] : (h->T > 2048 ? (h->nx >= 1024 ? 128 : 64) : 256), 0, s>>>(a);
+        a.T = h->T;
+        // round 6: sixteen timesteps per workgroup, the ids' extents reduced in LDS before they touch memory (k_extent_blk), for shards of
+        // more than 2048 timesteps on narrow grids (where k_extent ran one wave per plane); CTK_EXTENT_BLK=0 / 1 forbids / forces it
+        static const int ext_blk = getenv("CTK_EXTENT_BLK") ? atoi(getenv("CTK_EXTENT_BLK")) : -1;
+        const bool blk = h->small_threads[0] == 0 && (ext_blk == 1 || (ext_blk < 0 && h->T > 2048 && h->nx < 1024));
+        if (blk) k_extent_blk<<<(int)((h->T + EX_TW - 1) / EX_TW), 64 * EX_TW, 0, s>>>(a);
+        else k_extent<<<(int)h->T, h->small_threads[0] > 0 ? h->small_threads[0] : (h->T > 2048 ? (h->nx >= 1024 ? 128 : 64) : 256), 0, s>>>(a);
         HIPCHK(hipGetLastError());
     }
     return CTK_OK;
@@ -2163,7 +2160,8 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
     const size_t ids_guess = h->last_nlab ? (size_t)h->last_nlab + h->last_nlab / 4 : R / 32;
     const uint32_t own_ids = (uint32_t)std::min<size_t>(std::max<size_t>(ids_guess, 8192), R + 1);
     if (!h->last_nlab) h->op_cap_hint = std::max<uint32_t>(h->op_cap_hint, (uint32_t)std::min<size_t>(R / 256, 1u << 24));
-    if ((uint64_t)own_ids * SD_OPS_OWN + h->op_cap_hint > 0x7ffffff0ull) return ctk_set_error(CTK_E_RANGE, "more op slots than 2^31");
+    // (more op slots than int32 indices: not an error of the slab -- the synchronous resolver needs no such slots.  Round-5 advisor finding.)
+    if ((uint64_t)own_ids * SD_OPS_OWN + h->op_cap_hint > 0x7ffffff0ull) { h->stats[CTK_S_HOST_REASON] |= 1024; return 1; }
     const uint32_t op_cap = own_ids * SD_OPS_OWN + h->op_cap_hint;
     CTKCHK(ensure(h, h->ops, (size_t)op_cap * (sizeof(CtkOp) + 4)));
     // ids <= components <= runs: R + 1 is the offset of the second half of ext (only the entries of real ids are ever touched)
@@ -3318,14 +3316,13 @@ extern "C" int ctk_lifecycle_exact(ctk_handle *h, const int64_t *row_idx, int64_
     HIPCHK(hipMemcpy(h->lc_offs.p, offs.data(), (size_t)n * 16, hipMemcpyHostToDevice));
     double *d_sw = P<double>(h->lc_sw);
     const size_t st = px / 8;
-    if (h->lc_f64)
-        k_life_exact<double><<<(unsigned)n, lx_threads, 0, s>>>(h->lc_flag, (const double *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),
-                                                         P<uint64_t>(h->lc_offs) + n, h->lc_ny, h->lc_nx, d_sw, d_sw + st, d_sw + 2 * st, d_sw + 3 * st, d_sw + 4 * st,
-                                                         P<uint32_t>(h->lc_sp), P<CtkLifeExact>(h->lc_out));
-    else
-        k_life_exact<float><<<(unsigned)n, lx_threads, 0, s>>>(h->lc_flag, (const float *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),
-                                                        P<uint64_t>(h->lc_offs) + n, h->lc_ny, h->lc_nx, d_sw, d_sw + st, d_sw + 2 * st, d_sw + 3 * st, d_sw + 4 * st,
-                                                        P<uint32_t>(h->lc_sp), P<CtkLifeExact>(h->lc_out));
+#define CTK_LX_LAUNCH(VT, G)                                                                                                                                       \
+    k_life_exact<VT, G><<<(unsigned)n, 256 * G, 0, s>>>(h->lc_flag, (const VT *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),   \
+                                                        P<uint64_t>(h->lc_offs) + n, h->lc_ny, h->lc_nx, d_sw, d_sw + st, d_sw + 2 * st, d_sw + 3 * st, d_sw + 4 * st, \
+                                                        P<uint32_t>(h->lc_sp), P<CtkLifeExact>(h->lc_out))
+    if (h->lc_f64) { if (lx_threads == 1024) CTK_LX_LAUNCH(double, 4); else CTK_LX_LAUNCH(double, 1); }
+    else { if (lx_threads == 1024) CTK_LX_LAUNCH(float, 4); else CTK_LX_LAUNCH(float, 1); }
+#undef CTK_LX_LAUNCH
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, h->lc_out.p, (size_t)n * sizeof(CtkLifeExact), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -1168,47 +1168,25 @@ struct OverlapArgs {
     // (~20 ns per add, serialised: 54 us).  0: ranges from the counter (the synchronous resolver wants them contiguous).
     uint32_t pslot;
     uint32_t upair_cap;            // ungrouped records the end of the buffer may hold
-    // round 6, fused one-call path (fuse != 0): k_compact_init's work is done HERE -- the workgroup of timestep t sums the component
-    // counts in front of it, compacts the tables of ITS components into dense (t, c) order and initialises their resolver arrays;
-    // cprefix / mrep above are then unused (the prefixes are computed, the representatives read from k_label2d's slots).  The
-    // forward sums F of the components of t - 1 come from this workgroup alone (every record of timestep t is made here): they are
-    // accumulated in LDS and stored, no global atomics and nobody else's zeroing to wait for.  One launch less (9 us at 2707 x 181 x 360).
-    int fuse;
-    const uint32_t *ncomp, *cs_mrep, *cs_box;
-    const int64_t *cs_area;
-    uint32_t *cprefix_w, *d_mrep, *d_comp_t;
-    uint16_t *d_box;
-    int64_t *d_area;
-    CompInit ci;
 };
-#define CTK_OV_FCAP 256                 // components of t - 1 whose forward sums live in LDS (more: global atomics, as before)
 
-// fl: the LDS forward sums of the fused form (nullptr: global atomics); mc / md: representatives of the components of t / t - 1
-__device__ __forceinline__ void pair_prepare(const OverlapArgs &a, uint32_t slot, uint32_t cb, uint32_t db, uint32_t c, uint32_t d, int64_t lo, int64_t hi,
-                                             const uint32_t *mc = nullptr, const uint32_t *md = nullptr, long long *fl = nullptr)
+__device__ __forceinline__ void pair_prepare(const OverlapArgs &a, uint32_t slot, uint32_t cb, uint32_t db, uint32_t c, uint32_t d, int64_t lo, int64_t hi)
 {
     const uint32_t gc = cb + c, gd = db + d;
-    const uint32_t rdl = md ? md[d] : a.mrep[gd], rcl = mc ? mc[c] : a.mrep[gc];
-    const uint32_t rd = db + rdl;
-    a.p_gc[slot] = gc; a.p_gd[slot] = gd; a.p_rc[slot] = cb + rcl; a.p_rd[slot] = rd;
-    if (fl) {
-        atomicAdd((unsigned long long *)&fl[2 * rdl], (unsigned long long)lo);
-        atomicAdd((unsigned long long *)&fl[2 * rdl + 1], (unsigned long long)hi);
-    } else {
-        atomicAdd((unsigned long long *)&a.F[2 * (int64_t)rd], (unsigned long long)lo);
-        atomicAdd((unsigned long long *)&a.F[2 * (int64_t)rd + 1], (unsigned long long)hi);
-    }
+    const uint32_t rd = db + a.mrep[gd];
+    a.p_gc[slot] = gc; a.p_gd[slot] = gd; a.p_rc[slot] = cb + a.mrep[gc]; a.p_rd[slot] = rd;
+    atomicAdd((unsigned long long *)&a.F[2 * (int64_t)rd], (unsigned long long)lo);
+    atomicAdd((unsigned long long *)&a.F[2 * (int64_t)rd + 1], (unsigned long long)hi);
 }
 
-__device__ __forceinline__ void emit_pair(const OverlapArgs &a, uint32_t t, uint32_t c, uint32_t d, int64_t lo, int64_t hi, uint32_t cb = 0, uint32_t db = 0,
-                                          const uint32_t *mc = nullptr, const uint32_t *md = nullptr, long long *fl = nullptr)
+__device__ __forceinline__ void emit_pair(const OverlapArgs &a, uint32_t t, uint32_t c, uint32_t d, int64_t lo, int64_t hi, uint32_t cb = 0, uint32_t db = 0)
 {
     uint32_t i = atomicAdd(&a.counters[CTK_CNT_UPAIRS], 1u);
     if (i < a.upair_cap) {
         CtkPair p;
         p.t = t; p.c = c; p.d = d; p.pad = 0; p.lo = lo; p.hi = hi;
         a.pairs[a.pair_cap - 1u - i] = p;
-        if (a.p_rc) pair_prepare(a, a.pair_cap - 1u - i, cb, db, c, d, lo, hi, mc, md, fl);
+        if (a.p_rc) pair_prepare(a, a.pair_cap - 1u - i, cb, db, c, d, lo, hi);
     } else atomicOr(&a.counters[CTK_CNT_OVERFLOW], CTK_OVF_PAIRS);
 }
 
@@ -1220,69 +1198,18 @@ template <int OVB, int THREADS = 256>
 __global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
 {
     const int t = (int)blockIdx.x;
-    if (t == 0 && !a.has_prev && !a.fuse) {
+    if (t == 0 && !a.has_prev) {
         if (threadIdx.x == 0) { a.pair_base[t] = 0; a.pair_cnt[t] = 0; }
         return;
     }
     const int tid = (int)threadIdx.x;
     const int ny = a.ny, W = a.W;
+    // (fused path: the component prefixes of t and t-1, needed when the table is flushed -- requested now, used then)
+    const uint32_t cbc = a.p_rc ? a.cprefix[t] : 0u, cbd = a.p_rc ? a.cprefix[t - 1] : 0u;
     __shared__ unsigned long long hkey[CTK_HASH_SLOTS];
     __shared__ long long hlo[CTK_HASH_SLOTS], hhi[CTK_HASH_SLOTS];
     __shared__ uint32_t sm_scan[THREADS / 64 + 1];
     __shared__ uint32_t out_base;
-    __shared__ long long Fl[2 * CTK_OV_FCAP];
-    // (fused path: the component prefixes of t and t-1, needed when the table is flushed)
-    uint32_t cbc = 0u, cbd = 0u, nprev = 0u;
-    const uint32_t *mrc = nullptr, *mrd = nullptr;            // representatives of the components of t / t - 1 in k_label2d's slots
-    long long *fl = nullptr;
-    if (a.fuse) {
-        // k_compact_init's prefix: the component counts of the timesteps in front (T^2 / 2 cached loads in all; long shards: block sums first)
-        const CompInit &ci = a.ci;
-        uint32_t s = 0;
-        int u0 = 0;
-        if (ci.bsum) { const int nb = t / CTK_CI_BLOCK; for (int u = tid; u < nb; u += THREADS) s += ci.bsum[u]; u0 = nb * CTK_CI_BLOCK; }
-        for (int u = u0 + tid; u < t; u += THREADS) s += a.ncomp[u];
-        const uint32_t n = a.ncomp[t], rb = a.run_base[t];
-        nprev = t > 0 ? a.ncomp[t - 1] : 0u;
-        const uint32_t rbp = t > 0 ? a.run_base[t - 1] : 0u;
-        uint32_t cb;
-        (void)block_excl_scan(s, sm_scan, &cb);
-        cbc = cb; cbd = cb - nprev;
-        mrc = a.cs_mrep + rb; mrd = a.cs_mrep + rbp;
-        if (tid == 0) { a.cprefix_w[t] = cb; if (t == ci.T - 1) a.cprefix_w[ci.T] = cb + n; }
-        // this timestep's components: dense tables + resolver arrays
-        for (uint32_t c = tid; c < n; c += THREADS) {
-            const uint32_t g = cb + c;
-            a.d_mrep[g] = a.cs_mrep[rb + c];
-            for (int k = 0; k < 4; k++) a.d_box[(int64_t)g * 4 + k] = (uint16_t)a.cs_box[(int64_t)(rb + c) * 4 + k];
-            a.d_area[(int64_t)g * 2] = a.cs_area[(int64_t)(rb + c) * 2];
-            a.d_area[(int64_t)g * 2 + 1] = a.cs_area[(int64_t)(rb + c) * 2 + 1];
-            a.d_comp_t[g] = (uint32_t)t;
-            ci.B[2 * (int64_t)g] = 0; ci.B[2 * (int64_t)g + 1] = 0;
-            ci.keep0[g] = 1; ci.keep1[g] = 1;
-            ci.touch[g] = 0;
-            ci.parent[g] = g;
-            if (t == ci.T - 1) { ci.F[2 * (int64_t)g] = 0; ci.F[2 * (int64_t)g + 1] = 0; }      // (nothing follows the last timestep)
-        }
-        // the forward sums of t - 1: in LDS when they fit, else zeroed here and accumulated with global atomics (behind the barrier below)
-        if (nprev <= CTK_OV_FCAP) { fl = Fl; for (uint32_t i = tid; i < 2 * nprev; i += THREADS) Fl[i] = 0; }
-        else for (uint32_t i = tid; i < 2 * nprev; i += THREADS) ci.F[2 * (int64_t)cbd + i] = 0;
-        if (t == 0) {
-            for (int i = tid; i < ci.nchanged; i += THREADS) ci.changed[i] = 0u;
-            if (tid == 0) { *ci.ambig = 0u; if (ci.amb_cnt) *ci.amb_cnt = 0u; if (ci.dcount) *ci.dcount = 0u; }
-        }
-        if (ci.pstate && tid == 0) { ci.pstate[(size_t)t * ci.pstride] = 0u; if (t == ci.T - 1) ci.pstate[(size_t)ci.T * ci.pstride] = 0u; }
-        __syncthreads();                                           // touch[] is zero, F of t - 1 is zero
-        // seam-merged components that hold a row with very low weight bits (ResolveDev::next_tiny): flag at the representative
-        for (uint32_t c = tid; c < n; c += THREADS) {
-            const uint32_t y0 = a.cs_box[(int64_t)(rb + c) * 4], y1 = a.cs_box[(int64_t)(rb + c) * 4 + 1];
-            if (ci.next_tiny[y0] <= (int32_t)y1) ci.touch[cb + a.cs_mrep[rb + c]] = 1u;
-        }
-        if (t == 0 && !a.has_prev) {
-            if (tid == 0) { a.pair_base[t] = 0; a.pair_cnt[t] = 0; }
-            return;
-        }
-    } else if (a.p_rc) { cbc = a.cprefix[t]; cbd = a.cprefix[t - 1]; }
     for (int i = tid; i < CTK_HASH_SLOTS; i += THREADS) { hkey[i] = FULL64; hlo[i] = 0; hhi[i] = 0; }
     __syncthreads();
 
@@ -1316,7 +1243,7 @@ __global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
             }
             h = (h + 1) & (CTK_HASH_SLOTS - 1);
         }
-        emit_pair(a, (uint32_t)t, cc, cd, lo, hi, cbc, cbd, mrc, mrd, fl);
+        emit_pair(a, (uint32_t)t, cc, cd, lo, hi, cbc, cbd);
     };
     const int lane = tid & 63;
     for (int i0 = tid; i0 < nwords; i0 += THREADS * OVB) {
@@ -1418,7 +1345,7 @@ __global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
         for (int i = tid; i < CTK_HASH_SLOTS; i += THREADS) {
             if (hkey[i] == FULL64) continue;
             if (a.pslot && j >= jend) {                                         // more entries than the timestep's slots: ungrouped
-                emit_pair(a, (uint32_t)t, (uint32_t)(hkey[i] >> 32), (uint32_t)hkey[i], hlo[i], hhi[i], cbc, cbd, mrc, mrd, fl);
+                emit_pair(a, (uint32_t)t, (uint32_t)(hkey[i] >> 32), (uint32_t)hkey[i], hlo[i], hhi[i], cbc, cbd);
                 j++;
                 continue;
             }
@@ -1427,14 +1354,10 @@ __global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
                 p.t = (uint32_t)t; p.c = (uint32_t)(hkey[i] >> 32); p.d = (uint32_t)hkey[i]; p.pad = 0;
                 p.lo = hlo[i]; p.hi = hhi[i];
                 a.pairs[j] = p;
-                if (a.p_rc) pair_prepare(a, j, cbc, cbd, p.c, p.d, p.lo, p.hi, mrc, mrd, fl);
+                if (a.p_rc) pair_prepare(a, j, cbc, cbd, p.c, p.d, p.lo, p.hi);
             }
             j++;
         }
-    }
-    if (fl) {                                                      // the forward sums of t - 1 leave LDS (zeros included)
-        __syncthreads();
-        for (uint32_t i = tid; i < 2 * nprev; i += THREADS) a.F[2 * (int64_t)cbd + i] = Fl[i];
     }
 }
 
@@ -1551,6 +1474,7 @@ struct ExtentArgs {
     int64_t t_begin;
     FoldArgs fold;
     int ny, nx, W;
+    int64_t T;                     // timesteps of the shard (k_extent_blk: several per workgroup)
 };
 
 // time extent of an id: look before the atomic (a long-lived id gets one update per timestep -- or per pixel -- and
@@ -1600,6 +1524,77 @@ __global__ __launch_bounds__(256) void k_extent(ExtentArgs a)
                 ext_update(tmin, tmax, fl, tg);
             }
         });
+    }
+}
+
+// k_extent with EX_TW consecutive timesteps per workgroup, one wave each (round 6).  The time extents are min / max reductions onto
+// HOT addresses: an id that lives for hundreds of timesteps is updated by every one of them, from all eight XCDs, and each update is
+// a device-scope look (the L2s of the XCDs are not coherent with each other) plus, sometimes, an atomic -- 2-5 us apiece under load.
+// With one wave per timestep that chain is the kernel: 2.0 ms at 438 000 x 192 x 288 (93 % of the wave cycles waiting).  Here the
+// waves of a workgroup reduce (id -> first / last timestep) in an LDS hash first and the workgroup touches global memory once per
+// id: EX_TW times fewer hot operations (the scheme of k_fz_groups).  Complex components (per-pixel folds) update directly, as before.
+#define EX_TW 16
+#define EX_HS 512
+#define EX_PROBES 8
+__global__ __launch_bounds__(64 * EX_TW) void k_extent_blk(ExtentArgs a)
+{
+    if (ctk_guard_bad(a.guard)) return;
+    __shared__ int32_t hk[EX_HS], hlo[EX_HS], hhi[EX_HS];
+    for (int s = (int)threadIdx.x; s < EX_HS; s += 64 * EX_TW) { hk[s] = 0; hlo[s] = INT32_MAX; hhi[s] = INT32_MIN; }
+    __syncthreads();
+    const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int64_t T = a.T;
+    const int64_t t = (int64_t)blockIdx.x * EX_TW + wv;
+    int32_t *tmin = a.ext, *tmax = a.ext + a.n_labels + 1;
+    if (t < T) {
+        const uint32_t n = a.ncomp[t], cb = a.cprefix[t];
+        const int32_t tg = (int32_t)(a.t_begin + t);
+        int ylo = 0x7fffffff, yhi = -1;                     // rows that hold pixels of complex components
+        for (uint32_t c = lane; c < n; c += 64) {
+            int32_t l;
+            if (a.lab) {
+                l = a.lab[cb + c];
+                const uint2 bq = *reinterpret_cast<const uint2 *>(a.box + 4 * (int64_t)(cb + c));
+                if (l > 0) l = comp_final_label(a.fold, l, tg, (int)(bq.x & 0xffffu), (int)(bq.x >> 16), (int)(bq.y & 0xffffu), (int)(bq.y >> 16));
+                a.comp_label_w[cb + c] = l;
+                if (l < 0) { ylo = min(ylo, (int)(bq.x & 0xffffu)); yhi = max(yhi, (int)(bq.x >> 16)); }
+            } else {
+                l = a.comp_label[cb + c];
+                if (l < 0) { ylo = min(ylo, (int)a.box[4 * (int64_t)(cb + c)]); yhi = max(yhi, (int)a.box[4 * (int64_t)(cb + c) + 1]); }
+            }
+            if (l > 0) {
+                uint32_t s = ((uint32_t)l * 2654435761u) >> 16;
+                bool placed = false;
+                for (int p = 0; p < EX_PROBES; p++, s++) {
+                    const int32_t old = atomicCAS(&hk[s & (EX_HS - 1)], 0, l);
+                    if (old == 0 || old == l) { atomicMin(&hlo[s & (EX_HS - 1)], tg); atomicMax(&hhi[s & (EX_HS - 1)], tg); placed = true; break; }
+                }
+                if (!placed) ext_update(tmin, tmax, l, tg);                      // (a crowded hash: straight to memory)
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) { ylo = min(ylo, __shfl_xor(ylo, o)); yhi = max(yhi, __shfl_xor(yhi, o)); }
+        if (yhi >= 0) {                                                          // (wave-uniform) pixels of complex components, folded one by one
+            __threadfence_block();                                               // (the labels this wave just stored are read back below, by other lanes)
+            const uint32_t *rc = a.run_comp + a.run_base[t];
+            for (int y = ylo; y <= yhi && y < a.ny; y++) {
+                const uint64_t *mw = a.mask + ((int64_t)t * a.ny + y) * a.W;
+                for_each_fg_pixel_in_row(mw, a.W, a.rowstart[(int64_t)t * a.ny + y], [&](int x, uint32_t run) {
+                    const int32_t l = a.comp_label_w[cb + rc[run]];
+                    if (l < 0) {
+                        const int32_t fl = fold_pixel(a.fold, -l, tg, y, x);
+                        ext_update(tmin, tmax, fl, tg);
+                    }
+                });
+            }
+        }
+    }
+    __syncthreads();
+    for (int s = (int)threadIdx.x; s < EX_HS; s += 64 * EX_TW) {
+        const int32_t l = hk[s];
+        if (l == 0) continue;
+        const int32_t lo = hlo[s], hi = hhi[s];
+        if (lo < __hip_atomic_load(&tmin[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&tmin[l], lo);
+        if (hi > __hip_atomic_load(&tmax[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&tmax[l], hi);
     }
 }
 

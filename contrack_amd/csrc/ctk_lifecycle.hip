@@ -848,19 +848,22 @@ __global__ __launch_bounds__(1024) void k_life_count(const int32_t *__restrict__
 // 1024 threads when a listed row is large -- sixteen waves share the two scans over the rows --, and the sequential sums read their
 // block from LDS two values per load, eight values ahead of the add chain, while ALL threads already hold the next block's values in
 // registers (the global loads travel underneath the chain; two LDS buffers, one barrier per block).
-#define LX_STAGE 1024
-template <typename VT>
-__global__ __launch_bounds__(1024) void k_life_exact(const int32_t *__restrict__ flag, const VT *__restrict__ field, const float *__restrict__ wrow,
+// Round 6 (advisor finding): the LDS tables follow the launch -- G = threads / 256 groups of the pairwise sums, blocks of 512 (one
+// group) or 1024 values of the sequential sums -- so that the common 256-thread launch keeps its ~30 KB (five workgroups per CU) and
+// only the 1024-thread launch for large contours takes ~66 KB.
+template <typename VT, int G>
+__global__ __launch_bounds__(256 * G) void k_life_exact(const int32_t *__restrict__ flag, const VT *__restrict__ field, const float *__restrict__ wrow,
                                                     const CtkLifeKey *__restrict__ keys, const uint64_t *__restrict__ offs, const uint64_t *__restrict__ roffs,
                                                     int ny, int nx, double *__restrict__ sw, double *__restrict__ sp_, double *__restrict__ sq,
                                                     double *__restrict__ sqy, double *__restrict__ sqx, uint32_t *__restrict__ rowtab,
                                                     CtkLifeExact *__restrict__ out)
 {
+    constexpr int LX_STAGE = G == 1 ? 512 : 1024;
     __shared__ uint32_t part[256];
-    __shared__ uint32_t lo[4 * 128], ln[4 * 128];
-    __shared__ double lv[4 * 256], cres[8];
-    __shared__ int nleaf[4];
-    __shared__ NpFrame frames[4 * 32];
+    __shared__ uint32_t lo[G * 128], ln[G * 128];
+    __shared__ double lv[G * 256], cres[8];
+    __shared__ int nleaf[G];
+    __shared__ NpFrame frames[G * 32];
     __shared__ __attribute__((aligned(16))) double stage[2][3][LX_STAGE];
     __shared__ double res[5];
     const CtkLifeKey k = keys[blockIdx.x];
