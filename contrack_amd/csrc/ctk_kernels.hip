@@ -726,8 +726,10 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
         const uint64_t *mglob = a.mask + (int64_t)t * ny * W;
         const int nwords = ny * W;
         // one word: the i-th start bit and the i-th end bit of a row delimit its i-th run
-        auto extract = [&](int k, uint64_t m, uint64_t left, uint64_t right, uint32_t wpre) {
-            const int y = k / W, w = k - y * W;
+        // (y, w) = row and word-in-row of word k: the callers advance them without dividing (an integer division by a run-time W is ~25
+        // VALU instructions, five of them per thread of the staged form: a tenth of this kernel's instructions -- it is issue-bound)
+        auto extract = [&](int k, int y, int w, uint64_t m, uint64_t left, uint64_t right, uint32_t wpre) {
+            (void)k;
             const uint64_t cin = (w > 0) ? (left >> 63) : 0ull;
             const uint64_t nin = (w + 1 < W) ? (right & 1ull) : 0ull;
             uint64_t starts = m & ~((m << 1) | cin);
@@ -750,21 +752,29 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
                 ei++;
             }
         };
+        const int dq = THREADS / W, dr = THREADS - dq * W;           // word k + THREADS lies dq rows and dr words further (+ a carry)
+        int yk = tid / W, wk = tid - yk * W;                         // (one division per thread)
         if (NW > 0) {                                                // the timestep's words are in LDS, the prefixes of this thread's in registers
 #pragma unroll
             for (int u = 0; u < (NW > 0 ? NW : 1); u++) {
                 const int k = tid + u * THREADS;
                 if (k >= nwords) break;
+                const int y = yk, w = wk;
+                yk += dq; wk += dr;
+                if (wk >= W) { wk -= W; yk++; }
                 const uint64_t m = mrow[k];
                 if (m == 0ull) continue;
-                extract(k, m, k > 0 ? mrow[k - 1] : 0ull, k + 1 < nwords ? mrow[k + 1] : 0ull, pf.w[u]);
+                extract(k, y, w, m, k > 0 ? mrow[k - 1] : 0ull, k + 1 < nwords ? mrow[k + 1] : 0ull, pf.w[u]);
             }
         } else if (mrow_staged) {                                    // the timestep's words are in LDS
             const uint16_t *ws = wglob;
             for (int k = tid; k < nwords; k += THREADS) {
+                const int y = yk, w = wk;
+                yk += dq; wk += dr;
+                if (wk >= W) { wk -= W; yk++; }
                 const uint64_t m = mrow[k];
                 if (m == 0ull) continue;
-                extract(k, m, k > 0 ? mrow[k - 1] : 0ull, k + 1 < nwords ? mrow[k + 1] : 0ull, ws[k]);
+                extract(k, y, w, m, k > 0 ? mrow[k - 1] : 0ull, k + 1 < nwords ? mrow[k + 1] : 0ull, ws[k]);
             }
         } else {
             // Straight from global memory (L2), P2B words per thread at a time: every load is issued before the first word is
@@ -774,6 +784,7 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
             for (int k0 = tid; k0 < nwords; k0 += THREADS * P2B) {
                 uint64_t m[P2B], ml[P2B], mr[P2B];
                 uint32_t wp[P2B];
+                int yy[P2B], ww[P2B];
 #pragma unroll
                 for (int u = 0; u < P2B; u++) {
                     const int k = k0 + u * THREADS, kc = min(k, nwords - 1);
@@ -781,9 +792,12 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
                     ml[u] = mglob[max(kc - 1, 0)];
                     mr[u] = mglob[min(kc + 1, nwords - 1)];
                     wp[u] = wglob[kc];
+                    yy[u] = yk; ww[u] = wk;
+                    yk += dq; wk += dr;
+                    if (wk >= W) { wk -= W; yk++; }
                 }
 #pragma unroll
-                for (int u = 0; u < P2B; u++) if (m[u] != 0ull) extract(k0 + u * THREADS, m[u], ml[u], mr[u], wp[u]);
+                for (int u = 0; u < P2B; u++) if (m[u] != 0ull) extract(k0 + u * THREADS, yy[u], ww[u], m[u], ml[u], mr[u], wp[u]);
             }
         }
     }
@@ -1246,6 +1260,10 @@ __global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
         emit_pair(a, (uint32_t)t, cc, cd, lo, hi, cbc, cbd);
     };
     const int lane = tid & 63;
+    // (row, word-in-row) of the thread's next word, advanced by THREADS words at a time without dividing (a division by a run-time W is
+    // ~25 VALU instructions; OVB of them per thread were a tenth of this kernel's instructions -- it is issue-bound: NOTES round 6)
+    const int dq = THREADS / W, dr = THREADS - dq * W;
+    int yk = tid / W, wk = tid - yk * W;
     for (int i0 = tid; i0 < nwords; i0 += THREADS * OVB) {
         // Registers decide how many of these workgroups a CU holds (every load in flight owns its destination): the words to the
         // left are not loaded -- consecutive threads hold consecutive words, so the carry-in bit comes from the lane to the left
@@ -1255,10 +1273,14 @@ __global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
         uint32_t ec[OVB], ep[OVB], lt[OVB];                              // lt: bit 0 / 1 = carry-in of c / p (top bit of the word to the left, same row)
         uint32_t ltc[OVB], ltp[OVB];
         int yy[OVB];
+        uint32_t first = 0;                                              // bit u: word u is the first of its row
 #pragma unroll
         for (int u = 0; u < OVB; u++) {                                  // level 1 (and everything whose address is known already)
             const int idx = i0 + u * THREADS, ii = min(idx, nwords - 1), im = max(ii - 1, 0);
-            const int y = ii / W;
+            const int y = min(yk, ny - 1);                               // (= ii / W: past the end the last row's tables are loaded in vain)
+            if (wk == 0) first |= 1u << u;
+            yk += dq; wk += dr;
+            if (wk >= W) { wk -= W; yk++; }
             yy[u] = idx < nwords ? y : -1;
             c[u] = mc[ii]; p[u] = mp[ii];
             // lane 0's left neighbours: requested by EVERY lane (the others ask for the first word of the plane, one cached line) --
@@ -1273,8 +1295,7 @@ __global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
             const uint32_t mine = (uint32_t)(c[u] >> 63) | ((uint32_t)(p[u] >> 63) << 1);
             const uint32_t left = (uint32_t)__shfl_up((int)mine, 1);
             lt[u] = lane != 0 ? left : ((ltc[u] >> 31) | ((ltp[u] >> 31) << 1));
-            const int ii = min(i0 + u * THREADS, nwords - 1);
-            if (ii - yy[u] * W <= 0) lt[u] = 0;                          // first word of a row: nothing to the left
+            if ((first >> u) & 1u) lt[u] = 0;                            // first word of a row: nothing to the left
             if (yy[u] < 0) c[u] = 0ull;                                  // past the end: no common pixels
         }
         // what the table phase needs of a word: c, p, lt (pieces are re-derived from them), the run prefixes, the components of
