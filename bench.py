@@ -208,6 +208,20 @@ def live_pmc_traffic(workload, a, kernels, timeout_s=150):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def stream_ceiling(trk, d_in, d_out, nbytes, per):
+    try:
+        rd, wr = trk.stream_ceiling(d_in, nbytes, write=False), trk.stream_ceiling(d_out, nbytes, write=True)
+    except _native.ContrackHipError as e:
+        return dict(error=str(e))
+    out = dict(plain_load_stream_gbs=nbytes / rd / 1e6, plain_store_stream_gbs=nbytes / wr / 1e6, plain_load_ms=rd, plain_store_ms=wr,
+               note="k_stream_load / k_stream_store (ctk_debug_stream_ceiling): 16-byte non-temporal loads of the slab / stores over the flag slab, nothing else")
+    if per.get("k_threshold", 0) > 0:
+        out["k_threshold_of_plain_load_stream"] = rd / per["k_threshold"]
+    if per.get("k_relabel", 0) > 0:
+        out["k_relabel_of_plain_store_stream"] = wr / per["k_relabel"]
+    return out
+
+
 def cpu_baseline(wl, a, w, budget_s=20.0):
     """The CPU restatement of the reference path (oracle/scipy_port.py: same scipy.ndimage / numpy call
     sequence as contrack.py:646-796, one core) timed on a bounded sample of the same workload."""
@@ -517,6 +531,9 @@ def main():
                              other_streaming_kernel={k: dict(achieved=alg_bytes[k] / (per[k] * 1e-3) / 1e9, avg_kernel_ms=per[k])
                                                      for k in alg_bytes if k != kern and per.get(k, 0) > 0}),
                kernels_ms=per, workload_stats=trk.stats(), pmc_live=live_pmc,
+               # what a PLAIN 16-byte non-temporal stream reaches on this board, measured here on the same two buffers (best of 5): the write
+               # kernel cannot beat the store stream, the threshold kernel not the load stream -- `frac` above stays against the 8 TB/s peak
+               stream_ceiling=stream_ceiling(trk, d_in, d_out, nbytes, per),
                path_effective_gbs=8.0 * px / (ms_per_step * 1e-3) / 1e9,
                # the two pixel-streaming kernels together move the path's algorithmic 8 B per pixel
                streaming=dict(bytes=8.0 * px, ms=per.get("k_threshold", 0.0) + per.get("k_relabel", 0.0),

@@ -3462,6 +3462,35 @@ extern "C" int ctk_dev_memset(ctk_handle *h, void *p_dev, int byte, size_t nbyte
     return CTK_OK;
 }
 
+/* measurement support: best-of-`reps` time of a plain 16-byte non-temporal store (mode 1) / load (mode 0) stream over [p_dev, p_dev + nbytes) */
+extern "C" int ctk_debug_stream_ceiling(ctk_handle *h, void *p_dev, size_t nbytes, int mode, int reps, double *best_ms)
+{
+    if (!h || !p_dev || !best_ms || nbytes < 16 || (((uintptr_t)p_dev) & 15) || reps < 1) return ctk_set_error(CTK_E_INVALID, "ctk_debug_stream_ceiling: bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    CTKCHK(ensure(h, h->dbg, 64));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return ctk_set_error(CTK_E_NODEVICE, "hipEventCreate failed"); }
+    const int64_t n16 = (int64_t)(nbytes / 16);
+    const unsigned grid = (unsigned)((n16 + 2047) / 2048);
+    double best = 1e30;
+    hipError_t err = hipSuccess;
+    for (int r = 0; r < reps + 1 && err == hipSuccess; r++) {          // (+ 1: the first launch is not counted)
+        err = hipEventRecord(e0, h->stream);
+        if (mode) k_stream_store<<<grid, 256, 0, h->stream>>>((i32x4 *)p_dev, n16);
+        else k_stream_load<<<grid, 256, 0, h->stream>>>((const i32x4 *)p_dev, n16, P<int32_t>(h->dbg));
+        if (err == hipSuccess) err = hipEventRecord(e1, h->stream);
+        if (err == hipSuccess) err = hipEventSynchronize(e1);
+        float f = 0.f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&f, e0, e1);
+        if (r > 0 && f < best) best = f;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (err != hipSuccess) return ctk_set_error(CTK_E_NODEVICE, "ctk_debug_stream_ceiling: %s", hipGetErrorString(err));
+    *best_ms = best;
+    return CTK_OK;
+}
+
 extern "C" int ctk_check_flag_dev(ctk_handle *h, const float *anom_dev, const int32_t *flag_dev, int64_t T, int ny, int nx, const double *thr, int cmp_op,
                                   int persistence, int64_t max_id, uint64_t *out6)
 {

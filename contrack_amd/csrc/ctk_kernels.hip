@@ -2280,6 +2280,31 @@ __global__ void k_synth(float *__restrict__ out, int64_t T, int ny, int nx, uint
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// What a PLAIN stream of the two streaming kernels' shape reaches on this board (ctk_debug_stream_ceiling; bench.py puts it next to
+// the roofline): 16-byte non-temporal stores of zeros over a buffer / 16-byte non-temporal loads ORed into a register.  The write
+// kernel k_relabel_v5 cannot be faster than the first, k_threshold_v7 not faster than the second.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stream_store(i32x4 *__restrict__ dst, int64_t n16)
+{
+    constexpr int U = 8;
+    const int64_t base = (int64_t)blockIdx.x * (256 * U) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int64_t i = base + u * 256; if (i < n16) __builtin_nontemporal_store((i32x4)(0), dst + i); }
+}
+__global__ __launch_bounds__(256) void k_stream_load(const i32x4 *__restrict__ src, int64_t n16, int32_t *__restrict__ sink)
+{
+    constexpr int U = 8;
+    const int64_t base = (int64_t)blockIdx.x * (256 * U) + threadIdx.x;
+    i32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(src + min(base + u * 256, n16 - 1));
+    int32_t acc = 0;
+#pragma unroll
+    for (int u = 0; u < U; u++) acc |= v[u].x | v[u].y | v[u].z | v[u].w;
+    if (acc == 0x5a5a5a5a) *sink = acc;                       // (never, in practice: keeps the loads alive)
+}
+
 // position-weighted checksum of an int32 array (ctk_checksum_i32_dev): out[0] += sum (uint32)p[i] * (((index0 + i) * golden) | 1),
 // out[1] += nonzero elements.  One 64-bit atomic pair per workgroup (integer: the result does not depend on the order).
 __global__ __launch_bounds__(256) void k_checksum_i32(const int32_t *__restrict__ p, int64_t n, int64_t index0, unsigned long long *__restrict__ out)

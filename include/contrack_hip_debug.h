@@ -61,6 +61,11 @@ int ctk_debug_set_xcd(ctk_handle *h, int thr_mode, int rel_mode);
 /* experiments: threads (0 = default, 256 / 512 / 1024) and rows (0 = default) per workgroup of the write kernel k_relabel_v5 */
 int ctk_debug_set_relabel(ctk_handle *h, int threads, int rows);
 
+/* measurement support (bench.py, next to the roofline): best-of-`reps` time in ms of a PLAIN stream over a 16-byte-aligned device buffer --
+ * mode 1: 16-byte non-temporal stores of zeros (what bounds the write kernel), mode 0: 16-byte non-temporal loads (what bounds the
+ * threshold kernel).  Overwrites the buffer in mode 1. */
+int ctk_debug_stream_ceiling(ctk_handle *h, void *p_dev, size_t nbytes, int mode, int reps, double *best_ms);
+
 /* experiments: threads per workgroup (0 = default, 64 / 128 / 256) of the one-workgroup-per-timestep kernels k_extent, k_run_values,
  * k_compact_init of the one-call pass */
 int ctk_debug_set_small_threads(ctk_handle *h, int extent, int run_values, int compact_init);
