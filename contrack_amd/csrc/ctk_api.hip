@@ -1097,7 +1097,11 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         if (vs.v2 || vs.v3) HIPCHK(hipEventRecord(h->ev_fork, s));
         if (vs.v1) {
             if (v0_ok) k_label2d_lds<832, 240, -1, 256, 256><<<(int)T, 256, 0, s>>>(a);
-            else k_label2d_lds<1024, 288, -1, 256><<<(int)T, 256, 0, s>>>(a);
+            else {
+                // (experiment, CTK_L2D_PAD_KB: unused dynamic LDS on top of the kernel's 25.6 KB -- fewer workgroups per CU; NOTES round 6)
+                static const int pad_kb = getenv("CTK_L2D_PAD_KB") ? atoi(getenv("CTK_L2D_PAD_KB")) : 0;
+                k_label2d_lds<1024, 288, -1, 256><<<(int)T, 256, (size_t)pad_kb * 1024, s>>>(a);
+            }
         }
         if (vs.v1hi) k_label2d_lds<1024, 288, 832, 256><<<(int)T, 256, 0, s>>>(a);
         if (vs.v2) {

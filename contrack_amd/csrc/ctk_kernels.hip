@@ -825,42 +825,19 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
     // ---- phase 4: flatten (no-wrap components) --------------------------------------------------
     for (uint32_t r = tid; r < nruns; r += THREADS) root[r] = (IT)uf_find(parent, r);
     __syncthreads();
-    for (uint32_t r = tid; r < nruns; r += THREADS) parent[r] = root[r];
-    __syncthreads();
 
     PHASE_MARK(4);
-    // ---- phase 5: seam unions on top, second flatten (kept in `parent`) ----------------------------
-    for (int y = tid; y < ny; y += THREADS) {
-        uint32_t f = rs[y], l = rs[y + 1];
-        if (f == l) continue;
-        l--;
-        if (x0[f] == 0 && x1[l] == (uint16_t)(nx - 1) && f != l) uf_unite(parent, f, l);
-    }
-    __syncthreads();
-    for (uint32_t r = tid; r < nruns; r += THREADS) {
-        uint32_t m = uf_find(parent, r);
-        idmap[r] = (IT)m;                  // temporarily: merged root of r
-    }
-    __syncthreads();
-    for (uint32_t r = tid; r < nruns; r += THREADS) parent[r] = idmap[r];
-    __syncthreads();
-
-    PHASE_MARK(5);
-    // ---- phase 6: ids, tables ------------------------------------------------------------------------
+    // ---- phase 5: ids.  Round 6: ONE block scan -- every thread counts the roots among `per` consecutive runs (raster order is
+    // kept: thread by thread, run by run) -- instead of one scan per THREADS runs (two at 1 degree: four barriers).
     uint32_t ncomp = 0;
     {
-        uint32_t carry = 0;
-        for (uint32_t r0 = 0; r0 < nruns; r0 += THREADS) {
-            uint32_t r = r0 + tid;
-            uint32_t v = (r < nruns && root[r] == r) ? 1u : 0u, tot;
-            uint32_t ex = block_excl_scan(v, sm_scan, &tot);
-            if (r < nruns) idmap[r] = (IT)(carry + ex);    // meaningful at roots only
-            carry += tot;
-        }
-        ncomp = carry;
+        const uint32_t per = (nruns + THREADS - 1) / THREADS, rb = min(nruns, (uint32_t)tid * per), re = min(nruns, rb + per);
+        uint32_t v = 0, tot;
+        for (uint32_t r = rb; r < re; r++) v += (root[r] == r) ? 1u : 0u;
+        uint32_t ex = block_excl_scan(v, sm_scan, &tot);
+        for (uint32_t r = rb; r < re; r++) if (root[r] == r) idmap[r] = (IT)(ex++);      // (meaningful at roots only)
+        ncomp = tot;
     }
-    __syncthreads();
-    PHASE_MARK(6);
     if (tid == 0) a.ncomp[t] = ncomp;
     uint32_t *cmrep = a.cs_mrep + rbase;
     uint32_t *gbox = a.cs_box + (int64_t)rbase * 4;
@@ -870,11 +847,31 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
     const bool tab_lds = lds_tab != nullptr && ncomp <= (uint32_t)LDS_COMPS;
     int64_t *carea = tab_lds ? (int64_t *)lds_tab : garea;
     uint32_t *cbox = tab_lds ? (uint32_t *)((int64_t *)lds_tab + 2 * LDS_COMPS) : gbox;
+    // Round 6: the seam merge (contrack.py:693-698) is a union-find over COMPONENTS -- a few dozen per plane, a handful of seam rows --
+    // in the run-level parent array, which is dead once the roots are known.  Component ids follow the raster order of the root
+    // runs, so "smallest id of the set" is the component of the smallest run: the representative the run-level form found by
+    // uniting the seam runs on top of the flattened forest and flattening ALL runs a second time (three more passes over the runs
+    // and five barriers).
     for (uint32_t c = tid; c < ncomp; c += THREADS) {
+        parent[c] = c;
         cbox[c * 4 + 0] = 0xffffu; cbox[c * 4 + 1] = 0u; cbox[c * 4 + 2] = 0xffffu; cbox[c * 4 + 3] = 0u;
         carea[c * 2] = 0; carea[c * 2 + 1] = 0;
     }
     __syncthreads();
+
+    PHASE_MARK(5);
+    // ---- phase 6: seam unions between components ---------------------------------------------------------
+    for (int y = tid; y < ny; y += THREADS) {
+        uint32_t f = rs[y], l = rs[y + 1];
+        if (f == l) continue;
+        l--;
+        if (x0[f] == 0 && x1[l] == (uint16_t)(nx - 1) && f != l) {
+            const uint32_t cf = idmap[root[f]], cl = idmap[root[l]];
+            if (cf != cl) uf_unite(parent, cf, cl);
+        }
+    }
+    __syncthreads();
+    PHASE_MARK(6);
     // (the weight limbs of four runs' rows are requested before the first is used: a plane's ~500 runs would otherwise walk
     // row -> weights -> atomics two or three times in a row)
     constexpr int TBN = THREADS == 1024 ? 2 : 4;                  // (the 1024-thread variants run at 64 VGPRs)
@@ -894,14 +891,14 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
             a.run_comp[rbase + r] = c;
             const int y = yy[j];
             const int64_t len = (int64_t)x1[r] - (int64_t)x0[r] + 1;
-            const uint32_t cm = idmap[parent[r]];              // seam-merged component: its area is what contrack.py:717 sums
+            const uint32_t cm = uf_find(parent, c);            // seam-merged component: its area is what contrack.py:717 sums
             atomicAdd((unsigned long long *)&carea[cm * 2], (unsigned long long)(len * wl[j]));
             atomicAdd((unsigned long long *)&carea[cm * 2 + 1], (unsigned long long)(len * wh[j]));
             atomicMin(&cbox[c * 4 + 0], (uint32_t)y);
             atomicMax(&cbox[c * 4 + 1], (uint32_t)y);
             atomicMin(&cbox[c * 4 + 2], (uint32_t)x0[r]);
             atomicMax(&cbox[c * 4 + 3], (uint32_t)x1[r]);
-            if (rt == r) cmrep[c] = idmap[parent[r]];          // merged root is itself a no-wrap root (smallest run)
+            if (rt == r) cmrep[c] = cm;                        // (the representative: smallest component id of the merged set)
         }
     }
     if (tab_lds) {
