@@ -656,7 +656,8 @@ extern "C" int ctk_debug_set_xcd(ctk_handle *h, int thr_mode, int rel_mode)
 
 extern "C" int ctk_debug_set_small_threads(ctk_handle *h, int extent, int run_values, int compact_init)
 {
-    for (int v : {extent, run_values, compact_init}) if (v != 0 && v != 64 && v != 128 && v != 256) return ctk_set_error(CTK_E_INVALID, "ctk_debug_set_small_threads: 0 / 64 / 128 / 256");
+    for (int v : {run_values, compact_init}) if (v != 0 && v != 64 && v != 128 && v != 256) return ctk_set_error(CTK_E_INVALID, "ctk_debug_set_small_threads: 0 / 64 / 128 / 256");
+    if (extent != 0 && extent != 64 && extent != 128 && extent != 256 && extent != 1024) return ctk_set_error(CTK_E_INVALID, "ctk_debug_set_small_threads: extent 0 / 64 / 128 / 256, or 1024 = k_extent_blk");
     if (!h) return ctk_set_error(CTK_E_INVALID, "null handle");
     h->small_threads[0] = extent; h->small_threads[1] = run_values; h->small_threads[2] = compact_init;
     return CTK_OK;
@@ -1586,7 +1587,7 @@ static int launch_extents(ctk_handle *h, bool ext_filled = false, bool with_fina
         // round 6: sixteen timesteps per workgroup, the ids' extents reduced in LDS before they touch memory (k_extent_blk), for shards of
         // more than 2048 timesteps on narrow grids (where k_extent ran one wave per plane); CTK_EXTENT_BLK=0 / 1 forbids / forces it
         static const int ext_blk = getenv("CTK_EXTENT_BLK") ? atoi(getenv("CTK_EXTENT_BLK")) : -1;
-        const bool blk = h->small_threads[0] == 0 && (ext_blk == 1 || (ext_blk < 0 && h->T > 2048 && h->nx < 1024));
+        const bool blk = h->small_threads[0] == 1024 || (h->small_threads[0] == 0 && (ext_blk == 1 || (ext_blk < 0 && h->T > 2048 && h->nx < 1024)));
         if (blk) k_extent_blk<<<(int)((h->T + EX_TW - 1) / EX_TW), 64 * EX_TW, 0, s>>>(a);
         else k_extent<<<(int)h->T, h->small_threads[0] > 0 ? h->small_threads[0] : (h->T > 2048 ? (h->nx >= 1024 ? 128 : 64) : 256), 0, s>>>(a);
         HIPCHK(hipGetLastError());

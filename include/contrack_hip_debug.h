@@ -67,7 +67,8 @@ int ctk_debug_set_relabel(ctk_handle *h, int threads, int rows);
 int ctk_debug_stream_ceiling(ctk_handle *h, void *p_dev, size_t nbytes, int mode, int reps, double *best_ms);
 
 /* experiments: threads per workgroup (0 = default, 64 / 128 / 256) of the one-workgroup-per-timestep kernels k_extent, k_run_values,
- * k_compact_init of the one-call pass */
+ * k_compact_init of the one-call pass; extent = 1024: the sixteen-timesteps-per-workgroup form k_extent_blk whatever the shard's length
+ * (test hook: by default it serves shards of more than 2048 timesteps on grids narrower than 1024) */
 int ctk_debug_set_small_threads(ctk_handle *h, int extent, int run_values, int compact_init);
 
 /* placement experiment: the bit mask `off` bytes (a multiple of 256, up to 64 MB) into a larger allocation from the next call on; -1: plain */

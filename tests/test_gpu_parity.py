@@ -28,6 +28,34 @@ def test_hip_matches_reference_golden(trk, name):
     assert n == len(np.unique(g["flag"])) - 1
 
 
+@pytest.mark.parametrize("name", golden_util.case_names())
+def test_extent_kernel_with_sixteen_timesteps_per_workgroup(name):
+    """k_extent_blk (round 6: the ids' time extents reduced in LDS per sixteen timesteps before they touch memory) serves shards of more
+    than 2048 timesteps by default; forced here (ctk_debug_set_small_threads extent = 1024) on every golden -- chain_* hold the complex
+    components whose pixels are folded one by one -- through the dense device path and through the host entry."""
+    g = golden_util.load(name)
+    op = _native.CMP_OPS[g["gorl"]]
+    t = _native.Tracker(0)
+    try:
+        _native.check(_native.lib().ctk_debug_set_small_threads(t.handle, 1024, 0, 0))
+        flag, n = t.track(g["anom"], g["thr"], op, g["wrow"], g["overlap"], g["persistence"], g["twosided"])
+        assert np.array_equal(flag, g["flag"]) and n == len(np.unique(g["flag"])) - 1
+        T, ny, nx = g["anom"].shape
+        d_in, d_out = t.malloc(g["anom"].nbytes), t.malloc(T * ny * nx * 4)
+        try:
+            t.h2d(d_in, np.ascontiguousarray(g["anom"]))
+            for _ in range(2):                               # (the second call runs speculatively on the first one's capacities)
+                n2 = t.track_dev(d_in, T, ny, nx, g["thr"], op, g["wrow"], g["overlap"], g["persistence"], g["twosided"], d_out)
+                out = np.empty((T, ny, nx), dtype=np.int32)
+                t.d2h(out, d_out)
+                assert np.array_equal(out, g["flag"]) and n2 == n
+        finally:
+            t.free(d_in)
+            t.free(d_out)
+    finally:
+        t.close()
+
+
 def _staged(trk, anom, thr, op, wrow):
     T, ny, nx = anom.shape
     d = trk.malloc(anom.nbytes)
