@@ -822,22 +822,20 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
     __syncthreads();
 
     PHASE_MARK(3);
-    // ---- phase 4: flatten (no-wrap components) --------------------------------------------------
-    for (uint32_t r = tid; r < nruns; r += THREADS) root[r] = (IT)uf_find(parent, r);
-    __syncthreads();
-
-    PHASE_MARK(4);
-    // ---- phase 5: ids.  Round 6: ONE block scan -- every thread counts the roots among `per` consecutive runs (raster order is
-    // kept: thread by thread, run by run) -- instead of one scan per THREADS runs (two at 1 degree: four barriers).
+    // ---- phase 4: flatten (no-wrap components) + ids ---------------------------------------------------
+    // Round 6: every thread takes `per` CONSECUTIVE runs (raster order is kept: thread by thread, run by run), finds their roots and
+    // counts its roots on the way; ONE block scan numbers them (was: a strided flatten pass, then one scan per THREADS runs -- two at
+    // 1 degree, four barriers -- over the roots read back from LDS).
     uint32_t ncomp = 0;
     {
         const uint32_t per = (nruns + THREADS - 1) / THREADS, rb = min(nruns, (uint32_t)tid * per), re = min(nruns, rb + per);
         uint32_t v = 0, tot;
-        for (uint32_t r = rb; r < re; r++) v += (root[r] == r) ? 1u : 0u;
-        uint32_t ex = block_excl_scan(v, sm_scan, &tot);
+        for (uint32_t r = rb; r < re; r++) { const uint32_t q = uf_find(parent, r); root[r] = (IT)q; v += (q == r) ? 1u : 0u; }
+        uint32_t ex = block_excl_scan(v, sm_scan, &tot);                 // (its first barrier: every root is in LDS)
         for (uint32_t r = rb; r < re; r++) if (root[r] == r) idmap[r] = (IT)(ex++);      // (meaningful at roots only)
         ncomp = tot;
     }
+    PHASE_MARK(4);
     if (tid == 0) a.ncomp[t] = ncomp;
     uint32_t *cmrep = a.cs_mrep + rbase;
     uint32_t *gbox = a.cs_box + (int64_t)rbase * 4;
@@ -860,17 +858,39 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
     __syncthreads();
 
     PHASE_MARK(5);
-    // ---- phase 6: seam unions between components ---------------------------------------------------------
-    for (int y = tid; y < ny; y += THREADS) {
-        uint32_t f = rs[y], l = rs[y + 1];
-        if (f == l) continue;
-        l--;
-        if (x0[f] == 0 && x1[l] == (uint16_t)(nx - 1) && f != l) {
-            const uint32_t cf = idmap[root[f]], cl = idmap[root[l]];
-            if (cf != cl) uf_unite(parent, cf, cl);
+    // ---- phase 6: seam unions between components, and the seam-row records ---------------------------------------------
+    // seam rows: both seam pixels set (also when they are one run / one component: chain events can still
+    // split them, SURVEY.md appendix A4b).  Written in y order into the timestep's slice of a row-indexed
+    // scratch (at most ny records per timestep).  (Round 6: one pass over the rows for both; the scan's barriers are the ones the
+    // unions need in front of the tables.)
+    {
+        uint32_t carry = 0;
+        CtkSeam *out = a.seams + (int64_t)t * ny;
+        for (int y0 = 0; y0 < ny; y0 += THREADS) {
+            const int y = y0 + tid;
+            uint32_t f = 0, l = 0, v = 0, cf = 0, cl = 0;
+            if (y < ny) {
+                f = rs[y]; l = rs[y + 1];
+                if (f != l) {
+                    l--;
+                    v = (x0[f] == 0 && x1[l] == (uint16_t)(nx - 1)) ? 1u : 0u;
+                    if (v) {
+                        cf = idmap[root[f]]; cl = idmap[root[l]];
+                        if (cf != cl) uf_unite(parent, cf, cl);
+                    }
+                }
+            }
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan(v, sm_scan, &tot);
+            if (v) {
+                CtkSeam q;
+                q.t = (uint32_t)t; q.y = (uint32_t)y; q.cl = cf; q.cr = cl;
+                out[carry + ex] = q;
+            }
+            carry += tot;
         }
+        if (tid == 0) a.seam_cnt[t] = carry;
     }
-    __syncthreads();
     PHASE_MARK(6);
     // (the weight limbs of four runs' rows are requested before the first is used: a plane's ~500 runs would otherwise walk
     // row -> weights -> atomics two or three times in a row)
@@ -907,30 +927,6 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
         for (uint32_t i = tid; i < ncomp * 2; i += THREADS) garea[i] = carea[i];
     }
     PHASE_MARK(7);
-    // seam rows: both seam pixels set (also when they are one run / one component: chain events can still
-    // split them, SURVEY.md appendix A4b).  Written in y order into the timestep's slice of a row-indexed
-    // scratch (at most ny records per timestep).
-    {
-        uint32_t carry = 0;
-        CtkSeam *out = a.seams + (int64_t)t * ny;
-        for (int y0 = 0; y0 < ny; y0 += THREADS) {
-            int y = y0 + tid;
-            uint32_t f = 0, l = 0, v = 0;
-            if (y < ny) {
-                f = rs[y]; l = rs[y + 1];
-                if (f != l) { l--; v = (x0[f] == 0 && x1[l] == (uint16_t)(nx - 1)) ? 1u : 0u; }
-            }
-            uint32_t tot;
-            uint32_t ex = block_excl_scan(v, sm_scan, &tot);
-            if (v) {
-                CtkSeam q;
-                q.t = (uint32_t)t; q.y = (uint32_t)y; q.cl = idmap[root[f]]; q.cr = idmap[root[l]];
-                out[carry + ex] = q;
-            }
-            carry += tot;
-        }
-        if (tid == 0) a.seam_cnt[t] = carry;
-    }
     PHASE_MARK(8);
 }
 
