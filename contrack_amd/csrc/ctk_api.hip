@@ -1017,13 +1017,17 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
                     if (rc == CTK_OK && (ro2 > 1.04 * ro_ms || ro_ms > 1.04 * ro2 || best_ms < 0.98 * std::min(ro_ms, ro2))) { best_ms = 0.0; h->mask_tries = 0; if (++h->mask_check_retries <= 3) h->mask_check_pending = true; }      // (inconclusive: no search now; up to three later calls try again)
                     else ro_ms = std::min(ro_ms, ro2);
                 } else if (rc == CTK_OK && best_ms < 0.98 * ro_ms) h->mask_tries = 0;
-                // Round 6 (verdict item 4): the search is BOUNDED -- at most one other allocation, behind one spacer of 1 GB that is
+                // Round 6 (verdict item 4): the search is OFF by default and BOUNDED when asked for -- at most one other allocation, behind one spacer of 1 GB that is
                 // released before the call goes on; nothing is ever kept alive besides the mask itself (round 5 tried up to five
                 // allocations behind 29 GB of spacers and two 6 GB arenas; on the boxes where it mattered it found nothing, and what it
                 // cost a caller's second call was recorded nowhere).  Its host time and the spacer it held are in the statistics
                 // (CTK_S_MASK_CHECK_US, CTK_S_MASK_SPACER_MB).  Where the first two candidates share the slab's class the kernel runs
                 // at 5.9-6.1 instead of 6.5 TB/s; DESIGN.md section 3 says so.
-                static const int max_tries = getenv("CTK_MASK_TRIES") ? std::min(atoi(getenv("CTK_MASK_TRIES")), 1) : 1;
+                // DEFAULT: NO search at all -- the check only measures (4 launches) and reports; the kernel runs at 5.9 or 6.5 TB/s as
+                // the allocator happened to place the mask.  (The one retry found memory of the other class for about a quarter of this
+                // round's handles and cost 1.3-6 ms of the handle's second call, once 32 ms: hipMalloc / hipFree of the spacer synchronise
+                // the device.)  CTK_MASK_TRIES=1: the one retry described above, opt-in.
+                static const int max_tries = getenv("CTK_MASK_TRIES") ? std::min(std::max(atoi(getenv("CTK_MASK_TRIES")), 0), 1) : 0;
                 const double accept = accept_first;
                 std::vector<void *> held;                                               // the spacer and the rejected mask: freed when the search is over
                 struct FreeHeld { std::vector<void *> &v; ~FreeHeld() { for (void *q : v) (void)hipFree(q); } } free_held{held};
