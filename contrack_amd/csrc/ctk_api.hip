@@ -2359,7 +2359,9 @@ static void tune_relabel(ctk_handle *h, int persistence, int32_t *flag_dev)
     // (like the mask check: at the SECOND pass on a shape, so that a one-shot call does not pay nine extra launches)
     if (!(h->rel_seen_T == h->T && h->rel_seen_ny == h->ny && h->rel_seen_nx == h->nx)) { h->rel_seen_T = h->T; h->rel_seen_ny = h->ny; h->rel_seen_nx = h->nx; return; }
     h->rel_tuned_T = h->T; h->rel_tuned_ny = h->ny; h->rel_tuned_nx = h->nx; h->rel_tuned_flag = flag_dev;
-    if ((size_t)h->T * h->ny * h->nx * 4 > ((size_t)8 << 30)) { h->xcd_rel_tuned = -1; return; }
+    // (beyond 8 GB nothing is timed: by the shape -- one contiguous eighth per XCD won on every narrow grid it was timed on (2707 x 181 x 360:
+    // -5 ... -8 %; 438 000 x 192 x 288, round 6: 18.75 -> 18.07 ms), the launch order on 1440-wide ones)
+    if ((size_t)h->T * h->ny * h->nx * 4 > ((size_t)8 << 30)) { h->xcd_rel_tuned = h->nx < 1024 ? 1 : -1; return; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); return; }
     int rows = 0;
