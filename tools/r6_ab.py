@@ -105,6 +105,8 @@ def main():
                 continue
             d = json.loads(line[-1])
             res[v].append(d)
+            for ln in sorted(set(x for x in p.stderr.splitlines() if x.startswith("SDDBG")))[:3]:
+                print("    " + ln, flush=True)
             print("%-60s %.4f ms  n=%s cs=%s zero=%s us fused=%s rk=%s mask=%s/%s  %s" % (v, d["ms"], d["n_tracked"], d["checksum"][0] % 1000003, d["zero_fill_us"], d["fused"], d["relabel_kernel"],
                                                                                       d["mask_tries"], d["mask_ratio"], d["kernels"]), flush=True)
     print("---- summary (min / median ms per pass)")
