@@ -609,6 +609,18 @@ extern "C" int ctk_debug_phase_times(unsigned long long *out)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_t), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
 }
+// k_rs_pass_blk's per-workgroup stamps; reset != 0 re-arms them (entry = ~0 for the atomicMin, the rest 0)
+extern "C" int ctk_debug_pb_times(unsigned long long *out, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pb_t), sizeof(unsigned long long) * 4096) != hipSuccess) return -1;
+    if (reset) {
+        std::vector<unsigned long long> z(4096, 0ull);
+        for (int i = 0; i < 1024; i++) z[4 * i] = ~0ull;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_pb_t), z.data(), sizeof(unsigned long long) * 4096) != hipSuccess) return -1;
+    }
+    return 0;
+}
 #endif
 
 extern "C" int ctk_get_stats(ctk_handle *h, int64_t *out)

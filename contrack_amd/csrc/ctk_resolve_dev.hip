@@ -610,6 +610,14 @@ __device__ __forceinline__ void pb_wave_sync(bool through_memory)
     __builtin_amdgcn_wave_barrier();
     if (!through_memory) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+#ifdef CTK_PHASE_TIMING
+__device__ unsigned long long g_pb_t[4 * 1024];      // per workgroup: first entry | after the start-up barrier (last wave) | iterations done (last wave) | end (last wave)
+#define PB_MARK_MIN(k) do { if (lane == 0 && blockIdx.x < 1024) atomicMin(&g_pb_t[4 * blockIdx.x + (k)], wall_clock64()); } while (0)
+#define PB_MARK_MAX(k) do { __builtin_amdgcn_s_waitcnt(0); if (lane == 0 && blockIdx.x < 1024) atomicMax(&g_pb_t[4 * blockIdx.x + (k)], wall_clock64()); } while (0)
+#else
+#define PB_MARK_MIN(k) do { } while (0)
+#define PB_MARK_MAX(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0, int K, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_cnt,
                                                            uint32_t *__restrict__ pstate /* [T + 1], zeroed */, int prep_inline, int do_unite)
 {
@@ -618,6 +626,7 @@ __global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0
     __shared__ uint8_t kb_all[PB_G][PB_COMPS];                 // current keep bits of the wave's timestep (components < PB_COMPS)
     __shared__ uint32_t lstate[PB_G];                          // the wave's pstate word
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+    PB_MARK_MIN(0);
     const int Kfull = K;
     const int t = (int)blockIdx.x * PB_G + w + r.t_lo;
     const bool live = t < (int)r.T;
@@ -659,6 +668,7 @@ __global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0
     uint8_t kold0 = has_c ? __hip_atomic_load(&keep[g0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
     if (lds) for (uint32_t c = lane; c < nct; c += 64) kb[c] = (c == (uint32_t)lane) ? kold0 : __hip_atomic_load(&keep[cb + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();                                           // lstate = 0 and the initial bits of every wave are in LDS
+    PB_MARK_MAX(1);
     if (!live) return;
     if (r.dbg_stall && blockIdx.x == 0) {                      // test hook: the head of the chain is late / never publishes
         if (r.dbg_stall == 2) return;
@@ -675,17 +685,23 @@ __global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0
     };
     const bool publish_mem = w == PB_G - 1 || t == (int)r.T - 1 || !lds;      // somebody outside the workgroup (or without my LDS bits) listens
     const bool dyn_pred = t > r.t_lo;                          // the predecessor is filtered by this launch too
-    uint32_t mybits = 0;
+    uint32_t mybits = 0, st_seen = 0;
     for (int k = 0; k < K; k++) {
         const int it = it0 + k;
         bool evaluate = k == 0;
         if (k > 0 && dyn_pred) {
-            uint32_t st;
+            // The predecessor's word holds the FINAL change bits of all the iterations it counts: a word read earlier that already
+            // counts k is as good as a new one.  (Every read of a word of another workgroup is a trip to L2, ~1 us; wave 0 used to
+            // make one per iteration even when its predecessor was iterations ahead, and the waves behind it wait for wave 0.)
+            uint32_t st = st_seen;
             SpinGuard sg;
             bool gave_up = false;
-            while (((st = pred_state()) >> 24) < (uint32_t)k) {
-                __builtin_amdgcn_s_sleep(1);
-                if (spin_expired(sg, r.spin_limit)) { gave_up = true; break; }
+            if ((st >> 24) < (uint32_t)k) {
+                while (((st = pred_state()) >> 24) < (uint32_t)k) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (spin_expired(sg, r.spin_limit)) { gave_up = true; break; }
+                }
+                st_seen = st;
             }
             if (gave_up) {
                 // nobody may wait for this wave either: the poisoned word says "everything published" to the waves behind
@@ -791,13 +807,14 @@ __global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0
             __hip_atomic_store(&lstate[w], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+    PB_MARK_MAX(2);
     if (!do_unite) return;
     // 3-D links of this timestep (contrack.py:748-750): its kept components with the kept components of t-1 they overlap.  The
     // predecessor's bits are final once it has published all of its iterations.
     if (t - 1 >= r.t_lo && t - 1 <= r.t_hi) {
         const uint32_t need = (uint32_t)Kfull;
         SpinGuard sg;
-        while ((pred_state() >> 24) < need) {
+        while ((st_seen >> 24) < need && (pred_state() >> 24) < need) {
             __builtin_amdgcn_s_sleep(1);
             if (spin_expired(sg, r.spin_limit)) { if (lane == 0) atomicOr(r.poison, CTK_POISON_SPIN); return; }
         }
@@ -819,6 +836,7 @@ __global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0
     };
     for (uint32_t i = lane; i < pn; i += 64) link(pb + i, i == (uint32_t)lane);
     for (uint32_t i = lane; i < nu; i += 64) { if ((int)r.pairs[r.pair_cap - 1u - i].t == t) link(r.pair_cap - 1u - i, false); }
+    PB_MARK_MAX(3);
 }
 
 __global__ void k_rs_unite(ResolveDev r)

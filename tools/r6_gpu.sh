@@ -1,16 +1,11 @@
 #!/bin/bash
-# round 6: long seeded fuzz of the final library (GPU vs oracle / port)
-cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out
+cd /root/repo
 export TMPDIR=/tmp
-(
-timeout 3000 python tools/fuzz.py 800000 30000 2>&1 | tail -1
-timeout 1500 python tools/fuzz.py 840000 10000 edge 2>&1 | tail -1
-timeout 1200 python tools/fuzz.py 860000 5000 f64 2>&1 | tail -1
-timeout 1200 python tools/fuzz.py 870000 5000 thr 2>&1 | tail -1
-timeout 2400 python tools/fuzz_sharded.py 880000 10000 2>&1 | tail -1
-CTK_SH_FORCE_SPLIT=1 timeout 1200 python tools/fuzz_sharded.py 895000 2000 2>&1 | tail -1
-timeout 1200 python tools/fuzz_stream.py 900000 3000 2>&1 | tail -1
-timeout 1200 python tools/fuzz_lifecycle.py 910000 5000 2>&1 | tail -1
-) > gpurun_out/r06_fuzz_long.txt 2>&1
-cat gpurun_out/r06_fuzz_long.txt
+mkdir -p gpurun_out
+timeout 300 python tools/phase_probe_pb.py era5_1deg_djf30 > gpurun_out/pb_probe_1deg_cached.txt 2>&1
+tail -14 gpurun_out/pb_probe_1deg_cached.txt
+timeout 900 python -m pytest tests -m gpu -x -q -k "parity or golden or resolve or filter" 2>&1 | tail -5
+timeout 600 python tools/r6_ab.py --steps 40 --rounds 3 base > gpurun_out/ab_pb_cached.txt 2>&1
+tail -8 gpurun_out/ab_pb_cached.txt
+timeout 600 python tools/r6_ab.py --workload era5_025deg_480 --steps 30 --rounds 2 base > gpurun_out/ab_pb_cached_025.txt 2>&1
+tail -5 gpurun_out/ab_pb_cached_025.txt
