@@ -3317,7 +3317,7 @@ extern "C" int ctk_lifecycle_exact(ctk_handle *h, const int64_t *row_idx, int64_
     }
     CTKCHK(ensure(h, h->lc_ekeys, (size_t)n * sizeof(CtkLifeKey)));
     CTKCHK(ensure(h, h->lc_offs, (size_t)n * 16));                           // pixel offsets, row-table offsets
-    CTKCHK(ensure(h, h->lc_out, (size_t)n * sizeof(CtkLifeExact)));
+    CTKCHK(ensure(h, h->lc_out, (size_t)(n + 1) * sizeof(CtkLifeExact)));      // (+ the kernel's failure word behind the rows)
     HIPCHK(hipMemcpy(h->lc_ekeys.p, keys.data(), (size_t)n * sizeof(CtkLifeKey), hipMemcpyHostToDevice));
     uint32_t *d_counts = (uint32_t *)h->lc_out.p;                            // (reused below for the results)
     k_life_count<<<(unsigned)n, 1024, 0, s>>>(h->lc_flag, P<CtkLifeKey>(h->lc_ekeys), h->lc_ny, h->lc_nx, d_counts);
@@ -3343,16 +3343,21 @@ extern "C" int ctk_lifecycle_exact(ctk_handle *h, const int64_t *row_idx, int64_
     HIPCHK(hipMemcpy(h->lc_offs.p, offs.data(), (size_t)n * 16, hipMemcpyHostToDevice));
     double *d_sw = P<double>(h->lc_sw);
     const size_t st = px / 8;
+    uint32_t *d_fail = reinterpret_cast<uint32_t *>(P<CtkLifeExact>(h->lc_out) + n);
+    HIPCHK(hipMemsetAsync(d_fail, 0, 4, s));
 #define CTK_LX_LAUNCH(VT, G)                                                                                                                                       \
     k_life_exact<VT, G><<<(unsigned)n, 256 * G, 0, s>>>(h->lc_flag, (const VT *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),   \
                                                         P<uint64_t>(h->lc_offs) + n, h->lc_ny, h->lc_nx, d_sw, d_sw + st, d_sw + 2 * st, d_sw + 3 * st, d_sw + 4 * st, \
-                                                        P<uint32_t>(h->lc_sp), P<CtkLifeExact>(h->lc_out))
+                                                        P<uint32_t>(h->lc_sp), P<CtkLifeExact>(h->lc_out), d_fail)
     if (h->lc_f64) { if (lx_threads == 1024) CTK_LX_LAUNCH(double, 4); else CTK_LX_LAUNCH(double, 1); }
     else { if (lx_threads == 1024) CTK_LX_LAUNCH(float, 4); else CTK_LX_LAUNCH(float, 1); }
 #undef CTK_LX_LAUNCH
     HIPCHK(hipGetLastError());
+    uint32_t failed = 0;
     HIPCHK(hipMemcpyAsync(out, h->lc_out.p, (size_t)n * sizeof(CtkLifeExact), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&failed, d_fail, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (failed) return ctk_set_error(CTK_E_INTERNAL, "ctk_lifecycle_exact: a wait between the waves of k_life_exact expired");
     return CTK_OK;
 }
 

@@ -771,14 +771,17 @@ __device__ inline double np_walk(uint32_t cn, Leaf leaf, NpFrame *f)
 // combines them in the tree's order.  lo / ln: LDS scratch for 128 leaves.
 // Two such sums over lists of the same length at once (k_life_exact: the area and the weighted sum of one contour): the tree, and
 // so the list of leaves, depends on the length only -- it is listed once per chunk LENGTH (every chunk but the last is 8192 long),
-// the leaves of both lists are summed side by side (threads 0..127 / 128..255) and combined by two waves at the same time.
+// the leaves of both lists are summed side by side (threads 0..63 / 64..127 of a group: its first two waves; the other two take no part -- k_life_exact
+// gives them other work) and combined by two waves at the same time.
 // lv: 256 doubles, frames: 2 x 16.  Results valid in thread 0 (ra) and thread 64 (rb).
 // Round 5: a workgroup of 1024 threads takes FOUR blocks per round (groups of 256 threads, each with its own leaf list, leaf sums and
 // the two threads that walk the trees); the block sums are added in the order of the blocks by thread 0 / thread 64, as numpy's
 // buffered reduction adds its 8192-element buffers one after the other.
 // lo / ln: [G][128], lv: [G][256], nleaf: [G], frames: [G][32], cres: [2][4]   (G = blockDim / 256 <= 4)
+// sync: the barrier between the steps, made by every thread that runs this function (the first two waves of every group at least)
+template <typename Sync>
 __device__ inline void wg_np_sum2(const double *a, const double *b, size_t n, uint32_t *lo_all, uint32_t *ln_all, double *lv_all, int *nleaf_all, NpFrame *frames_all,
-                                  double *cres, double &ra, double &rb)
+                                  double *cres, double &ra, double &rb, Sync sync)
 {
     double acc = 0.0;
     const int tid = (int)threadIdx.x, G = (int)(blockDim.x >> 8) > 0 ? (int)(blockDim.x >> 8) : 1, grp = tid >> 8, t8 = tid & 255;
@@ -797,17 +800,17 @@ __device__ inline void wg_np_sum2(const double *a, const double *b, size_t n, ui
             }
             listed = cn;
         }
-        __syncthreads();
+        sync();
         const int nl = cn ? nleaf_all[grp] : 0;
         if (t8 < nl) lv[t8] = dev_np_leaf(a + c0 + lo[t8], ln[t8]);
-        else if (t8 >= 128 && t8 - 128 < nl) lv[t8] = dev_np_leaf(b + c0 + lo[t8 - 128], ln[t8 - 128]);
-        __syncthreads();
+        else if (t8 >= 64 && t8 - 64 < nl) lv[64 + t8] = dev_np_leaf(b + c0 + lo[t8 - 64], ln[t8 - 64]);
+        sync();
         if (cn && t8 == 0) { int k = 0; cres[grp] = np_walk(cn, [&](uint32_t, uint32_t) { return lv[k++]; }, frames); }
         else if (cn && t8 == 64) { int k = 128; cres[4 + grp] = np_walk(cn, [&](uint32_t, uint32_t) { return lv[k++]; }, frames + 16); }
-        __syncthreads();
+        sync();
         if (tid == 0) { for (int g = 0; g < G; g++) if (r0 + (size_t)8192 * g < n) acc += cres[g]; }
         else if (tid == 64) { for (int g = 0; g < G; g++) if (r0 + (size_t)8192 * g < n) acc += cres[4 + g]; }
-        __syncthreads();
+        sync();
     }
     if (tid == 0) ra = acc;
     if (tid == 64) rb = acc;
@@ -848,29 +851,34 @@ __global__ __launch_bounds__(1024) void k_life_count(const int32_t *__restrict__
 // 1024 threads when a listed row is large -- sixteen waves share the two scans over the rows --, and the sequential sums read their
 // block from LDS two values per load, eight values ahead of the add chain, while ALL threads already hold the next block's values in
 // registers (the global loads travel underneath the chain; two LDS buffers, one barrier per block).
-// Round 6 (advisor finding): the LDS tables follow the launch -- G = threads / 256 groups of the pairwise sums, blocks of 512 (one
-// group) or 1024 values of the sequential sums -- so that the common 256-thread launch keeps its ~30 KB (five workgroups per CU) and
-// only the 1024-thread launch for large contours takes ~66 KB.
+// Round 6 (advisor finding): the LDS tables follow the launch -- G = threads / 256 groups of the pairwise sums, a ring of four blocks of
+// 256 (one group) or 512 values of the sequential sums -- so that the common 256-thread launch keeps its ~31 KB and only the 1024-thread
+// launch for large contours takes ~66 KB.  Round 6 also: the pairwise sums, the sequential sums and their loads run on different waves at
+// the same time (see "D and E" below): 1.60 -> 0.83 ms for the 105 000-pixel contour.
 template <typename VT, int G>
 __global__ __launch_bounds__(256 * G) void k_life_exact(const int32_t *__restrict__ flag, const VT *__restrict__ field, const float *__restrict__ wrow,
                                                     const CtkLifeKey *__restrict__ keys, const uint64_t *__restrict__ offs, const uint64_t *__restrict__ roffs,
                                                     int ny, int nx, double *__restrict__ sw, double *__restrict__ sp_, double *__restrict__ sq,
                                                     double *__restrict__ sqy, double *__restrict__ sqx, uint32_t *__restrict__ rowtab,
-                                                    CtkLifeExact *__restrict__ out)
+                                                    CtkLifeExact *__restrict__ out, uint32_t *__restrict__ fail /* zeroed; != 0: a wait inside a workgroup expired */)
 {
-    constexpr int LX_STAGE = G == 1 ? 512 : 1024;
+    constexpr int LX_EB = G == 1 ? 256 : 512;                   // values of a list per block of the sequential sums
+    constexpr int LX_NSLOT = 4;                                 // blocks in LDS
+    constexpr int LX_NF = G;                                    // waves that feed them (the third wave of every group of four)
+    constexpr uint64_t LX_SPIN = 20000000ull;                   // 0.2 s of the 100 MHz clock: no wait inside this kernel is longer than microseconds
     __shared__ uint32_t part[256];
+    __shared__ uint32_t d_arrived, e_consumed, e_filled[LX_NSLOT], lx_bad;
     __shared__ uint32_t lo[G * 128], ln[G * 128];
     __shared__ double lv[G * 256], cres[8];
     __shared__ int nleaf[G];
     __shared__ NpFrame frames[G * 32];
-    __shared__ __attribute__((aligned(16))) double stage[2][3][LX_STAGE];
+    __shared__ __attribute__((aligned(16))) double stage[LX_NSLOT][3][LX_EB + 2];      // (+2: the three lists of a block start in different banks)
     __shared__ double res[5];
     const CtkLifeKey k = keys[blockIdx.x];
     const uint32_t npx = (uint32_t)ny * (uint32_t)nx;
     const int32_t *fp = flag + (int64_t)k.t * npx;
     const VT *vp = field + (int64_t)k.t * npx;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)(blockDim.x >> 6), nthr = (int)blockDim.x;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)(blockDim.x >> 6);
     const int ya = (int)((uint32_t)k.pad & 0xffffu), yb = min(ny - 1, (int)((uint32_t)k.pad >> 16)), nrows = yb - ya + 1;
     const int shift = k.shift > 0 ? k.shift : 0;
     double *gw = sw + offs[blockIdx.x], *gp = sp_ + offs[blockIdx.x], *gq = sq + offs[blockIdx.x], *gqy = sqy + offs[blockIdx.x], *gqx = sqx + offs[blockIdx.x];
@@ -956,77 +964,132 @@ __global__ __launch_bounds__(256 * G) void k_life_exact(const int32_t *__restric
     }
     __syncthreads();
     LX_MARK(1);
-    // D: np.sum over the raster-order lists
-    {
+    // D and E at the same time (round 6; they were 0.2-0.34 + 0.9 ms of 1.6 for a contour of 105 000 pixels), by three kinds of waves:
+    // D, waves 4g and 4g+1: np.sum over the raster-order lists (wg_np_sum2).  Their barrier is a counter in LDS -- the hardware barrier would
+    //    stop the other waves too.
+    // E, wave 3: np.bincount's strictly sequential sums over the rolled lists.  Lane l walks list l % 3 (lanes 0..2 keep the results), so the
+    //    three chains advance with ONE v_add_f64 per step; a full block is one basic block of LX_EB adds and LX_EB / 2 LDS loads (hipcc waits
+    //    for ALL outstanding LDS loads -- lgkmcnt(0) -- in front of the first use of a value that was loaded before a loop edge, i.e. also for
+    //    the loads just issued: 1.6 of the old loop's 4.3 ns per add; tools/f64chain.hip: 2.7 ns for adds from registers, 3.5 in this form;
+    //    the old form -- three waves, lane 0 of each -- ran at 8.5 ns inside this kernel).
+    // F, waves 4g+2: they carry the blocks of the three lists from memory into a ring of LX_NSLOT blocks in LDS, each its own blocks
+    //    (f, f + LX_NF, ...), one block in registers while the previous one waits for its slot.  (The chain wave feeding itself had one block
+    //    of loads in flight and waited ~1 us of every 2.9 for it.)
+    // Hand-over through LDS words: e_filled[slot] = block + 1 once a block is stored, e_consumed = blocks the chain has finished.  LDS
+    // executes the operations of a wave in order, so a word written behind the data is seen behind the data.
+    const bool role_d = (wave & 3) < 2, role_f = (wave & 3) == 2, role_e = wave == 3;
+    const uint32_t d_waves = (uint32_t)nw / 2u;
+    const size_t nblk = (total + LX_EB - 1) / LX_EB;
+    if (tid == 0) { d_arrived = 0u; e_consumed = 0u; lx_bad = 0u; }
+    if (tid < LX_NSLOT) e_filled[tid] = 0u;
+    __syncthreads();
+    auto lds_ld = [&](uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto give_up = [&]() { if (lane == 0) __hip_atomic_store(&lx_bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    double acc = 0.0;
+    if (role_d) {
+        uint32_t d_phase = 0;
         double area = 0.0, swv = 0.0;
-        wg_np_sum2(gw, gp, total, lo, ln, lv, nleaf, frames, cres, area, swv);
+        wg_np_sum2(gw, gp, total, lo, ln, lv, nleaf, frames, cres, area, swv, [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            d_phase++;
+            if (lane == 0) atomicAdd(&d_arrived, 1u);
+            SpinGuard sg;
+            while (lds_ld(&d_arrived) < d_waves * d_phase && !lds_ld(&lx_bad)) {
+                __builtin_amdgcn_s_sleep(2);
+                if (spin_expired(sg, LX_SPIN)) { give_up(); break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        });
         if (tid == 0) res[0] = area;
         if (tid == 64) res[1] = swv;
-    }
-    LX_MARK(2);
-    // E: np.bincount's strictly sequential sums over the rolled lists: blocks staged in LDS, one lane per sum
-    double acc = 0.0;
-    {
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        const int per = LX_STAGE / nthr > 0 ? LX_STAGE / nthr : 1;           // values per thread and list of a block (4 at 256 threads, 1 at 1024)
-        double hq[4], hy[4], hx[4];
-        auto fetch = [&](size_t c0) {                                        // the block at c0 into registers (zeros behind the end)
+        LX_MARK(2);                                                          // (the pairwise sums are done; [4]: the chains)
+    } else if (role_f) {
+        constexpr int PER = LX_EB / 64;                                      // values per lane and list of a block
+        double aq[PER], ay[PER], ax[PER], bq[PER], by[PER], bx[PER];
+        auto fetch = [&](double (&hq)[PER], double (&hy)[PER], double (&hx)[PER], size_t blk) {      // (zeros behind the end of the lists)
+            const size_t c0 = blk * LX_EB;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const size_t i = c0 + (size_t)u * nthr + tid;
-                const bool in = u < per && i < total && (size_t)u * nthr + tid < LX_STAGE;
+            for (int u = 0; u < PER; ++u) {
+                const size_t i = c0 + (size_t)u * 64 + lane;
+                const bool in = i < total;
                 hq[u] = in ? gq[i] : 0.0; hy[u] = in ? gqy[i] : 0.0; hx[u] = in ? gqx[i] : 0.0;
             }
         };
-        auto put = [&](int b) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = u * nthr + tid;
-                if (u < per && i < LX_STAGE) { stage[b][0][i] = hq[u]; stage[b][1][i] = hy[u]; stage[b][2][i] = hx[u]; }
+        auto put = [&](const double (&hq)[PER], const double (&hy)[PER], const double (&hx)[PER], size_t blk) -> bool {
+            const int slot = (int)(blk % LX_NSLOT);
+            SpinGuard sg;
+            while ((size_t)lds_ld(&e_consumed) + LX_NSLOT <= blk) {          // the block that sits in this slot is not finished yet
+                if (lds_ld(&lx_bad)) return false;
+                __builtin_amdgcn_s_sleep(4);
+                if (spin_expired(sg, LX_SPIN)) { give_up(); return false; }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (int u = 0; u < PER; ++u) { stage[slot][0][u * 64 + lane] = hq[u]; stage[slot][1][u * 64 + lane] = hy[u]; stage[slot][2][u * 64 + lane] = hx[u]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&e_filled[slot], (uint32_t)(blk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return true;
         };
-        int cur = 0;
-        if (total > 0) { fetch(0); put(0); }
-        __syncthreads();
-        for (size_t c0 = 0; c0 < total; c0 += LX_STAGE) {
-            const int cn = (int)min((size_t)LX_STAGE, total - c0);
-            const bool more = c0 + LX_STAGE < total;
-            if (more) fetch(c0 + LX_STAGE);                                  // (in flight underneath the chain below)
-            if (lane == 0 && wave < 3) {
-                const double *sv = stage[cur][wave];                         // (behind the end of the list: zeros are NOT added -- cn bounds the loop)
-                int i = 0;
-                if (cn >= 8) {
-                    // two register sets, loaded sixteen values ahead in turn.  (With one set and a copy at the end of the iteration hipcc
-                    // merged the two and issued the loads right in front of their use: ~120 cycles of LDS latency per eight adds.  The empty
-                    // asm statements -- the chain's value passes through them -- keep the loads in front of the adds that are meant to cover them.)
+        size_t blk = (size_t)(wave >> 2);
+        if (blk < nblk) fetch(aq, ay, ax, blk);
+        while (blk < nblk) {
+            if (blk + LX_NF < nblk) fetch(bq, by, bx, blk + LX_NF);          // (in flight while the block in hand waits for its slot)
+            if (!put(aq, ay, ax, blk)) break;
+            blk += LX_NF;
+            if (blk >= nblk) break;
+            if (blk + LX_NF < nblk) fetch(aq, ay, ax, blk + LX_NF);
+            if (!put(bq, by, bx, blk)) break;
+            blk += LX_NF;
+        }
+    } else if (role_e) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const int l3 = lane % 3;
+        for (size_t blk = 0; blk < nblk; ++blk) {
+            const int slot = (int)(blk % LX_NSLOT);
+            const int cn = (int)min((size_t)LX_EB, total - blk * LX_EB);
+            SpinGuard sg;
+            bool ok = true;
+            while (lds_ld(&e_filled[slot]) != (uint32_t)(blk + 1)) {
+                if (lds_ld(&lx_bad)) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+                if (spin_expired(sg, LX_SPIN)) { give_up(); ok = false; break; }
+            }
+            if (!ok) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const double *sv = stage[slot][l3];                              // (behind the end of the list: zeros are NOT added -- cn bounds the loop)
+            if (cn == LX_EB) {
 #define LX_LD(o) (*reinterpret_cast<const d2 *>(sv + (o)))
 #define LX_ADD(q0, q1, q2, q3) do { acc += q0.x; acc += q0.y; acc += q1.x; acc += q1.y; acc += q2.x; acc += q2.y; acc += q3.x; acc += q3.y; } while (0)
-                    d2 a0 = LX_LD(0), a1 = LX_LD(2), a2 = LX_LD(4), a3 = LX_LD(6);
-                    for (i = 8; i + 16 <= cn; i += 16) {
-                        const d2 b0 = LX_LD(i), b1 = LX_LD(i + 2), b2 = LX_LD(i + 4), b3 = LX_LD(i + 6);
-                        asm volatile("" : "+v"(acc) : : "memory");
-                        LX_ADD(a0, a1, a2, a3);
-                        a0 = LX_LD(i + 8); a1 = LX_LD(i + 10); a2 = LX_LD(i + 12); a3 = LX_LD(i + 14);
-                        asm volatile("" : "+v"(acc) : : "memory");
-                        LX_ADD(b0, b1, b2, b3);
-                    }
-                    LX_ADD(a0, a1, a2, a3);
+                // sixteen values ahead of the adds.  (The empty asm statements -- the chain's value passes through them -- keep the loads in front of
+                // the adds that are meant to cover them.)
+                d2 a0 = LX_LD(0), a1 = LX_LD(2), a2 = LX_LD(4), a3 = LX_LD(6), a4 = LX_LD(8), a5 = LX_LD(10), a6 = LX_LD(12), a7 = LX_LD(14);
+#pragma unroll
+                for (int j = 16; j < LX_EB; j += 16) {
+                    const d2 b0 = LX_LD(j), b1 = LX_LD(j + 2), b2 = LX_LD(j + 4), b3 = LX_LD(j + 6), b4 = LX_LD(j + 8), b5 = LX_LD(j + 10), b6 = LX_LD(j + 12), b7 = LX_LD(j + 14);
+                    asm volatile("" : "+v"(acc) : : "memory");
+                    LX_ADD(a0, a1, a2, a3); LX_ADD(a4, a5, a6, a7);
+                    a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
+                }
+                LX_ADD(a0, a1, a2, a3); LX_ADD(a4, a5, a6, a7);
 #undef LX_LD
 #undef LX_ADD
-                }
-                for (; i < cn; ++i) acc += sv[i];
+            } else {
+                for (int i = 0; i < cn; ++i) acc += sv[i];
             }
-            if (more) put(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&e_consumed, (uint32_t)(blk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+#ifdef CTK_PHASE_TIMING
+        if (total > 50000 && lane == 0) g_phase_t[4] = wall_clock64();
+#endif
     }
-    LX_MARK(3);
-    if (lane == 0 && wave < 3) res[2 + wave] = acc;
+    if (role_e && lane < 3) res[2 + lane] = acc;
     __syncthreads();
+    LX_MARK(3);
     if (tid == 0) {
         CtkLifeExact r;
         r.area = res[0]; r.swv = res[1]; r.s = res[2]; r.sy = res[3]; r.sx = res[4];
         out[blockIdx.x] = r;
+        if (lx_bad) atomicOr(fail, 1u);
     }
 }

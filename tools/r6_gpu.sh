@@ -2,10 +2,10 @@
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 300 python tools/phase_probe_pb.py era5_1deg_djf30 > gpurun_out/pb_probe_1deg_cached.txt 2>&1
-tail -14 gpurun_out/pb_probe_1deg_cached.txt
-timeout 900 python -m pytest tests -m gpu -x -q -k "parity or golden or resolve or filter" 2>&1 | tail -5
-timeout 600 python tools/r6_ab.py --steps 40 --rounds 3 base > gpurun_out/ab_pb_cached.txt 2>&1
-tail -8 gpurun_out/ab_pb_cached.txt
-timeout 600 python tools/r6_ab.py --workload era5_025deg_480 --steps 30 --rounds 2 base > gpurun_out/ab_pb_cached_025.txt 2>&1
-tail -5 gpurun_out/ab_pb_cached_025.txt
+rm -rf gpurun_out/prof_life
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_life -o life -- python tools/lifecycle_probe.py 480 721 1440 > gpurun_out/life_probe_rocprof.txt 2>&1
+grep -v "^W2026\|^E2026" gpurun_out/life_probe_rocprof.txt | tail -8
+f=$(find gpurun_out/prof_life -name "*kernel_stats.csv" | head -1)
+cp "$f" gpurun_out/r06_lifecycle_025deg_480_kernel_stats.csv
+grep "k_life" gpurun_out/r06_lifecycle_025deg_480_kernel_stats.csv | cut -c1-40,260-
+rm -rf gpurun_out/prof_life
