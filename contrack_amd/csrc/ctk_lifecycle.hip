@@ -830,12 +830,12 @@ __global__ __launch_bounds__(1024) void k_life_count(const int32_t *__restrict__
     uint32_t c = 0;
     const uint32_t pa = ((uint32_t)k.pad & 0xffffu) * (uint32_t)nx, pb = min(npx, (((uint32_t)k.pad >> 16) + 1u) * (uint32_t)nx);
     const uint32_t nt = blockDim.x;
-    for (uint32_t p = pa + threadIdx.x; p < pb; p += 4 * nt) {                // four loads in flight per lane (latency-bound scan)
-        int32_t v[4];
+    for (uint32_t p = pa + threadIdx.x; p < pb; p += 8 * nt) {                // eight loads in flight per lane (latency-bound scan)
+        int32_t v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = (p + u * nt < pb) ? fp[p + u * nt] : 0;
+        for (int u = 0; u < 8; ++u) v[u] = (p + u * nt < pb) ? fp[p + u * nt] : 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) c += (p + u * nt < pb && v[u] == k.label) ? 1u : 0u;
+        for (int u = 0; u < 8; ++u) c += (p + u * nt < pb && v[u] == k.label) ? 1u : 0u;
     }
     c = wave_sum_u32(c);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(1024) void k_life_count(const int32_t *__restrict__
 // Round 6 (advisor finding): the LDS tables follow the launch -- G = threads / 256 groups of the pairwise sums, a ring of four blocks of
 // 256 (one group) or 512 values of the sequential sums -- so that the common 256-thread launch keeps its ~31 KB and only the 1024-thread
 // launch for large contours takes ~66 KB.  Round 6 also: the pairwise sums, the sequential sums and their loads run on different waves at
-// the same time (see "D and E" below): 1.60 -> 0.83 ms for the 105 000-pixel contour.
+// the same time (see "D and E" below): 1.60 -> 0.76 ms for the 105 000-pixel contour.
 template <typename VT, int G>
 __global__ __launch_bounds__(256 * G) void k_life_exact(const int32_t *__restrict__ flag, const VT *__restrict__ field, const float *__restrict__ wrow,
                                                     const CtkLifeKey *__restrict__ keys, const uint64_t *__restrict__ offs, const uint64_t *__restrict__ roffs,
@@ -863,6 +863,7 @@ __global__ __launch_bounds__(256 * G) void k_life_exact(const int32_t *__restric
                                                     CtkLifeExact *__restrict__ out, uint32_t *__restrict__ fail /* zeroed; != 0: a wait inside a workgroup expired */)
 {
     constexpr int LX_EB = G == 1 ? 256 : 512;                   // values of a list per block of the sequential sums
+    constexpr int LX_U = 12;                                    // flag loads in flight per lane in the two scans over the rows
     constexpr int LX_NSLOT = 4;                                 // blocks in LDS
     constexpr int LX_NF = G;                                    // waves that feed them (the third wave of every group of four)
     constexpr uint64_t LX_SPIN = 20000000ull;                   // 0.2 s of the 100 MHz clock: no wait inside this kernel is longer than microseconds
@@ -888,12 +889,12 @@ __global__ __launch_bounds__(256 * G) void k_life_exact(const int32_t *__restric
     for (int r = wave; r < nrows; r += nw) {
         const int32_t *rp = fp + (size_t)(ya + r) * nx;
         uint32_t c = 0, cl = 0;
-        for (int x0 = 0; x0 < nx; x0 += 4 * 64) {                            // four loads in flight per lane
-            int32_t v[4];
+        for (int x0 = 0; x0 < nx; x0 += LX_U * 64) {                         // LX_U loads in flight per lane (one wave per row: a scan bound by the trips to memory)
+            int32_t v[LX_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int x = x0 + u * 64 + lane; v[u] = x < nx ? rp[x] : 0; }
+            for (int u = 0; u < LX_U; ++u) { const int x = x0 + u * 64 + lane; v[u] = x < nx ? rp[x] : 0; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < LX_U; ++u) {
                 const int x = x0 + u * 64 + lane;
                 const bool m = x < nx && v[u] == k.label;
                 c += (uint32_t)__popcll(__ballot(m));
@@ -936,19 +937,23 @@ __global__ __launch_bounds__(256 * G) void k_life_exact(const int32_t *__restric
         const uint32_t base = roff[r], nleft = rleft[r], nright = rcnt[r] - nleft;
         if (rcnt[r] == 0) continue;                                        // (wave-uniform)
         uint32_t seen = 0;
-        for (int xq = 0; xq < nx; xq += 4 * 64) {
-          int32_t v4[4];
+        for (int xq = 0; xq < nx; xq += LX_U * 64) {
+          int32_t v4[LX_U];
+          VT f4[LX_U];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { const int x = xq + u * 64 + lane; v4[u] = x < nx ? rp[x] : 0; }
+          for (int u = 0; u < LX_U; ++u) { const int x = xq + u * 64 + lane; v4[u] = x < nx ? rp[x] : 0; }
+          // (the values of all members of the batch in one trip: a load inside the branch below would be a trip of its own per u)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < LX_U; ++u) { const int x = xq + u * 64 + lane; f4[u] = (x < nx && v4[u] == k.label) ? rv[x] : (VT)0; }
+#pragma unroll
+          for (int u = 0; u < LX_U; ++u) {
             const int x = xq + u * 64 + lane;
             const bool m = x < nx && v4[u] == k.label;
             const uint64_t bal = __ballot(m);
             if (!bal) continue;
             if (m) {
                 const uint32_t idx = seen + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                const double p = (double)rv[x] * w;                       // variable * weight_grid (:886 / :892) = weight_grid * variable (:875)
+                const double p = (double)f4[u] * w;                       // variable * weight_grid (:886 / :892) = weight_grid * variable (:875)
                 gw[base + idx] = w;
                 gp[base + idx] = p;
                 int xr = x - shift;
