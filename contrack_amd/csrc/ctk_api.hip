@@ -3317,40 +3317,50 @@ extern "C" int ctk_lifecycle_exact(ctk_handle *h, const int64_t *row_idx, int64_
     }
     CTKCHK(ensure(h, h->lc_ekeys, (size_t)n * sizeof(CtkLifeKey)));
     CTKCHK(ensure(h, h->lc_offs, (size_t)n * 16));                           // pixel offsets, row-table offsets
-    CTKCHK(ensure(h, h->lc_out, (size_t)(n + 1) * sizeof(CtkLifeExact)));      // (+ the kernel's failure word behind the rows)
-    HIPCHK(hipMemcpy(h->lc_ekeys.p, keys.data(), (size_t)n * sizeof(CtkLifeKey), hipMemcpyHostToDevice));
-    uint32_t *d_counts = (uint32_t *)h->lc_out.p;                            // (reused below for the results)
-    k_life_count<<<(unsigned)n, 1024, 0, s>>>(h->lc_flag, P<CtkLifeKey>(h->lc_ekeys), h->lc_ny, h->lc_nx, d_counts);
-    HIPCHK(hipGetLastError());
-    std::vector<uint32_t> counts((size_t)n);
-    HIPCHK(hipMemcpyAsync(counts.data(), d_counts, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    CTKCHK(ensure(h, h->lc_out, (size_t)(n + 1) * sizeof(CtkLifeExact) + (size_t)n * 4));      // the rows | the kernel's failure word | the pixel counts
+    // row tables: three words per row of every contour's row extent (the keys know the extents)
     std::vector<uint64_t> offs((size_t)2 * n);
-    uint64_t total = 0, rtotal = 0;
+    uint64_t rtotal = 0;
+    int max_rows = 1;
     for (int64_t i = 0; i < n; ++i) {
-        offs[(size_t)i] = total; total += counts[(size_t)i];
         const uint32_t pad = (uint32_t)keys[(size_t)i].pad;
         const int ya = (int)(pad & 0xffffu), yb = std::min(h->lc_ny - 1, (int)(pad >> 16));
         if (yb < ya) return ctk_set_error(CTK_E_INTERNAL, "ctk_lifecycle_exact: row %lld has no row extent", (long long)row_idx[i]);
         offs[(size_t)(n + i)] = rtotal; rtotal += 3 * (uint64_t)(yb - ya + 1);
+        max_rows = std::max(max_rows, yb - ya + 1);
     }
+    CTKCHK(ensure(h, h->lc_sp, (size_t)std::max<uint64_t>(rtotal, 1) * 4));
+    HIPCHK(hipMemcpyAsync(h->lc_ekeys.p, keys.data(), (size_t)n * sizeof(CtkLifeKey), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(P<uint64_t>(h->lc_offs) + n, offs.data() + n, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    uint32_t *d_fail = reinterpret_cast<uint32_t *>(P<CtkLifeExact>(h->lc_out) + n);
+    uint32_t *d_counts = d_fail + sizeof(CtkLifeExact) / 4;
+    const dim3 rgrid((unsigned)n, (unsigned)((max_rows + 3) / 4));           // (x: the listed row, y: four rows of its row extent)
+    k_life_rows<<<rgrid, 256, 0, s>>>(h->lc_flag, P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs) + n, h->lc_ny, h->lc_nx, P<uint32_t>(h->lc_sp));
+    k_life_rowscan<<<(unsigned)n, 256, 0, s>>>(P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs) + n, h->lc_ny, P<uint32_t>(h->lc_sp), d_counts);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> counts((size_t)n);
+    HIPCHK(hipMemcpyAsync(counts.data(), d_counts, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    uint64_t total = 0;
     uint32_t max_count = 0;
-    for (int64_t i = 0; i < n; ++i) max_count = std::max(max_count, counts[(size_t)i]);
-    const int lx_threads = max_count > 8192 ? 1024 : 256;      // (large contours: sixteen waves share the row scans)
+    for (int64_t i = 0; i < n; ++i) { offs[(size_t)i] = total; total += counts[(size_t)i]; max_count = std::max(max_count, counts[(size_t)i]); }
+    const int lx_threads = max_count > 8192 ? 1024 : 256;      // (large contours: four groups of the pairwise sums, four feeder waves)
     const size_t px = (size_t)std::max<uint64_t>(total, 1) * 8;
     CTKCHK(ensure(h, h->lc_sw, 5 * px));                                      // sw | sp | sq | sqy | sqx
-    CTKCHK(ensure(h, h->lc_sp, (size_t)std::max<uint64_t>(rtotal, 1) * 4));   // the row tables
-    HIPCHK(hipMemcpy(h->lc_offs.p, offs.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(h->lc_offs.p, offs.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(d_fail, 0, 4, s));
     double *d_sw = P<double>(h->lc_sw);
     const size_t st = px / 8;
-    uint32_t *d_fail = reinterpret_cast<uint32_t *>(P<CtkLifeExact>(h->lc_out) + n);
-    HIPCHK(hipMemsetAsync(d_fail, 0, 4, s));
-#define CTK_LX_LAUNCH(VT, G)                                                                                                                                       \
-    k_life_exact<VT, G><<<(unsigned)n, 256 * G, 0, s>>>(h->lc_flag, (const VT *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs),   \
-                                                        P<uint64_t>(h->lc_offs) + n, h->lc_ny, h->lc_nx, d_sw, d_sw + st, d_sw + 2 * st, d_sw + 3 * st, d_sw + 4 * st, \
-                                                        P<uint32_t>(h->lc_sp), P<CtkLifeExact>(h->lc_out), d_fail)
-    if (h->lc_f64) { if (lx_threads == 1024) CTK_LX_LAUNCH(double, 4); else CTK_LX_LAUNCH(double, 1); }
-    else { if (lx_threads == 1024) CTK_LX_LAUNCH(float, 4); else CTK_LX_LAUNCH(float, 1); }
+    if (h->lc_f64)
+        k_life_lists<double><<<rgrid, 256, 0, s>>>(h->lc_flag, (const double *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs), P<uint64_t>(h->lc_offs) + n,
+                                                   h->lc_ny, h->lc_nx, d_sw, d_sw + st, d_sw + 2 * st, d_sw + 3 * st, d_sw + 4 * st, P<uint32_t>(h->lc_sp));
+    else
+        k_life_lists<float><<<rgrid, 256, 0, s>>>(h->lc_flag, (const float *)h->lc_field, P<float>(h->lc_w), P<CtkLifeKey>(h->lc_ekeys), P<uint64_t>(h->lc_offs), P<uint64_t>(h->lc_offs) + n,
+                                                  h->lc_ny, h->lc_nx, d_sw, d_sw + st, d_sw + 2 * st, d_sw + 3 * st, d_sw + 4 * st, P<uint32_t>(h->lc_sp));
+#define CTK_LX_LAUNCH(G)                                                                                                                                   \
+    k_life_exact<G><<<(unsigned)n, 256 * G, 0, s>>>(P<uint64_t>(h->lc_offs), d_counts, d_sw, d_sw + st, d_sw + 2 * st, d_sw + 3 * st, d_sw + 4 * st,         \
+                                                    P<CtkLifeExact>(h->lc_out), d_fail)
+    if (lx_threads == 1024) CTK_LX_LAUNCH(4); else CTK_LX_LAUNCH(1);
 #undef CTK_LX_LAUNCH
     HIPCHK(hipGetLastError());
     uint32_t failed = 0;

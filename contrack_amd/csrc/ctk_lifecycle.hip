@@ -820,133 +820,101 @@ struct CtkLifeKey {
     int32_t t, label, shift, pad;
 };
 
-// members of every listed (time step, id)
-__global__ __launch_bounds__(1024) void k_life_count(const int32_t *__restrict__ flag, const CtkLifeKey *__restrict__ keys, int ny, int nx, uint32_t *__restrict__ counts)
+// ------------------------------------------------------------------------------------------------
+// The compact lists of the listed rows (round 6: three kernels over ALL rows of ALL listed contours; they were the first three phases
+// of k_life_exact -- one workgroup per contour, 0.08 + 0.21 ms on one CU for a contour of 105 000 pixels -- and k_life_count, a scan of
+// its own over the same rows, 75 us).
+// rowtab (per key, 3 * nrows words at roffs[key]): pixels of the id per row | those left of the roll edge | their offset in the lists.
+//   k_life_rows  <<<(keys, rows / 4), 256>>>  one wave per row of the contour's row extent: the two counts
+//   k_life_rowscan <<<keys, 256>>>            exclusive scan of the counts, the contour's pixel count -> counts[key]  (the host sums them: list offsets)
+//   k_life_lists <<<(keys, rows / 4), 256>>>  one wave per row: the five lists.  sw / sp: the weights and products in raster order of the plane
+//       (what np.sum sees, contrack.py:874-875); sq / sqy / sqx: p, p*y, p*x' in raster order of the ROLLED plane (np.bincount's order inside
+//       ndimage.center_of_mass, :886 / :892): of a row the pixels right of the edge (x >= shift) first, then those left of it.
+// ------------------------------------------------------------------------------------------------
+#define LR_U 12                                                  // flag loads in flight per lane (one wave per row: a scan bound by the trips to memory)
+__global__ __launch_bounds__(256) void k_life_rows(const int32_t *__restrict__ flag, const CtkLifeKey *__restrict__ keys, const uint64_t *__restrict__ roffs,
+                                                   int ny, int nx, uint32_t *__restrict__ rowtab)
 {
-    __shared__ uint32_t part[16];
     const CtkLifeKey k = keys[blockIdx.x];
-    const uint32_t npx = (uint32_t)ny * (uint32_t)nx;
-    const int32_t *fp = flag + (int64_t)k.t * npx;
-    uint32_t c = 0;
-    const uint32_t pa = ((uint32_t)k.pad & 0xffffu) * (uint32_t)nx, pb = min(npx, (((uint32_t)k.pad >> 16) + 1u) * (uint32_t)nx);
-    const uint32_t nt = blockDim.x;
-    for (uint32_t p = pa + threadIdx.x; p < pb; p += 8 * nt) {                // eight loads in flight per lane (latency-bound scan)
-        int32_t v[8];
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int ya = (int)((uint32_t)k.pad & 0xffffu), yb = min(ny - 1, (int)((uint32_t)k.pad >> 16)), nrows = yb - ya + 1;
+    const int r = (int)blockIdx.y * 4 + wave;
+    if (r >= nrows) return;
+    const int shift = k.shift > 0 ? k.shift : 0;
+    const int32_t *rp = flag + (int64_t)k.t * ((int64_t)ny * nx) + (size_t)(ya + r) * nx;
+    uint32_t *rcnt = rowtab + roffs[blockIdx.x], *rleft = rcnt + nrows;
+    uint32_t c = 0, cl = 0;
+    for (int x0 = 0; x0 < nx; x0 += LR_U * 64) {
+        int32_t v[LR_U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (p + u * nt < pb) ? fp[p + u * nt] : 0;
+        for (int u = 0; u < LR_U; ++u) { const int x = x0 + u * 64 + lane; v[u] = x < nx ? rp[x] : 0; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c += (p + u * nt < pb && v[u] == k.label) ? 1u : 0u;
+        for (int u = 0; u < LR_U; ++u) {
+            const int x = x0 + u * 64 + lane;
+            const bool m = x < nx && v[u] == k.label;
+            c += (uint32_t)__popcll(__ballot(m));
+            cl += (uint32_t)__popcll(__ballot(m && x < shift));
+        }
     }
-    c = wave_sum_u32(c);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t i = 0; i < (nt >> 6); ++i) t += part[i]; counts[blockIdx.x] = t; }
+    if (lane == 0) { rcnt[r] = c; rleft[r] = cl; }
 }
 
-// One workgroup per listed row.  rowtab (per key, 2 * nrows words): pixels of the id per row -> their offset in the compact
-// lists, and how many of them lie left of the roll edge.  sw / sp: the weights and products in raster order of the plane (what
-// np.sum sees, contrack.py:874-875); sq / sqy / sqx: p, p*y, p*x' in raster order of the ROLLED plane (np.bincount's order inside
-// ndimage.center_of_mass, :886 / :892).
-// Round 5 (one contour of 105 000 pixels at 0.25 deg cost 2.8 ms: row scans 1.2, pairwise sums 0.6, sequential sums 1.3): launched with
-// 1024 threads when a listed row is large -- sixteen waves share the two scans over the rows --, and the sequential sums read their
-// block from LDS two values per load, eight values ahead of the add chain, while ALL threads already hold the next block's values in
-// registers (the global loads travel underneath the chain; two LDS buffers, one barrier per block).
-// Round 6 (advisor finding): the LDS tables follow the launch -- G = threads / 256 groups of the pairwise sums, a ring of four blocks of
-// 256 (one group) or 512 values of the sequential sums -- so that the common 256-thread launch keeps its ~31 KB and only the 1024-thread
-// launch for large contours takes ~66 KB.  Round 6 also: the pairwise sums, the sequential sums and their loads run on different waves at
-// the same time (see "D and E" below): 1.60 -> 0.76 ms for the 105 000-pixel contour.
-template <typename VT, int G>
-__global__ __launch_bounds__(256 * G) void k_life_exact(const int32_t *__restrict__ flag, const VT *__restrict__ field, const float *__restrict__ wrow,
+__global__ __launch_bounds__(256) void k_life_rowscan(const CtkLifeKey *__restrict__ keys, const uint64_t *__restrict__ roffs, int ny, uint32_t *__restrict__ rowtab,
+                                                      uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t part[256];
+    const CtkLifeKey k = keys[blockIdx.x];
+    const int tid = (int)threadIdx.x;
+    const int ya = (int)((uint32_t)k.pad & 0xffffu), yb = min(ny - 1, (int)((uint32_t)k.pad >> 16)), nrows = yb - ya + 1;
+    uint32_t *rcnt = rowtab + roffs[blockIdx.x], *roff = rcnt + 2 * (size_t)nrows;
+    const int per = (nrows + 255) / 256, r0 = tid * per, r1 = min(nrows, r0 + per);
+    uint32_t sum = 0;
+    for (int r = r0; r < r1; ++r) sum += rcnt[r];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 256; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; }
+        counts[blockIdx.x] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[tid];
+    for (int r = r0; r < r1; ++r) { roff[r] = run; run += rcnt[r]; }
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_life_lists(const int32_t *__restrict__ flag, const VT *__restrict__ field, const float *__restrict__ wrow,
                                                     const CtkLifeKey *__restrict__ keys, const uint64_t *__restrict__ offs, const uint64_t *__restrict__ roffs,
                                                     int ny, int nx, double *__restrict__ sw, double *__restrict__ sp_, double *__restrict__ sq,
-                                                    double *__restrict__ sqy, double *__restrict__ sqx, uint32_t *__restrict__ rowtab,
-                                                    CtkLifeExact *__restrict__ out, uint32_t *__restrict__ fail /* zeroed; != 0: a wait inside a workgroup expired */)
+                                                    double *__restrict__ sqy, double *__restrict__ sqx, const uint32_t *__restrict__ rowtab)
 {
-    constexpr int LX_EB = G == 1 ? 256 : 512;                   // values of a list per block of the sequential sums
-    constexpr int LX_U = 12;                                    // flag loads in flight per lane in the two scans over the rows
-    constexpr int LX_NSLOT = 4;                                 // blocks in LDS
-    constexpr int LX_NF = G;                                    // waves that feed them (the third wave of every group of four)
-    constexpr uint64_t LX_SPIN = 20000000ull;                   // 0.2 s of the 100 MHz clock: no wait inside this kernel is longer than microseconds
-    __shared__ uint32_t part[256];
-    __shared__ uint32_t d_arrived, e_consumed, e_filled[LX_NSLOT], lx_bad;
-    __shared__ uint32_t lo[G * 128], ln[G * 128];
-    __shared__ double lv[G * 256], cres[8];
-    __shared__ int nleaf[G];
-    __shared__ NpFrame frames[G * 32];
-    __shared__ __attribute__((aligned(16))) double stage[LX_NSLOT][3][LX_EB + 2];      // (+2: the three lists of a block start in different banks)
-    __shared__ double res[5];
     const CtkLifeKey k = keys[blockIdx.x];
-    const uint32_t npx = (uint32_t)ny * (uint32_t)nx;
-    const int32_t *fp = flag + (int64_t)k.t * npx;
-    const VT *vp = field + (int64_t)k.t * npx;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)(blockDim.x >> 6);
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
     const int ya = (int)((uint32_t)k.pad & 0xffffu), yb = min(ny - 1, (int)((uint32_t)k.pad >> 16)), nrows = yb - ya + 1;
+    const int r = (int)blockIdx.y * 4 + wave;
+    if (r >= nrows) return;
+    const uint32_t *rcnt = rowtab + roffs[blockIdx.x], *rleft = rcnt + nrows, *roff = rleft + nrows;
+    if (rcnt[r] == 0) return;                                              // (wave-uniform)
     const int shift = k.shift > 0 ? k.shift : 0;
-    double *gw = sw + offs[blockIdx.x], *gp = sp_ + offs[blockIdx.x], *gq = sq + offs[blockIdx.x], *gqy = sqy + offs[blockIdx.x], *gqx = sqx + offs[blockIdx.x];
-    uint32_t *rcnt = rowtab + roffs[blockIdx.x], *rleft = rcnt + nrows, *roff = rleft + nrows;
-
-    // A: per row the id's pixels, and those left of the roll edge (one wave per row, round robin)
-    for (int r = wave; r < nrows; r += nw) {
-        const int32_t *rp = fp + (size_t)(ya + r) * nx;
-        uint32_t c = 0, cl = 0;
-        for (int x0 = 0; x0 < nx; x0 += LX_U * 64) {                         // LX_U loads in flight per lane (one wave per row: a scan bound by the trips to memory)
-            int32_t v[LX_U];
+    const int y = ya + r;
+    const int64_t npx = (int64_t)ny * nx;
+    const int32_t *rp = flag + (int64_t)k.t * npx + (size_t)y * nx;
+    const VT *rv = field + (int64_t)k.t * npx + (size_t)y * nx;
+    const uint64_t o = offs[blockIdx.x];
+    double *gw = sw + o, *gp = sp_ + o, *gq = sq + o, *gqy = sqy + o, *gqx = sqx + o;
+    const double w = (double)wrow[y];
+    const uint32_t base = roff[r], nleft = rleft[r], nright = rcnt[r] - nleft;
+    uint32_t seen = 0;
+    for (int xq = 0; xq < nx; xq += LR_U * 64) {
+        int32_t v4[LR_U];
+        VT f4[LR_U];
 #pragma unroll
-            for (int u = 0; u < LX_U; ++u) { const int x = x0 + u * 64 + lane; v[u] = x < nx ? rp[x] : 0; }
+        for (int u = 0; u < LR_U; ++u) { const int x = xq + u * 64 + lane; v4[u] = x < nx ? rp[x] : 0; }
+        // (the values of all members of the batch in one trip: a load inside the branch below would be a trip of its own per u)
 #pragma unroll
-            for (int u = 0; u < LX_U; ++u) {
-                const int x = x0 + u * 64 + lane;
-                const bool m = x < nx && v[u] == k.label;
-                c += (uint32_t)__popcll(__ballot(m));
-                cl += (uint32_t)__popcll(__ballot(m && x < shift));
-            }
-        }
-        if (lane == 0) { rcnt[r] = c; rleft[r] = cl; }
-    }
-    __syncthreads();
-    // B: exclusive scan of the row counts
-    {
-        const int per = (nrows + 255) / 256, r0 = tid * per, r1 = min(nrows, r0 + per);
-        if (tid < 256) {
-            uint32_t sum = 0;
-            for (int r = r0; r < r1; ++r) sum += rcnt[r];
-            part[tid] = sum;
-        }
-        __syncthreads();
-        if (tid == 0) { uint32_t run = 0; for (int i = 0; i < 256; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; } }
-        __syncthreads();
-        if (tid < 256) {
-            uint32_t run = part[tid];
-            for (int r = r0; r < r1; ++r) { roff[r] = run; run += rcnt[r]; }
-        }
-    }
-    __syncthreads();
-    const size_t total = (size_t)roff[nrows - 1] + rcnt[nrows - 1];
-#ifdef CTK_PHASE_TIMING
-#define LX_MARK(k) do { if (total > 50000 && tid == 0) g_phase_t[k] = wall_clock64(); } while (0)
-#else
-#define LX_MARK(k) do { } while (0)
-#endif
-    LX_MARK(0);
-    // C: the compact lists.  Rolled row = the pixels right of the edge (x >= shift) first, then those left of it.
-    for (int r = wave; r < nrows; r += nw) {
-        const int y = ya + r;
-        const int32_t *rp = fp + (size_t)y * nx;
-        const VT *rv = vp + (size_t)y * nx;
-        const double w = (double)wrow[y];
-        const uint32_t base = roff[r], nleft = rleft[r], nright = rcnt[r] - nleft;
-        if (rcnt[r] == 0) continue;                                        // (wave-uniform)
-        uint32_t seen = 0;
-        for (int xq = 0; xq < nx; xq += LX_U * 64) {
-          int32_t v4[LX_U];
-          VT f4[LX_U];
+        for (int u = 0; u < LR_U; ++u) { const int x = xq + u * 64 + lane; f4[u] = (x < nx && v4[u] == k.label) ? rv[x] : (VT)0; }
 #pragma unroll
-          for (int u = 0; u < LX_U; ++u) { const int x = xq + u * 64 + lane; v4[u] = x < nx ? rp[x] : 0; }
-          // (the values of all members of the batch in one trip: a load inside the branch below would be a trip of its own per u)
-#pragma unroll
-          for (int u = 0; u < LX_U; ++u) { const int x = xq + u * 64 + lane; f4[u] = (x < nx && v4[u] == k.label) ? rv[x] : (VT)0; }
-#pragma unroll
-          for (int u = 0; u < LX_U; ++u) {
+        for (int u = 0; u < LR_U; ++u) {
             const int x = xq + u * 64 + lane;
             const bool m = x < nx && v4[u] == k.label;
             const uint64_t bal = __ballot(m);
@@ -964,10 +932,41 @@ __global__ __launch_bounds__(256 * G) void k_life_exact(const int32_t *__restric
                 gqx[base + pos] = p * (double)xr;
             }
             seen += (uint32_t)__popcll(bal);
-          }
         }
     }
-    __syncthreads();
+}
+
+// One workgroup per listed row, on the lists of k_life_lists: out[i] = the five sums in the reference's orders.
+// History: round 5 launched it with 1024 threads when a listed contour is large (one contour of 105 000 pixels at 0.25 deg: 2.8 -> 1.6 ms:
+// row scans, pairwise sums, sequential sums one after the other, three waves walking one chain each from LDS).  Round 6: G = threads / 256
+// groups of the pairwise sums, a ring of four blocks of 256 (one group) or 512 values of the sequential sums (~31 KB of LDS for the common
+// 256-thread launch, ~66 KB for the large one); the pairwise sums, the sequential sums and their loads on different waves at the same time
+// (see "D and E" below); the lists built by kernels of their own (above): 1.60 -> 0.46 (+ 0.11) ms for that contour.
+template <int G>
+__global__ __launch_bounds__(256 * G) void k_life_exact(const uint64_t *__restrict__ offs, const uint32_t *__restrict__ counts,
+                                                    const double *__restrict__ sw, const double *__restrict__ sp_, const double *__restrict__ sq,
+                                                    const double *__restrict__ sqy, const double *__restrict__ sqx,
+                                                    CtkLifeExact *__restrict__ out, uint32_t *__restrict__ fail /* zeroed; != 0: a wait inside a workgroup expired */)
+{
+    constexpr int LX_EB = G == 1 ? 256 : 512;                   // values of a list per block of the sequential sums
+    constexpr int LX_NSLOT = 4;                                 // blocks in LDS
+    constexpr int LX_NF = G;                                    // waves that feed them (the third wave of every group of four)
+    constexpr uint64_t LX_SPIN = 20000000ull;                   // 0.2 s of the 100 MHz clock: no wait inside this kernel is longer than microseconds
+    __shared__ uint32_t d_arrived, e_consumed, e_filled[LX_NSLOT], lx_bad;
+    __shared__ uint32_t lo[G * 128], ln[G * 128];
+    __shared__ double lv[G * 256], cres[8];
+    __shared__ int nleaf[G];
+    __shared__ NpFrame frames[G * 32];
+    __shared__ __attribute__((aligned(16))) double stage[LX_NSLOT][3][LX_EB + 2];      // (+2: the three lists of a block start in different banks)
+    __shared__ double res[5];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)(blockDim.x >> 6);
+    const double *gw = sw + offs[blockIdx.x], *gp = sp_ + offs[blockIdx.x], *gq = sq + offs[blockIdx.x], *gqy = sqy + offs[blockIdx.x], *gqx = sqx + offs[blockIdx.x];
+    const size_t total = counts[blockIdx.x];
+#ifdef CTK_PHASE_TIMING
+#define LX_MARK(k) do { if (total > 50000 && tid == 0) g_phase_t[k] = wall_clock64(); } while (0)
+#else
+#define LX_MARK(k) do { } while (0)
+#endif
     LX_MARK(1);
     // D and E at the same time (round 6; they were 0.2-0.34 + 0.9 ms of 1.6 for a contour of 105 000 pixels), by three kinds of waves:
     // D, waves 4g and 4g+1: np.sum over the raster-order lists (wg_np_sum2).  Their barrier is a counter in LDS -- the hardware barrier would

@@ -1,5 +1,5 @@
 """Phase times of k_life_exact's workgroup with the largest contour (> 50 000 pixels; library built with -DCTK_PHASE_TIMING into
-tools/exp/lib_phase.so): compact lists | pairwise sums and, next to them, the sequential sums (both counted from the end of the lists).  python tools/phase_probe_life.py 480 721 1440"""
+tools/exp/lib_phase.so): pairwise sums and, next to them, the sequential sums.  python tools/phase_probe_life.py 480 721 1440"""
 import ctypes as C, os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["CTK_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "exp", "lib_phase.so")
@@ -19,5 +19,5 @@ for rep in range(3):
     buf = (C.c_ulonglong * 16)()
     _native.lib().ctk_debug_phase_times(buf)
     t = np.array(list(buf), dtype=np.int64)
-    print("us: lists %.1f | from there: pairwise sums done after %.1f, sequential sums after %.1f, both (workgroup) after %.1f" % (
-        (t[1] - t[0]) / 100.0, (t[2] - t[1]) / 100.0, (t[4] - t[1]) / 100.0, (t[3] - t[1]) / 100.0))
+    print("us from the entry of k_life_exact's workgroup: pairwise sums done after %.1f, sequential sums after %.1f, both (workgroup) after %.1f" % (
+        (t[2] - t[1]) / 100.0, (t[4] - t[1]) / 100.0, (t[3] - t[1]) / 100.0))
