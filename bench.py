@@ -210,11 +210,16 @@ def live_pmc_traffic(workload, a, kernels, timeout_s=150):
 
 def stream_ceiling(trk, d_in, d_out, nbytes, per):
     try:
-        rd, wr = trk.stream_ceiling(d_in, nbytes, write=False), trk.stream_ceiling(d_out, nbytes, write=True)
+        rd = trk.stream_ceiling(d_in, nbytes, write=0)
+        wr_order, wr_xcd = trk.stream_ceiling(d_out, nbytes, write=1), trk.stream_ceiling(d_out, nbytes, write=2)
     except _native.ContrackHipError as e:
         return dict(error=str(e))
+    wr = min(wr_order, wr_xcd)
     out = dict(plain_load_stream_gbs=nbytes / rd / 1e6, plain_store_stream_gbs=nbytes / wr / 1e6, plain_load_ms=rd, plain_store_ms=wr,
-               note="k_stream_load / k_stream_store (ctk_debug_stream_ceiling): 16-byte non-temporal loads of the slab / stores over the flag slab, nothing else")
+               plain_store_stream_launch_order_gbs=nbytes / wr_order / 1e6, plain_store_stream_eighth_per_xcd_gbs=nbytes / wr_xcd / 1e6,
+               note="k_stream_load / k_stream_store (ctk_debug_stream_ceiling): 16-byte non-temporal loads of the slab / stores over the flag slab, "
+                    "nothing else; the store stream in two chunk orders (launch order -- rounds 1-6a quoted this one -- and one contiguous eighth "
+                    "of the slab per XCD), plain_store_* = the faster")
     if per.get("k_threshold", 0) > 0:
         out["k_threshold_of_plain_load_stream"] = rd / per["k_threshold"]
     if per.get("k_relabel", 0) > 0:

@@ -863,9 +863,10 @@ class Tracker:
         return ({k: (float(v) / int(n) if n else 0.0) for k, v, n in zip(TIMER_NAMES, sums, cnt)}, dict(zip(TIMER_NAMES, cnt.tolist())))
 
     def stream_ceiling(self, ptr, nbytes, write, reps=5):
-        """best-of-reps ms of a plain 16-byte non-temporal store (write) / load stream over a device buffer (overwritten when write)"""
+        """best-of-reps ms of a plain 16-byte non-temporal store (write; 2: one contiguous eighth of the buffer per XCD) / load stream
+        over a device buffer (overwritten when write)"""
         ms = C.c_double(0.0)
-        check(lib().ctk_debug_stream_ceiling(self._h, ptr, int(nbytes), int(bool(write)), int(reps), C.byref(ms)))
+        check(lib().ctk_debug_stream_ceiling(self._h, ptr, int(nbytes), int(write), int(reps), C.byref(ms)))
         return ms.value
 
     def timings(self):

@@ -609,6 +609,18 @@ extern "C" int ctk_debug_phase_times(unsigned long long *out)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_t), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
 }
+extern "C" int ctk_debug_rel_times(unsigned long long *out)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rel_t), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+extern "C" int ctk_debug_rel_acc(unsigned long long *out, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rel_acc), sizeof(unsigned long long) * 2048) != hipSuccess) return -1;
+    if (reset) { std::vector<unsigned long long> z(2048, 0ull); if (hipMemcpyToSymbol(HIP_SYMBOL(g_rel_acc), z.data(), 2048 * 8) != hipSuccess) return -1; }
+    return 0;
+}
 // k_rs_pass_blk's per-workgroup stamps; reset != 0 re-arms them (entry = ~0 for the atomicMin, the rest 0)
 extern "C" int ctk_debug_pb_times(unsigned long long *out, int reset)
 {
@@ -3500,7 +3512,8 @@ extern "C" int ctk_dev_memset(ctk_handle *h, void *p_dev, int byte, size_t nbyte
     return CTK_OK;
 }
 
-/* measurement support: best-of-`reps` time of a plain 16-byte non-temporal store (mode 1) / load (mode 0) stream over [p_dev, p_dev + nbytes) */
+/* measurement support: best-of-`reps` time of a plain 16-byte non-temporal store (mode 1: chunks in launch order, mode 2: one contiguous
+ * eighth of the buffer per XCD) / load (mode 0) stream over [p_dev, p_dev + nbytes) */
 extern "C" int ctk_debug_stream_ceiling(ctk_handle *h, void *p_dev, size_t nbytes, int mode, int reps, double *best_ms)
 {
     if (!h || !p_dev || !best_ms || nbytes < 16 || (((uintptr_t)p_dev) & 15) || reps < 1) return ctk_set_error(CTK_E_INVALID, "ctk_debug_stream_ceiling: bad argument");
@@ -3515,7 +3528,7 @@ extern "C" int ctk_debug_stream_ceiling(ctk_handle *h, void *p_dev, size_t nbyte
     hipError_t err = hipSuccess;
     for (int r = 0; r < reps + 1 && err == hipSuccess; r++) {          // (+ 1: the first launch is not counted)
         err = hipEventRecord(e0, h->stream);
-        if (mode) k_stream_store<<<grid, 256, 0, h->stream>>>((i32x4 *)p_dev, n16);
+        if (mode) k_stream_store<<<grid, 256, 0, h->stream>>>((i32x4 *)p_dev, n16, mode == 2 ? 1 : 0);
         else k_stream_load<<<grid, 256, 0, h->stream>>>((const i32x4 *)p_dev, n16, P<int32_t>(h->dbg));
         if (err == hipSuccess) err = hipEventRecord(e1, h->stream);
         if (err == hipSuccess) err = hipEventSynchronize(e1);

@@ -1802,10 +1802,24 @@ __global__ __launch_bounds__(256) void k_relabel_v4(RelabelArgs a, int rb, int r
 // assembled in LDS (dynamic LDS: the tables + rvcap * 4 + rows * nx * 4 bytes) and stored from there.  Used while that image
 // leaves room for eight workgroups per CU (1 degree: 11 rows = 15.8 KB; 0.25 degree: 2 rows = 11.5 KB); the 8-row chunks of
 // slabs with millions of chunks stay with k_relabel_v4.
+#ifdef CTK_PHASE_TIMING
+__device__ unsigned long long g_rel_t[16];
+#define REL_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 + 8) g_rel_t[k] = wall_clock64(); } while (0)
+__device__ unsigned long long g_rel_acc[2048];       // [0..1023] sums of (end - entry) of the workgroups b with b % 1024 == slot, [1024..] their maxima
+#define REL_IN() const unsigned long long rel_t_in = wall_clock64()
+#define REL_OUT() do { if (threadIdx.x == 0) { const unsigned long long d_ = wall_clock64() - rel_t_in; atomicAdd(&g_rel_acc[blockIdx.x & 1023u], d_); atomicMax(&g_rel_acc[1024 + (blockIdx.x & 1023u)], d_); } } while (0)
+#else
+#define REL_IN() do { } while (0)
+#define REL_OUT() do { } while (0)
+#define REL_MARK(k) do { } while (0)
+#endif
 template <int TH /* threads: 256; 512 / 1024 for tall chunks (fewer stores per lane at the same number of workgroups) */>
 __device__ __forceinline__ void relabel_v5_body(const RelabelArgs &a, int rb, int rvcap, int sub /* rows per LDS image: rb, or less for tall chunks */)
 {
+    REL_IN();
+    REL_MARK(0);
     if (ctk_guard_bad(a.guard)) return;
+    REL_MARK(1);
     const int ny = a.ny, nx = a.nx, W = a.W;
     const int nchunk = (ny + rb - 1) / rb;
     const unsigned bid = xcd_chunk(blockIdx.x, gridDim.x, a.xcd_remap);
@@ -1853,6 +1867,7 @@ __device__ __forceinline__ void relabel_v5_body(const RelabelArgs &a, int rb, in
         if (lane_id() == 0) ctk_zf_set(a.counters, blockIdx.x * (unsigned)(TH / 64) + (threadIdx.x >> 6));
         return;
     }
+    REL_MARK(2);
     const int32_t *rvg = a.run_val + a.run_base[t] + r0;
     const bool staged = nr <= (uint32_t)rvcap;
     if (!(a.chunk_vals && nr <= (uint32_t)CTK_CV)) {                    // more runs than the chunk-ordered copy holds (or no copy)
@@ -1875,8 +1890,10 @@ __device__ __forceinline__ void relabel_v5_body(const RelabelArgs &a, int rb, in
     for (int s0 = 0; s0 < rows; s0 += sub) {
         const int srows = min(sub, rows - s0), total = srows * n4;
         i32x4 *dst = reinterpret_cast<i32x4 *>(a.flag + (row0 + s0) * (int64_t)nx);
+        if (s0 == 0) REL_MARK(3);
         for (int i = tid; i < total; i += TH) outv4[i] = (i32x4)(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s0 == 0) REL_MARK(4);
         const int nw = srows * W;
         for (int k = tid; k < nw; k += TH) {
             const int idx = s0 * W + k;                                         // word of the chunk
@@ -1918,10 +1935,15 @@ __device__ __forceinline__ void relabel_v5_body(const RelabelArgs &a, int rb, in
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s0 == 0) REL_MARK(5);
         if (a.plain_stores) { for (int i = tid; i < total; i += TH) dst[i] = outv4[i]; }
         else for (int i = tid; i < total; i += TH) __builtin_nontemporal_store(outv4[i], dst + i);    // (the rows are contiguous: slot i)
+        if (s0 == 0) REL_MARK(6);
         if (s0 + sub < rows) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // the image is zeroed again
+        if (s0 == 0) REL_MARK(7);
     }
+    REL_OUT();
+    REL_MARK(8);
     if (__ballot(z) && lane_id() == 0) ctk_zf_set(a.counters, blockIdx.x * (unsigned)(TH / 64) + (threadIdx.x >> 6));
 }
 
@@ -2278,10 +2300,12 @@ __global__ void k_synth(float *__restrict__ out, int64_t T, int ny, int nx, uint
 // the roofline): 16-byte non-temporal stores of zeros over a buffer / 16-byte non-temporal loads ORed into a register.  The write
 // kernel k_relabel_v5 cannot be faster than the first, k_threshold_v7 not faster than the second.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stream_store(i32x4 *__restrict__ dst, int64_t n16)
+// xcd: 0 the chunks in launch order, 1 one contiguous eighth of the buffer per XCD (xcd_chunk: +10 % for a store stream on every size
+// timed, 705 MB ... 8 GB, tools/store_stream.hip)
+__global__ __launch_bounds__(256) void k_stream_store(i32x4 *__restrict__ dst, int64_t n16, int xcd)
 {
     constexpr int U = 8;
-    const int64_t base = (int64_t)blockIdx.x * (256 * U) + threadIdx.x;
+    const int64_t base = (int64_t)xcd_chunk(blockIdx.x, gridDim.x, xcd) * (256 * U) + threadIdx.x;
 #pragma unroll
     for (int u = 0; u < U; u++) { const int64_t i = base + u * 256; if (i < n16) __builtin_nontemporal_store((i32x4)(0), dst + i); }
 }

@@ -62,8 +62,9 @@ int ctk_debug_set_xcd(ctk_handle *h, int thr_mode, int rel_mode);
 int ctk_debug_set_relabel(ctk_handle *h, int threads, int rows);
 
 /* measurement support (bench.py, next to the roofline): best-of-`reps` time in ms of a PLAIN stream over a 16-byte-aligned device buffer --
- * mode 1: 16-byte non-temporal stores of zeros (what bounds the write kernel), mode 0: 16-byte non-temporal loads (what bounds the
- * threshold kernel).  Overwrites the buffer in mode 1. */
+ * mode 1: 16-byte non-temporal stores of zeros, 32 KB per workgroup in launch order; mode 2: the same with one contiguous eighth of the
+ * buffer per XCD (the faster store stream on every size timed; the better of the two bounds the write kernel); mode 0: 16-byte
+ * non-temporal loads (what bounds the threshold kernel).  Overwrites the buffer in modes 1 and 2. */
 int ctk_debug_stream_ceiling(ctk_handle *h, void *p_dev, size_t nbytes, int mode, int reps, double *best_ms);
 
 /* experiments: threads per workgroup (0 = default, 64 / 128 / 256) of the one-workgroup-per-timestep kernels k_extent, k_run_values,
