@@ -24,7 +24,7 @@ EXPORTS = [
     "ctk_track_f32_dev", "ctk_track_f64", "ctk_track_f64_dev", "ctk_release_io", "ctk_shard_label2d", "ctk_shard_label2d_f64", "ctk_shard_halo_size", "ctk_shard_halo_export",
     "ctk_shard_halo_import", "ctk_shard_overlap", "ctk_shard_tables", "ctk_resolve", "ctk_result_free",
     "ctk_result_info", "ctk_result_arrays", "ctk_result_nshards", "ctk_weights_to_limbs", "ctk_shard_extents", "ctk_shard_write",
-    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_set_seam_caps", "ctk_debug_set_spin", "ctk_debug_set_xcd", "ctk_debug_set_relabel", "ctk_debug_set_small_threads", "ctk_debug_np_sum", "ctk_debug_boundary_resolve", "ctk_set_timing", "ctk_get_timings", "ctk_get_timing_sums", "ctk_set_device_resolve", "ctk_set_fused_pass", "ctk_set_result_transfer", "ctk_debug_set_mask_offset", "ctk_debug_drop_buffer", "ctk_expand_runs_host", "ctk_set_filter_round", "ctk_get_stats", "ctk_get_stats_n", "ctk_debug_stream_ceiling",
+    "ctk_shard_count_tracked", "ctk_debug_mask", "ctk_debug_label2d", "ctk_debug_set_pair_capacity", "ctk_debug_set_mailbox", "ctk_debug_set_seam_caps", "ctk_debug_set_spin", "ctk_debug_set_xcd", "ctk_debug_set_relabel", "ctk_debug_set_small_threads", "ctk_debug_np_sum", "ctk_debug_boundary_resolve", "ctk_set_timing", "ctk_get_timings", "ctk_get_timing_sums", "ctk_set_device_resolve", "ctk_set_fused_pass", "ctk_set_result_transfer", "ctk_debug_set_mask_offset", "ctk_debug_drop_buffer", "ctk_expand_runs_host", "ctk_set_filter_round", "ctk_get_stats", "ctk_get_stats_n", "ctk_debug_stream_ceiling", "ctk_debug_time_relabel",
     "ctk_dev_malloc", "ctk_dev_free", "ctk_host_alloc", "ctk_host_free", "ctk_host_register", "ctk_host_unregister", "ctk_memcpy_h2d", "ctk_memcpy_d2h", "ctk_sync", "ctk_stream",
     "ctk_synth_fill",
     "ctk_comm_unique_id", "ctk_comm_init_rccl", "ctk_comm_group_create", "ctk_comm_group_destroy", "ctk_comm_init_local", "ctk_comm_init_shm",
@@ -122,6 +122,7 @@ def lib():
     L.ctk_get_stats.argtypes = [p, p]
     L.ctk_get_stats_n.argtypes = [p, p, i32]
     L.ctk_debug_stream_ceiling.argtypes = [p, p, sz, i32, i32, p]
+    L.ctk_debug_time_relabel.argtypes = [p, p, i32, i32, i32, i32, p]
     L.ctk_set_filter_round.argtypes = [p, i32]
     L.ctk_dev_malloc.argtypes = [p, pp, sz]
     L.ctk_dev_free.argtypes = [p, p]
@@ -861,6 +862,13 @@ class Tracker:
         cnt = np.zeros(len(TIMER_NAMES), dtype=np.int64)
         check(lib().ctk_get_timing_sums(self._h, sums.ctypes.data, cnt.ctypes.data, int(bool(reset))))
         return ({k: (float(v) / int(n) if n else 0.0) for k, v, n in zip(TIMER_NAMES, sums, cnt)}, dict(zip(TIMER_NAMES, cnt.tolist())))
+
+    def time_relabel(self, flag_dev, persistence, variant, xcd=-1, reps=5):
+        """ms of `reps` launches of the write kernel on the finished tables of the last track_dev pass (variant 0 k_relabel_v5, 1 without its
+        SGPR limit; xcd: chunk -> XCD order, -1 the handle's)"""
+        ms = np.zeros(reps, dtype=np.float64)
+        check(lib().ctk_debug_time_relabel(self._h, flag_dev, int(persistence), int(variant), int(xcd), int(reps), ms.ctypes.data))
+        return ms
 
     def stream_ceiling(self, ptr, nbytes, write, reps=5):
         """best-of-reps ms of a plain 16-byte non-temporal store (write; 2: one contiguous eighth of the buffer per XCD) / load stream

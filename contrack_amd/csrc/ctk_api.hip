@@ -351,6 +351,7 @@ struct ctk_handle {
     bool thr_nostore = false;                     // the threshold kernel without its mask stores: the yardstick of the mask placement check
     bool thr_probe = false;                       // the launches of that check run under their own kernel name (k_threshold_probe)
     bool rel_probe = false;                       // ... and those of the write kernel's chunk -> XCD timing (k_relabel_probe)
+    int rel_variant = -1;                         // ctk_debug_time_relabel: 0 k_relabel_v5, 1 the same without the SGPR limit (-1: the default's rules)
     bool mask_check_pending = false;              // the mask was (re)allocated and has not been checked against a slab yet
     int mask_check_retries = 0;                   // checks that found the device busy with other work (their times meant nothing)
     int mask_tries = 0; double mask_ratio = 0.0;  // allocations of the mask that were checked when it was last (re)allocated; kernel time / its time without stores
@@ -617,8 +618,8 @@ extern "C" int ctk_debug_rel_times(unsigned long long *out)
 extern "C" int ctk_debug_rel_acc(unsigned long long *out, int reset)
 {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rel_acc), sizeof(unsigned long long) * 2048) != hipSuccess) return -1;
-    if (reset) { std::vector<unsigned long long> z(2048, 0ull); if (hipMemcpyToSymbol(HIP_SYMBOL(g_rel_acc), z.data(), 2048 * 8) != hipSuccess) return -1; }
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rel_acc), sizeof(unsigned long long) * 4096) != hipSuccess) return -1;
+    if (reset) { std::vector<unsigned long long> z(4096, 0ull); if (hipMemcpyToSymbol(HIP_SYMBOL(g_rel_acc), z.data(), 4096 * 8) != hipSuccess) return -1; }
     return 0;
 }
 // k_rs_pass_blk's per-workgroup stamps; reset != 0 re-arms them (entry = ~0 for the atomicMin, the rest 0)
@@ -691,6 +692,42 @@ extern "C" int ctk_debug_set_relabel(ctk_handle *h, int threads, int rows)
 {
     if (!h || (threads != 0 && threads != 128 && threads != 256 && threads != 257 && threads != 512 && threads != 1024) || rows < 0) return ctk_set_error(CTK_E_INVALID, "ctk_debug_set_relabel: threads 0 / 256 / 512 / 1024, rows >= 0");
     h->relabel_threads = threads; h->relabel_rows_dbg = rows;
+    return CTK_OK;
+}
+
+/* measurement support: the write kernel launched `reps` times on the finished tables of the last one-call pass (it writes the same flags again),
+ * every launch timed by events -> ms[reps].  variant: 0 k_relabel_v5, 1 the same without its SGPR limit; xcd: chunk -> XCD order
+ * (0 launch order, 1 one eighth of the launch per XCD, 16 tiles of 16; -1: what the handle uses) */
+static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, bool with_fold, const int32_t *chunk_vals = nullptr, int64_t t0 = 0, int64_t nt = -1);
+static int32_t *chunk_vals_for(ctk_handle *h, const int32_t *flag_dev, int *rows);
+extern "C" int ctk_debug_time_relabel(ctk_handle *h, int32_t *flag_dev, int persistence, int variant, int xcd, int reps, double *ms)
+{
+    if (!h || !flag_dev || !ms || reps < 1 || variant < 0 || variant > 1) return ctk_set_error(CTK_E_INVALID, "ctk_debug_time_relabel: bad argument");
+    if (h->state != ST_TABLES) return ctk_set_error(CTK_E_STATE, "ctk_debug_time_relabel needs a finished pass");
+    HIPCHK(hipSetDevice(h->device));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return ctk_set_error(CTK_E_NODEVICE, "hipEventCreate failed"); }
+    int rows = 0;
+    const int32_t *cv = chunk_vals_for(h, flag_dev, &rows);
+    const int keep_variant = h->rel_variant, keep_xcd = h->xcd_rel;
+    h->rel_variant = variant;
+    if (xcd >= 0) h->xcd_rel = xcd;
+    int rc = CTK_OK;
+    hipError_t err = hipSuccess;
+    for (int r = 0; r < reps && rc == CTK_OK && err == hipSuccess; r++) {
+        err = hipEventRecord(e0, h->stream);
+        rc = launch_relabel(h, persistence, flag_dev, true, cv, 0, -1);
+        if (err == hipSuccess) err = hipEventRecord(e1, h->stream);
+        if (err == hipSuccess) err = hipEventSynchronize(e1);
+        float f = 0.f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&f, e0, e1);
+        ms[r] = f;
+    }
+    h->rel_variant = keep_variant; h->xcd_rel = keep_xcd;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc != CTK_OK) return rc;
+    if (err != hipSuccess) return ctk_set_error(CTK_E_NODEVICE, "ctk_debug_time_relabel: %s", hipGetErrorString(err));
     return CTK_OK;
 }
 
@@ -1111,7 +1148,12 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
     // then need the 1024-run variant behind it; v0_ok depends on the shape alone, so a speculative launch and the later check agree)
     struct VariantSet { bool v1, v2, v3, glb, one, v1hi; };
     static const bool v0_env = !getenv("CTK_L2D_NO_SMALL");
-    const bool v0_ok = v0_env && T > 65536 && ny <= 256 && (int64_t)ny * W <= 960;
+    // (round 6: the same for planes of 961 .. 1088 words -- 181 x 360 -- with 768 runs and 20.3 KB: eight workgroups per CU instead of the six
+    // of the 25.6 KB variant, k_label2d 52.5 -> 49 us at 2707 x 181 x 360; CTK_L2D_SMALL1=0 turns it off)
+    static const bool v0b_env = !(getenv("CTK_L2D_SMALL1") && atoi(getenv("CTK_L2D_SMALL1")) == 0);
+    const bool v0b = v0_env && v0b_env && ny <= 256 && (int64_t)ny * W > 960 && (int64_t)ny * W <= 1088;
+    const bool v0_ok = (v0_env && T > 65536 && ny <= 256 && (int64_t)ny * W <= 960) || v0b;
+    const uint32_t v0_runs = v0b ? 768u : 832u;
     auto launch_label2d = [&](const VariantSet &vs, uint32_t cap_runs) -> int {
         Label2dArgs a;
         a.mask = P<uint64_t>(h->mask); a.wstart = P<uint16_t>(h->wstart); a.rowstart = P<uint32_t>(h->rowstart);
@@ -1125,14 +1167,15 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         if (vs.one) k_label2d_lds<4096, 512, -1, 1024><<<(int)T, 1024, 0, s>>>(a);
         if (vs.v2 || vs.v3) HIPCHK(hipEventRecord(h->ev_fork, s));
         if (vs.v1) {
-            if (v0_ok) k_label2d_lds<832, 240, -1, 256, 256><<<(int)T, 256, 0, s>>>(a);
+            if (v0b) k_label2d_lds<768, 272, -1, 256, 256><<<(int)T, 256, 0, s>>>(a);
+            else if (v0_ok) k_label2d_lds<832, 240, -1, 256, 256><<<(int)T, 256, 0, s>>>(a);
             else {
                 // (experiment, CTK_L2D_PAD_KB: unused dynamic LDS on top of the kernel's 25.6 KB -- fewer workgroups per CU; NOTES round 6)
                 static const int pad_kb = getenv("CTK_L2D_PAD_KB") ? atoi(getenv("CTK_L2D_PAD_KB")) : 0;
                 k_label2d_lds<1024, 288, -1, 256><<<(int)T, 256, (size_t)pad_kb * 1024, s>>>(a);
             }
         }
-        if (vs.v1hi) k_label2d_lds<1024, 288, 832, 256><<<(int)T, 256, 0, s>>>(a);
+        if (vs.v1hi) { if (v0b) k_label2d_lds<1024, 288, 768, 256><<<(int)T, 256, 0, s>>>(a); else k_label2d_lds<1024, 288, 832, 256><<<(int)T, 256, 0, s>>>(a); }
         if (vs.v2) {
             HIPCHK(hipStreamWaitEvent(h->side[0], h->ev_fork, 0));
             k_label2d_lds<2048, 512, 1024, 512><<<(int)T, 512, 0, h->side[0]>>>(a);
@@ -1223,7 +1266,7 @@ static int shard_label2d_impl(ctk_handle *h, const void *anom_dev, bool f64, int
         static const bool no_one = getenv("CTK_L2D_NO_ONE") != nullptr;
         const bool prefer_one = !no_one && T <= 512 && h->max_runs_step > 1024;
         const bool none_lds = !launched.v1 && !launched.v2 && !launched.v3 && !launched.one;
-        VariantSet need = {true, h->max_runs_step > 1024, h->max_runs_step > 2048, h->need_glb, false, v0_ok && h->max_runs_step > 832};
+        VariantSet need = {true, h->max_runs_step > 1024, h->max_runs_step > 2048, h->need_glb, false, v0_ok && h->max_runs_step > v0_runs};
         if (prefer_one && (none_lds || launched.one)) need = {false, false, false, h->need_glb, true, false};
         else if (launched.one) need = {false, false, false, h->need_glb, true, false};          // (the large variant took every timestep it can take)
         const VariantSet missing = {need.v1 && !launched.v1, need.v2 && !launched.v2, need.v3 && !launched.v3, need.glb && !launched.glb, need.one && !launched.one,
@@ -2008,7 +2051,10 @@ static int relabel_rows(const ctk_handle *h)
     // (tools/cesm_relabel_sweep.py) -- the cap of ~2300 stores was found on 1440-wide rows (360 stores each); up to ~6900 where a row is short.
     const int store_cap = n4r >= 256 ? 2304 : 6912;
     const int rb_max = std::min(h->ny, std::max(rb, std::min(96, store_cap / n4r)));
-    while (rb < rb_max && h->T * ((h->ny + rb - 1) / rb) > 250000) rb++;
+    // Round 6, with eight workgroups per CU really there (CTK_SGPR_8WAVES), us per launch: 480 steps 2 rows 371 | 3: 332-349 | 4: 353-367 | 5: 337-345 |
+    // 6: 348-353; 1000 steps 3 rows 716-734 | 4: 702-707 | 5: 609-699 | 6: 599-707; 2000 steps 4 rows 1688-1762 | 5: 1518-1553 | 6: 1370-1373
+    // -> the smallest chunk that keeps the launch at or below ~130 000 workgroups (it was 250 000).
+    while (rb < rb_max && h->T * ((h->ny + rb - 1) / rb) > 130000) rb++;
     while (rb < h->ny && h->T * ((h->ny + rb - 1) / rb) >= (1 << 24)) rb++;
     if (ctk_env().relabel_rows > 0) rb = std::min(h->ny, ctk_env().relabel_rows);
     if (h->relabel_rows_dbg > 0) rb = std::min(h->ny, h->relabel_rows_dbg);
@@ -2033,7 +2079,7 @@ static int32_t *chunk_vals_for(ctk_handle *h, const int32_t *flag_dev, int *rows
 }
 
 // timesteps [t0, t0 + nt) of the shard into flag_dev (which starts at t0); nt < 0: the whole shard
-static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, bool with_fold, const int32_t *chunk_vals = nullptr, int64_t t0 = 0, int64_t nt = -1)
+static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, bool with_fold, const int32_t *chunk_vals, int64_t t0, int64_t nt)
 {
     if (h->rle_out) { h->stats[CTK_S_RELABEL_KERNEL] = -1; return CTK_OK; }      // the result leaves as run tables (deliver_runs expands them on the host)
     if (nt < 0) nt = h->T;
@@ -2087,6 +2133,7 @@ static int launch_relabel(ctk_handle *h, int persistence, int32_t *flag_dev, boo
             else if (th == 1024) k_relabel_v5<1024><<<grid, 1024, lds5, h->stream>>>(a, rb, rv5, sub);
             else if (th == 512) k_relabel_v5<512><<<grid, 512, lds5, h->stream>>>(a, rb, rv5, sub);
             else if (th == 128) k_relabel_v5<128><<<grid, 128, lds5, h->stream>>>(a, rb, rv5, sub);
+            else if (h->rel_variant == 1 || (h->rel_variant < 0 && getenv("CTK_RELABEL_SGPR") && atoi(getenv("CTK_RELABEL_SGPR")) == 0)) k_relabel_v5_allsgpr<256><<<grid, 256, lds5, h->stream>>>(a, rb, rv5, sub);
             else k_relabel_v5<256><<<grid, 256, lds5, h->stream>>>(a, rb, rv5, sub);
             h->stats[CTK_S_RELABEL_KERNEL] = 5;
         }

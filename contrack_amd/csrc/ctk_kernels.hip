@@ -15,6 +15,7 @@
 // A run is a maximal horizontal segment of foreground pixels; all labelling works on runs (about 1 % of
 // the pixel count on Z500 anomaly fields), the only per-pixel passes are the first and the last kernel.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include "ctk_tables.h"
 #include "ctk_device.h"
@@ -175,6 +176,13 @@ __device__ __forceinline__ unsigned xcd_chunk(unsigned b, unsigned n, int on)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+// SGPRs cost occupancy on this board (round 6, tools/occupancy_probe.hip: workgroups of 256 threads per CU with 16 SGPRs in use 8, with 86 or
+// 94: 7, with 102 or 108: 6 -- whatever the guides say about a fixed SGPR allotment per wave).  Kernels that take a struct of a dozen pointers by
+// value and hold it in SGPRs end at 100-106: six waves per SIMD, i.e. six instead of eight 256-thread workgroups per CU, ONE instead of two
+// 1024-thread workgroups.  With the limit below the compiler keeps what does not fit in lanes of a VGPR (v_writelane / v_readlane), which
+// costs nothing measurable: k_relabel_v5 -3 ... -5 % in the same process (tools/relabel_variants.py), 18.0 -> 15.2 ms at 438 000 x 192 x 288;
+// k_rs_pass_blk there 2.5 -> 1.9 ms.
+#define CTK_SGPR_8WAVES __attribute__((amdgpu_num_sgpr(80)))
 #define CTK_RB 16                  // rows per workgroup in the two streaming kernels
 
 template <int OP, int U = 8 /* independent 16-byte loads in flight per lane (8 vs 4: 2.5 % at 1 deg, equal at 0.25 deg) */>
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(256) void k_threshold(const TIN *__restrict__ anom,
 //   tcount[t]      = runs of the timestep
 // ------------------------------------------------------------------------------------------------
 #define RC_ROWS 2048
-__global__ __launch_bounds__(1024) void k_rowcount(const uint64_t *__restrict__ mask, int ny, int W, uint16_t *__restrict__ wstart,
+__global__ __launch_bounds__(1024) CTK_SGPR_8WAVES void k_rowcount(const uint64_t *__restrict__ mask, int ny, int W, uint16_t *__restrict__ wstart,
                                                   uint32_t *__restrict__ rowstart, uint32_t *__restrict__ tcount)
 {
     const int t = (int)blockIdx.x, tid = (int)threadIdx.x;
@@ -942,7 +950,7 @@ __device__ __forceinline__ void label2d_body(const Label2dArgs &a, const int t, 
 // 480 planes of a 0.25 deg grid then run as two rounds of one workgroup per CU: 86 us instead of ~45)
 //   <832, 240, ..., 256, 256>: 19.9 KB -> 8 workgroups per CU: small planes (ny <= 256, at most 960 mask words: 192 x 288) in long shards,
 //   where the kernel is bound by the planes in flight, not by a plane's chain (round 5; the planes with 833 .. 1024 runs go to
-//   <1024, 288, 832, 256>)
+//   <1024, 288, 832, 256>); <768, 272, ..., 256, 256>: 20.3 KB, the same for planes of up to 1088 mask words (181 x 360; round 6)
 template <int RUNS, int COMPS, int RUNS_BELOW, int THREADS, int NYCAP = CTK_LDS_NY>
 __global__ __launch_bounds__(THREADS, (THREADS == 1024 || NYCAP < CTK_LDS_NY) ? 8 : 1) void k_label2d_lds(Label2dArgs a)
 {
@@ -1805,7 +1813,7 @@ __global__ __launch_bounds__(256) void k_relabel_v4(RelabelArgs a, int rb, int r
 #ifdef CTK_PHASE_TIMING
 __device__ unsigned long long g_rel_t[16];
 #define REL_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 + 8) g_rel_t[k] = wall_clock64(); } while (0)
-__device__ unsigned long long g_rel_acc[2048];       // [0..1023] sums of (end - entry) of the workgroups b with b % 1024 == slot, [1024..] their maxima
+__device__ unsigned long long g_rel_acc[4096];       // [0..1023] sums of (end - entry) of the workgroups b with b % 1024 == slot, [1024..] their maxima
 #define REL_IN() const unsigned long long rel_t_in = wall_clock64()
 #define REL_OUT() do { if (threadIdx.x == 0) { const unsigned long long d_ = wall_clock64() - rel_t_in; atomicAdd(&g_rel_acc[blockIdx.x & 1023u], d_); atomicMax(&g_rel_acc[1024 + (blockIdx.x & 1023u)], d_); } } while (0)
 #else
@@ -1895,6 +1903,8 @@ __device__ __forceinline__ void relabel_v5_body(const RelabelArgs &a, int rb, in
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (s0 == 0) REL_MARK(4);
         const int nw = srows * W;
+        auto decode = [&](auto staged_c) {
+        constexpr bool STAGED = decltype(staged_c)::value;
         for (int k = tid; k < nw; k += TH) {
             const int idx = s0 * W + k;                                         // word of the chunk
             const uint64_t m = mrow[idx];
@@ -1913,7 +1923,8 @@ __device__ __forceinline__ void relabel_v5_body(const RelabelArgs &a, int rb, in
                 const int n = (~sh == 0ull) ? 64 : __builtin_ctzll(~sh);
                 const uint64_t below = (b + 1 >= 64) ? FULL64 : ((1ull << (b + 1)) - 1ull);     // bits 0..b
                 const uint32_t kk = base + (uint32_t)__popcll(st & below) - 1u;
-                const int32_t val = staged ? rvs[kk] : rvg[kk];
+                int32_t val;
+                if constexpr (STAGED) val = rvs[kk]; else val = rvg[kk];
                 if (val > 0) {                                                      // head up to a multiple of four, 16-byte LDS stores, tail
                     int q = b;
                     const int e = b + n;
@@ -1934,6 +1945,10 @@ __device__ __forceinline__ void relabel_v5_body(const RelabelArgs &a, int rb, in
                 mm = (n >= 64 - b) ? 0ull : (mm & ~(((1ull << n) - 1ull) << b));
             }
         }
+        };
+        // (two copies of the loop: with `staged ? rvs[kk] : rvg[kk]` in one loop hipcc selects the ADDRESS and reads it with a flat load, which
+        // counts in vmcnt too -- the decode of a chunk's second image then waited for the stores of its first to drain)
+        if (staged) decode(std::true_type{}); else decode(std::false_type{});
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (s0 == 0) REL_MARK(5);
         if (a.plain_stores) { for (int i = tid; i < total; i += TH) dst[i] = outv4[i]; }
@@ -1947,12 +1962,15 @@ __device__ __forceinline__ void relabel_v5_body(const RelabelArgs &a, int rb, in
     if (__ballot(z) && lane_id() == 0) ctk_zf_set(a.counters, blockIdx.x * (unsigned)(TH / 64) + (threadIdx.x >> 6));
 }
 
+// (80 SGPRs instead of 101: eight workgroups per CU instead of six -- CTK_SGPR_8WAVES)
 template <int TH>
-__global__ __launch_bounds__(TH) void k_relabel_v5(RelabelArgs a, int rb, int rvcap, int sub) { relabel_v5_body<TH>(a, rb, rvcap, sub); }
+__global__ __launch_bounds__(TH) CTK_SGPR_8WAVES void k_relabel_v5(RelabelArgs a, int rb, int rvcap, int sub) { relabel_v5_body<TH>(a, rb, rvcap, sub); }
+template <int TH>
+__global__ __launch_bounds__(TH) void k_relabel_v5_allsgpr(RelabelArgs a, int rb, int rvcap, int sub) { relabel_v5_body<TH>(a, rb, rvcap, sub); }      // (A/B: CTK_RELABEL_SGPR=0)
 // the same code under another name: the launches that time the chunk -> XCD mapping once per shape (tune_relabel, ctk_api.hip) -- kept
 // apart so that a profile's statistics of k_relabel_v5 are those of the passes (as k_threshold_probe does for the mask placement check)
 template <int TH>
-__global__ __launch_bounds__(TH) void k_relabel_probe(RelabelArgs a, int rb, int rvcap, int sub) { relabel_v5_body<TH>(a, rb, rvcap, sub); }
+__global__ __launch_bounds__(TH) CTK_SGPR_8WAVES void k_relabel_probe(RelabelArgs a, int rb, int rvcap, int sub) { relabel_v5_body<TH>(a, rb, rvcap, sub); }
 
 __global__ __launch_bounds__(256) void k_relabel(RelabelArgs a)
 {

@@ -618,7 +618,8 @@ __device__ unsigned long long g_pb_t[4 * 1024];      // per workgroup: first ent
 #define PB_MARK_MIN(k) do { } while (0)
 #define PB_MARK_MAX(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0, int K, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_cnt,
+// (80 SGPRs: with the 106 it would take a SIMD holds six of its waves, i.e. ONE workgroup of sixteen per CU instead of two -- see CTK_SGPR_8WAVES)
+__global__ __launch_bounds__(64 * PB_G) CTK_SGPR_8WAVES void k_rs_pass_blk(ResolveDev r, int it0, int K, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_cnt,
                                                            uint32_t *__restrict__ pstate /* [T + 1], zeroed */, int prep_inline, int do_unite)
 {
     if (dev_tables_bad(r)) return;

@@ -67,6 +67,10 @@ int ctk_debug_set_relabel(ctk_handle *h, int threads, int rows);
  * non-temporal loads (what bounds the threshold kernel).  Overwrites the buffer in modes 1 and 2. */
 int ctk_debug_stream_ceiling(ctk_handle *h, void *p_dev, size_t nbytes, int mode, int reps, double *best_ms);
 
+/* measurement support: the write kernel launched `reps` times on the finished tables of the last one-call pass into flag_dev (the same flags
+ * again), every launch timed by events -> ms[reps].  variant: 0 k_relabel_v5, 1 the same without its SGPR limit; xcd: chunk -> XCD order (0 launch order, 1 one eighth of the launch per XCD, 16: tiles of 16; -1: the handle's). */
+int ctk_debug_time_relabel(ctk_handle *h, int32_t *flag_dev, int persistence, int variant, int xcd, int reps, double *ms);
+
 /* experiments: threads per workgroup (0 = default, 64 / 128 / 256) of the one-workgroup-per-timestep kernels k_extent, k_run_values,
  * k_compact_init of the one-call pass; extent = 1024: the sixteen-timesteps-per-workgroup form k_extent_blk whatever the shard's length
  * (test hook: by default it serves shards of more than 2048 timesteps on grids narrower than 1024) */
