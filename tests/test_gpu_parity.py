@@ -105,6 +105,7 @@ CASES_VS_ORACLE = [
     (64, 181, 360, 4, "smooth", 150.0, ">", 0.5, 5, False),
     (6, 721, 1440, 5, "smooth", 160.0, ">=", 0.5, 2, True),          # 0.25 deg grid: 23 words per row
     (8, 181, 360, 6, "noise", 0.8, ">=", 0.5, 2, True),              # ~10^4 runs per step: global-memory labelling variant
+    (6, 181, 360, 12, "noise", 2.2, ">=", 0.5, 2, True),             # ~900 runs per step: beyond the 768 of the 20 KB labelling variant for 181 x 360 planes
     (5, 192, 288, 7, "smooth", 160.0, ">=", 0.5, 2, True),           # CESM grid
     (1, 91, 180, 8, "smooth", 150.0, ">=", 0.5, 1, True),            # T = 1 (the reference cannot even set up)
     (40, 91, 4200, 9, "smooth", 150.0, ">=", 0.5, 3, True),          # more than 64 words per row
