@@ -2284,7 +2284,11 @@ static int resolve_async(ctk_handle *h, double overlap, int twosided, int persis
         if (!(sys && NP > 0)) k_rs_prep<<<gc, 256, 0, s>>>(r);         // (k_rs_pass_sys does it for its own timestep)
         // (grid: the filtered timesteps 1 .. T-2 and T-1, whose workgroup only unites its pairs)
         static const bool pass_blk = !getenv("CTK_PASS_SYS");           // (the one-wave-per-workgroup form, for comparison)
-        if (sys && NP > 0 && pass_blk) k_rs_pass_blk<<<(int)((T - 1 + PB_G - 1) / PB_G), 64 * PB_G, 0, s>>>(r, 0, NP, in.pair_base, in.pair_cnt, r.pstate, 1, 1);
+        if (sys && NP > 0 && pass_blk) {
+            const int nb = (int)((T - 1 + PB_G - 1) / PB_G);
+            if (nb > h->n_cus) k_rs_pass_blk_2pc<<<nb, 64 * PB_G, 0, s>>>(r, 0, NP, in.pair_base, in.pair_cnt, r.pstate, 1, 1);      // (two workgroups per CU: ctk_resolve_dev.hip)
+            else k_rs_pass_blk<<<nb, 64 * PB_G, 0, s>>>(r, 0, NP, in.pair_base, in.pair_cnt, r.pstate, 1, 1);
+        }
         else if (sys && NP > 0) k_rs_pass_sys<<<(int)(T - 1), 64, 0, s>>>(r, 0, NP, in.pair_base, in.pair_cnt, r.pstate, 1, 1);
         else
             for (int it = 0; it < NP; it++)

@@ -181,7 +181,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // value and hold it in SGPRs end at 100-106: six waves per SIMD, i.e. six instead of eight 256-thread workgroups per CU, ONE instead of two
 // 1024-thread workgroups.  With the limit below the compiler keeps what does not fit in lanes of a VGPR (v_writelane / v_readlane), which
 // costs nothing measurable: k_relabel_v5 -3 ... -5 % in the same process (tools/relabel_variants.py), 18.0 -> 15.2 ms at 438 000 x 192 x 288;
-// k_rs_pass_blk there 2.5 -> 1.9 ms.
+// k_rs_pass_blk there 2.5 -> 1.9 ms (its second build, k_rs_pass_blk_2pc; short launches keep their SGPRs: ctk_resolve_dev.hip).
 #define CTK_SGPR_8WAVES __attribute__((amdgpu_num_sgpr(80)))
 #define CTK_RB 16                  // rows per workgroup in the two streaming kernels
 

@@ -618,9 +618,8 @@ __device__ unsigned long long g_pb_t[4 * 1024];      // per workgroup: first ent
 #define PB_MARK_MIN(k) do { } while (0)
 #define PB_MARK_MAX(k) do { } while (0)
 #endif
-// (80 SGPRs: with the 106 it would take a SIMD holds six of its waves, i.e. ONE workgroup of sixteen per CU instead of two -- see CTK_SGPR_8WAVES)
-__global__ __launch_bounds__(64 * PB_G) CTK_SGPR_8WAVES void k_rs_pass_blk(ResolveDev r, int it0, int K, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_cnt,
-                                                           uint32_t *__restrict__ pstate /* [T + 1], zeroed */, int prep_inline, int do_unite)
+__device__ __forceinline__ void rs_pass_blk_body(const ResolveDev &r, int it0, int K, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_cnt,
+                                                 uint32_t *__restrict__ pstate /* [T + 1], zeroed */, int prep_inline, int do_unite)
 {
     if (dev_tables_bad(r)) return;
     __shared__ long long Bl_all[PB_G][2 * PB_COMPS];
@@ -838,6 +837,20 @@ __global__ __launch_bounds__(64 * PB_G) CTK_SGPR_8WAVES void k_rs_pass_blk(Resol
     for (uint32_t i = lane; i < pn; i += 64) link(pb + i, i == (uint32_t)lane);
     for (uint32_t i = lane; i < nu; i += 64) { if ((int)r.pairs[r.pair_cap - 1u - i].t == t) link(r.pair_cap - 1u - i, false); }
     PB_MARK_MAX(3);
+}
+// Two builds of the same body.  With the 106 SGPRs it takes when left alone a SIMD holds six of its waves: ONE workgroup of sixteen per CU
+// instead of two (CTK_SGPR_8WAVES, ctk_kernels.hip) -- that is the build for launches with more workgroups than CUs (438 000 x 192 x 288: 2.5 ->
+// 1.9 ms).  A launch that leaves CUs empty anyway (2707 steps: 170 workgroups) is one chain per workgroup, and the ~110 values the limit moves
+// into VGPR lanes sit in that chain: 29.8 -> 32.6 us; it keeps all its SGPRs.
+__global__ __launch_bounds__(64 * PB_G) void k_rs_pass_blk(ResolveDev r, int it0, int K, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_cnt,
+                                                           uint32_t *__restrict__ pstate, int prep_inline, int do_unite)
+{
+    rs_pass_blk_body(r, it0, K, pair_base, pair_cnt, pstate, prep_inline, do_unite);
+}
+__global__ __launch_bounds__(64 * PB_G) CTK_SGPR_8WAVES void k_rs_pass_blk_2pc(ResolveDev r, int it0, int K, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_cnt,
+                                                                               uint32_t *__restrict__ pstate, int prep_inline, int do_unite)
+{
+    rs_pass_blk_body(r, it0, K, pair_base, pair_cnt, pstate, prep_inline, do_unite);
 }
 
 __global__ void k_rs_unite(ResolveDev r)

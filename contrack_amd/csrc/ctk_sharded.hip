@@ -1095,8 +1095,9 @@ static int track_sharded_impl(ctk_handle *h, ctk_comm *c, const void *anom_dev, 
                     // all passes of the round in one launch (neighbour hand-shake through LDS / pstate, zeroed by k_rs_init / by the
                     // previous round's k_sh_unpack_keep); with `spec` also the 3-D unions of the surviving pairs
                     if (spec && parent_dirty) k_rs_parent_init<<<gc, 256, 0, s>>>(r);
-                    k_rs_pass_blk<<<(int)((T - r.t_lo + PB_G - 1) / PB_G), 64 * PB_G, 0, s>>>(r, it_done, npass, in.pair_base, in.pair_cnt, r.pstate, prepped ? 0 : 1,
-                                                                                              spec ? 1 : 0);
+                    const int nb = (int)((T - r.t_lo + PB_G - 1) / PB_G);
+                    if (nb > h->n_cus) k_rs_pass_blk_2pc<<<nb, 64 * PB_G, 0, s>>>(r, it_done, npass, in.pair_base, in.pair_cnt, r.pstate, prepped ? 0 : 1, spec ? 1 : 0);
+                    else k_rs_pass_blk<<<nb, 64 * PB_G, 0, s>>>(r, it_done, npass, in.pair_base, in.pair_cnt, r.pstate, prepped ? 0 : 1, spec ? 1 : 0);
                     united = spec;
                     prepped = true;
                 } else {
