@@ -1440,7 +1440,9 @@ static int launch_overlap(ctk_handle *h)
         // many small planes (throughput regime): two waves per plane, ten workgroups per CU at 101 VGPRs -- 438 000 x 192 x 288: 3.95 -> 3.50 ms
         // (eight words per thread in one step: 169 VGPRs, 5.5 ms); CTK_OVERLAP_SMALL=1 / 0 forces / forbids it
         static const int ov_small = getenv("CTK_OVERLAP_SMALL") ? atoi(getenv("CTK_OVERLAP_SMALL")) : -1;
-        if (ov_small == 1 || (ov_small < 0 && h->T > 65536 && nwords <= 2048)) k_overlap<4, 128><<<(int)h->T, 128, 0, h->stream>>>(a);
+        // (small planes in long shards: room for five waves per SIMD -- 96 VGPRs, 14 of the 105 in scratch -- 3.49 -> 3.05 ms at 438 000 x 192 x 288;
+        // at 2707 x 181 x 360, one round of latency chains, the same costs <5, 256> ten of its 36 us: only here)
+        if (ov_small == 1 || (ov_small < 0 && h->T > 65536 && nwords <= 2048)) k_overlap<4, 128, 5><<<(int)h->T, 128, 0, h->stream>>>(a);
         else if (h->T <= 1024 && nwords >= 8192) k_overlap<4, 512><<<(int)h->T, 512, 0, h->stream>>>(a);
         else if (per <= 4 || per > 8) k_overlap<4><<<(int)h->T, 256, 0, h->stream>>>(a);
         else if (per == 5) k_overlap<5><<<(int)h->T, 256, 0, h->stream>>>(a);

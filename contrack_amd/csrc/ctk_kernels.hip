@@ -1209,8 +1209,8 @@ __device__ __forceinline__ void emit_pair(const OverlapArgs &a, uint32_t t, uint
 // 181 x 360: five per thread; with four a second step ran for the last 62 words)
 // THREADS: 256, or 1024 when the timesteps alone leave the chip empty (480 x 721 x 1440: 16 steps of three round trips per plane
 // with 256 threads, 4 with 1024)
-template <int OVB, int THREADS = 256>
-__global__ __launch_bounds__(THREADS) void k_overlap(OverlapArgs a)
+template <int OVB, int THREADS = 256, int WPE = 1 /* waves per SIMD the compiler has to make room for (experiment: occupancy against spills) */>
+__global__ __launch_bounds__(THREADS, WPE) void k_overlap(OverlapArgs a)
 {
     const int t = (int)blockIdx.x;
     if (t == 0 && !a.has_prev) {

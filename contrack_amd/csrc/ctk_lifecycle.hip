@@ -380,6 +380,8 @@ __device__ inline double row16_sum(double v)
 
 // VEC: nx a multiple of 4 and both slabs aligned for one 16- / 32-byte request per lane and row (the host checks); a compile-time
 // choice so that no branch stands between the loads of the pipeline below
+// (93-100 VGPRs: five waves per SIMD.  Room for six / seven / eight -- 80 / 72 / 63 VGPRs, 10 / 17 / 68 values in scratch -- costs more than it
+// brings: device part of the frame 0.81 -> 0.90 / 0.98 / 1.25 ms at 2707 x 181 x 360; round 6)
 template <typename VT, bool VEC>
 __global__ __launch_bounds__(LB_THREADS) void k_life_strips(const int32_t *__restrict__ flag, const VT *__restrict__ field, int ny, int nx, int nxw, int nsx, int nby, int rw,
                                                             const int64_t *__restrict__ wlo, const int64_t *__restrict__ whi, const float *__restrict__ wrow,
