@@ -1,3 +1,10 @@
 #!/bin/bash
+# the builder's scratch script of round 6 (gpurun -- 'bash tools/r6_gpu.sh'): the full GPU suite, smoke() and a driver-style bench line
 cd /root/repo
-timeout -k 5 300 python tools/exp/life_host_prof.py 2>&1 | tail -40
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.txt 2>&1
+grep -n "passed\|failed\|error" gpurun_out/gpu_tests.txt | tail -3
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
+tail -c 600 gpurun_out/bench_final.json
