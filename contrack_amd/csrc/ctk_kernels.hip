@@ -1509,7 +1509,7 @@ __device__ inline void ext_update(int32_t *tmin, int32_t *tmax, int32_t l, int32
     if (tg > __hip_atomic_load(&tmax[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&tmax[l], tg);
 }
 
-__global__ __launch_bounds__(256) void k_extent(ExtentArgs a)
+__global__ __launch_bounds__(256) CTK_SGPR_8WAVES void k_extent(ExtentArgs a)
 {
     if (ctk_guard_bad(a.guard)) return;
     const int t = (int)blockIdx.x;
@@ -1972,7 +1972,7 @@ __global__ __launch_bounds__(TH) void k_relabel_v5_allsgpr(RelabelArgs a, int rb
 template <int TH>
 __global__ __launch_bounds__(TH) CTK_SGPR_8WAVES void k_relabel_probe(RelabelArgs a, int rb, int rvcap, int sub) { relabel_v5_body<TH>(a, rb, rvcap, sub); }
 
-__global__ __launch_bounds__(256) void k_relabel(RelabelArgs a)
+__global__ __launch_bounds__(256) CTK_SGPR_8WAVES void k_relabel(RelabelArgs a)
 {
     if (ctk_guard_bad(a.guard)) return;
     const int lane = lane_id();
